@@ -1,0 +1,165 @@
+/*
+ * lqp_amd.h -- C ABI of the MI355X-native batched box-QP ADMM layer.
+ *
+ * The reference (ipo-lab/lqp_py) has no FFI: its boundary is a Python API on
+ * top of torch.linalg.  Each entry point below replaces the reference call
+ * sites listed next to it; the Python shim in lqp_py_amd/ binds them with
+ * ctypes and keeps the reference's signatures.
+ *
+ * Conventions
+ *   - every function returns an int status (LQP_OK == 0), never throws,
+ *     never allocates: scratch comes from the caller (`workspace`), sized by
+ *     the matching *_workspace_bytes query;
+ *   - all tensor pointers are DEVICE pointers to dense, batch-first,
+ *     row-major (C-contiguous) arrays, exactly the layout of a contiguous
+ *     torch tensor of the stated shape;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - dtype: LQP_F32 or LQP_F64 (the arithmetic type of every tensor).
+ */
+#ifndef LQP_AMD_H
+#define LQP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LQP_ABI_VERSION 1
+
+enum { LQP_F32 = 0, LQP_F64 = 1 };
+
+enum {
+    LQP_OK = 0,
+    LQP_ERR_INVALID = 1,      /* bad argument (null pointer, negative size, unknown dtype) */
+    LQP_ERR_WORKSPACE = 2,    /* workspace smaller than *_workspace_bytes               */
+    LQP_ERR_SINGULAR = 3,     /* exactly-zero pivot; batch index in stats / info         */
+    LQP_ERR_HIP = 4,          /* a HIP runtime call failed                               */
+    LQP_ERR_TIMEOUT = 5,      /* in-kernel grid barrier gave up (bounded spin)           */
+    LQP_ERR_UNSUPPORTED = 6   /* size outside what the kernels are built for             */
+};
+
+/* Resolved solver controls.  Key-name resolution of the reference's control
+ * dict (lqp_py/solve_box_qp_admm_torch.py:133-154, lqp_py/control.py:1-24) and
+ * the dict side effect (:37-38) stay in the Python shim; this struct carries
+ * the numbers the loop actually uses. */
+typedef struct lqp_boxqp_ctrl {
+    int32_t max_iters;
+    int32_t check_solved;            /* convergence test every this many iterations   */
+    int32_t adaptive_rho;            /* 0/1                                            */
+    int32_t adaptive_rho_iter;       /* already rounded to a multiple of check_solved */
+    int32_t adaptive_rho_max_iter;
+    int32_t scale;                   /* 0/1 auto-scaling (:160-197)                    */
+    int32_t any_lb;                  /* 0/1: max(lb) > -inf over the WHOLE batch (:129)*/
+    int32_t any_ub;                  /* 0/1: min(ub) < +inf over the WHOLE batch (:130)*/
+    int32_t rho_mode;                /* 0 auto (||Q||_F/sqrt(n), :200-203), 1 scalar rho_value,
+                                        2 per-problem array `rho_in` (B values)        */
+    int32_t beta_mode;               /* 0 auto (quantile rule :171-174), 1 scalar beta_value */
+    int32_t launch_mode;             /* 0 auto, 1 one launch per check segment,
+                                        2 persistent loop kernel with in-kernel grid barrier */
+    int32_t reserved;
+    double eps_abs;
+    double eps_rel;
+    double rho_value;
+    double rho_min;
+    double rho_max;
+    double adaptive_rho_tol;
+    double adaptive_rho_threshold;
+    double beta_value;
+} lqp_boxqp_ctrl;
+
+/* Host-side bookkeeping returned by the forward solve. */
+typedef struct lqp_boxqp_stats {
+    int32_t iters;          /* == the reference's sol["iter"]                          */
+    int32_t n_factor;       /* LU factorisations (1 + adaptive-rho refactors)          */
+    int32_t n_solve;        /* x-updates == iters + 1                                  */
+    int32_t n_check;        /* convergence checks performed                            */
+    int32_t rho_updated;    /* 1 if adaptive rho changed rho at least once             */
+    int32_t fail_index;     /* batch index of the first singular problem, or -1        */
+    int32_t n_launch;       /* kernel launches issued                                  */
+    int32_t mode_used;      /* 1 segmented, 2 persistent                               */
+} lqp_boxqp_stats;
+
+int lqp_abi_version(void);
+const char* lqp_status_string(int status);
+
+/* ---- forward ADMM solve ------------------------------------------------
+ * Replaces torch_solve_box_qp (lqp_py/solve_box_qp_admm_torch.py:108-333):
+ * scaling :160-197, rho :199-203, KKT assembly + LU :205-215, the hot loop
+ * :235-313 (lu_solve :267, clamp :271-276, residuals :279-282, check
+ * :285-313, adaptive-rho refactor :237-256) and unscale/duals :315-327.
+ * Shapes: Q (B,n,n) p (B,n,1) A (B,m,n)|NULL b (B,m,1)|NULL lb,ub (B,n,1);
+ * outputs x,z,u (B,n,1) lams (B,2n,1) nus (B,m,1)|NULL rho_out (B) (always
+ * written, one value per problem).  rho_in: B values when rho_mode == 2.  */
+size_t lqp_boxqp_forward_workspace_bytes(int dtype, int B, int n, int m);
+int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m,
+                      const void* Q, const void* p, const void* A, const void* b,
+                      const void* lb, const void* ub,
+                      const lqp_boxqp_ctrl* ctrl, const void* rho_in,
+                      void* x, void* z, void* u, void* lams, void* nus, void* rho_out,
+                      lqp_boxqp_stats* stats,
+                      void* workspace, size_t workspace_bytes);
+
+/* ---- fixed-point implicit backward --------------------------------------
+ * Replaces torch_solve_box_qp_grad (solve_box_qp_admm_torch.py:349-432):
+ * active-set mask :360-365, non-symmetric system :378-392, linalg.solve
+ * :393, gradient epilogue :396-430.  rho_mode 1 = scalar rho_value, 2 =
+ * per-problem rho_in.  Any of dQ (B,n,n), dp (B,n,1), dA (B,m,n), db (B,m,1),
+ * dlb, dub (B,n,1) may be NULL = skip.                                      */
+size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m);
+int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
+                          const void* dl_dz, const void* x, const void* u,
+                          const void* lams, const void* nus,
+                          const void* Q, const void* A, const void* lb, const void* ub,
+                          int rho_mode, double rho_value, const void* rho_in,
+                          void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
+                          int32_t* fail_index,
+                          void* workspace, size_t workspace_bytes);
+
+/* ---- batched LU (partial pivoting) and cached LU solve ------------------
+ * Replace torch.linalg.lu_factor / lu_solve as used by lqp_py/lu_layer.py:
+ * 10,31,33,52 and solve_box_qp_admm_torch.py:215,254,267.  M (B,N,N) is
+ * overwritten by the packed LU (LAPACK layout), piv (B,N) int32 1-based,
+ * info (B) int32: 0 or the 1-based index of the first zero pivot.          */
+size_t lqp_lu_factor_workspace_bytes(int dtype, int B, int N);
+int lqp_lu_factor_batched(void* stream, int dtype, int B, int N,
+                          void* M_inout, int32_t* piv_out, int32_t* info_out,
+                          void* workspace, size_t workspace_bytes);
+
+/* rhs (B,N,k) overwritten by the solution.  The factor is first re-laid
+ * out into solve-ordered 64x64 panels inside `workspace`.                   */
+size_t lqp_lu_solve_workspace_bytes(int dtype, int B, int N);
+int lqp_lu_solve_batched(void* stream, int dtype, int B, int N, int k,
+                         const void* LU, const int32_t* piv, void* rhs_inout,
+                         void* workspace, size_t workspace_bytes);
+
+/* Two-step form for a factor that is reused many times (TorchLU in unroll
+ * mode): pack once into `packed` (size lqp_lu_packed_bytes), solve often.   */
+size_t lqp_lu_packed_bytes(int dtype, int B, int N);
+int lqp_lu_pack(void* stream, int dtype, int B, int N,
+                const void* LU, const int32_t* piv, void* packed);
+int lqp_lu_solve_packed(void* stream, int dtype, int B, int N, int k,
+                        const void* packed, void* rhs_inout);
+
+/* ---- equality-constrained / unconstrained QP = one KKT solve ------------
+ * Replaces torch_solve_qp_eqcon (lqp_py/solve_qp_eqcon_torch.py:6-34, KKT
+ * block from lqp_py/utils.py:23-32) and, with m == 0, torch_solve_qp_uncon
+ * (lqp_py/solve_qp_uncon_torch.py:4-15): [[Q,A^T],[A,0]] [x;nu] = [-p;b].   */
+size_t lqp_kkt_solve_workspace_bytes(int dtype, int B, int n, int m);
+int lqp_kkt_solve(void* stream, int dtype, int B, int n, int m,
+                  const void* Q, const void* p, const void* A, const void* b,
+                  void* x, void* nus, int32_t* fail_index,
+                  void* workspace, size_t workspace_bytes);
+
+/* Symmetric rank-2 epilogue shared by the eq-con / uncon gradients
+ * (solve_qp_eqcon_torch.py:57-66, solve_qp_uncon_torch.py:29-33):
+ * dQ = 0.5 (dx x^T + x dx^T), dA = dnu x^T + nus dx^T (dA skipped if m==0). */
+int lqp_qp_outer_grads(void* stream, int dtype, int B, int n, int m,
+                       const void* dx, const void* x, const void* dnu, const void* nus,
+                       void* dQ, void* dA);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LQP_AMD_H */

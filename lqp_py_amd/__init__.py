@@ -1,0 +1,16 @@
+"""MI355X-native batched box-QP ADMM layer (drop-in for the box-QP path of
+ipo-lab/lqp_py).  The compute path is the HIP library built from ``csrc/``;
+there is no CPU fallback: CPU tensors or a missing library raise."""
+from .control import box_qp_control
+from .utils import get_ncon, torch_qp_eqcon_mat
+from .solve_box_qp_admm_torch import (SolveBoxQP, SolveBoxQPLayer, BoxQPTH, torch_solve_box_qp,
+                                      torch_solve_box_qp_grad)
+from .lu_layer import TorchLU, TorchLULayer
+from .solve_qp_eqcon_torch import torch_solve_qp_eqcon, torch_solve_qp_eqcon_grad
+from .solve_qp_uncon_torch import torch_solve_qp_uncon, torch_solve_qp_uncon_grad
+
+__all__ = [
+    "box_qp_control", "get_ncon", "torch_qp_eqcon_mat", "SolveBoxQP", "SolveBoxQPLayer", "BoxQPTH",
+    "torch_solve_box_qp", "torch_solve_box_qp_grad", "TorchLU", "TorchLULayer",
+    "torch_solve_qp_eqcon", "torch_solve_qp_eqcon_grad", "torch_solve_qp_uncon", "torch_solve_qp_uncon_grad",
+]

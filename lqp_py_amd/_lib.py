@@ -1,0 +1,148 @@
+"""ctypes binding of the C ABI declared in include/lqp_amd.h.
+
+The shared library is built in-tree (``lqp_py_amd/csrc/liblqp_amd.so``) by
+``build_library()`` / ``__graft_entry__.build()``.  Loading fails loudly: there
+is no fallback path.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "liblqp_amd.so")
+SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_common.cuh"]
+
+LQP_F32, LQP_F64 = 0, 1
+STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
+          5: "grid barrier timeout", 6: "unsupported size"}
+
+c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
+
+
+class BoxQPCtrl(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in (
+        "max_iters", "check_solved", "adaptive_rho", "adaptive_rho_iter", "adaptive_rho_max_iter", "scale",
+        "any_lb", "any_ub", "rho_mode", "beta_mode", "launch_mode", "reserved")] + [
+        (k, ctypes.c_double) for k in (
+            "eps_abs", "eps_rel", "rho_value", "rho_min", "rho_max", "adaptive_rho_tol",
+            "adaptive_rho_threshold", "beta_value")]
+
+
+class BoxQPStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in (
+        "iters", "n_factor", "n_solve", "n_check", "rho_updated", "fail_index", "n_launch", "mode_used")]
+
+
+# every symbol include/lqp_amd.h declares: name -> (restype, argtypes)
+_P = c_void_p
+SYMBOLS = {
+    "lqp_abi_version": (c_int, []),
+    "lqp_status_string": (ctypes.c_char_p, [c_int]),
+    "lqp_boxqp_forward_workspace_bytes": (c_size_t, [c_int] * 4),
+    "lqp_boxqp_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
+                                  ctypes.POINTER(BoxQPCtrl), _P, _P, _P, _P, _P, _P, _P,
+                                  ctypes.POINTER(BoxQPStats), _P, c_size_t]),
+    "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
+    "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
+                              [ctypes.POINTER(ctypes.c_int32), _P, c_size_t]),
+    "lqp_lu_factor_workspace_bytes": (c_size_t, [c_int] * 3),
+    "lqp_lu_factor_batched": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t]),
+    "lqp_lu_solve_workspace_bytes": (c_size_t, [c_int] * 3),
+    "lqp_lu_solve_batched": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t]),
+    "lqp_lu_packed_bytes": (c_size_t, [c_int] * 3),
+    "lqp_lu_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "lqp_lu_solve_packed": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "lqp_kkt_solve_workspace_bytes": (c_size_t, [c_int] * 4),
+    "lqp_kkt_solve": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
+                              ctypes.POINTER(ctypes.c_int32), _P, c_size_t]),
+    "lqp_qp_outer_grads": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> csrc/liblqp_amd.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "lqp_amd.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s)):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB_PATH, os.path.join(CSRC, "lqp_amd.hip")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once).  Raises RuntimeError if it is missing -- no fallback."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"lqp_py_amd: HIP library not built ({LIB_PATH}); run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or lqp_py_amd._lib.build_library()). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if lib.lqp_abi_version() != 1:
+            raise RuntimeError("lqp_py_amd: ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def check(status, what, extra=""):
+    if status == 0:
+        return
+    msg = STATUS.get(status, f"status {status}")
+    raise RuntimeError(f"lqp_py_amd.{what}: {msg}{extra}")
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return LQP_F32
+    if t.dtype == torch.float64:
+        return LQP_F64
+    raise TypeError(f"lqp_py_amd supports float32/float64 tensors, got {t.dtype}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("lqp_py_amd: inputs must live on the GPU (HIP device); there is no CPU path")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(device, nbytes, tag):
+    """Reusable device scratch buffer per (device, tag); grows monotonically."""
+    key = (device.index, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def c(t):
+    """contiguous, detached view of a tensor (None passes through)"""
+    return None if t is None else t.detach().contiguous()

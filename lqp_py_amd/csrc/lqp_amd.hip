@@ -1,0 +1,592 @@
+// C ABI of the MI355X box-QP ADMM layer: workspace carving, launch
+// orchestration, status reporting.  See include/lqp_amd.h for the contract.
+#include "../../include/lqp_amd.h"
+#include "lqp_boxqp.cuh"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <mutex>
+#include <vector>
+#include <unordered_map>
+
+using namespace lqp;
+
+namespace {
+
+constexpr int kRing = 1024;          // per-check counter slots
+constexpr int kMaxN = 1024;          // one panel row per thread
+constexpr size_t kAlign = 256;
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base((char*)p) {}
+    template <typename U> U* take(size_t count) {
+        off = (off + kAlign - 1) / kAlign * kAlign;
+        U* r = base ? (U*)(base + off) : nullptr;
+        off += count * sizeof(U);
+        return r;
+    }
+};
+
+#define HIP_OK(call)                                                      \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) {                                           \
+            if (getenv("LQP_DEBUG")) fprintf(stderr, "[lqp] %s failed: %s\n", #call, hipGetErrorString(e_)); \
+            return LQP_ERR_HIP;                                           \
+        }                                                                 \
+    } while (0)
+
+// dynamic LDS above 64 KB needs an opt-in per kernel
+std::mutex g_attr_mutex;
+std::unordered_map<const void*, int> g_attr_set;
+int ensure_lds(const void* fn, int bytes) {
+    if (bytes > 160 * 1024) return LQP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    auto it = g_attr_set.find(fn);
+    if (it != g_attr_set.end() && it->second >= bytes) return LQP_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return LQP_ERR_HIP;
+    g_attr_set[fn] = bytes;
+    return LQP_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
+// ---- LU launch: pick panel width / trailing-update flavour --------------------
+template <typename T, int PB, bool MFMA>
+int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
+                   const int* gate) {
+    const int lds = LuLds<T, PB>(round_up(N, 64)).total;
+    auto fn = k_lu_factor<T, PB, MFMA>;
+    int rc = ensure_lds((const void*)fn, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
+              const int* gate) {
+    const int pb = lu_panel_width<float>(N);
+    const bool mfma = env_int("LQP_LU_MFMA", 1) != 0;
+    if (pb == 32) return mfma ? launch_lu_impl<float, 32, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate)
+                              : launch_lu_impl<float, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+    if (pb == 16) return mfma ? launch_lu_impl<float, 16, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate)
+                              : launch_lu_impl<float, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+    return launch_lu_impl<float, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+}
+int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
+              const int* gate) {
+    const int pb = lu_panel_width<double>(N);
+    if (pb == 32) return launch_lu_impl<double, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+    if (pb == 16) return launch_lu_impl<double, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+    return launch_lu_impl<double, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+}
+
+template <typename T>
+int launch_pack(hipStream_t st, int B, const T* LU, int N, int ld, size_t mstride, const int* piv, int pstride,
+                T* packed, int* dest, const int* gate) {
+    const int K = round_up(N, LQP_NB) / LQP_NB;
+    const int lds = pack_lds_bytes<T>();
+    auto fn = k_pack<T>;
+    int rc = ensure_lds((const void*)fn, lds);
+    if (rc) return rc;
+    const bool vec_ok = (ld % 4 == 0) && (mstride % 4 == 0) && (((uintptr_t)LU) % (4 * sizeof(T)) == 0);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, LU, N, ld, mstride, piv, pstride, packed,
+                       packed_blocks(K) * LQP_BLK, dest, K * LQP_NB, vec_ok ? 1 : 0, gate);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+template <typename T>
+int launch_solve(hipStream_t st, int B, const T* packed, int N, const int* dest, T* rhs, int nrhs, size_t bstride,
+                 int rstride, int cstride) {
+    const int K = round_up(N, LQP_NB) / LQP_NB, Np = K * LQP_NB;
+    const int lds = solve_lds_bytes<T>(Np);
+    auto fn = k_packed_solve<T>;
+    int rc = ensure_lds((const void*)fn, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, packed, N, Np, K, dest, rhs, nrhs, bstride, rstride, cstride);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+// first failing batch index from the per-problem info array (host side, after a sync)
+int first_failure(hipStream_t st, const int* info_dev, int B, int* fail_index) {
+    std::vector<int> h(B);
+    HIP_OK(hipMemcpyAsync(h.data(), info_dev, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    *fail_index = -1;
+    for (int i = 0; i < B; ++i)
+        if (h[i] != 0) { *fail_index = i; return LQP_ERR_SINGULAR; }
+    return LQP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <typename T> struct FwdLayout {
+    FwdParams<T> P;
+    size_t bytes;
+};
+
+template <typename T>
+FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
+    FwdLayout<T> L;
+    memset(&L.P, 0, sizeof(L.P));
+    FwdParams<T>& P = L.P;
+    P.B = B; P.n = n; P.m = m; P.N = n + m;
+    P.Np = round_up(P.N, LQP_NB); P.K = P.Np / LQP_NB; P.ldq = round_up(n, 4);
+    P.vstride = vec_stride(n, m);
+    Carver c(ws);
+    P.status = c.take<int>(ST_WORDS);
+    P.counters = c.take<unsigned int>((size_t)kRing * CT_WORDS);
+    P.info = c.take<int>(B);
+    P.scal = c.take<T>((size_t)B * SC_WORDS);
+    P.vecs = c.take<T>((size_t)B * P.vstride);
+    P.piv = c.take<int>((size_t)B * P.Np);
+    P.dest = c.take<int>((size_t)B * P.Np);
+    P.Qs = c.take<T>((size_t)B * n * P.ldq);
+    P.M = c.take<T>((size_t)B * P.Np * P.Np);
+    P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
+    L.bytes = c.off + kAlign;
+    return L;
+}
+
+template <typename T>
+int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void* p, const void* A, const void* b,
+                 const void* lb, const void* ub, const lqp_boxqp_ctrl* ctl, const void* rho_in, void* x, void* z,
+                 void* u, void* lams, void* nus, void* rho_out, lqp_boxqp_stats* stats, void* ws, size_t ws_bytes) {
+    FwdLayout<T> L = carve_forward<T>(ws, B, n, m);
+    if (ws_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+    FwdParams<T>& P = L.P;
+    P.Q = (const T*)Q; P.p = (const T*)p; P.A = (const T*)A; P.b = (const T*)b;
+    P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in;
+    P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
+    P.scale = ctl->scale; P.any_lb = ctl->any_lb; P.any_ub = ctl->any_ub;
+    P.rho_mode = ctl->rho_mode; P.beta_mode = ctl->beta_mode;
+    P.check_solved = ctl->check_solved < 1 ? 1 : ctl->check_solved;
+    P.adaptive_rho = ctl->adaptive_rho;
+    P.eps_abs = (T)ctl->eps_abs; P.eps_rel = (T)ctl->eps_rel; P.rho_value = (T)ctl->rho_value;
+    P.rho_min = (T)ctl->rho_min; P.rho_max = (T)ctl->rho_max;
+    P.ar_tol = (T)ctl->adaptive_rho_tol; P.ar_inv_tol = (T)(1.0 / ctl->adaptive_rho_tol);
+    P.ar_thr = (T)ctl->adaptive_rho_threshold; P.beta_value = (T)ctl->beta_value;
+
+    const int check = P.check_solved;
+    const int max_iters = ctl->max_iters;
+    const int ar_iter = ctl->adaptive_rho_iter < 1 ? 1 : ctl->adaptive_rho_iter;
+    int n_launch = 0;
+
+    // ---- zero status + counter ring, setup, factor, pack ----
+    HIP_OK(hipMemsetAsync(P.status, 0, (char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status, st));
+    {
+        const int lds = setup_lds_bytes<T>(n);
+        auto fn = k_fwd_setup<T>;
+        int rc = ensure_lds((const void*)fn, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
+        ++n_launch;
+    }
+    int rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr);
+    if (rc) return rc;
+    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr);
+    if (rc) return rc;
+    n_launch += 2;
+
+    // ---- launch mode ----
+    const int loop_lds = loop_lds_bytes<T>(n, m, P.Np);
+    auto loop_fn = k_admm_loop<T>;
+    rc = ensure_lds((const void*)loop_fn, loop_lds);
+    if (rc) return rc;
+    int mode = ctl->launch_mode;
+    if (mode == 0) mode = env_int("LQP_LAUNCH_MODE", 1);
+    if (mode == 2) {
+        int dev = 0, cus = 0, per_cu = 0;
+        HIP_OK(hipGetDevice(&dev));
+        HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_fn, LQP_NT, loop_lds));
+        if (per_cu < 1 || B > cus * per_cu) mode = 1;     // not every workgroup resident: no grid barrier
+    }
+    const int max_checks_per_launch = kRing / 4;
+
+    // ---- iterate ----
+    int h_status[ST_WORDS];
+    memset(h_status, 0, sizeof(h_status));
+    int it = 0;
+    long long zeroed_upto = kRing;     // check indices [0, zeroed_upto) have clean slots
+    bool done = false, singular_checked = false;
+    int chunk_cap = env_int("LQP_SPEC_LAUNCHES", 6);
+    int fail_index = -1;
+    while (it < max_iters && !done) {
+        int in_chunk = 0;
+        while (it < max_iters && in_chunk < chunk_cap) {
+            // adaptive-rho event at the start of iteration `it` (:237)
+            if (ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter) {
+                const int last_slot = ((it - 1) / check) % kRing;
+                hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot);
+                rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, P.status + ST_GATE);
+                if (rc) return rc;
+                rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest,
+                                    P.status + ST_GATE);
+                if (rc) return rc;
+                n_launch += 3;
+            }
+            // end of this launch
+            int e = max_iters;
+            const int next_check = ((it + check - 1) / check) * check;
+            if (mode == 1) e = std::min(e, next_check + 1);
+            else e = std::min(e, next_check + 1 + (max_checks_per_launch - 1) * check);
+            if (ctl->adaptive_rho) {
+                const int a = (it / ar_iter + 1) * ar_iter;
+                if (a < ctl->adaptive_rho_max_iter) e = std::min(e, a);
+            }
+            if (e <= it) e = it + 1;
+            // counter slots of the checks inside [it, e)
+            const long long c_first = (it + check - 1) / check;        // first check index >= it
+            const long long c_last = (e - 1) / check;                  // last check index <= e-1
+            while (c_last >= zeroed_upto) {
+                const int s0 = (int)(zeroed_upto % kRing);
+                HIP_OK(hipMemsetAsync(P.counters + (size_t)s0 * CT_WORDS, 0, sizeof(unsigned int) * CT_WORDS * (kRing / 2), st));
+                zeroed_upto += kRing / 2;
+            }
+            const int ctr_base = (int)(c_first % kRing);
+            const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
+            hipLaunchKernelGGL(loop_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, ctr_base, prev_slot,
+                               mode == 2 ? 1 : 0);
+            ++n_launch;
+            ++in_chunk;
+            it = e;
+        }
+        // ---- close the chunk: did the last check stop the loop? ----
+        if (it > 0 && ((it - 1) % check) == 0) {
+            // trailing no-op launch evaluates the early-exit test for the last check
+            const int prev_slot = ((it - 1) / check) % kRing;
+            hipLaunchKernelGGL(loop_fn, dim3(1), dim3(LQP_NT), loop_lds, st, P, it, it, 0, prev_slot, 0);
+            ++n_launch;
+        }
+        HIP_OK(hipMemcpyAsync(h_status, P.status, sizeof(h_status), hipMemcpyDeviceToHost, st));
+        if (!singular_checked) {
+            rc = first_failure(st, P.info, B, &fail_index);      // synchronises
+            singular_checked = true;
+            if (rc == LQP_ERR_SINGULAR) {
+                if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
+                return rc;
+            }
+            if (rc) return rc;
+        } else {
+            HIP_OK(hipStreamSynchronize(st));
+        }
+        if (h_status[ST_TIMEOUT]) return LQP_ERR_TIMEOUT;
+        done = h_status[ST_DONE] != 0;
+        chunk_cap = std::min(chunk_cap * 2, 64);
+    }
+    const int final_iter = done ? h_status[ST_FINAL_ITER] : max_iters - 1;
+
+    hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P);
+    ++n_launch;
+    if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
+    if (stats) {
+        stats->iters = final_iter;
+        stats->n_factor = 1 + h_status[ST_NFACTOR];
+        stats->n_solve = final_iter + 1;
+        stats->n_check = final_iter / check + 1;
+        stats->rho_updated = h_status[ST_RHO_UPDATED];
+        stats->fail_index = -1;
+        stats->n_launch = n_launch;
+        stats->mode_used = mode;
+    }
+    return LQP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+template <typename T>
+size_t carve_backward(void* ws, int B, int n, int m, BwdParams<T>& P) {
+    P.B = B; P.n = n; P.m = m; P.N = n + m;
+    P.Np = round_up(P.N, LQP_NB); P.K = P.Np / LQP_NB;
+    Carver c(ws);
+    P.info = c.take<int>(B);
+    P.piv = c.take<int>((size_t)B * P.Np);
+    P.dest = c.take<int>((size_t)B * P.Np);
+    P.rhs = c.take<T>((size_t)B * P.Np);
+    P.M = c.take<T>((size_t)B * P.Np * P.Np);
+    P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
+    return c.off + kAlign;
+}
+
+template <typename T>
+int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void* x, const void* u, const void* lams,
+                  const void* nus, const void* Q, const void* A, const void* lb, const void* ub, int rho_mode,
+                  double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
+                  int32_t* fail_index, void* ws, size_t ws_bytes) {
+    BwdParams<T> P;
+    memset(&P, 0, sizeof(P));
+    const size_t need = carve_backward<T>(ws, B, n, m, P);
+    if (ws_bytes < need) return LQP_ERR_WORKSPACE;
+    P.g = (const T*)g; P.x = (const T*)x; P.u = (const T*)u; P.lams = (const T*)lams; P.nus = (const T*)nus;
+    P.Q = (const T*)Q; P.A = (const T*)A; P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in;
+    P.rho_value = (T)rho_value; P.rho_mode = rho_mode;
+    P.dQ = (T*)dQ; P.dp = (T*)dp; P.dA = (T*)dA; P.db = (T*)db; P.dlb = (T*)dlb; P.dub = (T*)dub;
+    hipLaunchKernelGGL(k_bwd_build<T>, dim3(B), dim3(LQP_NT), 0, st, P);
+    int rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr);
+    if (rc) return rc;
+    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr);
+    if (rc) return rc;
+    rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0);
+    if (rc) return rc;
+    {
+        const int lds = (2 * n + m + 8) * (int)sizeof(T);
+        auto fn = k_bwd_epilogue<T>;
+        rc = ensure_lds((const void*)fn, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
+    }
+    if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
+    if (fail_index) {
+        int fi = -1;
+        rc = first_failure(st, P.info, B, &fi);       // torch.linalg.solve checks info (and syncs) too
+        *fail_index = fi;
+        if (rc) return rc;
+    }
+    return LQP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LU / solve / KKT entry points
+// ---------------------------------------------------------------------------
+template <typename T>
+size_t carve_lu(void* ws, int B, int N, T*& M, int*& piv) {
+    const int Np = round_up(N, LQP_NB);
+    Carver c(ws);
+    piv = c.take<int>((size_t)B * Np);
+    M = c.take<T>((size_t)B * Np * Np);
+    return c.off + kAlign;
+}
+
+template <typename T>
+int lu_factor_impl(hipStream_t st, int B, int N, void* Mio, int32_t* piv_out, int32_t* info_out, void* ws, size_t ws_bytes) {
+    T* M; int* piv;
+    const size_t need = carve_lu<T>(ws, B, N, M, piv);
+    if (ws_bytes < need) return LQP_ERR_WORKSPACE;
+    const int Np = round_up(N, LQP_NB);
+    hipLaunchKernelGGL(k_copy_matrix<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)Mio, N, (size_t)N * N, M, Np, (size_t)Np * Np, N);
+    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info_out, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_copy_matrix<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)M, Np, (size_t)Np * Np, (T*)Mio, N, (size_t)N * N, N);
+    hipLaunchKernelGGL(k_copy_ints<int>, dim3(B), dim3(256), 0, st, (const int*)piv, Np, (int*)piv_out, N, N);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+template <typename T> size_t packed_bytes_t(int B, int N) {
+    const int K = round_up(N, LQP_NB) / LQP_NB;
+    Carver c(nullptr);
+    c.take<int>((size_t)B * K * LQP_NB);
+    c.take<T>((size_t)B * packed_blocks(K) * LQP_BLK);
+    return c.off + kAlign;
+}
+template <typename T> void carve_packed(void* buf, int B, int N, int*& dest, T*& packed) {
+    const int K = round_up(N, LQP_NB) / LQP_NB;
+    Carver c(buf);
+    dest = c.take<int>((size_t)B * K * LQP_NB);
+    packed = c.take<T>((size_t)B * packed_blocks(K) * LQP_BLK);
+}
+
+template <typename T>
+int lu_pack_impl(hipStream_t st, int B, int N, const void* LU, const int32_t* piv, void* buf) {
+    int* dest; T* packed;
+    carve_packed<T>(buf, B, N, dest, packed);
+    return launch_pack<T>(st, B, (const T*)LU, N, N, (size_t)N * N, (const int*)piv, N, packed, dest, nullptr);
+}
+template <typename T>
+int lu_solve_packed_impl(hipStream_t st, int B, int N, int k, const void* buf, void* rhs) {
+    int* dest; T* packed;
+    carve_packed<T>((void*)buf, B, N, dest, packed);
+    return launch_solve<T>(st, B, packed, N, dest, (T*)rhs, k, (size_t)N * k, k, 1);
+}
+
+template <typename T>
+size_t carve_kkt(void* ws, int B, int n, int m, T*& M, T*& packed, T*& rhs, int*& piv, int*& dest, int*& info) {
+    const int N = n + m, Np = round_up(N, LQP_NB), K = Np / LQP_NB;
+    Carver c(ws);
+    info = c.take<int>(B);
+    piv = c.take<int>((size_t)B * Np);
+    dest = c.take<int>((size_t)B * Np);
+    rhs = c.take<T>((size_t)B * Np);
+    M = c.take<T>((size_t)B * Np * Np);
+    packed = c.take<T>((size_t)B * packed_blocks(K) * LQP_BLK);
+    return c.off + kAlign;
+}
+
+template <typename T>
+int kkt_solve_impl(hipStream_t st, int B, int n, int m, const void* Q, const void* p, const void* A, const void* b,
+                   void* x, void* nus, int32_t* fail_index, void* ws, size_t ws_bytes) {
+    T *M, *packed, *rhs; int *piv, *dest, *info;
+    const size_t need = carve_kkt<T>(ws, B, n, m, M, packed, rhs, piv, dest, info);
+    if (ws_bytes < need) return LQP_ERR_WORKSPACE;
+    const int N = n + m, Np = round_up(N, LQP_NB);
+    hipLaunchKernelGGL(k_kkt_build<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)Q, (const T*)p, (const T*)A, (const T*)b,
+                       n, m, Np, M, rhs, info);
+    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info, nullptr);
+    if (rc) return rc;
+    rc = launch_pack<T>(st, B, M, N, Np, (size_t)Np * Np, piv, Np, packed, dest, nullptr);
+    if (rc) return rc;
+    rc = launch_solve<T>(st, B, packed, N, dest, rhs, 1, (size_t)Np, 1, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_kkt_unpack<T>, dim3(B), dim3(256), 0, st, (const T*)rhs, n, m, Np, (T*)x, (T*)nus);
+    if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
+    if (fail_index) {
+        int fi = -1;
+        rc = first_failure(st, info, B, &fi);
+        *fail_index = fi;
+        if (rc) return rc;
+    }
+    return LQP_OK;
+}
+
+bool bad_dims(int dtype, int B, int n, int m) {
+    return (dtype != LQP_F32 && dtype != LQP_F64) || B < 1 || n < 1 || m < 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int lqp_abi_version(void) { return LQP_ABI_VERSION; }
+
+const char* lqp_status_string(int s) {
+    switch (s) {
+        case LQP_OK: return "ok";
+        case LQP_ERR_INVALID: return "invalid argument";
+        case LQP_ERR_WORKSPACE: return "workspace too small";
+        case LQP_ERR_SINGULAR: return "singular matrix (exactly zero pivot)";
+        case LQP_ERR_HIP: return "HIP runtime error";
+        case LQP_ERR_TIMEOUT: return "in-kernel grid barrier timed out";
+        case LQP_ERR_UNSUPPORTED: return "size not supported by this build (n + m <= 1024)";
+        default: return "unknown status";
+    }
+}
+
+size_t lqp_boxqp_forward_workspace_bytes(int dtype, int B, int n, int m) {
+    if (bad_dims(dtype, B, n, m)) return 0;
+    return dtype == LQP_F32 ? carve_forward<float>(nullptr, B, n, m).bytes : carve_forward<double>(nullptr, B, n, m).bytes;
+}
+
+int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m, const void* Q, const void* p, const void* A,
+                      const void* b, const void* lb, const void* ub, const lqp_boxqp_ctrl* ctrl, const void* rho_in,
+                      void* x, void* z, void* u, void* lams, void* nus, void* rho_out, lqp_boxqp_stats* stats,
+                      void* workspace, size_t workspace_bytes) {
+    if (bad_dims(dtype, B, n, m) || !Q || !p || !lb || !ub || !ctrl || !x || !z || !u || !lams || !rho_out || !workspace)
+        return LQP_ERR_INVALID;
+    if (m > 0 && (!A || !b || !nus)) return LQP_ERR_INVALID;
+    if (ctrl->rho_mode == 2 && !rho_in) return LQP_ERR_INVALID;
+    if (ctrl->max_iters < 1) return LQP_ERR_INVALID;
+    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LQP_F32)
+        return forward_impl<float>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes);
+    return forward_impl<double>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes);
+}
+
+size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m) {
+    if (bad_dims(dtype, B, n, m)) return 0;
+    if (dtype == LQP_F32) { BwdParams<float> P; return carve_backward<float>(nullptr, B, n, m, P); }
+    BwdParams<double> P; return carve_backward<double>(nullptr, B, n, m, P);
+}
+
+int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x, const void* u,
+                          const void* lams, const void* nus, const void* Q, const void* A, const void* lb, const void* ub,
+                          int rho_mode, double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db,
+                          void* dlb, void* dub, int32_t* fail_index, void* workspace, size_t workspace_bytes) {
+    if (bad_dims(dtype, B, n, m) || !dl_dz || !x || !u || !lams || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
+    if (m > 0 && (!A || !nus)) return LQP_ERR_INVALID;
+    if (rho_mode != 1 && rho_mode != 2) return LQP_ERR_INVALID;
+    if (rho_mode == 2 && !rho_in) return LQP_ERR_INVALID;
+    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LQP_F32)
+        return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes);
+    return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes);
+}
+
+size_t lqp_lu_factor_workspace_bytes(int dtype, int B, int N) {
+    if (bad_dims(dtype, B, N, 0)) return 0;
+    int* piv;
+    if (dtype == LQP_F32) { float* M; return carve_lu<float>(nullptr, B, N, M, piv); }
+    double* M; return carve_lu<double>(nullptr, B, N, M, piv);
+}
+
+int lqp_lu_factor_batched(void* stream, int dtype, int B, int N, void* M_inout, int32_t* piv_out, int32_t* info_out,
+                          void* workspace, size_t workspace_bytes) {
+    if (bad_dims(dtype, B, N, 0) || !M_inout || !piv_out || !info_out || !workspace) return LQP_ERR_INVALID;
+    if (N > kMaxN) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == LQP_F32 ? lu_factor_impl<float>(st, B, N, M_inout, piv_out, info_out, workspace, workspace_bytes)
+                            : lu_factor_impl<double>(st, B, N, M_inout, piv_out, info_out, workspace, workspace_bytes);
+}
+
+size_t lqp_lu_packed_bytes(int dtype, int B, int N) {
+    if (bad_dims(dtype, B, N, 0)) return 0;
+    return dtype == LQP_F32 ? packed_bytes_t<float>(B, N) : packed_bytes_t<double>(B, N);
+}
+size_t lqp_lu_solve_workspace_bytes(int dtype, int B, int N) { return lqp_lu_packed_bytes(dtype, B, N); }
+
+int lqp_lu_pack(void* stream, int dtype, int B, int N, const void* LU, const int32_t* piv, void* packed) {
+    if (bad_dims(dtype, B, N, 0) || !LU || !piv || !packed) return LQP_ERR_INVALID;
+    if (N > kMaxN) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == LQP_F32 ? lu_pack_impl<float>(st, B, N, LU, piv, packed) : lu_pack_impl<double>(st, B, N, LU, piv, packed);
+}
+
+int lqp_lu_solve_packed(void* stream, int dtype, int B, int N, int k, const void* packed, void* rhs_inout) {
+    if (bad_dims(dtype, B, N, 0) || k < 1 || !packed || !rhs_inout) return LQP_ERR_INVALID;
+    if (N > kMaxN) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == LQP_F32 ? lu_solve_packed_impl<float>(st, B, N, k, packed, rhs_inout)
+                            : lu_solve_packed_impl<double>(st, B, N, k, packed, rhs_inout);
+}
+
+int lqp_lu_solve_batched(void* stream, int dtype, int B, int N, int k, const void* LU, const int32_t* piv, void* rhs_inout,
+                         void* workspace, size_t workspace_bytes) {
+    if (!workspace || workspace_bytes < lqp_lu_packed_bytes(dtype, B, N)) return workspace ? LQP_ERR_WORKSPACE : LQP_ERR_INVALID;
+    int rc = lqp_lu_pack(stream, dtype, B, N, LU, piv, workspace);
+    if (rc) return rc;
+    return lqp_lu_solve_packed(stream, dtype, B, N, k, workspace, rhs_inout);
+}
+
+size_t lqp_kkt_solve_workspace_bytes(int dtype, int B, int n, int m) {
+    if (bad_dims(dtype, B, n, m)) return 0;
+    int *piv, *dest, *info;
+    if (dtype == LQP_F32) { float *M, *pk, *rhs; return carve_kkt<float>(nullptr, B, n, m, M, pk, rhs, piv, dest, info); }
+    double *M, *pk, *rhs; return carve_kkt<double>(nullptr, B, n, m, M, pk, rhs, piv, dest, info);
+}
+
+int lqp_kkt_solve(void* stream, int dtype, int B, int n, int m, const void* Q, const void* p, const void* A, const void* b,
+                  void* x, void* nus, int32_t* fail_index, void* workspace, size_t workspace_bytes) {
+    if (bad_dims(dtype, B, n, m) || !Q || !p || !x || !workspace) return LQP_ERR_INVALID;
+    if (m > 0 && (!A || !b || !nus)) return LQP_ERR_INVALID;
+    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == LQP_F32 ? kkt_solve_impl<float>(st, B, n, m, Q, p, A, b, x, nus, fail_index, workspace, workspace_bytes)
+                            : kkt_solve_impl<double>(st, B, n, m, Q, p, A, b, x, nus, fail_index, workspace, workspace_bytes);
+}
+
+int lqp_qp_outer_grads(void* stream, int dtype, int B, int n, int m, const void* dx, const void* x, const void* dnu,
+                       const void* nus, void* dQ, void* dA) {
+    if (bad_dims(dtype, B, n, m) || !dx || !x) return LQP_ERR_INVALID;
+    if (m > 0 && dA && (!dnu || !nus)) return LQP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LQP_F32)
+        hipLaunchKernelGGL(k_outer_grads<float>, dim3(B), dim3(LQP_NT), 0, st, (const float*)dx, (const float*)x,
+                           (const float*)dnu, (const float*)nus, n, m, (float*)dQ, (float*)dA);
+    else
+        hipLaunchKernelGGL(k_outer_grads<double>, dim3(B), dim3(LQP_NT), 0, st, (const double*)dx, (const double*)x,
+                           (const double*)dnu, (const double*)nus, n, m, (double*)dQ, (double*)dA);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+}  // extern "C"

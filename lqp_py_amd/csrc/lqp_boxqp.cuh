@@ -1,0 +1,757 @@
+// Kernels of the box-QP ADMM layer (forward setup / loop / epilogue, adaptive
+// rho, fixed-point backward, KKT solve).  One 1024-thread workgroup per QP.
+#pragma once
+#include "lqp_common.cuh"
+#include "lqp_lu.cuh"
+#include "lqp_trsv.cuh"
+
+namespace lqp {
+
+// ---- device-side status block (ints) ---------------------------------------
+enum { ST_DONE = 0, ST_FINAL_ITER = 1, ST_GATE = 2, ST_NFACTOR = 3, ST_RHO_UPDATED = 4,
+       ST_TIMEOUT = 5, ST_NCHECK = 6, ST_WORDS = 16 };
+// per-check counters (uint32 x 4): not-optimal, wants-rho, ratio-trigger, arrivals
+enum { CT_NOTOPT = 0, CT_WANTS = 1, CT_TRIG = 2, CT_ARRIVE = 3, CT_WORDS = 4 };
+// per-problem scalars
+enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_WORDS = 8 };
+
+template <typename T> struct FwdParams {
+    int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
+    // inputs
+    const T *Q, *p, *A, *b, *lb, *ub, *rho_in;
+    // outputs
+    T *x, *z, *u, *lams, *nus, *rho_out;
+    // workspace
+    T* Qs;            // B * n * ldq (scale) or unused
+    T* M;             // B * Np * Np
+    T* packed;        // B * K(K+1) * 4096
+    T* vecs;          // B * vstride
+    T* scal;          // B * SC_WORDS
+    int* piv;         // B * Np
+    int* dest;        // B * Np
+    int* info;        // B
+    int* status;      // ST_WORDS
+    unsigned int* counters;   // ring of CT_WORDS per check
+    size_t vstride;
+    // controls
+    int scale, any_lb, any_ub, rho_mode, beta_mode, check_solved, adaptive_rho;
+    T eps_abs, eps_rel, rho_value, rho_min, rho_max, ar_tol, ar_inv_tol, ar_thr, beta_value;
+};
+
+// vector block of problem b: [ps | lbs | ubs | D | z | u | x | As (m*n) | bs | E | nu]
+template <typename T> struct VecView {
+    T *ps, *lbs, *ubs, *D, *z, *u, *x, *As, *bs, *E, *nu;
+    __device__ VecView(T* base, int n, int m) {
+        ps = base; lbs = ps + n; ubs = lbs + n; D = ubs + n; z = D + n; u = z + n; x = u + n;
+        As = x + n; bs = As + (size_t)m * n; E = bs + m; nu = E + m;
+    }
+};
+__host__ __device__ inline size_t vec_stride(int n, int m) { return (size_t)round_up(7 * n + m * n + 3 * m, 8); }
+
+// ---------------------------------------------------------------------------
+// setup: norms, auto-scaling, rho, KKT assembly, state init
+// (lqp_py/solve_box_qp_admm_torch.py:124-131, 160-212, 221-223)
+// LDS: red[NW * n] | d[n] | sel[8] | scratch[NW]
+// ---------------------------------------------------------------------------
+template <typename T> __host__ __device__ inline int setup_lds_bytes(int n) {
+    return (LQP_NW * n + n + 8 + LQP_NW + 8) * (int)sizeof(T);
+}
+
+template <typename T>
+__device__ void assemble_kkt_rows(const FwdParams<T>& P, const int b, const T* __restrict__ Qs, const int ldq,
+                                  const VecView<T>& V, const T rho) {
+    // M = [[Qs + rho I, As^T], [As, 0]]  (solve_box_qp_admm_torch.py:206-212, 252)
+    const int n = P.n, m = P.m, Np = P.Np;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T* M = P.M + (size_t)b * Np * Np;
+    for (int i = w; i < n; i += LQP_NW) {
+        const T* q = Qs + (size_t)i * ldq;
+        T* mr = M + (size_t)i * Np;
+        for (int j = lane; j < n; j += 64) mr[j] = q[j] + (i == j ? rho : T(0));
+        for (int r = lane; r < m; r += 64) mr[n + r] = V.As[(size_t)r * n + i];
+    }
+    for (int r = w; r < m; r += LQP_NW) {
+        T* mr = M + (size_t)(n + r) * Np;
+        for (int j = lane; j < n; j += 64) mr[j] = V.As[(size_t)r * n + j];
+        for (int c = lane; c < m; c += 64) mr[n + c] = T(0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T* red = (T*)smem;
+    T* d = red + (size_t)LQP_NW * n;
+    T* sel = d + n;
+    T* scratch = sel + 8;
+    const T* Q = P.Q + (size_t)b * n * n;
+    const T* p = P.p + (size_t)b * n;
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    T* scal = P.scal + (size_t)b * SC_WORDS;
+    if (tid == 0) P.info[b] = 0;
+
+    // ---- ||p||_inf on the unscaled p (:127) ----
+    T pm = T(0);
+    for (int i = tid; i < n; i += LQP_NT) pm = tmax(pm, tabs(p[i]));
+    pm = wg_max(pm, scratch);
+    if (tid == 0) scal[SC_PNORM] = pm;
+
+    const T* Qs = Q;
+    int ldq = n;
+    T fro2 = T(0);
+    if (P.scale) {
+        // ---- column max of |Q| (:163) ----
+        T cm[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cm[q] = T(0);
+        for (int i = w; i < n; i += LQP_NW) {
+            const T* qr = Q + (size_t)i * n;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = lane + 64 * q;
+                if (j < n) cm[q] = tmax(cm[q], tabs(qr[j]));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int j = lane + 64 * q;
+            if (j < n) red[(size_t)w * n + j] = cm[q];
+        }
+        __syncthreads();
+        T part = T(0);
+        for (int j = tid; j < n; j += LQP_NT) {
+            T v = red[j];
+#pragma unroll
+            for (int ww = 1; ww < LQP_NW; ++ww) v = tmax(v, red[(size_t)ww * n + j]);
+            d[j] = v;
+            part += v;
+        }
+        // ---- zero guard (:164-168) ----
+        const T mean_norm = wg_sum(part, scratch) / T(n);
+        const T floor_v = tmax(mean_norm, T(1e-6));
+        part = T(0);
+        for (int j = tid; j < n; j += LQP_NT) {
+            T v = d[j];
+            if (v <= T(0)) v = tmax(v, floor_v);
+            v = tsqrt(T(1) / v);          // D = sqrt(1 / Q_norm) (:170)
+            d[j] = v;
+            part += v;
+        }
+        const T dmean = wg_sum(part, scratch) / T(n);     // also makes d[] visible
+        // ---- beta = 1 - q10(D) / q90(D), linear-interpolated quantiles (:171-174) ----
+        T beta = P.beta_value;
+        if (P.beta_mode == 0) {
+            const T pos0 = T(0.10) * T(n - 1), pos1 = T(0.90) * T(n - 1);
+            const int lo0 = (int)tfloor(pos0), hi0 = (int)tceil(pos0);
+            const int lo1 = (int)tfloor(pos1), hi1 = (int)tceil(pos1);
+            for (int j = tid; j < n; j += LQP_NT) {
+                const T dj = d[j];
+                int rank = 0;
+                for (int k = 0; k < n; ++k) {
+                    const T dk = d[k];
+                    rank += (dk < dj || (dk == dj && k < j)) ? 1 : 0;
+                }
+                if (rank == lo0) sel[0] = dj;
+                if (rank == hi0) sel[1] = dj;
+                if (rank == lo1) sel[2] = dj;
+                if (rank == hi1) sel[3] = dj;
+            }
+            __syncthreads();
+            const T w0 = pos0 - tfloor(pos0), w1 = pos1 - tfloor(pos1);
+            // torch lerp: w < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
+            const T q10 = (w0 < T(0.5)) ? sel[0] + w0 * (sel[1] - sel[0]) : sel[1] - (sel[1] - sel[0]) * (T(1) - w0);
+            const T q90 = (w1 < T(0.5)) ? sel[2] + w1 * (sel[3] - sel[2]) : sel[3] - (sel[3] - sel[2]) * (T(1) - w1);
+            beta = T(1) - q10 / q90;
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += LQP_NT) {
+            const T v = (T(1) - beta) * d[j] + beta * dmean;     // (:175)
+            d[j] = v;
+            V.D[j] = v;
+        }
+        __syncthreads();
+        // ---- Qs = (D_i Q_ij) D_j and its Frobenius norm (:176, :201) ----
+        ldq = P.ldq;
+        T* Qw = P.Qs + (size_t)b * n * ldq;
+        for (int i = w; i < n; i += LQP_NW) {
+            const T* qr = Q + (size_t)i * n;
+            T* qo = Qw + (size_t)i * ldq;
+            const T di = d[i];
+            for (int j = lane; j < n; j += 64) {
+                const T v = (di * qr[j]) * d[j];
+                qo[j] = v;
+                fro2 += v * v;
+            }
+        }
+        Qs = Qw;
+        for (int i = tid; i < n; i += LQP_NT) V.ps[i] = d[i] * p[i];       // (:177)
+    } else {
+        for (int i = tid; i < n; i += LQP_NT) { V.D[i] = T(1); V.ps[i] = p[i]; }
+        if (P.rho_mode == 0) {
+            for (int i = w; i < n; i += LQP_NW) {
+                const T* qr = Q + (size_t)i * n;
+                for (int j = lane; j < n; j += 64) { const T v = qr[j]; fro2 += v * v; }
+            }
+        }
+    }
+    // ---- rho (:140, :157-158, :200-203) ----
+    T rho;
+    if (P.rho_mode == 0) {
+        const T fro = tsqrt(wg_sum(fro2, scratch));
+        rho = fro / T(sqrt((double)n));
+        rho = tmin(tmax(rho, P.rho_min), P.rho_max);
+    } else if (P.rho_mode == 1) {
+        rho = P.rho_value;
+    } else {
+        rho = P.rho_in[b];
+    }
+    if (tid == 0) { scal[SC_RHO] = rho; scal[SC_RATIO] = T(1); scal[SC_WANTS] = T(0); }
+
+    // ---- equality block: A D, row normalisation E (:179-190) ----
+    if (m > 0) {
+        const T* A = P.A + (size_t)b * m * n;
+        const T* bb = P.b + (size_t)b * m;
+        if (P.scale) {
+            T esum = T(0);
+            for (int r = 0; r < m; ++r) {
+                T am = T(0);
+                for (int j = tid; j < n; j += LQP_NT) {
+                    const T v = A[(size_t)r * n + j] * d[j];
+                    V.As[(size_t)r * n + j] = v;
+                    am = tmax(am, tabs(v));
+                }
+                am = wg_max(am, scratch);
+                if (tid == 0) V.E[r] = am;      // row norm for now
+                esum += am;
+            }
+            __syncthreads();
+            const T floor_a = tmax(esum / T(m), T(1e-6));
+            for (int r = 0; r < m; ++r) {
+                T an = V.E[r];
+                if (an <= T(0)) an = tmax(an, floor_a);
+                const T e = T(1) / an;
+                for (int j = tid; j < n; j += LQP_NT) V.As[(size_t)r * n + j] = e * V.As[(size_t)r * n + j];
+                __syncthreads();
+                if (tid == 0) { V.E[r] = e; V.bs[r] = e * bb[r]; }
+            }
+        } else {
+            for (int t = tid; t < m * n; t += LQP_NT) V.As[t] = A[t];
+            for (int r = tid; r < m; r += LQP_NT) { V.E[r] = T(1); V.bs[r] = bb[r]; }
+        }
+    }
+    // ---- bounds (:192-194) and state ----
+    const T* lb = P.lb + (size_t)b * n;
+    const T* ub = P.ub + (size_t)b * n;
+    const bool any_ineq = P.any_lb || P.any_ub;
+    for (int i = tid; i < n; i += LQP_NT) {
+        const T di = (P.scale && any_ineq) ? V.D[i] : T(1);
+        V.lbs[i] = lb[i] / di;
+        V.ubs[i] = ub[i] / di;
+        V.z[i] = T(0); V.u[i] = T(0); V.x[i] = T(0);
+    }
+    for (int r = tid; r < m; r += LQP_NT) V.nu[r] = T(0);
+    __syncthreads();
+    assemble_kkt_rows(P, b, Qs, ldq, V, rho);
+}
+
+// ---------------------------------------------------------------------------
+// LU and pack kernels (gated: *gate == 0 -> nothing to do)
+// ---------------------------------------------------------------------------
+template <typename T, int PB, bool MFMA>
+__global__ __launch_bounds__(LQP_NT) void k_lu_factor(T* __restrict__ Mall, const int N, const int ld,
+                                                      const size_t mstride, int* __restrict__ piv,
+                                                      const int pstride, int* __restrict__ info,
+                                                      const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) info[b] = 0;
+    __syncthreads();
+    wg_lu_factor<T, PB, MFMA>(Mall + (size_t)b * mstride, N, ld, piv + (size_t)b * pstride, info + b, smem);
+}
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_pack(const T* __restrict__ LUall, const int N, const int ld,
+                                                 const size_t mstride, const int* __restrict__ piv,
+                                                 const int pstride, T* __restrict__ packed,
+                                                 const size_t pkstride, int* __restrict__ dest,
+                                                 const int dstride, const int vec_ok,
+                                                 const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x;
+    wg_pack_factor<T>(LUall + (size_t)b * mstride, N, ld, piv + (size_t)b * pstride,
+                      packed + (size_t)b * pkstride, dest + (size_t)b * dstride, smem, vec_ok != 0);
+}
+
+// ---------------------------------------------------------------------------
+// ADMM loop: iterations [it0, it1) for every problem (:235-313)
+// LDS: v[Np] | tmp[64] | z[n] | u[n] | ps[n] | lb[n] | ub[n] | D[n] | bs[m] | red[NW*8] | dest[Np] (int)
+// ---------------------------------------------------------------------------
+template <typename T> __host__ __device__ inline int loop_lds_bytes(int n, int m, int Np) {
+    return (Np + 64 + 6 * n + m + LQP_NW * 8 + 8) * (int)sizeof(T) + Np * 4;
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ void wg_max_n(T (&v)[NV], T* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = wave_max(v[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[w * 8 + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        T r = red[q];
+#pragma unroll
+        for (int ww = 1; ww < LQP_NW; ++ww) r = tmax(r, red[ww * 8 + q]);
+        v[q] = r;
+    }
+}
+
+// bounded spin on a device-scope counter (persistent mode only)
+__device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int target, int* status) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {    // 2 s: give up
+                __hip_atomic_store(status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
+                                                      const int ctr_base,       // counter slot of check it0 / check
+                                                      const int prev_slot,      // slot of the last check before it0, -1: none / known not done
+                                                      const int persistent) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, n = P.n, m = P.m, N = P.N, Np = P.Np, K = P.K;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // every problem stopped at an earlier check -> nothing to do (break at :312)
+    if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (prev_slot >= 0) {
+        if (__hip_atomic_load(P.counters + (size_t)prev_slot * CT_WORDS + CT_NOTOPT, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            if (b == 0 && tid == 0) {
+                P.status[ST_FINAL_ITER] = it0 - 1;
+                __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
+    if (it0 >= it1) return;
+    T* v = (T*)smem;
+    T* tmp = v + Np;
+    T* z = tmp + 64;
+    T* u = z + n;
+    T* ps = u + n;
+    T* lb = ps + n;
+    T* ub = lb + n;
+    T* D = ub + n;
+    T* bs = D + n;
+    T* red = bs + m;
+    int* dest = (int*)(red + LQP_NW * 8 + 8);
+
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    T* scal = P.scal + (size_t)b * SC_WORDS;
+    const T* packed = P.packed + (size_t)b * packed_blocks(K) * LQP_BLK;
+    const T* Qs = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
+    const int ldq = P.scale ? P.ldq : n;
+    const T rho = scal[SC_RHO];
+    const T pnorm = scal[SC_PNORM];
+    const int S = K * (K + 1);
+    const bool cyclic = (S % LQP_PF) == 0;
+
+    BlockStream<T> st;
+    stream_prime(st, packed, S);
+
+    for (int i = tid; i < n; i += LQP_NT) {
+        z[i] = V.z[i]; u[i] = V.u[i]; ps[i] = V.ps[i]; lb[i] = V.lbs[i]; ub[i] = V.ubs[i]; D[i] = V.D[i];
+    }
+    for (int r = tid; r < m; r += LQP_NT) bs[r] = V.bs[r];
+    const int* gdest = P.dest + (size_t)b * Np;
+    for (int i = tid; i < Np; i += LQP_NT) dest[i] = gdest[i];
+    __syncthreads();
+
+    int slot = ctr_base;
+    for (int it = it0; it < it1; ++it) {
+        // ---- rhs = [-p + rho (z - u); b], scattered to its pivoted position (:259-262) ----
+        for (int i = tid; i < Np; i += LQP_NT) {
+            T val = T(0);
+            if (i < n) val = -ps[i] + rho * (z[i] - u[i]);
+            else if (i < N) val = bs[i - n];
+            v[dest[i]] = val;
+        }
+        __syncthreads();
+        // ---- x-update: cached triangular solves (:267) ----
+        wg_packed_solve(st, packed, K, v, tmp, cyclic);
+        if (!cyclic && it + 1 < it1) stream_prime(st, packed, S);
+        // ---- z-update, residuals, dual (:271-282) ----
+        const bool check = (it % P.check_solved) == 0;
+        T mx[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) mx[q] = T(0);
+        for (int i = tid; i < n; i += LQP_NT) {
+            const T xi = v[i];
+            const T zp = z[i];
+            const T ui = u[i];
+            T zn = xi + ui;
+            if (P.any_lb) zn = tmax(zn, lb[i]);
+            if (P.any_ub) zn = tmin(zn, ub[i]);
+            const T r = xi - zn;
+            const T s = rho * (zn - zp);
+            const T un = ui + r;
+            z[i] = zn;
+            u[i] = un;
+            if (check) {
+                const T di = D[i];
+                mx[0] = tmax(mx[0], tabs(di * r));
+                mx[1] = tmax(mx[1], tabs(di * s));
+                mx[2] = tmax(mx[2], tabs(di * xi));
+                mx[3] = tmax(mx[3], tabs(di * zn));
+                mx[4] = tmax(mx[4], tabs((rho * di) * un));
+            }
+        }
+        if (check) {
+            // ---- ||Q x / D||_inf (:299): one wave per row of Qs ----
+            T qmax = T(0);
+            for (int i = w; i < n; i += LQP_NW) {
+                const T* qr = Qs + (size_t)i * ldq;
+                T acc = T(0);
+                for (int j = lane; j < n; j += 64) acc += qr[j] * v[j];
+                acc = wave_sum(acc);
+                qmax = tmax(qmax, tabs(acc / D[i]));
+            }
+            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], qmax};
+            wg_max_n<T, 6>(mv, red);
+            const T tiny = T(1e-16);
+            const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
+            const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
+            const T dua_scale = tmax(tmax(tmax(mv[4], mv[5]), pnorm), tiny);
+            const T tol_d = P.eps_abs + P.eps_rel * dua_scale;
+            const bool solved = (mv[0] < tol_p) && (mv[1] < tol_d);
+            const bool wants = (mv[0] > tmax(tol_p, P.ar_thr)) || (mv[1] > tmax(tol_d, P.ar_thr));
+            // ratio for the next adaptive-rho step (:239-245)
+            const T num = tmax(mv[0] / pri_scale, tiny);
+            const T den = tmax(mv[1] / dua_scale, tiny);
+            const T ratio = tsqrt(num / den);
+            const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
+            unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
+            if (tid == 0) {
+                scal[SC_RATIO] = ratio;
+                scal[SC_WANTS] = wants ? T(1) : T(0);
+                if (!solved) atomicAdd(ct + CT_NOTOPT, 1u);
+                if (wants) atomicAdd(ct + CT_WANTS, 1u);
+                if (trig) atomicAdd(ct + CT_TRIG, 1u);
+            }
+            ++slot;
+            if (persistent) {
+                // all workgroups resident: device-wide "all optimal?" (torch.all at :312)
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(ct + CT_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                grid_wait(ct + CT_ARRIVE, gridDim.x, P.status);
+                const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (notopt == 0 || tmo) {
+                    if (b == 0 && tid == 0) {
+                        P.status[ST_FINAL_ITER] = it;
+                        __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    // leave the loop with the state of iteration `it`
+                    __syncthreads();
+                    for (int i = tid; i < n; i += LQP_NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
+                    for (int r = tid; r < m; r += LQP_NT) V.nu[r] = v[n + r];
+                    return;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- save state for the next launch / the epilogue ----
+    for (int i = tid; i < n; i += LQP_NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
+    for (int r = tid; r < m; r += LQP_NT) V.nu[r] = v[n + r];
+}
+
+// ---------------------------------------------------------------------------
+// adaptive rho (:237-256): global decision from the counters of the last
+// check, masked per-problem update, KKT re-assembly; sets the gate for the
+// LU + pack launches that follow.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, const int last_slot) {
+    const int b = blockIdx.x, n = P.n, m = P.m;
+    if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (b == 0 && threadIdx.x == 0) P.status[ST_GATE] = 0;
+        return;
+    }
+    const unsigned int* ct = P.counters + (size_t)last_slot * CT_WORDS;
+    const bool all_done = ct[CT_NOTOPT] == 0;
+    const bool fire = !all_done && ct[CT_WANTS] > 0 && ct[CT_TRIG] > 0;
+    if (b == 0 && threadIdx.x == 0) {
+        P.status[ST_GATE] = fire ? 1 : 0;
+        if (fire) { P.status[ST_NFACTOR] += 1; P.status[ST_RHO_UPDATED] = 1; }
+    }
+    if (!fire) return;
+    T* scal = P.scal + (size_t)b * SC_WORDS;
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    T rho = scal[SC_RHO];
+    if (scal[SC_WANTS] != T(0)) rho = rho * scal[SC_RATIO];
+    rho = tmin(tmax(rho, P.rho_min), P.rho_max);
+    __syncthreads();
+    if (threadIdx.x == 0) scal[SC_RHO] = rho;
+    const T* Qs = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
+    assemble_kkt_rows(P, b, Qs, P.scale ? P.ldq : n, V, rho);
+}
+
+// ---------------------------------------------------------------------------
+// epilogue: undo scaling, duals (:316-327)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_fwd_epilogue(const FwdParams<T> P) {
+    const int b = blockIdx.x, n = P.n, m = P.m;
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    const T rho = P.scal[(size_t)b * SC_WORDS + SC_RHO];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const T d = V.D[i];
+        const T xo = d * V.x[i], zo = d * V.z[i], uo = V.u[i] / d;
+        P.x[(size_t)b * n + i] = xo;
+        P.z[(size_t)b * n + i] = zo;
+        P.u[(size_t)b * n + i] = uo;
+        const T y = uo * rho;
+        P.lams[(size_t)b * 2 * n + i] = (-y > T(0)) ? -y : T(0);
+        P.lams[(size_t)b * 2 * n + n + i] = (y > T(0)) ? y : T(0);
+    }
+    for (int r = threadIdx.x; r < m; r += blockDim.x) P.nus[(size_t)b * m + r] = V.nu[r] * V.E[r];
+    if (threadIdx.x == 0) P.rho_out[b] = rho;
+}
+
+// ---------------------------------------------------------------------------
+// fixed-point backward (solve_box_qp_admm_torch.py:349-432)
+// ---------------------------------------------------------------------------
+template <typename T> struct BwdParams {
+    int B, n, m, N, Np, K;
+    const T *g, *x, *u, *lams, *nus, *Q, *A, *lb, *ub, *rho_in;
+    T rho_value;
+    int rho_mode;
+    T *dQ, *dp, *dA, *db, *dlb, *dub;
+    T* M;        // B * Np * Np
+    T* packed;
+    T* rhs;      // B * Np  (rhs, then the solution d)
+    int *piv, *dest, *info;
+};
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_bwd_build(const BwdParams<T> P) {
+    // mask :360-365, rhs :368-375, non-symmetric system :378-392
+    const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const T rho = (P.rho_mode == 2) ? P.rho_in[b] : P.rho_value;
+    const T* x = P.x + (size_t)b * n;
+    const T* u = P.u + (size_t)b * n;
+    const T* lb = P.lb + (size_t)b * n;
+    const T* ub = P.ub + (size_t)b * n;
+    const T* g = P.g + (size_t)b * n;
+    const T* Q = P.Q + (size_t)b * n * n;
+    const T* A = P.A ? P.A + (size_t)b * m * n : nullptr;
+    T* M = P.M + (size_t)b * Np * Np;
+    T* rhs = P.rhs + (size_t)b * Np;
+    if (tid == 0) P.info[b] = 0;
+    for (int i = w; i < n; i += LQP_NW) {
+        const T s = x[i] + u[i];
+        const T keep = (s > ub[i] || s < lb[i]) ? T(0) : T(1);
+        const T* qr = Q + (size_t)i * n;
+        T* mr = M + (size_t)i * Np;
+        for (int j = lane; j < n; j += 64) {
+            T val = keep * qr[j];
+            if (j == i) val = (val + rho * (T(1) - keep)) + T(1e-8);
+            mr[j] = val;
+        }
+        for (int r = lane; r < m; r += 64) mr[n + r] = keep * A[(size_t)r * n + i];
+        if (lane == 0) rhs[i] = -(g[i] * keep);
+    }
+    for (int r = w; r < m; r += LQP_NW) {
+        T* mr = M + (size_t)(n + r) * Np;
+        for (int j = lane; j < n; j += 64) mr[j] = A[(size_t)r * n + j];
+        for (int c = lane; c < m; c += 64) mr[n + c] = (c == r) ? T(1e-8) : T(0);
+        if (lane == 0) rhs[n + r] = T(0);
+    }
+}
+
+// solve with the packed factor (one rhs per problem, in global memory, in place)
+// LDS: v[Np] | tmp[64] | dest[Np]
+template <typename T> __host__ __device__ inline int solve_lds_bytes(int Np) { return (Np + 64) * (int)sizeof(T) + Np * 4; }
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_packed_solve(const T* __restrict__ packed_all, const int N, const int Np,
+                                                         const int K, const int* __restrict__ dest_all,
+                                                         T* __restrict__ rhs_all, const int nrhs,
+                                                         const size_t rhs_bstride, const int rhs_rstride,
+                                                         const int rhs_cstride) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    T* v = (T*)smem;
+    T* tmp = v + Np;
+    int* dest = (int*)(tmp + 64);
+    const T* packed = packed_all + (size_t)b * packed_blocks(K) * LQP_BLK;
+    const int S = K * (K + 1);
+    const bool cyclic = (S % LQP_PF) == 0;
+    BlockStream<T> st;
+    stream_prime(st, packed, S);
+    for (int i = tid; i < Np; i += LQP_NT) dest[i] = dest_all[(size_t)b * Np + i];
+    __syncthreads();
+    T* rhs = rhs_all + (size_t)b * rhs_bstride;
+    for (int c = 0; c < nrhs; ++c) {
+        for (int i = tid; i < Np; i += LQP_NT) v[dest[i]] = (i < N) ? rhs[(size_t)i * rhs_rstride + (size_t)c * rhs_cstride] : T(0);
+        __syncthreads();
+        wg_packed_solve(st, packed, K, v, tmp, cyclic && (c + 1 < nrhs));
+        if (!cyclic && c + 1 < nrhs) stream_prime(st, packed, S);
+        for (int i = tid; i < N; i += LQP_NT) rhs[(size_t)i * rhs_rstride + (size_t)c * rhs_cstride] = v[i];
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
+    // gradients :396-430; d = [dv; dnu] is in P.rhs
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T* dv = (T*)smem;          // n
+    T* xs = dv + n;            // n
+    T* dnu = xs + n;           // m
+    const T rho = (P.rho_mode == 2) ? P.rho_in[b] : P.rho_value;
+    const T* d = P.rhs + (size_t)b * Np;
+    const T* x = P.x + (size_t)b * n;
+    for (int i = tid; i < n; i += LQP_NT) { dv[i] = d[i]; xs[i] = x[i]; }
+    for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[n + r];
+    __syncthreads();
+    if (P.dp) for (int i = tid; i < n; i += LQP_NT) P.dp[(size_t)b * n + i] = dv[i];
+    if (P.db) for (int r = tid; r < m; r += LQP_NT) P.db[(size_t)b * m + r] = -dnu[r];
+    if (P.dA && m > 0) {
+        const T* nus = P.nus + (size_t)b * m;
+        for (int t = tid; t < m * n; t += LQP_NT) {
+            const int r = t / n, j = t - r * n;
+            P.dA[(size_t)b * m * n + t] = dnu[r] * xs[j] + nus[r] * dv[j];
+        }
+    }
+    const T* Q = P.Q + (size_t)b * n * n;
+    const T* A = P.A ? P.A + (size_t)b * m * n : nullptr;
+    const bool need_kkt = P.dlb || P.dub;
+    T* dQ = P.dQ ? P.dQ + (size_t)b * n * n : nullptr;
+    for (int i = w; i < n; i += LQP_NW) {
+        const T hi = T(0.5) * dv[i], xi = xs[i];
+        T acc = T(0);
+        if (need_kkt) {
+            const T* qr = Q + (size_t)i * n;
+            for (int j = lane; j < n; j += 64) acc += qr[j] * dv[j];
+            acc = wave_sum(acc);
+        }
+        if (dQ) {
+            T* o = dQ + (size_t)i * n;
+            for (int j = lane; j < n; j += 64) o[j] = hi * xs[j] + (T(0.5) * dv[j]) * xi;
+        }
+        if (need_kkt && lane == 0) {
+            T kkt = -P.g[(size_t)b * n + i] - acc;
+            T at = T(0);
+            for (int r = 0; r < m; ++r) at += A[(size_t)r * n + i] * dnu[r];
+            if (m > 0) kkt = kkt - at;
+            T div = rho * P.u[(size_t)b * n + i];
+            if (div == T(0)) div = T(1);
+            const T dlam = kkt / div;
+            const T* lams = P.lams + (size_t)b * 2 * n;
+            if (P.dlb) P.dlb[(size_t)b * n + i] = dlam * lams[i];
+            if (P.dub) P.dub[(size_t)b * n + i] = -dlam * lams[n + i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// KKT solve helpers (lqp_py/solve_qp_eqcon_torch.py:23-25, utils.py:23-32)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_kkt_build(const T* __restrict__ Qall, const T* __restrict__ pall,
+                                                      const T* __restrict__ Aall, const T* __restrict__ ball,
+                                                      const int n, const int m, const int Np,
+                                                      T* __restrict__ Mall, T* __restrict__ rhsall, int* info) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const T* Q = Qall + (size_t)b * n * n;
+    T* M = Mall + (size_t)b * Np * Np;
+    T* rhs = rhsall + (size_t)b * Np;
+    if (tid == 0) info[b] = 0;
+    for (int i = w; i < n; i += LQP_NW) {
+        const T* qr = Q + (size_t)i * n;
+        T* mr = M + (size_t)i * Np;
+        for (int j = lane; j < n; j += 64) mr[j] = qr[j];
+        for (int r = lane; r < m; r += 64) mr[n + r] = Aall[(size_t)b * m * n + (size_t)r * n + i];
+        if (lane == 0) rhs[i] = -pall[(size_t)b * n + i];
+    }
+    for (int r = w; r < m; r += LQP_NW) {
+        T* mr = M + (size_t)(n + r) * Np;
+        for (int j = lane; j < n; j += 64) mr[j] = Aall[(size_t)b * m * n + (size_t)r * n + j];
+        for (int c = lane; c < m; c += 64) mr[n + c] = T(0);
+        if (lane == 0) rhs[n + r] = ball[(size_t)b * m + r];
+    }
+}
+
+template <typename T>
+__global__ void k_kkt_unpack(const T* __restrict__ rhsall, const int n, const int m, const int Np,
+                             T* __restrict__ x, T* __restrict__ nus) {
+    const int b = blockIdx.x;
+    const T* d = rhsall + (size_t)b * Np;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x[(size_t)b * n + i] = d[i];
+    if (nus) for (int r = threadIdx.x; r < m; r += blockDim.x) nus[(size_t)b * m + r] = d[n + r];
+}
+
+// dQ = 0.5 (dx x^T + x dx^T); dA = dnu x^T + nus dx^T
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_outer_grads(const T* __restrict__ dx, const T* __restrict__ x,
+                                                        const T* __restrict__ dnu, const T* __restrict__ nus,
+                                                        const int n, const int m, T* __restrict__ dQ, T* __restrict__ dA) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const T* dxb = dx + (size_t)b * n;
+    const T* xb = x + (size_t)b * n;
+    if (dQ) {
+        for (int i = w; i < n; i += LQP_NW) {
+            const T di = dxb[i], xi = xb[i];
+            T* o = dQ + (size_t)b * n * n + (size_t)i * n;
+            for (int j = lane; j < n; j += 64) o[j] = T(0.5) * (di * xb[j] + xi * dxb[j]);
+        }
+    }
+    if (dA && m > 0) {
+        for (int t = tid; t < m * n; t += LQP_NT) {
+            const int r = t / n, j = t - r * n;
+            dA[(size_t)b * m * n + t] = dnu[(size_t)b * m + r] * xb[j] + nus[(size_t)b * m + r] * dxb[j];
+        }
+    }
+}
+
+// strided copies between a user (B,N,N) matrix and the padded workspace
+template <typename T>
+__global__ void k_copy_matrix(const T* __restrict__ src, const int lds_, const size_t sstride,
+                              T* __restrict__ dst, const int ldd, const size_t dstride, const int N) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = w; i < N; i += nw)
+        for (int j = lane; j < N; j += 64) dst[(size_t)b * dstride + (size_t)i * ldd + j] = src[(size_t)b * sstride + (size_t)i * lds_ + j];
+}
+template <typename TI>
+__global__ void k_copy_ints(const TI* __restrict__ src, const int sstride, TI* __restrict__ dst, const int dstride, const int N) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) dst[(size_t)b * dstride + i] = src[(size_t)b * sstride + i];
+}
+
+}  // namespace lqp

@@ -1,0 +1,95 @@
+// Common device helpers for the gfx950 box-QP kernels.
+// One workgroup (LQP_NT = 1024 threads = 16 wave64) owns one QP at a time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LQP_NT 1024            // threads per workgroup
+#define LQP_NW (LQP_NT / 64)   // waves per workgroup
+#define LQP_NB 64              // triangular-solve block edge
+#define LQP_BLK (LQP_NB * LQP_NB)
+
+namespace lqp {
+
+__host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// 4-element vector of T: one 16-B (f32) or 32-B (f64) global access per lane.
+template <typename T> struct V4;
+template <> struct __attribute__((aligned(16))) V4<float>  { float  v[4]; };
+template <> struct __attribute__((aligned(32))) V4<double> { double v[4]; };
+
+template <typename T> __device__ __forceinline__ T tabs(T a) { return a < T(0) ? -a : a; }
+template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
+__device__ __forceinline__ float  tsqrt(float a)  { return sqrtf(a); }
+__device__ __forceinline__ double tsqrt(double a) { return sqrt(a); }
+__device__ __forceinline__ float  tfloor(float a)  { return floorf(a); }
+__device__ __forceinline__ double tfloor(double a) { return floor(a); }
+__device__ __forceinline__ float  tceil(float a)  { return ceilf(a); }
+__device__ __forceinline__ double tceil(double a) { return ceil(a); }
+
+// ---- DPP moves (no LDS crossbar): quad_perm / row_ror inside a 16-lane row ----
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ float dpp(float v) {
+    return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = dpp_i32<CTRL>((int)(b & 0xffffffffLL));
+    int hi = dpp_i32<CTRL>((int)(b >> 32));
+    long long r = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(double, r);
+}
+// sum over the 16 lanes of a DPP row; every lane of the row gets the total
+template <typename T> __device__ __forceinline__ T row16_sum(T v) {
+    v += dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp<0x124>(v);   // row_ror:4
+    v += dpp<0x128>(v);   // row_ror:8
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+    v = tmax(v, dpp<0xB1>(v));
+    v = tmax(v, dpp<0x4E>(v));
+    v = tmax(v, dpp<0x124>(v));
+    v = tmax(v, dpp<0x128>(v));
+    v = tmax(v, (T)__shfl_xor(v, 16));
+    v = tmax(v, (T)__shfl_xor(v, 32));
+    return v;
+}
+
+// Workgroup reductions through a small LDS scratch (>= LQP_NW elements of T).
+// Both end with every thread holding the result; both contain barriers, so
+// every thread of the workgroup must call them.
+template <typename T> __device__ __forceinline__ T wg_sum(T v, T* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();                       // scratch may still be read by a previous call
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T r = T(0);
+#pragma unroll
+    for (int i = 0; i < LQP_NW; ++i) r += scratch[i];
+    return r;
+}
+template <typename T> __device__ __forceinline__ T wg_max(T v, T* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < LQP_NW; ++i) r = tmax(r, scratch[i]);
+    return r;
+}
+
+}  // namespace lqp

@@ -1,0 +1,260 @@
+"""Batched box-constrained QP layer on MI355X: ADMM forward + fixed-point
+implicit backward, behind the reference's Python surface.
+
+    x* = argmin_x 0.5 x^T Q x + p^T x   s.t.  A x = b,  lb <= x <= ub
+
+Drop-in for ``lqp_py/solve_box_qp_admm_torch.py`` of ipo-lab/lqp_py:
+``SolveBoxQP`` (:7-18), ``SolveBoxQPLayer`` (:21-67), ``BoxQPTH`` (:70-105),
+``torch_solve_box_qp`` (:108-333), ``torch_solve_box_qp_grad`` (:349-432).
+Everything numeric runs in the HIP library (``lqp_boxqp_forward`` /
+``lqp_boxqp_backward_fp``, include/lqp_amd.h); this module only resolves the
+control dict -- including its key-name traps and the caller-dict side effect --
+and moves pointers.  Tensors must be on the GPU; there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .utils import get_ncon
+
+_INF = float("inf")
+
+
+class SolveBoxQP(nn.Module):
+    """nn.Module holding the control dict (reference :7-18)."""
+
+    def __init__(self, control):
+        super().__init__()
+        self.control = control
+
+    def forward(self, Q, p, A, b, lb, ub):
+        if self.control.get('unroll', False):
+            return torch_solve_box_qp(Q=Q, p=p, A=A, b=b, lb=lb, ub=ub, control=self.control)
+        return SolveBoxQPLayer.apply(Q, p, A, b, lb, ub, self.control)
+
+
+class SolveBoxQPLayer(torch.autograd.Function):
+    """ADMM forward solve / fixed-point implicit backward (reference :21-67)."""
+
+    @staticmethod
+    def forward(ctx, Q, p, A, b, lb, ub, control):
+        has_lb, has_ub = _finite_bounds(lb, ub)
+        if not (has_lb or has_ub):
+            control['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
+        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=(has_lb, has_ub))
+        ctx.rho = sol['rho']
+        ctx.backward_method = control.get('backward', 'fixed_point')
+        ctx.save_for_backward(sol['x'], sol['u'], sol['lams'], sol['nus'], Q, A, lb, ub)
+        return sol['x']
+
+    @staticmethod
+    def backward(ctx, dl_dz):
+        x, u, lams, nus, Q, A, lb, ub = ctx.saved_tensors
+        if ctx.backward_method == 'kkt':
+            raise NotImplementedError("lqp_py_amd: backward='kkt' is not built yet (SURVEY 8(f) rank 2); "
+                                      "use the default backward='fixed_point'")
+        need = ctx.needs_input_grad
+        want = dict(dQ=need[0], dp=need[1], dA=need[2] and A is not None, db=need[3] and A is not None,
+                    dlb=need[4], dub=need[5])
+        grads = _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, ctx.rho, want)
+        return grads
+
+
+class BoxQPTH:
+    """Stateful holder (reference :70-105), including its quirk that passing
+    ``lb``/``ub`` to ``update`` clears them (:99-102)."""
+
+    def __init__(self, Q, p, A, b, lb, ub, control):
+        self.Q, self.p, self.A, self.b, self.lb, self.ub = Q, p, A, b, lb, ub
+        self.control = control
+        self.sol = {}
+
+    def solve(self):
+        self.sol = torch_solve_box_qp(Q=self.Q, p=self.p, A=self.A, b=self.b, lb=self.lb, ub=self.ub,
+                                      control=self.control)
+        return self.sol.get('x')
+
+    def update(self, Q=None, p=None, A=None, b=None, lb=None, ub=None, control=None):
+        if Q is not None:
+            self.Q = Q
+        if p is not None:
+            self.p = p
+        if A is not None:
+            self.A = A
+        if b is not None:
+            self.b = b
+        if lb is not None:
+            self.lb = None
+        if ub is not None:
+            self.ub = None
+        if control is not None:
+            self.control = control
+        return None
+
+
+def torch_solve_box_qp(Q, p, A, b, lb, ub, control):
+    """Forward solve; returns {"x","z","u","lams","nus","rho","iter"} (reference :108-333)."""
+    if control.get('unroll', False):
+        raise NotImplementedError("lqp_py_amd: unroll=True (differentiating through the loop) is not built yet "
+                                  "(SURVEY 8(f) rank 1); use SolveBoxQP with the default fixed-point backward")
+    return _forward_solve(Q, p, A, b, lb, ub, control, bounds=None)
+
+
+def torch_solve_box_qp_grad(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho):
+    """Fixed-point implicit gradients -> (dQ, dp, dA, db, dlb, dub, None) (reference :349-432)."""
+    has_eq = A is not None
+    want = dict(dQ=True, dp=True, dA=has_eq, db=has_eq, dlb=True, dub=True)
+    return _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want)
+
+
+# ---------------------------------------------------------------------------
+# internals
+# ---------------------------------------------------------------------------
+def _finite_bounds(lb, ub):
+    # global over the whole batch, as in the reference (:33-34, :129-130); one host sync
+    flags = torch.stack((torch.max(lb) > -_INF, torch.min(ub) < _INF)).tolist()
+    return bool(flags[0]), bool(flags[1])
+
+
+def resolve_control(control, n_x):
+    """Numbers the loop uses, with the reference's defaults and key names (:133-154)."""
+    g = control.get
+    check = g('check_solved', max(round((n_x ** 0.5) / 10) * 10, 1))
+    ar_iter = max(round(g('adaptive_rho_iter', 100) / check) * check, 1)
+    return dict(
+        max_iters=g('max_iters', 10_000),
+        eps_abs=max(g('eps_abs', 1e-3), 1e-12),
+        eps_rel=max(g('eps_rel', 1e-3), 1e-12),
+        check_solved=check,
+        rho=g('rho', None), rho_min=g('rho_min', 1e-6), rho_max=g('rho_max', 1e6),
+        adaptive_rho=bool(g('adaptive_rho', False)),
+        adaptive_rho_tol=g('adaptive_rho_tol', 5),
+        adaptive_rho_iter=ar_iter,
+        adaptive_rho_max_iter=g('adaptive_max_iter', 1000),
+        adaptive_rho_threshold=g('adaptive_rho_threshold', 1e-5),
+        scale=bool(g('scale', False)),
+        beta=g('beta'),
+        verbose=g('verbose', False),
+        launch_mode=g('launch_mode', 0),         # extension: 0 auto, 1 segmented, 2 persistent
+    )
+
+
+def _rho_argument(rho, B, like):
+    """-> (mode, scalar value, device tensor or None): 0 auto, 1 scalar, 2 one value per problem"""
+    if rho is None:
+        return 0, 0.0, None
+    if not torch.is_tensor(rho):
+        return 1, float(rho), None
+    if rho.numel() == 1:
+        return 1, float(rho), None
+    if rho.numel() != B:
+        _bad("a rho tensor must hold one value per problem, e.g. shape (B,1,1)")
+    return 2, 0.0, rho.detach().to(device=like.device, dtype=like.dtype).reshape(B).contiguous()
+
+
+def _bad(msg):
+    raise ValueError("lqp_py_amd: " + msg)
+
+
+def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None):
+    _lib.require_gpu(Q, p, A, b, lb, ub)
+    lib = _lib.load()
+    B, n = Q.shape[0], p.shape[1]
+    m = get_ncon(A, dim=1)
+    dt = _lib.dtype_code(p)
+    dev = p.device
+    has_lb, has_ub = bounds if bounds is not None else _finite_bounds(lb, ub)
+    r = resolve_control(control, n)
+    rho = r['rho']
+    if not (has_lb or has_ub):
+        rho = 0                                     # one iteration solves it (:157-158)
+    if r['beta'] is not None and torch.is_tensor(r['beta']) and r['beta'].numel() != 1:
+        _bad("per-problem beta tensors are not supported; pass a float or None")
+
+    Qc, pc, Ac, bc, lbc, ubc = (_lib.c(t) for t in (Q, p, A, b, lb, ub))
+    Qc, lbc, ubc = (t.to(p.dtype) for t in (Qc, lbc, ubc))
+    if m > 0:
+        Ac, bc = Ac.to(p.dtype), bc.to(p.dtype)
+    rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, p)
+
+    ctl = _lib.BoxQPCtrl(
+        max_iters=int(r['max_iters']), check_solved=int(r['check_solved']),
+        adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
+        adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),
+        any_lb=int(has_lb), any_ub=int(has_ub), rho_mode=rho_mode,
+        beta_mode=0 if r['beta'] is None else 1, launch_mode=int(r['launch_mode']), reserved=0,
+        eps_abs=float(r['eps_abs']), eps_rel=float(r['eps_rel']), rho_value=rho_value,
+        rho_min=float(r['rho_min']), rho_max=float(r['rho_max']),
+        adaptive_rho_tol=float(r['adaptive_rho_tol']),
+        adaptive_rho_threshold=float(r['adaptive_rho_threshold']),
+        beta_value=0.0 if r['beta'] is None else float(r['beta']))
+    stats = _lib.BoxQPStats()
+
+    x = torch.empty((B, n, 1), dtype=p.dtype, device=dev)
+    z = torch.empty_like(x)
+    u = torch.empty_like(x)
+    lams = torch.empty((B, 2 * n, 1), dtype=p.dtype, device=dev)
+    nus = torch.empty((B, m, 1), dtype=p.dtype, device=dev) if m > 0 else None
+    rho_out = torch.empty((B,), dtype=p.dtype, device=dev)
+    nbytes = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
+    ws = _lib.workspace(dev, nbytes, "fwd")
+    with torch.cuda.device(dev):
+        st = lib.lqp_boxqp_forward(_lib.stream_ptr(dev), dt, B, n, m,
+                                   _lib.ptr(Qc), _lib.ptr(pc), _lib.ptr(Ac), _lib.ptr(bc), _lib.ptr(lbc), _lib.ptr(ubc),
+                                   ctypes.byref(ctl), _lib.ptr(rho_tensor),
+                                   _lib.ptr(x), _lib.ptr(z), _lib.ptr(u), _lib.ptr(lams), _lib.ptr(nus), _lib.ptr(rho_out),
+                                   ctypes.byref(stats), _lib.ptr(ws), ws.numel())
+    if st == 3:
+        # the reference's torch.linalg.lu_factor raises on an exactly singular KKT matrix (:215)
+        raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "
+                           f"(batch index {stats.fail_index}); the KKT matrix is singular")
+    _lib.check(st, "torch_solve_box_qp")
+    if r['verbose']:
+        print(f'iteration = {stats.iters}  (checks: {stats.n_check}, factorisations: {stats.n_factor})')
+
+    # type of the returned rho follows the reference: a python number stays one unless
+    # adaptive rho rewrote it (:248-250); None becomes a (B,1,1) tensor (:200-203)
+    if rho_mode == 1 and not stats.rho_updated:
+        rho_ret = rho
+    else:
+        rho_ret = rho_out.view(B, 1, 1)
+    sol = {"x": x, "z": z, "u": u, "lams": lams, "nus": nus, "rho": rho_ret, "iter": int(stats.iters)}
+    sol["_stats"] = {k: getattr(stats, k) for k, _ in stats._fields_}
+    return sol
+
+
+def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want):
+    _lib.require_gpu(dl_dz, x, u, lams, nus, Q, A, lb, ub)
+    lib = _lib.load()
+    B, n = Q.shape[0], Q.shape[1]
+    m = get_ncon(A, dim=1)
+    dt = _lib.dtype_code(x)
+    dev, dty = x.device, x.dtype
+    if rho is None:
+        rho = 1.0                                          # (:356-357)
+    rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, x)
+    gc, xc, uc, lc, nc, Qc, Ac, lbc, ubc = (None if t is None else _lib.c(t).to(dty)
+                                             for t in (dl_dz, x, u, lams, nus, Q, A, lb, ub))
+    mk = lambda on, shape: torch.empty(shape, dtype=dty, device=dev) if on else None
+    dQ = mk(want['dQ'], (B, n, n))
+    dp = mk(want['dp'], (B, n, 1))
+    dA = mk(want['dA'] and m > 0, (B, m, n))
+    db = mk(want['db'] and m > 0, (B, m, 1))
+    dlb = mk(want['dlb'], (B, n, 1))
+    dub = mk(want['dub'], (B, n, 1))
+    nbytes = lib.lqp_boxqp_backward_fp_workspace_bytes(dt, B, n, m)
+    ws = _lib.workspace(dev, nbytes, "bwd")
+    fail = ctypes.c_int32(-1)
+    with torch.cuda.device(dev):
+        st = lib.lqp_boxqp_backward_fp(_lib.stream_ptr(dev), dt, B, n, m,
+                                       _lib.ptr(gc), _lib.ptr(xc), _lib.ptr(uc), _lib.ptr(lc), _lib.ptr(nc),
+                                       _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
+                                       rho_mode, rho_value, _lib.ptr(rho_tensor),
+                                       _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
+                                       ctypes.byref(fail), _lib.ptr(ws), ws.numel())
+    if st == 3:
+        raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {fail.value})")
+    _lib.check(st, "torch_solve_box_qp_grad")
+    return (dQ, dp, dA, db, dlb, dub, None)

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Stage-by-stage diagnostic of the HIP kernels against torch-CPU / the oracle.
+Not a pytest file: prints one line per check and never stops at the first
+failure (GPU box round-trips are expensive)."""
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import lqp_py_amd as L                      # noqa: E402
+from lqp_py_amd import lu_layer             # noqa: E402
+from oracle import boxqp_oracle as O        # noqa: E402
+from conftest import load_golden            # noqa: E402
+
+dev = torch.device("cuda:0")
+TOL = dict(eps_abs=1e-5, eps_rel=1e-5)
+FAILS = []
+
+
+def report(name, err, tol):
+    ok = err <= tol
+    print(f"{'PASS' if ok else 'FAIL'}  {name:58s} err={err:.3e} tol={tol:.1e}", flush=True)
+    if not ok:
+        FAILS.append(name)
+
+
+def maxerr(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def relerr(a, b):
+    b = b.detach().cpu().double()
+    return float((a.detach().cpu().double() - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def step(fn):
+    def run(*a, **k):
+        try:
+            t = time.time()
+            fn(*a, **k)
+            torch.cuda.synchronize()
+            print(f"      [{fn.__name__} {a} {time.time() - t:.2f}s]", flush=True)
+        except Exception:
+            traceback.print_exc()
+            FAILS.append(fn.__name__ + str(a))
+    return run
+
+
+@step
+def lu_check(N, B, dtype, mfma, kind="randn"):
+    os.environ["LQP_LU_MFMA"] = "1" if mfma else "0"
+    torch.manual_seed(N + B)
+    A = torch.randn(B, N, N, dtype=dtype)
+    if kind == "kkt":          # symmetric indefinite KKT-like
+        n = N - max(1, N // 10)
+        G = torch.randn(B, 2 * n, n, dtype=dtype)
+        Q = G.transpose(1, 2) @ G / (2 * n) + 1.2 * torch.eye(n, dtype=dtype)
+        Am = torch.randn(B, N - n, n, dtype=dtype)
+        A = O.kkt_matrix(Q, Am)
+    LUr, Pr = torch.linalg.lu_factor(A)
+    LU, P = lu_layer.lu_factor(A.to(dev))
+    tag = f"lu N={N} B={B} {str(dtype)[6:]} mfma={int(mfma)} {kind}"
+    same_piv = bool((P.cpu() == Pr).all())
+    report(tag + " pivots equal", 0.0 if same_piv else 1.0, 0.5)
+    # reconstruction P^T L U == A regardless of pivot ties
+    Pm, Lm, Um = torch.lu_unpack(LU.cpu(), P.cpu())
+    report(tag + " |PLU-A|/|A|", relerr(Pm @ Lm @ Um, A), 5e-5 if dtype == torch.float32 else 1e-12)
+    if same_piv:
+        report(tag + " LU vs torch", relerr(LU, LUr), 2e-4 if dtype == torch.float32 else 1e-10)
+    rhs = torch.randn(B, N, 3, dtype=dtype)
+    xr = torch.linalg.lu_solve(LUr, Pr, rhs)
+    x1 = lu_layer.lu_solve(LUr.to(dev), Pr.to(dev), rhs.to(dev))          # torch factor, our solve
+    report(tag + " solve(torch LU)", relerr(x1, xr), 2e-3 if dtype == torch.float32 else 1e-9)
+    x2 = lu_layer.lu_solve(LU, P, rhs.to(dev))                             # our factor, our solve
+    report(tag + " solve(our LU)", relerr(x2, xr), 2e-3 if dtype == torch.float32 else 1e-9)
+
+
+@step
+def kkt_check():
+    g = load_golden("g9_lu_eqcon")
+    Q, p, A, b = (g[k].to(dev) for k in ("Q", "p", "A", "b"))
+    s = L.torch_solve_qp_eqcon(Q, p, A, b)
+    report("eqcon x", maxerr(s["x"], g["eq_x"]), 2e-5)
+    report("eqcon nus", maxerr(s["nus"], g["eq_nus"]), 2e-5)
+    gr = L.torch_solve_qp_eqcon_grad(g["gz"].to(dev), s["x"], s["nus"], Q, A)
+    for t, k in zip(gr, ("eq_dQ", "eq_dp", "eq_dA", "eq_db")):
+        report("eqcon grad " + k, maxerr(t, g[k]), 5e-5)
+    us = L.torch_solve_qp_uncon(Q, p)
+    report("uncon x", maxerr(us["x"], g["un_x"]), 1e-4)
+
+
+def to_dev(*ts):
+    return [None if t is None else t.to(dev) for t in ts]
+
+
+@step
+def fwd_check(name, inputs, ctl, gold, keys, tol, grad_cot=None, grad_gold=None, gtol=1e-4):
+    Q, p, A, b, lb, ub = to_dev(*inputs)
+    sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, dict(ctl))
+    print(f"      {name}: iter={sol['iter']} gold_iter={gold.get('iter')} stats={sol['_stats']}")
+    report(f"{name} iter", abs(sol["iter"] - int(gold["iter"])), 0.5)
+    for k in keys:
+        report(f"{name} {k}", maxerr(sol[k], gold[k]), tol)
+    if grad_cot is not None:
+        gr = L.torch_solve_box_qp_grad(grad_cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
+        for nm, t in zip(("dQ", "dp", "dA", "db", "dlb", "dub"), gr):
+            if t is not None and grad_gold.get(nm) is not None:
+                report(f"{name} grad {nm}", relerr(t, grad_gold[nm]), gtol)
+    return sol
+
+
+def main():
+    print(torch.cuda.get_device_name(0), flush=True)
+    quick = "--quick" in sys.argv
+    for mfma in (False, True):
+        for (N, B) in ((6, 3), (33, 4), (64, 2), (65, 2), (130, 3), (501, 4)):
+            lu_check(N, B, torch.float32, mfma)
+        lu_check(501, 4, torch.float32, mfma, "kkt")
+    lu_check(40, 3, torch.float64, False)
+    lu_check(200, 2, torch.float64, False)
+    lu_check(501, 2, torch.float64, False, "kkt")
+    lu_check(1001, 2, torch.float32, True, "kkt")
+    kkt_check()
+
+    g = load_golden("g1_b32_n10_box")
+    fwd_check("G1 n10 box", (g["Q"], g["p"], None, None, g["lb"], g["ub"]), O.make_control(**TOL), g,
+              ("x", "z", "u", "lams"), 2e-5)
+    g = load_golden("g2_b8_n50_eq")
+    gg = {k[:-5]: v for k, v in g.items() if k.endswith("_rand")}
+    fwd_check("G2 n50 eq", tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")), O.make_control(**TOL), g,
+              ("x", "z", "u", "lams", "nus"), 2e-5, g["g_rand"], gg)
+    g8 = load_golden("g8_b8_n50_eq_f64")
+    gg = {k[:-5]: v for k, v in g8.items() if k.endswith("_rand")}
+    fwd_check("G8 n50 f64", tuple(g[k].double() for k in ("Q", "p", "A", "b", "lb", "ub")), O.make_control(**TOL), g8,
+              ("x", "z", "u", "lams", "nus"), 1e-9, g["g_rand"].double(), gg, 1e-7)
+    for tag in ("noscale", "scale"):
+        g = load_golden(f"g6_adaptive_{tag}")
+        gg = {k: g[k] for k in ("dQ", "dp", "dA", "db", "dlb", "dub")}
+        fwd_check(f"G6 adaptive {tag}", tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")),
+                  O.make_control(rho=100.0, scale=(tag == "scale"), **TOL), g, ("x", "z", "u", "lams", "nus", "rho"),
+                  5e-5, g["g"], gg, 2e-3)
+    g = load_golden("g10_scalar_rho")
+    ga = {k[2:]: v for k, v in g.items() if k.startswith("a_")}
+    fwd_check("G10a rho=1e-3 adaptive", tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")),
+              O.make_control(rho=0.001, **TOL), ga, ("x", "u", "lams", "nus", "rho"), 5e-5)
+    g = load_golden("g11_hard_f64")
+    Qh = O.create_hard_qp_data(100, 0.85, list(range(8)))
+    gg = {k: g[k] for k in ("dQ", "dp", "dA", "db", "dlb", "dub")}
+    fwd_check("G11 hard f64", Qh, O.make_control(**TOL), g, ("x", "z", "u", "lams", "nus", "rho"), 1e-7, g["g"], gg, 1e-5)
+    g = load_golden("g3_b128_n100_box")
+    Q, p, _, _, lb, ub = O.create_qp_data(100, 128, seed=0, with_eq=False)
+    fwd_check("G3 cfg2 n100", (Q, p, None, None, lb, ub), O.make_control(**TOL), g, ("x", "u"), 5e-5)
+    if not quick:
+        g = load_golden("g4_b128_n500_eq")
+        inp = O.create_qp_data(500, 128, seed=0)
+        gg = {k[:-5]: v for k, v in g.items() if k.endswith("_ones")}
+        fwd_check("G4 cfg3 n500", inp, O.make_control(**TOL), g, ("x", "u", "nus"), 5e-5,
+                  torch.ones(128, 500, 1), gg, 2e-3)
+        # timing
+        Q, p, A, b, lb, ub = to_dev(*inp)
+        ctl = L.box_qp_control(**TOL)
+        for _ in range(2):
+            sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, dict(ctl))
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(5):
+            sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, dict(ctl))
+        torch.cuda.synchronize()
+        tf = (time.time() - t) / 5
+        cot = torch.ones(128, 500, 1, device=dev)
+        t = time.time()
+        for _ in range(5):
+            gr = L.torch_solve_box_qp_grad(cot, sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
+        torch.cuda.synchronize()
+        tb = (time.time() - t) / 5
+        print(f"TIMING cfg3: fwd {tf * 1e3:.2f} ms  bwd {tb * 1e3:.2f} ms  -> {128 / (tf + tb):.0f} QPs/s", flush=True)
+    print("FAILED:" if FAILS else "ALL PASS", FAILS, flush=True)
+    return 1 if FAILS else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
