@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: QPs/sec forward+backward of the box-QP ADMM layer.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted
+on): batch=128 per GPU, dz=500, one equality constraint (A = ones), random
+box bounds, fp32, eps_abs = eps_rel = 1e-5, default box_qp_control
+(scale=True, adaptive_rho=True, rho=None); synthetic inputs drawn exactly like
+experiments/utils.py:41-61 of the reference, resident in HBM before timing.
+One step = SolveBoxQP forward + x.backward(ones) (experiments/experiment_1.py:
+69-78) on one batch, plus -- for N > 1 -- the single all-gather of x.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+B_PER_GPU, N_X, N_EQ = 128, 500, 1
+TOL = 1e-5
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="QPs per GPU")
+    ap.add_argument("--n", type=int, default=N_X)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(es, n, m, iters, n_check, n_refactor, scale=True):
+    """per-QP algorithmic bytes of forward / backward / the loop kernel alone."""
+    N = n + m
+    I = iters + 1
+    S = 1 if scale else 0
+    fwd = es * (2 * S * n * n + n * n + N * N + 2 * N * N + I * N * N + n_check * n * n
+                + n_refactor * (n * n + 3 * N * N))
+    bwd = es * (3 * n * n + 4 * N * N)
+    loop = es * (I * N * N + n_check * n * n)
+    return fwd, bwd, loop
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference, torch CPU) timed on this host."""
+    from oracle import boxqp_oracle as O
+    B, n = args.batch, args.n
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=0)
+    ctl = O.make_control(eps_abs=TOL, eps_rel=TOL)
+    ones = torch.ones(B, n, 1)
+
+    def once():
+        sol = O.solve_box_qp(Q, p, A, b, lb, ub, dict(ctl))
+        O.solve_box_qp_grad(ones, sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
+
+    once()
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_reps):
+        once()
+    dt = (time.perf_counter() - t0) / args.cpu_reps
+    return {"value": B / dt, "unit": "QPs/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{args.cpu_reps} x (forward+backward of one batch={B} dz={n} m=1 tol=1e-5), "
+                      f"{dt:.2f} s each, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import lqp_py_amd as L
+    from lqp_py_amd import _lib
+    from lqp_py_amd.dist import ShardedBoxQP
+    from oracle import boxqp_oracle as O        # data generator only (restated experiments/utils.py)
+
+    B, n, m = args.batch, args.n, N_EQ
+    # a few distinct batches (different seeds, like the reference's per-simulation data), HBM resident
+    n_sets = 3
+    data = []
+    for s in range(n_sets):
+        Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=1000 * rank + s)
+        data.append([t.to(dev) for t in (Q, p, A, b, lb, ub)])
+    ones = torch.ones(B, n, 1, device=dev)
+    control = L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, reduce='max')
+    layer = ShardedBoxQP(control) if world > 1 else None
+    qp = L.SolveBoxQP(control=control)
+    last = {}
+
+    def step(i):
+        Q, p, A, b, lb, ub = data[i % n_sets]
+        Q = Q.detach().requires_grad_(True)          # experiment_1 differentiates w.r.t. Q and p
+        p = p.detach().requires_grad_(True)
+        if world > 1:
+            x, x_all = layer(Q, p, A, b, lb, ub)
+        else:
+            x = qp(Q, p, A, b, lb, ub)
+        x.backward(ones)
+        last["x"] = x
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    _lib.profile(enable=True, reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile()
+    _lib.profile(enable=False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B / (dt / args.steps)
+
+    # ---- roofline of the dominant kernel (the persistent / segmented ADMM loop) ----
+    Q, p, A, b, lb, ub = data[0]
+    sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, dict(control))
+    st = sol["_stats"]
+    es = 4
+    fwd_b, bwd_b, loop_b = algorithmic_bytes(es, n, m, st["iters"], st["n_check"], st["n_factor"] - 1)
+    loop_ms, loop_launches = prof["admm_loop"]
+    solves = args.steps
+    loop_ms_per_solve = loop_ms / max(solves, 1)
+    achieved = (loop_b * B) / (loop_ms_per_solve * 1e-3) / 1e9 if loop_ms_per_solve > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_admm_loop", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "per": "one forward solve of one batch (all loop launches of the solve summed)",
+                "algorithmic_bytes": loop_b * B, "ms": round(loop_ms_per_solve, 4),
+                "launches_per_solve": loop_launches / max(solves, 1),
+                "whole_step_frac_of_hbm_roofline": round(((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)}
+    breakdown = {k: round(v[0] / max(solves, 1), 4) for k, v in prof.items() if v[1]}
+
+    out = {"metric": "QPs/sec forward+backward, batch=128 dz=500 tol=1e-5", "value": round(value, 1),
+           "unit": "QPs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[2]: batch={B}/GPU dz={n} m={m} box+equality QP, "
+                                  "ADMM forward + fixed-point backward, eps 1e-5, scale+adaptive_rho defaults",
+                      "global_batch": world * B, "iters": st["iters"], "checks": st["n_check"],
+                      "launch_mode": st["mode_used"], "parallelism": f"batch-sharded x{world}"},
+           "roofline": roofline, "kernel_ms_per_step": breakdown}
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

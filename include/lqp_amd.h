@@ -84,6 +84,20 @@ typedef struct lqp_boxqp_stats {
 int lqp_abi_version(void);
 const char* lqp_status_string(int status);
 
+/* ---- measurement hooks (not part of the reference surface) ----------------
+ * When enabled, every kernel launch issued by this library is bracketed by a
+ * pair of HIP events recorded on the launch stream; lqp_profile_get waits for
+ * them and returns, per kernel class, the summed device time in ms and the
+ * launch count since the last reset.  bench.py uses this for the roofline. */
+void lqp_profile_enable(int on);
+void lqp_profile_reset(void);
+int lqp_profile_classes(void);
+const char* lqp_profile_class_name(int cls);
+int lqp_profile_get(double* total_ms, long long* launches, int n);
+/* debug: device buffer of 4 uint64 per problem; every LU launch then writes its shader-clock
+ * cycles spent in (panel, swaps+U12, trailing update, total).  NULL switches it off. */
+void lqp_debug_set_lu_counters(void* device_buf);
+
 /* ---- forward ADMM solve ------------------------------------------------
  * Replaces torch_solve_box_qp (lqp_py/solve_box_qp_admm_torch.py:108-333):
  * scaling :160-197, rho :199-203, KKT assembly + LU :205-215, the hot loop

@@ -42,6 +42,12 @@ _P = c_void_p
 SYMBOLS = {
     "lqp_abi_version": (c_int, []),
     "lqp_status_string": (ctypes.c_char_p, [c_int]),
+    "lqp_profile_enable": (None, [c_int]),
+    "lqp_profile_reset": (None, []),
+    "lqp_profile_classes": (c_int, []),
+    "lqp_profile_class_name": (ctypes.c_char_p, [c_int]),
+    "lqp_profile_get": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_longlong), c_int]),
+    "lqp_debug_set_lu_counters": (None, [_P]),
     "lqp_boxqp_forward_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                   ctypes.POINTER(BoxQPCtrl), _P, _P, _P, _P, _P, _P, _P,
@@ -74,6 +80,8 @@ def build_library(force=False, verbose=False):
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-mllvm", "-pragma-unroll-threshold=200000",      # the 32-column panel loops must fully unroll
+           "-fno-slp-vectorize",     # SLP packing of f32 ops (v_pk_*) blows up register pressure in the LU panel
            "-o", LIB_PATH, os.path.join(CSRC, "lqp_amd.hip")]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -99,6 +107,21 @@ def load():
             raise RuntimeError("lqp_py_amd: ABI version mismatch")
         _lib = lib
         return lib
+
+
+def profile(enable=None, reset=False):
+    """Per-kernel-class device times (ms) and launch counts since the last reset."""
+    lib = load()
+    if reset:
+        lib.lqp_profile_reset()
+    if enable is not None:
+        lib.lqp_profile_enable(1 if enable else 0)
+        return None
+    n = lib.lqp_profile_classes()
+    ms = (c_double * n)()
+    cnt = (ctypes.c_longlong * n)()
+    check(lib.lqp_profile_get(ms, cnt, n), "profile_get")
+    return {lib.lqp_profile_class_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
 
 
 def check(status, what, extra=""):

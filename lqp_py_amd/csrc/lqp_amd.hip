@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <mutex>
 #include <vector>
+#include <string>
 #include <unordered_map>
 
 using namespace lqp;
@@ -53,10 +54,39 @@ int ensure_lds(const void* fn, int bytes) {
     return LQP_OK;
 }
 
+// ---- optional per-kernel-class timing with HIP events on the launch stream ----
+enum { PC_SETUP = 0, PC_LU, PC_PACK, PC_LOOP, PC_RHO, PC_EPILOGUE, PC_BWD_BUILD, PC_SOLVE, PC_BWD_EPILOGUE,
+       PC_MISC, PC_COUNT };
+struct ProfRec { int cls; hipEvent_t a, b; };
+std::mutex g_prof_mutex;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+double g_prof_ms[PC_COUNT];
+long long g_prof_n[PC_COUNT];
+
+struct ProfScope {
+    hipStream_t st; int cls; bool on; hipEvent_t a, b;
+    ProfScope(hipStream_t s, int c) : st(s), cls(c), on(g_prof_on) {
+        if (on) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            hipEventRecord(a, st);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            hipEventRecord(b, st);
+            std::lock_guard<std::mutex> lock(g_prof_mutex);
+            g_prof_recs.push_back({cls, a, b});
+        }
+    }
+};
+
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return s ? atoi(s) : dflt;
 }
+
+unsigned long long* g_lu_dbg = nullptr;     // optional device buffer (4 counters per problem), debug only
 
 // ---- LU launch: pick panel width / trailing-update flavour --------------------
 template <typename T, int PB, bool MFMA>
@@ -66,13 +96,16 @@ int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, i
     auto fn = k_lu_factor<T, PB, MFMA>;
     int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate);
+    { ProfScope ps(st, PC_LU);
+      hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, g_lu_dbg); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate) {
-    const int pb = lu_panel_width<float>(N);
+    int pb = lu_panel_width<float>(N);
+    const int want = env_int("LQP_LU_PB", 0);            // experiments: force a narrower panel
+    if (want == 8 || want == 16 || want == 32) pb = std::min(pb, want);
     const bool mfma = env_int("LQP_LU_MFMA", 1) != 0;
     if (pb == 32) return mfma ? launch_lu_impl<float, 32, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate)
                               : launch_lu_impl<float, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
@@ -97,6 +130,7 @@ int launch_pack(hipStream_t st, int B, const T* LU, int N, int ld, size_t mstrid
     int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
     const bool vec_ok = (ld % 4 == 0) && (mstride % 4 == 0) && (((uintptr_t)LU) % (4 * sizeof(T)) == 0);
+    ProfScope ps(st, PC_PACK);
     hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, LU, N, ld, mstride, piv, pstride, packed,
                        packed_blocks(K) * LQP_BLK, dest, K * LQP_NB, vec_ok ? 1 : 0, gate);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
@@ -110,6 +144,7 @@ int launch_solve(hipStream_t st, int B, const T* packed, int N, const int* dest,
     auto fn = k_packed_solve<T>;
     int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
+    ProfScope ps(st, PC_SOLVE);
     hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, packed, N, Np, K, dest, rhs, nrhs, bstride, rstride, cstride);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
@@ -187,6 +222,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         auto fn = k_fwd_setup<T>;
         int rc = ensure_lds((const void*)fn, lds);
         if (rc) return rc;
+        ProfScope ps(st, PC_SETUP);
         hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
         ++n_launch;
     }
@@ -222,11 +258,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     int fail_index = -1;
     while (it < max_iters && !done) {
         int in_chunk = 0;
-        while (it < max_iters && in_chunk < chunk_cap) {
+        const int cap_now = (mode == 2) ? 1 : chunk_cap;       // persistent: the kernel itself stops at convergence
+        while (it < max_iters && in_chunk < cap_now) {
             // adaptive-rho event at the start of iteration `it` (:237)
             if (ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter) {
                 const int last_slot = ((it - 1) / check) % kRing;
-                hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot);
+                { ProfScope ps(st, PC_RHO);
+                  hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
                 rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, P.status + ST_GATE);
                 if (rc) return rc;
                 rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest,
@@ -254,17 +292,19 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             }
             const int ctr_base = (int)(c_first % kRing);
             const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
-            hipLaunchKernelGGL(loop_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, ctr_base, prev_slot,
-                               mode == 2 ? 1 : 0);
+            { ProfScope ps(st, PC_LOOP);
+              hipLaunchKernelGGL(loop_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, ctr_base, prev_slot,
+                                 mode == 2 ? 1 : 0); }
             ++n_launch;
             ++in_chunk;
             it = e;
         }
         // ---- close the chunk: did the last check stop the loop? ----
         if (it > 0 && ((it - 1) % check) == 0) {
-            // trailing no-op launch evaluates the early-exit test for the last check
+            // did the last check of this chunk stop the loop?  (tiny kernel, own name in traces)
             const int prev_slot = ((it - 1) / check) % kRing;
-            hipLaunchKernelGGL(loop_fn, dim3(1), dim3(LQP_NT), loop_lds, st, P, it, it, 0, prev_slot, 0);
+            ProfScope ps(st, PC_MISC);
+            hipLaunchKernelGGL(k_check_done, dim3(1), dim3(64), 0, st, P.status, P.counters, prev_slot, it - 1);
             ++n_launch;
         }
         HIP_OK(hipMemcpyAsync(h_status, P.status, sizeof(h_status), hipMemcpyDeviceToHost, st));
@@ -285,7 +325,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     }
     const int final_iter = done ? h_status[ST_FINAL_ITER] : max_iters - 1;
 
-    hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P);
+    { ProfScope ps(st, PC_EPILOGUE);
+      hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P); }
     ++n_launch;
     if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
     if (stats) {
@@ -331,7 +372,8 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     P.Q = (const T*)Q; P.A = (const T*)A; P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in;
     P.rho_value = (T)rho_value; P.rho_mode = rho_mode;
     P.dQ = (T*)dQ; P.dp = (T*)dp; P.dA = (T*)dA; P.db = (T*)db; P.dlb = (T*)dlb; P.dub = (T*)dub;
-    hipLaunchKernelGGL(k_bwd_build<T>, dim3(B), dim3(LQP_NT), 0, st, P);
+    { ProfScope ps(st, PC_BWD_BUILD);
+      hipLaunchKernelGGL(k_bwd_build<T>, dim3(B), dim3(LQP_NT), 0, st, P); }
     int rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr);
     if (rc) return rc;
     rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr);
@@ -343,6 +385,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         auto fn = k_bwd_epilogue<T>;
         rc = ensure_lds((const void*)fn, lds);
         if (rc) return rc;
+        ProfScope ps(st, PC_BWD_EPILOGUE);
         hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
     }
     if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
@@ -457,6 +500,43 @@ bool bad_dims(int dtype, int B, int n, int m) {
 extern "C" {
 
 int lqp_abi_version(void) { return LQP_ABI_VERSION; }
+
+void lqp_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_on = on != 0;
+}
+
+void lqp_profile_reset(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    for (auto& r : g_prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    g_prof_recs.clear();
+    for (int i = 0; i < PC_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; }
+}
+
+void lqp_debug_set_lu_counters(void* device_buf) { g_lu_dbg = (unsigned long long*)device_buf; }
+
+int lqp_profile_classes(void) { return PC_COUNT; }
+
+const char* lqp_profile_class_name(int c) {
+    static const char* names[PC_COUNT] = {"fwd_setup", "lu_factor", "pack", "admm_loop", "rho_update", "fwd_epilogue",
+                                          "bwd_build", "packed_solve", "bwd_epilogue", "misc"};
+    return (c >= 0 && c < PC_COUNT) ? names[c] : "?";
+}
+
+int lqp_profile_get(double* total_ms, long long* launches, int n) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    for (auto& r : g_prof_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return LQP_ERR_HIP;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return LQP_ERR_HIP;
+        g_prof_ms[r.cls] += ms;
+        g_prof_n[r.cls] += 1;
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    g_prof_recs.clear();
+    for (int i = 0; i < n && i < PC_COUNT; ++i) { total_ms[i] = g_prof_ms[i]; launches[i] = g_prof_n[i]; }
+    return LQP_OK;
+}
 
 const char* lqp_status_string(int s) {
     switch (s) {

@@ -54,20 +54,44 @@ __host__ __device__ inline size_t vec_stride(int n, int m) { return (size_t)roun
 // LDS: red[NW * n] | d[n] | sel[8] | scratch[NW]
 // ---------------------------------------------------------------------------
 template <typename T> __host__ __device__ inline int setup_lds_bytes(int n) {
-    return (LQP_NW * n + n + 8 + LQP_NW + 8) * (int)sizeof(T);
+    return (round_up(LQP_NW * n, 8) + round_up(n, 8) + 8 + LQP_NW + 8) * (int)sizeof(T);
 }
 
+// M = [[Qs + rho I, As^T], [As, 0]]  (solve_box_qp_admm_torch.py:206-212, 252).
+// copy_q == false: the top-left block already holds Qs (written by the scaling pass), only
+// rho is added on the diagonal.
 template <typename T>
-__device__ void assemble_kkt_rows(const FwdParams<T>& P, const int b, const T* __restrict__ Qs, const int ldq,
-                                  const VecView<T>& V, const T rho) {
-    // M = [[Qs + rho I, As^T], [As, 0]]  (solve_box_qp_admm_torch.py:206-212, 252)
+__device__ __forceinline__ void assemble_kkt_rows(const FwdParams<T>& P, const int b, const T* __restrict__ Qs, const int ldq,
+                                                  const VecView<T>& V, const T rho, const bool copy_q) {
     const int n = P.n, m = P.m, Np = P.Np;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     T* M = P.M + (size_t)b * Np * Np;
+    typedef V4<T> vec;
+    const bool vec_ok = (ldq % 4 == 0) && ((((uintptr_t)Qs) % sizeof(vec)) == 0);
+    if (copy_q) {
+        for (int i = w; i < n; i += LQP_NW) {
+            const T* q = Qs + (size_t)i * ldq;
+            T* mr = M + (size_t)i * Np;
+            if (vec_ok) {
+                for (int j = lane * 4; j < n; j += 256) {
+                    if (j + 3 < n) {
+                        vec v = *(const vec*)(q + j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (j + e == i) v.v[e] += rho;
+                        *(vec*)(mr + j) = v;
+                    } else {
+                        for (int e = 0; e < 4 && j + e < n; ++e) mr[j + e] = q[j + e] + (i == j + e ? rho : T(0));
+                    }
+                }
+            } else {
+                for (int j = lane; j < n; j += 64) mr[j] = q[j] + (i == j ? rho : T(0));
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += LQP_NT) M[(size_t)i * Np + i] += rho;
+    }
     for (int i = w; i < n; i += LQP_NW) {
-        const T* q = Qs + (size_t)i * ldq;
         T* mr = M + (size_t)i * Np;
-        for (int j = lane; j < n; j += 64) mr[j] = q[j] + (i == j ? rho : T(0));
         for (int r = lane; r < m; r += 64) mr[n + r] = V.As[(size_t)r * n + i];
     }
     for (int r = w; r < m; r += LQP_NW) {
@@ -83,8 +107,8 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     T* red = (T*)smem;
-    T* d = red + (size_t)LQP_NW * n;
-    T* sel = d + n;
+    T* d = red + (size_t)round_up(LQP_NW * n, 8);
+    T* sel = d + round_up(n, 8);
     T* scratch = sel + 8;
     const T* Q = P.Q + (size_t)b * n * n;
     const T* p = P.p + (size_t)b * n;
@@ -101,23 +125,54 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     const T* Qs = Q;
     int ldq = n;
     T fro2 = T(0);
+    bool q_in_m = false;          // top-left KKT block already written by the scaling pass
     if (P.scale) {
-        // ---- column max of |Q| (:163) ----
-        T cm[16];
+        // ---- column max of |Q| (:163): wave w sweeps rows w, w+16, ...; 16 B per lane per load ----
+        const bool qvec = (n % 4 == 0) && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
+        if (qvec) {
+            T cm[4][4];                                   // up to 4 column quads per lane (n <= 1024)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) cm[q] = T(0);
-        for (int i = w; i < n; i += LQP_NW) {
-            const T* qr = Q + (size_t)i * n;
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cm[q][e] = T(0);
+#pragma unroll 4
+            for (int i = w; i < n; i += LQP_NW) {
+                const T* qr = Q + (size_t)i * n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = (lane + 64 * q) * 4;
+                    if (j < n) {
+                        const V4<T> v = *(const V4<T>*)(qr + j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cm[q][e] = tmax(cm[q][e], tabs(v.v[e]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = (lane + 64 * q) * 4;
+                if (j < n) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red[(size_t)w * n + j + e] = cm[q][e];
+                }
+            }
+        } else {
+            T cm[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cm[q] = T(0);
+            for (int i = w; i < n; i += LQP_NW) {
+                const T* qr = Q + (size_t)i * n;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int j = lane + 64 * q;
+                    if (j < n) cm[q] = tmax(cm[q], tabs(qr[j]));
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int j = lane + 64 * q;
-                if (j < n) cm[q] = tmax(cm[q], tabs(qr[j]));
+                if (j < n) red[(size_t)w * n + j] = cm[q];
             }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int j = lane + 64 * q;
-            if (j < n) red[(size_t)w * n + j] = cm[q];
         }
         __syncthreads();
         T part = T(0);
@@ -172,19 +227,41 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             V.D[j] = v;
         }
         __syncthreads();
-        // ---- Qs = (D_i Q_ij) D_j and its Frobenius norm (:176, :201) ----
+        // ---- Qs = (D_i Q_ij) D_j, its Frobenius norm (:176, :201), and the top-left KKT block ----
         ldq = P.ldq;
         T* Qw = P.Qs + (size_t)b * n * ldq;
-        for (int i = w; i < n; i += LQP_NW) {
-            const T* qr = Q + (size_t)i * n;
-            T* qo = Qw + (size_t)i * ldq;
-            const T di = d[i];
-            for (int j = lane; j < n; j += 64) {
-                const T v = (di * qr[j]) * d[j];
-                qo[j] = v;
-                fro2 += v * v;
+        T* Mw = P.M + (size_t)b * Np * Np;
+        if (qvec) {
+#pragma unroll 2
+            for (int i = w; i < n; i += LQP_NW) {
+                const T* qr = Q + (size_t)i * n;
+                T* qo = Qw + (size_t)i * ldq;
+                T* mo = Mw + (size_t)i * Np;
+                const T di = d[i];
+                for (int j = lane * 4; j < n; j += 256) {
+                    V4<T> v = *(const V4<T>*)(qr + j);
+                    const V4<T> dj = *(const V4<T>*)(d + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v.v[e] = (di * v.v[e]) * dj.v[e]; fro2 += v.v[e] * v.v[e]; }
+                    *(V4<T>*)(qo + j) = v;
+                    *(V4<T>*)(mo + j) = v;
+                }
+            }
+        } else {
+            for (int i = w; i < n; i += LQP_NW) {
+                const T* qr = Q + (size_t)i * n;
+                T* qo = Qw + (size_t)i * ldq;
+                T* mo = Mw + (size_t)i * Np;
+                const T di = d[i];
+                for (int j = lane; j < n; j += 64) {
+                    const T v = (di * qr[j]) * d[j];
+                    qo[j] = v;
+                    mo[j] = v;
+                    fro2 += v * v;
+                }
             }
         }
+        q_in_m = true;
         Qs = Qw;
         for (int i = tid; i < n; i += LQP_NT) V.ps[i] = d[i] * p[i];       // (:177)
     } else {
@@ -253,7 +330,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     }
     for (int r = tid; r < m; r += LQP_NT) V.nu[r] = T(0);
     __syncthreads();
-    assemble_kkt_rows(P, b, Qs, ldq, V, rho);
+    assemble_kkt_rows(P, b, Qs, ldq, V, rho, !q_in_m);
 }
 
 // ---------------------------------------------------------------------------
@@ -263,13 +340,15 @@ template <typename T, int PB, bool MFMA>
 __global__ __launch_bounds__(LQP_NT) void k_lu_factor(T* __restrict__ Mall, const int N, const int ld,
                                                       const size_t mstride, int* __restrict__ piv,
                                                       const int pstride, int* __restrict__ info,
-                                                      const int* __restrict__ gate) {
+                                                      const int* __restrict__ gate,
+                                                      unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x;
     if (threadIdx.x == 0) info[b] = 0;
     __syncthreads();
-    wg_lu_factor<T, PB, MFMA>(Mall + (size_t)b * mstride, N, ld, piv + (size_t)b * pstride, info + b, smem);
+    wg_lu_factor<T, PB, MFMA>(Mall + (size_t)b * mstride, N, ld, piv + (size_t)b * pstride, info + b, smem,
+                              dbg ? dbg + (size_t)b * 4 : nullptr);
 }
 
 template <typename T>
@@ -486,6 +565,14 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
     for (int r = tid; r < m; r += LQP_NT) V.nu[r] = v[n + r];
 }
 
+// all problems optimal at the check held in `slot` (iteration `it_check`)?  -> DONE
+__global__ void k_check_done(int* status, const unsigned int* counters, const int slot, const int it_check) {
+    if (threadIdx.x == 0 && status[ST_DONE] == 0 && counters[(size_t)slot * CT_WORDS + CT_NOTOPT] == 0) {
+        status[ST_FINAL_ITER] = it_check;
+        status[ST_DONE] = 1;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // adaptive rho (:237-256): global decision from the counters of the last
 // check, masked per-problem update, KKT re-assembly; sets the gate for the
@@ -514,7 +601,7 @@ __global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, con
     __syncthreads();
     if (threadIdx.x == 0) scal[SC_RHO] = rho;
     const T* Qs = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
-    assemble_kkt_rows(P, b, Qs, P.scale ? P.ldq : n, V, rho);
+    assemble_kkt_rows(P, b, Qs, P.scale ? P.ldq : n, V, rho, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -570,15 +657,30 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build(const BwdParams<T> P) {
     T* M = P.M + (size_t)b * Np * Np;
     T* rhs = P.rhs + (size_t)b * Np;
     if (tid == 0) P.info[b] = 0;
+    const bool qvec = (n % 4 == 0) && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
+#pragma unroll 2
     for (int i = w; i < n; i += LQP_NW) {
         const T s = x[i] + u[i];
         const T keep = (s > ub[i] || s < lb[i]) ? T(0) : T(1);
         const T* qr = Q + (size_t)i * n;
         T* mr = M + (size_t)i * Np;
-        for (int j = lane; j < n; j += 64) {
-            T val = keep * qr[j];
-            if (j == i) val = (val + rho * (T(1) - keep)) + T(1e-8);
-            mr[j] = val;
+        if (qvec) {
+            for (int j = lane * 4; j < n; j += 256) {
+                V4<T> v = *(const V4<T>*)(qr + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    T val = keep * v.v[e];
+                    if (j + e == i) val = (val + rho * (T(1) - keep)) + T(1e-8);
+                    v.v[e] = val;
+                }
+                *(V4<T>*)(mr + j) = v;
+            }
+        } else {
+            for (int j = lane; j < n; j += 64) {
+                T val = keep * qr[j];
+                if (j == i) val = (val + rho * (T(1) - keep)) + T(1e-8);
+                mr[j] = val;
+            }
         }
         for (int r = lane; r < m; r += 64) mr[n + r] = keep * A[(size_t)r * n + i];
         if (lane == 0) rhs[i] = -(g[i] * keep);

@@ -5,14 +5,16 @@
 //
 // Right-looking, panel width PB:
 //   1. panel  : thread r keeps row k0+r of the panel in registers; per column
-//               a wave max-|.| search (first index wins ties, as isamax),
-//               the pivot row is broadcast through LDS, rank-1 update in regs;
+//               a wave max-|.| search (DPP inside 16-lane rows; first index
+//               wins ties, as isamax), the pivot row is broadcast through
+//               LDS, rank-1 update in registers;
 //   2. swaps  : the PB row interchanges are composed into one gather map and
 //               applied to the columns left and right of the panel, one
-//               thread per column (all loads before all stores);
+//               thread per column;
 //   3. U12    : the same threads solve L11 * U12 = (P A)12 in registers;
-//   4. update : A22 -= L21 * U12 with L21^T and U12 staged in LDS
-//               (8x4 register tiles, or MFMA 32x32x2 f32 tiles).
+//   4. update : A22 -= L21 * U12 with L21^T and U12 staged in LDS: MFMA
+//               32x32x2 f32 tiles (C tile prefetched one tile ahead and used
+//               as the accumulator: D = C - L21 U12), or 8x4 VALU tiles.
 #pragma once
 #include "lqp_common.cuh"
 
@@ -20,16 +22,18 @@ namespace lqp {
 
 template <typename T, int PB> struct LuLds {
     // byte offsets inside the dynamic LDS block, all multiples of 32
-    int lt, up, l11, rowp, rowj, wval, widx, pidx, src, xdst, xsrc, cnt, total;
+    int lt, up, l11, rowp, rowj, wval, wrcp, widx, wtid, pidx, src, xdst, xsrc, cnt, total;
     __host__ __device__ explicit LuLds(int Mpad) {
         int o = 0;
         lt = o;   o += PB * Mpad * (int)sizeof(T);
         up = o;   o += PB * Mpad * (int)sizeof(T);
         l11 = o;  o += round_up(PB * (PB + 1) * (int)sizeof(T), 32);
-        rowp = o; o += round_up(PB * (int)sizeof(T), 32);
-        rowj = o; o += round_up(PB * (int)sizeof(T), 32);
-        wval = o; o += round_up(LQP_NW * (int)sizeof(T), 32);
-        widx = o; o += round_up(LQP_NW * 4, 32);
+        rowp = o; o += 2 * LQP_NW * PB * (int)sizeof(T);       // candidate pivot rows [parity][wave][PB]
+        rowj = o; o += round_up(2 * PB * (int)sizeof(T), 32);  // row at the diagonal position [parity][PB]
+        wval = o; o += round_up(2 * LQP_NW * (int)sizeof(T), 32);
+        wrcp = o; o += round_up(2 * LQP_NW * (int)sizeof(T), 32);
+        widx = o; o += round_up(2 * LQP_NW * 4, 32);
+        wtid = o; o += round_up(2 * LQP_NW * 4, 32);
         pidx = o; o += round_up(PB * 4, 32);
         src = o;  o += Mpad * 4;
         xdst = o; o += round_up(PB * 4, 32);
@@ -38,6 +42,38 @@ template <typename T, int PB> struct LuLds {
         total = o;
     }
 };
+
+// ---- wave-level arg-max without control flow --------------------------------
+__device__ __forceinline__ float readlane_t(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double readlane_t(double v, int l) {
+    long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T> __device__ __forceinline__ T row16_max(T m) {
+    m = tmax(m, dpp<0xB1>(m));
+    m = tmax(m, dpp<0x4E>(m));
+    m = tmax(m, dpp<0x124>(m));
+    m = tmax(m, dpp<0x128>(m));
+    return m;
+}
+__device__ __forceinline__ int row16_min_i32(int m) {
+    m = min(m, dpp_i32<0xB1>(m));
+    m = min(m, dpp_i32<0x4E>(m));
+    m = min(m, dpp_i32<0x124>(m));
+    m = min(m, dpp_i32<0x128>(m));
+    return m;
+}
+// max of `key` over the wave (wave-uniform) and the LOWEST lane that holds it: with keys
+// ordered by row this is isamax's "first index wins ties".
+template <typename T> __device__ __forceinline__ void wave_argmax(const T key, T& best, int& lane_of_best) {
+    const T m = row16_max(key);
+    best = tmax(tmax(readlane_t(m, 0), readlane_t(m, 16)), tmax(readlane_t(m, 32), readlane_t(m, 48)));
+    lane_of_best = __ffsll((unsigned long long)__ballot(key == best)) - 1;
+}
 
 // MFMA trailing update (f32 only): each wave owns 32x32 tiles of A22.
 // A operand (32x2 slice of L21): lane l holds L21[i = l&31][k = l>>5];
@@ -52,33 +88,54 @@ __device__ __forceinline__ void lu_trailing_mfma_f32(float* __restrict__ A22, co
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int nt = (M2 + 31) >> 5;
-    for (int t = w; t < nt * nt; t += LQP_NW) {
+    const int ntiles = nt * nt;
+    // lane part of every address (same for all 16 accumulator registers); the tile / register
+    // part is wave-uniform and stays in SGPRs
+    const int voff = 4 * lh * ld + li;
+    auto load_c = [&](int t, f32x16& c) {
+        const int ti = t / nt, tj = t - ti * nt;
+        const float* base = A22 + (size_t)(ti << 5) * ld + (tj << 5);
+        const bool colok = (tj << 5) + li < M2;
+        const int rlim = M2 - (ti << 5) - 4 * lh;          // valid iff qrow < rlim
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int qrow = (q & 3) + 8 * (q >> 2);
+            c[q] = (colok && qrow < rlim) ? base[(size_t)qrow * ld + voff] : 0.f;
+        }
+    };
+    for (int t = __builtin_amdgcn_readfirstlane(w); t < ntiles; t += LQP_NW) {
+        f32x16 cur;
+        load_c(t, cur);                         // in flight underneath the MFMA chain below
         const int ti = t / nt, tj = t - ti * nt;
         const int i0 = ti << 5, j0 = tj << 5;
+        const float* lt = LT + i0 + li + lh * Mpad;
+        const float* up = UP + j0 + li + lh * Mpad;
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < PB; kk += 2) {
-            const float a = LT[(kk + lh) * Mpad + i0 + li];
-            const float b = UP[(kk + lh) * Mpad + j0 + li];
+            const float a = lt[kk * Mpad];
+            const float b = up[kk * Mpad];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
-        const int col = j0 + li;
+        cur -= acc;
+        float* base = A22 + (size_t)i0 * ld + j0;
+        const bool colok = j0 + li < M2;
+        const int rlim = M2 - i0 - 4 * lh;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-            if (row < M2 && col < M2) {
-                float* p = A22 + (size_t)row * ld + col;
-                *p = *p - acc[q];
-            }
+            const int qrow = (q & 3) + 8 * (q >> 2);
+            if (colok && qrow < rlim) base[(size_t)qrow * ld + voff] = cur[q];
         }
     }
 }
 
+// dbg (optional): 4 cycle counters per workgroup: panel, swaps+U12, trailing update, total
 template <typename T, int PB, bool USE_MFMA>
-__device__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* __restrict__ ipiv,
-                             int* __restrict__ info, char* __restrict__ smem) {
+__device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* __restrict__ ipiv,
+                                             int* __restrict__ info, char* __restrict__ smem,
+                                             unsigned long long* __restrict__ dbg) {
     const int Mpad = round_up(N, 64);
     const LuLds<T, PB> L(Mpad);
     T* LT = (T*)(smem + L.lt);
@@ -87,7 +144,9 @@ __device__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* 
     T* rowP = (T*)(smem + L.rowp);
     T* rowJ = (T*)(smem + L.rowj);
     T* wval = (T*)(smem + L.wval);
+    T* wrcp = (T*)(smem + L.wrcp);
     int* widx = (int*)(smem + L.widx);
+    int* wtid = (int*)(smem + L.wtid);
     int* pidx = (int*)(smem + L.pidx);
     int* src = (int*)(smem + L.src);
     int* xdst = (int*)(smem + L.xdst);
@@ -96,6 +155,10 @@ __device__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* 
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     typedef V4<T> vec;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);     // first row handled by this wave
+    if (tid == 0) cnt[1] = 0;       // first zero pivot (1-based) seen by this factorisation, 0 = none
+    unsigned long long t_panel = 0, t_swap = 0, t_trail = 0, t0 = 0, t_begin = 0;
+    if (dbg) t_begin = clock64();
 
     for (int k0 = 0; k0 < N; k0 += PB) {
         const int pb = (N - k0 < PB) ? (N - k0) : PB;
@@ -103,137 +166,174 @@ __device__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* 
         const int M2 = M - pb;
         const int r = tid;
         const bool act = r < M;
-        T row[PB];
-        // ---- load this thread's panel row ----
-        if (pb == PB) {
-#pragma unroll
-            for (int c = 0; c < PB; c += 4) {
-                vec v;
-                if (act) v = *(const vec*)(A + (size_t)(k0 + r) * ld + k0 + c);
-                else { v.v[0] = v.v[1] = v.v[2] = v.v[3] = T(0); }
-                row[c] = v.v[0]; row[c + 1] = v.v[1]; row[c + 2] = v.v[2]; row[c + 3] = v.v[3];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < PB; ++c) row[c] = (act && c < pb) ? A[(size_t)(k0 + r) * ld + k0 + c] : T(0);
-        }
-        if (tid == 0) *cnt = 0;
-
-        // ---- unblocked panel factorisation, one column at a time ----
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            if (j < pb) {
-                T key = (act && r >= j) ? tabs(row[j]) : T(-1);
-                int idx = r;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const T ok = __shfl_xor(key, off);
-                    const int oi = __shfl_xor(idx, off);
-                    if (ok > key || (ok == key && oi < idx)) { key = ok; idx = oi; }
-                }
-                if (lane == 0) { wval[w] = key; widx[w] = idx; }
-                __syncthreads();
-                T best = wval[0];
-                int bi = widx[0];
-#pragma unroll
-                for (int i = 1; i < LQP_NW; ++i) {
-                    const T v = wval[i];
-                    const int ii = widx[i];
-                    if (v > best || (v == best && ii < bi)) { best = v; bi = ii; }
-                }
-                if (tid == 0) {
-                    ipiv[k0 + j] = k0 + bi + 1;
-                    pidx[j] = bi;
-                    if (!(best > T(0)) && *info == 0) *info = k0 + j + 1;
-                }
-                if (r == bi) {
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) rowP[c] = row[c];
-                }
-                if (r == j) {
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) rowJ[c] = row[c];
-                }
-                __syncthreads();
-                if (r == j) {
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) row[c] = rowP[c];
-                } else if (r == bi) {
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) row[c] = rowJ[c];
-                }
-                if (act && r > j) {
-                    const T pv = rowP[j];
-                    if (pv != T(0)) {
-                        const T l = row[j] * (T(1) / pv);
-                        row[j] = l;
-#pragma unroll
-                        for (int c = j + 1; c < PB; ++c) row[c] -= l * rowP[c];
-                    }
-                }
-            }
-        }
-
-        // ---- write the factored panel back; stage L11 and L21^T in LDS ----
-        if (act) {
+        if (dbg) t0 = clock64();
+        {
+            T row[PB];
+            int curpos = r;             // LAPACK position of this thread's row
+            bool done = !act;           // already a pivot row (or no row at all)
+            const bool wact = wbase < M;   // this wave holds rows of the panel (loop-invariant, wave-uniform)
+            // ---- load this thread's panel row ----
             if (pb == PB) {
 #pragma unroll
                 for (int c = 0; c < PB; c += 4) {
                     vec v;
-                    v.v[0] = row[c]; v.v[1] = row[c + 1]; v.v[2] = row[c + 2]; v.v[3] = row[c + 3];
-                    *(vec*)(A + (size_t)(k0 + r) * ld + k0 + c) = v;
+                    if (act) v = *(const vec*)(A + (size_t)(k0 + r) * ld + k0 + c);
+                    else { v.v[0] = v.v[1] = v.v[2] = v.v[3] = T(0); }
+                    row[c] = v.v[0]; row[c + 1] = v.v[1]; row[c + 2] = v.v[2]; row[c + 3] = v.v[3];
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < PB; ++c)
-                    if (c < pb) A[(size_t)(k0 + r) * ld + k0 + c] = row[c];
+                for (int c = 0; c < PB; ++c) row[c] = (act && c < pb) ? A[(size_t)(k0 + r) * ld + k0 + c] : T(0);
             }
-            if (r < pb) {
-#pragma unroll
-                for (int c = 0; c < PB; ++c) L11[r * (PB + 1) + c] = row[c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < PB; ++c) LT[c * Mpad + (r - pb)] = row[c];
-            }
-        }
-        // ---- compose the pb interchanges: where does original (relative) row r end up? ----
-        if (act) {
-            int pos = r;
+            if (tid == 0) *cnt = 0;
+
+            // ---- unblocked panel factorisation, one column at a time ----
+            // Rows never move between threads: thread r keeps the row it loaded, `curpos` is the
+            // position LAPACK's explicit interchanges would have moved that row to, `done` marks
+            // rows already used as pivots.  Per column: wave arg-max of |a_rj| over the live rows
+            // (ties: smallest position, as isamax), each wave's winner publishes its row, ONE
+            // barrier, cross-wave arg-max, rank-1 update against the broadcast pivot row.  The
+            // publish buffers alternate with the column parity, so column j+1 never overwrites
+            // what a slow wave still reads for column j.
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
                 if (j < pb) {
-                    const int pj = pidx[j];
-                    if (pos == j) pos = pj;
-                    else if (pos == pj) pos = j;
+                    const int par = j & 1;
+                    T* cand = rowP + par * (LQP_NW * PB);
+                    T* wv = wval + par * LQP_NW;
+                    int* wi = widx + par * LQP_NW;
+                    int* wt = wtid + par * LQP_NW;
+                    T* wr = wrcp + par * LQP_NW;
+                    if (wact) {
+                        const T key = done ? T(-1) : tabs(row[j]);
+                        const T myrcp = T(1) / row[j];       // independent of the arg-max chain; only the winner's is used
+                        T bw; int lb;
+                        wave_argmax(key, bw, lb);
+                        const unsigned long long tied = __ballot(key == bw);
+#ifndef LQP_NO_TIE
+                        if (__popcll(tied) > 1) {                            // rare: smallest position wins
+                            int cp = (key == bw) ? curpos : 0x7fffffff;
+                            cp = row16_min_i32(cp);
+                            cp = min(min(__builtin_amdgcn_readlane(cp, 0), __builtin_amdgcn_readlane(cp, 16)),
+                                     min(__builtin_amdgcn_readlane(cp, 32), __builtin_amdgcn_readlane(cp, 48)));
+                            lb = __ffsll((unsigned long long)__ballot(key == bw && curpos == cp)) - 1;
+                        }
+#endif
+                        if (lane == lb) {
+                            wv[w] = bw;
+                            wr[w] = myrcp;
+                            wi[w] = curpos;
+                            wt[w] = r;
+#pragma unroll
+                            for (int c = 0; c < PB; c += 4) {
+                                vec v; v.v[0] = row[c]; v.v[1] = row[c + 1]; v.v[2] = row[c + 2]; v.v[3] = row[c + 3];
+                                *(vec*)(cand + w * PB + c) = v;
+                            }
+                        }
+                    } else if (lane == 0) {
+                        wv[w] = T(-2);                                       // can never win
+                    }
+                    __syncthreads();
+                    if (wact) {
+                    // cross-wave arg-max: lane l looks at wave (l & 15)'s winner
+                    const T cv = wv[lane & 15];
+                    const int ci = wi[lane & 15];
+                    const int ct = wt[lane & 15];
+                    const T best = row16_max(cv);
+                    const unsigned long long tied = __ballot(cv == best) & 0xFFFFull;
+                    int ww = __ffsll(tied) - 1;
+#ifndef LQP_NO_TIE
+                    if (__popcll(tied) > 1) {
+                        const int cp = row16_min_i32((cv == best) ? ci : 0x7fffffff);
+                        ww = __ffsll((unsigned long long)__ballot(cv == best && ci == cp) & 0xFFFFull) - 1;
+                    }
+#endif
+                    const int pivpos = __builtin_amdgcn_readlane(ci, ww);    // pivot row's position before the swap
+                    const int bi = __builtin_amdgcn_readlane(ct, ww);        // thread that owns the pivot row
+                    const T* rowPc = cand + ww * PB;
+                    const T rinv = wr[ww];
+                    if (r == bi) {
+                        pidx[j] = pivpos;      // pivots / info go to global memory once per panel
+                        if (!(best > T(0)) && cnt[1] == 0) cnt[1] = k0 + j + 1;
+                        curpos = j;
+                        done = true;
+                    } else if (curpos == j) {
+                        curpos = pivpos;       // the row that sat on the diagonal takes the pivot's old place
+                    }
+                    if (!done) {
+                        if (best > T(0)) {                    // a zero pivot column is left untouched (as getf2)
+                            const T l = row[j] * rinv;
+                            row[j] = l;
+#pragma unroll
+                            for (int c = j + 1; c < PB; ++c) row[c] -= l * rowPc[c];
+                        }
+                    }
+                    }
                 }
             }
-            src[pos] = r;
+
+            // ---- write the factored panel back at its final position; stage L11 and L21^T in LDS ----
+            if (act) {
+                if (pb == PB) {
+#pragma unroll
+                    for (int c = 0; c < PB; c += 4) {
+                        vec v;
+                        v.v[0] = row[c]; v.v[1] = row[c + 1]; v.v[2] = row[c + 2]; v.v[3] = row[c + 3];
+                        *(vec*)(A + (size_t)(k0 + curpos) * ld + k0 + c) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < PB; ++c)
+                        if (c < pb) A[(size_t)(k0 + curpos) * ld + k0 + c] = row[c];
+                }
+                if (curpos < pb) {
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) L11[curpos * (PB + 1) + c] = row[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) LT[c * Mpad + (curpos - pb)] = row[c];
+                }
+                src[curpos] = r;                        // position -> original (relative) row
+                // a displaced top row that ended below the panel top (its source is always < pb)
+                if (curpos >= pb && curpos != r) {
+                    const int q = atomicAdd(cnt, 1);
+                    xdst[q] = curpos;
+                    xsrc[q] = r;
+                }
+            }
         }
         __syncthreads();
-        if (act && r >= pb && src[r] != r) {
-            const int q = atomicAdd(cnt, 1);
-            xdst[q] = r;
-            xsrc[q] = src[r];
-        }
-        __syncthreads();
-        const int ne = *cnt;
+        if (tid < pb) ipiv[k0 + tid] = k0 + pidx[tid] + 1;
+        if (dbg) { const unsigned long long t1 = clock64(); t_panel += t1 - t0; t0 = t1; }
+        const int ne = __builtin_amdgcn_readfirstlane(*cnt);
         bool anyswap = ne > 0;
 #pragma unroll
         for (int j = 0; j < PB; ++j)
-            if (j < pb && src[j] != j) anyswap = true;
+            if (j < pb && __builtin_amdgcn_readfirstlane(src[j]) != j) anyswap = true;
 
         // ---- apply the interchanges left and right of the panel; U12 = L11^-1 (PA)12 ----
         if (tid < N - pb) {
             const bool right = tid >= k0;
             const int col = right ? tid + pb : tid;
             if (right || anyswap) {
-                T top[PB], ext[PB];
+                T* Ac = A + (size_t)k0 * ld + col;
+                T top[PB];
+                // (1) new top rows: sources anywhere in the panel rows
 #pragma unroll
                 for (int j = 0; j < PB; ++j)
-                    top[j] = (j < pb) ? A[(size_t)(k0 + src[j]) * ld + col] : T(0);
+                    top[j] = (j < pb) ? Ac[(size_t)__builtin_amdgcn_readfirstlane(src[j]) * ld] : T(0);
+                // (2) displaced top rows go down, 8 at a time (their sources are original
+                //     top rows, which are only overwritten in step (4))
+                for (int q0 = 0; q0 < ne; q0 += 8) {
+                    T ext[8];
 #pragma unroll
-                for (int q = 0; q < PB; ++q)
-                    ext[q] = (q < ne) ? A[(size_t)(k0 + xsrc[q]) * ld + col] : T(0);
+                    for (int q = 0; q < 8; ++q)
+                        ext[q] = (q0 + q < ne) ? Ac[(size_t)__builtin_amdgcn_readfirstlane(xsrc[q0 + q]) * ld] : T(0);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q0 + q < ne) Ac[(size_t)__builtin_amdgcn_readfirstlane(xdst[q0 + q]) * ld] = ext[q];
+                }
+                // (3) U12 column: forward substitution with the unit-lower L11
                 if (right) {
 #pragma unroll
                     for (int j = 0; j < PB; ++j) {
@@ -243,15 +343,14 @@ __device__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* 
 #pragma unroll
                     for (int j = 0; j < PB; ++j) UP[j * Mpad + (col - k0 - pb)] = top[j];
                 }
+                // (4) store the new top rows
 #pragma unroll
                 for (int j = 0; j < PB; ++j)
-                    if (j < pb && (right || src[j] != j)) A[(size_t)(k0 + j) * ld + col] = top[j];
-#pragma unroll
-                for (int q = 0; q < PB; ++q)
-                    if (q < ne) A[(size_t)(k0 + xdst[q]) * ld + col] = ext[q];
+                    if (j < pb && (right || __builtin_amdgcn_readfirstlane(src[j]) != j)) Ac[(size_t)j * ld] = top[j];
             }
         }
         __syncthreads();
+        if (dbg) { const unsigned long long t1 = clock64(); t_swap += t1 - t0; t0 = t1; }
 
         // ---- trailing update A22 -= L21 * U12 ----
         if (M2 > 0) {
@@ -302,6 +401,11 @@ __device__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* 
             }
         }
         __syncthreads();
+        if (dbg) { const unsigned long long t1 = clock64(); t_trail += t1 - t0; }
+    }
+    if (tid == 0 && cnt[1] != 0) *info = cnt[1];
+    if (dbg && tid == 0) {
+        dbg[0] = t_panel; dbg[1] = t_swap; dbg[2] = t_trail; dbg[3] = clock64() - t_begin;
     }
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ V4<T> load_padded4(const T* __restrict__ LU, const in
 }
 
 template <typename T>
-__device__ void wg_pack_factor(const T* __restrict__ LU, const int N, const int ld,
+__device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const int N, const int ld,
                                const int* __restrict__ ipiv, T* __restrict__ packed,
                                int* __restrict__ dest, char* __restrict__ smem, const bool vec_ok) {
     const int K = round_up(N, LQP_NB) / LQP_NB;

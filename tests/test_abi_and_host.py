@@ -1,0 +1,82 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol that
+include/lqp_amd.h declares, the control-dict resolution mirrors the reference's
+traps, and the product path refuses CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import lqp_py_amd as L
+from lqp_py_amd import _lib
+from lqp_py_amd.solve_box_qp_admm_torch import resolve_control
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(REPO, "include", "lqp_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lqp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build_library()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/lqp_amd.h but not exported"
+    assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
+    assert _lib.load().lqp_abi_version() == 1
+
+
+def test_workspace_queries_and_argument_checks_without_gpu():
+    lib = _lib.load()
+    assert lib.lqp_boxqp_forward_workspace_bytes(0, 128, 500, 1) > 128 * 512 * 512 * 4 * 2
+    assert lib.lqp_boxqp_forward_workspace_bytes(7, 1, 1, 0) == 0          # unknown dtype
+    assert lib.lqp_lu_packed_bytes(1, 2, 100) > 2 * 128 * 128 * 8
+    # null pointers are rejected before anything touches the device
+    ctl = _lib.BoxQPCtrl(max_iters=10, check_solved=1)
+    assert lib.lqp_boxqp_forward(None, 0, 1, 4, 0, None, None, None, None, None, None, ctypes.byref(ctl), None,
+                                 None, None, None, None, None, None, None, None, 0) == 1
+    assert lib.lqp_status_string(3).decode().startswith("singular")
+
+
+def test_control_factory_and_resolution_traps():
+    c = L.box_qp_control(check_solved=3, adaptive_rho_max_iter=7, reduce='max')
+    assert c["check_terimnation"] == 3 and "check_solved" not in c and c["reduce"] == 'max'
+    r = resolve_control(c, 500)
+    assert r["check_solved"] == 20 and r["adaptive_rho_max_iter"] == 1000 and r["adaptive_rho_iter"] == 100
+    assert [resolve_control({}, n)["check_solved"] for n in (10, 50, 100, 250, 500, 1000)] == [1, 10, 10, 20, 20, 30]
+    assert resolve_control({}, 1000)["adaptive_rho_iter"] == 90
+    e = resolve_control({}, 10)
+    assert (e["adaptive_rho"], e["adaptive_rho_tol"], e["scale"]) == (False, 5, False)
+    assert resolve_control({"eps_abs": 0.0}, 10)["eps_abs"] == 1e-12
+
+
+def test_no_cpu_fallback():
+    Q = torch.eye(4).unsqueeze(0)
+    p = torch.ones(1, 4, 1)
+    lb, ub = -torch.ones(1, 4, 1), torch.ones(1, 4, 1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        L.torch_solve_box_qp(Q, p, None, None, lb, ub, L.box_qp_control())
+    with pytest.raises(RuntimeError, match="GPU"):
+        L.torch_solve_qp_eqcon(Q, p, None, None)
+
+
+def test_utils_match_reference_shapes():
+    assert L.get_ncon(None, 1) == 0 and L.get_ncon(torch.zeros(3, 2, 5), 1) == 2
+    Q, A = torch.randn(2, 3, 3), torch.randn(2, 1, 3)
+    M = L.torch_qp_eqcon_mat(Q, A)
+    assert M.shape == (2, 4, 4) and torch.equal(M[:, 3:, :3], A) and float(M[:, 3, 3].abs().max()) == 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "lqp_py_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("the oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,298 @@
+"""Parity of the HIP path (through the C ABI, via the Python shim) against the
+CPU oracle and the golden vectors made from the reference.  GPU only.
+
+Tolerances: fp32 solutions to 5e-5 absolute (north_star: residuals to 1e-5 with
+eps_abs = eps_rel = 1e-5), gradients to rtol 1e-4 of the gradient's scale
+(2e-3 where the stopping tolerance itself limits agreement); fp64 to 1e-9.
+"""
+import os
+
+import pytest
+import torch
+
+import lqp_py_amd as L
+from lqp_py_amd import _lib, lu_layer
+from oracle import boxqp_oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = dict(eps_abs=1e-5, eps_rel=1e-5)
+GRADS = ("dQ", "dp", "dA", "db", "dlb", "dub")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _lib.load()                       # fails loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def err(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def rel(a, b):
+    b = b.detach().cpu().double()
+    return err(a, b) / (float(b.abs().max()) + 1e-300)
+
+
+def solve(dev, inputs, ctl):
+    args = [None if t is None else t.to(dev) for t in inputs]
+    return L.torch_solve_box_qp(*args, dict(ctl)), args
+
+
+# ---------------------------------------------------------------- LU / solves
+@pytest.mark.parametrize("N,B,dtype", [(6, 3, torch.float32), (64, 2, torch.float32), (65, 2, torch.float32),
+                                       (130, 3, torch.float32), (200, 2, torch.float64)])
+def test_lu_factor_matches_lapack(dev, N, B, dtype):
+    torch.manual_seed(N)
+    A = torch.randn(B, N, N, dtype=dtype)
+    LUr, Pr = torch.linalg.lu_factor(A)
+    LU, P = lu_layer.lu_factor(A.to(dev))
+    assert torch.equal(P.cpu(), Pr)
+    tol = 2e-4 if dtype == torch.float32 else 1e-10
+    assert rel(LU, LUr) < tol
+    rhs = torch.randn(B, N, 3, dtype=dtype)
+    xr = torch.linalg.lu_solve(LUr, Pr, rhs)
+    stol = 2e-3 if dtype == torch.float32 else 1e-9
+    assert rel(lu_layer.lu_solve(LUr.to(dev), Pr.to(dev), rhs.to(dev)), xr) < stol     # torch factor, HIP solve
+    assert rel(lu_layer.lu_solve(LU, P, rhs.to(dev)), xr) < stol                         # HIP factor, HIP solve
+
+
+@pytest.mark.parametrize("mfma", ["0", "1"])
+@pytest.mark.parametrize("n,dtype", [(500, torch.float32), (1000, torch.float32), (500, torch.float64)])
+def test_lu_kkt_sized(dev, n, dtype, mfma, monkeypatch):
+    monkeypatch.setenv("LQP_LU_MFMA", mfma)
+    B = 3
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=1, dtype=dtype)
+    M = O.kkt_matrix(Q + 1.2 * torch.eye(n, dtype=dtype), A)
+    LUr, Pr = torch.linalg.lu_factor(M)
+    LU, P = lu_layer.lu_factor(M.to(dev))
+    assert torch.equal(P.cpu(), Pr)
+    assert rel(LU, LUr) < (2e-4 if dtype == torch.float32 else 1e-10)
+
+
+def test_lu_singular_raises(dev):
+    A = torch.randn(2, 8, 8)
+    A[1, :, 3] = 0
+    with pytest.raises(RuntimeError, match="is zero"):
+        lu_layer.lu_factor(A.to(dev))
+
+
+def test_g9_lu_layer_eqcon_uncon(dev):
+    g = load_golden("g9_lu_eqcon")
+    S, rhs, gy = (g[k].to(dev) for k in ("S", "rhs", "gy"))
+    Sg, rg = S.clone().requires_grad_(True), rhs.clone().requires_grad_(True)
+    lu = L.TorchLU(A=S)
+    assert torch.equal(lu.P.cpu(), g["P"]) and err(lu.LU, g["LU"]) < 1e-5
+    y = lu(Sg, rg)
+    y.backward(gy)
+    assert err(y, g["y"]) < 1e-5 and err(Sg.grad, g["dS"]) < 1e-5 and err(rg.grad, g["drhs"]) < 1e-5
+    # a factor made by torch works too (interchangeable LAPACK layout)
+    lu2 = L.TorchLU(LU=g["LU"].to(dev), P=g["P"].to(dev))
+    assert err(lu2(S, rhs), g["y"]) < 1e-5
+    Q, p, A, b, gz = (g[k].to(dev) for k in ("Q", "p", "A", "b", "gz"))
+    s = L.torch_solve_qp_eqcon(Q, p, A, b)
+    assert err(s["x"], g["eq_x"]) < 2e-5 and err(s["nus"], g["eq_nus"]) < 2e-5
+    for t, k in zip(L.torch_solve_qp_eqcon_grad(gz, s["x"], s["nus"], Q, A), ("eq_dQ", "eq_dp", "eq_dA", "eq_db")):
+        assert err(t, g[k]) < 5e-5, k
+    u = L.torch_solve_qp_uncon(Q, p)
+    assert err(u["x"], g["un_x"]) < 1e-4
+    ug = L.torch_solve_qp_uncon_grad(gz, u["x"], Q)
+    assert err(ug[0], g["un_dQ"]) < 1e-3 and err(ug[1], g["un_dp"]) < 1e-3
+
+
+# ---------------------------------------------------------------- forward / backward vs goldens
+def test_g1_config1_box_only(dev):
+    g = load_golden("g1_b32_n10_box")
+    sol, _ = solve(dev, (g["Q"], g["p"], None, None, g["lb"], g["ub"]), O.make_control(**TOL))
+    assert sol["iter"] == g["iter"] and sol["nus"] is None
+    for k in ("x", "z", "u", "lams", "rho"):
+        assert err(sol[k], g[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_g2_forward_and_all_fp_grads(dev, mode):
+    g = load_golden("g2_b8_n50_eq")
+    ctl = O.make_control(launch_mode=mode, **TOL)
+    sol, a = solve(dev, tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")), ctl)
+    assert sol["iter"] == g["iter"] and sol["_stats"]["mode_used"] == mode
+    for k in ("x", "z", "u", "lams", "nus", "rho"):
+        assert err(sol[k], g[k]) < 2e-5, k
+    for tag, cot in (("ones", torch.ones(8, 50, 1)), ("rand", g["g_rand"])):
+        gr = L.torch_solve_box_qp_grad(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
+        assert gr[6] is None
+        for nm, t in zip(GRADS, gr):
+            assert err(t, g[f"{nm}_{tag}"]) < 1e-4 * max(1.0, float(g[f"{nm}_{tag}"].abs().max())), (tag, nm)
+
+
+def test_g8_fp64(dev):
+    base, g = load_golden("g2_b8_n50_eq"), load_golden("g8_b8_n50_eq_f64")
+    sol, a = solve(dev, tuple(base[k].double() for k in ("Q", "p", "A", "b", "lb", "ub")), O.make_control(**TOL))
+    assert sol["iter"] == g["iter"]
+    for k in ("x", "z", "u", "lams", "nus", "rho"):
+        assert err(sol[k], g[k]) < 1e-9, k
+    gr = L.torch_solve_box_qp_grad(base["g_rand"].double().to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"],
+                                   a[0], a[2], a[4], a[5], sol["rho"])
+    for nm, t in zip(GRADS, gr):
+        assert rel(t, g[f"{nm}_rand"]) < 1e-7, nm
+
+
+@pytest.mark.parametrize("tag", ["noscale", "scale"])
+def test_g6_adaptive_rho_refactorises(dev, tag):
+    g = load_golden(f"g6_adaptive_{tag}")
+    ctl = O.make_control(rho=100.0, scale=(tag == "scale"), **TOL)
+    sol, a = solve(dev, tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")), ctl)
+    assert sol["iter"] == g["iter"] == 100 and sol["_stats"]["n_factor"] == 2
+    assert torch.is_tensor(sol["rho"]) and sol["rho"].shape == (16, 1, 1)
+    for k in ("x", "z", "lams", "nus"):
+        assert err(sol[k], g[k]) < 5e-5, k
+    assert rel(sol["rho"], g["rho"]) < 2e-3            # rho = sqrt(ratio of tiny residuals): fp32-noise sensitive
+    gr = L.torch_solve_box_qp_grad(g["g"].to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
+    for nm, t in zip(GRADS, gr):
+        assert rel(t, g[nm]) < 2e-3, nm
+
+
+def test_g7_no_inequality_rho0_and_dict_mutation(dev):
+    g = load_golden("g7_noineq")
+    n, B = 20, 4
+    lb = torch.full((B, n, 1), -float("inf"), device=dev)
+    ub = torch.full((B, n, 1), float("inf"), device=dev)
+    ctl = L.box_qp_control(**TOL)
+    Q = g["Q"].to(dev).requires_grad_(True)
+    x = L.SolveBoxQP(control=ctl)(Q, g["p"].to(dev), g["A"].to(dev), g["b"].to(dev), lb, ub)
+    assert ctl["rho"] == 0                              # caller's dict mutated (reference :37-38)
+    assert err(x, g["x_layer"]) < 2e-5
+    sol = L.torch_solve_box_qp(g["Q"].to(dev), g["p"].to(dev), g["A"].to(dev), g["b"].to(dev), lb, ub, L.box_qp_control(**TOL))
+    assert sol["iter"] == g["iter"] == 0 and sol["rho"] == 0 and not torch.is_tensor(sol["rho"])
+    for k in ("x", "u", "lams", "nus"):
+        assert err(sol[k], g[k]) < 2e-5, k
+    x.sum().backward()
+    assert torch.isfinite(Q.grad).all()
+
+
+def test_g10_scalar_rho_return_types(dev):
+    g = load_golden("g10_scalar_rho")
+    inp = tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub"))
+    sa, _ = solve(dev, inp, O.make_control(rho=0.001, **TOL))
+    assert torch.is_tensor(sa["rho"]) and sa["iter"] == g["a_iter"] and sa["_stats"]["rho_updated"] == 1
+    sb, _ = solve(dev, inp, O.make_control(rho=1.0, adaptive_rho=False, **TOL))
+    assert sb["rho"] == 1.0 and not torch.is_tensor(sb["rho"]) and sb["iter"] == g["b_iter"]
+    for tag, s in (("a", sa), ("b", sb)):
+        for k in ("x", "lams", "nus"):
+            assert err(s[k], g[f"{tag}_{k}"]) < 5e-5, (tag, k)
+    # a per-problem rho tensor is accepted too
+    sc, _ = solve(dev, inp, O.make_control(rho=torch.full((4, 1, 1), 1.0), adaptive_rho=False, **TOL))
+    assert torch.is_tensor(sc["rho"]) and err(sc["x"], g["b_x"]) < 5e-5
+
+
+def test_g11_hard_distribution_fp64(dev):
+    g = load_golden("g11_hard_f64")
+    inp = O.create_hard_qp_data(100, 0.85, list(range(8)))
+    sol, a = solve(dev, inp, O.make_control(**TOL))
+    assert sol["iter"] == g["iter"]
+    for k in ("x", "z", "u", "lams", "nus", "rho"):
+        assert err(sol[k], g[k]) < 1e-7, k
+    gr = L.torch_solve_box_qp_grad(g["g"].to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
+    for nm, t in zip(GRADS, gr):
+        assert rel(t, g[nm]) < 1e-5, nm
+
+
+def test_g3_config2(dev):
+    g = load_golden("g3_b128_n100_box")
+    Q, p, _, _, lb, ub = O.create_qp_data(100, 128, seed=0, with_eq=False)
+    sol, _ = solve(dev, (Q, p, None, None, lb, ub), O.make_control(**TOL))
+    assert sol["iter"] == g["iter"] == 70
+    assert err(sol["x"], g["x"]) < 5e-5 and err(sol["u"], g["u"]) < 5e-5
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_g4_headline_config3(dev, mode):
+    g = load_golden("g4_b128_n500_eq")
+    inp = O.create_qp_data(500, 128, seed=0)
+    sol, a = solve(dev, inp, O.make_control(launch_mode=mode, **TOL))
+    assert sol["iter"] == g["iter"] == 60 and sol["_stats"]["n_check"] == 4 and sol["_stats"]["n_factor"] == 1
+    for k in ("x", "u", "nus"):
+        assert err(sol[k], g[k]) < 5e-5, k
+    torch.manual_seed(7)
+    for tag, cot in (("ones", torch.ones(128, 500, 1)), ("rand", torch.randn(128, 500, 1))):
+        gr = L.torch_solve_box_qp_grad(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
+        for nm, t in zip(GRADS[1:], gr[1:6]):
+            scale = max(1.0, float(g[f"{nm}_{tag}"].abs().max()))
+            assert err(t, g[f"{nm}_{tag}"]) < 2e-3 * scale, (tag, nm)
+        dQ = gr[0]
+        assert rel(torch.linalg.matrix_norm(dQ), g[f"dQ_fro_{tag}"]) < 2e-3 or tag == "ones"
+        samp = dQ[g["sb"].long(), g["si"].long(), g["sj"].long()]
+        assert err(samp, g[f"dQ_samples_{tag}"]) < 2e-3 * max(1.0, float(g[f"dQ_samples_{tag}"].abs().max()))
+
+
+def test_g5_config4_n1000(dev):
+    g = load_golden("g5_b128_n1000_eq")
+    inp = O.create_qp_data(1000, 128, seed=0)
+    sol, _ = solve(dev, inp, O.make_control(**TOL))
+    assert sol["iter"] == g["iter"] == 60
+    assert err(sol["x"], g["x"]) < 5e-5 and rel(sol["rho"], g["rho"]) < 1e-5
+
+
+# ---------------------------------------------------------------- size-independent properties
+def test_kkt_conditions_at_full_size(dev):
+    """Known-answer check independent of the oracle, at the headline size."""
+    inp = O.create_qp_data(500, 128, seed=3)
+    sol, a = solve(dev, inp, O.make_control(eps_abs=1e-6, eps_rel=1e-6))
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sol.items()}
+    res = O.kkt_residuals(*inp, cpu)
+    assert float(res["stationarity"].max()) < 2e-3
+    assert float(res["equality"].max()) < 1e-4
+    assert float(res["box"].max()) == 0.0
+    assert float(res["x_minus_z"].max()) < 1e-4
+    assert float((cpu["lams"] < 0).sum()) == 0
+    # complementarity: a multiplier is non-zero only on an active bound
+    n = 500
+    lo_gap = (cpu["z"] - inp[4]).abs()
+    hi_gap = (inp[5] - cpu["z"]).abs()
+    assert float((cpu["lams"][:, :n] * lo_gap).abs().max()) < 1e-3
+    assert float((cpu["lams"][:, n:] * hi_gap).abs().max()) < 1e-3
+
+
+def test_batch_independence_and_determinism(dev):
+    """Each QP is independent: solving a sub-batch gives the same answers (up to the shared
+    stopping rule, which we neutralise by fixing the iteration count)."""
+    inp = O.create_qp_data(200, 12, seed=9)
+    ctl = O.make_control(max_iters=40, eps_abs=1e-12, eps_rel=1e-12)
+    full, _ = solve(dev, inp, ctl)
+    again, _ = solve(dev, inp, ctl)
+    assert torch.equal(full["x"], again["x"])                     # bitwise reproducible
+    sub, _ = solve(dev, tuple(t[3:7] for t in inp), ctl)
+    assert torch.equal(sub["x"], full["x"][3:7])
+
+
+def test_autograd_module_matches_functional(dev):
+    inp = O.create_qp_data(64, 5, seed=4)
+    Q, p, A, b, lb, ub = (t.to(dev) for t in inp)
+    Qg, pg = Q.clone().requires_grad_(True), p.clone().requires_grad_(True)
+    ctl = L.box_qp_control(**TOL)
+    x = L.SolveBoxQP(control=ctl)(Qg, pg, A, b, lb, ub)
+    cot = torch.randn_like(x)
+    x.backward(cot)
+    sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, L.box_qp_control(**TOL))
+    gr = L.torch_solve_box_qp_grad(cot, sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
+    assert torch.equal(x.detach(), sol["x"])
+    assert torch.equal(Qg.grad, gr[0]) and torch.equal(pg.grad, gr[1])
+
+
+def test_singular_kkt_raises(dev):
+    Q = torch.zeros(2, 6, 6, device=dev)
+    p = torch.ones(2, 6, 1, device=dev)
+    lb, ub = -torch.ones(2, 6, 1, device=dev), torch.ones(2, 6, 1, device=dev)
+    with pytest.raises(RuntimeError, match="singular|zero pivot"):
+        L.torch_solve_box_qp(Q, p, None, None, lb, ub, {"rho": 0.0, "scale": False})
+
+
+def test_unsupported_modes_fail_loudly(dev):
+    inp = [t.to(dev) for t in O.create_qp_data(8, 2, seed=0)]
+    with pytest.raises(NotImplementedError):
+        L.torch_solve_box_qp(*inp, L.box_qp_control(unroll=True))
+    big = O.create_qp_data(8, 1, seed=0)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        L.torch_solve_box_qp(torch.zeros(1, 1100, 1100, device=dev), torch.zeros(1, 1100, 1, device=dev), None, None,
+                             -torch.ones(1, 1100, 1, device=dev), torch.ones(1, 1100, 1, device=dev), {})
