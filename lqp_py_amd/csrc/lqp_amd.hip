@@ -91,39 +91,39 @@ unsigned long long* g_lu_dbg = nullptr;     // optional device buffer (4 counter
 // ---- LU launch: pick panel width / trailing-update flavour --------------------
 template <typename T, int PB, bool MFMA>
 int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
-                   const int* gate) {
+                   const int* gate, const int* nvec) {
     const int lds = LuLds<T, PB>(round_up(N, 64)).total;
     auto fn = k_lu_factor<T, PB, MFMA>;
     int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
     { ProfScope ps(st, PC_LU);
-      hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, g_lu_dbg); }
+      hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, g_lu_dbg, nvec); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
-              const int* gate) {
+              const int* gate, const int* nvec = nullptr) {
     int pb = lu_panel_width<float>(N);
     const int want = env_int("LQP_LU_PB", 0);            // experiments: force a narrower panel
     if (want == 8 || want == 16 || want == 32) pb = std::min(pb, want);
     const bool mfma = env_int("LQP_LU_MFMA", 1) != 0;
-    if (pb == 32) return mfma ? launch_lu_impl<float, 32, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate)
-                              : launch_lu_impl<float, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
-    if (pb == 16) return mfma ? launch_lu_impl<float, 16, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate)
-                              : launch_lu_impl<float, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
-    return launch_lu_impl<float, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+    if (pb == 32) return mfma ? launch_lu_impl<float, 32, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
+                              : launch_lu_impl<float, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
+    if (pb == 16) return mfma ? launch_lu_impl<float, 16, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
+                              : launch_lu_impl<float, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
+    return launch_lu_impl<float, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
 }
 int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
-              const int* gate) {
+              const int* gate, const int* nvec = nullptr) {
     const int pb = lu_panel_width<double>(N);
-    if (pb == 32) return launch_lu_impl<double, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
-    if (pb == 16) return launch_lu_impl<double, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
-    return launch_lu_impl<double, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate);
+    if (pb == 32) return launch_lu_impl<double, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
+    if (pb == 16) return launch_lu_impl<double, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
+    return launch_lu_impl<double, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
 }
 
 template <typename T>
 int launch_pack(hipStream_t st, int B, const T* LU, int N, int ld, size_t mstride, const int* piv, int pstride,
-                T* packed, int* dest, const int* gate) {
+                T* packed, int* dest, const int* gate, const int* nvec = nullptr) {
     const int K = round_up(N, LQP_NB) / LQP_NB;
     const int lds = pack_lds_bytes<T>();
     auto fn = k_pack<T>;
@@ -132,20 +132,20 @@ int launch_pack(hipStream_t st, int B, const T* LU, int N, int ld, size_t mstrid
     const bool vec_ok = (ld % 4 == 0) && (mstride % 4 == 0) && (((uintptr_t)LU) % (4 * sizeof(T)) == 0);
     ProfScope ps(st, PC_PACK);
     hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, LU, N, ld, mstride, piv, pstride, packed,
-                       packed_blocks(K) * LQP_BLK, dest, K * LQP_NB, vec_ok ? 1 : 0, gate);
+                       packed_blocks(K) * LQP_BLK, dest, K * LQP_NB, vec_ok ? 1 : 0, gate, nvec);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
 template <typename T>
 int launch_solve(hipStream_t st, int B, const T* packed, int N, const int* dest, T* rhs, int nrhs, size_t bstride,
-                 int rstride, int cstride) {
+                 int rstride, int cstride, const int* nvec = nullptr) {
     const int K = round_up(N, LQP_NB) / LQP_NB, Np = K * LQP_NB;
     const int lds = solve_lds_bytes<T>(Np);
     auto fn = k_packed_solve<T>;
     int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
     ProfScope ps(st, PC_SOLVE);
-    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, packed, N, Np, K, dest, rhs, nrhs, bstride, rstride, cstride);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, packed, N, Np, K, dest, rhs, nrhs, bstride, rstride, cstride, nvec);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
@@ -238,7 +238,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     rc = ensure_lds((const void*)loop_fn, loop_lds);
     if (rc) return rc;
     int mode = ctl->launch_mode;
-    if (mode == 0) mode = env_int("LQP_LAUNCH_MODE", 1);
+    if (mode == 0) mode = env_int("LQP_LAUNCH_MODE", 2);     // auto: persistent when every workgroup is resident
     if (mode == 2) {
         int dev = 0, cus = 0, per_cu = 0;
         HIP_OK(hipGetDevice(&dev));
@@ -354,6 +354,8 @@ size_t carve_backward(void* ws, int B, int n, int m, BwdParams<T>& P) {
     P.piv = c.take<int>((size_t)B * P.Np);
     P.dest = c.take<int>((size_t)B * P.Np);
     P.rhs = c.take<T>((size_t)B * P.Np);
+    P.fidx = c.take<int>((size_t)B * n);
+    P.nred = c.take<int>(B);
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
     return c.off + kAlign;
@@ -372,13 +374,22 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     P.Q = (const T*)Q; P.A = (const T*)A; P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in;
     P.rho_value = (T)rho_value; P.rho_mode = rho_mode;
     P.dQ = (T*)dQ; P.dp = (T*)dp; P.dA = (T*)dA; P.db = (T*)db; P.dlb = (T*)dlb; P.dub = (T*)dub;
-    { ProfScope ps(st, PC_BWD_BUILD);
-      hipLaunchKernelGGL(k_bwd_build<T>, dim3(B), dim3(LQP_NT), 0, st, P); }
-    int rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr);
+    // default: solve on the free set only (see k_bwd_build_reduced); LQP_BWD_FULL=1 keeps the full system
+    P.reduced = env_int("LQP_BWD_FULL", 0) ? 0 : 1;
+    const int* nvec = P.reduced ? P.nred : nullptr;
+    if (P.reduced) {
+        const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
+        ProfScope ps(st, PC_BWD_BUILD);
+        hipLaunchKernelGGL(k_bwd_build_reduced<T>, dim3(B), dim3(LQP_NT), lds, st, P);
+    } else {
+        ProfScope ps(st, PC_BWD_BUILD);
+        hipLaunchKernelGGL(k_bwd_build<T>, dim3(B), dim3(LQP_NT), 0, st, P);
+    }
+    int rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec);
     if (rc) return rc;
-    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr);
+    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr, nvec);
     if (rc) return rc;
-    rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0);
+    rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);
     if (rc) return rc;
     {
         const int lds = (2 * n + m + 8) * (int)sizeof(T);

@@ -341,13 +341,15 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor(T* __restrict__ Mall, cons
                                                       const size_t mstride, int* __restrict__ piv,
                                                       const int pstride, int* __restrict__ info,
                                                       const int* __restrict__ gate,
-                                                      unsigned long long* __restrict__ dbg) {
+                                                      unsigned long long* __restrict__ dbg,
+                                                      const int* __restrict__ Nvec) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x;
     if (threadIdx.x == 0) info[b] = 0;
     __syncthreads();
-    wg_lu_factor<T, PB, MFMA>(Mall + (size_t)b * mstride, N, ld, piv + (size_t)b * pstride, info + b, smem,
+    const int Nb = Nvec ? Nvec[b] : N;            // per-problem size (reduced backward systems)
+    wg_lu_factor<T, PB, MFMA>(Mall + (size_t)b * mstride, Nb, ld, piv + (size_t)b * pstride, info + b, smem,
                               dbg ? dbg + (size_t)b * 4 : nullptr);
 }
 
@@ -357,11 +359,11 @@ __global__ __launch_bounds__(LQP_NT) void k_pack(const T* __restrict__ LUall, co
                                                  const int pstride, T* __restrict__ packed,
                                                  const size_t pkstride, int* __restrict__ dest,
                                                  const int dstride, const int vec_ok,
-                                                 const int* __restrict__ gate) {
+                                                 const int* __restrict__ gate, const int* __restrict__ Nvec) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x;
-    wg_pack_factor<T>(LUall + (size_t)b * mstride, N, ld, piv + (size_t)b * pstride,
+    wg_pack_factor<T>(LUall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld, piv + (size_t)b * pstride,
                       packed + (size_t)b * pkstride, dest + (size_t)b * dstride, smem, vec_ok != 0);
 }
 
@@ -639,6 +641,9 @@ template <typename T> struct BwdParams {
     T* packed;
     T* rhs;      // B * Np  (rhs, then the solution d)
     int *piv, *dest, *info;
+    int* fidx;   // B * n : indices of the free variables (reduced system), in order
+    int* nred;   // B     : size of the reduced system = #free + m
+    int reduced; // 1: solve on the free set only
 };
 
 template <typename T>
@@ -693,27 +698,94 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build(const BwdParams<T> P) {
     }
 }
 
+// Reduced fixed-point system.  For an active bound (keep_i = 0) row i of the reference's system
+// (:378-392) reads (rho + 1e-8) dv_i = 0, so dv_i = 0 exactly and the variable drops out of every
+// other row: what is left is [[Q_FF, A_F^T], [A_F, 0]] (+1e-8 I) [dv_F; dnu] = [-g_F; 0] on the
+// free set F.  Same solution, (|F|+m)^3 instead of (n+m)^3 work.  LDS: fl[n] (int) | wtot[NW]
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T> P) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int* fl = (int*)smem;               // free list
+    int* wtot = fl + round_up(n, 8);
+    const T* x = P.x + (size_t)b * n;
+    const T* u = P.u + (size_t)b * n;
+    const T* lb = P.lb + (size_t)b * n;
+    const T* ub = P.ub + (size_t)b * n;
+    const T* g = P.g + (size_t)b * n;
+    const T* Q = P.Q + (size_t)b * n * n;
+    const T* A = P.A ? P.A + (size_t)b * m * n : nullptr;
+    T* M = P.M + (size_t)b * Np * Np;
+    T* rhs = P.rhs + (size_t)b * Np;
+    if (tid == 0) P.info[b] = 0;
+    // ---- ordered compaction of the free set (n <= 1024: one variable per thread) ----
+    bool keep = false;
+    if (tid < n) {
+        const T sxu = x[tid] + u[tid];
+        keep = !(sxu > ub[tid] || sxu < lb[tid]);
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[w] = __popcll(bal);
+    __syncthreads();
+    int base = 0, nf = 0;
+#pragma unroll
+    for (int ww = 0; ww < LQP_NW; ++ww) {
+        const int c = wtot[ww];
+        if (ww < w) base += c;
+        nf += c;
+    }
+    if (keep) {
+        fl[base + before] = tid;
+        P.fidx[(size_t)b * n + base + before] = tid;
+    }
+    if (tid == 0) P.nred[b] = nf + m;
+    __syncthreads();
+    // ---- reduced matrix and right-hand side ----
+    for (int a = w; a < nf; a += LQP_NW) {
+        const int i = fl[a];
+        const T* qr = Q + (size_t)i * n;
+        T* mr = M + (size_t)a * Np;
+        for (int c = lane; c < nf; c += 64) {
+            T val = qr[fl[c]];
+            if (c == a) val = val + T(1e-8);
+            mr[c] = val;
+        }
+        for (int r = lane; r < m; r += 64) mr[nf + r] = A[(size_t)r * n + i];
+        if (lane == 0) rhs[a] = -g[i];
+    }
+    for (int r = w; r < m; r += LQP_NW) {
+        T* mr = M + (size_t)(nf + r) * Np;
+        for (int c = lane; c < nf; c += 64) mr[c] = A[(size_t)r * n + fl[c]];
+        for (int c = lane; c < m; c += 64) mr[nf + c] = (c == r) ? T(1e-8) : T(0);
+        if (lane == 0) rhs[nf + r] = T(0);
+    }
+}
+
 // solve with the packed factor (one rhs per problem, in global memory, in place)
 // LDS: v[Np] | tmp[64] | dest[Np]
 template <typename T> __host__ __device__ inline int solve_lds_bytes(int Np) { return (Np + 64) * (int)sizeof(T) + Np * 4; }
 
 template <typename T>
-__global__ __launch_bounds__(LQP_NT) void k_packed_solve(const T* __restrict__ packed_all, const int N, const int Np,
-                                                         const int K, const int* __restrict__ dest_all,
+__global__ __launch_bounds__(LQP_NT) void k_packed_solve(const T* __restrict__ packed_all, const int Nuni, const int Npmax,
+                                                         const int Kmax, const int* __restrict__ dest_all,
                                                          T* __restrict__ rhs_all, const int nrhs,
                                                          const size_t rhs_bstride, const int rhs_rstride,
-                                                         const int rhs_cstride) {
+                                                         const int rhs_cstride, const int* __restrict__ Nvec) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = Nvec ? Nvec[b] : Nuni;
+    const int K = round_up(N, LQP_NB) / LQP_NB, Np = K * LQP_NB;
     T* v = (T*)smem;
-    T* tmp = v + Np;
+    T* tmp = v + Npmax;
     int* dest = (int*)(tmp + 64);
-    const T* packed = packed_all + (size_t)b * packed_blocks(K) * LQP_BLK;
+    const T* packed = packed_all + (size_t)b * packed_blocks(Kmax) * LQP_BLK;
     const int S = K * (K + 1);
     const bool cyclic = (S % LQP_PF) == 0;
     BlockStream<T> st;
     stream_prime(st, packed, S);
-    for (int i = tid; i < Np; i += LQP_NT) dest[i] = dest_all[(size_t)b * Np + i];
+    for (int i = tid; i < Np; i += LQP_NT) dest[i] = dest_all[(size_t)b * Npmax + i];
     __syncthreads();
     T* rhs = rhs_all + (size_t)b * rhs_bstride;
     for (int c = 0; c < nrhs; ++c) {
@@ -738,8 +810,17 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     const T rho = (P.rho_mode == 2) ? P.rho_in[b] : P.rho_value;
     const T* d = P.rhs + (size_t)b * Np;
     const T* x = P.x + (size_t)b * n;
-    for (int i = tid; i < n; i += LQP_NT) { dv[i] = d[i]; xs[i] = x[i]; }
-    for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[n + r];
+    if (P.reduced) {
+        const int nf = P.nred[b] - m;
+        const int* fl = P.fidx + (size_t)b * n;
+        for (int i = tid; i < n; i += LQP_NT) { dv[i] = T(0); xs[i] = x[i]; }
+        __syncthreads();
+        for (int a = tid; a < nf; a += LQP_NT) dv[fl[a]] = d[a];
+        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[nf + r];
+    } else {
+        for (int i = tid; i < n; i += LQP_NT) { dv[i] = d[i]; xs[i] = x[i]; }
+        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[n + r];
+    }
     __syncthreads();
     if (P.dp) for (int i = tid; i < n; i += LQP_NT) P.dp[(size_t)b * n + i] = dv[i];
     if (P.db) for (int r = tid; r < m; r += LQP_NT) P.db[(size_t)b * m + r] = -dnu[r];
