@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "liblqp_amd.so")
+LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQP_LIB: A/B builds
 SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_common.cuh"]
 
 LQP_F32, LQP_F64 = 0, 1

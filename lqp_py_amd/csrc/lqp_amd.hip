@@ -104,8 +104,8 @@ int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, i
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
     int pb = lu_panel_width<float>(N);
-    const int want = env_int("LQP_LU_PB", 0);            // experiments: force a narrower panel
-    if (want == 8 || want == 16 || want == 32) pb = std::min(pb, want);
+    const int want = env_int("LQP_LU_PB", 0);            // experiments: force another panel width
+    if ((want == 8 || want == 16 || want == 32) && 2 * want * round_up(N, 64) * 4 <= 128 * 1024) pb = want;
     const bool mfma = env_int("LQP_LU_MFMA", 1) != 0;
     if (pb == 32) return mfma ? launch_lu_impl<float, 32, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
                               : launch_lu_impl<float, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);

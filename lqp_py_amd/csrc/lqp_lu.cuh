@@ -53,11 +53,13 @@ __device__ __forceinline__ double readlane_t(double v, int l) {
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+__device__ __forceinline__ float hwmax(float a, float b) { return fmaxf(a, b); }     // v_max_f32 (DPP-fusable)
+__device__ __forceinline__ double hwmax(double a, double b) { return fmax(a, b); }
 template <typename T> __device__ __forceinline__ T row16_max(T m) {
-    m = tmax(m, dpp<0xB1>(m));
-    m = tmax(m, dpp<0x4E>(m));
-    m = tmax(m, dpp<0x124>(m));
-    m = tmax(m, dpp<0x128>(m));
+    m = hwmax(m, dpp<0xB1>(m));
+    m = hwmax(m, dpp<0x4E>(m));
+    m = hwmax(m, dpp<0x124>(m));
+    m = hwmax(m, dpp<0x128>(m));
     return m;
 }
 __device__ __forceinline__ int row16_min_i32(int m) {
@@ -71,7 +73,7 @@ __device__ __forceinline__ int row16_min_i32(int m) {
 // ordered by row this is isamax's "first index wins ties".
 template <typename T> __device__ __forceinline__ void wave_argmax(const T key, T& best, int& lane_of_best) {
     const T m = row16_max(key);
-    best = tmax(tmax(readlane_t(m, 0), readlane_t(m, 16)), tmax(readlane_t(m, 32), readlane_t(m, 48)));
+    best = hwmax(hwmax(readlane_t(m, 0), readlane_t(m, 16)), hwmax(readlane_t(m, 32), readlane_t(m, 48)));
     lane_of_best = __ffsll((unsigned long long)__ballot(key == best)) - 1;
 }
 
@@ -168,22 +170,22 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
         const bool act = r < M;
         if (dbg) t0 = clock64();
         {
-            T row[PB];
+            // this thread's panel row as PB/4 four-wide vectors: row element c = row4[c >> 2].v[c & 3]
+            vec row4[PB / 4];
             int curpos = r;             // LAPACK position of this thread's row
             bool done = !act;           // already a pivot row (or no row at all)
             const bool wact = wbase < M;   // this wave holds rows of the panel (loop-invariant, wave-uniform)
             // ---- load this thread's panel row ----
             if (pb == PB) {
 #pragma unroll
-                for (int c = 0; c < PB; c += 4) {
-                    vec v;
-                    if (act) v = *(const vec*)(A + (size_t)(k0 + r) * ld + k0 + c);
-                    else { v.v[0] = v.v[1] = v.v[2] = v.v[3] = T(0); }
-                    row[c] = v.v[0]; row[c + 1] = v.v[1]; row[c + 2] = v.v[2]; row[c + 3] = v.v[3];
+                for (int q = 0; q < PB / 4; ++q) {
+                    if (act) row4[q] = *(const vec*)(A + (size_t)(k0 + r) * ld + k0 + 4 * q);
+                    else { row4[q].v[0] = row4[q].v[1] = row4[q].v[2] = row4[q].v[3] = T(0); }
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < PB; ++c) row[c] = (act && c < pb) ? A[(size_t)(k0 + r) * ld + k0 + c] : T(0);
+                for (int c = 0; c < PB; ++c)
+                    row4[c >> 2].v[c & 3] = (act && c < pb) ? A[(size_t)(k0 + r) * ld + k0 + c] : T(0);
             }
             if (tid == 0) *cnt = 0;
 
@@ -192,9 +194,9 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
             // position LAPACK's explicit interchanges would have moved that row to, `done` marks
             // rows already used as pivots.  Per column: wave arg-max of |a_rj| over the live rows
             // (ties: smallest position, as isamax), each wave's winner publishes its row, ONE
-            // barrier, cross-wave arg-max, rank-1 update against the broadcast pivot row.  The
-            // publish buffers alternate with the column parity, so column j+1 never overwrites
-            // what a slow wave still reads for column j.
+            // barrier, cross-wave arg-max, branch-free rank-1 update against the broadcast pivot
+            // row.  The publish buffers alternate with the column parity, so column j+1 never
+            // overwrites what a slow wave still reads for column j.
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
                 if (j < pb) {
@@ -205,12 +207,13 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
                     int* wt = wtid + par * LQP_NW;
                     T* wr = wrcp + par * LQP_NW;
                     if (wact) {
-                        const T key = done ? T(-1) : tabs(row[j]);
-                        const T myrcp = T(1) / row[j];       // independent of the arg-max chain; only the winner's is used
+                        const T aj = row4[j >> 2].v[j & 3];
+                        const T key = done ? T(-1) : tabs(aj);
+                        T myrcp = T(1) / aj;                 // independent of the arg-max chain below
+                        asm volatile("" : "+v"(myrcp));      // keep it out of the winner-only branch
                         T bw; int lb;
                         wave_argmax(key, bw, lb);
                         const unsigned long long tied = __ballot(key == bw);
-#ifndef LQP_NO_TIE
                         if (__popcll(tied) > 1) {                            // rare: smallest position wins
                             int cp = (key == bw) ? curpos : 0x7fffffff;
                             cp = row16_min_i32(cp);
@@ -218,56 +221,54 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
                                      min(__builtin_amdgcn_readlane(cp, 32), __builtin_amdgcn_readlane(cp, 48)));
                             lb = __ffsll((unsigned long long)__ballot(key == bw && curpos == cp)) - 1;
                         }
-#endif
                         if (lane == lb) {
                             wv[w] = bw;
                             wr[w] = myrcp;
                             wi[w] = curpos;
                             wt[w] = r;
 #pragma unroll
-                            for (int c = 0; c < PB; c += 4) {
-                                vec v; v.v[0] = row[c]; v.v[1] = row[c + 1]; v.v[2] = row[c + 2]; v.v[3] = row[c + 3];
-                                *(vec*)(cand + w * PB + c) = v;
-                            }
+                            for (int q = 0; q < PB / 4; ++q) *(vec*)(cand + w * PB + 4 * q) = row4[q];
                         }
                     } else if (lane == 0) {
                         wv[w] = T(-2);                                       // can never win
                     }
                     __syncthreads();
                     if (wact) {
-                    // cross-wave arg-max: lane l looks at wave (l & 15)'s winner
-                    const T cv = wv[lane & 15];
-                    const int ci = wi[lane & 15];
-                    const int ct = wt[lane & 15];
-                    const T best = row16_max(cv);
-                    const unsigned long long tied = __ballot(cv == best) & 0xFFFFull;
-                    int ww = __ffsll(tied) - 1;
-#ifndef LQP_NO_TIE
-                    if (__popcll(tied) > 1) {
-                        const int cp = row16_min_i32((cv == best) ? ci : 0x7fffffff);
-                        ww = __ffsll((unsigned long long)__ballot(cv == best && ci == cp) & 0xFFFFull) - 1;
-                    }
-#endif
-                    const int pivpos = __builtin_amdgcn_readlane(ci, ww);    // pivot row's position before the swap
-                    const int bi = __builtin_amdgcn_readlane(ct, ww);        // thread that owns the pivot row
-                    const T* rowPc = cand + ww * PB;
-                    const T rinv = wr[ww];
-                    if (r == bi) {
-                        pidx[j] = pivpos;      // pivots / info go to global memory once per panel
-                        if (!(best > T(0)) && cnt[1] == 0) cnt[1] = k0 + j + 1;
-                        curpos = j;
-                        done = true;
-                    } else if (curpos == j) {
-                        curpos = pivpos;       // the row that sat on the diagonal takes the pivot's old place
-                    }
-                    if (!done) {
-                        if (best > T(0)) {                    // a zero pivot column is left untouched (as getf2)
-                            const T l = row[j] * rinv;
-                            row[j] = l;
-#pragma unroll
-                            for (int c = j + 1; c < PB; ++c) row[c] -= l * rowPc[c];
+                        // cross-wave arg-max: lane l looks at wave (l & 15)'s winner
+                        const T cv = wv[lane & 15];
+                        const int ci = wi[lane & 15];
+                        const int ct = wt[lane & 15];
+                        const T best = row16_max(cv);
+                        const unsigned long long tied = __ballot(cv == best) & 0xFFFFull;
+                        int ww = __ffsll(tied) - 1;
+                        if (__popcll(tied) > 1) {
+                            const int cp = row16_min_i32((cv == best) ? ci : 0x7fffffff);
+                            ww = __ffsll((unsigned long long)__ballot(cv == best && ci == cp) & 0xFFFFull) - 1;
                         }
-                    }
+                        const int pivpos = __builtin_amdgcn_readlane(ci, ww);    // pivot row's position before the swap
+                        const int bi = __builtin_amdgcn_readlane(ct, ww);        // thread that owns the pivot row
+                        // the whole pivot row, 16 B per LDS read, all reads independent
+                        const T* rowPc = cand + ww * PB;
+                        vec pr[PB / 4];
+#pragma unroll
+                        for (int q = j >> 2; q < PB / 4; ++q) pr[q] = *(const vec*)(rowPc + 4 * q);
+                        const T rinv = wr[ww];
+                        if (r == bi) {
+                            pidx[j] = pivpos;      // pivots / info go to global memory once per panel
+                            if (!(best > T(0)) && cnt[1] == 0) cnt[1] = k0 + j + 1;
+                            curpos = j;
+                            done = true;
+                        } else if (curpos == j) {
+                            curpos = pivpos;       // the row that sat on the diagonal takes the pivot's old place
+                        }
+                        // branch-free elimination: finished rows (and a zero pivot column, as getf2) use l = 0
+                        const bool upd = !done && (best > T(0));
+                        const T aj = row4[j >> 2].v[j & 3];
+                        const T l = upd ? aj * rinv : T(0);
+                        row4[j >> 2].v[j & 3] = upd ? l : aj;
+#pragma unroll
+                        for (int c = j + 1; c < PB; ++c)
+                            row4[c >> 2].v[c & 3] -= l * pr[c >> 2].v[c & 3];
                     }
                 }
             }
@@ -276,22 +277,19 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
             if (act) {
                 if (pb == PB) {
 #pragma unroll
-                    for (int c = 0; c < PB; c += 4) {
-                        vec v;
-                        v.v[0] = row[c]; v.v[1] = row[c + 1]; v.v[2] = row[c + 2]; v.v[3] = row[c + 3];
-                        *(vec*)(A + (size_t)(k0 + curpos) * ld + k0 + c) = v;
-                    }
+                    for (int q = 0; q < PB / 4; ++q)
+                        *(vec*)(A + (size_t)(k0 + curpos) * ld + k0 + 4 * q) = row4[q];
                 } else {
 #pragma unroll
                     for (int c = 0; c < PB; ++c)
-                        if (c < pb) A[(size_t)(k0 + curpos) * ld + k0 + c] = row[c];
+                        if (c < pb) A[(size_t)(k0 + curpos) * ld + k0 + c] = row4[c >> 2].v[c & 3];
                 }
                 if (curpos < pb) {
 #pragma unroll
-                    for (int c = 0; c < PB; ++c) L11[curpos * (PB + 1) + c] = row[c];
+                    for (int c = 0; c < PB; ++c) L11[curpos * (PB + 1) + c] = row4[c >> 2].v[c & 3];
                 } else {
 #pragma unroll
-                    for (int c = 0; c < PB; ++c) LT[c * Mpad + (curpos - pb)] = row[c];
+                    for (int c = 0; c < PB; ++c) LT[c * Mpad + (curpos - pb)] = row4[c >> 2].v[c & 3];
                 }
                 src[curpos] = r;                        // position -> original (relative) row
                 // a displaced top row that ended below the panel top (its source is always < pb)
@@ -409,12 +407,15 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
     }
 }
 
-// Panel width that keeps L21^T and U12 (2 * PB * Mpad elements) inside LDS.
+// Panel width: L21^T and U12 (2 * PB * Mpad elements) must fit in LDS, and the panel row plus the
+// broadcast pivot row (2 * PB elements per thread) must fit the 128-VGPR budget of a 1024-thread
+// workgroup without spilling: 16 columns for f32, 8 for f64 (measured: wider panels spill and lose).
 template <typename T> __host__ __device__ inline int lu_panel_width(int N) {
     const int Mpad = round_up(N, 64);
     const int budget = 128 * 1024;
-    if (2 * 32 * Mpad * (int)sizeof(T) <= budget) return 32;
-    if (2 * 16 * Mpad * (int)sizeof(T) <= budget) return 16;
+    const int widest = sizeof(T) == 4 ? 16 : 8;
+    if (widest >= 32 && 2 * 32 * Mpad * (int)sizeof(T) <= budget) return 32;
+    if (widest >= 16 && 2 * 16 * Mpad * (int)sizeof(T) <= budget) return 16;
     return 8;
 }
 

@@ -20,7 +20,9 @@
 
 namespace lqp {
 
+#ifndef LQP_PF
 #define LQP_PF 8   // blocks in flight per thread (f32: 128 KB per workgroup)
+#endif
 
 __host__ __device__ inline size_t packed_blocks(int K) { return (size_t)K * (K + 1); }
 

@@ -36,4 +36,4 @@ for pb in (32, 16):
         Pm, Lm, Um = torch.lu_unpack(LU.cpu(), P.cpu())
         err = float((Pm @ Lm @ Um - M.cpu()).abs().max())
         print(f"N={N} PB={pb} mfma={mfma}: {ms*1e3:8.1f} us/launch | cycles panel {c[0]:.0f} swaps+U12 {c[1]:.0f} "
-              f"trailing {c[2]:.0f} total {c[3]:.0f} (100MHz ticks?) | recon err {err:.2e}", flush=True)
+              f"trailing {c[2]:.0f} total {c[3]:.0f} | recon err {err:.2e}", flush=True)
