@@ -54,9 +54,26 @@ def algorithmic_bytes(es, n, m, iters, n_check, n_refactor, scale=True):
     return fwd, bwd, loop
 
 
+def measured_traffic(kernel, mode, B, n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE / WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  Only valid for the configuration it was measured on; otherwise null."""
+    path = os.path.join(REPO, "profiles", "r01_b_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("launch_mode") == mode and B == B_PER_GPU and n == N_X:
+            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], "profiles/r01_b_traffic.json (rocprofv3 --pmc)"
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference, torch CPU) timed on this host."""
+    """The oracle (CPU restatement of the reference, torch CPU) timed on this host's cores.
+    Thread count: the box's CPU share for one GPU (16), not all 256 hardware threads --
+    batched LAPACK on small matrices gets slower, not faster, when oversubscribed."""
     from oracle import boxqp_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     B, n = args.batch, args.n
     Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=0)
     ctl = O.make_control(eps_abs=TOL, eps_rel=TOL)
@@ -152,8 +169,10 @@ def main():
     solves = args.steps
     loop_ms_per_solve = loop_ms / max(solves, 1)
     achieved = (loop_b * B) / (loop_ms_per_solve * 1e-3) / 1e9 if loop_ms_per_solve > 0 else 0.0
+    traffic, traffic_src = measured_traffic("lqp::k_admm_loop<float>", st["mode_used"], B, n)
     roofline = {"bound": "hbm", "kernel": "k_admm_loop", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "per": "one forward solve of one batch (all loop launches of the solve summed)",
                 "algorithmic_bytes": loop_b * B, "ms": round(loop_ms_per_solve, 4),
                 "launches_per_solve": loop_launches / max(solves, 1),
