@@ -233,8 +233,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     n_launch += 2;
 
     // ---- launch mode ----
-    const int loop_lds = loop_lds_bytes<T>(n, m, P.Np);
-    auto loop_fn = k_admm_loop<T>;
+    const bool resident = loop_resident_ok(P.K, sizeof(T)) && env_int("LQP_RESIDENT", 1) != 0 &&
+                          loop_lds_bytes<T>(n, m, P.Np, true) <= 160 * 1024;
+    const int loop_lds = loop_lds_bytes<T>(n, m, P.Np, resident);
+    auto loop_fn = k_admm_loop<T, false>;
+    if constexpr (sizeof(T) == 4) {
+        if (resident) loop_fn = k_admm_loop<T, true>;
+    }
     rc = ensure_lds((const void*)loop_fn, loop_lds);
     if (rc) return rc;
     int mode = ctl->launch_mode;

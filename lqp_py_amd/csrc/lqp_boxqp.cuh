@@ -371,8 +371,14 @@ __global__ __launch_bounds__(LQP_NT) void k_pack(const T* __restrict__ LUall, co
 // ADMM loop: iterations [it0, it1) for every problem (:235-313)
 // LDS: v[Np] | tmp[64] | z[n] | u[n] | ps[n] | lb[n] | ub[n] | D[n] | bs[m] | red[NW*8] | dest[Np] (int)
 // ---------------------------------------------------------------------------
-template <typename T> __host__ __device__ inline int loop_lds_bytes(int n, int m, int Np) {
-    return (Np + 64 + 6 * n + m + LQP_NW * 8 + 8) * (int)sizeof(T) + Np * 4;
+template <typename T> __host__ __device__ inline int loop_lds_bytes(int n, int m, int Np, bool resident) {
+    return (resident ? LQP_RLDS * LQP_BLK * (int)sizeof(T) : 0) +
+           (Np + 64 + 6 * n + m + LQP_NW * 8 + 8) * (int)sizeof(T) + Np * 4;
+}
+// residency applies when the stream is long enough and the ring can stay cyclic over the streamed tail
+__host__ __device__ inline bool loop_resident_ok(int K, size_t elem) {
+    const int S = K * (K + 1);
+    return elem == 4 && S >= LQP_R0 + LQP_PF && ((S - LQP_R0) % LQP_PF) == 0;
 }
 
 template <typename T, int NV>
@@ -411,7 +417,7 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
     return true;
 }
 
-template <typename T>
+template <typename T, bool RES>
 __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
                                                       const int ctr_base,       // counter slot of check it0 / check
                                                       const int prev_slot,      // slot of the last check before it0, -1: none / known not done
@@ -432,7 +438,8 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
         }
     }
     if (it0 >= it1) return;
-    T* v = (T*)smem;
+    T* lds_res = (T*)smem;                                   // resident blocks (RES only), 16-KB aligned chunks
+    T* v = lds_res + (RES ? LQP_RLDS * LQP_BLK : 0);
     T* tmp = v + Np;
     T* z = tmp + 64;
     T* u = z + n;
@@ -455,7 +462,13 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
     const bool cyclic = (S % LQP_PF) == 0;
 
     BlockStream<T> st;
-    stream_prime(st, packed, S);
+    ResidentRegs<T> rr;
+    if constexpr (RES) {
+        resident_load(rr, lds_res, packed);
+        stream_prime_from(st, packed, LQP_R0, S);
+    } else {
+        stream_prime(st, packed, S);
+    }
 
     for (int i = tid; i < n; i += LQP_NT) {
         z[i] = V.z[i]; u[i] = V.u[i]; ps[i] = V.ps[i]; lb[i] = V.lbs[i]; ub[i] = V.ubs[i]; D[i] = V.D[i];
@@ -474,10 +487,14 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
             else if (i < N) val = bs[i - n];
             v[dest[i]] = val;
         }
-        __syncthreads();
+        wg_barrier_lds();
         // ---- x-update: cached triangular solves (:267) ----
-        wg_packed_solve(st, packed, K, v, tmp, cyclic);
-        if (!cyclic && it + 1 < it1) stream_prime(st, packed, S);
+        if constexpr (RES) {
+            wg_packed_solve_resident(st, rr, lds_res, packed, K, v, tmp, true);
+        } else {
+            wg_packed_solve(st, packed, K, v, tmp, cyclic);
+            if (!cyclic && it + 1 < it1) stream_prime(st, packed, S);
+        }
         // ---- z-update, residuals, dual (:271-282) ----
         const bool check = (it % P.check_solved) == 0;
         T mx[5];
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
                 }
             }
         }
-        __syncthreads();
+        wg_barrier_lds();
     }
     // ---- save state for the next launch / the epilogue ----
     for (int i = tid; i < n; i += LQP_NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(LQP_NT) void k_packed_solve(const T* __restrict__ p
     T* rhs = rhs_all + (size_t)b * rhs_bstride;
     for (int c = 0; c < nrhs; ++c) {
         for (int i = tid; i < Np; i += LQP_NT) v[dest[i]] = (i < N) ? rhs[(size_t)i * rhs_rstride + (size_t)c * rhs_cstride] : T(0);
-        __syncthreads();
+        wg_barrier_lds();
         wg_packed_solve(st, packed, K, v, tmp, cyclic && (c + 1 < nrhs));
         if (!cyclic && c + 1 < nrhs) stream_prime(st, packed, S);
         for (int i = tid; i < N; i += LQP_NT) rhs[(size_t)i * rhs_rstride + (size_t)c * rhs_cstride] = v[i];

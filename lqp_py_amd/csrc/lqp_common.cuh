@@ -66,6 +66,14 @@ template <typename T> __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. it
+// drains every global load in flight -- fatal for a kernel whose prefetch ring must stay full across
+// the barrier (the streaming triangular solve has two barriers per 64-row block).  Here: wait for
+// this wave's LDS operations, then a raw s_barrier; global loads keep flying.
+__device__ __forceinline__ void wg_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Workgroup reductions through a small LDS scratch (>= LQP_NW elements of T).
 // Both end with every thread holding the result; both contain barriers, so
 // every thread of the workgroup must call them.

@@ -171,6 +171,112 @@ __device__ __forceinline__ T dot4(const V4<T>& a, const V4<T>& b) {
     return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2] + a.v[3] * b.v[3];
 }
 
+// ---- on-chip residency of the head of the stream --------------------------------------------
+// The loop kernel is at the per-CU streaming limit, so bytes that never leave the chip are pure
+// gain: the first LQP_RREG blocks of the stream live in otherwise idle VGPRs (one 16-B vector per
+// thread per block), the next LQP_RLDS blocks in LDS, for every iteration of the launch; only
+// blocks [R0, S) are streamed through the prefetch ring.  f32 only; needs S >= R0 and, for the
+// cyclic ring, (S - R0) % LQP_PF == 0 (K = 8: 72 blocks, 16 resident, 56 streamed).
+#ifndef LQP_RREG
+#define LQP_RREG 8      // measured: 8+8 resident blocks, PF 8 is spill-free and fastest (16 spills, 12 needs PF 4)
+#endif
+#ifndef LQP_RLDS
+#define LQP_RLDS 8
+#endif
+#define LQP_R0 (LQP_RREG + LQP_RLDS)
+
+template <typename T> struct ResidentRegs {
+    V4<T> r[LQP_RREG];
+};
+
+template <typename T>
+__device__ __forceinline__ void resident_load(ResidentRegs<T>& rr, T* __restrict__ lds_res, const T* __restrict__ packed) {
+    const V4<T>* p = (const V4<T>*)packed + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < LQP_RREG; ++i) rr.r[i] = p[(size_t)i * (LQP_BLK / 4)];
+#pragma unroll
+    for (int i = 0; i < LQP_RLDS; ++i)
+        *(V4<T>*)(lds_res + (size_t)i * LQP_BLK + threadIdx.x * 4) = p[(size_t)(LQP_RREG + i) * (LQP_BLK / 4)];
+}
+
+// walk state of the blocked solve (all wave-uniform)
+template <typename T> struct SolveWalk {
+    int phase, k, j;
+    T acc;
+};
+
+// consume one 64x64 block of the stream
+template <typename T>
+__device__ __forceinline__ void solve_block(SolveWalk<T>& wk, const V4<T>& blk, const int K, T* __restrict__ v,
+                                            T* __restrict__ tmp, const int row, const int cq) {
+    if (wk.j != wk.k) {
+        const V4<T> yv = *(const V4<T>*)(v + wk.j * LQP_NB + cq * 4);
+        wk.acc += dot4(blk, yv);
+        wk.j += wk.phase ? -1 : 1;
+    } else {
+        const T a = row16_sum(wk.acc);
+        if (cq == 0) tmp[row] = v[wk.k * LQP_NB + row] - a;
+        wg_barrier_lds();
+        const V4<T> tv = *(const V4<T>*)(tmp + cq * 4);
+        const T y = row16_sum(dot4(blk, tv));
+        if (cq == 0) v[wk.k * LQP_NB + row] = y;
+        wg_barrier_lds();
+        wk.acc = T(0);
+        if (wk.phase == 0) {
+            if (wk.k == K - 1) { wk.phase = 1; wk.j = K - 1; }
+            else { ++wk.k; wk.j = 0; }
+        } else {
+            --wk.k; wk.j = K - 1;
+        }
+    }
+}
+
+// prime the ring with the first LQP_PF STREAMED blocks (those after the resident head)
+template <typename T>
+__device__ __forceinline__ void stream_prime_from(BlockStream<T>& st, const T* __restrict__ packed, const int first,
+                                                  const int S) {
+    const V4<T>* p = (const V4<T>*)packed + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < LQP_PF; ++i)
+        if (first + i < S) st.buf[i] = p[(size_t)(first + i) * (LQP_BLK / 4)];
+}
+
+// solve with a resident head: blocks [0, RREG) from registers, [RREG, R0) from LDS, [R0, S) streamed
+template <typename T>
+__device__ __forceinline__ void wg_packed_solve_resident(BlockStream<T>& st, const ResidentRegs<T>& rr,
+                                                         const T* __restrict__ lds_res, const T* __restrict__ packed,
+                                                         const int K, T* __restrict__ v, T* __restrict__ tmp,
+                                                         const bool cyclic) {
+    const int tid = threadIdx.x;
+    const int row = tid >> 4, cq = tid & 15;
+    const int S = K * (K + 1);
+    SolveWalk<T> wk;
+    wk.phase = 0; wk.k = 0; wk.j = 0; wk.acc = T(0);
+#pragma unroll
+    for (int s = 0; s < LQP_RREG; ++s) solve_block(wk, rr.r[s], K, v, tmp, row, cq);
+    for (int s = 0; s < LQP_RLDS; ++s) {
+        const V4<T> blk = *(const V4<T>*)(lds_res + (size_t)s * LQP_BLK + tid * 4);
+        solve_block(wk, blk, K, v, tmp, row, cq);
+    }
+    const V4<T>* p = (const V4<T>*)packed + tid;
+    const int Sr = S - LQP_R0;                       // streamed blocks
+    for (int s0 = 0; s0 < Sr; s0 += LQP_PF) {
+#pragma unroll
+        for (int i = 0; i < LQP_PF; ++i) {
+            const int s = s0 + i;
+            if (s < Sr) {
+                const V4<T> blk = st.buf[i];
+                {
+                    int nx = s + LQP_PF;
+                    if (nx >= Sr && cyclic) nx -= Sr;
+                    if (nx < Sr) st.buf[i] = p[(size_t)(LQP_R0 + nx) * (LQP_BLK / 4)];
+                }
+                solve_block(wk, blk, K, v, tmp, row, cq);
+            }
+        }
+    }
+}
+
 // cyclic: S % LQP_PF == 0 and the caller will solve again with the same factor:
 // the tail of this solve already fetches the head of the next one.
 template <typename T>
@@ -203,11 +309,11 @@ __device__ __forceinline__ void wg_packed_solve(BlockStream<T>& st, const T* __r
                 } else {
                     acc = row16_sum(acc);
                     if (cq == 0) tmp[row] = v[k * LQP_NB + row] - acc;
-                    __syncthreads();
+                    wg_barrier_lds();
                     const V4<T> tv = *(const V4<T>*)(tmp + cq * 4);
                     T y = row16_sum(dot4(blk, tv));
                     if (cq == 0) v[k * LQP_NB + row] = y;
-                    __syncthreads();
+                    wg_barrier_lds();
                     acc = T(0);
                     if (phase == 0) {
                         if (k == K - 1) { phase = 1; j = K - 1; /* k stays K-1 */ }
