@@ -166,6 +166,16 @@ def workspace(device, nbytes, tag):
     return buf
 
 
+def norm(t, dtype):
+    """detached, contiguous, right dtype -- without touching tensors that already are"""
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def c(t):
     """contiguous, detached view of a tensor (None passes through)"""
     return None if t is None else t.detach().contiguous()

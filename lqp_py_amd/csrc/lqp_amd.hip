@@ -312,6 +312,11 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             hipLaunchKernelGGL(k_check_done, dim3(1), dim3(64), 0, st, P.status, P.counters, prev_slot, it - 1);
             ++n_launch;
         }
+        // the epilogue only reads state: run it now so that the common case (converged in this chunk)
+        // pays no host round trip between the loop and its outputs; a later chunk simply re-runs it
+        { ProfScope ps(st, PC_EPILOGUE);
+          hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P); }
+        ++n_launch;
         HIP_OK(hipMemcpyAsync(h_status, P.status, sizeof(h_status), hipMemcpyDeviceToHost, st));
         if (!singular_checked) {
             rc = first_failure(st, P.info, B, &fail_index);      // synchronises
@@ -330,9 +335,6 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     }
     const int final_iter = done ? h_status[ST_FINAL_ITER] : max_iters - 1;
 
-    { ProfScope ps(st, PC_EPILOGUE);
-      hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P); }
-    ++n_launch;
     if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
     if (stats) {
         stats->iters = final_iter;

@@ -12,6 +12,7 @@ control dict -- including its key-name traps and the caller-dict side effect --
 and moves pointers.  Tensors must be on the GPU; there is no CPU fallback.
 """
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
@@ -112,10 +113,21 @@ def torch_solve_box_qp_grad(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho):
 # ---------------------------------------------------------------------------
 # internals
 # ---------------------------------------------------------------------------
+_bounds_cache = []      # [(weakref(lb), lb._version, weakref(ub), ub._version, (any_lb, any_ub))]
+
+
 def _finite_bounds(lb, ub):
-    # global over the whole batch, as in the reference (:33-34, :129-130); one host sync
+    """(any_lb, any_ub): global over the whole batch, as in the reference (:33-34, :129-130).
+    Costs two reductions and a host sync, so the answer is remembered for the SAME live tensor
+    objects at the same in-place version -- training loops pass the same bounds every step."""
+    for rl, vl, ru, vu, res in _bounds_cache:
+        if rl() is lb and ru() is ub and vl == lb._version and vu == ub._version:
+            return res
     flags = torch.stack((torch.max(lb) > -_INF, torch.min(ub) < _INF)).tolist()
-    return bool(flags[0]), bool(flags[1])
+    res = (bool(flags[0]), bool(flags[1]))
+    _bounds_cache[:] = [e for e in _bounds_cache if e[0]() is not None and e[2]() is not None][-7:]
+    _bounds_cache.append((weakref.ref(lb), lb._version, weakref.ref(ub), ub._version, res))
+    return res
 
 
 def resolve_control(control, n_x):
@@ -173,10 +185,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None):
     if r['beta'] is not None and torch.is_tensor(r['beta']) and r['beta'].numel() != 1:
         _bad("per-problem beta tensors are not supported; pass a float or None")
 
-    Qc, pc, Ac, bc, lbc, ubc = (_lib.c(t) for t in (Q, p, A, b, lb, ub))
-    Qc, lbc, ubc = (t.to(p.dtype) for t in (Qc, lbc, ubc))
-    if m > 0:
-        Ac, bc = Ac.to(p.dtype), bc.to(p.dtype)
+    Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
     rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, p)
 
     ctl = _lib.BoxQPCtrl(
@@ -235,8 +244,7 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want):
     if rho is None:
         rho = 1.0                                          # (:356-357)
     rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, x)
-    gc, xc, uc, lc, nc, Qc, Ac, lbc, ubc = (None if t is None else _lib.c(t).to(dty)
-                                             for t in (dl_dz, x, u, lams, nus, Q, A, lb, ub))
+    gc, xc, uc, lc, nc, Qc, Ac, lbc, ubc = (_lib.norm(t, dty) for t in (dl_dz, x, u, lams, nus, Q, A, lb, ub))
     mk = lambda on, shape: torch.empty(shape, dtype=dty, device=dev) if on else None
     dQ = mk(want['dQ'], (B, n, n))
     dp = mk(want['dp'], (B, n, 1))
