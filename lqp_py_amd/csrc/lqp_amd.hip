@@ -89,36 +89,52 @@ int env_int(const char* name, int dflt) {
 unsigned long long* g_lu_dbg = nullptr;     // optional device buffer (4 counters per problem), debug only
 
 // ---- LU launch: pick panel width / trailing-update flavour --------------------
-template <typename T, int PB, bool MFMA>
+template <typename T, int PB, bool MFMA, int NT>
 int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                    const int* gate, const int* nvec) {
     const int lds = LuLds<T, PB>(round_up(N, 64)).total;
-    auto fn = k_lu_factor<T, PB, MFMA>;
+    auto fn = k_lu_factor<T, PB, MFMA, NT>;
     int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
     { ProfScope ps(st, PC_LU);
-      hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, g_lu_dbg, nvec); }
+      hipLaunchKernelGGL(fn, dim3(B), dim3(NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, g_lu_dbg, nvec); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
+// N <= 512: 512 threads (one row per thread, 256-VGPR budget) -> 32-column panel for f32, 16 for f64;
+// larger N: 1024 threads, 16 / 8 columns.  LQP_LU_PB / LQP_LU_MFMA / LQP_LU_NT override for experiments.
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
+    int nt = lu_threads<float>(N);
     int pb = lu_panel_width<float>(N);
-    const int want = env_int("LQP_LU_PB", 0);            // experiments: force another panel width
+    const int want_nt = env_int("LQP_LU_NT", 0);
+    if (want_nt == 1024) { nt = 1024; pb = std::min(pb, 16); }
+    const int want = env_int("LQP_LU_PB", 0);
     if ((want == 8 || want == 16 || want == 32) && 2 * want * round_up(N, 64) * 4 <= 128 * 1024) pb = want;
     const bool mfma = env_int("LQP_LU_MFMA", 1) != 0;
-    if (pb == 32) return mfma ? launch_lu_impl<float, 32, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
-                              : launch_lu_impl<float, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
-    if (pb == 16) return mfma ? launch_lu_impl<float, 16, true>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
-                              : launch_lu_impl<float, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
-    return launch_lu_impl<float, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
+#define LQP_LU_CASE(PBV, MF, NTV) return launch_lu_impl<float, PBV, MF, NTV>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
+    if (nt == 512) {
+        if (pb == 32) { if (mfma) LQP_LU_CASE(32, true, 512); LQP_LU_CASE(32, false, 512); }
+        if (pb == 16) { if (mfma) LQP_LU_CASE(16, true, 512); LQP_LU_CASE(16, false, 512); }
+        LQP_LU_CASE(8, false, 512);
+    }
+    if (pb == 32) { if (mfma) LQP_LU_CASE(32, true, 1024); LQP_LU_CASE(32, false, 1024); }
+    if (pb == 16) { if (mfma) LQP_LU_CASE(16, true, 1024); LQP_LU_CASE(16, false, 1024); }
+    LQP_LU_CASE(8, false, 1024);
+#undef LQP_LU_CASE
 }
 int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
+    const int nt = lu_threads<double>(N);
     const int pb = lu_panel_width<double>(N);
-    if (pb == 32) return launch_lu_impl<double, 32, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
-    if (pb == 16) return launch_lu_impl<double, 16, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
-    return launch_lu_impl<double, 8, false>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec);
+#define LQP_LU_CASE(PBV, NTV) return launch_lu_impl<double, PBV, false, NTV>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
+    if (nt == 512) {
+        if (pb == 16) LQP_LU_CASE(16, 512);
+        LQP_LU_CASE(8, 512);
+    }
+    if (pb == 16) LQP_LU_CASE(16, 1024);
+    LQP_LU_CASE(8, 1024);
+#undef LQP_LU_CASE
 }
 
 template <typename T>

@@ -336,8 +336,8 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
 // ---------------------------------------------------------------------------
 // LU and pack kernels (gated: *gate == 0 -> nothing to do)
 // ---------------------------------------------------------------------------
-template <typename T, int PB, bool MFMA>
-__global__ __launch_bounds__(LQP_NT) void k_lu_factor(T* __restrict__ Mall, const int N, const int ld,
+template <typename T, int PB, bool MFMA, int NT>
+__global__ __launch_bounds__(NT) void k_lu_factor(T* __restrict__ Mall, const int N, const int ld,
                                                       const size_t mstride, int* __restrict__ piv,
                                                       const int pstride, int* __restrict__ info,
                                                       const int* __restrict__ gate,
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor(T* __restrict__ Mall, cons
     if (threadIdx.x == 0) info[b] = 0;
     __syncthreads();
     const int Nb = Nvec ? Nvec[b] : N;            // per-problem size (reduced backward systems)
-    wg_lu_factor<T, PB, MFMA>(Mall + (size_t)b * mstride, Nb, ld, piv + (size_t)b * pstride, info + b, smem,
+    wg_lu_factor<T, PB, MFMA, NT>(Mall + (size_t)b * mstride, Nb, ld, piv + (size_t)b * pstride, info + b, smem,
                               dbg ? dbg + (size_t)b * 4 : nullptr);
 }
 

@@ -83,7 +83,7 @@ template <typename T> __device__ __forceinline__ void wave_argmax(const T key, T
 // C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int PB>
+template <int PB, int NT>
 __device__ __forceinline__ void lu_trailing_mfma_f32(float* __restrict__ A22, const int ld, const int M2,
                                                       const float* __restrict__ LT, const float* __restrict__ UP,
                                                       const int Mpad) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void lu_trailing_mfma_f32(float* __restrict__ A22, co
             c[q] = (colok && qrow < rlim) ? base[(size_t)qrow * ld + voff] : 0.f;
         }
     };
-    for (int t = __builtin_amdgcn_readfirstlane(w); t < ntiles; t += LQP_NW) {
+    for (int t = __builtin_amdgcn_readfirstlane(w); t < ntiles; t += NT / 64) {
         f32x16 cur;
         load_c(t, cur);                         // in flight underneath the MFMA chain below
         const int ti = t / nt, tj = t - ti * nt;
@@ -134,7 +134,8 @@ __device__ __forceinline__ void lu_trailing_mfma_f32(float* __restrict__ A22, co
 }
 
 // dbg (optional): 4 cycle counters per workgroup: panel, swaps+U12, trailing update, total
-template <typename T, int PB, bool USE_MFMA>
+// NT = threads in the workgroup (512 or 1024); rows per panel N - k0 <= NT and columns N - PB <= NT
+template <typename T, int PB, bool USE_MFMA, int NT>
 __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, const int ld, int* __restrict__ ipiv,
                                              int* __restrict__ info, char* __restrict__ smem,
                                              unsigned long long* __restrict__ dbg) {
@@ -159,6 +160,7 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
     typedef V4<T> vec;
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);     // first row handled by this wave
     if (tid == 0) cnt[1] = 0;       // first zero pivot (1-based) seen by this factorisation, 0 = none
+    if (tid < 2 * LQP_NW) wval[tid] = T(-2);     // slots of waves that do not exist (NT < 1024) never win
     unsigned long long t_panel = 0, t_swap = 0, t_trail = 0, t0 = 0, t_begin = 0;
     if (dbg) t_begin = clock64();
 
@@ -354,10 +356,10 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
         if (M2 > 0) {
             T* A22 = A + (size_t)(k0 + pb) * ld + (k0 + pb);
             if constexpr (USE_MFMA) {
-                lu_trailing_mfma_f32<PB>((float*)A22, ld, M2, (const float*)LT, (const float*)UP, Mpad);
+                lu_trailing_mfma_f32<PB, NT>((float*)A22, ld, M2, (const float*)LT, (const float*)UP, Mpad);
             } else {
                 const int tj_n = (M2 + 3) >> 2, ti_n = (M2 + 7) >> 3;
-                for (int t = tid; t < ti_n * tj_n; t += LQP_NT) {
+                for (int t = tid; t < ti_n * tj_n; t += NT) {
                     const int ti = t / tj_n, tj = t - ti * tj_n;
                     const int i0 = ti << 3, j0 = tj << 2;
                     T acc[8][4];
@@ -408,12 +410,14 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
 }
 
 // Panel width: L21^T and U12 (2 * PB * Mpad elements) must fit in LDS, and the panel row plus the
-// broadcast pivot row (2 * PB elements per thread) must fit the 128-VGPR budget of a 1024-thread
-// workgroup without spilling: 16 columns for f32, 8 for f64 (measured: wider panels spill and lose).
+// broadcast pivot row (2 * PB elements per thread) must fit the register budget without spilling:
+// 128 VGPRs in a 1024-thread workgroup (f32: 16 columns, f64: 8), 256 VGPRs in a 512-thread one
+// (f32: 32, f64: 16).  Measured: a wider panel that spills loses to the narrower one.
+template <typename T> __host__ __device__ inline int lu_threads(int N) { return N <= 512 ? 512 : 1024; }
 template <typename T> __host__ __device__ inline int lu_panel_width(int N) {
     const int Mpad = round_up(N, 64);
     const int budget = 128 * 1024;
-    const int widest = sizeof(T) == 4 ? 16 : 8;
+    const int widest = (sizeof(T) == 4 ? 16 : 8) * (lu_threads<T>(N) == 512 ? 2 : 1);
     if (widest >= 32 && 2 * 32 * Mpad * (int)sizeof(T) <= budget) return 32;
     if (widest >= 16 && 2 * 16 * Mpad * (int)sizeof(T) <= budget) return 16;
     return 8;
