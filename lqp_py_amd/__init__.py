@@ -4,13 +4,15 @@ there is no CPU fallback: CPU tensors or a missing library raise."""
 from .control import box_qp_control
 from .utils import get_ncon, torch_qp_eqcon_mat
 from .solve_box_qp_admm_torch import (SolveBoxQP, SolveBoxQPLayer, BoxQPTH, torch_solve_box_qp,
-                                      torch_solve_box_qp_grad)
+                                      torch_solve_box_qp_grad, torch_solve_box_qp_grad_kkt,
+                                      torch_qp_int_grads, torch_qp_int_grads_admm)
 from .lu_layer import TorchLU, TorchLULayer
 from .solve_qp_eqcon_torch import torch_solve_qp_eqcon, torch_solve_qp_eqcon_grad
 from .solve_qp_uncon_torch import torch_solve_qp_uncon, torch_solve_qp_uncon_grad
 
 __all__ = [
     "box_qp_control", "get_ncon", "torch_qp_eqcon_mat", "SolveBoxQP", "SolveBoxQPLayer", "BoxQPTH",
-    "torch_solve_box_qp", "torch_solve_box_qp_grad", "TorchLU", "TorchLULayer",
+    "torch_solve_box_qp", "torch_solve_box_qp_grad", "torch_solve_box_qp_grad_kkt", "torch_qp_int_grads",
+    "torch_qp_int_grads_admm", "TorchLU", "TorchLULayer",
     "torch_solve_qp_eqcon", "torch_solve_qp_eqcon_grad", "torch_solve_qp_uncon", "torch_solve_qp_uncon_grad",
 ]

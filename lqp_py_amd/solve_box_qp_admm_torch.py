@@ -54,8 +54,7 @@ class SolveBoxQPLayer(torch.autograd.Function):
     def backward(ctx, dl_dz):
         x, u, lams, nus, Q, A, lb, ub = ctx.saved_tensors
         if ctx.backward_method == 'kkt':
-            raise NotImplementedError("lqp_py_amd: backward='kkt' is not built yet (SURVEY 8(f) rank 2); "
-                                      "use the default backward='fixed_point'")
+            return torch_solve_box_qp_grad_kkt(dl_dz, x=x, lams=lams, nus=nus, Q=Q, A=A, lb=lb, ub=ub)
         need = ctx.needs_input_grad
         want = dict(dQ=need[0], dp=need[1], dA=need[2] and A is not None, db=need[3] and A is not None,
                     dlb=need[4], dub=need[5])
@@ -98,8 +97,11 @@ class BoxQPTH:
 def torch_solve_box_qp(Q, p, A, b, lb, ub, control):
     """Forward solve; returns {"x","z","u","lams","nus","rho","iter"} (reference :108-333)."""
     if control.get('unroll', False):
-        raise NotImplementedError("lqp_py_amd: unroll=True (differentiating through the loop) is not built yet "
-                                  "(SURVEY 8(f) rank 1); use SolveBoxQP with the default fixed-point backward")
+        # autograd through the loop (:328-329 returns the bare x); see lqp_py_amd/unrolled.py
+        from .unrolled import unrolled_solve_box_qp
+        _lib.require_gpu(Q, p, A, b, lb, ub)
+        has_lb, has_ub = _finite_bounds(lb, ub)
+        return unrolled_solve_box_qp(Q, p, A, b, lb, ub, resolve_control(control, p.shape[1]), has_lb, has_ub)
     return _forward_solve(Q, p, A, b, lb, ub, control, bounds=None)
 
 
@@ -108,6 +110,58 @@ def torch_solve_box_qp_grad(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho):
     has_eq = A is not None
     want = dict(dQ=True, dp=True, dA=has_eq, db=has_eq, dlb=True, dub=True)
     return _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want)
+
+
+def torch_solve_box_qp_grad_kkt(dl_dz, x, lams, nus, Q, A, lb, ub):
+    """KKT-system backward (reference :435-469).  The reference solves the (3n+m) system
+        [[Q, G^T diag(lam), A^T], [G, -diag(slack), 0], [A, 0, 0]] [dx; dlam; dnu] = [-dl_dz; 0; 0]
+    with G = [-I; I].  Eliminating dlam = diag(1/slack) G dx exactly turns it into one (n+m) KKT
+    solve with Q + diag(lam_lo/slack_lo + lam_hi/slack_hi) -- the same solution, on the HIP KKT
+    solve (lqp_kkt_solve).  Clamps (1e-8) and the lb/ub bookkeeping of :565-584 are kept."""
+    from .solve_qp_eqcon_torch import _kkt_solve
+    _lib.require_gpu(dl_dz, x, lams, nus, Q, A, lb, ub)
+    n = Q.shape[1]
+    any_lb, any_ub = _finite_bounds(lb, ub)
+    dlam = None
+    Qw = Q
+    if any_lb or any_ub:
+        slack = torch.clamp(torch.cat((x - lb, ub - x), dim=1), 10 ** -8)          # h - G x
+        lams = torch.clamp(lams, 10 ** -8)
+        w = lams[:, :n, :] / slack[:, :n, :] + lams[:, n:, :] / slack[:, n:, :]
+        Qw = Q.detach().clone()
+        Qw.diagonal(dim1=1, dim2=2).add_(w.squeeze(2))
+    zeros = None if A is None else torch.zeros((Q.shape[0], A.shape[1], 1), dtype=Q.dtype, device=Q.device)
+    dx, dnu = _kkt_solve(Qw, dl_dz, A, zeros)
+    if any_lb or any_ub:
+        dlam = torch.cat((-dx / slack[:, :n, :], dx / slack[:, n:, :]), dim=1)
+    return torch_qp_int_grads_admm(x=x, lams=lams, nus=nus, dx=dx, dlam=dlam, dnu=dnu, any_lb=any_lb, any_ub=any_ub)
+
+
+def torch_qp_int_grads(x, lams, nus, dx, dlam, dnu):
+    """(dQ, dp, dA, db, dG, dh) from the differentials (reference :527-562)."""
+    from .solve_qp_eqcon_torch import _outer_grads
+    dl_dQ, dl_dA = _outer_grads(dx, x, dnu, nus if dnu is not None else None)
+    dl_db = -dnu if dnu is not None else None
+    dl_dG = dl_dh = None
+    if dlam is not None:
+        dl_dG = lams * (dlam * x.transpose(1, 2)) + torch.matmul(lams, dx.transpose(1, 2))
+        dl_dh = -lams * dlam
+    return (dl_dQ, dx, dl_dA, dl_db, dl_dG, dl_dh)
+
+
+def torch_qp_int_grads_admm(x, lams, nus, dx, dlam, dnu, any_lb, any_ub):
+    """7-tuple (dQ, dp, dA, db, dlb, dub, None) (reference :565-584, including its choice of the
+    first n rows of dl_dh in the ub-only case)."""
+    n = x.shape[1]
+    dl_dQ, dl_dp, dl_dA, dl_db, _, dl_dh = torch_qp_int_grads(x=x, lams=lams, nus=nus, dx=dx, dlam=dlam, dnu=dnu)
+    dl_dlb = dl_dub = None
+    if any_lb and any_ub:
+        dl_dlb, dl_dub = -dl_dh[:, :n, :], dl_dh[:, n:(2 * n), :]
+    elif any_lb:
+        dl_dlb = -dl_dh[:, :n, :]
+    elif any_ub:
+        dl_dub = dl_dh[:, :n, :]
+    return (dl_dQ, dl_dp, dl_dA, dl_db, dl_dlb, dl_dub, None)
 
 
 # ---------------------------------------------------------------------------

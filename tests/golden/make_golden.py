@@ -211,6 +211,36 @@ def main():
          b_rho=np.array(float(sb_["rho"])))
     print("   scalar-rho iters", sa["iter"], sb_["iter"])
 
+    # G12: backward='kkt' through the autograd layer (solve_box_qp_admm_torch.py:435-584), fp32
+    Q, p, A, b, lb, ub = ref_inputs(40, 6, 8)
+    torch.manual_seed(12)
+    cot = torch.randn(6, 40, 1)
+    leaves = [t.clone().requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+    xk = SolveBoxQP(control=box_qp_control(backward='kkt', **tol))(*leaves)
+    xk.backward(cot)
+    out = dict(Q=Q, p=p, A=A, b=b, lb=lb, ub=ub, cot=cot, x=xk.detach())
+    for nm, t in zip(GRAD_NAMES, leaves):
+        out[nm] = t.grad
+    # box-only variant (no equality block)
+    leaves2 = [t.clone().requires_grad_(True) for t in (Q, p, lb, ub)]
+    xk2 = SolveBoxQP(control=box_qp_control(backward='kkt', **tol))(leaves2[0], leaves2[1], None, None, leaves2[2], leaves2[3])
+    xk2.backward(cot)
+    out.update(x_box=xk2.detach(), dQ_box=leaves2[0].grad, dp_box=leaves2[1].grad, dlb_box=leaves2[2].grad, dub_box=leaves2[3].grad)
+    save("g12_kkt_backward", **out)
+
+    # G13: unroll=True -- autograd through the ADMM loop (:14-15, 216-219, 264-265 + lu_layer.py)
+    Q, p, A, b, lb, ub = ref_inputs(20, 4, 9)
+    torch.manual_seed(13)
+    cot = torch.randn(4, 20, 1)
+    ctl = box_qp_control(unroll=True, eps_abs=1e-6, eps_rel=1e-6)
+    leaves = [t.clone().requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+    xu = SolveBoxQP(control=ctl)(*leaves)
+    xu.backward(cot)
+    out = dict(Q=Q, p=p, A=A, b=b, lb=lb, ub=ub, cot=cot, x=xu.detach())
+    for nm, t in zip(GRAD_NAMES, leaves):
+        out[nm] = t.grad
+    save("g13_unroll", **out)
+
     # G11: hard sparse QP distribution, fp64, n=100 m=10 (experiments/utils.py:64-131)
     seeds = list(range(8))
     Qh, ph, Ah, bh, lbh, ubh, _, _ = generate_hard_qp_torch(100, 0.85, seeds)

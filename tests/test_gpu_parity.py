@@ -266,6 +266,16 @@ def test_batch_independence_and_determinism(dev):
     assert torch.equal(sub["x"], full["x"][3:7])
 
 
+def test_more_problems_than_resident_workgroups(dev):
+    """B > 256 CUs: the persistent grid barrier is impossible, the library must fall back to one launch
+    per check segment on its own and still reproduce the global stopping rule."""
+    inp = O.create_qp_data(32, 300, seed=11)
+    ref = O.solve_box_qp(*inp, O.make_control(**TOL))
+    sol, _ = solve(dev, inp, O.make_control(**TOL))
+    assert sol["_stats"]["mode_used"] == 1 and sol["iter"] == ref["iter"]
+    assert err(sol["x"], ref["x"]) < 5e-5 and err(sol["lams"], ref["lams"]) < 5e-5
+
+
 def test_autograd_module_matches_functional(dev):
     inp = O.create_qp_data(64, 5, seed=4)
     Q, p, A, b, lb, ub = (t.to(dev) for t in inp)
@@ -288,11 +298,35 @@ def test_singular_kkt_raises(dev):
         L.torch_solve_box_qp(Q, p, None, None, lb, ub, {"rho": 0.0, "scale": False})
 
 
-def test_unsupported_modes_fail_loudly(dev):
-    inp = [t.to(dev) for t in O.create_qp_data(8, 2, seed=0)]
-    with pytest.raises(NotImplementedError):
-        L.torch_solve_box_qp(*inp, L.box_qp_control(unroll=True))
-    big = O.create_qp_data(8, 1, seed=0)
+def test_g12_kkt_backward_mode(dev):
+    """backward='kkt' (SURVEY 8f rank 2): reference solves the (3n+m) system, we its exact (n+m) reduction."""
+    g = load_golden("g12_kkt_backward")
+    leaves = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    x = L.SolveBoxQP(control=L.box_qp_control(backward='kkt', **TOL))(*leaves)
+    x.backward(g["cot"].to(dev))
+    assert err(x, g["x"]) < 2e-5
+    for nm, t in zip(GRADS, leaves):
+        assert err(t.grad, g[nm]) < 1e-4 * max(1.0, float(g[nm].abs().max())), nm
+    lv = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "lb", "ub")]
+    x2 = L.SolveBoxQP(control=L.box_qp_control(backward='kkt', **TOL))(lv[0], lv[1], None, None, lv[2], lv[3])
+    x2.backward(g["cot"].to(dev))
+    for nm, t in zip(("dQ_box", "dp_box", "dlb_box", "dub_box"), lv):
+        assert err(t.grad, g[nm]) < 1e-4 * max(1.0, float(g[nm].abs().max())), nm
+
+
+def test_g13_unroll_mode(dev):
+    """unroll=True: autograd through the loop, HIP LU factor/solve inside TorchLU."""
+    g = load_golden("g13_unroll")
+    leaves = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    ctl = L.box_qp_control(unroll=True, eps_abs=1e-6, eps_rel=1e-6)
+    x = L.SolveBoxQP(control=ctl)(*leaves)
+    assert torch.is_tensor(x) and err(x, g["x"]) < 2e-5
+    x.backward(g["cot"].to(dev))
+    for nm, t in zip(GRADS, leaves):
+        assert err(t.grad, g[nm]) < 2e-4 * max(1.0, float(g[nm].abs().max())), nm
+
+
+def test_unsupported_sizes_fail_loudly(dev):
     with pytest.raises(RuntimeError, match="unsupported"):
         L.torch_solve_box_qp(torch.zeros(1, 1100, 1100, device=dev), torch.zeros(1, 1100, 1, device=dev), None, None,
                              -torch.ones(1, 1100, 1, device=dev), torch.ones(1, 1100, 1, device=dev), {})
