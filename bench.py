@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--n", type=int, default=N_X)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--sync", action="store_true", help="layer calls wait for the GPU (reference-style error timing)")
     return ap.parse_args()
 
 
@@ -120,6 +121,8 @@ def main():
         data.append([t.to(dev) for t in (Q, p, A, b, lb, ub)])
     ones = torch.ones(B, n, 1, device=dev)
     control = L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, reduce='max')
+    if args.sync:
+        control['sync'] = True
     layer = ShardedBoxQP(control) if world > 1 else None
     qp = L.SolveBoxQP(control=control)
     last = {}
@@ -144,12 +147,22 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    _lib.profile(enable=True, reset=True)
+    # ---- timed region: exactly K steps, nothing else on the stream ----
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
+    L.synchronize()                       # surface any deferred error of the un-synchronised layer calls
+    # ---- the same K steps again with every library launch bracketed by HIP events on its stream:
+    #      per-kernel device times for the roofline (kept out of the timed region: the event pairs
+    #      cost a few microseconds per launch) ----
+    _lib.profile(enable=True, reset=True)
+    tp = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    dt_prof = time.perf_counter() - tp
     prof = _lib.profile()
     _lib.profile(enable=False)
     if world > 1:
@@ -187,7 +200,8 @@ def main():
                                   "ADMM forward + fixed-point backward, eps 1e-5, scale+adaptive_rho defaults",
                       "global_batch": world * B, "iters": st["iters"], "checks": st["n_check"],
                       "launch_mode": st["mode_used"], "parallelism": f"batch-sharded x{world}"},
-           "roofline": roofline, "kernel_ms_per_step": breakdown}
+           "roofline": roofline, "kernel_ms_per_step": breakdown,
+           "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -58,7 +58,10 @@ typedef struct lqp_boxqp_ctrl {
     int32_t beta_mode;               /* 0 auto (quantile rule :171-174), 1 scalar beta_value */
     int32_t launch_mode;             /* 0 auto, 1 one launch per check segment,
                                         2 persistent loop kernel with in-kernel grid barrier */
-    int32_t reserved;
+    int32_t reserved;                /* 1: do not synchronise with the host (needs persistent launches and a
+                                        short adaptive-rho schedule, else ignored): the whole schedule is
+                                        enqueued speculatively, stats come back as -1, and the caller fetches
+                                        status / info later (lqp_boxqp_forward_layout)                       */
     double eps_abs;
     double eps_rel;
     double rho_value;
@@ -78,7 +81,7 @@ typedef struct lqp_boxqp_stats {
     int32_t rho_updated;    /* 1 if adaptive rho changed rho at least once             */
     int32_t fail_index;     /* batch index of the first singular problem, or -1        */
     int32_t n_launch;       /* kernel launches issued                                  */
-    int32_t mode_used;      /* 1 segmented, 2 persistent                               */
+    int32_t mode_used;      /* 1 segmented, 2 persistent, 3 persistent without host sync */
 } lqp_boxqp_stats;
 
 int lqp_abi_version(void);
@@ -107,6 +110,12 @@ void lqp_debug_set_lu_counters(void* device_buf);
  * outputs x,z,u (B,n,1) lams (B,2n,1) nus (B,m,1)|NULL rho_out (B) (always
  * written, one value per problem).  rho_in: B values when rho_mode == 2.  */
 size_t lqp_boxqp_forward_workspace_bytes(int dtype, int B, int n, int m);
+/* Where, inside the workspace, the device-side status block (16 int32: [0] done, [1] final iteration,
+ * [3] adaptive-rho refactorisations, [4] rho updated, [5] grid-barrier timeout) and the per-problem LU
+ * info array (B int32, non-zero = exactly singular) live -- for callers that skipped the host sync
+ * (ctrl.reserved = 1) and fetch them asynchronously. */
+int lqp_boxqp_forward_layout(int dtype, int B, int n, int m, size_t* status_offset, size_t* status_bytes,
+                             size_t* info_offset, size_t* info_bytes);
 int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m,
                       const void* Q, const void* p, const void* A, const void* b,
                       const void* lb, const void* ub,

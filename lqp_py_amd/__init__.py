@@ -10,8 +10,18 @@ from .lu_layer import TorchLU, TorchLULayer
 from .solve_qp_eqcon_torch import torch_solve_qp_eqcon, torch_solve_qp_eqcon_grad
 from .solve_qp_uncon_torch import torch_solve_qp_uncon, torch_solve_qp_uncon_grad
 
+
+
+def synchronize():
+    """Wait for every un-synchronised layer call and raise any error it reported (singular KKT matrix,
+    barrier timeout).  ``SolveBoxQP`` (the autograd path) does not wait for the GPU by default; pass
+    ``sync=True`` in the control dict to get the reference's raise-at-the-call behaviour."""
+    from . import _lib
+    _lib.poll_errors(block=True)
+
+
 __all__ = [
-    "box_qp_control", "get_ncon", "torch_qp_eqcon_mat", "SolveBoxQP", "SolveBoxQPLayer", "BoxQPTH",
+    "synchronize", "box_qp_control", "get_ncon", "torch_qp_eqcon_mat", "SolveBoxQP", "SolveBoxQPLayer", "BoxQPTH",
     "torch_solve_box_qp", "torch_solve_box_qp_grad", "torch_solve_box_qp_grad_kkt", "torch_qp_int_grads",
     "torch_qp_int_grads_admm", "TorchLU", "TorchLULayer",
     "torch_solve_qp_eqcon", "torch_solve_qp_eqcon_grad", "torch_solve_qp_uncon", "torch_solve_qp_uncon_grad",

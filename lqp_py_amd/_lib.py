@@ -52,6 +52,7 @@ SYMBOLS = {
     "lqp_boxqp_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                   ctypes.POINTER(BoxQPCtrl), _P, _P, _P, _P, _P, _P, _P,
                                   ctypes.POINTER(BoxQPStats), _P, c_size_t]),
+    "lqp_boxqp_forward_layout": (c_int, [c_int] * 4 + [ctypes.POINTER(c_size_t)] * 4),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
                               [ctypes.POINTER(ctypes.c_int32), _P, c_size_t]),
@@ -151,6 +152,48 @@ def ptr(t):
 
 def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---- deferred error reporting for calls that did not synchronise with the host -----------------
+class _Pending:
+    """status / LU-info words of an un-synchronised call, copied to pinned memory on the call's stream"""
+    __slots__ = ("what", "event", "status", "info")
+
+    def __init__(self, what, event, status, info):
+        self.what, self.event, self.status, self.info = what, event, status, info
+
+
+_pending = []
+
+
+def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes):
+    status = torch.empty(status_bytes // 4, dtype=torch.int32, pin_memory=True) if status_bytes else None
+    info = torch.empty(info_bytes // 4, dtype=torch.int32, pin_memory=True)
+    if status is not None:
+        status.copy_(ws[status_off:status_off + status_bytes].view(torch.int32), non_blocking=True)
+    info.copy_(ws[info_off:info_off + info_bytes].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(ws.device))
+    _pending.append(_Pending(what, ev, status, info))
+    if len(_pending) > 64:
+        poll_errors(block=True)
+
+
+def poll_errors(block=False):
+    """Raise the first error of an earlier un-synchronised call whose results have arrived.
+    block=True waits for all of them (``lqp_py_amd.synchronize()``)."""
+    while _pending:
+        p = _pending[0]
+        if not block and not p.event.query():
+            return
+        p.event.synchronize()
+        _pending.pop(0)
+        bad = torch.nonzero(p.info)
+        if bad.numel():
+            raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): LU hit an exactly "
+                               f"zero pivot for batch index {int(bad[0])}; the matrix is singular")
+        if p.status is not None and int(p.status[5]):
+            raise RuntimeError(f"lqp_py_amd.{p.what}: in-kernel grid barrier timed out")
 
 
 _ws_cache = {}

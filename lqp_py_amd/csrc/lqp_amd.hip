@@ -269,6 +269,66 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     }
     const int max_checks_per_launch = kRing / 4;
 
+    // ---- no-host-sync plan (ctrl.reserved == 1, persistent launches): enqueue the WHOLE schedule.
+    //      Every kernel exits at once when the device-side DONE flag is up, the refactor chains are
+    //      gated on device, so nothing needs the host; errors are read later by the caller
+    //      (lqp_boxqp_forward_layout).  Only taken when the number of adaptive-rho events is small.
+    if (ctl->reserved == 1 && mode == 2) {
+        int n_events = 0;
+        if (ctl->adaptive_rho)
+            for (int a = ar_iter; a < max_iters && a < ctl->adaptive_rho_max_iter; a += ar_iter) ++n_events;
+        if (n_events <= env_int("LQP_NOSYNC_MAX_EVENTS", 12)) {
+            int it = 0;
+            while (it < max_iters) {
+                if (ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter) {
+                    const int last_slot = ((it - 1) / check) % kRing;
+                    { ProfScope ps(st, PC_RHO);
+                      hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
+                    rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, P.status + ST_GATE);
+                    if (rc) return rc;
+                    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest,
+                                        P.status + ST_GATE);
+                    if (rc) return rc;
+                    n_launch += 3;
+                }
+                int e = max_iters;
+                if (ctl->adaptive_rho) {
+                    const int a = (it / ar_iter + 1) * ar_iter;
+                    if (a < ctl->adaptive_rho_max_iter) e = std::min(e, a);
+                }
+                // a launch may hold at most kRing/2 checks (counter ring); longer tails are split
+                e = std::min(e, it + (kRing / 2) * check);
+                const long long c_first = (it + check - 1) / check;
+                const long long c_last = (e - 1) / check;
+                if (c_last >= kRing) {      // these slots were used one ring ago: clear exactly them (stream-ordered)
+                    for (long long c = std::max<long long>(c_first, kRing); c <= c_last; ) {
+                        const int s0 = (int)(c % kRing);
+                        const long long run = std::min<long long>(c_last - c + 1, kRing - s0);
+                        HIP_OK(hipMemsetAsync(P.counters + (size_t)s0 * CT_WORDS, 0,
+                                              sizeof(unsigned int) * CT_WORDS * (size_t)run, st));
+                        c += run;
+                    }
+                }
+                const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
+                { ProfScope ps(st, PC_LOOP);
+                  hipLaunchKernelGGL(loop_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, (int)(c_first % kRing),
+                                     prev_slot, 1); }
+                ++n_launch;
+                it = e;
+            }
+            { ProfScope ps(st, PC_EPILOGUE);
+              hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P); }
+            ++n_launch;
+            if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
+            if (stats) {
+                memset(stats, 0, sizeof(*stats));
+                stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
+                stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
+            }
+            return LQP_OK;
+        }
+    }
+
     // ---- iterate ----
     int h_status[ST_WORDS];
     memset(h_status, 0, sizeof(h_status));
@@ -583,6 +643,22 @@ const char* lqp_status_string(int s) {
         case LQP_ERR_UNSUPPORTED: return "size not supported by this build (n + m <= 1024)";
         default: return "unknown status";
     }
+}
+
+int lqp_boxqp_forward_layout(int dtype, int B, int n, int m, size_t* status_offset, size_t* status_bytes,
+                             size_t* info_offset, size_t* info_bytes) {
+    if (bad_dims(dtype, B, n, m) || !status_offset || !status_bytes || !info_offset || !info_bytes) return LQP_ERR_INVALID;
+    char* base = (char*)4096;       // any non-null base: only offsets are used
+    if (dtype == LQP_F32) {
+        FwdLayout<float> L = carve_forward<float>(base, B, n, m);
+        *status_offset = (char*)L.P.status - base; *info_offset = (char*)L.P.info - base;
+    } else {
+        FwdLayout<double> L = carve_forward<double>(base, B, n, m);
+        *status_offset = (char*)L.P.status - base; *info_offset = (char*)L.P.info - base;
+    }
+    *status_bytes = sizeof(int) * ST_WORDS;
+    *info_bytes = sizeof(int) * (size_t)B;
+    return LQP_OK;
 }
 
 size_t lqp_boxqp_forward_workspace_bytes(int dtype, int B, int n, int m) {

@@ -44,8 +44,12 @@ class SolveBoxQPLayer(torch.autograd.Function):
         has_lb, has_ub = _finite_bounds(lb, ub)
         if not (has_lb or has_ub):
             control['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
-        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=(has_lb, has_ub))
+        # the module path never exposes iter/stats, so it does not wait for the GPU: the whole schedule
+        # is enqueued and a singular-KKT error, if any, is raised by a later call (or lqp_py_amd.synchronize())
+        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=(has_lb, has_ub),
+                             sync=bool(control.get('sync', False)))
         ctx.rho = sol['rho']
+        ctx.sync = bool(control.get('sync', False))
         ctx.backward_method = control.get('backward', 'fixed_point')
         ctx.save_for_backward(sol['x'], sol['u'], sol['lams'], sol['nus'], Q, A, lb, ub)
         return sol['x']
@@ -58,7 +62,7 @@ class SolveBoxQPLayer(torch.autograd.Function):
         need = ctx.needs_input_grad
         want = dict(dQ=need[0], dp=need[1], dA=need[2] and A is not None, db=need[3] and A is not None,
                     dlb=need[4], dub=need[5])
-        grads = _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, ctx.rho, want)
+        grads = _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, ctx.rho, want, sync=ctx.sync)
         return grads
 
 
@@ -224,9 +228,10 @@ def _bad(msg):
     raise ValueError("lqp_py_amd: " + msg)
 
 
-def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None):
+def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True):
     _lib.require_gpu(Q, p, A, b, lb, ub)
     lib = _lib.load()
+    _lib.poll_errors()
     B, n = Q.shape[0], p.shape[1]
     m = get_ncon(A, dim=1)
     dt = _lib.dtype_code(p)
@@ -247,7 +252,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None):
         adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
         adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),
         any_lb=int(has_lb), any_ub=int(has_ub), rho_mode=rho_mode,
-        beta_mode=0 if r['beta'] is None else 1, launch_mode=int(r['launch_mode']), reserved=0,
+        beta_mode=0 if r['beta'] is None else 1, launch_mode=int(r['launch_mode']), reserved=0 if sync else 1,
         eps_abs=float(r['eps_abs']), eps_rel=float(r['eps_rel']), rho_value=rho_value,
         rho_min=float(r['rho_min']), rho_max=float(r['rho_max']),
         adaptive_rho_tol=float(r['adaptive_rho_tol']),
@@ -274,23 +279,29 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None):
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "
                            f"(batch index {stats.fail_index}); the KKT matrix is singular")
     _lib.check(st, "torch_solve_box_qp")
+    if stats.mode_used == 3:          # nothing was waited for: fetch status / LU info asynchronously
+        so, sb, io, ib = (ctypes.c_size_t() for _ in range(4))
+        _lib.check(lib.lqp_boxqp_forward_layout(dt, B, n, m, ctypes.byref(so), ctypes.byref(sb), ctypes.byref(io),
+                                                ctypes.byref(ib)), "forward_layout")
+        _lib.defer_check("SolveBoxQP.forward", ws, so.value, sb.value, io.value, ib.value)
     if r['verbose']:
         print(f'iteration = {stats.iters}  (checks: {stats.n_check}, factorisations: {stats.n_factor})')
 
     # type of the returned rho follows the reference: a python number stays one unless
     # adaptive rho rewrote it (:248-250); None becomes a (B,1,1) tensor (:200-203)
-    if rho_mode == 1 and not stats.rho_updated:
+    if rho_mode == 1 and not stats.rho_updated and not (stats.mode_used == 3 and r['adaptive_rho']):
         rho_ret = rho
     else:
-        rho_ret = rho_out.view(B, 1, 1)
+        rho_ret = rho_out.view(B, 1, 1)     # (un-synchronised calls cannot know whether rho was adapted: tensor)
     sol = {"x": x, "z": z, "u": u, "lams": lams, "nus": nus, "rho": rho_ret, "iter": int(stats.iters)}
     sol["_stats"] = {k: getattr(stats, k) for k, _ in stats._fields_}
     return sol
 
 
-def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want):
+def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True):
     _lib.require_gpu(dl_dz, x, u, lams, nus, Q, A, lb, ub)
     lib = _lib.load()
+    _lib.poll_errors()
     B, n = Q.shape[0], Q.shape[1]
     m = get_ncon(A, dim=1)
     dt = _lib.dtype_code(x)
@@ -315,8 +326,10 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want):
                                        _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
                                        rho_mode, rho_value, _lib.ptr(rho_tensor),
                                        _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
-                                       ctypes.byref(fail), _lib.ptr(ws), ws.numel())
+                                       ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel())
     if st == 3:
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {fail.value})")
     _lib.check(st, "torch_solve_box_qp_grad")
+    if not sync:                        # info array sits at the start of the backward workspace
+        _lib.defer_check("SolveBoxQP.backward", ws, 0, 0, 0, 4 * B)
     return (dQ, dp, dA, db, dlb, dub, None)

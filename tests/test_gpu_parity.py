@@ -290,6 +290,30 @@ def test_autograd_module_matches_functional(dev):
     assert torch.equal(Qg.grad, gr[0]) and torch.equal(pg.grad, gr[1])
 
 
+def test_module_path_does_not_sync_and_defers_errors(dev):
+    """SolveBoxQP (autograd path) enqueues the whole schedule without waiting for the GPU; results are
+    the same as the synchronous path, errors surface at a later call / lqp_py_amd.synchronize()."""
+    inp = [t.to(dev) for t in O.create_qp_data(48, 6, seed=2)]
+    x_async = L.SolveBoxQP(control=L.box_qp_control(**TOL))(*inp)
+    x_sync = L.SolveBoxQP(control=L.box_qp_control(sync=True, **TOL))(*inp)
+    L.synchronize()
+    assert torch.equal(x_async, x_sync)
+    # adaptive rho firing inside the speculative schedule (G6): still the reference's answer
+    g = load_golden("g6_adaptive_scale")
+    a = [g[k].to(dev) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    xa = L.SolveBoxQP(control=L.box_qp_control(rho=100.0, scale=True, **TOL))(*a)
+    L.synchronize()
+    assert err(xa, g["x"]) < 5e-5
+    # singular KKT: no exception at the call, RuntimeError when the status arrives
+    Qz = torch.zeros(2, 6, 6, device=dev)
+    pz = torch.ones(2, 6, 1, device=dev)
+    lbz, ubz = -torch.ones(2, 6, 1, device=dev), torch.ones(2, 6, 1, device=dev)
+    L.SolveBoxQP(control={"rho": 0.0, "scale": False})(Qz, pz, None, None, lbz, ubz)
+    with pytest.raises(RuntimeError, match="singular"):
+        L.synchronize()
+    L.synchronize()          # queue drained
+
+
 def test_singular_kkt_raises(dev):
     Q = torch.zeros(2, 6, 6, device=dev)
     p = torch.ones(2, 6, 1, device=dev)
