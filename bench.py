@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--n", type=int, default=N_X)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sync", action="store_true", help="layer calls wait for the GPU (reference-style error timing)")
     return ap.parse_args()
 
@@ -63,18 +64,15 @@ def measured_traffic(kernel, mode, B, n):
     try:
         d = json.load(open(path))
         if d.get("launch_mode") == mode and B == B_PER_GPU and n == N_X:
-            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], "profiles/r01_b_traffic.json (rocprofv3 --pmc)"
+            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], "profiles/r01_c_traffic.json (rocprofv3 --pmc)"
     except Exception:
         pass
     return None, None
 
 
-def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference, torch CPU) timed on this host's cores.
-    Thread count: the box's CPU share for one GPU (16), not all 256 hardware threads --
-    batched LAPACK on small matrices gets slower, not faster, when oversubscribed."""
+def cpu_baseline_worker(args):
+    """(child process, OMP/MKL threads pinned by the environment before torch was imported)"""
     from oracle import boxqp_oracle as O
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
     B, n = args.batch, args.n
     Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=0)
     ctl = O.make_control(eps_abs=TOL, eps_rel=TOL)
@@ -89,13 +87,32 @@ def cpu_baseline(args):
     for _ in range(args.cpu_reps):
         once()
     dt = (time.perf_counter() - t0) / args.cpu_reps
-    return {"value": B / dt, "unit": "QPs/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{args.cpu_reps} x (forward+backward of one batch={B} dz={n} m=1 tol=1e-5), "
-                      f"{dt:.2f} s each, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+    print(json.dumps({"value": B / dt, "unit": "QPs/sec", "cores": torch.get_num_threads(), "kind": "port",
+                      "sample": f"{args.cpu_reps} x (forward+backward of one batch={B} dz={n} m=1 tol=1e-5), "
+                                f"{dt:.2f} s each, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}))
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference, torch CPU) timed on this host's cores, in a child
+    process whose OMP/MKL thread count is the box's CPU share for one GPU (16).  (Changing the thread
+    count of an already-imported torch breaks MKL's batched getrf on this image, and all 256 hardware
+    threads make small batched LAPACK slower, not faster.)"""
+    import subprocess
+    threads = str(min(16, os.cpu_count() or 1))
+    env = dict(os.environ, OMP_NUM_THREADS=threads, MKL_NUM_THREADS=threads, HIP_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--batch", str(args.batch),
+           "--n", str(args.n), "--cpu-reps", str(args.cpu_reps)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    for line in reversed(res.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"value": None, "error": (res.stderr or res.stdout)[-300:]}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -182,7 +199,7 @@ def main():
     solves = args.steps
     loop_ms_per_solve = loop_ms / max(solves, 1)
     achieved = (loop_b * B) / (loop_ms_per_solve * 1e-3) / 1e9 if loop_ms_per_solve > 0 else 0.0
-    traffic, traffic_src = measured_traffic("lqp::k_admm_loop<float>", st["mode_used"], B, n)
+    traffic, traffic_src = measured_traffic("lqp::k_admm_loop<float, true, false>", st["mode_used"], B, n)
     roofline = {"bound": "hbm", "kernel": "k_admm_loop", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,

@@ -56,7 +56,7 @@ int ensure_lds(const void* fn, int bytes) {
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream ----
 enum { PC_SETUP = 0, PC_LU, PC_PACK, PC_LOOP, PC_RHO, PC_EPILOGUE, PC_BWD_BUILD, PC_SOLVE, PC_BWD_EPILOGUE,
-       PC_MISC, PC_COUNT };
+       PC_MISC, PC_LOOP_TAIL, PC_COUNT };
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::mutex g_prof_mutex;
 bool g_prof_on = false;
@@ -252,11 +252,14 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     const bool resident = loop_resident_ok(P.K, sizeof(T)) && env_int("LQP_RESIDENT", 1) != 0 &&
                           loop_lds_bytes<T>(n, m, P.Np, true) <= 160 * 1024;
     const int loop_lds = loop_lds_bytes<T>(n, m, P.Np, resident);
-    auto loop_fn = k_admm_loop<T, false>;
+    auto loop_fn = k_admm_loop<T, false, false>;
+    auto tail_fn = k_admm_loop<T, false, true>;        // same code, own name: continuation launches
     if constexpr (sizeof(T) == 4) {
-        if (resident) loop_fn = k_admm_loop<T, true>;
+        if (resident) { loop_fn = k_admm_loop<T, true, false>; tail_fn = k_admm_loop<T, true, true>; }
     }
     rc = ensure_lds((const void*)loop_fn, loop_lds);
+    if (rc) return rc;
+    rc = ensure_lds((const void*)tail_fn, loop_lds);
     if (rc) return rc;
     int mode = ctl->launch_mode;
     if (mode == 0) mode = env_int("LQP_LAUNCH_MODE", 2);     // auto: persistent when every workgroup is resident
@@ -310,9 +313,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     }
                 }
                 const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
-                { ProfScope ps(st, PC_LOOP);
-                  hipLaunchKernelGGL(loop_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, (int)(c_first % kRing),
-                                     prev_slot, 1); }
+                { ProfScope ps(st, it == 0 ? PC_LOOP : PC_LOOP_TAIL);
+                  hipLaunchKernelGGL(it == 0 ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e,
+                                     (int)(c_first % kRing), prev_slot, 1); }
                 ++n_launch;
                 it = e;
             }
@@ -373,9 +376,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             }
             const int ctr_base = (int)(c_first % kRing);
             const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
-            { ProfScope ps(st, PC_LOOP);
-              hipLaunchKernelGGL(loop_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, ctr_base, prev_slot,
-                                 mode == 2 ? 1 : 0); }
+            { const bool first = (mode == 2 && it == 0) || mode == 1;
+              ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);
+              hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, ctr_base,
+                                 prev_slot, mode == 2 ? 1 : 0); }
             ++n_launch;
             ++in_chunk;
             it = e;
@@ -613,7 +617,7 @@ int lqp_profile_classes(void) { return PC_COUNT; }
 
 const char* lqp_profile_class_name(int c) {
     static const char* names[PC_COUNT] = {"fwd_setup", "lu_factor", "pack", "admm_loop", "rho_update", "fwd_epilogue",
-                                          "bwd_build", "packed_solve", "bwd_epilogue", "misc"};
+                                          "bwd_build", "packed_solve", "bwd_epilogue", "misc", "admm_loop_tail"};
     return (c >= 0 && c < PC_COUNT) ? names[c] : "?";
 }
 

@@ -417,7 +417,9 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
     return true;
 }
 
-template <typename T, bool RES>
+// TAIL only changes the kernel's NAME: continuation launches of the speculative schedule (which exit at
+// once when the first launch converged) show up separately from the one real launch in traces / profiles.
+template <typename T, bool RES, bool TAIL>
 __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
                                                       const int ctr_base,       // counter slot of check it0 / check
                                                       const int prev_slot,      // slot of the last check before it0, -1: none / known not done
