@@ -147,7 +147,8 @@ int launch_pack(hipStream_t st, int B, const T* LU, int N, int ld, size_t mstrid
     if (rc) return rc;
     const bool vec_ok = (ld % 4 == 0) && (mstride % 4 == 0) && (((uintptr_t)LU) % (4 * sizeof(T)) == 0);
     ProfScope ps(st, PC_PACK);
-    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, LU, N, ld, mstride, piv, pstride, packed,
+    const int split = (B <= 128 && env_int("LQP_SPLIT2", 1)) ? 2 : 1;      // use the idle half of the chip
+    hipLaunchKernelGGL(fn, dim3(B, split), dim3(LQP_NT), lds, st, LU, N, ld, mstride, piv, pstride, packed,
                        packed_blocks(K) * LQP_BLK, dest, K * LQP_NB, vec_ok ? 1 : 0, gate, nvec);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
@@ -259,7 +260,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     }
     rc = ensure_lds((const void*)loop_fn, loop_lds);
     if (rc) return rc;
-    rc = ensure_lds((const void*)tail_fn, loop_lds);
+    // the continuation kernel also runs LU + pack (in-kernel adaptive-rho refactor): LDS = max of the three
+    int tail_lds = std::max(loop_lds, LuLds<T, (sizeof(T) == 4 ? 16 : 8)>(round_up(P.N, 64)).total);
+    tail_lds = std::max(tail_lds, (int)pack_lds_bytes<T>());
+    rc = ensure_lds((const void*)tail_fn, tail_lds);
     if (rc) return rc;
     int mode = ctl->launch_mode;
     if (mode == 0) mode = env_int("LQP_LAUNCH_MODE", 2);     // auto: persistent when every workgroup is resident
@@ -283,7 +287,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if (n_events <= env_int("LQP_NOSYNC_MAX_EVENTS", 12)) {
             int it = 0;
             while (it < max_iters) {
-                if (ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter) {
+                // the adaptive-rho step of iteration `it` runs as the prologue of the continuation kernel
+                bool event = ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter;
+                if (event && sizeof(T) != 4) {          // f64: separate gated kernels
                     const int last_slot = ((it - 1) / check) % kRing;
                     { ProfScope ps(st, PC_RHO);
                       hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
@@ -293,6 +299,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                                         P.status + ST_GATE);
                     if (rc) return rc;
                     n_launch += 3;
+                    event = false;
                 }
                 int e = max_iters;
                 if (ctl->adaptive_rho) {
@@ -314,8 +321,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 }
                 const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
                 { ProfScope ps(st, it == 0 ? PC_LOOP : PC_LOOP_TAIL);
-                  hipLaunchKernelGGL(it == 0 ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e,
-                                     (int)(c_first % kRing), prev_slot, 1); }
+                  hipLaunchKernelGGL(it == 0 ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), it == 0 ? loop_lds : tail_lds, st,
+                                     P, it, e, (int)(c_first % kRing), prev_slot, event ? 3 : 1); }
                 ++n_launch;
                 it = e;
             }
@@ -378,8 +385,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
             { const bool first = (mode == 2 && it == 0) || mode == 1;
               ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);
-              hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), loop_lds, st, P, it, e, ctr_base,
-                                 prev_slot, mode == 2 ? 1 : 0); }
+              hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), first ? loop_lds : tail_lds, st, P, it, e,
+                                 ctr_base, prev_slot, mode == 2 ? 1 : 0); }
             ++n_launch;
             ++in_chunk;
             it = e;
@@ -467,7 +474,8 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     if (P.reduced) {
         const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
         ProfScope ps(st, PC_BWD_BUILD);
-        hipLaunchKernelGGL(k_bwd_build_reduced<T>, dim3(B), dim3(LQP_NT), lds, st, P);
+        const int split = (B <= 128 && env_int("LQP_SPLIT2", 1)) ? 2 : 1;
+        hipLaunchKernelGGL(k_bwd_build_reduced<T>, dim3(B, split), dim3(LQP_NT), lds, st, P);
     } else {
         ProfScope ps(st, PC_BWD_BUILD);
         hipLaunchKernelGGL(k_bwd_build<T>, dim3(B), dim3(LQP_NT), 0, st, P);

@@ -363,8 +363,10 @@ __global__ __launch_bounds__(LQP_NT) void k_pack(const T* __restrict__ LUall, co
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x;
+    // gridDim.y == 2: two workgroups per factor (L half / U half) -- at B <= 128 half the CUs are idle
+    const int part = gridDim.y == 2 ? 1 + (int)blockIdx.y : 0;
     wg_pack_factor<T>(LUall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld, piv + (size_t)b * pstride,
-                      packed + (size_t)b * pkstride, dest + (size_t)b * dstride, smem, vec_ok != 0);
+                      packed + (size_t)b * pkstride, dest + (size_t)b * dstride, smem, vec_ok != 0, part);
 }
 
 // ---------------------------------------------------------------------------
@@ -417,8 +419,11 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
     return true;
 }
 
-// TAIL only changes the kernel's NAME: continuation launches of the speculative schedule (which exit at
-// once when the first launch converged) show up separately from the one real launch in traces / profiles.
+// TAIL = continuation launch of the speculative (no host sync) schedule.  It has its own name in traces /
+// profiles (it exits at once when the first launch converged) and, when `persistent & 2`, starts with the
+// adaptive-rho step of iteration it0 (:237-256) done in-kernel: global decision from the counters of the
+// last check, masked rho update, KKT re-assembly, LU refactorisation and re-pack by this workgroup.  Only
+// this cold variant carries the LU / pack code; the first (hot) launch stays lean.
 template <typename T, bool RES, bool TAIL>
 __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
                                                       const int ctr_base,       // counter slot of check it0 / check
@@ -440,6 +445,31 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
         }
     }
     if (it0 >= it1) return;
+    if constexpr (TAIL && sizeof(T) == 4) {      // f64 keeps the separate gated kernels (register budget)
+        if ((persistent & 2) && prev_slot >= 0) {
+            const unsigned int* ctl = P.counters + (size_t)prev_slot * CT_WORDS;
+            if (ctl[CT_WANTS] > 0 && ctl[CT_TRIG] > 0) {                     // uniform over the whole grid
+                constexpr int kPB = sizeof(T) == 4 ? 16 : 8;
+                T* scal_ = P.scal + (size_t)b * SC_WORDS;
+                VecView<T> V_(P.vecs + (size_t)b * P.vstride, n, m);
+                T rho_ = scal_[SC_RHO];
+                if (scal_[SC_WANTS] != T(0)) rho_ = rho_ * scal_[SC_RATIO];
+                rho_ = tmin(tmax(rho_, P.rho_min), P.rho_max);
+                __syncthreads();
+                if (tid == 0) scal_[SC_RHO] = rho_;
+                if (b == 0 && tid == 0) { P.status[ST_NFACTOR] += 1; P.status[ST_RHO_UPDATED] = 1; }
+                const T* Qs_ = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
+                assemble_kkt_rows(P, b, Qs_, P.scale ? P.ldq : n, V_, rho_, true);
+                __syncthreads();
+                wg_lu_factor<T, kPB, sizeof(T) == 4, LQP_NT>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
+                                                            P.info + b, smem, nullptr);
+                __syncthreads();
+                wg_pack_factor<T>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
+                                  P.packed + (size_t)b * packed_blocks(K) * LQP_BLK, P.dest + (size_t)b * Np, smem, true);
+                __syncthreads();
+            }
+        }
+    }
     T* lds_res = (T*)smem;                                   // resident blocks (RES only), 16-KB aligned chunks
     T* v = lds_res + (RES ? LQP_RLDS * LQP_BLK : 0);
     T* tmp = v + Np;
@@ -556,7 +586,7 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
                 if (trig) atomicAdd(ct + CT_TRIG, 1u);
             }
             ++slot;
-            if (persistent) {
+            if (persistent & 1) {
                 // all workgroups resident: device-wide "all optimal?" (torch.all at :312)
                 if (tid == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -737,7 +767,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
     const T* A = P.A ? P.A + (size_t)b * m * n : nullptr;
     T* M = P.M + (size_t)b * Np * Np;
     T* rhs = P.rhs + (size_t)b * Np;
-    if (tid == 0) P.info[b] = 0;
+    if (tid == 0 && blockIdx.y == 0) P.info[b] = 0;
     // ---- ordered compaction of the free set (n <= 1024: one variable per thread) ----
     bool keep = false;
     if (tid < n) {
@@ -757,12 +787,13 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
     }
     if (keep) {
         fl[base + before] = tid;
-        P.fidx[(size_t)b * n + base + before] = tid;
+        if (blockIdx.y == 0) P.fidx[(size_t)b * n + base + before] = tid;
     }
-    if (tid == 0) P.nred[b] = nf + m;
+    if (tid == 0 && blockIdx.y == 0) P.nred[b] = nf + m;
     __syncthreads();
-    // ---- reduced matrix and right-hand side ----
-    for (int a = w; a < nf; a += LQP_NW) {
+    // ---- reduced matrix and right-hand side (rows interleaved over the gridDim.y workgroups) ----
+    const int wy = blockIdx.y, ny = gridDim.y;
+    for (int a = w * ny + wy; a < nf; a += LQP_NW * ny) {
         const int i = fl[a];
         const T* qr = Q + (size_t)i * n;
         T* mr = M + (size_t)a * Np;
@@ -774,7 +805,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
         for (int r = lane; r < m; r += 64) mr[nf + r] = A[(size_t)r * n + i];
         if (lane == 0) rhs[a] = -g[i];
     }
-    for (int r = w; r < m; r += LQP_NW) {
+    for (int r = w * ny + wy; r < m; r += LQP_NW * ny) {
         T* mr = M + (size_t)(nf + r) * Np;
         for (int c = lane; c < nf; c += 64) mr[c] = A[(size_t)r * n + fl[c]];
         for (int c = lane; c < m; c += 64) mr[nf + c] = (c == r) ? T(1e-8) : T(0);

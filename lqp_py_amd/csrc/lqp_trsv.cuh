@@ -56,7 +56,11 @@ __device__ __forceinline__ V4<T> load_padded4(const T* __restrict__ LU, const in
 template <typename T>
 __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const int N, const int ld,
                                const int* __restrict__ ipiv, T* __restrict__ packed,
-                               int* __restrict__ dest, char* __restrict__ smem, const bool vec_ok) {
+                               int* __restrict__ dest, char* __restrict__ smem, const bool vec_ok,
+                               const int part = 0) {
+    // part 0: whole factor; part 1: L panels + inv(L diagonal) + rhs permutation; part 2: U panels + inv(U
+    // diagonal).  The two halves are independent, so two workgroups (two CUs) can pack one factor.
+    const bool doL = part != 2, doU = part != 1;
     const int K = round_up(N, LQP_NB) / LQP_NB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = tid >> 4, cq = tid & 15;
@@ -67,13 +71,13 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
     // ---- off-diagonal blocks: straight copies with zero padding ----
     {
         size_t s = 0;
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; doL && k < K; ++k) {
             for (int j = 0; j < k; ++j, ++s)
                 *(vec*)(Lpk + s * LQP_BLK + tid * 4) = load_padded4(LU, N, ld, k * LQP_NB + row, j * LQP_NB + cq * 4, vec_ok);
             ++s;   // diagonal slot, filled below
         }
         s = 0;
-        for (int k = K - 1; k >= 0; --k) {
+        for (int k = K - 1; doU && k >= 0; --k) {
             for (int j = K - 1; j > k; --j, ++s)
                 *(vec*)(Upk + s * LQP_BLK + tid * 4) = load_padded4(LU, N, ld, k * LQP_NB + row, j * LQP_NB + cq * 4, vec_ok);
             ++s;
@@ -102,7 +106,7 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
         __syncthreads();
         const int g = w >> 1;
         const bool lower = (w & 1) == 0;
-        if (g < G && g0 + g < K) {
+        if (g < G && g0 + g < K && (lower ? doL : doU)) {
             const int kb = g0 + g;
             const T* Tk = Tb + g * LQP_BLK;
             const int c = lane;
@@ -135,7 +139,7 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
 
     // ---- destination of each rhs row under the LAPACK interchanges ----
     const int Np = K * LQP_NB;
-    for (int r = tid; r < Np; r += LQP_NT) {
+    for (int r = tid; doL && r < Np; r += LQP_NT) {
         int pos = r;
         if (r < N) {
             for (int i = 0; i < N; ++i) {
