@@ -105,6 +105,16 @@ int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, i
 // larger N: 1024 threads, 16 / 8 columns.  LQP_LU_PB / LQP_LU_MFMA / LQP_LU_NT override for experiments.
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
+    if (N <= 512 && N > 64 && env_int("LQP_LU_LA", 0) != 0) {       // lookahead variant (see lqp_lu.cuh)
+        constexpr int PB = 16;
+        const int lds = LuLds<float, PB>(round_up(N, 64)).total;
+        auto fn = k_lu_factor_la<PB>;
+        int rc = ensure_lds((const void*)fn, lds);
+        if (rc) return rc;
+        { ProfScope ps(st, PC_LU);
+          hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, g_lu_dbg); }
+        return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+    }
     int nt = lu_threads<float>(N);
     int pb = lu_panel_width<float>(N);
     const int want_nt = env_int("LQP_LU_NT", 0);

@@ -353,6 +353,21 @@ __global__ __launch_bounds__(NT) void k_lu_factor(T* __restrict__ Mall, const in
                               dbg ? dbg + (size_t)b * 4 : nullptr);
 }
 
+// lookahead LU (f32, N <= 512): panel k+1 on waves 0-7 while waves 8-15 run panel k's trailing update
+template <int PB>
+__global__ __launch_bounds__(LQP_NT) void k_lu_factor_la(float* __restrict__ Mall, const int N, const int ld,
+                                                         const size_t mstride, int* __restrict__ piv, const int pstride,
+                                                         int* __restrict__ info, const int* __restrict__ gate,
+                                                         const int* __restrict__ Nvec, unsigned long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) info[b] = 0;
+    __syncthreads();
+    wg_lu_factor_la_f32<PB>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld, piv + (size_t)b * pstride, info + b, smem,
+                            dbg ? dbg + (size_t)b * 4 : nullptr);
+}
+
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_pack(const T* __restrict__ LUall, const int N, const int ld,
                                                  const size_t mstride, const int* __restrict__ piv,

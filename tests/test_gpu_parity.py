@@ -350,6 +350,34 @@ def test_g13_unroll_mode(dev):
         assert err(t.grad, g[nm]) < 2e-4 * max(1.0, float(g[nm].abs().max())), nm
 
 
+def test_training_loop_matches_cpu_oracle(dev):
+    """Linear -> SolveBoxQP -> QP loss -> SGD (experiments/experiment_2.py:57-99).
+    The GPU layer and an autograd wrapper around the CPU oracle must produce the same loss trajectory."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import experiment_2 as E
+
+    class OracleLayer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, Q, p, A, b, lb, ub):
+            sol = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+            ctx.save_for_backward(sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
+            return sol["x"]
+
+        @staticmethod
+        def backward(ctx, g):
+            x, u, lams, nus, Q, A, lb, ub, rho = ctx.saved_tensors
+            return O.solve_box_qp_grad(g, x, u, lams, nus, Q, A, lb, ub, rho)[:6]
+
+    kw = dict(n_x=40, n_batch=16, n_mini=8, n_epochs=6, lr=1e-2, verbose=False)
+    gpu_losses, _, _ = E.train(dev=dev, **kw)
+    cpu_losses, _, _ = E.train(dev=torch.device("cpu"), layer=lambda *a: OracleLayer.apply(*a), **kw)
+    L.synchronize()
+    assert len(gpu_losses) == 6
+    for a, b in zip(gpu_losses, cpu_losses):
+        assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (gpu_losses, cpu_losses)
+
+
 def test_unsupported_sizes_fail_loudly(dev):
     with pytest.raises(RuntimeError, match="unsupported"):
         L.torch_solve_box_qp(torch.zeros(1, 1100, 1100, device=dev), torch.zeros(1, 1100, 1, device=dev), None, None,

@@ -14,8 +14,9 @@ Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=0)
 M = O.kkt_matrix(Q + 1.2 * torch.eye(n), A).to(dev)
 N = M.shape[1]
 dbg = torch.zeros(B * 4, dtype=torch.int64, device=dev)
-for (nt, pb, mfma) in ((512, 32, 1), (512, 32, 0), (512, 16, 1), (1024, 16, 1)):
+for (nt, pb, mfma, la) in ((1024, 16, 1, 1), (512, 32, 1, 0), (1024, 16, 1, 0)):
     if True:
+        os.environ["LQP_LU_LA"] = str(la)
         os.environ["LQP_LU_NT"] = str(nt)
         os.environ["LQP_LU_PB"] = str(pb)
         os.environ["LQP_LU_MFMA"] = str(mfma)
@@ -36,5 +37,5 @@ for (nt, pb, mfma) in ((512, 32, 1), (512, 32, 0), (512, 16, 1), (1024, 16, 1)):
         c = dbg.view(B, 4).double().mean(0).tolist()
         Pm, Lm, Um = torch.lu_unpack(LU.cpu(), P.cpu())
         err = float((Pm @ Lm @ Um - M.cpu()).abs().max())
-        print(f"N={N} NT={nt} PB={pb} mfma={mfma}: {ms*1e3:8.1f} us/launch | cycles panel {c[0]:.0f} swaps+U12 {c[1]:.0f} "
+        print(f"N={N} LA={la} NT={nt} PB={pb} mfma={mfma}: {ms*1e3:8.1f} us/launch | cycles panel(P) {c[0]:.0f} swaps+U12(serial) {c[1]:.0f} "
               f"trailing {c[2]:.0f} total {c[3]:.0f} | recon err {err:.2e}", flush=True)
