@@ -20,13 +20,37 @@ from .solve_box_qp_admm_torch import SolveBoxQPLayer
 _INF = float("inf")
 
 
+_flag_cache = []     # [(weakref(lb), version, weakref(ub), version, group, result)]
+
+
 def global_bound_flags(lb, ub, group=None):
-    """(any_lb, any_ub) over the batches of ALL ranks."""
+    """(any_lb, any_ub) over the batches of ALL ranks.  Two reductions, one tiny all-reduce and a host
+    sync -- remembered for the same live tensor objects at the same in-place version.  (Every rank
+    runs the same program on its own shard, so all ranks hit or miss together and the collective
+    stays matched; set LQP_DIST_NO_CACHE=1 if your ranks do not pass bounds in lockstep.)"""
+    import os
+    import weakref
+    use_cache = not os.environ.get("LQP_DIST_NO_CACHE")
+    if use_cache:
+        for rl, vl, ru, vu, g, res in _flag_cache:
+            if rl() is lb and ru() is ub and vl == lb._version and vu == ub._version and g is group:
+                return res
     flags = torch.stack(((torch.max(lb) > -_INF), (torch.min(ub) < _INF))).to(torch.int32)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
     f = flags.tolist()
-    return bool(f[0]), bool(f[1])
+    res = (bool(f[0]), bool(f[1]))
+    if use_cache:
+        _flag_cache[:] = [e for e in _flag_cache if e[0]() is not None and e[2]() is not None][-7:]
+        _flag_cache.append((weakref.ref(lb), lb._version, weakref.ref(ub), ub._version, group, res))
+    return res
+
+
+def _local_flags(lb, ub):
+    if not lb.is_cuda:                      # CPU stand-in used by the gloo tests
+        return bool(torch.max(lb) > -_INF), bool(torch.min(ub) < _INF)
+    from .solve_box_qp_admm_torch import _finite_bounds
+    return _finite_bounds(lb, ub)
 
 
 def all_gather_solutions(x_local, group=None):
@@ -63,7 +87,7 @@ class ShardedBoxQP(torch.nn.Module):
         ctl = self.control
         if not (has_lb or has_ub):
             ctl['rho'] = 0
-        elif (not bool(torch.max(lb) > -_INF)) and (not bool(torch.min(ub) < _INF)):
+        elif _local_flags(lb, ub) == (False, False):
             # this shard alone has no finite bound but another rank does: keep the ADMM path
             # (a private copy of the dict protects the caller's rho from the layer's side effect)
             ctl = dict(ctl)
