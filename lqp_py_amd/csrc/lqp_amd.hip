@@ -69,12 +69,12 @@ struct ProfScope {
     ProfScope(hipStream_t s, int c) : st(s), cls(c), on(g_prof_on) {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-            hipEventRecord(a, st);
+            (void)hipEventRecord(a, st);
         }
     }
     ~ProfScope() {
         if (on) {
-            hipEventRecord(b, st);
+            (void)hipEventRecord(b, st);
             std::lock_guard<std::mutex> lock(g_prof_mutex);
             g_prof_recs.push_back({cls, a, b});
         }
@@ -105,14 +105,24 @@ int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, i
 // larger N: 1024 threads, 16 / 8 columns.  LQP_LU_PB / LQP_LU_MFMA / LQP_LU_NT override for experiments.
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
-    if (N <= 512 && N > 64 && env_int("LQP_LU_LA", 0) != 0) {       // lookahead variant (see lqp_lu.cuh)
-        constexpr int PB = 16;
-        const int lds = LuLds<float, PB>(round_up(N, 64)).total;
-        auto fn = k_lu_factor_la<PB>;
-        int rc = ensure_lds((const void*)fn, lds);
-        if (rc) return rc;
-        { ProfScope ps(st, PC_LU);
-          hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, g_lu_dbg); }
+    const int la = env_int("LQP_LU_LA", 0);       // lookahead variants (see lqp_lu.cuh): 1 = 16 columns / 1024
+    if (N <= 512 && N > 64 && la != 0) {           // threads, 2 = 32 columns / 768 threads (8 + 4 waves)
+        int rc;
+        if (la == 2) {
+            const int lds = LuLds<float, 32>(round_up(N, 64)).total;
+            auto fn = k_lu_factor_la<32, 768>;
+            rc = ensure_lds((const void*)fn, lds);
+            if (rc) return rc;
+            ProfScope ps(st, PC_LU);
+            hipLaunchKernelGGL(fn, dim3(B), dim3(768), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, g_lu_dbg);
+        } else {
+            const int lds = LuLds<float, 16>(round_up(N, 64)).total;
+            auto fn = k_lu_factor_la<16, 1024>;
+            rc = ensure_lds((const void*)fn, lds);
+            if (rc) return rc;
+            ProfScope ps(st, PC_LU);
+            hipLaunchKernelGGL(fn, dim3(B), dim3(1024), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, g_lu_dbg);
+        }
         return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
     }
     int nt = lu_threads<float>(N);
@@ -260,13 +270,21 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     n_launch += 2;
 
     // ---- launch mode ----
-    const bool resident = loop_resident_ok(P.K, sizeof(T)) && env_int("LQP_RESIDENT", 1) != 0 &&
+    // hot (first) launch: optional 512-thread build (256 VGPRs per thread: 16 register-resident blocks instead
+    // of 8).  Measured SLOWER at B=128 n=500 (2.03 ms vs 1.54 ms; 1.76 ms with a 6-deep ring and 4 spills):
+    // 8 waves hide the per-block dependent chain worse than 16, which costs more than the 8 extra resident
+    // blocks save.  Kept selectable (LQP_LOOP512=1) for re-measurement; continuation launches always use 1024.
+    const bool res_env = env_int("LQP_RESIDENT", 1) != 0;
+    const bool resident = loop_resident_ok<1024>(P.K, sizeof(T)) && res_env &&
                           loop_lds_bytes<T>(n, m, P.Np, true) <= 160 * 1024;
+    const bool hot512 = resident && loop_resident_ok<512>(P.K, sizeof(T)) && env_int("LQP_LOOP512", 0) != 0;
     const int loop_lds = loop_lds_bytes<T>(n, m, P.Np, resident);
-    auto loop_fn = k_admm_loop<T, false, false>;
-    auto tail_fn = k_admm_loop<T, false, true>;        // same code, own name: continuation launches
+    const int loop_nt = hot512 ? 512 : 1024;
+    auto loop_fn = k_admm_loop<T, false, false, 1024>;
+    auto tail_fn = k_admm_loop<T, false, true, 1024>;        // same code, own name: continuation launches
     if constexpr (sizeof(T) == 4) {
-        if (resident) { loop_fn = k_admm_loop<T, true, false>; tail_fn = k_admm_loop<T, true, true>; }
+        if (resident) { loop_fn = k_admm_loop<T, true, false, 1024>; tail_fn = k_admm_loop<T, true, true, 1024>; }
+        if (hot512) loop_fn = k_admm_loop<T, true, false, 512>;
     }
     rc = ensure_lds((const void*)loop_fn, loop_lds);
     if (rc) return rc;
@@ -281,7 +299,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         int dev = 0, cus = 0, per_cu = 0;
         HIP_OK(hipGetDevice(&dev));
         HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_fn, LQP_NT, loop_lds));
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_fn, loop_nt, loop_lds));
         if (per_cu < 1 || B > cus * per_cu) mode = 1;     // not every workgroup resident: no grid barrier
     }
     const int max_checks_per_launch = kRing / 4;
@@ -331,7 +349,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 }
                 const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
                 { ProfScope ps(st, it == 0 ? PC_LOOP : PC_LOOP_TAIL);
-                  hipLaunchKernelGGL(it == 0 ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), it == 0 ? loop_lds : tail_lds, st,
+                  hipLaunchKernelGGL(it == 0 ? loop_fn : tail_fn, dim3(B), dim3(it == 0 ? loop_nt : LQP_NT), it == 0 ? loop_lds : tail_lds, st,
                                      P, it, e, (int)(c_first % kRing), prev_slot, event ? 3 : 1); }
                 ++n_launch;
                 it = e;
@@ -395,7 +413,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
             { const bool first = (mode == 2 && it == 0) || mode == 1;
               ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);
-              hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(LQP_NT), first ? loop_lds : tail_lds, st, P, it, e,
+              hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(first ? loop_nt : LQP_NT), first ? loop_lds : tail_lds, st, P, it, e,
                                  ctr_base, prev_slot, mode == 2 ? 1 : 0); }
             ++n_launch;
             ++in_chunk;
@@ -624,7 +642,7 @@ void lqp_profile_enable(int on) {
 
 void lqp_profile_reset(void) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    for (auto& r : g_prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof_recs.clear();
     for (int i = 0; i < PC_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; }
 }
@@ -647,7 +665,7 @@ int lqp_profile_get(double* total_ms, long long* launches, int n) {
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return LQP_ERR_HIP;
         g_prof_ms[r.cls] += ms;
         g_prof_n[r.cls] += 1;
-        hipEventDestroy(r.a); hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     g_prof_recs.clear();
     for (int i = 0; i < n && i < PC_COUNT; ++i) { total_ms[i] = g_prof_ms[i]; launches[i] = g_prof_n[i]; }

@@ -354,8 +354,8 @@ __global__ __launch_bounds__(NT) void k_lu_factor(T* __restrict__ Mall, const in
 }
 
 // lookahead LU (f32, N <= 512): panel k+1 on waves 0-7 while waves 8-15 run panel k's trailing update
-template <int PB>
-__global__ __launch_bounds__(LQP_NT) void k_lu_factor_la(float* __restrict__ Mall, const int N, const int ld,
+template <int PB, int NT>
+__global__ __launch_bounds__(NT) void k_lu_factor_la(float* __restrict__ Mall, const int N, const int ld,
                                                          const size_t mstride, int* __restrict__ piv, const int pstride,
                                                          int* __restrict__ info, const int* __restrict__ gate,
                                                          const int* __restrict__ Nvec, unsigned long long* __restrict__ dbg) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_la(float* __restrict__ Mal
     const int b = blockIdx.x;
     if (threadIdx.x == 0) info[b] = 0;
     __syncthreads();
-    wg_lu_factor_la_f32<PB>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld, piv + (size_t)b * pstride, info + b, smem,
+    wg_lu_factor_la_f32<PB, NT>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld, piv + (size_t)b * pstride, info + b, smem,
                             dbg ? dbg + (size_t)b * 4 : nullptr);
 }
 
@@ -393,12 +393,12 @@ template <typename T> __host__ __device__ inline int loop_lds_bytes(int n, int m
            (Np + 64 + 6 * n + m + LQP_NW * 8 + 8) * (int)sizeof(T) + Np * 4;
 }
 // residency applies when the stream is long enough and the ring can stay cyclic over the streamed tail
-__host__ __device__ inline bool loop_resident_ok(int K, size_t elem) {
-    const int S = K * (K + 1);
-    return elem == 4 && S >= LQP_R0 + LQP_PF && ((S - LQP_R0) % LQP_PF) == 0;
+template <int NT> __host__ __device__ inline bool loop_resident_ok(int K, size_t elem) {
+    const int S = K * (K + 1), R0 = resident_total<NT>();
+    return elem == 4 && S >= R0 + LQP_PF && ((S - R0) % LQP_PF) == 0;
 }
 
-template <typename T, int NV>
+template <typename T, int NV, int NWV = LQP_NW>
 __device__ __forceinline__ void wg_max_n(T (&v)[NV], T* red) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -413,7 +413,7 @@ __device__ __forceinline__ void wg_max_n(T (&v)[NV], T* red) {
     for (int q = 0; q < NV; ++q) {
         T r = red[q];
 #pragma unroll
-        for (int ww = 1; ww < LQP_NW; ++ww) r = tmax(r, red[ww * 8 + q]);
+        for (int ww = 1; ww < NWV; ++ww) r = tmax(r, red[ww * 8 + q]);
         v[q] = r;
     }
 }
@@ -439,8 +439,8 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
 // adaptive-rho step of iteration it0 (:237-256) done in-kernel: global decision from the counters of the
 // last check, masked rho update, KKT re-assembly, LU refactorisation and re-pack by this workgroup.  Only
 // this cold variant carries the LU / pack code; the first (hot) launch stays lean.
-template <typename T, bool RES, bool TAIL>
-__global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
+template <typename T, bool RES, bool TAIL, int NT>
+__global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
                                                       const int ctr_base,       // counter slot of check it0 / check
                                                       const int prev_slot,      // slot of the last check before it0, -1: none / known not done
                                                       const int persistent) {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
         }
     }
     if (it0 >= it1) return;
-    if constexpr (TAIL && sizeof(T) == 4) {      // f64 keeps the separate gated kernels (register budget)
+    if constexpr (TAIL && sizeof(T) == 4 && NT == 1024) {      // f64 keeps the separate gated kernels (register budget)
         if ((persistent & 2) && prev_slot >= 0) {
             const unsigned int* ctl = P.counters + (size_t)prev_slot * CT_WORDS;
             if (ctl[CT_WANTS] > 0 && ctl[CT_TRIG] > 0) {                     // uniform over the whole grid
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
                 const T* Qs_ = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
                 assemble_kkt_rows(P, b, Qs_, P.scale ? P.ldq : n, V_, rho_, true);
                 __syncthreads();
-                wg_lu_factor<T, kPB, sizeof(T) == 4, LQP_NT>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
+                wg_lu_factor<T, kPB, sizeof(T) == 4, NT>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
                                                             P.info + b, smem, nullptr);
                 __syncthreads();
                 wg_pack_factor<T>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
     T* D = ub + n;
     T* bs = D + n;
     T* red = bs + m;
-    int* dest = (int*)(red + LQP_NW * 8 + 8);
+    int* dest = (int*)(red + (NT / 64) * 8 + 8);
 
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
@@ -508,27 +508,27 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
     const int S = K * (K + 1);
     const bool cyclic = (S % LQP_PF) == 0;
 
-    BlockStream<T> st;
-    ResidentRegs<T> rr;
+    BlockStream<T, NT> st;
+    ResidentRegs<T, NT> rr;
     if constexpr (RES) {
-        resident_load(rr, lds_res, packed);
-        stream_prime_from(st, packed, LQP_R0, S);
+        resident_load<T, NT>(rr, lds_res, packed);
+        stream_prime_from<T, NT>(st, packed, resident_total<NT>(), S);
     } else {
-        stream_prime(st, packed, S);
+        stream_prime<T, NT>(st, packed, S);
     }
 
-    for (int i = tid; i < n; i += LQP_NT) {
+    for (int i = tid; i < n; i += NT) {
         z[i] = V.z[i]; u[i] = V.u[i]; ps[i] = V.ps[i]; lb[i] = V.lbs[i]; ub[i] = V.ubs[i]; D[i] = V.D[i];
     }
-    for (int r = tid; r < m; r += LQP_NT) bs[r] = V.bs[r];
+    for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
     const int* gdest = P.dest + (size_t)b * Np;
-    for (int i = tid; i < Np; i += LQP_NT) dest[i] = gdest[i];
+    for (int i = tid; i < Np; i += NT) dest[i] = gdest[i];
     __syncthreads();
 
     int slot = ctr_base;
     for (int it = it0; it < it1; ++it) {
         // ---- rhs = [-p + rho (z - u); b], scattered to its pivoted position (:259-262) ----
-        for (int i = tid; i < Np; i += LQP_NT) {
+        for (int i = tid; i < Np; i += NT) {
             T val = T(0);
             if (i < n) val = -ps[i] + rho * (z[i] - u[i]);
             else if (i < N) val = bs[i - n];
@@ -537,17 +537,17 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
         wg_barrier_lds();
         // ---- x-update: cached triangular solves (:267) ----
         if constexpr (RES) {
-            wg_packed_solve_resident(st, rr, lds_res, packed, K, v, tmp, true);
+            wg_packed_solve_resident<T, NT>(st, rr, lds_res, packed, K, v, tmp, true);
         } else {
-            wg_packed_solve(st, packed, K, v, tmp, cyclic);
-            if (!cyclic && it + 1 < it1) stream_prime(st, packed, S);
+            wg_packed_solve<T, NT>(st, packed, K, v, tmp, cyclic);
+            if (!cyclic && it + 1 < it1) stream_prime<T, NT>(st, packed, S);
         }
         // ---- z-update, residuals, dual (:271-282) ----
         const bool check = (it % P.check_solved) == 0;
         T mx[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) mx[q] = T(0);
-        for (int i = tid; i < n; i += LQP_NT) {
+        for (int i = tid; i < n; i += NT) {
             const T xi = v[i];
             const T zp = z[i];
             const T ui = u[i];
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
         if (check) {
             // ---- ||Q x / D||_inf (:299): one wave per row of Qs ----
             T qmax = T(0);
-            for (int i = w; i < n; i += LQP_NW) {
+            for (int i = w; i < n; i += (NT / 64)) {
                 const T* qr = Qs + (size_t)i * ldq;
                 T acc = T(0);
                 for (int j = lane; j < n; j += 64) acc += qr[j] * v[j];
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
                 qmax = tmax(qmax, tabs(acc / D[i]));
             }
             T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], qmax};
-            wg_max_n<T, 6>(mv, red);
+            wg_max_n<T, 6, NT / 64>(mv, red);
             const T tiny = T(1e-16);
             const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
             const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
@@ -618,8 +618,8 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
                     }
                     // leave the loop with the state of iteration `it`
                     __syncthreads();
-                    for (int i = tid; i < n; i += LQP_NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
-                    for (int r = tid; r < m; r += LQP_NT) V.nu[r] = v[n + r];
+                    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
+                    for (int r = tid; r < m; r += NT) V.nu[r] = v[n + r];
                     return;
                 }
             }
@@ -627,8 +627,8 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop(const FwdParams<T> P, cons
         wg_barrier_lds();
     }
     // ---- save state for the next launch / the epilogue ----
-    for (int i = tid; i < n; i += LQP_NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
-    for (int r = tid; r < m; r += LQP_NT) V.nu[r] = v[n + r];
+    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
+    for (int r = tid; r < m; r += NT) V.nu[r] = v[n + r];
 }
 
 // all problems optimal at the check held in `slot` (iteration `it_check`)?  -> DONE
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(LQP_NT) void k_packed_solve(const T* __restrict__ p
     const T* packed = packed_all + (size_t)b * packed_blocks(Kmax) * LQP_BLK;
     const int S = K * (K + 1);
     const bool cyclic = (S % LQP_PF) == 0;
-    BlockStream<T> st;
+    BlockStream<T, LQP_NT> st;
     stream_prime(st, packed, S);
     for (int i = tid; i < Np; i += LQP_NT) dest[i] = dest_all[(size_t)b * Npmax + i];
     __syncthreads();

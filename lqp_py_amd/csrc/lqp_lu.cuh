@@ -502,7 +502,7 @@ __device__ __forceinline__ void lu_trailing_mfma_f32_part(float* __restrict__ A2
     }
 }
 
-template <int PB>
+template <int PB, int NT>
 __device__ __forceinline__ void wg_lu_factor_la_f32(float* __restrict__ A, const int N, const int ld,
                                                     int* __restrict__ ipiv, int* __restrict__ info,
                                                     char* __restrict__ smem, unsigned long long* __restrict__ dbg) {
@@ -674,7 +674,7 @@ __device__ __forceinline__ void wg_lu_factor_la_f32(float* __restrict__ A, const
                                         [&] { group_barrier(cnt + 2, epoch, NPW); });
             }
         } else if (M2 > 0) {
-            lu_trailing_mfma_f32_part<PB>(A + (size_t)k1 * ld + k1, ld, M2, LT, UP, Mpad, NPW, LQP_NW - NPW,
+            lu_trailing_mfma_f32_part<PB>(A + (size_t)k1 * ld + k1, ld, M2, LT, UP, Mpad, NPW, NT / 64 - NPW,
                                           pb1 > 0 ? pb1 : 0);
         }
         if (dbg) { const unsigned long long t1 = clock64(); if (isP) t_p += t1 - tq; else t_u += t1 - tq; }

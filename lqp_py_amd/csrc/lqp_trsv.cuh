@@ -153,54 +153,99 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
 }
 
 // ---------------------------------------------------------------------------
-// streaming solve.  v (LDS, Np elements) holds P*rhs on entry (padding = 0)
-// and the solution on exit; tmp is 64 elements of LDS scratch.  The register
-// ring `buf` must have been primed with stream_prime() (the first LQP_PF
-// blocks), which lets the caller issue those loads early.
+// streaming solve.  v (LDS, Np elements) holds P*rhs on entry (padding = 0) and the solution on exit;
+// tmp is 64 elements of LDS scratch.
+//
+// NT threads walk the block stream together: thread t owns the EPT = 4096 / NT consecutive elements
+// [EPT*t, EPT*(t+1)) of every block (NT = 1024: one 16-B vector, row t>>4; NT = 512: two vectors,
+// row t>>3), so a block is one fully coalesced load instruction (or two) per thread, and the lanes that
+// share a block row are adjacent (16 or 8 lanes): the row dot-product is reduced with DPP only.
+// Loads run LQP_PF blocks ahead of their use through a register ring that wraps into the next solve.
 // ---------------------------------------------------------------------------
-template <typename T> struct BlockStream {
-    V4<T> buf[LQP_PF];
+template <typename T, int NT> struct Frag {
+    static constexpr int NV = LQP_BLK / NT / 4;      // 16-B vectors per thread per block
+    V4<T> q[NV];
+};
+template <typename T, int NT> struct BlockStream {
+    Frag<T, NT> buf[LQP_PF];
 };
 
-template <typename T>
-__device__ __forceinline__ void stream_prime(BlockStream<T>& st, const T* __restrict__ packed, const int S) {
-    const V4<T>* p = (const V4<T>*)packed + threadIdx.x;
+template <typename T, int NT>
+__device__ __forceinline__ Frag<T, NT> frag_load(const T* __restrict__ blk) {
+    Frag<T, NT> f;
+    const V4<T>* p = (const V4<T>*)blk + threadIdx.x * Frag<T, NT>::NV;
 #pragma unroll
-    for (int i = 0; i < LQP_PF; ++i)
-        if (i < S) st.buf[i] = p[(size_t)i * (LQP_BLK / 4)];
+    for (int i = 0; i < Frag<T, NT>::NV; ++i) f.q[i] = p[i];
+    return f;
+}
+template <typename T, int NT>
+__device__ __forceinline__ void frag_store(T* __restrict__ blk, const Frag<T, NT>& f) {
+    V4<T>* p = (V4<T>*)blk + threadIdx.x * Frag<T, NT>::NV;
+#pragma unroll
+    for (int i = 0; i < Frag<T, NT>::NV; ++i) p[i] = f.q[i];
 }
 
 template <typename T>
 __device__ __forceinline__ T dot4(const V4<T>& a, const V4<T>& b) {
     return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2] + a.v[3] * b.v[3];
 }
+// dot of this thread's fragment with the matching slice of an LDS vector (64 values at `vec64`)
+template <typename T, int NT>
+__device__ __forceinline__ T frag_dot(const Frag<T, NT>& f, const T* __restrict__ vec64, const int col0) {
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < Frag<T, NT>::NV; ++i) acc += dot4(f.q[i], *(const V4<T>*)(vec64 + col0 + 4 * i));
+    return acc;
+}
+// sum over the lanes that share a block row (16 lanes for NT = 1024, 8 for NT = 512); all of them get it
+template <int NT, typename T> __device__ __forceinline__ T rowgroup_sum(T v) {
+    v += dpp<0xB1>(v);                // quad_perm [1,0,3,2]
+    v += dpp<0x4E>(v);                // quad_perm [2,3,0,1]
+    if constexpr (NT == 1024) {
+        v += dpp<0x124>(v);           // row_ror:4
+        v += dpp<0x128>(v);           // row_ror:8
+    } else {
+        v += dpp<0x141>(v);           // row_half_mirror: lane i <-> 7 - i inside each group of 8
+    }
+    return v;
+}
+
+template <typename T, int NT = LQP_NT>
+__device__ __forceinline__ void stream_prime(BlockStream<T, NT>& st, const T* __restrict__ packed, const int S) {
+#pragma unroll
+    for (int i = 0; i < LQP_PF; ++i)
+        if (i < S) st.buf[i] = frag_load<T, NT>(packed + (size_t)i * LQP_BLK);
+}
 
 // ---- on-chip residency of the head of the stream --------------------------------------------
 // The loop kernel is at the per-CU streaming limit, so bytes that never leave the chip are pure
-// gain: the first LQP_RREG blocks of the stream live in otherwise idle VGPRs (one 16-B vector per
-// thread per block), the next LQP_RLDS blocks in LDS, for every iteration of the launch; only
-// blocks [R0, S) are streamed through the prefetch ring.  f32 only; needs S >= R0 and, for the
-// cyclic ring, (S - R0) % LQP_PF == 0 (K = 8: 72 blocks, 16 resident, 56 streamed).
+// gain: the first RREG blocks of the stream live in otherwise idle VGPRs, the next LQP_RLDS blocks in
+// LDS, for every iteration of the launch; only blocks [R0, S) are streamed through the prefetch ring.
+// f32 only; needs S >= R0 + LQP_PF and, for the cyclic ring, (S - R0) % LQP_PF == 0 (K = 8: 72 blocks).
+// 1024 threads (128 VGPRs): 8 register blocks; 512 threads (256 VGPRs): 16.
 #ifndef LQP_RREG
 #define LQP_RREG 8      // measured: 8+8 resident blocks, PF 8 is spill-free and fastest (16 spills, 12 needs PF 4)
+#endif
+#ifndef LQP_RREG512
+#define LQP_RREG512 16
 #endif
 #ifndef LQP_RLDS
 #define LQP_RLDS 8
 #endif
-#define LQP_R0 (LQP_RREG + LQP_RLDS)
+template <int NT> __host__ __device__ constexpr int resident_regs() { return NT == 512 ? LQP_RREG512 : LQP_RREG; }
+template <int NT> __host__ __device__ constexpr int resident_total() { return resident_regs<NT>() + LQP_RLDS; }
 
-template <typename T> struct ResidentRegs {
-    V4<T> r[LQP_RREG];
+template <typename T, int NT> struct ResidentRegs {
+    Frag<T, NT> r[resident_regs<NT>()];
 };
 
-template <typename T>
-__device__ __forceinline__ void resident_load(ResidentRegs<T>& rr, T* __restrict__ lds_res, const T* __restrict__ packed) {
-    const V4<T>* p = (const V4<T>*)packed + threadIdx.x;
+template <typename T, int NT>
+__device__ __forceinline__ void resident_load(ResidentRegs<T, NT>& rr, T* __restrict__ lds_res, const T* __restrict__ packed) {
 #pragma unroll
-    for (int i = 0; i < LQP_RREG; ++i) rr.r[i] = p[(size_t)i * (LQP_BLK / 4)];
+    for (int i = 0; i < resident_regs<NT>(); ++i) rr.r[i] = frag_load<T, NT>(packed + (size_t)i * LQP_BLK);
 #pragma unroll
     for (int i = 0; i < LQP_RLDS; ++i)
-        *(V4<T>*)(lds_res + (size_t)i * LQP_BLK + threadIdx.x * 4) = p[(size_t)(LQP_RREG + i) * (LQP_BLK / 4)];
+        frag_store<T, NT>(lds_res + (size_t)i * LQP_BLK, frag_load<T, NT>(packed + (size_t)(resident_regs<NT>() + i) * LQP_BLK));
 }
 
 // walk state of the blocked solve (all wave-uniform)
@@ -210,19 +255,20 @@ template <typename T> struct SolveWalk {
 };
 
 // consume one 64x64 block of the stream
-template <typename T>
-__device__ __forceinline__ void solve_block(SolveWalk<T>& wk, const V4<T>& blk, const int K, T* __restrict__ v,
-                                            T* __restrict__ tmp, const int row, const int cq) {
+template <typename T, int NT>
+__device__ __forceinline__ void solve_block(SolveWalk<T>& wk, const Frag<T, NT>& blk, const int K, T* __restrict__ v,
+                                            T* __restrict__ tmp) {
+    constexpr int EPT = LQP_BLK / NT;               // elements per thread per block
+    constexpr int LPR = LQP_NB / EPT;               // lanes per block row
+    const int row = threadIdx.x / LPR, cq = threadIdx.x % LPR, col0 = cq * EPT;
     if (wk.j != wk.k) {
-        const V4<T> yv = *(const V4<T>*)(v + wk.j * LQP_NB + cq * 4);
-        wk.acc += dot4(blk, yv);
+        wk.acc += frag_dot<T, NT>(blk, v + wk.j * LQP_NB, col0);
         wk.j += wk.phase ? -1 : 1;
     } else {
-        const T a = row16_sum(wk.acc);
+        const T a = rowgroup_sum<NT>(wk.acc);
         if (cq == 0) tmp[row] = v[wk.k * LQP_NB + row] - a;
         wg_barrier_lds();
-        const V4<T> tv = *(const V4<T>*)(tmp + cq * 4);
-        const T y = row16_sum(dot4(blk, tv));
+        const T y = rowgroup_sum<NT>(frag_dot<T, NT>(blk, tmp, col0));
         if (cq == 0) v[wk.k * LQP_NB + row] = y;
         wg_barrier_lds();
         wk.acc = T(0);
@@ -236,96 +282,68 @@ __device__ __forceinline__ void solve_block(SolveWalk<T>& wk, const V4<T>& blk, 
 }
 
 // prime the ring with the first LQP_PF STREAMED blocks (those after the resident head)
-template <typename T>
-__device__ __forceinline__ void stream_prime_from(BlockStream<T>& st, const T* __restrict__ packed, const int first,
+template <typename T, int NT>
+__device__ __forceinline__ void stream_prime_from(BlockStream<T, NT>& st, const T* __restrict__ packed, const int first,
                                                   const int S) {
-    const V4<T>* p = (const V4<T>*)packed + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < LQP_PF; ++i)
-        if (first + i < S) st.buf[i] = p[(size_t)(first + i) * (LQP_BLK / 4)];
+        if (first + i < S) st.buf[i] = frag_load<T, NT>(packed + (size_t)(first + i) * LQP_BLK);
 }
 
 // solve with a resident head: blocks [0, RREG) from registers, [RREG, R0) from LDS, [R0, S) streamed
-template <typename T>
-__device__ __forceinline__ void wg_packed_solve_resident(BlockStream<T>& st, const ResidentRegs<T>& rr,
+template <typename T, int NT>
+__device__ __forceinline__ void wg_packed_solve_resident(BlockStream<T, NT>& st, const ResidentRegs<T, NT>& rr,
                                                          const T* __restrict__ lds_res, const T* __restrict__ packed,
                                                          const int K, T* __restrict__ v, T* __restrict__ tmp,
                                                          const bool cyclic) {
-    const int tid = threadIdx.x;
-    const int row = tid >> 4, cq = tid & 15;
+    constexpr int R0 = resident_total<NT>();
     const int S = K * (K + 1);
     SolveWalk<T> wk;
     wk.phase = 0; wk.k = 0; wk.j = 0; wk.acc = T(0);
 #pragma unroll
-    for (int s = 0; s < LQP_RREG; ++s) solve_block(wk, rr.r[s], K, v, tmp, row, cq);
+    for (int s = 0; s < resident_regs<NT>(); ++s) solve_block<T, NT>(wk, rr.r[s], K, v, tmp);
     for (int s = 0; s < LQP_RLDS; ++s) {
-        const V4<T> blk = *(const V4<T>*)(lds_res + (size_t)s * LQP_BLK + tid * 4);
-        solve_block(wk, blk, K, v, tmp, row, cq);
+        const Frag<T, NT> blk = frag_load<T, NT>(lds_res + (size_t)s * LQP_BLK);
+        solve_block<T, NT>(wk, blk, K, v, tmp);
     }
-    const V4<T>* p = (const V4<T>*)packed + tid;
-    const int Sr = S - LQP_R0;                       // streamed blocks
+    const int Sr = S - R0;                           // streamed blocks
     for (int s0 = 0; s0 < Sr; s0 += LQP_PF) {
 #pragma unroll
         for (int i = 0; i < LQP_PF; ++i) {
             const int s = s0 + i;
             if (s < Sr) {
-                const V4<T> blk = st.buf[i];
+                const Frag<T, NT> blk = st.buf[i];
                 {
                     int nx = s + LQP_PF;
                     if (nx >= Sr && cyclic) nx -= Sr;
-                    if (nx < Sr) st.buf[i] = p[(size_t)(LQP_R0 + nx) * (LQP_BLK / 4)];
+                    if (nx < Sr) st.buf[i] = frag_load<T, NT>(packed + (size_t)(R0 + nx) * LQP_BLK);
                 }
-                solve_block(wk, blk, K, v, tmp, row, cq);
+                solve_block<T, NT>(wk, blk, K, v, tmp);
             }
         }
     }
 }
 
-// cyclic: S % LQP_PF == 0 and the caller will solve again with the same factor:
-// the tail of this solve already fetches the head of the next one.
-template <typename T>
-__device__ __forceinline__ void wg_packed_solve(BlockStream<T>& st, const T* __restrict__ packed, const int K,
+// plain streaming solve (no resident head).  cyclic: S % LQP_PF == 0 and the caller will solve again with
+// the same factor: the tail of this solve already fetches the head of the next one.
+template <typename T, int NT = LQP_NT>
+__device__ __forceinline__ void wg_packed_solve(BlockStream<T, NT>& st, const T* __restrict__ packed, const int K,
                                                 T* __restrict__ v, T* __restrict__ tmp, const bool cyclic) {
-    const int tid = threadIdx.x;
-    const int row = tid >> 4, cq = tid & 15;
     const int S = K * (K + 1);
-    const V4<T>* p = (const V4<T>*)packed + tid;
-    // wave-uniform walk state
-    int phase = 0;              // 0: L (k ascending, j ascending), 1: U (k descending, j descending)
-    int k = 0, j = 0;           // current block row k, next column block j
-    T acc = T(0);
+    SolveWalk<T> wk;
+    wk.phase = 0; wk.k = 0; wk.j = 0; wk.acc = T(0);
     for (int s0 = 0; s0 < S; s0 += LQP_PF) {
 #pragma unroll
         for (int i = 0; i < LQP_PF; ++i) {
             const int s = s0 + i;
             if (s < S) {
-                const V4<T> blk = st.buf[i];
+                const Frag<T, NT> blk = st.buf[i];
                 {
                     int nx = s + LQP_PF;
                     if (nx >= S && cyclic) nx -= S;
-                    if (nx < S) st.buf[i] = p[(size_t)nx * (LQP_BLK / 4)];
+                    if (nx < S) st.buf[i] = frag_load<T, NT>(packed + (size_t)nx * LQP_BLK);
                 }
-                const bool diag = (j == k);
-                if (!diag) {
-                    const V4<T> yv = *(const V4<T>*)(v + j * LQP_NB + cq * 4);
-                    acc += dot4(blk, yv);
-                    j += phase ? -1 : 1;
-                } else {
-                    acc = row16_sum(acc);
-                    if (cq == 0) tmp[row] = v[k * LQP_NB + row] - acc;
-                    wg_barrier_lds();
-                    const V4<T> tv = *(const V4<T>*)(tmp + cq * 4);
-                    T y = row16_sum(dot4(blk, tv));
-                    if (cq == 0) v[k * LQP_NB + row] = y;
-                    wg_barrier_lds();
-                    acc = T(0);
-                    if (phase == 0) {
-                        if (k == K - 1) { phase = 1; j = K - 1; /* k stays K-1 */ }
-                        else { ++k; j = 0; }
-                    } else {
-                        --k; j = K - 1;
-                    }
-                }
+                solve_block<T, NT>(wk, blk, K, v, tmp);
             }
         }
     }
