@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 1
+#define LQP_ABI_VERSION 2
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -62,6 +62,11 @@ typedef struct lqp_boxqp_ctrl {
                                         short adaptive-rho schedule, else ignored): the whole schedule is
                                         enqueued speculatively, stats come back as -1, and the caller fetches
                                         status / info later (lqp_boxqp_forward_layout)                       */
+    int32_t linsolve;                /* x-update linear algebra: 0 auto, 1 pivoted LU of the KKT matrix (the
+                                        reference's, :214-215/:267), 2 symmetric inverse of Qs + rho I with a
+                                        rank-m equality correction (f32, n <= 512, m <= 16, rho > 0; anything
+                                        else, or a matrix that is not positive definite, runs on LU)            */
+    int32_t reserved2;
     double eps_abs;
     double eps_rel;
     double rho_value;
@@ -111,7 +116,8 @@ void lqp_debug_set_lu_counters(void* device_buf);
  * written, one value per problem).  rho_in: B values when rho_mode == 2.  */
 size_t lqp_boxqp_forward_workspace_bytes(int dtype, int B, int n, int m);
 /* Where, inside the workspace, the device-side status block (16 int32: [0] done, [1] final iteration,
- * [3] adaptive-rho refactorisations, [4] rho updated, [5] grid-barrier timeout) and the per-problem LU
+ * [3] adaptive-rho refactorisations, [4] rho updated, [5] grid-barrier timeout, [7] linsolve 2 met a matrix
+ * that is not positive definite: results invalid, repeat with linsolve 1) and the per-problem LU
  * info array (B int32, non-zero = exactly singular) live -- for callers that skipped the host sync
  * (ctrl.reserved = 1) and fetch them asynchronously. */
 int lqp_boxqp_forward_layout(int dtype, int B, int n, int m, size_t* status_offset, size_t* status_bytes,
@@ -164,6 +170,14 @@ int lqp_lu_pack(void* stream, int dtype, int B, int N,
                 const void* LU, const int32_t* piv, void* packed);
 int lqp_lu_solve_packed(void* stream, int dtype, int B, int N, int k,
                         const void* packed, void* rhs_inout);
+
+/* ---- batched SPD inverse (f32, n <= 512) ---------------------------------
+ * Building block of linsolve 2 (the x-update x = H w + c replaces the cached LU solve of
+ * solve_box_qp_admm_torch.py:267): Kinv_out (B,n,n) = K_in^-1 for symmetric positive definite K_in (B,n,n);
+ * info (B) int32: 0, or 1 + index of the first non-positive pivot (K_in not positive definite).           */
+size_t lqp_spd_inverse_workspace_bytes(int dtype, int B, int n);
+int lqp_spd_inverse_batched(void* stream, int dtype, int B, int n, const void* K_in, void* Kinv_out,
+                            int32_t* info_out, void* workspace, size_t workspace_bytes);
 
 /* ---- equality-constrained / unconstrained QP = one KKT solve ------------
  * Replaces torch_solve_qp_eqcon (lqp_py/solve_qp_eqcon_torch.py:6-34, KKT

@@ -14,7 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQP_LIB: A/B builds
-SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_common.cuh"]
+SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
 
 LQP_F32, LQP_F64 = 0, 1
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
@@ -26,7 +26,7 @@ c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_si
 class BoxQPCtrl(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in (
         "max_iters", "check_solved", "adaptive_rho", "adaptive_rho_iter", "adaptive_rho_max_iter", "scale",
-        "any_lb", "any_ub", "rho_mode", "beta_mode", "launch_mode", "reserved")] + [
+        "any_lb", "any_ub", "rho_mode", "beta_mode", "launch_mode", "reserved", "linsolve", "reserved2")] + [
         (k, ctypes.c_double) for k in (
             "eps_abs", "eps_rel", "rho_value", "rho_min", "rho_max", "adaptive_rho_tol",
             "adaptive_rho_threshold", "beta_value")]
@@ -63,6 +63,8 @@ SYMBOLS = {
     "lqp_lu_packed_bytes": (c_size_t, [c_int] * 3),
     "lqp_lu_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "lqp_lu_solve_packed": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "lqp_spd_inverse_workspace_bytes": (c_size_t, [c_int] * 3),
+    "lqp_spd_inverse_batched": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t]),
     "lqp_kkt_solve_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_kkt_solve": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                               ctypes.POINTER(ctypes.c_int32), _P, c_size_t]),
@@ -104,7 +106,7 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.lqp_abi_version() != 1:
+        if lib.lqp_abi_version() != 2:
             raise RuntimeError("lqp_py_amd: ABI version mismatch")
         _lib = lib
         return lib
@@ -189,6 +191,11 @@ def poll_errors(block=False):
         p.event.synchronize()
         _pending.pop(0)
         bad = torch.nonzero(p.info)
+        if p.status is not None and int(p.status[7]):
+            raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): Q + rho I is not "
+                               f"positive definite in float32 (batch index {int(bad[0]) if bad.numel() else -1}); the "
+                               f"symmetric-inverse x-update does not apply: pass control['linsolve']='lu' (or "
+                               f"control['sync']=True, which falls back by itself)")
         if bad.numel():
             raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): LU hit an exactly "
                                f"zero pivot for batch index {int(bad[0])}; the matrix is singular")

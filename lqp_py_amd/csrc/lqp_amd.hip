@@ -56,7 +56,7 @@ int ensure_lds(const void* fn, int bytes) {
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream ----
 enum { PC_SETUP = 0, PC_LU, PC_PACK, PC_LOOP, PC_RHO, PC_EPILOGUE, PC_BWD_BUILD, PC_SOLVE, PC_BWD_EPILOGUE,
-       PC_MISC, PC_LOOP_TAIL, PC_COUNT };
+       PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_COUNT };
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::mutex g_prof_mutex;
 bool g_prof_on = false;
@@ -212,6 +212,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     FwdParams<T>& P = L.P;
     P.B = B; P.n = n; P.m = m; P.N = n + m;
     P.Np = round_up(P.N, LQP_NB); P.K = P.Np / LQP_NB; P.ldq = round_up(n, 4);
+    P.Ks = round_up(n, LQP_NB) / LQP_NB;
     P.vstride = vec_stride(n, m);
     Carver c(ws);
     P.status = c.take<int>(ST_WORDS);
@@ -231,7 +232,8 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
 template <typename T>
 int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void* p, const void* A, const void* b,
                  const void* lb, const void* ub, const lqp_boxqp_ctrl* ctl, const void* rho_in, void* x, void* z,
-                 void* u, void* lams, void* nus, void* rho_out, lqp_boxqp_stats* stats, void* ws, size_t ws_bytes) {
+                 void* u, void* lams, void* nus, void* rho_out, lqp_boxqp_stats* stats, void* ws, size_t ws_bytes,
+                 const bool force_lu = false) {
     FwdLayout<T> L = carve_forward<T>(ws, B, n, m);
     if (ws_bytes < L.bytes) return LQP_ERR_WORKSPACE;
     FwdParams<T>& P = L.P;
@@ -263,11 +265,44 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
         ++n_launch;
     }
-    int rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr);
+    // ---- x-update linear algebra: pivoted LU of the KKT matrix, or the symmetric inverse (lqp_spd.cuh) ----
+    bool spd = false;
+    if constexpr (sizeof(T) == 4) {
+        int want = ctl->linsolve;
+        if (want == 0) want = env_int("LQP_LINSOLVE", 0);
+        const bool rho_pos = !(ctl->rho_mode == 1 && !(ctl->rho_value > 0.0));
+        spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_MAXK && m <= SPD_MAXM;
+    }
+    int rc = LQP_OK;
+    // factorise (gate == nullptr) or refactorise under the device-side gate of k_rho_update
+    auto factor_step = [&](const int* gate) -> int {
+        if constexpr (sizeof(T) == 4) {
+            if (spd) {
+                const int lds = spd_lds_bytes(P.Ks);
+                int r2 = ensure_lds((const void*)k_spd_inverse, lds);
+                if (r2) return r2;
+                { ProfScope ps(st, PC_SPD_INV);
+                  hipLaunchKernelGGL(k_spd_inverse, dim3(B), dim3(LQP_NT), lds, st, P, gate); }
+                ++n_launch;
+                if (m > 0) {
+                    const int lds2 = eqc_lds_bytes(m, P.Ks);
+                    r2 = ensure_lds((const void*)k_eq_correct, lds2);
+                    if (r2) return r2;
+                    ProfScope ps(st, PC_EQ_CORR);
+                    hipLaunchKernelGGL(k_eq_correct, dim3(B), dim3(LQP_NT), lds2, st, P, gate);
+                    ++n_launch;
+                }
+                return LQP_OK;
+            }
+        }
+        int r2 = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, gate);
+        if (r2) return r2;
+        r2 = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, gate);
+        n_launch += 2;
+        return r2;
+    };
+    rc = factor_step(nullptr);
     if (rc) return rc;
-    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr);
-    if (rc) return rc;
-    n_launch += 2;
 
     // ---- launch mode ----
     // hot (first) launch: optional 512-thread build (256 VGPRs per thread: 16 register-resident blocks instead
@@ -278,19 +313,31 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     const bool resident = loop_resident_ok<1024>(P.K, sizeof(T)) && res_env &&
                           loop_lds_bytes<T>(n, m, P.Np, true) <= 160 * 1024;
     const bool hot512 = resident && loop_resident_ok<512>(P.K, sizeof(T)) && env_int("LQP_LOOP512", 0) != 0;
-    const int loop_lds = loop_lds_bytes<T>(n, m, P.Np, resident);
-    const int loop_nt = hot512 ? 512 : 1024;
+    int loop_lds = loop_lds_bytes<T>(n, m, P.Np, resident);
+    int loop_nt = hot512 ? 512 : 1024;
     auto loop_fn = k_admm_loop<T, false, false, 1024>;
     auto tail_fn = k_admm_loop<T, false, true, 1024>;        // same code, own name: continuation launches
+    // the continuation kernel also runs LU + pack (in-kernel adaptive-rho refactor): LDS = max of the three
+    int tail_lds = 0;
+    bool inkernel_refactor = sizeof(T) == 4;
     if constexpr (sizeof(T) == 4) {
         if (resident) { loop_fn = k_admm_loop<T, true, false, 1024>; tail_fn = k_admm_loop<T, true, true, 1024>; }
         if (hot512) loop_fn = k_admm_loop<T, true, false, 512>;
+        if (spd) {
+            P.sym_rl = sym_resident_lds_blocks(n, m, P.Ks);
+            loop_lds = tail_lds = sym_loop_lds_bytes(n, m, P.Ks, P.sym_rl);
+            loop_nt = 1024;
+            loop_fn = k_admm_loop<T, true, false, 1024, true>;
+            tail_fn = k_admm_loop<T, true, true, 1024, true>;
+            inkernel_refactor = false;
+        }
     }
     rc = ensure_lds((const void*)loop_fn, loop_lds);
     if (rc) return rc;
-    // the continuation kernel also runs LU + pack (in-kernel adaptive-rho refactor): LDS = max of the three
-    int tail_lds = std::max(loop_lds, LuLds<T, (sizeof(T) == 4 ? 16 : 8)>(round_up(P.N, 64)).total);
-    tail_lds = std::max(tail_lds, (int)pack_lds_bytes<T>());
+    if (!spd) {
+        tail_lds = std::max(loop_lds, LuLds<T, (sizeof(T) == 4 ? 16 : 8)>(round_up(P.N, 64)).total);
+        tail_lds = std::max(tail_lds, (int)pack_lds_bytes<T>());
+    }
     rc = ensure_lds((const void*)tail_fn, tail_lds);
     if (rc) return rc;
     int mode = ctl->launch_mode;
@@ -317,16 +364,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             while (it < max_iters) {
                 // the adaptive-rho step of iteration `it` runs as the prologue of the continuation kernel
                 bool event = ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter;
-                if (event && sizeof(T) != 4) {          // f64: separate gated kernels
+                if (event && !inkernel_refactor) {      // f64 / symmetric path: separate gated kernels
                     const int last_slot = ((it - 1) / check) % kRing;
                     { ProfScope ps(st, PC_RHO);
                       hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
-                    rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, P.status + ST_GATE);
+                    ++n_launch;
+                    rc = factor_step(P.status + ST_GATE);
                     if (rc) return rc;
-                    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest,
-                                        P.status + ST_GATE);
-                    if (rc) return rc;
-                    n_launch += 3;
                     event = false;
                 }
                 int e = max_iters;
@@ -384,12 +428,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 const int last_slot = ((it - 1) / check) % kRing;
                 { ProfScope ps(st, PC_RHO);
                   hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
-                rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, P.status + ST_GATE);
+                ++n_launch;
+                rc = factor_step(P.status + ST_GATE);
                 if (rc) return rc;
-                rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest,
-                                    P.status + ST_GATE);
-                if (rc) return rc;
-                n_launch += 3;
             }
             // end of this launch
             int e = max_iters;
@@ -436,6 +477,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if (!singular_checked) {
             rc = first_failure(st, P.info, B, &fail_index);      // synchronises
             singular_checked = true;
+            if (rc == LQP_ERR_SINGULAR && spd)      // Qs + rho I not positive definite in f32: the LU path takes it
+                return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
+                                       ws, ws_bytes, true);
             if (rc == LQP_ERR_SINGULAR) {
                 if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
                 return rc;
@@ -653,7 +697,8 @@ int lqp_profile_classes(void) { return PC_COUNT; }
 
 const char* lqp_profile_class_name(int c) {
     static const char* names[PC_COUNT] = {"fwd_setup", "lu_factor", "pack", "admm_loop", "rho_update", "fwd_epilogue",
-                                          "bwd_build", "packed_solve", "bwd_epilogue", "misc", "admm_loop_tail"};
+                                          "bwd_build", "packed_solve", "bwd_epilogue", "misc", "admm_loop_tail",
+                                          "spd_inverse", "eq_correct"};
     return (c >= 0 && c < PC_COUNT) ? names[c] : "?";
 }
 
@@ -741,6 +786,32 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const vo
     if (dtype == LQP_F32)
         return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes);
     return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes);
+}
+
+size_t lqp_spd_inverse_workspace_bytes(int dtype, int B, int n) {
+    if (dtype != LQP_F32 || B < 0 || n < 1) return 0;
+    const int Ks = round_up(n, LQP_NB) / LQP_NB;
+    return (size_t)B * sym_blocks(Ks) * LQP_BLK * sizeof(float) + kAlign;
+}
+
+int lqp_spd_inverse_batched(void* stream, int dtype, int B, int n, const void* K_in, void* Kinv_out, int32_t* info_out,
+                            void* workspace, size_t workspace_bytes) {
+    if (dtype != LQP_F32) return LQP_ERR_UNSUPPORTED;
+    if (B < 0 || n < 1 || !K_in || !Kinv_out || !info_out || !workspace) return LQP_ERR_INVALID;
+    const int Ks = round_up(n, LQP_NB) / LQP_NB;
+    if (Ks > SPD_MAXK) return LQP_ERR_UNSUPPORTED;
+    if (workspace_bytes < lqp_spd_inverse_workspace_bytes(dtype, B, n)) return LQP_ERR_WORKSPACE;
+    if (B == 0) return LQP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace);
+    float* Hs = c.take<float>((size_t)B * sym_blocks(Ks) * LQP_BLK);
+    const int lds = spd_lds_bytes(Ks);
+    int rc = ensure_lds((const void*)k_spd_inverse_dense, lds);
+    if (rc) return rc;
+    { ProfScope ps(st, PC_SPD_INV);
+      hipLaunchKernelGGL(k_spd_inverse_dense, dim3(B), dim3(LQP_NT), lds, st, (const float*)K_in, (float*)Kinv_out, Hs,
+                         (int*)info_out, n, Ks); }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
 size_t lqp_lu_factor_workspace_bytes(int dtype, int B, int N) {

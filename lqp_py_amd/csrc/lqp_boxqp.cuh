@@ -4,12 +4,13 @@
 #include "lqp_common.cuh"
 #include "lqp_lu.cuh"
 #include "lqp_trsv.cuh"
+#include "lqp_spd.cuh"
 
 namespace lqp {
 
 // ---- device-side status block (ints) ---------------------------------------
 enum { ST_DONE = 0, ST_FINAL_ITER = 1, ST_GATE = 2, ST_NFACTOR = 3, ST_RHO_UPDATED = 4,
-       ST_TIMEOUT = 5, ST_NCHECK = 6, ST_WORDS = 16 };
+       ST_TIMEOUT = 5, ST_NCHECK = 6, ST_NOTSPD = 7, ST_WORDS = 16 };
 // per-check counters (uint32 x 4): not-optimal, wants-rho, ratio-trigger, arrivals
 enum { CT_NOTOPT = 0, CT_WANTS = 1, CT_TRIG = 2, CT_ARRIVE = 3, CT_WORDS = 4 };
 // per-problem scalars
@@ -17,6 +18,7 @@ enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_WORDS = 8 };
 
 template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
+    int Ks, sym_rl;                      // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in;
     // outputs
@@ -38,15 +40,17 @@ template <typename T> struct FwdParams {
     T eps_abs, eps_rel, rho_value, rho_min, rho_max, ar_tol, ar_inv_tol, ar_thr, beta_value;
 };
 
-// vector block of problem b: [ps | lbs | ubs | D | z | u | x | As (m*n) | bs | E | nu]
+// vector block of problem b: [ps | lbs | ubs | D | z | u | x | As (m*n) | bs | E | nu | cv | Tm (m*n) | s0]
+// (cv, Tm, s0: constant term c, T = G S^-1 and S^-1 b of the symmetric-inverse path, lqp_spd.cuh)
 template <typename T> struct VecView {
-    T *ps, *lbs, *ubs, *D, *z, *u, *x, *As, *bs, *E, *nu;
+    T *ps, *lbs, *ubs, *D, *z, *u, *x, *As, *bs, *E, *nu, *cv, *Tm, *s0;
     __device__ VecView(T* base, int n, int m) {
         ps = base; lbs = ps + n; ubs = lbs + n; D = ubs + n; z = D + n; u = z + n; x = u + n;
         As = x + n; bs = As + (size_t)m * n; E = bs + m; nu = E + m;
+        cv = nu + m; Tm = cv + n; s0 = Tm + (size_t)m * n;
     }
 };
-__host__ __device__ inline size_t vec_stride(int n, int m) { return (size_t)round_up(7 * n + m * n + 3 * m, 8); }
+__host__ __device__ inline size_t vec_stride(int n, int m) { return (size_t)round_up(8 * n + 2 * m * n + 4 * m, 8); }
 
 // ---------------------------------------------------------------------------
 // setup: norms, auto-scaling, rho, KKT assembly, state init
@@ -439,7 +443,37 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
 // adaptive-rho step of iteration it0 (:237-256) done in-kernel: global decision from the counters of the
 // last check, masked rho update, KKT re-assembly, LU refactorisation and re-pack by this workgroup.  Only
 // this cold variant carries the LU / pack code; the first (hot) launch stays lean.
-template <typename T, bool RES, bool TAIL, int NT>
+// equality duals of the last x-update.  LU path: the tail of the solve vector.  Symmetric path:
+// nu = S^-1 (G^T w - b) = T^T w - s0, with w still in v (one wave per row)
+template <typename T, int NT, bool SYM>
+__device__ __forceinline__ void loop_store_nu(const VecView<T>& V, const T* __restrict__ v, const int n, const int m) {
+    if constexpr (SYM) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int r = w; r < m; r += NT / 64) {
+            T acc = T(0);
+            for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
+            acc = wave_sum(acc);
+            if (lane == 0) V.nu[r] = acc - V.s0[r];
+        }
+    } else {
+        for (int r = threadIdx.x; r < m; r += NT) V.nu[r] = v[n + r];
+    }
+}
+// LDS of the loop on the symmetric path; rl = LDS-resident blocks
+__host__ __device__ inline int sym_loop_lds_bytes(int n, int m, int Ks, int rl) {
+    const int Nps = Ks * LQP_NB;
+    return (rl * LQP_BLK + 4 * Nps + LQP_NW * Nps + 6 * n + m + LQP_NW * 8 + 8) * 4 + 64;
+}
+// how many blocks of the symmetric stream stay in LDS (after the LQP_RREG register blocks)
+__host__ __device__ inline int sym_resident_lds_blocks(int n, int m, int Ks) {
+    const int S = sym_blocks(Ks);
+    int rl = S - LQP_RREG;
+    if (rl < 0) rl = 0;
+    while (rl > 0 && sym_loop_lds_bytes(n, m, Ks, rl) > 160 * 1024) --rl;
+    return rl;
+}
+
+template <typename T, bool RES, bool TAIL, int NT, bool SYM = false>
 __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
                                                       const int ctr_base,       // counter slot of check it0 / check
                                                       const int prev_slot,      // slot of the last check before it0, -1: none / known not done
@@ -460,7 +494,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
         }
     }
     if (it0 >= it1) return;
-    if constexpr (TAIL && sizeof(T) == 4 && NT == 1024) {      // f64 keeps the separate gated kernels (register budget)
+    if constexpr (TAIL && sizeof(T) == 4 && NT == 1024 && !SYM) {   // f64 / symmetric path keep the separate gated kernels
         if ((persistent & 2) && prev_slot >= 0) {
             const unsigned int* ctl = P.counters + (size_t)prev_slot * CT_WORDS;
             if (ctl[CT_WANTS] > 0 && ctl[CT_TRIG] > 0) {                     // uniform over the whole grid
@@ -485,10 +519,18 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
             }
         }
     }
+    // LDS carve.  LU path:  [resident blocks] v tmp | z u ps lb ub D bs red | dest
+    //            SYM path: [resident blocks] v xs ylds cvl part[NW][Nps] | z u ps lb ub D bs red
+    const int Nps = SYM ? P.Ks * LQP_NB : Np;                // padded length of the solve vector
+    const int rl = SYM ? P.sym_rl : LQP_RLDS;
     T* lds_res = (T*)smem;                                   // resident blocks (RES only), 16-KB aligned chunks
-    T* v = lds_res + (RES ? LQP_RLDS * LQP_BLK : 0);
-    T* tmp = v + Np;
-    T* z = tmp + 64;
+    T* v = lds_res + (RES ? (size_t)rl * LQP_BLK : 0);
+    T* tmp = v + Nps;                                        // LU: 64 scratch; SYM: xs (the new x)
+    T* xs = tmp;
+    T* ylds = xs + Nps;
+    T* cvl = ylds + Nps;
+    T* part = cvl + Nps;
+    T* z = SYM ? part + (size_t)(NT / 64) * Nps : tmp + 64;
     T* u = z + n;
     T* ps = u + n;
     T* lb = ps + n;
@@ -496,7 +538,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     T* D = ub + n;
     T* bs = D + n;
     T* red = bs + m;
-    int* dest = (int*)(red + (NT / 64) * 8 + 8);
+    int* dest = (int*)(red + (NT / 64) * 8 + 8);             // LU only
 
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
@@ -505,12 +547,17 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     const int ldq = P.scale ? P.ldq : n;
     const T rho = scal[SC_RHO];
     const T pnorm = scal[SC_PNORM];
-    const int S = K * (K + 1);
+    const int S = SYM ? sym_blocks(P.Ks) : K * (K + 1);
     const bool cyclic = (S % LQP_PF) == 0;
 
     BlockStream<T, NT> st;
     ResidentRegs<T, NT> rr;
-    if constexpr (RES) {
+    if constexpr (SYM) {
+        if constexpr (RES) {
+            sym_resident_load(rr, lds_res, packed, S, rl);
+            sym_prime(st, packed, (S < LQP_RREG ? S : LQP_RREG) + rl, S);
+        }
+    } else if constexpr (RES) {
         resident_load<T, NT>(rr, lds_res, packed);
         stream_prime_from<T, NT>(st, packed, resident_total<NT>(), S);
     } else {
@@ -521,22 +568,42 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
         z[i] = V.z[i]; u[i] = V.u[i]; ps[i] = V.ps[i]; lb[i] = V.lbs[i]; ub[i] = V.ubs[i]; D[i] = V.D[i];
     }
     for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
-    const int* gdest = P.dest + (size_t)b * Np;
-    for (int i = tid; i < Np; i += NT) dest[i] = gdest[i];
+    if constexpr (SYM) {
+        for (int i = tid; i < Nps; i += NT) { cvl[i] = (i < n && m > 0) ? V.cv[i] : T(0); ylds[i] = T(0); }
+    } else {
+        const int* gdest = P.dest + (size_t)b * Np;
+        for (int i = tid; i < Np; i += NT) dest[i] = gdest[i];
+    }
+    const T* xv = SYM ? xs : v;                              // where the x-update leaves x
     __syncthreads();
 
     int slot = ctr_base;
     for (int it = it0; it < it1; ++it) {
         // ---- rhs = [-p + rho (z - u); b], scattered to its pivoted position (:259-262) ----
-        for (int i = tid; i < Np; i += NT) {
-            T val = T(0);
-            if (i < n) val = -ps[i] + rho * (z[i] - u[i]);
-            else if (i < N) val = bs[i - n];
-            v[dest[i]] = val;
+        if constexpr (SYM) {
+            for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
+        } else {
+            for (int i = tid; i < Np; i += NT) {
+                T val = T(0);
+                if (i < n) val = -ps[i] + rho * (z[i] - u[i]);
+                else if (i < N) val = bs[i - n];
+                v[dest[i]] = val;
+            }
         }
         wg_barrier_lds();
-        // ---- x-update: cached triangular solves (:267) ----
-        if constexpr (RES) {
+        // ---- x-update: cached triangular solves (:267), or x = c - Hs w on the symmetric path ----
+        if constexpr (SYM) {
+            wg_sym_gemv<RES>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
+            wg_barrier_lds();
+            for (int e = tid; e < Nps; e += NT) {
+                T y = ylds[e];
+#pragma unroll
+                for (int ww = 0; ww < NT / 64; ++ww) y += part[(size_t)ww * Nps + e];
+                xs[e] = cvl[e] - y;
+                ylds[e] = T(0);
+            }
+            wg_barrier_lds();
+        } else if constexpr (RES) {
             wg_packed_solve_resident<T, NT>(st, rr, lds_res, packed, K, v, tmp, true);
         } else {
             wg_packed_solve<T, NT>(st, packed, K, v, tmp, cyclic);
@@ -548,7 +615,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
 #pragma unroll
         for (int q = 0; q < 5; ++q) mx[q] = T(0);
         for (int i = tid; i < n; i += NT) {
-            const T xi = v[i];
+            const T xi = xv[i];
             const T zp = z[i];
             const T ui = u[i];
             T zn = xi + ui;
@@ -574,7 +641,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
             for (int i = w; i < n; i += (NT / 64)) {
                 const T* qr = Qs + (size_t)i * ldq;
                 T acc = T(0);
-                for (int j = lane; j < n; j += 64) acc += qr[j] * v[j];
+                for (int j = lane; j < n; j += 64) acc += qr[j] * xv[j];
                 acc = wave_sum(acc);
                 qmax = tmax(qmax, tabs(acc / D[i]));
             }
@@ -618,8 +685,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
                     }
                     // leave the loop with the state of iteration `it`
                     __syncthreads();
-                    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
-                    for (int r = tid; r < m; r += NT) V.nu[r] = v[n + r];
+                    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
+                    loop_store_nu<T, NT, SYM>(V, v, n, m);
                     return;
                 }
             }
@@ -627,8 +694,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
         wg_barrier_lds();
     }
     // ---- save state for the next launch / the epilogue ----
-    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = v[i]; }
-    for (int r = tid; r < m; r += NT) V.nu[r] = v[n + r];
+    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
+    loop_store_nu<T, NT, SYM>(V, v, n, m);
 }
 
 // all problems optimal at the check held in `slot` (iteration `it_check`)?  -> DONE
@@ -637,6 +704,149 @@ __global__ void k_check_done(int* status, const unsigned int* counters, const in
         status[ST_FINAL_ITER] = it_check;
         status[ST_DONE] = 1;
     }
+}
+
+// ---------------------------------------------------------------------------
+// symmetric-inverse path (lqp_spd.cuh): Hs = -(Qs + rho I)^-1 on the packed lower blocks, read from the
+// top-left n x n of the assembled KKT matrix M.  Gated like the LU kernel (adaptive-rho refactor).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P, const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x;
+    float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+    wg_sym_init(Hs, P.M + (size_t)b * P.Np * P.Np, P.Np, P.n, P.Ks, 0.f);
+    __syncthreads();
+    wg_spd_sweep(Hs, P.Ks, P.info + b, smem);
+    if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
+}
+
+// standalone SPD inverse (test / utility entry lqp_spd_inverse_batched): dense (B,n,n) in, dense inverse out
+__global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __restrict__ Kin, float* __restrict__ out,
+                                                              float* __restrict__ Hs_all, int* __restrict__ info,
+                                                              const int n, const int Ks) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* Hs = Hs_all + (size_t)b * sym_blocks(Ks) * LQP_BLK;
+    if (tid == 0) info[b] = 0;
+    wg_sym_init(Hs, Kin + (size_t)b * n * n, n, n, Ks, 0.f);
+    __syncthreads();
+    wg_spd_sweep(Hs, Ks, info + b, smem);
+    __syncthreads();
+    float* o = out + (size_t)b * n * n;
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    for (int j = 0; j < Ks; ++j)
+        for (int i = j; i < Ks; ++i) {
+            const V4<float> h = *(const V4<float>*)(Hs + (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4);
+            const int gr = i * 64 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gc = j * 64 + c4 + e;
+                if (gr < n && gc < n) {
+                    o[(size_t)gr * n + gc] = -h.v[e];
+                    if (i != j) o[(size_t)gc * n + gr] = -h.v[e];
+                }
+            }
+        }
+}
+
+// equality rows: G = K^-1 A^T, S = A G, T = G S^-1, c = T b, s0 = S^-1 b, Hs += T G^T  (m <= SPD_MAXM)
+// LDS: v | ylds | part[NW][Nps] | G[m][Nps] | Tl[m][Nps] | Sm[m*m] | Si[m*m]
+__host__ __device__ inline int eqc_lds_bytes(int m, int Ks) {
+    const int Nps = Ks * LQP_NB;
+    return (2 * Nps + LQP_NW * Nps + 2 * m * Nps + 2 * m * m + 8) * 4;
+}
+__global__ __launch_bounds__(LQP_NT) void k_eq_correct(const FwdParams<float> P, const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x, n = P.n, m = P.m, Ks = P.Ks, Nps = Ks * LQP_NB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* v = (float*)smem;
+    float* ylds = v + Nps;
+    float* part = ylds + Nps;
+    float* G = part + (size_t)LQP_NW * Nps;
+    float* Tl = G + (size_t)m * Nps;
+    float* Sm = Tl + (size_t)m * Nps;
+    float* Si = Sm + m * m;
+    VecView<float> V(P.vecs + (size_t)b * P.vstride, n, m);
+    float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+    BlockStream<float, LQP_NT> st;
+    SymResident rr;
+    // ---- G[q] = K^-1 a_q = -(Hs a_q) ----
+    for (int q = 0; q < m; ++q) {
+        for (int i = tid; i < Nps; i += LQP_NT) { v[i] = i < n ? V.As[(size_t)q * n + i] : 0.f; ylds[i] = 0.f; }
+        __syncthreads();
+        wg_sym_gemv<false>(st, rr, nullptr, 0, Hs, Ks, Nps, v, ylds, part);
+        __syncthreads();
+        for (int e = tid; e < Nps; e += LQP_NT) {
+            float y = ylds[e];
+#pragma unroll
+            for (int ww = 0; ww < LQP_NW; ++ww) y += part[(size_t)ww * Nps + e];
+            G[(size_t)q * Nps + e] = -y;
+        }
+        __syncthreads();
+    }
+    // ---- S = A G (m x m), one wave per entry ----
+    for (int t = w; t < m * m; t += LQP_NW) {
+        const int q = t / m, q2 = t - q * m;
+        float acc = 0.f;
+        for (int i = lane; i < n; i += 64) acc += V.As[(size_t)q * n + i] * G[(size_t)q2 * Nps + i];
+        acc = wave_sum(acc);
+        if (lane == 0) Sm[t] = acc;
+    }
+    __syncthreads();
+    // ---- S^-1 by Gauss-Jordan (S is SPD: no pivoting), one thread: m <= 16 ----
+    if (tid == 0) {
+        for (int i = 0; i < m * m; ++i) Si[i] = 0.f;
+        for (int i = 0; i < m; ++i) Si[i * m + i] = 1.f;
+        int bad = 0;
+        for (int c = 0; c < m; ++c) {
+            const float d = Sm[c * m + c];
+            if (!(d > 0.f)) bad = 1;
+            const float inv = d > 0.f ? 1.f / d : 0.f;
+            for (int j = 0; j < m; ++j) { Sm[c * m + j] *= inv; Si[c * m + j] *= inv; }
+            for (int r = 0; r < m; ++r) {
+                if (r == c) continue;
+                const float f = Sm[r * m + c];
+                for (int j = 0; j < m; ++j) { Sm[r * m + j] -= f * Sm[c * m + j]; Si[r * m + j] -= f * Si[c * m + j]; }
+            }
+        }
+        if (bad) { if (P.info[b] == 0) P.info[b] = P.Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient: not this path
+    }
+    __syncthreads();
+    // ---- T = G S^-1, c = T b, s0 = S^-1 b ----
+    for (int t = tid; t < m * Nps; t += LQP_NT) {
+        const int q = t / Nps, e = t - q * Nps;
+        float acc = 0.f;
+        for (int q2 = 0; q2 < m; ++q2) acc += G[(size_t)q2 * Nps + e] * Si[q2 * m + q];
+        Tl[t] = acc;
+        if (e < n) V.Tm[(size_t)q * n + e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += LQP_NT) {
+        float acc = 0.f;
+        for (int q = 0; q < m; ++q) acc += Tl[(size_t)q * Nps + e] * V.bs[q];
+        V.cv[e] = acc;
+    }
+    for (int q = tid; q < m; q += LQP_NT) {
+        float acc = 0.f;
+        for (int q2 = 0; q2 < m; ++q2) acc += Si[q * m + q2] * V.bs[q2];
+        V.s0[q] = acc;
+    }
+    // ---- Hs += T G^T on every lower block ----
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    for (int j = 0; j < Ks; ++j)
+        for (int i = j; i < Ks; ++i) {
+            float* blk = Hs + (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4;
+            V4<float> h = *(const V4<float>*)blk;
+            for (int q = 0; q < m; ++q) {
+                const float t = Tl[(size_t)q * Nps + i * 64 + r];
+                const V4<float> g = *(const V4<float>*)(G + (size_t)q * Nps + j * 64 + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h.v[e] += t * g.v[e];
+            }
+            *(V4<float>*)blk = h;
+        }
 }
 
 // ---------------------------------------------------------------------------

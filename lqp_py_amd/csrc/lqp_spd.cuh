@@ -1,0 +1,356 @@
+// Symmetric "inverse" path of the x-update (f32, n <= 512, few equality rows).
+//
+// The reference solves M [x; nu] = [w; b], M = [[K, A^T], [A, 0]], K = Qs + rho I, with a cached pivoted
+// LU every iteration (lqp_py/solve_box_qp_admm_torch.py:205-215, 258-268).  K is symmetric positive
+// definite whenever the QP is convex and rho > 0, and only x is needed inside the loop, so
+//
+//     x = H w + c,    H = K^-1 - G S^-1 G^T,   G = K^-1 A^T,   S = A G,   c = G S^-1 b,
+//     nu = S^-1 (G^T w - b)                                  (needed once, after the last x-update)
+//
+// H is symmetric: its lower 64x64 blocks are stored once and every block serves BOTH products
+// (y_i += B x_j and y_j += B^T x_i).  Per iteration the loop then moves n^2/2 elements instead of the
+// N^2 of the two triangular solves, has no dependent chain (a GEMV), and its head stays on chip.
+//
+//   wg_spd_sweep      -K^-1 in place on the block-packed lower triangle: block symmetric sweep, each pivot
+//                     block through its Cholesky factor (W = L^-1), all rank-64 updates on MFMA
+//   wg_sym_gemv       y = Hs w from the packed lower blocks (register / LDS resident head + prefetch ring)
+//   k_eq_correct      G, S^-1, T = G S^-1, c, s0 = S^-1 b and the rank-m correction Hs += T G^T
+//
+// Stored matrix Hs = -H (the sweep ends at -K^-1; the sign is folded into the loop: x = c - Hs w).
+// A non-positive pivot (K not positive definite in f32) is reported through info; the host then repeats
+// the solve on the LU path.
+#pragma once
+#include "lqp_common.cuh"
+#include "lqp_lu.cuh"
+#include "lqp_trsv.cuh"
+
+namespace lqp {
+
+constexpr int SPD_LS = 68;          // LDS row stride (floats) of the 64-row operand panels: 16-B aligned, conflict-free b128
+constexpr int SPD_MAXK = 8;         // n <= 512: the (K-1)-block panel + W + W^T fill the 160 KB of LDS
+constexpr int SPD_MAXM = 16;        // equality rows handled by the rank-m correction
+
+__host__ __device__ constexpr int sym_blocks(int K) { return K * (K + 1) / 2; }
+// stream index of lower block (i, j), i >= j: column-major over the lower triangle
+__host__ __device__ constexpr int sym_idx(int i, int j, int K) { return j * K - j * (j - 1) / 2 + (i - j); }
+__host__ __device__ inline int spd_lds_bytes(int K) {
+    return ((K > 1 ? K - 1 : 1) + 2) * 64 * SPD_LS * 4 + 4 * 64 * 4 + 16;
+}
+
+// ---- packed lower blocks <- K = src (+ rho on the diagonal), identity on the padding ----
+__device__ __forceinline__ void wg_sym_init(float* __restrict__ Hs, const float* __restrict__ src, const int ld,
+                                            const int n, const int K, const float rho_add) {
+    const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
+    const bool vec_ok = (ld % 4 == 0) && ((((uintptr_t)src) & 15) == 0);
+    for (int j = 0; j < K; ++j)
+        for (int i = j; i < K; ++i) {
+            const int gr = i * 64 + r, gc = j * 64 + c4;
+            V4<float> v;
+            if (gr < n && gc + 3 < n && vec_ok) {
+                v = *(const V4<float>*)(src + (size_t)gr * ld + gc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v.v[e] = (gr < n && gc + e < n) ? src[(size_t)gr * ld + gc + e] : (gr == gc + e ? 1.f : 0.f);
+            }
+            if (gr < n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (gr == gc + e) v.v[e] += rho_add;
+            }
+            *(V4<float>*)(Hs + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4) = v;
+        }
+}
+
+// one 32x32 output quadrant: acc = X[x0 .. x0+31][0..63] * Z[z0 .. z0+31][0..63]^T, both operands in LDS with
+// row stride SPD_LS.  Lane l feeds row l&31 and the k range 32*(l>>5) .. +31 (any pairing of k values is a
+// valid MFMA schedule as long as A and B agree).
+__device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, const float* __restrict__ Z) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const float* xa = X + li * SPD_LS + 32 * lh;
+    const float* zb = Z + li * SPD_LS + 32 * lh;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const V4<float> a = *(const V4<float>*)(xa + 4 * t);
+        const V4<float> b = *(const V4<float>*)(zb + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[e], b.v[e], acc, 0, 0, 0);
+    }
+    return acc;
+}
+// accumulator register q of lane l is element (row = (q&3) + 8 (q>>2) + 4 (l>>5), col = l&31) of the quadrant
+__device__ __forceinline__ int quad_row(int q, int lh) { return (q & 3) + 8 * (q >> 2) + 4 * lh; }
+
+// ---- block symmetric sweep: Hs (lower blocks of an SPD matrix) -> -inverse, in place ----
+// info: 0, or 1 + index of the first non-positive pivot.
+__device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = tid >> 4, cq = tid & 15, li = lane & 31, lh = lane >> 5;
+    const int nslot = K > 1 ? K - 1 : 1;
+    float* Y = (float*)smem;                       // nslot x 64 x LS: the panel of the current pivot block
+    float* W = Y + (size_t)nslot * 64 * SPD_LS;    // L^-1 of the pivot block (lower)
+    float* WT = W + 64 * SPD_LS;                   // its transpose
+    float* prow = WT + 64 * SPD_LS;                // [2][64] pivot row, by column parity
+    float* pcol = prow + 128;                      // [2][64] pivot column
+    int* flag = (int*)(pcol + 128);
+    if (tid == 0) flag[0] = 0;
+
+    for (int k = 0; k < K; ++k) {
+        // ---- panel blocks A_ik (i != k) into registers; they land while the pivot block is factorised ----
+        V4<float> preg[SPD_MAXK - 1];
+#pragma unroll
+        for (int s = 0; s < SPD_MAXK - 1; ++s) {
+            if (s < K - 1) {
+                const int i = s < k ? s : s + 1;
+                const int blk = i > k ? sym_idx(i, k, K) : sym_idx(k, i, K);
+                preg[s] = *(const V4<float>*)(Hs + (size_t)blk * LQP_BLK + tid * 4);
+            }
+        }
+        // ---- pivot block: in-place forward elimination of [A_kk | I] -> W = L^-1 (A_kk = L L^T) ----
+        // thread (r, cq) keeps elements [r][4cq .. 4cq+3]; column c switches role from "A" to "augmented" at step c
+        V4<float> x = *(const V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4);
+        __syncthreads();                           // previous step's LDS reads are over
+#pragma unroll 1
+        for (int c4 = 0; c4 < 16; ++c4) {
+#pragma unroll
+            for (int e0 = 0; e0 < 4; ++e0) {
+                const int c = c4 * 4 + e0, par = e0 & 1;
+                if (r == c) *(V4<float>*)(prow + par * 64 + cq * 4) = x;
+                if (cq == c4) pcol[par * 64 + r] = x.v[e0];
+                wg_barrier_lds();
+                const float d = prow[par * 64 + c];
+                const bool ok = d > 0.f;
+                if (!ok && tid == 0 && flag[0] == 0) flag[0] = k * 64 + c + 1;
+                const float s = ok ? 1.f / sqrtf(d) : 0.f;
+                const V4<float> pr = *(const V4<float>*)(prow + par * 64 + cq * 4);
+                const float f = pcol[par * 64 + r] * s;
+                if (r > c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x.v[e] -= f * (pr.v[e] * s);
+                    if (cq == c4) x.v[e0] = -f * s;
+                } else if (r == c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x.v[e] *= s;
+                    if (cq == c4) x.v[e0] = s;
+                }
+            }
+        }
+        // W (lower, zero above the diagonal) and W^T
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = cq * 4 + e;
+            if (q > r) x.v[e] = 0.f;
+            WT[q * SPD_LS + r] = x.v[e];
+        }
+        *(V4<float>*)(W + r * SPD_LS + cq * 4) = x;
+        // ---- panel to LDS: slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k ----
+#pragma unroll
+        for (int s = 0; s < SPD_MAXK - 1; ++s) {
+            if (s < K - 1) {
+                float* Ys = Y + (size_t)s * 64 * SPD_LS;
+                if (s >= k) {
+                    *(V4<float>*)(Ys + r * SPD_LS + cq * 4) = preg[s];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ys[(cq * 4 + e) * SPD_LS + r] = preg[s].v[e];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Y_i = P_i W^T (in place: all products first, then the writes) ----
+        {
+            const int ntask = (K - 1) * 4;
+            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                if (task < ntask) {
+                    const int s = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                    acc[u] = spd_quadrant(Y + ((size_t)s * 64 + 32 * qi) * SPD_LS, W + (32 * qj) * SPD_LS);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                if (task < ntask) {
+                    const int s = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                    float* dst = Y + ((size_t)s * 64 + 32 * qi) * SPD_LS + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) dst[quad_row(q, lh) * SPD_LS] = acc[u][q];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- all writes of this step (every task only READS LDS) ----
+        //   [0, nupd):            A_ij -= Y_i Y_j^T            (i >= j, both != k)
+        //   [nupd, nupd + npan):  A_ik  = Y_i W  (stored as block (i,k), or as its transpose W^T Y_i^T in (k,i))
+        //   last 4:               A_kk  = -(W^T W)
+        {
+            const int npair = (K - 1) * K / 2;
+            const int nupd = npair * 4, npan = (K - 1) * 4, ntask = nupd + npan + 4;
+            for (int task = __builtin_amdgcn_readfirstlane(w); task < ntask; task += LQP_NW) {
+                const int qi = (task >> 1) & 1, qj = task & 1;
+                if (task < nupd) {
+                    const int p = task >> 2;
+                    int si = 0;
+                    while ((si + 1) * (si + 2) / 2 <= p) ++si;
+                    const int sj = p - si * (si + 1) / 2;
+                    const int i = si < k ? si : si + 1, j = sj < k ? sj : sj + 1;
+                    float* C = Hs + (size_t)sym_idx(i, j, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+                    f32x16 cur;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];     // in flight under the MFMA chain
+                    const f32x16 acc = spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS,
+                                                    Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
+                    cur -= acc;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                } else if (task < nupd + npan) {
+                    const int s = (task - nupd) >> 2;
+                    const int i = s < k ? s : s + 1;
+                    const float* Ys = Y + (size_t)s * 64 * SPD_LS;
+                    f32x16 acc;
+                    float* C;
+                    if (i > k) {
+                        acc = spd_quadrant(Ys + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS);
+                        C = Hs + (size_t)sym_idx(i, k, K) * LQP_BLK;
+                    } else {
+                        acc = spd_quadrant(WT + (32 * qi) * SPD_LS, Ys + (32 * qj) * SPD_LS);
+                        C = Hs + (size_t)sym_idx(k, i, K) * LQP_BLK;
+                    }
+                    C += (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = acc[q];
+                } else {
+                    const f32x16 acc = spd_quadrant(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS);
+                    float* C = Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = -acc[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
+// ---------------------------------------------------------------------------
+// y = Hs w from the packed lower blocks.  Thread t owns elements [4t, 4t+4) of every block (row t>>4, columns
+// 4 (t&15) ..), as in the triangular stream.  Blocks arrive column by column (j, then i = j .. K-1):
+//   product 1  y_i[r] += sum_c B[r][c] w_j[c]   row sum: 16 adjacent lanes (DPP), added to ylds by its owner thread
+//   product 2  y_j[c] += sum_r B[r][c] w_i[r]   kept in 4 registers over the whole block column, reduced over the
+//              4 rows of the wave at the end of the column and written to this wave's own slice part[w][.]
+// so no barrier is needed inside the product.  The caller combines y[e] = ylds[e] + sum_w part[w][e] after a
+// barrier.  Blocks [0, LQP_RREG) live in registers, the next `rl` in LDS, the rest stream through the ring
+// (which wraps into the next call: virtual length padded to a multiple of LQP_PF).
+// ---------------------------------------------------------------------------
+struct SymWalk {
+    int i, j;
+    V4<float> wj;          // w_j slice of this thread's 4 columns
+    float acc2[4];
+};
+
+__device__ __forceinline__ void sym_begin(SymWalk& wk, const float* __restrict__ v) {
+    wk.i = 0; wk.j = 0;
+    wk.wj = *(const V4<float>*)(v + (threadIdx.x & 15) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wk.acc2[e] = 0.f;
+}
+
+__device__ __forceinline__ void sym_block(SymWalk& wk, const Frag<float, LQP_NT>& blk, const int K, const int Np,
+                                          const float* __restrict__ v, float* __restrict__ ylds,
+                                          float* __restrict__ part) {
+    const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
+    const V4<float> b = blk.q[0];
+    const float s1 = rowgroup_sum<LQP_NT>(dot4(b, wk.wj));
+    if (cq == 0) ylds[wk.i * 64 + r] += s1;
+    if (wk.i != wk.j) {
+        const float wi = v[wk.i * 64 + r];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wk.acc2[e] += b.v[e] * wi;
+    }
+    if (++wk.i == K) {
+        // end of block column j: fold the 4 rows this wave holds, publish 64 column sums
+        V4<float> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = wk.acc2[e];
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            o.v[e] = a;
+            wk.acc2[e] = 0.f;
+        }
+        if (lane < 16) *(V4<float>*)(part + (size_t)w * Np + wk.j * 64 + cq * 4) = o;
+        ++wk.j;
+        wk.i = wk.j;
+        if (wk.j < K) wk.wj = *(const V4<float>*)(v + wk.j * 64 + cq * 4);
+    }
+}
+
+// register-resident head of the symmetric stream
+typedef ResidentRegs<float, LQP_NT> SymResident;
+__device__ __forceinline__ void sym_resident_load(SymResident& rr, float* __restrict__ lds_res,
+                                                  const float* __restrict__ Hs, const int S, const int rl) {
+#pragma unroll
+    for (int i = 0; i < LQP_RREG; ++i)
+        if (i < S) rr.r[i] = frag_load<float, LQP_NT>(Hs + (size_t)i * LQP_BLK);
+    for (int i = 0; i < rl; ++i)
+        frag_store<float, LQP_NT>(lds_res + (size_t)i * LQP_BLK,
+                                  frag_load<float, LQP_NT>(Hs + (size_t)(LQP_RREG + i) * LQP_BLK));
+}
+// prime the ring with the first streamed blocks
+__device__ __forceinline__ void sym_prime(BlockStream<float, LQP_NT>& st, const float* __restrict__ Hs,
+                                          const int first, const int S) {
+#pragma unroll
+    for (int i = 0; i < LQP_PF; ++i)
+        if (first + i < S) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(first + i) * LQP_BLK);
+}
+
+// RES: resident head (registers + rl LDS blocks) and a ring that already holds the first streamed blocks and is
+// refilled cyclically; !RES: everything streamed, ring primed here, not cyclic.
+template <bool RES>
+__device__ __forceinline__ void wg_sym_gemv(BlockStream<float, LQP_NT>& st, const SymResident& rr,
+                                            const float* __restrict__ lds_res, const int rl,
+                                            const float* __restrict__ Hs, const int K, const int Np,
+                                            const float* __restrict__ v, float* __restrict__ ylds,
+                                            float* __restrict__ part) {
+    const int S = sym_blocks(K);
+    SymWalk wk;
+    sym_begin(wk, v);
+    int R0 = 0;
+    if constexpr (RES) {
+#pragma unroll
+        for (int s = 0; s < LQP_RREG; ++s)
+            if (s < S) sym_block(wk, rr.r[s], K, Np, v, ylds, part);
+        for (int s = 0; s < rl; ++s) {
+            const Frag<float, LQP_NT> blk = frag_load<float, LQP_NT>(lds_res + (size_t)s * LQP_BLK);
+            sym_block(wk, blk, K, Np, v, ylds, part);
+        }
+        R0 = (S < LQP_RREG ? S : LQP_RREG) + rl;
+    } else {
+        sym_prime(st, Hs, 0, S);
+    }
+    const int Sr = S - R0;                                  // streamed blocks
+    const int Sv = round_up(Sr, LQP_PF);                    // virtual ring length
+    for (int s0 = 0; s0 < Sv; s0 += LQP_PF) {
+#pragma unroll
+        for (int i = 0; i < LQP_PF; ++i) {
+            const int s = s0 + i;
+            if (s < Sr) {
+                const Frag<float, LQP_NT> blk = st.buf[i];
+                int nx = s + LQP_PF;
+                if (RES && nx >= Sv) nx -= Sv;
+                if (nx < Sr) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
+                sym_block(wk, blk, K, Np, v, ylds, part);
+            } else if (RES) {
+                const int nx = s + LQP_PF - Sv;             // padding slot: only refill it for the next call
+                if (nx >= 0 && nx < Sr) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
+            }
+        }
+    }
+}
+
+}  // namespace lqp

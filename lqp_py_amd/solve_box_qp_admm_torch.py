@@ -208,6 +208,7 @@ def resolve_control(control, n_x):
         beta=g('beta'),
         verbose=g('verbose', False),
         launch_mode=g('launch_mode', 0),         # extension: 0 auto, 1 segmented, 2 persistent
+        linsolve=g('linsolve', 'auto'),          # extension: 'auto' | 'lu' (the reference's cached LU) | 'spd'
     )
 
 
@@ -222,6 +223,9 @@ def _rho_argument(rho, B, like):
     if rho.numel() != B:
         _bad("a rho tensor must hold one value per problem, e.g. shape (B,1,1)")
     return 2, 0.0, rho.detach().to(device=like.device, dtype=like.dtype).reshape(B).contiguous()
+
+
+_LINSOLVE = {'auto': 0, 'lu': 1, 'spd': 2, 0: 0, 1: 1, 2: 2}
 
 
 def _bad(msg):
@@ -247,7 +251,10 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True):
     Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
     rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, p)
 
+    if r['linsolve'] not in _LINSOLVE:
+        _bad("control['linsolve'] must be 'auto', 'lu' or 'spd'")
     ctl = _lib.BoxQPCtrl(
+        linsolve=_LINSOLVE[r['linsolve']],
         max_iters=int(r['max_iters']), check_solved=int(r['check_solved']),
         adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
         adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),

@@ -14,7 +14,7 @@ Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=0)
 M = O.kkt_matrix(Q + 1.2 * torch.eye(n), A).to(dev)
 N = M.shape[1]
 dbg = torch.zeros(B * 4, dtype=torch.int64, device=dev)
-for (nt, pb, mfma, la) in ((768, 32, 1, 2), (1024, 16, 1, 1), (512, 32, 1, 0)):
+for (nt, pb, mfma, la) in ((512, 32, 1, 0), (512, 16, 1, 0), (1024, 16, 1, 0)):
     if True:
         os.environ["LQP_LU_LA"] = str(la)
         os.environ["LQP_LU_NT"] = str(nt)
