@@ -19,6 +19,7 @@ enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_WORDS = 8 };
 template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
     int Ks, sym_rl;                      // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
+    unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in;
     // outputs
@@ -462,7 +463,7 @@ __device__ __forceinline__ void loop_store_nu(const VecView<T>& V, const T* __re
 // LDS of the loop on the symmetric path; rl = LDS-resident blocks
 __host__ __device__ inline int sym_loop_lds_bytes(int n, int m, int Ks, int rl) {
     const int Nps = Ks * LQP_NB;
-    return (rl * LQP_BLK + 4 * Nps + LQP_NW * Nps + 6 * n + m + LQP_NW * 8 + 8) * 4 + 64;
+    return (rl * LQP_BLK + 3 * Nps + sym_blocks(Ks) * 64 + LQP_NW * Nps + 6 * n + 2 * m + LQP_NW * 8 + 8) * 4 + 64;
 }
 // how many blocks of the symmetric stream stay in LDS (after the LQP_RREG register blocks)
 __host__ __device__ inline int sym_resident_lds_blocks(int n, int m, int Ks) {
@@ -527,8 +528,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     T* v = lds_res + (RES ? (size_t)rl * LQP_BLK : 0);
     T* tmp = v + Nps;                                        // LU: 64 scratch; SYM: xs (the new x)
     T* xs = tmp;
-    T* ylds = xs + Nps;
-    T* cvl = ylds + Nps;
+    T* ylds = xs + Nps;                                      // SYM: one 64-slot per block of the stream
+    T* cvl = ylds + (SYM ? sym_blocks(P.Ks) * 64 : 0);
     T* part = cvl + Nps;
     T* z = SYM ? part + (size_t)(NT / 64) * Nps : tmp + 64;
     T* u = z + n;
@@ -537,14 +538,12 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     T* ub = lb + n;
     T* D = ub + n;
     T* bs = D + n;
-    T* red = bs + m;
+    T* red = bs + (SYM ? 2 * m : m);                        // SYM: nu of the current check sits behind bs
     int* dest = (int*)(red + (NT / 64) * 8 + 8);             // LU only
 
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
     const T* packed = P.packed + (size_t)b * packed_blocks(K) * LQP_BLK;
-    const T* Qs = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
-    const int ldq = P.scale ? P.ldq : n;
     const T rho = scal[SC_RHO];
     const T pnorm = scal[SC_PNORM];
     const int S = SYM ? sym_blocks(P.Ks) : K * (K + 1);
@@ -569,7 +568,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     }
     for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
     if constexpr (SYM) {
-        for (int i = tid; i < Nps; i += NT) { cvl[i] = (i < n && m > 0) ? V.cv[i] : T(0); ylds[i] = T(0); }
+        for (int i = tid; i < Nps; i += NT) cvl[i] = (i < n && m > 0) ? V.cv[i] : T(0);
     } else {
         const int* gdest = P.dest + (size_t)b * Np;
         for (int i = tid; i < Np; i += NT) dest[i] = gdest[i];
@@ -577,8 +576,11 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     const T* xv = SYM ? xs : v;                              // where the x-update leaves x
     __syncthreads();
 
+    unsigned long long dbt[4] = {0, 0, 0, 0}, dt0 = 0;      // debug: cycles in rhs / product / combine / update+check
+    const bool dbg_on = SYM && P.dbg != nullptr;
     int slot = ctr_base;
     for (int it = it0; it < it1; ++it) {
+        if (dbg_on) dt0 = clock64();
         // ---- rhs = [-p + rho (z - u); b], scattered to its pivoted position (:259-262) ----
         if constexpr (SYM) {
             for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
@@ -591,18 +593,15 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
             }
         }
         wg_barrier_lds();
+        if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
         // ---- x-update: cached triangular solves (:267), or x = c - Hs w on the symmetric path ----
         if constexpr (SYM) {
             wg_sym_gemv<RES>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
             wg_barrier_lds();
-            for (int e = tid; e < Nps; e += NT) {
-                T y = ylds[e];
-#pragma unroll
-                for (int ww = 0; ww < NT / 64; ++ww) y += part[(size_t)ww * Nps + e];
-                xs[e] = cvl[e] - y;
-                ylds[e] = T(0);
-            }
+            if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
+            for (int e = tid; e < Nps; e += NT) xs[e] = cvl[e] - sym_combine(e, P.Ks, Nps, ylds, part);
             wg_barrier_lds();
+            if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
         } else if constexpr (RES) {
             wg_packed_solve_resident<T, NT>(st, rr, lds_res, packed, K, v, tmp, true);
         } else {
@@ -611,9 +610,25 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
         }
         // ---- z-update, residuals, dual (:271-282) ----
         const bool check = (it % P.check_solved) == 0;
-        T mx[5];
+        T mx[6];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) mx[q] = T(0);
+        for (int q = 0; q < 6; ++q) mx[q] = T(0);
+        // ||Q x / D||_inf of the check (:299) without touching Q: the x-update solved (Qs + rho I) x + As^T nu = w
+        // exactly (to the solve's rounding), so Qs x = w - rho x - As^T nu.  It only feeds a tolerance SCALE.
+        const T* nul = v + n;                                // LU path: nu is the tail of the solution
+        if constexpr (SYM) {
+            if (check && m > 0) {                            // nu = T^T w - s0, one wave per row
+                T* nus_l = bs + m;
+                for (int r = w; r < m; r += (NT / 64)) {
+                    T acc = T(0);
+                    for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
+                    acc = wave_sum(acc);
+                    if (lane == 0) nus_l[r] = acc - V.s0[r];
+                }
+                wg_barrier_lds();
+            }
+            nul = bs + m;
+        }
         for (int i = tid; i < n; i += NT) {
             const T xi = xv[i];
             const T zp = z[i];
@@ -633,19 +648,13 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
                 mx[2] = tmax(mx[2], tabs(di * xi));
                 mx[3] = tmax(mx[3], tabs(di * zn));
                 mx[4] = tmax(mx[4], tabs((rho * di) * un));
+                T qx = -ps[i] + rho * (zp - ui) - rho * xi;
+                for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nul[q];
+                mx[5] = tmax(mx[5], tabs(qx / di));
             }
         }
         if (check) {
-            // ---- ||Q x / D||_inf (:299): one wave per row of Qs ----
-            T qmax = T(0);
-            for (int i = w; i < n; i += (NT / 64)) {
-                const T* qr = Qs + (size_t)i * ldq;
-                T acc = T(0);
-                for (int j = lane; j < n; j += 64) acc += qr[j] * xv[j];
-                acc = wave_sum(acc);
-                qmax = tmax(qmax, tabs(acc / D[i]));
-            }
-            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], qmax};
+            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], mx[5]};
             wg_max_n<T, 6, NT / 64>(mv, red);
             const T tiny = T(1e-16);
             const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
@@ -687,12 +696,19 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
                     __syncthreads();
                     for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
                     loop_store_nu<T, NT, SYM>(V, v, n, m);
+                    if (dbg_on && tid == 0) {
+                        dbt[3] += clock64() - dt0;
+                        for (int q = 0; q < 4; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
+                    }
                     return;
                 }
             }
         }
         wg_barrier_lds();
+        if (dbg_on) { const unsigned long long t = clock64(); dbt[3] += t - dt0; }
     }
+    if (dbg_on && tid == 0)
+        for (int q = 0; q < 4; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
     // ---- save state for the next launch / the epilogue ----
     for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
     loop_store_nu<T, NT, SYM>(V, v, n, m);
@@ -717,7 +733,7 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P
     float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
     wg_sym_init(Hs, P.M + (size_t)b * P.Np * P.Np, P.Np, P.n, P.Ks, 0.f);
     __syncthreads();
-    wg_spd_sweep(Hs, P.Ks, P.info + b, smem);
+    wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
     if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
 }
 
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __res
 // LDS: v | ylds | part[NW][Nps] | G[m][Nps] | Tl[m][Nps] | Sm[m*m] | Si[m*m]
 __host__ __device__ inline int eqc_lds_bytes(int m, int Ks) {
     const int Nps = Ks * LQP_NB;
-    return (2 * Nps + LQP_NW * Nps + 2 * m * Nps + 2 * m * m + 8) * 4;
+    return (Nps + sym_blocks(Ks) * 64 + LQP_NW * Nps + 2 * m * Nps + 2 * m * m + 8) * 4;
 }
 __global__ __launch_bounds__(LQP_NT) void k_eq_correct(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -763,7 +779,7 @@ __global__ __launch_bounds__(LQP_NT) void k_eq_correct(const FwdParams<float> P,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* v = (float*)smem;
     float* ylds = v + Nps;
-    float* part = ylds + Nps;
+    float* part = ylds + sym_blocks(Ks) * 64;
     float* G = part + (size_t)LQP_NW * Nps;
     float* Tl = G + (size_t)m * Nps;
     float* Sm = Tl + (size_t)m * Nps;
@@ -774,16 +790,11 @@ __global__ __launch_bounds__(LQP_NT) void k_eq_correct(const FwdParams<float> P,
     SymResident rr;
     // ---- G[q] = K^-1 a_q = -(Hs a_q) ----
     for (int q = 0; q < m; ++q) {
-        for (int i = tid; i < Nps; i += LQP_NT) { v[i] = i < n ? V.As[(size_t)q * n + i] : 0.f; ylds[i] = 0.f; }
+        for (int i = tid; i < Nps; i += LQP_NT) v[i] = i < n ? V.As[(size_t)q * n + i] : 0.f;
         __syncthreads();
         wg_sym_gemv<false>(st, rr, nullptr, 0, Hs, Ks, Nps, v, ylds, part);
         __syncthreads();
-        for (int e = tid; e < Nps; e += LQP_NT) {
-            float y = ylds[e];
-#pragma unroll
-            for (int ww = 0; ww < LQP_NW; ++ww) y += part[(size_t)ww * Nps + e];
-            G[(size_t)q * Nps + e] = -y;
-        }
+        for (int e = tid; e < Nps; e += LQP_NT) G[(size_t)q * Nps + e] = -sym_combine(e, Ks, Nps, ylds, part);
         __syncthreads();
     }
     // ---- S = A G (m x m), one wave per entry ----

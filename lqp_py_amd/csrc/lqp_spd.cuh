@@ -85,7 +85,8 @@ __device__ __forceinline__ int quad_row(int q, int lh) { return (q & 3) + 8 * (q
 
 // ---- block symmetric sweep: Hs (lower blocks of an SPD matrix) -> -inverse, in place ----
 // info: 0, or 1 + index of the first non-positive pivot.
-__device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem) {
+__device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem,
+                                             unsigned long long* __restrict__ dbg = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = tid >> 4, cq = tid & 15, li = lane & 31, lh = lane >> 5;
     const int nslot = K > 1 ? K - 1 : 1;
@@ -96,8 +97,10 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
     float* pcol = prow + 128;                      // [2][64] pivot column
     int* flag = (int*)(pcol + 128);
     if (tid == 0) flag[0] = 0;
+    unsigned long long tp = 0, ty = 0, tu = 0, t0 = 0, tb = dbg ? clock64() : 0;   // debug cycle counters
 
     for (int k = 0; k < K; ++k) {
+        if (dbg) t0 = clock64();
         // ---- panel blocks A_ik (i != k) into registers; they land while the pivot block is factorised ----
         V4<float> preg[SPD_MAXK - 1];
 #pragma unroll
@@ -112,6 +115,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
         // thread (r, cq) keeps elements [r][4cq .. 4cq+3]; column c switches role from "A" to "augmented" at step c
         V4<float> x = *(const V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4);
         __syncthreads();                           // previous step's LDS reads are over
+        int bad = 0;                               // first non-positive pivot of this block (+1)
 #pragma unroll 1
         for (int c4 = 0; c4 < 16; ++c4) {
 #pragma unroll
@@ -120,23 +124,23 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                 if (r == c) *(V4<float>*)(prow + par * 64 + cq * 4) = x;
                 if (cq == c4) pcol[par * 64 + r] = x.v[e0];
                 wg_barrier_lds();
+                // three independent LDS reads, then a branch-free update (the chain per column is what costs)
                 const float d = prow[par * 64 + c];
-                const bool ok = d > 0.f;
-                if (!ok && tid == 0 && flag[0] == 0) flag[0] = k * 64 + c + 1;
-                const float s = ok ? 1.f / sqrtf(d) : 0.f;
                 const V4<float> pr = *(const V4<float>*)(prow + par * 64 + cq * 4);
-                const float f = pcol[par * 64 + r] * s;
-                if (r > c) {
+                const float pc = pcol[par * 64 + r];
+                const bool ok = d > 0.f;
+                if (!ok && bad == 0) bad = k * 64 + c + 1;
+                const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
+                const float f = pc * s;
+                const bool below = r > c, on = r == c;
+                const float coef = below ? f * s : 0.f;      // rows below the pivot: x -= (f s) * pivot row
+                const float mult = on ? s : 1.f;             // the pivot row itself is scaled by s
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x.v[e] -= f * (pr.v[e] * s);
-                    if (cq == c4) x.v[e0] = -f * s;
-                } else if (r == c) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x.v[e] *= s;
-                    if (cq == c4) x.v[e0] = s;
-                }
+                for (int e = 0; e < 4; ++e) x.v[e] = (x.v[e] - coef * pr.v[e]) * mult;
+                if (cq == c4) x.v[e0] = below ? -f * s : (on ? s : x.v[e0]);
             }
         }
+        if (bad != 0 && tid == 0 && flag[0] == 0) flag[0] = bad;
         // W (lower, zero above the diagonal) and W^T
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -159,6 +163,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             }
         }
         __syncthreads();
+        if (dbg) { const unsigned long long t = clock64(); tp += t - t0; t0 = t; }
         // ---- Y_i = P_i W^T (in place: all products first, then the writes) ----
         {
             const int ntask = (K - 1) * 4;
@@ -184,6 +189,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             }
             __syncthreads();
         }
+        if (dbg) { const unsigned long long t = clock64(); ty += t - t0; t0 = t; }
         // ---- all writes of this step (every task only READS LDS) ----
         //   [0, nupd):            A_ij -= Y_i Y_j^T            (i >= j, both != k)
         //   [nupd, nupd + npan):  A_ik  = Y_i W  (stored as block (i,k), or as its transpose W^T Y_i^T in (k,i))
@@ -233,28 +239,30 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             }
         }
         __syncthreads();
+        if (dbg) { const unsigned long long t = clock64(); tu += t - t0; }
     }
+    if (dbg && tid == 0) { dbg[4] = tp; dbg[5] = ty; dbg[6] = tu; dbg[7] = clock64() - tb; }
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
 
 // ---------------------------------------------------------------------------
 // y = Hs w from the packed lower blocks.  Thread t owns elements [4t, 4t+4) of every block (row t>>4, columns
 // 4 (t&15) ..), as in the triangular stream.  Blocks arrive column by column (j, then i = j .. K-1):
-//   product 1  y_i[r] += sum_c B[r][c] w_j[c]   row sum: 16 adjacent lanes (DPP), added to ylds by its owner thread
+//   product 1  y_i[r] += sum_c B[r][c] w_j[c]   row sum: 16 adjacent lanes (DPP), written to the block's own slot
+//              ylds[s][r] (s = stream index of the block)
 //   product 2  y_j[c] += sum_r B[r][c] w_i[r]   kept in 4 registers over the whole block column, reduced over the
 //              4 rows of the wave at the end of the column and written to this wave's own slice part[w][.]
-// so no barrier is needed inside the product.  The caller combines y[e] = ylds[e] + sum_w part[w][e] after a
-// barrier.  Blocks [0, LQP_RREG) live in registers, the next `rl` in LDS, the rest stream through the ring
+// so no barrier is needed inside the product.  The caller combines (sym_combine) after a barrier.  Blocks [0, LQP_RREG) live in registers, the next `rl` in LDS, the rest stream through the ring
 // (which wraps into the next call: virtual length padded to a multiple of LQP_PF).
 // ---------------------------------------------------------------------------
 struct SymWalk {
-    int i, j;
+    int i, j, s;
     V4<float> wj;          // w_j slice of this thread's 4 columns
     float acc2[4];
 };
 
 __device__ __forceinline__ void sym_begin(SymWalk& wk, const float* __restrict__ v) {
-    wk.i = 0; wk.j = 0;
+    wk.i = 0; wk.j = 0; wk.s = 0;
     wk.wj = *(const V4<float>*)(v + (threadIdx.x & 15) * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) wk.acc2[e] = 0.f;
@@ -266,7 +274,8 @@ __device__ __forceinline__ void sym_block(SymWalk& wk, const Frag<float, LQP_NT>
     const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
     const V4<float> b = blk.q[0];
     const float s1 = rowgroup_sum<LQP_NT>(dot4(b, wk.wj));
-    if (cq == 0) ylds[wk.i * 64 + r] += s1;
+    if (cq == 0) ylds[wk.s * 64 + r] = s1;           // one slot per block: write-only, no read-modify-write stall
+    ++wk.s;
     if (wk.i != wk.j) {
         const float wi = v[wk.i * 64 + r];
 #pragma unroll
@@ -307,6 +316,17 @@ __device__ __forceinline__ void sym_prime(BlockStream<float, LQP_NT>& st, const 
 #pragma unroll
     for (int i = 0; i < LQP_PF; ++i)
         if (first + i < S) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(first + i) * LQP_BLK);
+}
+
+// y[e] for e = 64 i + r: the row sums of blocks (i, j <= i) plus the 16 column partials
+__device__ __forceinline__ float sym_combine(const int e, const int K, const int Np, const float* __restrict__ ylds,
+                                             const float* __restrict__ part) {
+    const int i = e >> 6, r = e & 63;
+    float y = 0.f;
+    for (int j = 0; j <= i; ++j) y += ylds[sym_idx(i, j, K) * 64 + r];
+#pragma unroll
+    for (int ww = 0; ww < LQP_NW; ++ww) y += part[(size_t)ww * Np + e];
+    return y;
 }
 
 // RES: resident head (registers + rl LDS blocks) and a ring that already holds the first streamed blocks and is

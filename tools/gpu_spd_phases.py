@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""In-kernel cycle breakdown of the symmetric-inverse forward path (debug counters)."""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from lqp_py_amd import _lib
+import lqp_py_amd.solve_box_qp_admm_torch as L
+from oracle import boxqp_oracle as O
+dev = torch.device("cuda:0")
+lib = _lib.load()
+B, n = int(os.environ.get("BATCH", "128")), int(os.environ.get("N_X", "500"))
+inp = [t.to(dev) for t in O.create_qp_data(n, B, seed=0)]
+ctl = O.make_control(eps_abs=1e-5, eps_rel=1e-5, linsolve="spd")
+sol = L.torch_solve_box_qp(*inp, dict(ctl))
+dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
+lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
+sol = L.torch_solve_box_qp(*inp, dict(ctl))
+torch.cuda.synchronize()
+lib.lqp_debug_set_lu_counters(None)
+c = dbg.view(B, 8).double().mean(0).tolist()
+it = sol["iter"] + 1
+print(f"iters {it}; loop cycles/iter: rhs {c[0]/it:.0f} product {c[1]/it:.0f} combine {c[2]/it:.0f} update+check {c[3]/it:.0f} | total/iter {sum(c[:4])/it:.0f}")
+print(f"sweep cycles: pivot+panel-load {c[4]:.0f} panel->LDS+Y {c[5]:.0f} tasks {c[6]:.0f} total {c[7]:.0f}")
