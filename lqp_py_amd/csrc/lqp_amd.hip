@@ -255,6 +255,17 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     const int ar_iter = ctl->adaptive_rho_iter < 1 ? 1 : ctl->adaptive_rho_iter;
     int n_launch = 0;
 
+    // ---- x-update linear algebra: pivoted LU of the KKT matrix, or the symmetric inverse (lqp_spd.cuh) ----
+    bool spd = false;
+    if constexpr (sizeof(T) == 4) {
+        int want = ctl->linsolve;
+        if (want == 0) want = env_int("LQP_LINSOLVE", 0);
+        const bool rho_pos = !(ctl->rho_mode == 1 && !(ctl->rho_value > 0.0));
+        spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_MAXK && m <= SPD_MAXM;
+    }
+    P.spd = spd ? 1 : 0;
+    P.ar_iter = ar_iter; P.ar_max = ctl->adaptive_rho_max_iter; P.ring = kRing;
+
     // ---- zero status + counter ring, setup, factor, pack ----
     HIP_OK(hipMemsetAsync(P.status, 0, (char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status, st));
     {
@@ -266,33 +277,17 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
         ++n_launch;
     }
-    // ---- x-update linear algebra: pivoted LU of the KKT matrix, or the symmetric inverse (lqp_spd.cuh) ----
-    bool spd = false;
-    if constexpr (sizeof(T) == 4) {
-        int want = ctl->linsolve;
-        if (want == 0) want = env_int("LQP_LINSOLVE", 0);
-        const bool rho_pos = !(ctl->rho_mode == 1 && !(ctl->rho_value > 0.0));
-        spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_MAXK && m <= SPD_MAXM;
-    }
     int rc = LQP_OK;
     // factorise (gate == nullptr) or refactorise under the device-side gate of k_rho_update
     auto factor_step = [&](const int* gate) -> int {
         if constexpr (sizeof(T) == 4) {
             if (spd) {
-                const int lds = spd_lds_bytes(P.Ks);
-                int r2 = ensure_lds((const void*)k_spd_inverse, lds);
+                const int lds = spd_factor_lds_bytes(m, P.Ks);
+                const int r2 = ensure_lds((const void*)k_spd_inverse, lds);
                 if (r2) return r2;
-                { ProfScope ps(st, PC_SPD_INV);
-                  hipLaunchKernelGGL(k_spd_inverse, dim3(B), dim3(LQP_NT), lds, st, P, gate); }
+                ProfScope ps(st, PC_SPD_INV);
+                hipLaunchKernelGGL(k_spd_inverse, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                 ++n_launch;
-                if (m > 0) {
-                    const int lds2 = eqc_lds_bytes(m, P.Ks);
-                    r2 = ensure_lds((const void*)k_eq_correct, lds2);
-                    if (r2) return r2;
-                    ProfScope ps(st, PC_EQ_CORR);
-                    hipLaunchKernelGGL(k_eq_correct, dim3(B), dim3(LQP_NT), lds2, st, P, gate);
-                    ++n_launch;
-                }
                 return LQP_OK;
             }
         }
@@ -326,11 +321,11 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if (hot512) loop_fn = k_admm_loop<T, true, false, 512>;
         if (spd) {
             P.sym_rl = sym_resident_lds_blocks(n, m, P.Ks);
-            loop_lds = tail_lds = sym_loop_lds_bytes(n, m, P.Ks, P.sym_rl);
+            loop_lds = sym_loop_lds_bytes(n, m, P.Ks, P.sym_rl);
+            tail_lds = std::max(loop_lds, spd_factor_lds_bytes(m, P.Ks));      // the tail refactorises in-kernel
             loop_nt = 1024;
             loop_fn = k_admm_loop<T, true, false, 1024, true>;
             tail_fn = k_admm_loop<T, true, true, 1024, true>;
-            inkernel_refactor = false;
         }
     }
     rc = ensure_lds((const void*)loop_fn, loop_lds);
@@ -375,7 +370,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     event = false;
                 }
                 int e = max_iters;
-                if (ctl->adaptive_rho) {
+                if (ctl->adaptive_rho && !(spd && it > 0)) {      // (the symmetric tail walks through its events itself)
                     const int a = (it / ar_iter + 1) * ar_iter;
                     if (a < ctl->adaptive_rho_max_iter) e = std::min(e, a);
                 }
@@ -395,7 +390,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
                 { ProfScope ps(st, it == 0 ? PC_LOOP : PC_LOOP_TAIL);
                   hipLaunchKernelGGL(it == 0 ? loop_fn : tail_fn, dim3(B), dim3(it == 0 ? loop_nt : LQP_NT), it == 0 ? loop_lds : tail_lds, st,
-                                     P, it, e, (int)(c_first % kRing), prev_slot, event ? 3 : 1); }
+                                     P, it, e, (int)(c_first % kRing), prev_slot, (event || (spd && it > 0)) ? 3 : 1); }
                 ++n_launch;
                 it = e;
             }
@@ -425,7 +420,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         const int cap_now = (mode == 2) ? 1 : chunk_cap;       // persistent: the kernel itself stops at convergence
         while (it < max_iters && in_chunk < cap_now) {
             // adaptive-rho event at the start of iteration `it` (:237)
-            if (ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter) {
+            const bool tail_events = spd && mode == 2;       // symmetric path, persistent: events inside the tail kernel
+            if (!tail_events && ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter) {
                 const int last_slot = ((it - 1) / check) % kRing;
                 { ProfScope ps(st, PC_RHO);
                   hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
@@ -438,7 +434,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             const int next_check = ((it + check - 1) / check) * check;
             if (mode == 1) e = std::min(e, next_check + 1);
             else e = std::min(e, next_check + 1 + (max_checks_per_launch - 1) * check);
-            if (ctl->adaptive_rho) {
+            if (ctl->adaptive_rho && !(tail_events && it > 0)) {
                 const int a = (it / ar_iter + 1) * ar_iter;
                 if (a < ctl->adaptive_rho_max_iter) e = std::min(e, a);
             }
@@ -456,7 +452,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             { const bool first = (mode == 2 && it == 0) || mode == 1;
               ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);
               hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(first ? loop_nt : LQP_NT), first ? loop_lds : tail_lds, st, P, it, e,
-                                 ctr_base, prev_slot, mode == 2 ? 1 : 0); }
+                                 ctr_base, prev_slot, mode == 2 ? ((tail_events && !first) ? 3 : 1) : 0); }
             ++n_launch;
             ++in_chunk;
             it = e;

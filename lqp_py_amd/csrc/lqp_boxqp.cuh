@@ -20,6 +20,8 @@ template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
     int Ks, sym_rl;                      // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
+    int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
+    int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in;
     // outputs
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v.v[e] = (di * v.v[e]) * dj.v[e]; fro2 += v.v[e] * v.v[e]; }
                     *(V4<T>*)(qo + j) = v;
-                    *(V4<T>*)(mo + j) = v;
+                    if (!P.spd) *(V4<T>*)(mo + j) = v;
                 }
             }
         } else {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
                 for (int j = lane; j < n; j += 64) {
                     const T v = (di * qr[j]) * d[j];
                     qo[j] = v;
-                    mo[j] = v;
+                    if (!P.spd) mo[j] = v;
                     fro2 += v * v;
                 }
             }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     }
     for (int r = tid; r < m; r += LQP_NT) V.nu[r] = T(0);
     __syncthreads();
-    assemble_kkt_rows(P, b, Qs, ldq, V, rho, !q_in_m);
+    if (!P.spd) assemble_kkt_rows(P, b, Qs, ldq, V, rho, !q_in_m);
 }
 
 // ---------------------------------------------------------------------------
@@ -444,6 +446,164 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
 // adaptive-rho step of iteration it0 (:237-256) done in-kernel: global decision from the counters of the
 // last check, masked rho update, KKT re-assembly, LU refactorisation and re-pack by this workgroup.  Only
 // this cold variant carries the LU / pack code; the first (hot) launch stays lean.
+// ---------------------------------------------------------------------------
+// symmetric-inverse path (lqp_spd.cuh): factorisation kernels
+// ---------------------------------------------------------------------------
+// standalone SPD inverse (test / utility entry lqp_spd_inverse_batched): dense (B,n,n) in, dense inverse out
+__global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __restrict__ Kin, float* __restrict__ out,
+                                                              float* __restrict__ Hs_all, int* __restrict__ info,
+                                                              const int n, const int Ks) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* Hs = Hs_all + (size_t)b * sym_blocks(Ks) * LQP_BLK;
+    if (tid == 0) info[b] = 0;
+    wg_sym_init(Hs, Kin + (size_t)b * n * n, n, n, Ks, 0.f);
+    __syncthreads();
+    wg_spd_sweep(Hs, Ks, info + b, smem);
+    __syncthreads();
+    float* o = out + (size_t)b * n * n;
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    for (int j = 0; j < Ks; ++j)
+        for (int i = j; i < Ks; ++i) {
+            const V4<float> h = *(const V4<float>*)(Hs + (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4);
+            const int gr = i * 64 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gc = j * 64 + c4 + e;
+                if (gr < n && gc < n) {
+                    o[(size_t)gr * n + gc] = -h.v[e];
+                    if (i != j) o[(size_t)gc * n + gr] = -h.v[e];
+                }
+            }
+        }
+}
+
+// equality rows: G = K^-1 A^T, S = A G, T = G S^-1, c = T b, s0 = S^-1 b, Hs += T G^T  (m <= SPD_MAXM)
+// LDS: v | ylds | part[NW][Nps] | G[m][Nps] | Tl[m][Nps] | Sm[m*m] | Si[m*m]
+__host__ __device__ inline int eqc_lds_bytes(int m, int Ks) {
+    const int Nps = Ks * LQP_NB;
+    return (Nps + sym_blocks(Ks) * 64 + LQP_NW * Nps + 2 * m * Nps + 2 * m * m + 8) * 4;
+}
+__device__ __forceinline__ void wg_eq_correct(const FwdParams<float>& P, const int b, char* smem) {
+    const int n = P.n, m = P.m, Ks = P.Ks, Nps = Ks * LQP_NB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* v = (float*)smem;
+    float* ylds = v + Nps;
+    float* part = ylds + sym_blocks(Ks) * 64;
+    float* G = part + (size_t)LQP_NW * Nps;
+    float* Tl = G + (size_t)m * Nps;
+    float* Sm = Tl + (size_t)m * Nps;
+    float* Si = Sm + m * m;
+    VecView<float> V(P.vecs + (size_t)b * P.vstride, n, m);
+    float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+    BlockStream<float, LQP_NT> st;
+    SymResident rr;
+    // ---- G[q] = K^-1 a_q = -(Hs a_q) ----
+    for (int q = 0; q < m; ++q) {
+        for (int i = tid; i < Nps; i += LQP_NT) v[i] = i < n ? V.As[(size_t)q * n + i] : 0.f;
+        __syncthreads();
+        wg_sym_gemv<false>(st, rr, nullptr, 0, Hs, Ks, Nps, v, ylds, part);
+        __syncthreads();
+        for (int e = tid; e < Nps; e += LQP_NT) G[(size_t)q * Nps + e] = -sym_combine(e, Ks, Nps, ylds, part);
+        __syncthreads();
+    }
+    // ---- S = A G (m x m), one wave per entry ----
+    for (int t = w; t < m * m; t += LQP_NW) {
+        const int q = t / m, q2 = t - q * m;
+        float acc = 0.f;
+        for (int i = lane; i < n; i += 64) acc += V.As[(size_t)q * n + i] * G[(size_t)q2 * Nps + i];
+        acc = wave_sum(acc);
+        if (lane == 0) Sm[t] = acc;
+    }
+    __syncthreads();
+    // ---- S^-1 by Gauss-Jordan (S is SPD: no pivoting), one thread: m <= 16 ----
+    if (tid == 0) {
+        for (int i = 0; i < m * m; ++i) Si[i] = 0.f;
+        for (int i = 0; i < m; ++i) Si[i * m + i] = 1.f;
+        int bad = 0;
+        for (int c = 0; c < m; ++c) {
+            const float d = Sm[c * m + c];
+            if (!(d > 0.f)) bad = 1;
+            const float inv = d > 0.f ? 1.f / d : 0.f;
+            for (int j = 0; j < m; ++j) { Sm[c * m + j] *= inv; Si[c * m + j] *= inv; }
+            for (int r = 0; r < m; ++r) {
+                if (r == c) continue;
+                const float f = Sm[r * m + c];
+                for (int j = 0; j < m; ++j) { Sm[r * m + j] -= f * Sm[c * m + j]; Si[r * m + j] -= f * Si[c * m + j]; }
+            }
+        }
+        if (bad) { if (P.info[b] == 0) P.info[b] = P.Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient: not this path
+    }
+    __syncthreads();
+    // ---- T = G S^-1, c = T b, s0 = S^-1 b ----
+    for (int t = tid; t < m * Nps; t += LQP_NT) {
+        const int q = t / Nps, e = t - q * Nps;
+        float acc = 0.f;
+        for (int q2 = 0; q2 < m; ++q2) acc += G[(size_t)q2 * Nps + e] * Si[q2 * m + q];
+        Tl[t] = acc;
+        if (e < n) V.Tm[(size_t)q * n + e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += LQP_NT) {
+        float acc = 0.f;
+        for (int q = 0; q < m; ++q) acc += Tl[(size_t)q * Nps + e] * V.bs[q];
+        V.cv[e] = acc;
+    }
+    for (int q = tid; q < m; q += LQP_NT) {
+        float acc = 0.f;
+        for (int q2 = 0; q2 < m; ++q2) acc += Si[q * m + q2] * V.bs[q2];
+        V.s0[q] = acc;
+    }
+    // ---- Hs += T G^T on every lower block ----
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    for (int j = 0; j < Ks; ++j)
+        for (int i = j; i < Ks; ++i) {
+            float* blk = Hs + (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4;
+            V4<float> h = *(const V4<float>*)blk;
+            for (int q = 0; q < m; ++q) {
+                const float t = Tl[(size_t)q * Nps + i * 64 + r];
+                const V4<float> g = *(const V4<float>*)(G + (size_t)q * Nps + j * 64 + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h.v[e] += t * g.v[e];
+            }
+            *(V4<float>*)blk = h;
+        }
+}
+
+// (re)factorisation of the symmetric path for problem b: Hs = -(Qs + rho I)^-1, then the equality correction.
+// check_sym: also verify that Qs is symmetric to rounding (the sweep only ever reads its lower triangle); a
+// matrix that is not goes to the LU path like one that is not positive definite.
+__device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const int b, const float rho, char* smem,
+                                              const bool check_sym) {
+    float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+    const float* Qs = P.scale ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
+    const int ldq = P.scale ? P.ldq : P.n;
+    if (check_sym) {
+        float* red = (float*)smem;
+        const float asym = wg_sym_asymmetry(Qs, ldq, P.n, P.Ks, red);
+        if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
+        __syncthreads();
+    }
+    wg_sym_init(Hs, Qs, ldq, P.n, P.Ks, rho);
+    __syncthreads();
+    wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
+    if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
+    if (P.m > 0) {
+        __syncthreads();
+        wg_eq_correct(P, b, smem);
+    }
+}
+__host__ __device__ inline int spd_factor_lds_bytes(int m, int Ks) {
+    const int a = spd_lds_bytes(Ks), c = m > 0 ? eqc_lds_bytes(m, Ks) : 0;
+    return a > c ? a : c;
+}
+__global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P, const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x;
+    wg_spd_factor(P, b, P.scal[(size_t)b * SC_WORDS + SC_RHO], smem, gate == nullptr);
+}
+
 // equality duals of the last x-update.  LU path: the tail of the solve vector.  Symmetric path:
 // nu = S^-1 (G^T w - b) = T^T w - s0, with w still in v (one wave per row)
 template <typename T, int NT, bool SYM>
@@ -544,6 +704,33 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
     const T* packed = P.packed + (size_t)b * packed_blocks(K) * LQP_BLK;
+    // The continuation launch of the symmetric path walks through SEGMENTS [seg0, seg1) that end at the
+    // adaptive-rho events (:237-256) and refactorises in between, inside the kernel; every other build runs
+    // exactly one segment [it0, it1).
+    int seg0 = it0;
+    const int it_end = it1;
+  while (true) {
+    int seg1 = it_end;
+    if constexpr (TAIL && SYM) {
+        if (P.adaptive_rho && (persistent & 2)) {
+            const int nxt = (seg0 / P.ar_iter + 1) * P.ar_iter;
+            if (nxt < P.ar_max && nxt < seg1) seg1 = nxt;
+            if (seg0 > 0 && seg0 % P.ar_iter == 0 && seg0 < P.ar_max) {
+                const unsigned int* ctl = P.counters + (size_t)(((seg0 - 1) / P.check_solved) % P.ring) * CT_WORDS;
+                if (ctl[CT_WANTS] > 0 && ctl[CT_TRIG] > 0) {                 // uniform over the whole grid
+                    T rho_ = scal[SC_RHO];
+                    if (scal[SC_WANTS] != T(0)) rho_ = rho_ * scal[SC_RATIO];
+                    rho_ = tmin(tmax(rho_, P.rho_min), P.rho_max);
+                    __syncthreads();
+                    if (tid == 0) scal[SC_RHO] = rho_;
+                    if (b == 0 && tid == 0) { P.status[ST_NFACTOR] += 1; P.status[ST_RHO_UPDATED] = 1; }
+                    wg_spd_factor(P, b, rho_, smem, false);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    const int it0 = seg0, it1 = seg1;                        // (shadow the launch bounds inside the segment)
     const T rho = scal[SC_RHO];
     const T pnorm = scal[SC_PNORM];
     const int S = SYM ? sym_blocks(P.Ks) : K * (K + 1);
@@ -578,7 +765,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
 
     unsigned long long dbt[4] = {0, 0, 0, 0}, dt0 = 0;      // debug: cycles in rhs / product / combine / update+check
     const bool dbg_on = SYM && P.dbg != nullptr;
-    int slot = ctr_base;
+    int slot = (TAIL && SYM) ? ((it0 + P.check_solved - 1) / P.check_solved) % P.ring : ctr_base;
     for (int it = it0; it < it1; ++it) {
         if (dbg_on) dt0 = clock64();
         // ---- rhs = [-p + rho (z - u); b], scattered to its pivoted position (:259-262) ----
@@ -712,6 +899,10 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     // ---- save state for the next launch / the epilogue ----
     for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
     loop_store_nu<T, NT, SYM>(V, v, n, m);
+    if (!(TAIL && SYM) || seg1 >= it_end) break;
+    seg0 = seg1;
+    __syncthreads();
+  }
 }
 
 // all problems optimal at the check held in `slot` (iteration `it_check`)?  -> DONE
@@ -720,144 +911,6 @@ __global__ void k_check_done(int* status, const unsigned int* counters, const in
         status[ST_FINAL_ITER] = it_check;
         status[ST_DONE] = 1;
     }
-}
-
-// ---------------------------------------------------------------------------
-// symmetric-inverse path (lqp_spd.cuh): Hs = -(Qs + rho I)^-1 on the packed lower blocks, read from the
-// top-left n x n of the assembled KKT matrix M.  Gated like the LU kernel (adaptive-rho refactor).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P, const int* __restrict__ gate) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
-    if (gate && *gate == 0) return;
-    const int b = blockIdx.x;
-    float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
-    wg_sym_init(Hs, P.M + (size_t)b * P.Np * P.Np, P.Np, P.n, P.Ks, 0.f);
-    __syncthreads();
-    wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
-    if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
-}
-
-// standalone SPD inverse (test / utility entry lqp_spd_inverse_batched): dense (B,n,n) in, dense inverse out
-__global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __restrict__ Kin, float* __restrict__ out,
-                                                              float* __restrict__ Hs_all, int* __restrict__ info,
-                                                              const int n, const int Ks) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float* Hs = Hs_all + (size_t)b * sym_blocks(Ks) * LQP_BLK;
-    if (tid == 0) info[b] = 0;
-    wg_sym_init(Hs, Kin + (size_t)b * n * n, n, n, Ks, 0.f);
-    __syncthreads();
-    wg_spd_sweep(Hs, Ks, info + b, smem);
-    __syncthreads();
-    float* o = out + (size_t)b * n * n;
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
-    for (int j = 0; j < Ks; ++j)
-        for (int i = j; i < Ks; ++i) {
-            const V4<float> h = *(const V4<float>*)(Hs + (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4);
-            const int gr = i * 64 + r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gc = j * 64 + c4 + e;
-                if (gr < n && gc < n) {
-                    o[(size_t)gr * n + gc] = -h.v[e];
-                    if (i != j) o[(size_t)gc * n + gr] = -h.v[e];
-                }
-            }
-        }
-}
-
-// equality rows: G = K^-1 A^T, S = A G, T = G S^-1, c = T b, s0 = S^-1 b, Hs += T G^T  (m <= SPD_MAXM)
-// LDS: v | ylds | part[NW][Nps] | G[m][Nps] | Tl[m][Nps] | Sm[m*m] | Si[m*m]
-__host__ __device__ inline int eqc_lds_bytes(int m, int Ks) {
-    const int Nps = Ks * LQP_NB;
-    return (Nps + sym_blocks(Ks) * 64 + LQP_NW * Nps + 2 * m * Nps + 2 * m * m + 8) * 4;
-}
-__global__ __launch_bounds__(LQP_NT) void k_eq_correct(const FwdParams<float> P, const int* __restrict__ gate) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
-    if (gate && *gate == 0) return;
-    const int b = blockIdx.x, n = P.n, m = P.m, Ks = P.Ks, Nps = Ks * LQP_NB;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float* v = (float*)smem;
-    float* ylds = v + Nps;
-    float* part = ylds + sym_blocks(Ks) * 64;
-    float* G = part + (size_t)LQP_NW * Nps;
-    float* Tl = G + (size_t)m * Nps;
-    float* Sm = Tl + (size_t)m * Nps;
-    float* Si = Sm + m * m;
-    VecView<float> V(P.vecs + (size_t)b * P.vstride, n, m);
-    float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
-    BlockStream<float, LQP_NT> st;
-    SymResident rr;
-    // ---- G[q] = K^-1 a_q = -(Hs a_q) ----
-    for (int q = 0; q < m; ++q) {
-        for (int i = tid; i < Nps; i += LQP_NT) v[i] = i < n ? V.As[(size_t)q * n + i] : 0.f;
-        __syncthreads();
-        wg_sym_gemv<false>(st, rr, nullptr, 0, Hs, Ks, Nps, v, ylds, part);
-        __syncthreads();
-        for (int e = tid; e < Nps; e += LQP_NT) G[(size_t)q * Nps + e] = -sym_combine(e, Ks, Nps, ylds, part);
-        __syncthreads();
-    }
-    // ---- S = A G (m x m), one wave per entry ----
-    for (int t = w; t < m * m; t += LQP_NW) {
-        const int q = t / m, q2 = t - q * m;
-        float acc = 0.f;
-        for (int i = lane; i < n; i += 64) acc += V.As[(size_t)q * n + i] * G[(size_t)q2 * Nps + i];
-        acc = wave_sum(acc);
-        if (lane == 0) Sm[t] = acc;
-    }
-    __syncthreads();
-    // ---- S^-1 by Gauss-Jordan (S is SPD: no pivoting), one thread: m <= 16 ----
-    if (tid == 0) {
-        for (int i = 0; i < m * m; ++i) Si[i] = 0.f;
-        for (int i = 0; i < m; ++i) Si[i * m + i] = 1.f;
-        int bad = 0;
-        for (int c = 0; c < m; ++c) {
-            const float d = Sm[c * m + c];
-            if (!(d > 0.f)) bad = 1;
-            const float inv = d > 0.f ? 1.f / d : 0.f;
-            for (int j = 0; j < m; ++j) { Sm[c * m + j] *= inv; Si[c * m + j] *= inv; }
-            for (int r = 0; r < m; ++r) {
-                if (r == c) continue;
-                const float f = Sm[r * m + c];
-                for (int j = 0; j < m; ++j) { Sm[r * m + j] -= f * Sm[c * m + j]; Si[r * m + j] -= f * Si[c * m + j]; }
-            }
-        }
-        if (bad) { if (P.info[b] == 0) P.info[b] = P.Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient: not this path
-    }
-    __syncthreads();
-    // ---- T = G S^-1, c = T b, s0 = S^-1 b ----
-    for (int t = tid; t < m * Nps; t += LQP_NT) {
-        const int q = t / Nps, e = t - q * Nps;
-        float acc = 0.f;
-        for (int q2 = 0; q2 < m; ++q2) acc += G[(size_t)q2 * Nps + e] * Si[q2 * m + q];
-        Tl[t] = acc;
-        if (e < n) V.Tm[(size_t)q * n + e] = acc;
-    }
-    __syncthreads();
-    for (int e = tid; e < n; e += LQP_NT) {
-        float acc = 0.f;
-        for (int q = 0; q < m; ++q) acc += Tl[(size_t)q * Nps + e] * V.bs[q];
-        V.cv[e] = acc;
-    }
-    for (int q = tid; q < m; q += LQP_NT) {
-        float acc = 0.f;
-        for (int q2 = 0; q2 < m; ++q2) acc += Si[q * m + q2] * V.bs[q2];
-        V.s0[q] = acc;
-    }
-    // ---- Hs += T G^T on every lower block ----
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
-    for (int j = 0; j < Ks; ++j)
-        for (int i = j; i < Ks; ++i) {
-            float* blk = Hs + (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4;
-            V4<float> h = *(const V4<float>*)blk;
-            for (int q = 0; q < m; ++q) {
-                const float t = Tl[(size_t)q * Nps + i * 64 + r];
-                const V4<float> g = *(const V4<float>*)(G + (size_t)q * Nps + j * 64 + c4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h.v[e] += t * g.v[e];
-            }
-            *(V4<float>*)blk = h;
-        }
 }
 
 // ---------------------------------------------------------------------------
@@ -887,6 +940,7 @@ __global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, con
     rho = tmin(tmax(rho, P.rho_min), P.rho_max);
     __syncthreads();
     if (threadIdx.x == 0) scal[SC_RHO] = rho;
+    if (P.spd) return;
     const T* Qs = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
     assemble_kkt_rows(P, b, Qs, P.scale ? P.ldq : n, V, rho, true);
 }

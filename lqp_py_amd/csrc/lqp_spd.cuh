@@ -61,6 +61,32 @@ __device__ __forceinline__ void wg_sym_init(float* __restrict__ Hs, const float*
         }
 }
 
+// max |A_ij - A_ji| over the matrix, compared with its rounding level: returns > 0 when src is NOT symmetric
+// (difference above 1e-5 of the largest entry), 0 otherwise.  red: >= 2 * LQP_NW floats of LDS.
+__device__ __forceinline__ float wg_sym_asymmetry(const float* __restrict__ src, const int ld, const int n, const int K,
+                                                  float* __restrict__ red) {
+    const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
+    float dmax = 0.f, vmax = 0.f;
+    for (int j = 0; j < K; ++j)
+        for (int i = j; i < K; ++i) {
+            const int gr = i * 64 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gc = j * 64 + c4 + e;
+                if (gr < n && gc < n && gc < gr) {
+                    const float a = src[(size_t)gr * ld + gc], bt = src[(size_t)gc * ld + gr];
+                    dmax = tmax(dmax, tabs(a - bt));
+                    vmax = tmax(vmax, tmax(tabs(a), tabs(bt)));
+                } else if (gr < n && gc == gr) {
+                    vmax = tmax(vmax, tabs(src[(size_t)gr * ld + gc]));
+                }
+            }
+        }
+    dmax = wg_max(dmax, red);
+    vmax = wg_max(vmax, red + LQP_NW);
+    return dmax > 1e-5f * vmax ? dmax : 0.f;
+}
+
 // one 32x32 output quadrant: acc = X[x0 .. x0+31][0..63] * Z[z0 .. z0+31][0..63]^T, both operands in LDS with
 // row stride SPD_LS.  Lane l feeds row l&31 and the k range 32*(l>>5) .. +31 (any pairing of k values is a
 // valid MFMA schedule as long as A and B agree).

@@ -111,10 +111,11 @@ def test_g1_config1_box_only(dev):
         assert err(sol[k], g[k]) < 2e-5, k
 
 
+@pytest.mark.parametrize("linsolve", ["lu", "spd"])
 @pytest.mark.parametrize("mode", [1, 2])
-def test_g2_forward_and_all_fp_grads(dev, mode):
+def test_g2_forward_and_all_fp_grads(dev, mode, linsolve):
     g = load_golden("g2_b8_n50_eq")
-    ctl = O.make_control(launch_mode=mode, **TOL)
+    ctl = O.make_control(launch_mode=mode, linsolve=linsolve, **TOL)
     sol, a = solve(dev, tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")), ctl)
     assert sol["iter"] == g["iter"] and sol["_stats"]["mode_used"] == mode
     for k in ("x", "z", "u", "lams", "nus", "rho"):
@@ -138,10 +139,11 @@ def test_g8_fp64(dev):
         assert rel(t, g[f"{nm}_rand"]) < 1e-7, nm
 
 
+@pytest.mark.parametrize("linsolve,mode", [("lu", 2), ("spd", 2), ("spd", 1)])
 @pytest.mark.parametrize("tag", ["noscale", "scale"])
-def test_g6_adaptive_rho_refactorises(dev, tag):
+def test_g6_adaptive_rho_refactorises(dev, tag, linsolve, mode):
     g = load_golden(f"g6_adaptive_{tag}")
-    ctl = O.make_control(rho=100.0, scale=(tag == "scale"), **TOL)
+    ctl = O.make_control(rho=100.0, scale=(tag == "scale"), linsolve=linsolve, launch_mode=mode, **TOL)
     sol, a = solve(dev, tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")), ctl)
     assert sol["iter"] == g["iter"] == 100 and sol["_stats"]["n_factor"] == 2
     assert torch.is_tensor(sol["rho"]) and sol["rho"].shape == (16, 1, 1)
@@ -206,11 +208,12 @@ def test_g3_config2(dev):
     assert err(sol["x"], g["x"]) < 5e-5 and err(sol["u"], g["u"]) < 5e-5
 
 
+@pytest.mark.parametrize("linsolve", ["lu", "spd"])
 @pytest.mark.parametrize("mode", [1, 2])
-def test_g4_headline_config3(dev, mode):
+def test_g4_headline_config3(dev, mode, linsolve):
     g = load_golden("g4_b128_n500_eq")
     inp = O.create_qp_data(500, 128, seed=0)
-    sol, a = solve(dev, inp, O.make_control(launch_mode=mode, **TOL))
+    sol, a = solve(dev, inp, O.make_control(launch_mode=mode, linsolve=linsolve, **TOL))
     assert sol["iter"] == g["iter"] == 60 and sol["_stats"]["n_check"] == 4 and sol["_stats"]["n_factor"] == 1
     for k in ("x", "u", "nus"):
         assert err(sol[k], g[k]) < 5e-5, k
@@ -233,6 +236,73 @@ def test_g5_config4_n1000(dev):
     assert sol["iter"] == g["iter"] == 60
     assert err(sol["x"], g["x"]) < 5e-5 and rel(sol["rho"], g["rho"]) < 1e-4
 
+
+
+# ---------------------------------------------------------------- symmetric-inverse x-update (linsolve 'spd')
+@pytest.mark.parametrize("n,B", [(1, 2), (10, 3), (64, 2), (65, 2), (300, 3), (512, 2)])
+def test_spd_inverse_entry(dev, n, B):
+    lib = _lib.load()
+    torch.manual_seed(n)
+    Lm = torch.randn(B, 2 * n + 2, n)
+    K = (Lm.transpose(1, 2) @ Lm / (2 * n + 2) + 0.7 * torch.eye(n)).to(dev)
+    out = torch.empty_like(K)
+    info = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    nb = lib.lqp_spd_inverse_workspace_bytes(0, B, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    st = lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 0, B, n, _lib.ptr(K), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), nb)
+    assert st == 0 and info.tolist() == [0] * B
+    ref = torch.linalg.inv(K.double().cpu())
+    assert err(out, ref) < 5e-6 * float(ref.abs().max())
+    # not positive definite -> info says where, no exception, no fault
+    K2 = K.clone()
+    K2[0, n // 2, n // 2] = -1.0
+    st = lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 0, B, n, _lib.ptr(K2), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), nb)
+    assert st == 0 and int(info[0]) > 0 and info[1:].tolist() == [0] * (B - 1)
+    assert lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 1, B, n, _lib.ptr(K), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), nb) == 6
+    assert lib.lqp_spd_inverse_workspace_bytes(0, 1, 513) > 0 and \
+        lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 0, 1, 513, _lib.ptr(K), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), 1 << 40) == 6
+
+
+@pytest.mark.parametrize("n,m,B", [(10, 0, 5), (64, 1, 3), (100, 3, 4), (448, 16, 2), (512, 2, 2)])
+def test_spd_and_lu_paths_agree(dev, n, m, B):
+    """Both x-updates solve the same KKT system: same iteration count, same iterates to rounding."""
+    torch.manual_seed(n + m)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n, with_eq=False)
+    A = torch.randn(B, m, n) if m else None
+    b = 0.1 * torch.randn(B, m, 1) if m else None
+    sols = {}
+    for ls in ("lu", "spd"):
+        sols[ls], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve=ls, **TOL))
+    assert sols["lu"]["iter"] == sols["spd"]["iter"]
+    for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+        assert err(sols["lu"][k], sols["spd"][k]) < 5e-5, k
+    res = O.kkt_residuals(Q, p, A, b, lb, ub, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sols["spd"].items()})
+    assert float(res["stationarity"].max()) < 2e-3 and float(res["box"].max()) < 1e-6
+    if m:
+        assert float(res["equality"].max()) < 2e-4
+
+
+def test_spd_path_falls_back_to_lu(dev):
+    """A Q that is not symmetric, or Q + rho I that is not positive definite, is outside the symmetric
+    x-update: the synchronous call repeats on the LU path by itself (same answer as linsolve='lu'); the
+    un-synchronised module call reports it late."""
+    Q, p, A, b, lb, ub = O.create_qp_data(40, 4, seed=5)
+    Qn = Q.clone()
+    Qn[:, 3, 17] += 0.05                                   # not symmetric
+    Qi = Q - 0.9 * torch.eye(40)                           # indefinite
+    for Qx in (Qn, Qi):
+        ctl = dict(max_iters=200, **TOL)
+        s_auto, _ = solve(dev, (Qx, p, A, b, lb, ub), O.make_control(**ctl))
+        s_lu, _ = solve(dev, (Qx, p, A, b, lb, ub), O.make_control(linsolve="lu", **ctl))
+        assert s_auto["iter"] == s_lu["iter"]
+        assert torch.equal(torch.nan_to_num(s_auto["x"]), torch.nan_to_num(s_lu["x"]))   # (indefinite: may diverge)
+    L.SolveBoxQP(control=L.box_qp_control(**TOL))(*(t.to(dev) for t in (Qn, p, A, b, lb, ub)))
+    with pytest.raises(RuntimeError, match="linsolve"):
+        L.synchronize()
+    L.synchronize()
+    x = L.SolveBoxQP(control=L.box_qp_control(linsolve="lu", **TOL))(*(t.to(dev) for t in (Qn, p, A, b, lb, ub)))
+    L.synchronize()
+    assert torch.isfinite(x).all()
 
 # ---------------------------------------------------------------- size-independent properties
 def test_kkt_conditions_at_full_size(dev):
