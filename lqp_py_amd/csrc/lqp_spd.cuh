@@ -119,9 +119,8 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
     float* Y = (float*)smem;                       // nslot x 64 x LS: the panel of the current pivot block
     float* W = Y + (size_t)nslot * 64 * SPD_LS;    // L^-1 of the pivot block (lower)
     float* WT = W + 64 * SPD_LS;                   // its transpose
-    float* prow = WT + 64 * SPD_LS;                // [2][64] pivot row, by column parity
-    float* pcol = prow + 128;                      // [2][64] pivot column
-    int* flag = (int*)(pcol + 128);
+    float* pcol = WT + 64 * SPD_LS;                // [2][64] pivot column, by column parity
+    int* flag = (int*)(pcol + 256);
     if (tid == 0) flag[0] = 0;
     unsigned long long tp = 0, ty = 0, tu = 0, t0 = 0, tb = dbg ? clock64() : 0;   // debug cycle counters
 
@@ -138,43 +137,68 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             }
         }
         // ---- pivot block: in-place forward elimination of [A_kk | I] -> W = L^-1 (A_kk = L L^T) ----
-        // thread (r, cq) keeps elements [r][4cq .. 4cq+3]; column c switches role from "A" to "augmented" at step c
-        V4<float> x = *(const V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4);
-        __syncthreads();                           // previous step's LDS reads are over
-        int bad = 0;                               // first non-positive pivot of this block (+1)
-#pragma unroll 1
-        for (int c4 = 0; c4 < 16; ++c4) {
+        // Column c switches role from "A" to "augmented" at step c, so one 64x64 array is enough.  Only waves
+        // 0..3 work (lane = row, wave = 16-column quarter): the pivot row reaches a wave through v_readlane
+        // from its own lane c, the pivot column through 64 floats of LDS.  Measured per pivot block: 57k cycles
+        // with all 16 waves on 4 elements each, 52k like this, 63k with the row broadcast through LDS -- the
+        // write -> barrier -> read round trip per column is what costs.  The other waves only keep the barrier count.
+        const int prw = tid & 63, pq = tid >> 6;
+        float xq[16];
+        if (w < 4) {
+            const float* src = Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + prw * 64 + pq * 16;
 #pragma unroll
-            for (int e0 = 0; e0 < 4; ++e0) {
-                const int c = c4 * 4 + e0, par = e0 & 1;
-                if (r == c) *(V4<float>*)(prow + par * 64 + cq * 4) = x;
-                if (cq == c4) pcol[par * 64 + r] = x.v[e0];
-                wg_barrier_lds();
-                // three independent LDS reads, then a branch-free update (the chain per column is what costs)
-                const float d = prow[par * 64 + c];
-                const V4<float> pr = *(const V4<float>*)(prow + par * 64 + cq * 4);
-                const float pc = pcol[par * 64 + r];
-                const bool ok = d > 0.f;
-                if (!ok && bad == 0) bad = k * 64 + c + 1;
-                const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
-                const float f = pc * s;
-                const bool below = r > c, on = r == c;
-                const float coef = below ? f * s : 0.f;      // rows below the pivot: x -= (f s) * pivot row
-                const float mult = on ? s : 1.f;             // the pivot row itself is scaled by s
+            for (int t = 0; t < 4; ++t) {
+                const V4<float> v4 = *(const V4<float>*)(src + 4 * t);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x.v[e] = (x.v[e] - coef * pr.v[e]) * mult;
-                if (cq == c4) x.v[e0] = below ? -f * s : (on ? s : x.v[e0]);
+                for (int e = 0; e < 4; ++e) xq[4 * t + e] = v4.v[e];
             }
         }
-        if (bad != 0 && tid == 0 && flag[0] == 0) flag[0] = bad;
-        // W (lower, zero above the diagonal) and W^T
+        __syncthreads();                           // previous step's LDS reads are over
+        if (w < 4) {
+            int bad = 0;                           // first non-positive pivot of this block (+1)
+            float srow = 1.f;                      // scale of this lane's row once it has been the pivot row
+#pragma unroll 1
+            for (int qc = 0; qc < 4; ++qc) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int q = cq * 4 + e;
-            if (q > r) x.v[e] = 0.f;
-            WT[q * SPD_LS + r] = x.v[e];
+                for (int ec = 0; ec < 16; ++ec) {
+                    const int c = qc * 16 + ec, par = ec & 1;
+                    if (pq == qc) pcol[par * 64 + prw] = xq[ec];
+                    wg_barrier_lds();
+                    const float d = pcol[par * 64 + c];
+                    const float pc = pcol[par * 64 + prw];
+                    const bool ok = d > 0.f;
+                    if (!ok && bad == 0) bad = k * 64 + c + 1;
+                    const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
+                    const bool below = prw > c, on = prw == c;
+                    // rows below the pivot: x -= (x_rc / d) * (pivot row); the pivot row keeps its raw values and
+                    // remembers its scale s (it is final: nobody reads it again), applied when W is written
+                    const float coef = below ? pc * s * s : 0.f;
+                    if (on) srow = s;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)        // the pivot row comes from this wave's own lane c
+                        xq[e] -= coef * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
+                    if (pq == qc) xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
+                }
+            }
+            if (bad != 0 && tid == 0 && flag[0] == 0) flag[0] = bad;
+            // W (lower, zero above the diagonal) and W^T
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int q = pq * 16 + e;
+                xq[e] = (q > prw) ? 0.f : xq[e] * srow;
+                WT[q * SPD_LS + prw] = xq[e];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                V4<float> v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4.v[e] = xq[4 * t + e];
+                *(V4<float>*)(W + prw * SPD_LS + pq * 16 + 4 * t) = v4;
+            }
+        } else {
+#pragma unroll 1
+            for (int c = 0; c < 64; ++c) wg_barrier_lds();
         }
-        *(V4<float>*)(W + r * SPD_LS + cq * 4) = x;
         // ---- panel to LDS: slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k ----
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s) {
