@@ -139,12 +139,18 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
         // ---- pivot block: in-place forward elimination of [A_kk | I] -> W = L^-1 (A_kk = L L^T) ----
         // Column c switches role from "A" to "augmented" at step c, so one 64x64 array is enough.  Only waves
         // 0..3 work (lane = row, wave = 16-column quarter): the pivot row reaches a wave through v_readlane
-        // from its own lane c, the pivot column through 64 floats of LDS.  Measured per pivot block: 57k cycles
-        // with all 16 waves on 4 elements each, 52k like this, 63k with the row broadcast through LDS -- the
-        // write -> barrier -> read round trip per column is what costs.  The other waves only keep the barrier count.
-        const int prw = tid & 63, pq = tid >> 6;
+        // from its own lane c, the pivot column through LDS.  Measured per pivot block: 57k cycles with all 16
+        // waves on 4 elements each and a barrier per column, 48k with 4 waves and a barrier per column, 63k with
+        // the row broadcast through LDS too, 45-55k with barrier-free producer/consumer hand-overs (progress
+        // counter or sentinel slots in LDS): the barrier is not the expensive part.  The other waves only keep
+        // the barrier count.
+#ifndef SPD_WSTRIDE
+#define SPD_WSTRIDE 1
+#endif
+        const int prw = tid & 63, pq = w / SPD_WSTRIDE;
+        const bool pwork = (w % SPD_WSTRIDE) == 0 && pq < 4;
         float xq[16];
-        if (w < 4) {
+        if (pwork) {
             const float* src = Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + prw * 64 + pq * 16;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -154,14 +160,15 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             }
         }
         __syncthreads();                           // previous step's LDS reads are over
-        if (w < 4) {
+        if (pwork) {
             int bad = 0;                           // first non-positive pivot of this block (+1)
             float srow = 1.f;                      // scale of this lane's row once it has been the pivot row
 #pragma unroll 1
             for (int qc = 0; qc < 4; ++qc) {
 #pragma unroll
                 for (int ec = 0; ec < 16; ++ec) {
-                    const int c = qc * 16 + ec, par = ec & 1;
+                    const int c = qc * 16 + ec;
+                    const int par = ec & 1;
                     if (pq == qc) pcol[par * 64 + prw] = xq[ec];
                     wg_barrier_lds();
                     const float d = pcol[par * 64 + c];
@@ -174,9 +181,17 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                     // remembers its scale s (it is final: nobody reads it again), applied when W is written
                     const float coef = below ? pc * s * s : 0.f;
                     if (on) srow = s;
+                    // the pivot row comes from this wave's own lane c: all 16 v_readlane first, into 16 different
+                    // SGPRs (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
+                    // readlane -> fma -> readlane chain then costs ~35 cycles per element)
+                    float pr[16];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)        // the pivot row comes from this wave's own lane c
-                        xq[e] -= coef * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
+                    for (int e = 0; e < 16; ++e)
+                        pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xq[e] -= coef * pr[e];
+                    __builtin_amdgcn_sched_barrier(0);
                     if (pq == qc) xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
                 }
             }

@@ -21,4 +21,5 @@ lib.lqp_debug_set_lu_counters(None)
 c = dbg.view(B, 8).double().mean(0).tolist()
 it = sol["iter"] + 1
 print(f"iters {it}; loop cycles/iter: rhs {c[0]/it:.0f} product {c[1]/it:.0f} combine {c[2]/it:.0f} update+check {c[3]/it:.0f} | total/iter {sum(c[:4])/it:.0f}")
+
 print(f"sweep cycles: pivot+panel-load {c[4]:.0f} panel->LDS+Y {c[5]:.0f} tasks {c[6]:.0f} total {c[7]:.0f}")
