@@ -90,15 +90,19 @@ __device__ __forceinline__ float wg_sym_asymmetry(const float* __restrict__ src,
 // one 32x32 output quadrant: acc = X[x0 .. x0+31][0..63] * Z[z0 .. z0+31][0..63]^T, both operands in LDS with
 // row stride SPD_LS.  Lane l feeds row l&31 and the k range 32*(l>>5) .. +31 (any pairing of k values is a
 // valid MFMA schedule as long as A and B agree).
+// HALF: only k in [32, 64) (UP) or [0, 32) contributes (a triangular operand is zero on the other half): 16 MFMAs.
+template <int HALF = 0, bool UP = false>
 __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, const float* __restrict__ Z) {
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    const float* xa = X + li * SPD_LS + 32 * lh;
-    const float* zb = Z + li * SPD_LS + 32 * lh;
+    constexpr int KL = HALF ? 16 : 32;                   // k values per lane half
+    const int kb = (HALF && UP ? 32 : 0) + KL * lh;
+    const float* xa = X + li * SPD_LS + kb;
+    const float* zb = Z + li * SPD_LS + kb;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < KL / 4; ++t) {
         const V4<float> a = *(const V4<float>*)(xa + 4 * t);
         const V4<float> b = *(const V4<float>*)(zb + 4 * t);
 #pragma unroll
@@ -238,7 +242,8 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                 const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
                 if (task < ntask) {
                     const int s = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
-                    acc[u] = spd_quadrant(Y + ((size_t)s * 64 + 32 * qi) * SPD_LS, W + (32 * qj) * SPD_LS);
+                    const float* Xp = Y + ((size_t)s * 64 + 32 * qi) * SPD_LS;
+                    acc[u] = qj == 0 ? spd_quadrant<1, false>(Xp, W) : spd_quadrant(Xp, W + 32 * SPD_LS);
                 }
             }
             __syncthreads();
@@ -261,42 +266,75 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
         //   last 4:               A_kk  = -(W^T W)
         {
             const int npair = (K - 1) * K / 2;
-            const int nupd = npair * 4, npan = (K - 1) * 4, ntask = nupd + npan + 4;
-            for (int task = __builtin_amdgcn_readfirstlane(w); task < ntask; task += LQP_NW) {
-                const int qi = (task >> 1) & 1, qj = task & 1;
-                if (task < nupd) {
-                    const int p = task >> 2;
-                    int si = 0;
-                    while ((si + 1) * (si + 2) / 2 <= p) ++si;
-                    const int sj = p - si * (si + 1) / 2;
-                    const int i = si < k ? si : si + 1, j = sj < k ? sj : sj + 1;
-                    float* C = Hs + (size_t)sym_idx(i, j, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
-                    f32x16 cur;
+            const int nupd = npair * 4, nrest = (K - 1) * 4 + 4;
+            // update tiles: the C quadrant of the NEXT task is requested before the MFMA chain of this one, so the
+            // waves of a SIMD do not all sit in their load phase (then all in their MFMA phase) together
+            auto upd_addr = [&](const int task, int& si, int& sj, bool& skip, bool& mirror) -> float* {
+                const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
+                si = 0;
+                while ((si + 1) * (si + 2) / 2 <= p) ++si;
+                sj = p - si * (si + 1) / 2;
+                skip = si == sj && qi == 0 && qj == 1;          // diagonal tile: mirrored from its (1,0) quadrant
+                mirror = si == sj && qi == 1 && qj == 0;
+                const int i = si < k ? si : si + 1, j = sj < k ? sj : sj + 1;
+                return Hs + (size_t)sym_idx(i, j, K) * LQP_BLK;
+            };
+            auto upd_load = [&](const float* T0, const int task, f32x16& c) {
+                const float* C = T0 + (32 * ((task >> 1) & 1)) * 64 + 32 * (task & 1) + li;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];     // in flight under the MFMA chain
-                    const f32x16 acc = spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS,
-                                                    Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
+                for (int q = 0; q < 16; ++q) c[q] = C[quad_row(q, lh) * 64];
+            };
+            int task = __builtin_amdgcn_readfirstlane(w);
+            int si = 0, sj = 0; bool skip = false, mirror = false;
+            float* T0 = nullptr;
+            f32x16 nxt;
+            if (task < nupd) { T0 = upd_addr(task, si, sj, skip, mirror); if (!skip) upd_load(T0, task, nxt); }
+            while (task < nupd) {
+                const int qi = (task >> 1) & 1, qj = task & 1;
+                f32x16 cur = nxt;
+                float* Tc = T0;
+                const int csi = si, csj = sj;
+                const bool cskip = skip, cmirror = mirror;
+                const int ntask = task + LQP_NW;
+                if (ntask < nupd) { T0 = upd_addr(ntask, si, sj, skip, mirror); if (!skip) upd_load(T0, ntask, nxt); }
+                if (!cskip) {
+                    const f32x16 acc = spd_quadrant(Y + ((size_t)csi * 64 + 32 * qi) * SPD_LS,
+                                                    Y + ((size_t)csj * 64 + 32 * qj) * SPD_LS);
                     cur -= acc;
+                    float* C = Tc + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
-                } else if (task < nupd + npan) {
-                    const int s = (task - nupd) >> 2;
+                    if (cmirror) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) Tc[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                    }
+                }
+                task = ntask;
+            }
+            // the new panel column and the pivot block (stores only)
+            for (int t2 = __builtin_amdgcn_readfirstlane(w); t2 < nrest; t2 += LQP_NW) {
+                const int qi = (t2 >> 1) & 1, qj = t2 & 1;
+                if (t2 < nrest - 4) {
+                    const int s = t2 >> 2;
                     const int i = s < k ? s : s + 1;
                     const float* Ys = Y + (size_t)s * 64 * SPD_LS;
                     f32x16 acc;
                     float* C;
-                    if (i > k) {
-                        acc = spd_quadrant(Ys + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS);
+                    if (i > k) {          // Y W: column c >= 32 (qj == 1) only sees k >= 32
+                        acc = qj == 1 ? spd_quadrant<1, true>(Ys + (32 * qi) * SPD_LS, WT + 32 * SPD_LS)
+                                      : spd_quadrant(Ys + (32 * qi) * SPD_LS, WT);
                         C = Hs + (size_t)sym_idx(i, k, K) * LQP_BLK;
-                    } else {
-                        acc = spd_quadrant(WT + (32 * qi) * SPD_LS, Ys + (32 * qj) * SPD_LS);
+                    } else {              // W^T Y^T: row r >= 32 (qi == 1) only sees k >= 32
+                        acc = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Ys + (32 * qj) * SPD_LS)
+                                      : spd_quadrant(WT, Ys + (32 * qj) * SPD_LS);
                         C = Hs + (size_t)sym_idx(k, i, K) * LQP_BLK;
                     }
                     C += (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = acc[q];
                 } else {
-                    const f32x16 acc = spd_quadrant(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS);
+                    const f32x16 acc = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
+                                                 : spd_quadrant(WT, WT);
                     float* C = Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = -acc[q];
