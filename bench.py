@@ -44,27 +44,41 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(es, n, m, iters, n_check, n_refactor, scale=True):
-    """per-QP algorithmic bytes of forward / backward / the loop kernel alone."""
+def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True):
+    """Per-QP algorithmic bytes of forward / backward / the loop kernel alone.
+
+    linsolve 1 (pivoted LU, the reference's algorithm): SURVEY.md 8(d) -- every x-update streams the N x N
+    factor; the convergence check no longer reads Q (KKT identity), so its C n^2 term is gone.
+    linsolve 2 (symmetric inverse): every x-update is a symmetric product with H = (Qs + rho I)^-1 (corrected for
+    the equality rows), whose lower triangle n(n+1)/2 is all that has to move; the factorisation reads the lower
+    triangle of Qs and writes that of H."""
     N = n + m
     I = iters + 1
     S = 1 if scale else 0
-    fwd = es * (2 * S * n * n + n * n + N * N + 2 * N * N + I * N * N + n_check * n * n
-                + n_refactor * (n * n + 3 * N * N))
+    if linsolve == 2:
+        tri = n * (n + 1) // 2
+        loop = es * I * tri
+        fwd = es * (2 * S * n * n + (1 + n_refactor) * 2 * tri) + loop
+    else:
+        loop = es * I * N * N
+        fwd = es * (2 * S * n * n + n * n + N * N + 2 * N * N + n_refactor * (n * n + 3 * N * N)) + loop
     bwd = es * (3 * n * n + 4 * N * N)
-    loop = es * (I * N * N + n_check * n * n)
-    return fwd, bwd, loop
+    return fwd, bwd, loop, es * I * N * N
+
+
+LOOP_KERNEL = {1: "lqp::k_admm_loop<float, true, false, 1024, false>",
+               2: "lqp::k_admm_loop<float, true, false, 1024, true>"}
+TRAFFIC_FILE = "profiles/r01_d_traffic.json"
 
 
 def measured_traffic(kernel, mode, B, n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE / WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md).  Only valid for the configuration it was measured on; otherwise null."""
-    path = os.path.join(REPO, "profiles", "r01_b_traffic.json")
     try:
-        d = json.load(open(path))
+        d = json.load(open(os.path.join(REPO, TRAFFIC_FILE)))
         if d.get("launch_mode") == mode and B == B_PER_GPU and n == N_X:
-            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], "profiles/r01_c_traffic.json (rocprofv3 --pmc)"
+            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], TRAFFIC_FILE + " (rocprofv3 --pmc)"
     except Exception:
         pass
     return None, None
@@ -194,18 +208,25 @@ def main():
     sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, dict(control))
     st = sol["_stats"]
     es = 4
-    fwd_b, bwd_b, loop_b = algorithmic_bytes(es, n, m, st["iters"], st["n_check"], st["n_factor"] - 1)
+    ls = st["linsolve_used"]
+    fwd_b, bwd_b, loop_b, loop_ref_b = algorithmic_bytes(es, n, m, st["iters"], st["n_factor"] - 1, ls)
     loop_ms, loop_launches = prof["admm_loop"]
     solves = args.steps
     loop_ms_per_solve = loop_ms / max(solves, 1)
-    achieved = (loop_b * B) / (loop_ms_per_solve * 1e-3) / 1e9 if loop_ms_per_solve > 0 else 0.0
-    traffic, traffic_src = measured_traffic("lqp::k_admm_loop<float, true, false>", st["mode_used"], B, n)
-    roofline = {"bound": "hbm", "kernel": "k_admm_loop", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    gbs = lambda nbytes: (nbytes * B) / (loop_ms_per_solve * 1e-3) / 1e9 if loop_ms_per_solve > 0 else 0.0
+    achieved = gbs(loop_b)
+    traffic, traffic_src = measured_traffic(LOOP_KERNEL[ls], 3 if not args.sync else st["mode_used"], B, n)
+    roofline = {"bound": "hbm", "kernel": LOOP_KERNEL[ls], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
-                "per": "one forward solve of one batch (all loop launches of the solve summed)",
+                "per": "the first (hot) loop launch of one forward solve of one batch",
                 "algorithmic_bytes": loop_b * B, "ms": round(loop_ms_per_solve, 4),
                 "launches_per_solve": loop_launches / max(solves, 1),
+                "linsolve": {1: "lu", 2: "spd"}[ls],
+                # the same launch priced with the REFERENCE algorithm's bytes (I * N^2 * es, the
+                # cached-LU stream this kernel replaces): not a bandwidth, a like-for-like speed figure
+                "reference_algorithm_bytes": loop_ref_b * B,
+                "reference_algorithm_equiv_GBs": round(gbs(loop_ref_b), 1),
                 "whole_step_frac_of_hbm_roofline": round(((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)}
     breakdown = {k: round(v[0] / max(solves, 1), 4) for k, v in prof.items() if v[1]}
 

@@ -87,6 +87,8 @@ typedef struct lqp_boxqp_stats {
     int32_t fail_index;     /* batch index of the first singular problem, or -1        */
     int32_t n_launch;       /* kernel launches issued                                  */
     int32_t mode_used;      /* 1 segmented, 2 persistent, 3 persistent without host sync */
+    int32_t linsolve_used;  /* 1 pivoted LU, 2 symmetric inverse (what linsolve 0 / a fallback resolved to) */
+    int32_t reserved;
 } lqp_boxqp_stats;
 
 int lqp_abi_version(void);

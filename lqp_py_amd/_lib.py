@@ -34,7 +34,8 @@ class BoxQPCtrl(ctypes.Structure):
 
 class BoxQPStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in (
-        "iters", "n_factor", "n_solve", "n_check", "rho_updated", "fail_index", "n_launch", "mode_used")]
+        "iters", "n_factor", "n_solve", "n_check", "rho_updated", "fail_index", "n_launch", "mode_used", "linsolve_used",
+        "reserved")]
 
 
 # every symbol include/lqp_amd.h declares: name -> (restype, argtypes)

@@ -402,6 +402,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 memset(stats, 0, sizeof(*stats));
                 stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
                 stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
+                stats->linsolve_used = spd ? 2 : 1;
             }
             return LQP_OK;
         }
@@ -501,6 +502,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->fail_index = -1;
         stats->n_launch = n_launch;
         stats->mode_used = mode;
+        stats->linsolve_used = spd ? 2 : 1;
+        stats->reserved = 0;
     }
     return LQP_OK;
 }
