@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 2
+#define LQP_ABI_VERSION 3
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -137,7 +137,12 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m,
  * active-set mask :360-365, non-symmetric system :378-392, linalg.solve
  * :393, gradient epilogue :396-430.  rho_mode 1 = scalar rho_value, 2 =
  * per-problem rho_in.  Any of dQ (B,n,n), dp (B,n,1), dA (B,m,n), db (B,m,1),
- * dlb, dub (B,n,1) may be NULL = skip.                                      */
+ * dlb, dub (B,n,1) may be NULL = skip.  fail_index NULL = do not wait for the
+ * GPU (errors stay in the workspace's info array).  linsolve: 0/1 pivoted LU of
+ * the system like torch.linalg.solve (:393); 2 = Q is known to be symmetric
+ * (the forward ran linsolve 2 on it): blocked Cholesky of the free-set block
+ * Q_FF + the Schur complement of the equality rows (f32, n <= 512, m <= 16;
+ * otherwise, or when Q_FF is not positive definite, LU).                     */
 size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m);
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
                           const void* dl_dz, const void* x, const void* u,
@@ -146,7 +151,8 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
                           int rho_mode, double rho_value, const void* rho_in,
                           void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
                           int32_t* fail_index,
-                          void* workspace, size_t workspace_bytes);
+                          void* workspace, size_t workspace_bytes,
+                          int linsolve);
 
 /* ---- batched LU (partial pivoting) and cached LU solve ------------------
  * Replace torch.linalg.lu_factor / lu_solve as used by lqp_py/lu_layer.py:

@@ -56,7 +56,7 @@ SYMBOLS = {
     "lqp_boxqp_forward_layout": (c_int, [c_int] * 4 + [ctypes.POINTER(c_size_t)] * 4),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
-                              [ctypes.POINTER(ctypes.c_int32), _P, c_size_t]),
+                              [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int]),
     "lqp_lu_factor_workspace_bytes": (c_size_t, [c_int] * 3),
     "lqp_lu_factor_batched": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t]),
     "lqp_lu_solve_workspace_bytes": (c_size_t, [c_int] * 3),
@@ -107,7 +107,7 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.lqp_abi_version() != 2:
+        if lib.lqp_abi_version() != 3:
             raise RuntimeError("lqp_py_amd: ABI version mismatch")
         _lib = lib
         return lib

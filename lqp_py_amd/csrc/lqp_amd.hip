@@ -56,7 +56,7 @@ int ensure_lds(const void* fn, int bytes) {
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream ----
 enum { PC_SETUP = 0, PC_LU, PC_PACK, PC_LOOP, PC_RHO, PC_EPILOGUE, PC_BWD_BUILD, PC_SOLVE, PC_BWD_EPILOGUE,
-       PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_COUNT };
+       PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_BWD_CHOL, PC_COUNT };
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::mutex g_prof_mutex;
 bool g_prof_on = false;
@@ -531,7 +531,7 @@ template <typename T>
 int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void* x, const void* u, const void* lams,
                   const void* nus, const void* Q, const void* A, const void* lb, const void* ub, int rho_mode,
                   double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
-                  int32_t* fail_index, void* ws, size_t ws_bytes) {
+                  int32_t* fail_index, void* ws, size_t ws_bytes, int linsolve) {
     BwdParams<T> P;
     memset(&P, 0, sizeof(P));
     const size_t need = carve_backward<T>(ws, B, n, m, P);
@@ -543,7 +543,29 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     // default: solve on the free set only (see k_bwd_build_reduced); LQP_BWD_FULL=1 keeps the full system
     P.reduced = env_int("LQP_BWD_FULL", 0) ? 0 : 1;
     const int* nvec = P.reduced ? P.nred : nullptr;
-    if (P.reduced) {
+    // linsolve 2: the caller vouches for a symmetric Q (the forward's symmetric x-update checked it): the
+    // reduced system goes through a blocked Cholesky of Q_FF instead of the pivoted LU of the bordered matrix
+    bool chol = false;
+    if constexpr (sizeof(T) == 4) {
+        chol = P.reduced && linsolve == 2 && env_int("LQP_BWD_CHOL", 1) && round_up(n, LQP_NB) / LQP_NB <= SPD_MAXK &&
+               m <= SPD_MAXM;
+        if (chol) {
+            P.chol = 1;
+            {
+                const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
+                ProfScope ps(st, PC_BWD_BUILD);
+                const int split = B <= 128 ? 2 : 1;
+                hipLaunchKernelGGL(k_bwd_build_chol, dim3(B, split), dim3(LQP_NT), lds, st, P);
+            }
+            const int lds = bwd_chol_lds_bytes(n, m);
+            int r2 = ensure_lds((const void*)k_bwd_chol_solve, lds);
+            if (r2) return r2;
+            ProfScope ps(st, PC_BWD_CHOL);
+            hipLaunchKernelGGL(k_bwd_chol_solve, dim3(B), dim3(LQP_NT), lds, st, P);
+        }
+    }
+    if (chol) {
+    } else if (P.reduced) {
         const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
         ProfScope ps(st, PC_BWD_BUILD);
         const int split = (B <= 128 && env_int("LQP_SPLIT2", 1)) ? 2 : 1;
@@ -552,12 +574,15 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         ProfScope ps(st, PC_BWD_BUILD);
         hipLaunchKernelGGL(k_bwd_build<T>, dim3(B), dim3(LQP_NT), 0, st, P);
     }
-    int rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec);
-    if (rc) return rc;
-    rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr, nvec);
-    if (rc) return rc;
-    rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);
-    if (rc) return rc;
+    int rc = LQP_OK;
+    if (!chol) {
+        rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec);
+        if (rc) return rc;
+        rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr, nvec);
+        if (rc) return rc;
+        rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);
+        if (rc) return rc;
+    }
     {
         const int lds = (2 * n + m + 8) * (int)sizeof(T);
         auto fn = k_bwd_epilogue<T>;
@@ -570,6 +595,9 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     if (fail_index) {
         int fi = -1;
         rc = first_failure(st, P.info, B, &fi);       // torch.linalg.solve checks info (and syncs) too
+        if (rc == LQP_ERR_SINGULAR && chol)           // Q_FF not positive definite in f32: the pivoted LU takes it
+            return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
+                                    db, dlb, dub, fail_index, ws, ws_bytes, 1);
         *fail_index = fi;
         if (rc) return rc;
     }
@@ -698,7 +726,7 @@ int lqp_profile_classes(void) { return PC_COUNT; }
 const char* lqp_profile_class_name(int c) {
     static const char* names[PC_COUNT] = {"fwd_setup", "lu_factor", "pack", "admm_loop", "rho_update", "fwd_epilogue",
                                           "bwd_build", "packed_solve", "bwd_epilogue", "misc", "admm_loop_tail",
-                                          "spd_inverse", "eq_correct"};
+                                          "spd_inverse", "eq_correct", "bwd_cholesky"};
     return (c >= 0 && c < PC_COUNT) ? names[c] : "?";
 }
 
@@ -776,7 +804,7 @@ size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m) {
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x, const void* u,
                           const void* lams, const void* nus, const void* Q, const void* A, const void* lb, const void* ub,
                           int rho_mode, double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db,
-                          void* dlb, void* dub, int32_t* fail_index, void* workspace, size_t workspace_bytes) {
+                          void* dlb, void* dub, int32_t* fail_index, void* workspace, size_t workspace_bytes, int linsolve) {
     if (bad_dims(dtype, B, n, m) || !dl_dz || !x || !u || !lams || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
     if (m > 0 && (!A || !nus)) return LQP_ERR_INVALID;
     if (rho_mode != 1 && rho_mode != 2) return LQP_ERR_INVALID;
@@ -784,8 +812,8 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const vo
     if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LQP_F32)
-        return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes);
-    return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes);
+        return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, linsolve);
+    return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, 1);
 }
 
 size_t lqp_spd_inverse_workspace_bytes(int dtype, int B, int n) {

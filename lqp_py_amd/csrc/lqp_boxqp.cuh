@@ -983,6 +983,7 @@ template <typename T> struct BwdParams {
     int* fidx;   // B * n : indices of the free variables (reduced system), in order
     int* nred;   // B     : size of the reduced system = #free + m
     int reduced; // 1: solve on the free set only
+    int chol;    // 1: the reduced system is solved through a blocked Cholesky of Q_FF (f32, symmetric Q)
 };
 
 template <typename T>
@@ -1101,6 +1102,168 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
         for (int c = lane; c < m; c += 64) mr[nf + c] = (c == r) ? T(1e-8) : T(0);
         if (lane == 0) rhs[nf + r] = T(0);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky form of the reduced backward system (f32, Q symmetric, n <= 512, m <= 16):
+//   [[Kf, A_F^T], [A_F, eps I]] [dv_F; dnu] = [-g_F; 0],   Kf = Q_FF + eps I  (eps = 1e-8, :378-392)
+//   dv_F = u0 - G dnu,  u0 = Kf^-1 (-g_F),  G = Kf^-1 A_F^T,  (A_F G - eps I) dnu = A_F u0.
+// Build: ordered compaction of the free set, Kf as packed lower 64x64 blocks (identity padding), -g_F -> rhs,
+// A_F rows -> the (otherwise unused) M buffer.  LDS: fl[n] (int) | wtot[NW]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float> P) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int* fl = (int*)smem;
+    int* wtot = fl + round_up(n, 8);
+    const float* x = P.x + (size_t)b * n;
+    const float* u = P.u + (size_t)b * n;
+    const float* lb = P.lb + (size_t)b * n;
+    const float* ub = P.ub + (size_t)b * n;
+    const float* g = P.g + (size_t)b * n;
+    const float* Q = P.Q + (size_t)b * n * n;
+    const float* A = P.A ? P.A + (size_t)b * m * n : nullptr;
+    const int Kmax = round_up(n, LQP_NB) / LQP_NB, Npm = Kmax * LQP_NB;
+    float* Ls = P.packed + (size_t)b * sym_blocks(Kmax) * LQP_BLK;
+    float* AF = P.M + (size_t)b * Np * Np;
+    float* rhs = P.rhs + (size_t)b * Np;
+    if (tid == 0 && blockIdx.y == 0) P.info[b] = 0;
+    bool keep = false;
+    if (tid < n) {
+        const float sxu = x[tid] + u[tid];
+        keep = !(sxu > ub[tid] || sxu < lb[tid]);
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[w] = __popcll(bal);
+    __syncthreads();
+    int base = 0, nf = 0;
+#pragma unroll
+    for (int ww = 0; ww < LQP_NW; ++ww) {
+        const int c = wtot[ww];
+        if (ww < w) base += c;
+        nf += c;
+    }
+    if (keep) {
+        fl[base + before] = tid;
+        if (blockIdx.y == 0) P.fidx[(size_t)b * n + base + before] = tid;
+    }
+    if (tid == 0 && blockIdx.y == 0) P.nred[b] = nf + m;
+    __syncthreads();
+    const int Kb = round_up(nf, LQP_NB) / LQP_NB;
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const int nblk = sym_blocks(Kb);
+    for (int t = blockIdx.y; t < nblk; t += gridDim.y) {
+        int j = 0;
+        while (sym_idx(j + 1, j + 1, Kb) <= t && j + 1 < Kb) ++j;      // block column of stream position t
+        const int i = j + (t - sym_idx(j, j, Kb));
+        const int a = i * 64 + r;
+        V4<float> v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = j * 64 + c4 + e;
+            float val = (a == c) ? 1.f : 0.f;
+            if (a < nf && c < nf) {
+                val = Q[(size_t)fl[a] * n + fl[c]];
+                if (a == c) val += 1e-8f;
+            }
+            v.v[e] = val;
+        }
+        *(V4<float>*)(Ls + (size_t)t * LQP_BLK + tid * 4) = v;
+    }
+    if (blockIdx.y == 0) {
+        for (int a = tid; a < Npm; a += LQP_NT) rhs[a] = a < nf ? -g[fl[a]] : 0.f;
+        for (int q = 0; q < m; ++q)
+            for (int a = tid; a < Npm; a += LQP_NT) AF[(size_t)q * Npm + a] = a < nf ? A[(size_t)q * n + fl[a]] : 0.f;
+    }
+}
+
+// factor + solves + Schur complement of the equality rows; leaves [dv_F; dnu] in rhs like the LU path
+// LDS: wg_chol_factor's layout, then v | acc | u0 | G[m][Npm] | t[64] | part[NW*64] | S[m*m] | wv[m] | dn[m]
+__host__ __device__ inline int bwd_chol_lds_bytes(int n, int m) {
+    const int Kmax = round_up(n, LQP_NB) / LQP_NB, Npm = Kmax * LQP_NB;
+    const int a = spd_lds_bytes(Kmax);
+    const int c = ((3 + m) * Npm + 64 + LQP_NW * 64 + m * m + 2 * m + 8) * 4;
+    return a > c ? a : c;
+}
+__global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float> P) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int Kmax = round_up(n, LQP_NB) / LQP_NB, Npm = Kmax * LQP_NB;
+    const int nf = P.nred[b] - m;
+    const int Kb = round_up(nf, LQP_NB) / LQP_NB, Nb = Kb * LQP_NB;
+    float* Ls = P.packed + (size_t)b * sym_blocks(Kmax) * LQP_BLK;
+    const float* AF = P.M + (size_t)b * Np * Np;
+    float* rhs = P.rhs + (size_t)b * Np;
+    if (Kb > 0) wg_chol_factor(Ls, Kb, P.info + b, smem);
+    __syncthreads();
+    float* v = (float*)smem;
+    float* acc = v + Npm;
+    float* u0 = acc + Npm;
+    float* G = u0 + Npm;
+    float* t = G + (size_t)m * Npm;
+    float* part = t + 64;
+    float* S = part + LQP_NW * 64;
+    float* wv = S + m * m;
+    float* dn = wv + m;
+    for (int e = tid; e < Nb; e += LQP_NT) v[e] = rhs[e];
+    __syncthreads();
+    if (Kb > 0) wg_chol_solve(Ls, Kb, v, acc, t, part);
+    for (int e = tid; e < Nb; e += LQP_NT) u0[e] = v[e];
+    __syncthreads();
+    for (int q = 0; q < m; ++q) {
+        for (int e = tid; e < Nb; e += LQP_NT) v[e] = AF[(size_t)q * Npm + e];
+        __syncthreads();
+        if (Kb > 0) wg_chol_solve(Ls, Kb, v, acc, t, part);
+        for (int e = tid; e < Nb; e += LQP_NT) G[(size_t)q * Npm + e] = v[e];
+        __syncthreads();
+    }
+    if (m > 0) {
+        // S = A_F G - eps I,  wv = A_F u0  (one wave per entry)
+        for (int e = w; e < m * m + m; e += LQP_NW) {
+            const int q = e < m * m ? e / m : e - m * m;
+            const float* rv = e < m * m ? G + (size_t)(e - q * m) * Npm : u0;
+            float a = 0.f;
+            for (int i = lane; i < nf; i += 64) a += AF[(size_t)q * Npm + i] * rv[i];
+            a = wave_sum(a);
+            if (lane == 0) {
+                if (e < m * m) S[e] = a - ((e / m == e % m) ? 1e-8f : 0.f);
+                else wv[q] = a;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {                                      // (S - eps I) dnu = wv: Gauss-Jordan with partial pivoting, m <= 16
+            for (int c = 0; c < m; ++c) {
+                int pr = c;
+                float best = tabs(S[c * m + c]);
+                for (int rr = c + 1; rr < m; ++rr) if (tabs(S[rr * m + c]) > best) { best = tabs(S[rr * m + c]); pr = rr; }
+                if (!(best > 0.f)) { if (P.info[b] == 0) P.info[b] = nf + c + 1; continue; }
+                if (pr != c) {
+                    for (int jj = 0; jj < m; ++jj) { const float tmp = S[c * m + jj]; S[c * m + jj] = S[pr * m + jj]; S[pr * m + jj] = tmp; }
+                    const float tmp = wv[c]; wv[c] = wv[pr]; wv[pr] = tmp;
+                }
+                const float inv = 1.f / S[c * m + c];
+                for (int jj = 0; jj < m; ++jj) S[c * m + jj] *= inv;
+                wv[c] *= inv;
+                for (int rr = 0; rr < m; ++rr) {
+                    if (rr == c) continue;
+                    const float f = S[rr * m + c];
+                    for (int jj = 0; jj < m; ++jj) S[rr * m + jj] -= f * S[c * m + jj];
+                    wv[rr] -= f * wv[c];
+                }
+            }
+            for (int q = 0; q < m; ++q) dn[q] = wv[q];
+        }
+        __syncthreads();
+    }
+    for (int a = tid; a < nf; a += LQP_NT) {
+        float d = u0[a];
+        for (int q = 0; q < m; ++q) d -= G[(size_t)q * Npm + a] * dn[q];
+        rhs[a] = d;
+    }
+    for (int q = tid; q < m; q += LQP_NT) rhs[nf + q] = dn[q];
 }
 
 // solve with the packed factor (one rhs per problem, in global memory, in place)

@@ -113,6 +113,93 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
 // accumulator register q of lane l is element (row = (q&3) + 8 (q>>2) + 4 (l>>5), col = l&31) of the quadrant
 __device__ __forceinline__ int quad_row(int q, int lh) { return (q & 3) + 8 * (q >> 2) + 4 * lh; }
 
+// ---- pivot block: in-place forward elimination of [A | I] -> W = L^-1 (A = L L^T), W and W^T left in LDS ----
+// src: the 64x64 block in global memory (row-major); kbase: 64 * (index of the pivot block), for the error code.
+// Contains workgroup barriers: every thread of the workgroup must call it.
+__device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk, float* __restrict__ W,
+                                               float* __restrict__ WT, float* __restrict__ pcol,
+                                               int* __restrict__ flag, const int kbase) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    // ---- pivot block: in-place forward elimination of [A_kk | I] -> W = L^-1 (A_kk = L L^T) ----
+    // Column c switches role from "A" to "augmented" at step c, so one 64x64 array is enough.  Only waves
+    // 0..3 work (lane = row, wave = 16-column quarter): the pivot row reaches a wave through v_readlane
+    // from its own lane c, the pivot column through LDS.  Measured per pivot block: 57k cycles with all 16
+    // waves on 4 elements each and a barrier per column, 48k with 4 waves and a barrier per column, 63k with
+    // the row broadcast through LDS too, 45-55k with barrier-free producer/consumer hand-overs (progress
+    // counter or sentinel slots in LDS): the barrier is not the expensive part.  The other waves only keep
+    // the barrier count.
+#ifndef SPD_WSTRIDE
+#define SPD_WSTRIDE 1
+#endif
+    const int prw = tid & 63, pq = w / SPD_WSTRIDE;
+    const bool pwork = (w % SPD_WSTRIDE) == 0 && pq < 4;
+    float xq[16];
+    if (pwork) {
+        const float* src = src_blk + prw * 64 + pq * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const V4<float> v4 = *(const V4<float>*)(src + 4 * t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[4 * t + e] = v4.v[e];
+        }
+    }
+    __syncthreads();                           // previous step's LDS reads are over
+    if (pwork) {
+        int bad = 0;                           // first non-positive pivot of this block (+1)
+        float srow = 1.f;                      // scale of this lane's row once it has been the pivot row
+#pragma unroll 1
+        for (int qc = 0; qc < 4; ++qc) {
+#pragma unroll
+            for (int ec = 0; ec < 16; ++ec) {
+                const int c = qc * 16 + ec;
+                const int par = ec & 1;
+                if (pq == qc) pcol[par * 64 + prw] = xq[ec];
+                wg_barrier_lds();
+                const float d = pcol[par * 64 + c];
+                const float pc = pcol[par * 64 + prw];
+                const bool ok = d > 0.f;
+                if (!ok && bad == 0) bad = kbase + c + 1;
+                const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
+                const bool below = prw > c, on = prw == c;
+                // rows below the pivot: x -= (x_rc / d) * (pivot row); the pivot row keeps its raw values and
+                // remembers its scale s (it is final: nobody reads it again), applied when W is written
+                const float coef = below ? pc * s * s : 0.f;
+                if (on) srow = s;
+                // the pivot row comes from this wave's own lane c: all 16 v_readlane first, into 16 different
+                // SGPRs (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
+                // readlane -> fma -> readlane chain then costs ~35 cycles per element)
+                float pr[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) xq[e] -= coef * pr[e];
+                __builtin_amdgcn_sched_barrier(0);
+                if (pq == qc) xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
+            }
+        }
+        if (bad != 0 && tid == 0 && flag[0] == 0) flag[0] = bad;
+        // W (lower, zero above the diagonal) and W^T
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = pq * 16 + e;
+            xq[e] = (q > prw) ? 0.f : xq[e] * srow;
+            WT[q * SPD_LS + prw] = xq[e];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            V4<float> v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4.v[e] = xq[4 * t + e];
+            *(V4<float>*)(W + prw * SPD_LS + pq * 16 + 4 * t) = v4;
+        }
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < 64; ++c) wg_barrier_lds();
+    }
+}
+
 // ---- block symmetric sweep: Hs (lower blocks of an SPD matrix) -> -inverse, in place ----
 // info: 0, or 1 + index of the first non-positive pivot.
 __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem,
@@ -140,84 +227,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                 preg[s] = *(const V4<float>*)(Hs + (size_t)blk * LQP_BLK + tid * 4);
             }
         }
-        // ---- pivot block: in-place forward elimination of [A_kk | I] -> W = L^-1 (A_kk = L L^T) ----
-        // Column c switches role from "A" to "augmented" at step c, so one 64x64 array is enough.  Only waves
-        // 0..3 work (lane = row, wave = 16-column quarter): the pivot row reaches a wave through v_readlane
-        // from its own lane c, the pivot column through LDS.  Measured per pivot block: 57k cycles with all 16
-        // waves on 4 elements each and a barrier per column, 48k with 4 waves and a barrier per column, 63k with
-        // the row broadcast through LDS too, 45-55k with barrier-free producer/consumer hand-overs (progress
-        // counter or sentinel slots in LDS): the barrier is not the expensive part.  The other waves only keep
-        // the barrier count.
-#ifndef SPD_WSTRIDE
-#define SPD_WSTRIDE 1
-#endif
-        const int prw = tid & 63, pq = w / SPD_WSTRIDE;
-        const bool pwork = (w % SPD_WSTRIDE) == 0 && pq < 4;
-        float xq[16];
-        if (pwork) {
-            const float* src = Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + prw * 64 + pq * 16;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const V4<float> v4 = *(const V4<float>*)(src + 4 * t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xq[4 * t + e] = v4.v[e];
-            }
-        }
-        __syncthreads();                           // previous step's LDS reads are over
-        if (pwork) {
-            int bad = 0;                           // first non-positive pivot of this block (+1)
-            float srow = 1.f;                      // scale of this lane's row once it has been the pivot row
-#pragma unroll 1
-            for (int qc = 0; qc < 4; ++qc) {
-#pragma unroll
-                for (int ec = 0; ec < 16; ++ec) {
-                    const int c = qc * 16 + ec;
-                    const int par = ec & 1;
-                    if (pq == qc) pcol[par * 64 + prw] = xq[ec];
-                    wg_barrier_lds();
-                    const float d = pcol[par * 64 + c];
-                    const float pc = pcol[par * 64 + prw];
-                    const bool ok = d > 0.f;
-                    if (!ok && bad == 0) bad = k * 64 + c + 1;
-                    const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
-                    const bool below = prw > c, on = prw == c;
-                    // rows below the pivot: x -= (x_rc / d) * (pivot row); the pivot row keeps its raw values and
-                    // remembers its scale s (it is final: nobody reads it again), applied when W is written
-                    const float coef = below ? pc * s * s : 0.f;
-                    if (on) srow = s;
-                    // the pivot row comes from this wave's own lane c: all 16 v_readlane first, into 16 different
-                    // SGPRs (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
-                    // readlane -> fma -> readlane chain then costs ~35 cycles per element)
-                    float pr[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) xq[e] -= coef * pr[e];
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (pq == qc) xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
-                }
-            }
-            if (bad != 0 && tid == 0 && flag[0] == 0) flag[0] = bad;
-            // W (lower, zero above the diagonal) and W^T
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int q = pq * 16 + e;
-                xq[e] = (q > prw) ? 0.f : xq[e] * srow;
-                WT[q * SPD_LS + prw] = xq[e];
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                V4<float> v4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4.v[e] = xq[4 * t + e];
-                *(V4<float>*)(W + prw * SPD_LS + pq * 16 + 4 * t) = v4;
-            }
-        } else {
-#pragma unroll 1
-            for (int c = 0; c < 64; ++c) wg_barrier_lds();
-        }
+        wg_pivot_block(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
         // ---- panel to LDS: slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k ----
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s) {
@@ -473,6 +483,166 @@ __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, LQP_NT>& st, cons
                 if (nx >= 0 && nx < Sr) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Blocked Cholesky of an SPD matrix held as packed lower blocks, in place (the symmetric backward system):
+//   block (i,k), i > k  <-  L_ik;   block (k,k)  <-  W_k = L_kk^-1   (so the solves below need no substitution
+//   inside a block).  Same machinery as the sweep, restricted to the trailing part: pivot block through
+//   wg_pivot_block, panel Y_i = A_ik W^T and the tile updates A_ij -= Y_i Y_j^T on MFMA.
+// info: 0, or 1 + index of the first non-positive pivot.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = tid >> 4, cq = tid & 15, li = lane & 31, lh = lane >> 5;
+    const int nslot = K > 1 ? K - 1 : 1;
+    float* Y = (float*)smem;
+    float* W = Y + (size_t)nslot * 64 * SPD_LS;
+    float* WT = W + 64 * SPD_LS;
+    float* pcol = WT + 64 * SPD_LS;
+    int* flag = (int*)(pcol + 256);
+    if (tid == 0) flag[0] = 0;
+    for (int k = 0; k < K; ++k) {
+        const int np = K - 1 - k;                           // panel blocks below the pivot: slot s <-> row k+1+s
+        V4<float> preg[SPD_MAXK - 1];
+#pragma unroll
+        for (int s = 0; s < SPD_MAXK - 1; ++s)
+            if (s < np) preg[s] = *(const V4<float>*)(Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK + tid * 4);
+        wg_pivot_block(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+#pragma unroll
+        for (int s = 0; s < SPD_MAXK - 1; ++s)
+            if (s < np) *(V4<float>*)(Y + ((size_t)s * 64 + r) * SPD_LS + cq * 4) = preg[s];
+        __syncthreads();
+        // the pre-inverted diagonal block
+        *(V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4) = *(const V4<float>*)(W + r * SPD_LS + cq * 4);
+        // ---- Y_i = P_i W^T (in place: all products first, then the writes) ----
+        {
+            const int ntask = np * 4;
+            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                if (task < ntask) {
+                    const int s = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                    const float* Xp = Y + ((size_t)s * 64 + 32 * qi) * SPD_LS;
+                    acc[u] = qj == 0 ? spd_quadrant<1, false>(Xp, W) : spd_quadrant(Xp, W + 32 * SPD_LS);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                if (task < ntask) {
+                    const int s = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                    float* dst = Y + ((size_t)s * 64 + 32 * qi) * SPD_LS + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) dst[quad_row(q, lh) * SPD_LS] = acc[u][q];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- L_ik = Y_i to its block; trailing tiles A_ij -= Y_i Y_j^T (i >= j > k) ----
+        for (int s = 0; s < np; ++s)
+            *(V4<float>*)(Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK + tid * 4) =
+                *(const V4<float>*)(Y + ((size_t)s * 64 + r) * SPD_LS + cq * 4);
+        {
+            const int nupd = np * (np + 1) / 2 * 4;
+            for (int task = __builtin_amdgcn_readfirstlane(w); task < nupd; task += LQP_NW) {
+                const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
+                int si = 0;
+                while ((si + 1) * (si + 2) / 2 <= p) ++si;
+                const int sj = p - si * (si + 1) / 2;
+                if (si == sj && qi == 0 && qj == 1) continue;      // diagonal tile: mirrored from its (1,0) quadrant
+                float* T0 = Hs + (size_t)sym_idx(k + 1 + si, k + 1 + sj, K) * LQP_BLK;
+                float* C = T0 + (32 * qi) * 64 + 32 * qj + li;
+                f32x16 cur;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];
+                const f32x16 acc = spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS,
+                                                Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
+                cur -= acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                if (si == sj && qi == 1 && qj == 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T0[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
+// L L^T x = v with the factor above, v (LDS, 64 K values) in place.  acc: 64 K floats, t: 64, part: NW * 64 of LDS.
+__device__ __forceinline__ void wg_chol_solve(const float* __restrict__ Ls, const int K, float* __restrict__ v,
+                                              float* __restrict__ acc, float* __restrict__ t, float* __restrict__ part) {
+    const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < K * 64; e += LQP_NT) acc[e] = 0.f;
+    __syncthreads();
+    // ---- L y = v, column by column ----
+    for (int j = 0; j < K; ++j) {
+        if (tid < 64) t[tid] = v[j * 64 + tid] - acc[j * 64 + tid];
+        __syncthreads();
+        {
+            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(j, j, K) * LQP_BLK + tid * 4);
+            const float s1 = rowgroup_sum<LQP_NT>(dot4(b, *(const V4<float>*)(t + cq * 4)));
+            if (cq == 0) v[j * 64 + r] = s1;
+        }
+        __syncthreads();
+        const V4<float> yj = *(const V4<float>*)(v + j * 64 + cq * 4);
+        for (int i = j + 1; i < K; ++i) {
+            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4);
+            const float s1 = rowgroup_sum<LQP_NT>(dot4(b, yj));
+            if (cq == 0) acc[i * 64 + r] += s1;              // (row r of block row i always belongs to this thread)
+        }
+        __syncthreads();
+    }
+    // ---- L^T x = y, from the last block column up ----
+    auto fold = [&](float (&a2)[4]) {                        // column sums of this wave's 4 rows -> part[w][64]
+        V4<float> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = a2[e];
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            o.v[e] = a;
+        }
+        if (lane < 16) *(V4<float>*)(part + w * 64 + cq * 4) = o;
+    };
+    for (int j = K - 1; j >= 0; --j) {
+        float a2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = j + 1; i < K; ++i) {
+            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4);
+            const float xi = v[i * 64 + r];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a2[e] += b.v[e] * xi;
+        }
+        fold(a2);
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < LQP_NW; ++ww) sum += part[ww * 64 + tid];
+            t[tid] = v[j * 64 + tid] - sum;
+        }
+        __syncthreads();
+        {
+            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(j, j, K) * LQP_BLK + tid * 4);
+            const float tr = t[r];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a2[e] = b.v[e] * tr;
+            fold(a2);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < LQP_NW; ++ww) sum += part[ww * 64 + tid];
+            v[j * 64 + tid] = sum;
+        }
+        __syncthreads();
     }
 }
 

@@ -49,6 +49,7 @@ class SolveBoxQPLayer(torch.autograd.Function):
         sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=(has_lb, has_ub),
                              sync=bool(control.get('sync', False)))
         ctx.rho = sol['rho']
+        ctx.linsolve = int(sol['_stats']['linsolve_used'])     # 2: Q was checked symmetric by the forward
         ctx.sync = bool(control.get('sync', False))
         ctx.backward_method = control.get('backward', 'fixed_point')
         ctx.save_for_backward(sol['x'], sol['u'], sol['lams'], sol['nus'], Q, A, lb, ub)
@@ -62,7 +63,7 @@ class SolveBoxQPLayer(torch.autograd.Function):
         need = ctx.needs_input_grad
         want = dict(dQ=need[0], dp=need[1], dA=need[2] and A is not None, db=need[3] and A is not None,
                     dlb=need[4], dub=need[5])
-        grads = _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, ctx.rho, want, sync=ctx.sync)
+        grads = _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, ctx.rho, want, sync=ctx.sync, linsolve=ctx.linsolve)
         return grads
 
 
@@ -305,7 +306,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True):
     return sol
 
 
-def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True):
+def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1):
     _lib.require_gpu(dl_dz, x, u, lams, nus, Q, A, lb, ub)
     lib = _lib.load()
     _lib.poll_errors()
@@ -333,7 +334,7 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True):
                                        _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
                                        rho_mode, rho_value, _lib.ptr(rho_tensor),
                                        _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
-                                       ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel())
+                                       ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel(), int(linsolve))
     if st == 3:
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {fail.value})")
     _lib.check(st, "torch_solve_box_qp_grad")

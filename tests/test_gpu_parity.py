@@ -14,6 +14,7 @@ import lqp_py_amd as L
 from lqp_py_amd import _lib, lu_layer
 from oracle import boxqp_oracle as O
 from conftest import load_golden
+import lqp_py_amd.solve_box_qp_admm_torch as SB
 
 pytestmark = pytest.mark.gpu
 TOL = dict(eps_abs=1e-5, eps_rel=1e-5)
@@ -304,6 +305,56 @@ def test_spd_path_falls_back_to_lu(dev):
     L.synchronize()
     assert torch.isfinite(x).all()
 
+
+@pytest.mark.parametrize("case", ["g2", "g4", "g6"])
+def test_cholesky_backward_matches_goldens_and_lu(dev, case):
+    """linsolve 2 of lqp_boxqp_backward_fp (blocked Cholesky of Q_FF + Schur complement of the equality rows)
+    against the reference's gradients and against the LU form of the same system."""
+    if case == "g2":
+        g = load_golden("g2_b8_n50_eq")
+        inp = tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")); cot = g["g_rand"]; ctl = O.make_control(**TOL)
+        ref = {nm: g[f"{nm}_rand"] for nm in GRADS}
+    elif case == "g4":
+        g = load_golden("g4_b128_n500_eq")
+        inp = O.create_qp_data(500, 128, seed=0); ctl = O.make_control(**TOL)
+        torch.manual_seed(7); cot = torch.randn(128, 500, 1)
+        ref = {nm: g[f"{nm}_rand"] for nm in GRADS[1:]}
+    else:
+        g = load_golden("g6_adaptive_scale")
+        inp = tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")); cot = g["g"]; ctl = O.make_control(rho=100.0, scale=True, **TOL)
+        ref = {nm: g[nm] for nm in GRADS}
+    sol, a = solve(dev, inp, ctl)
+    want = dict(dQ=True, dp=True, dA=True, db=True, dlb=True, dub=True)
+    out = {}
+    for ls in (1, 2):
+        out[ls] = SB._fp_backward(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"],
+                                 want, sync=True, linsolve=ls)
+    prof = _lib.profile(enable=True, reset=True)
+    SB._fp_backward(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"], want,
+                   sync=True, linsolve=2)
+    used = _lib.profile(); _lib.profile(enable=False)
+    assert used["bwd_cholesky"][1] == 1 and used["lu_factor"][1] == 0          # really the Cholesky path
+    for idx, nm in enumerate(GRADS):
+        scale = max(1.0, float(out[1][idx].abs().max()))
+        assert err(out[2][idx], out[1][idx]) < 2e-4 * scale, nm
+        if nm in ref:
+            assert err(out[2][idx], ref[nm]) < 2e-3 * max(1.0, float(ref[nm].abs().max())), nm
+
+
+def test_cholesky_backward_falls_back(dev):
+    """Q_FF not positive definite: the synchronous call repeats on the LU form and returns its answer."""
+    Q, p, A, b, lb, ub = O.create_qp_data(40, 3, seed=9)
+    Qi = Q - 0.5 * torch.eye(40)
+    a = [t.to(dev) for t in (Qi, p, A, b, lb, ub)]
+    x = torch.zeros(3, 40, 1, device=dev); u = torch.zeros_like(x)
+    lams = torch.zeros(3, 80, 1, device=dev); nus = torch.zeros(3, 1, 1, device=dev)
+    cot = torch.randn(3, 40, 1, device=dev)
+    want = dict(dQ=True, dp=True, dA=True, db=True, dlb=True, dub=True)
+    g1 = SB._fp_backward(cot, x, u, lams, nus, a[0], a[2], a[4], a[5], 1.0, want, sync=True, linsolve=1)
+    g2 = SB._fp_backward(cot, x, u, lams, nus, a[0], a[2], a[4], a[5], 1.0, want, sync=True, linsolve=2)
+    for t1, t2 in zip(g1[:6], g2[:6]):
+        assert torch.equal(t1, t2)
+
 # ---------------------------------------------------------------- size-independent properties
 def test_kkt_conditions_at_full_size(dev):
     """Known-answer check independent of the oracle, at the headline size."""
@@ -357,7 +408,14 @@ def test_autograd_module_matches_functional(dev):
     sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, L.box_qp_control(**TOL))
     gr = L.torch_solve_box_qp_grad(cot, sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
     assert torch.equal(x.detach(), sol["x"])
-    assert torch.equal(Qg.grad, gr[0]) and torch.equal(pg.grad, gr[1])
+    # (the module's backward runs the Cholesky form of the reduced system, the functional one the reference's LU)
+    assert rel(Qg.grad, gr[0]) < 1e-4 and rel(pg.grad, gr[1]) < 1e-4
+    xl = L.SolveBoxQP(control=L.box_qp_control(linsolve='lu', **TOL))(Qg, pg, A, b, lb, ub)
+    Qg.grad = None; pg.grad = None
+    xl.backward(cot)
+    sl = L.torch_solve_box_qp(Q, p, A, b, lb, ub, L.box_qp_control(linsolve='lu', **TOL))
+    gl = L.torch_solve_box_qp_grad(cot, sl["x"], sl["u"], sl["lams"], sl["nus"], Q, A, lb, ub, sl["rho"])
+    assert torch.equal(xl.detach(), sl["x"]) and torch.equal(Qg.grad, gl[0]) and torch.equal(pg.grad, gl[1])
 
 
 def test_module_path_does_not_sync_and_defers_errors(dev):
