@@ -326,6 +326,16 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             loop_nt = 1024;
             loop_fn = k_admm_loop<T, true, false, 1024, true>;
             tail_fn = k_admm_loop<T, true, true, 1024, true>;
+            // optional 512-thread first launch (8 elements per thread, 12 register-resident blocks).  Measured at
+            // B=128 n=500: 0.96-0.99 ms with an 8-deep ring (26 spilled VGPRs), 0.87 ms with a 6-deep one, against
+            // 0.885 ms for the 1024-thread kernel: neither the halved instruction count nor the fewer streamed
+            // blocks show, the product is bound by the un-overlapped sum of its resident and streamed phases.
+            if (env_int("LQP_SYM512", 0)) {
+                P.sym_rl_hot = sym_resident_lds_blocks(n, m, P.Ks, resident_regs<512>(), 8);
+                loop_lds = sym_loop_lds_bytes(n, m, P.Ks, P.sym_rl_hot, 8);
+                loop_nt = 512;
+                loop_fn = k_admm_loop<T, true, false, 512, true>;
+            }
         }
     }
     rc = ensure_lds((const void*)loop_fn, loop_lds);

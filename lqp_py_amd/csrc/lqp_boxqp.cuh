@@ -18,7 +18,8 @@ enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_WORDS = 8 };
 
 template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
-    int Ks, sym_rl;                      // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
+    int Ks, sym_rl, sym_rl_hot;          // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
+                                         // (continuation kernel / 512-thread first launch)
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
@@ -621,16 +622,16 @@ __device__ __forceinline__ void loop_store_nu(const VecView<T>& V, const T* __re
     }
 }
 // LDS of the loop on the symmetric path; rl = LDS-resident blocks
-__host__ __device__ inline int sym_loop_lds_bytes(int n, int m, int Ks, int rl) {
+__host__ __device__ inline int sym_loop_lds_bytes(int n, int m, int Ks, int rl, int nw = LQP_NW) {
     const int Nps = Ks * LQP_NB;
-    return (rl * LQP_BLK + 3 * Nps + sym_blocks(Ks) * 64 + LQP_NW * Nps + 6 * n + 2 * m + LQP_NW * 8 + 8) * 4 + 64;
+    return (rl * LQP_BLK + 3 * Nps + sym_blocks(Ks) * 64 + nw * Nps + 6 * n + 2 * m + nw * 8 + 8) * 4 + 64;
 }
 // how many blocks of the symmetric stream stay in LDS (after the LQP_RREG register blocks)
-__host__ __device__ inline int sym_resident_lds_blocks(int n, int m, int Ks) {
+__host__ __device__ inline int sym_resident_lds_blocks(int n, int m, int Ks, int nreg = LQP_RREG, int nw = LQP_NW) {
     const int S = sym_blocks(Ks);
-    int rl = S - LQP_RREG;
+    int rl = S - nreg;
     if (rl < 0) rl = 0;
-    while (rl > 0 && sym_loop_lds_bytes(n, m, Ks, rl) > 160 * 1024) --rl;
+    while (rl > 0 && sym_loop_lds_bytes(n, m, Ks, rl, nw) > 160 * 1024) --rl;
     return rl;
 }
 
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     // LDS carve.  LU path:  [resident blocks] v tmp | z u ps lb ub D bs red | dest
     //            SYM path: [resident blocks] v xs ylds cvl part[NW][Nps] | z u ps lb ub D bs red
     const int Nps = SYM ? P.Ks * LQP_NB : Np;                // padded length of the solve vector
-    const int rl = SYM ? P.sym_rl : LQP_RLDS;
+    const int rl = SYM ? (NT == 512 ? P.sym_rl_hot : P.sym_rl) : LQP_RLDS;
     T* lds_res = (T*)smem;                                   // resident blocks (RES only), 16-KB aligned chunks
     T* v = lds_res + (RES ? (size_t)rl * LQP_BLK : 0);
     T* tmp = v + Nps;                                        // LU: 64 scratch; SYM: xs (the new x)
@@ -740,8 +741,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     ResidentRegs<T, NT> rr;
     if constexpr (SYM) {
         if constexpr (RES) {
-            sym_resident_load(rr, lds_res, packed, S, rl);
-            sym_prime(st, packed, (S < LQP_RREG ? S : LQP_RREG) + rl, S);
+            sym_resident_load<NT>(rr, lds_res, packed, S, rl);
+            sym_prime<NT>(st, packed, (S < resident_regs<NT>() ? S : resident_regs<NT>()) + rl, S);
         }
     } else if constexpr (RES) {
         resident_load<T, NT>(rr, lds_res, packed);
@@ -783,10 +784,10 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
         if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
         // ---- x-update: cached triangular solves (:267), or x = c - Hs w on the symmetric path ----
         if constexpr (SYM) {
-            wg_sym_gemv<RES>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
+            wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
             wg_barrier_lds();
             if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
-            for (int e = tid; e < Nps; e += NT) xs[e] = cvl[e] - sym_combine(e, P.Ks, Nps, ylds, part);
+            for (int e = tid; e < Nps; e += NT) xs[e] = cvl[e] - sym_combine<NT>(e, P.Ks, Nps, ylds, part);
             wg_barrier_lds();
             if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
         } else if constexpr (RES) {

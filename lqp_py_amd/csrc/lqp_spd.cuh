@@ -368,103 +368,130 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
 // so no barrier is needed inside the product.  The caller combines (sym_combine) after a barrier.  Blocks [0, LQP_RREG) live in registers, the next `rl` in LDS, the rest stream through the ring
 // (which wraps into the next call: virtual length padded to a multiple of LQP_PF).
 // ---------------------------------------------------------------------------
-struct SymWalk {
+template <int NT> struct SymWalk {
     int i, j, s;
-    V4<float> wj;          // w_j slice of this thread's 4 columns
-    float acc2[4];
+    Frag<float, NT> wj;    // w_j slice of this thread's columns
+    float acc2[LQP_BLK / NT];
 };
 
-__device__ __forceinline__ void sym_begin(SymWalk& wk, const float* __restrict__ v) {
+// thread t of an NT-thread workgroup owns EPT = 4096 / NT consecutive elements of a block: row t / LPR,
+// columns EPT * (t % LPR) ..  (NT = 1024: 4 elements, 16 lanes per row; NT = 512: 8 elements, 8 lanes per row)
+template <int NT>
+__device__ __forceinline__ void sym_begin(SymWalk<NT>& wk, const float* __restrict__ v) {
+    constexpr int EPT = LQP_BLK / NT, LPR = LQP_NB / EPT;
     wk.i = 0; wk.j = 0; wk.s = 0;
-    wk.wj = *(const V4<float>*)(v + (threadIdx.x & 15) * 4);
+    const float* p = v + (threadIdx.x % LPR) * EPT;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wk.acc2[e] = 0.f;
+    for (int q = 0; q < EPT / 4; ++q) wk.wj.q[q] = *(const V4<float>*)(p + 4 * q);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) wk.acc2[e] = 0.f;
 }
 
-__device__ __forceinline__ void sym_block(SymWalk& wk, const Frag<float, LQP_NT>& blk, const int K, const int Np,
+template <int NT>
+__device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>& blk, const int K, const int Np,
                                           const float* __restrict__ v, float* __restrict__ ylds,
                                           float* __restrict__ part) {
-    const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
-    const V4<float> b = blk.q[0];
-    const float s1 = rowgroup_sum<LQP_NT>(dot4(b, wk.wj));
+    constexpr int EPT = LQP_BLK / NT, LPR = LQP_NB / EPT;
+    const int tid = threadIdx.x, r = tid / LPR, cq = tid % LPR, lane = tid & 63, w = tid >> 6;
+    float d = 0.f;
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) d += dot4(blk.q[q], wk.wj.q[q]);
+    const float s1 = rowgroup_sum<NT>(d);
     if (cq == 0) ylds[wk.s * 64 + r] = s1;           // one slot per block: write-only, no read-modify-write stall
     ++wk.s;
     if (wk.i != wk.j) {
         const float wi = v[wk.i * 64 + r];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wk.acc2[e] += b.v[e] * wi;
+        for (int e = 0; e < EPT; ++e) wk.acc2[e] += blk.q[e >> 2].v[e & 3] * wi;
     }
     if (++wk.i == K) {
-        // end of block column j: fold the 4 rows this wave holds, publish 64 column sums
-        V4<float> o;
+        // end of block column j: fold the rows this wave holds, publish its 64 column sums
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EPT; ++e) {
             float a = wk.acc2[e];
-            a += __shfl_xor(a, 16);
-            a += __shfl_xor(a, 32);
-            o.v[e] = a;
-            wk.acc2[e] = 0.f;
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) a += __shfl_xor(a, off);
+            wk.acc2[e] = a;
         }
-        if (lane < 16) *(V4<float>*)(part + (size_t)w * Np + wk.j * 64 + cq * 4) = o;
+        if (lane < LPR) {
+            float* dst = part + (size_t)w * Np + wk.j * 64 + cq * EPT;
+#pragma unroll
+            for (int q = 0; q < EPT / 4; ++q) {
+                V4<float> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.v[e] = wk.acc2[4 * q + e];
+                *(V4<float>*)(dst + 4 * q) = o;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) wk.acc2[e] = 0.f;
         ++wk.j;
         wk.i = wk.j;
-        if (wk.j < K) wk.wj = *(const V4<float>*)(v + wk.j * 64 + cq * 4);
+        if (wk.j < K) {
+            const float* p = v + wk.j * 64 + cq * EPT;
+#pragma unroll
+            for (int q = 0; q < EPT / 4; ++q) wk.wj.q[q] = *(const V4<float>*)(p + 4 * q);
+        }
     }
 }
 
 // register-resident head of the symmetric stream
 typedef ResidentRegs<float, LQP_NT> SymResident;
-__device__ __forceinline__ void sym_resident_load(SymResident& rr, float* __restrict__ lds_res,
+template <int NT>
+__device__ __forceinline__ void sym_resident_load(ResidentRegs<float, NT>& rr, float* __restrict__ lds_res,
                                                   const float* __restrict__ Hs, const int S, const int rl) {
+    constexpr int NR = resident_regs<NT>();
 #pragma unroll
-    for (int i = 0; i < LQP_RREG; ++i)
-        if (i < S) rr.r[i] = frag_load<float, LQP_NT>(Hs + (size_t)i * LQP_BLK);
+    for (int i = 0; i < NR; ++i)
+        if (i < S) rr.r[i] = frag_load<float, NT>(Hs + (size_t)i * LQP_BLK);
     for (int i = 0; i < rl; ++i)
-        frag_store<float, LQP_NT>(lds_res + (size_t)i * LQP_BLK,
-                                  frag_load<float, LQP_NT>(Hs + (size_t)(LQP_RREG + i) * LQP_BLK));
+        frag_store<float, NT>(lds_res + (size_t)i * LQP_BLK, frag_load<float, NT>(Hs + (size_t)(NR + i) * LQP_BLK));
 }
 // prime the ring with the first streamed blocks
-__device__ __forceinline__ void sym_prime(BlockStream<float, LQP_NT>& st, const float* __restrict__ Hs,
+template <int NT>
+__device__ __forceinline__ void sym_prime(BlockStream<float, NT>& st, const float* __restrict__ Hs,
                                           const int first, const int S) {
 #pragma unroll
     for (int i = 0; i < LQP_PF; ++i)
-        if (first + i < S) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(first + i) * LQP_BLK);
+        if (first + i < S) st.buf[i] = frag_load<float, NT>(Hs + (size_t)(first + i) * LQP_BLK);
 }
 
-// y[e] for e = 64 i + r: the row sums of blocks (i, j <= i) plus the 16 column partials
+// y[e] for e = 64 i + r: the row sums of blocks (i, j <= i) plus the column partials of the NW waves
+template <int NT = LQP_NT>
 __device__ __forceinline__ float sym_combine(const int e, const int K, const int Np, const float* __restrict__ ylds,
                                              const float* __restrict__ part) {
     const int i = e >> 6, r = e & 63;
     float y = 0.f;
     for (int j = 0; j <= i; ++j) y += ylds[sym_idx(i, j, K) * 64 + r];
 #pragma unroll
-    for (int ww = 0; ww < LQP_NW; ++ww) y += part[(size_t)ww * Np + e];
+    for (int ww = 0; ww < NT / 64; ++ww) y += part[(size_t)ww * Np + e];
     return y;
 }
 
 // RES: resident head (registers + rl LDS blocks) and a ring that already holds the first streamed blocks and is
 // refilled cyclically; !RES: everything streamed, ring primed here, not cyclic.
-template <bool RES>
-__device__ __forceinline__ void wg_sym_gemv(BlockStream<float, LQP_NT>& st, const SymResident& rr,
+template <bool RES, int NT = LQP_NT>
+__device__ __forceinline__ void wg_sym_gemv(BlockStream<float, NT>& st, const ResidentRegs<float, NT>& rr,
                                             const float* __restrict__ lds_res, const int rl,
                                             const float* __restrict__ Hs, const int K, const int Np,
                                             const float* __restrict__ v, float* __restrict__ ylds,
                                             float* __restrict__ part) {
+    constexpr int NR = resident_regs<NT>();
     const int S = sym_blocks(K);
-    SymWalk wk;
-    sym_begin(wk, v);
+    SymWalk<NT> wk;
+    sym_begin<NT>(wk, v);
     int R0 = 0;
     if constexpr (RES) {
 #pragma unroll
-        for (int s = 0; s < LQP_RREG; ++s)
-            if (s < S) sym_block(wk, rr.r[s], K, Np, v, ylds, part);
+        for (int s = 0; s < NR; ++s)
+            if (s < S) sym_block<NT>(wk, rr.r[s], K, Np, v, ylds, part);
         for (int s = 0; s < rl; ++s) {
-            const Frag<float, LQP_NT> blk = frag_load<float, LQP_NT>(lds_res + (size_t)s * LQP_BLK);
-            sym_block(wk, blk, K, Np, v, ylds, part);
+            const Frag<float, NT> blk = frag_load<float, NT>(lds_res + (size_t)s * LQP_BLK);
+            sym_block<NT>(wk, blk, K, Np, v, ylds, part);
         }
-        R0 = (S < LQP_RREG ? S : LQP_RREG) + rl;
+        R0 = (S < NR ? S : NR) + rl;
     } else {
-        sym_prime(st, Hs, 0, S);
+        sym_prime<NT>(st, Hs, 0, S);
     }
     const int Sr = S - R0;                                  // streamed blocks
     const int Sv = round_up(Sr, LQP_PF);                    // virtual ring length
@@ -473,14 +500,14 @@ __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, LQP_NT>& st, cons
         for (int i = 0; i < LQP_PF; ++i) {
             const int s = s0 + i;
             if (s < Sr) {
-                const Frag<float, LQP_NT> blk = st.buf[i];
+                const Frag<float, NT> blk = st.buf[i];
                 int nx = s + LQP_PF;
                 if (RES && nx >= Sv) nx -= Sv;
-                if (nx < Sr) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
-                sym_block(wk, blk, K, Np, v, ylds, part);
+                if (nx < Sr) st.buf[i] = frag_load<float, NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
+                sym_block<NT>(wk, blk, K, Np, v, ylds, part);
             } else if (RES) {
                 const int nx = s + LQP_PF - Sv;             // padding slot: only refill it for the next call
-                if (nx >= 0 && nx < Sr) st.buf[i] = frag_load<float, LQP_NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
+                if (nx >= 0 && nx < Sr) st.buf[i] = frag_load<float, NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
             }
         }
     }

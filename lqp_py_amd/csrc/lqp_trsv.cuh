@@ -227,7 +227,7 @@ __device__ __forceinline__ void stream_prime(BlockStream<T, NT>& st, const T* __
 #define LQP_RREG 8      // measured: 8+8 resident blocks, PF 8 is spill-free and fastest (16 spills, 12 needs PF 4)
 #endif
 #ifndef LQP_RREG512
-#define LQP_RREG512 16
+#define LQP_RREG512 12
 #endif
 #ifndef LQP_RLDS
 #define LQP_RLDS 8
