@@ -442,11 +442,6 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
     return true;
 }
 
-// TAIL = continuation launch of the speculative (no host sync) schedule.  It has its own name in traces /
-// profiles (it exits at once when the first launch converged) and, when `persistent & 2`, starts with the
-// adaptive-rho step of iteration it0 (:237-256) done in-kernel: global decision from the counters of the
-// last check, masked rho update, KKT re-assembly, LU refactorisation and re-pack by this workgroup.  Only
-// this cold variant carries the LU / pack code; the first (hot) launch stays lean.
 // ---------------------------------------------------------------------------
 // symmetric-inverse path (lqp_spd.cuh): factorisation kernels
 // ---------------------------------------------------------------------------
@@ -635,6 +630,16 @@ __host__ __device__ inline int sym_resident_lds_blocks(int n, int m, int Ks, int
     return rl;
 }
 
+// ---------------------------------------------------------------------------
+// The ADMM loop (:235-313).  RES: resident head of the factor stream (registers + LDS); SYM: symmetric-inverse
+// x-update instead of the cached triangular solves; NT: threads.
+// TAIL = continuation launch of the speculative (no host sync) schedule.  It has its own name in traces /
+// profiles, exits at once when the first launch converged and, when `persistent & 2`, does the adaptive-rho
+// steps (:237-256) in-kernel: global decision from the counters of the last check, masked rho update and
+// refactorisation by this workgroup -- LU path: at its first iteration (LU + re-pack); symmetric path: at every
+// event inside [it0, it1), segment by segment.  Only this cold variant carries the factorisation code; the first
+// (hot) launch stays lean.
+// ---------------------------------------------------------------------------
 template <typename T, bool RES, bool TAIL, int NT, bool SYM = false>
 __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
                                                       const int ctr_base,       // counter slot of check it0 / check
