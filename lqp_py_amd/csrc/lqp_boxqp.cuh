@@ -601,20 +601,12 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P
 }
 
 // equality duals of the last x-update.  LU path: the tail of the solve vector.  Symmetric path:
-// nu = S^-1 (G^T w - b) = T^T w - s0, with w still in v (one wave per row)
+// nu = S^-1 (G^T w - b) = T^T w - s0, left in LDS by the loop
 template <typename T, int NT, bool SYM>
-__device__ __forceinline__ void loop_store_nu(const VecView<T>& V, const T* __restrict__ v, const int n, const int m) {
-    if constexpr (SYM) {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        for (int r = w; r < m; r += NT / 64) {
-            T acc = T(0);
-            for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
-            acc = wave_sum(acc);
-            if (lane == 0) V.nu[r] = acc - V.s0[r];
-        }
-    } else {
-        for (int r = threadIdx.x; r < m; r += NT) V.nu[r] = v[n + r];
-    }
+__device__ __forceinline__ void loop_store_nu(const VecView<T>& V, const T* __restrict__ v, const T* __restrict__ nus_l,
+                                              const int n, const int m) {
+    const T* src = SYM ? nus_l : v + n;          // symmetric path: computed while v still held w (check / last iteration)
+    for (int r = threadIdx.x; r < m; r += NT) V.nu[r] = src[r];
 }
 // LDS of the loop on the symmetric path; rl = LDS-resident blocks
 __host__ __device__ inline int sym_loop_lds_bytes(int n, int m, int Ks, int rl, int nw = LQP_NW) {
@@ -774,44 +766,25 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     int slot = (TAIL && SYM) ? ((it0 + P.check_solved - 1) / P.check_solved) % P.ring : ctr_base;
     for (int it = it0; it < it1; ++it) {
         if (dbg_on) dt0 = clock64();
-        // ---- rhs = [-p + rho (z - u); b], scattered to its pivoted position (:259-262) ----
-        if constexpr (SYM) {
-            for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
-        } else {
-            for (int i = tid; i < Np; i += NT) {
-                T val = T(0);
-                if (i < n) val = -ps[i] + rho * (z[i] - u[i]);
-                else if (i < N) val = bs[i - n];
-                v[dest[i]] = val;
-            }
-        }
-        wg_barrier_lds();
-        if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
-        // ---- x-update: cached triangular solves (:267), or x = c - Hs w on the symmetric path ----
-        if constexpr (SYM) {
-            wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
-            wg_barrier_lds();
-            if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
-            for (int e = tid; e < Nps; e += NT) xs[e] = cvl[e] - sym_combine<NT>(e, P.Ks, Nps, ylds, part);
-            wg_barrier_lds();
-            if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
-        } else if constexpr (RES) {
-            wg_packed_solve_resident<T, NT>(st, rr, lds_res, packed, K, v, tmp, true);
-        } else {
-            wg_packed_solve<T, NT>(st, packed, K, v, tmp, cyclic);
-            if (!cyclic && it + 1 < it1) stream_prime<T, NT>(st, packed, S);
-        }
-        // ---- z-update, residuals, dual (:271-282) ----
         const bool check = (it % P.check_solved) == 0;
         T mx[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) mx[q] = T(0);
         // ||Q x / D||_inf of the check (:299) without touching Q: the x-update solved (Qs + rho I) x + As^T nu = w
         // exactly (to the solve's rounding), so Qs x = w - rho x - As^T nu.  It only feeds a tolerance SCALE.
-        const T* nul = v + n;                                // LU path: nu is the tail of the solution
         if constexpr (SYM) {
-            if (check && m > 0) {                            // nu = T^T w - s0, one wave per row
-                T* nus_l = bs + m;
+            // ---- symmetric path: product | barrier | ONE fused element-wise pass (combine, z/u update, residual
+            //      norms, next right-hand side) | barrier.  v holds w = -p + rho (z - u) on entry. ----
+            if (it == it0) {
+                for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
+                wg_barrier_lds();
+            }
+            if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
+            wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
+            wg_barrier_lds();
+            if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
+            T* nus_l = bs + m;
+            if ((check || it + 1 == it1) && m > 0) {         // nu = T^T w - s0 (one wave per row) while v is still w
                 for (int r = w; r < m; r += (NT / 64)) {
                     T acc = T(0);
                     for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
@@ -820,30 +793,78 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
                 }
                 wg_barrier_lds();
             }
-            nul = bs + m;
-        }
-        for (int i = tid; i < n; i += NT) {
-            const T xi = xv[i];
-            const T zp = z[i];
-            const T ui = u[i];
-            T zn = xi + ui;
-            if (P.any_lb) zn = tmax(zn, lb[i]);
-            if (P.any_ub) zn = tmin(zn, ub[i]);
-            const T r = xi - zn;
-            const T s = rho * (zn - zp);
-            const T un = ui + r;
-            z[i] = zn;
-            u[i] = un;
-            if (check) {
-                const T di = D[i];
-                mx[0] = tmax(mx[0], tabs(di * r));
-                mx[1] = tmax(mx[1], tabs(di * s));
-                mx[2] = tmax(mx[2], tabs(di * xi));
-                mx[3] = tmax(mx[3], tabs(di * zn));
-                mx[4] = tmax(mx[4], tabs((rho * di) * un));
-                T qx = -ps[i] + rho * (zp - ui) - rho * xi;
-                for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nul[q];
-                mx[5] = tmax(mx[5], tabs(qx / di));
+            if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
+            for (int i = tid; i < Nps; i += NT) {
+                const T xi = cvl[i] - sym_combine<NT>(i, P.Ks, Nps, ylds, part);
+                xs[i] = xi;
+                T wn = T(0);
+                if (i < n) {
+                    const T zp = z[i];
+                    const T ui = u[i];
+                    T zn = xi + ui;
+                    if (P.any_lb) zn = tmax(zn, lb[i]);
+                    if (P.any_ub) zn = tmin(zn, ub[i]);
+                    const T r = xi - zn;
+                    const T s = rho * (zn - zp);
+                    const T un = ui + r;
+                    z[i] = zn;
+                    u[i] = un;
+                    if (check) {
+                        const T di = D[i];
+                        mx[0] = tmax(mx[0], tabs(di * r));
+                        mx[1] = tmax(mx[1], tabs(di * s));
+                        mx[2] = tmax(mx[2], tabs(di * xi));
+                        mx[3] = tmax(mx[3], tabs(di * zn));
+                        mx[4] = tmax(mx[4], tabs((rho * di) * un));
+                        T qx = v[i] - rho * xi;
+                        for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nus_l[q];
+                        mx[5] = tmax(mx[5], tabs(qx / di));
+                    }
+                    wn = -ps[i] + rho * (zn - un);           // next iteration's right-hand side
+                }
+                v[i] = wn;
+            }
+        } else {
+            // ---- rhs = [-p + rho (z - u); b], scattered to its pivoted position (:259-262) ----
+            for (int i = tid; i < Np; i += NT) {
+                T val = T(0);
+                if (i < n) val = -ps[i] + rho * (z[i] - u[i]);
+                else if (i < N) val = bs[i - n];
+                v[dest[i]] = val;
+            }
+            wg_barrier_lds();
+            // ---- x-update: cached triangular solves (:267) ----
+            if constexpr (RES) {
+                wg_packed_solve_resident<T, NT>(st, rr, lds_res, packed, K, v, tmp, true);
+            } else {
+                wg_packed_solve<T, NT>(st, packed, K, v, tmp, cyclic);
+                if (!cyclic && it + 1 < it1) stream_prime<T, NT>(st, packed, S);
+            }
+            // ---- z-update, residuals, dual (:271-282) ----
+            const T* nul = v + n;                            // nu is the tail of the solution
+            for (int i = tid; i < n; i += NT) {
+                const T xi = v[i];
+                const T zp = z[i];
+                const T ui = u[i];
+                T zn = xi + ui;
+                if (P.any_lb) zn = tmax(zn, lb[i]);
+                if (P.any_ub) zn = tmin(zn, ub[i]);
+                const T r = xi - zn;
+                const T s = rho * (zn - zp);
+                const T un = ui + r;
+                z[i] = zn;
+                u[i] = un;
+                if (check) {
+                    const T di = D[i];
+                    mx[0] = tmax(mx[0], tabs(di * r));
+                    mx[1] = tmax(mx[1], tabs(di * s));
+                    mx[2] = tmax(mx[2], tabs(di * xi));
+                    mx[3] = tmax(mx[3], tabs(di * zn));
+                    mx[4] = tmax(mx[4], tabs((rho * di) * un));
+                    T qx = -ps[i] + rho * (zp - ui) - rho * xi;
+                    for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nul[q];
+                    mx[5] = tmax(mx[5], tabs(qx / di));
+                }
             }
         }
         if (check) {
@@ -888,7 +909,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
                     // leave the loop with the state of iteration `it`
                     __syncthreads();
                     for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
-                    loop_store_nu<T, NT, SYM>(V, v, n, m);
+                    loop_store_nu<T, NT, SYM>(V, v, bs + m, n, m);
                     if (dbg_on && tid == 0) {
                         dbt[3] += clock64() - dt0;
                         for (int q = 0; q < 4; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
@@ -904,7 +925,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
         for (int q = 0; q < 4; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
     // ---- save state for the next launch / the epilogue ----
     for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
-    loop_store_nu<T, NT, SYM>(V, v, n, m);
+    loop_store_nu<T, NT, SYM>(V, v, bs + m, n, m);
     if (!(TAIL && SYM) || seg1 >= it_end) break;
     seg0 = seg1;
     __syncthreads();
