@@ -62,26 +62,53 @@ __device__ __forceinline__ void wg_sym_init(float* __restrict__ Hs, const float*
 }
 
 // max |A_ij - A_ji| over the matrix, compared with its rounding level: returns > 0 when src is NOT symmetric
-// (difference above 1e-5 of the largest entry), 0 otherwise.  red: >= 2 * LQP_NW floats of LDS.
+// (difference above 1e-5 of the largest entry), 0 otherwise.  Every block (i, j) is read next to its mirror
+// (j, i), both as coalesced row segments; the mirror goes through a padded LDS tile (two tiles alternate, one
+// barrier per block) and is compared transposed.  (Comparing src[c][r] straight from global memory cost 95 us per
+// launch at n = 500: 16-B pieces of 64 different rows per load instruction.)
+// smem: 2 * 64 * SPD_LS + 2 * LQP_NW floats.
 __device__ __forceinline__ float wg_sym_asymmetry(const float* __restrict__ src, const int ld, const int n, const int K,
-                                                  float* __restrict__ red) {
+                                                  float* __restrict__ smem_f) {
     const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
-    float dmax = 0.f, vmax = 0.f;
-    for (int j = 0; j < K; ++j)
-        for (int i = j; i < K; ++i) {
-            const int gr = i * 64 + r;
+    float* tile = smem_f;                                   // [2][64][SPD_LS]
+    float* red = smem_f + 2 * 64 * SPD_LS;
+    const bool vec_ok = (ld % 4 == 0) && ((((uintptr_t)src) & 15) == 0);
+    // 4 elements of row `row`, columns col .. col+3 (zero outside the matrix)
+    auto load4 = [&](const int row, const int col) -> V4<float> {
+        V4<float> v;
+        if (row < n && col + 3 < n && vec_ok) {
+            v = *(const V4<float>*)(src + (size_t)row * ld + col);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gc = j * 64 + c4 + e;
-                if (gr < n && gc < n && gc < gr) {
-                    const float a = src[(size_t)gr * ld + gc], bt = src[(size_t)gc * ld + gr];
-                    dmax = tmax(dmax, tabs(a - bt));
-                    vmax = tmax(vmax, tmax(tabs(a), tabs(bt)));
-                } else if (gr < n && gc == gr) {
-                    vmax = tmax(vmax, tabs(src[(size_t)gr * ld + gc]));
-                }
-            }
+            for (int e = 0; e < 4; ++e) v.v[e] = (row < n && col + e < n) ? src[(size_t)row * ld + col + e] : 0.f;
         }
+        return v;
+    };
+    float dmax = 0.f, vmax = 0.f;
+    const int nblk = sym_blocks(K);
+    int i = 0, j = 0;
+    V4<float> a = load4(r, c4), bm = a;                      // block (0,0) is its own mirror
+    for (int t = 0; t < nblk; ++t) {
+        float* T = tile + (t & 1) * 64 * SPD_LS;
+        *(V4<float>*)(T + r * SPD_LS + c4) = bm;
+        const V4<float> ac = a;
+        // the next block's two row segments are requested before this one is compared
+        int ni = i + 1, nj = j;
+        if (ni == K) { ++nj; ni = nj; }
+        if (t + 1 < nblk) {
+            a = load4(ni * 64 + r, nj * 64 + c4);
+            bm = load4(nj * 64 + r, ni * 64 + c4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bt = T[(c4 + e) * SPD_LS + r];      // mirror[c][r] = src[64 j + c][64 i + r]
+            dmax = tmax(dmax, tabs(ac.v[e] - bt));
+            vmax = tmax(vmax, tmax(tabs(ac.v[e]), tabs(bt)));
+        }
+        i = ni; j = nj;
+    }
+    __syncthreads();
     dmax = wg_max(dmax, red);
     vmax = wg_max(vmax, red + LQP_NW);
     return dmax > 1e-5f * vmax ? dmax : 0.f;
