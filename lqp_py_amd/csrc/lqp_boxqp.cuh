@@ -551,20 +551,30 @@ __device__ __forceinline__ void wg_eq_correct(const FwdParams<float>& P, const i
         for (int q2 = 0; q2 < m; ++q2) acc += Si[q * m + q2] * V.bs[q2];
         V.s0[q] = acc;
     }
-    // ---- Hs += T G^T on every lower block ----
+    // ---- Hs += T G^T on every lower block (8 blocks' loads in flight at a time: one after the other the
+    //      36 load -> update -> store round trips were pure latency) ----
     const int r = tid >> 4, c4 = (tid & 15) * 4;
-    for (int j = 0; j < Ks; ++j)
-        for (int i = j; i < Ks; ++i) {
-            float* blk = Hs + (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4;
-            V4<float> h = *(const V4<float>*)blk;
-            for (int q = 0; q < m; ++q) {
-                const float t = Tl[(size_t)q * Nps + i * 64 + r];
-                const V4<float> g = *(const V4<float>*)(G + (size_t)q * Nps + j * 64 + c4);
+    const int S = sym_blocks(Ks);
+    int bi = 0, bj = 0;                                      // block (bi, bj) of stream position s0
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        V4<float> h[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h.v[e] += t * g.v[e];
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < S) h[u] = *(const V4<float>*)(Hs + (size_t)(s0 + u) * LQP_BLK + tid * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + u < S) {
+                for (int q = 0; q < m; ++q) {
+                    const float t = Tl[(size_t)q * Nps + bi * 64 + r];
+                    const V4<float> g = *(const V4<float>*)(G + (size_t)q * Nps + bj * 64 + c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[u].v[e] += t * g.v[e];
+                }
+                *(V4<float>*)(Hs + (size_t)(s0 + u) * LQP_BLK + tid * 4) = h[u];
+                if (++bi == Ks) { ++bj; bi = bj; }
             }
-            *(V4<float>*)blk = h;
         }
+    }
 }
 
 // (re)factorisation of the symmetric path for problem b: Hs = -(Qs + rho I)^-1, then the equality correction.
