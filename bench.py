@@ -68,7 +68,7 @@ def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True):
 
 LOOP_KERNEL = {1: "lqp::k_admm_loop<float, true, false, 1024, false>",
                2: "lqp::k_admm_loop<float, true, false, 1024, true>"}
-TRAFFIC_FILE = "profiles/r01_e_traffic.json"
+TRAFFIC_FILE = "profiles/r01_f_traffic.json"
 
 
 def measured_traffic(kernel, mode, B, n):
