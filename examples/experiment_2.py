@@ -53,7 +53,7 @@ def train(n_x=500, n_batch=128, n_mini=32, n_epochs=100, n_features=5, lr=1e-3, 
         loss.backward()
         t2 = time.perf_counter()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         t_fwd += t1 - t0
         t_bwd += t2 - t1
         if verbose and (epoch % 10 == 0 or epoch == n_epochs - 1):

@@ -132,6 +132,13 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m,
                       lqp_boxqp_stats* stats,
                       void* workspace, size_t workspace_bytes);
 
+/* Primal / dual error (inf-norms of D r and D s, :287-288) of the LAST convergence check of the forward that
+ * used `workspace`, one value per problem -- the two numbers the reference's NumPy solver returns next to the
+ * solution (lqp_py/solve_box_qp_admm.py:265-267).  Either output may be NULL.                              */
+int lqp_boxqp_last_residuals(void* stream, int dtype, int B, int n, int m,
+                             const void* workspace, size_t workspace_bytes,
+                             void* primal_out, void* dual_out);
+
 /* ---- fixed-point implicit backward --------------------------------------
  * Replaces torch_solve_box_qp_grad (solve_box_qp_admm_torch.py:349-432):
  * active-set mask :360-365, non-symmetric system :378-392, linalg.solve

@@ -1,14 +1,17 @@
 """MI355X-native batched box-QP ADMM layer (drop-in for the box-QP path of
 ipo-lab/lqp_py).  The compute path is the HIP library built from ``csrc/``;
 there is no CPU fallback: CPU tensors or a missing library raise."""
-from .control import box_qp_control
-from .utils import get_ncon, torch_qp_eqcon_mat
+from .control import box_qp_control, optnet_control
+from .utils import get_ncon, make_matrix, torch_qp_eqcon_mat
 from .solve_box_qp_admm_torch import (SolveBoxQP, SolveBoxQPLayer, BoxQPTH, torch_solve_box_qp,
                                       torch_solve_box_qp_grad, torch_solve_box_qp_grad_kkt,
                                       torch_qp_int_grads, torch_qp_int_grads_admm)
 from .lu_layer import TorchLU, TorchLULayer
 from .solve_qp_eqcon_torch import torch_solve_qp_eqcon, torch_solve_qp_eqcon_grad
 from .solve_qp_uncon_torch import torch_solve_qp_uncon, torch_solve_qp_uncon_grad
+from .optnet import OptNet, OptNetLayer, torch_solve_qp_optnet
+from .solve_box_qp_admm import BoxQP, solve_box_qp
+from .solve_qp_uncon import solve_qp_uncon
 
 
 
@@ -25,4 +28,6 @@ __all__ = [
     "torch_solve_box_qp", "torch_solve_box_qp_grad", "torch_solve_box_qp_grad_kkt", "torch_qp_int_grads",
     "torch_qp_int_grads_admm", "TorchLU", "TorchLULayer",
     "torch_solve_qp_eqcon", "torch_solve_qp_eqcon_grad", "torch_solve_qp_uncon", "torch_solve_qp_uncon_grad",
+    "optnet_control", "make_matrix", "OptNet", "OptNetLayer", "torch_solve_qp_optnet", "BoxQP", "solve_box_qp",
+    "solve_qp_uncon",
 ]

@@ -54,6 +54,7 @@ SYMBOLS = {
                                   ctypes.POINTER(BoxQPCtrl), _P, _P, _P, _P, _P, _P, _P,
                                   ctypes.POINTER(BoxQPStats), _P, c_size_t]),
     "lqp_boxqp_forward_layout": (c_int, [c_int] * 4 + [ctypes.POINTER(c_size_t)] * 4),
+    "lqp_boxqp_last_residuals": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
                               [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int]),

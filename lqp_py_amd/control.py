@@ -23,3 +23,11 @@ def box_qp_control(max_iters=10_000, eps_abs=1e-3, eps_rel=1e-3, check_solved=No
     )
     control.update(**kwargs)                     # unknown keys (e.g. reduce='max') are carried, ignored
     return control
+
+
+def optnet_control(max_iters=10, tol=1e-3, check_solved=1, verbose=False, reduce='max', int_reg=1e-6, **kwargs):
+    """Control dict of ``OptNet`` (lqp_py/control.py:27-36, same keys, typo included)."""
+    control = dict(max_iters=max_iters, tol=tol, check_terimnation=check_solved, verbose=verbose, reduce=reduce,
+                   int_reg=int_reg)
+    control.update(**kwargs)
+    return control

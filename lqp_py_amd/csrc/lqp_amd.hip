@@ -806,6 +806,25 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m, const void* 
     return forward_impl<double>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes);
 }
 
+int lqp_boxqp_last_residuals(void* stream, int dtype, int B, int n, int m, const void* workspace, size_t workspace_bytes,
+                             void* primal_out, void* dual_out) {
+    if (bad_dims(dtype, B, n, m) || !workspace) return LQP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return LQP_OK;
+    if (dtype == LQP_F32) {
+        FwdLayout<float> L = carve_forward<float>(const_cast<void*>(workspace), B, n, m);
+        if (workspace_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+        hipLaunchKernelGGL(k_copy_residuals<float>, dim3((B + 255) / 256), dim3(256), 0, st, L.P.scal, (float*)primal_out,
+                           (float*)dual_out, B);
+    } else {
+        FwdLayout<double> L = carve_forward<double>(const_cast<void*>(workspace), B, n, m);
+        if (workspace_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+        hipLaunchKernelGGL(k_copy_residuals<double>, dim3((B + 255) / 256), dim3(256), 0, st, L.P.scal, (double*)primal_out,
+                           (double*)dual_out, B);
+    }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
 size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m) {
     if (bad_dims(dtype, B, n, m)) return 0;
     if (dtype == LQP_F32) { BwdParams<float> P; return carve_backward<float>(nullptr, B, n, m, P); }

@@ -14,7 +14,7 @@ enum { ST_DONE = 0, ST_FINAL_ITER = 1, ST_GATE = 2, ST_NFACTOR = 3, ST_RHO_UPDAT
 // per-check counters (uint32 x 4): not-optimal, wants-rho, ratio-trigger, arrivals
 enum { CT_NOTOPT = 0, CT_WANTS = 1, CT_TRIG = 2, CT_ARRIVE = 3, CT_WORDS = 4 };
 // per-problem scalars
-enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_WORDS = 8 };
+enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_PRI = 4, SC_DUA = 5, SC_WORDS = 8 };   // PRI/DUA: errors of the last check
 
 template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
@@ -897,6 +897,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
             if (tid == 0) {
                 scal[SC_RATIO] = ratio;
                 scal[SC_WANTS] = wants ? T(1) : T(0);
+                scal[SC_PRI] = mv[0];                        // primal / dual error of this check (the NumPy twin returns them)
+                scal[SC_DUA] = mv[1];
                 if (!solved) atomicAdd(ct + CT_NOTOPT, 1u);
                 if (wants) atomicAdd(ct + CT_WANTS, 1u);
                 if (trig) atomicAdd(ct + CT_TRIG, 1u);
@@ -981,6 +983,16 @@ __global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, con
     if (P.spd) return;
     const T* Qs = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
     assemble_kkt_rows(P, b, Qs, P.scale ? P.ldq : n, V, rho, true);
+}
+
+// primal / dual error of the last convergence check, per problem (lqp_boxqp_last_residuals)
+template <typename T>
+__global__ void k_copy_residuals(const T* __restrict__ scal, T* __restrict__ pri, T* __restrict__ dua, const int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        if (pri) pri[b] = scal[(size_t)b * SC_WORDS + SC_PRI];
+        if (dua) dua[b] = scal[(size_t)b * SC_WORDS + SC_DUA];
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -233,7 +233,7 @@ def _bad(msg):
     raise ValueError("lqp_py_amd: " + msg)
 
 
-def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True):
+def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False):
     _lib.require_gpu(Q, p, A, b, lb, ub)
     lib = _lib.load()
     _lib.poll_errors()
@@ -302,6 +302,13 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True):
     else:
         rho_ret = rho_out.view(B, 1, 1)     # (un-synchronised calls cannot know whether rho was adapted: tensor)
     sol = {"x": x, "z": z, "u": u, "lams": lams, "nus": nus, "rho": rho_ret, "iter": int(stats.iters)}
+    if residuals:                        # errors of the last check (the NumPy twin's extra outputs)
+        pri = torch.empty((B,), dtype=p.dtype, device=dev)
+        dua = torch.empty((B,), dtype=p.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.lqp_boxqp_last_residuals(_lib.stream_ptr(dev), dt, B, n, m, _lib.ptr(ws), ws.numel(),
+                                                    _lib.ptr(pri), _lib.ptr(dua)), "last_residuals")
+        sol["primal_error"], sol["dual_error"] = pri, dua
     sol["_stats"] = {k: getattr(stats, k) for k, _ in stats._fields_}
     return sol
 

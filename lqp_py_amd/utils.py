@@ -1,5 +1,14 @@
-"""Small helpers shared by the QP layers (reference: lqp_py/utils.py:14-32)."""
+"""Small helpers shared by the QP layers (reference: lqp_py/utils.py:5-32)."""
+import numpy as np
 import torch
+
+
+def make_matrix(x):
+    """1-D input -> column matrix (lqp_py/utils.py:5-11)."""
+    x = np.asarray(x)
+    if len(x.shape) < 2:
+        x = x.reshape(-1, 1)
+    return x
 
 
 def get_ncon(x, dim=0):

@@ -84,6 +84,42 @@ def main():
         _save = save
         save = lambda name, **kw: _save(name, **kw) if any(name.startswith(o) for o in only) else None
 
+    # G14: the NumPy twin (lqp_py/solve_box_qp_admm.py:45-91, single problem, float64) -- SURVEY 8f rank 4
+    from lqp_py.solve_box_qp_admm import solve_box_qp as np_solve_box_qp
+    out = {}
+    for tag, (n, with_eq, ctl) in {"a": (10, False, dict(scale=False, adaptive_rho=False)),
+                                   "b": (30, True, dict()),
+                                   "c": (64, True, dict(rho=5.0, adaptive_rho_iter=20))}.items():
+        Qt, pt, At, bt, lbt, ubt = ref_inputs(n, 1, 40 + n, with_eq=with_eq, dtype=torch.float64)
+        Qn, pn = Qt[0].numpy().astype(np.float64), pt[0, :, 0].numpy().astype(np.float64)
+        An = At[0].numpy().astype(np.float64) if with_eq else None
+        bn = bt[0, :, 0].numpy().astype(np.float64) if with_eq else None
+        lbn, ubn = lbt[0, :, 0].numpy().astype(np.float64), ubt[0, :, 0].numpy().astype(np.float64)
+        c = box_qp_control(**tol)
+        c.update(ctl)
+        sol = np_solve_box_qp(Qn, pn, An, bn, lbn, ubn, c)
+        out.update({f"{tag}_Q": Qn, f"{tag}_p": pn, f"{tag}_lb": lbn, f"{tag}_ub": ubn,
+                    f"{tag}_A": An if with_eq else np.zeros((0, n)), f"{tag}_b": bn if with_eq else np.zeros(0)})
+        for k2 in ("x", "z", "u", "lam", "rho", "primal_error", "dual_error", "iter"):
+            out[f"{tag}_{k2}"] = np.asarray(sol[k2])
+        out[f"{tag}_nu"] = np.asarray(sol["nu"]) if sol["nu"] is not None else np.zeros(0)
+        print("   numpy twin", tag, "iter", sol["iter"])
+    save("g14_numpy_twin", **out)
+
+    # G15: OptNet with equality constraints only (lqp_py/optnet.py:8-54 -> torch_solve_qp_eqcon / _grad)
+    from lqp_py.optnet import OptNet
+    from lqp_py.control import optnet_control
+    torch.manual_seed(15)
+    Qo, po, Ao, bo, _, _ = ref_inputs(20, 4, 15)
+    leaves = [t.clone().requires_grad_(True) for t in (Qo, po, Ao, bo)]
+    xo = OptNet(control=optnet_control())(leaves[0], leaves[1], leaves[2], leaves[3], None, None)
+    coto = torch.randn_like(xo)
+    xo.backward(coto)
+    save("g15_optnet_eq", Q=Qo, p=po, A=Ao, b=bo, cot=coto, x=xo, dQ=leaves[0].grad, dp=leaves[1].grad,
+         dA=leaves[2].grad, db=leaves[3].grad)
+    if only and all(o.startswith(("g14", "g15")) for o in only):
+        return
+
     # G1: BASELINE config 1 -- B=32 n=10 box-only, lb=-1 ub=1 (demo_solve_box_qp_torch.py:19-20)
     Q, p, _, _, _, _ = ref_inputs(10, 32, 0, with_eq=False)
     lb, ub = -torch.ones(32, 10, 1), torch.ones(32, 10, 1)

@@ -152,3 +152,22 @@ def test_kkt_conditions_known_answer():
     res = O.kkt_residuals(Q, p, A, b, lb, ub, sol)
     for k, v in res.items():
         assert float(v.max()) < 1e-6, (k, v)
+
+
+@pytest.mark.parametrize("tag,ctl", [("a", dict(scale=False, adaptive_rho=False)), ("b", dict()),
+                                     ("c", dict(rho=5.0, adaptive_rho_iter=20))])
+def test_g14_numpy_twin_is_the_same_algorithm(tag, ctl):
+    """The reference's NumPy solver (solve_box_qp_admm.py) and its torch solver are one algorithm: the oracle of the
+    torch path, run on a batch of one in float64, reproduces the NumPy goldens."""
+    g = load_golden("g14_numpy_twin")
+    t = lambda k: g[f"{tag}_{k}"].double()
+    n = t("p").shape[0]
+    has_eq = g[f"{tag}_A"] is not None
+    c = O.make_control(**TOL)
+    c.update(ctl)
+    sol = O.solve_box_qp(t("Q").reshape(1, n, n), t("p").reshape(1, n, 1),
+                         t("A").reshape(1, -1, n) if has_eq else None, t("b").reshape(1, -1, 1) if has_eq else None,
+                         t("lb").reshape(1, n, 1), t("ub").reshape(1, n, 1), c)
+    assert sol["iter"] == int(g[f"{tag}_iter"])
+    for k, kk in (("x", "x"), ("z", "z"), ("u", "u"), ("lams", "lam")):
+        close(sol[k].reshape(-1), t(kk), 1e-10, 1e-10)
