@@ -417,6 +417,7 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
                                           float* __restrict__ part) {
     constexpr int EPT = LQP_BLK / NT, LPR = LQP_NB / EPT;
     const int tid = threadIdx.x, r = tid / LPR, cq = tid % LPR, lane = tid & 63, w = tid >> 6;
+    const float wi = v[wk.i * 64 + r];               // (requested first: its LDS latency hides under the row sum)
     float d = 0.f;
 #pragma unroll
     for (int q = 0; q < EPT / 4; ++q) d += dot4(blk.q[q], wk.wj.q[q]);
@@ -424,7 +425,6 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
     if (cq == 0) ylds[wk.s * 64 + r] = s1;           // one slot per block: write-only, no read-modify-write stall
     ++wk.s;
     if (wk.i != wk.j) {
-        const float wi = v[wk.i * 64 + r];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) wk.acc2[e] += blk.q[e >> 2].v[e & 3] * wi;
     }

@@ -170,12 +170,14 @@ template <typename T, int NT> struct BlockStream {
     Frag<T, NT> buf[LQP_PF];
 };
 
+// (uniform block base + 32-bit per-thread byte offset: the load takes its base from SGPRs)
 template <typename T, int NT>
 __device__ __forceinline__ Frag<T, NT> frag_load(const T* __restrict__ blk) {
     Frag<T, NT> f;
-    const V4<T>* p = (const V4<T>*)blk + threadIdx.x * Frag<T, NT>::NV;
+    const char* base = (const char*)blk;
+    const unsigned int off = threadIdx.x * (unsigned int)(Frag<T, NT>::NV * sizeof(V4<T>));
 #pragma unroll
-    for (int i = 0; i < Frag<T, NT>::NV; ++i) f.q[i] = p[i];
+    for (int i = 0; i < Frag<T, NT>::NV; ++i) f.q[i] = *(const V4<T>*)(base + (off + i * (unsigned int)sizeof(V4<T>)));
     return f;
 }
 template <typename T, int NT>
