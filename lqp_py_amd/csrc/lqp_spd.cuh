@@ -417,18 +417,22 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
                                           float* __restrict__ part) {
     constexpr int EPT = LQP_BLK / NT, LPR = LQP_NB / EPT;
     const int tid = threadIdx.x, r = tid / LPR, cq = tid % LPR, lane = tid & 63, w = tid >> 6;
+    wk.i = __builtin_amdgcn_readfirstlane(wk.i);     // (the walk is uniform: keep it in SGPRs, scalar branches)
+    wk.j = __builtin_amdgcn_readfirstlane(wk.j);
+    wk.s = __builtin_amdgcn_readfirstlane(wk.s);
     const float wi = v[wk.i * 64 + r];               // (requested first: its LDS latency hides under the row sum)
     float d = 0.f;
 #pragma unroll
     for (int q = 0; q < EPT / 4; ++q) d += dot4(blk.q[q], wk.wj.q[q]);
     const float s1 = rowgroup_sum<NT>(d);
     if (cq == 0) ylds[wk.s * 64 + r] = s1;           // one slot per block: write-only, no read-modify-write stall
-    ++wk.s;
+    wk.s = __builtin_amdgcn_readfirstlane(wk.s + 1);     // (the walk is uniform: keep it in SGPRs, scalar branches)
     if (wk.i != wk.j) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) wk.acc2[e] += blk.q[e >> 2].v[e & 3] * wi;
     }
-    if (++wk.i == K) {
+    wk.i = __builtin_amdgcn_readfirstlane(wk.i + 1);
+    if (wk.i == K) {
         // end of block column j: fold the rows this wave holds, publish its 64 column sums
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -449,7 +453,7 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
         }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) wk.acc2[e] = 0.f;
-        ++wk.j;
+        wk.j = __builtin_amdgcn_readfirstlane(wk.j + 1);
         wk.i = wk.j;
         if (wk.j < K) {
             const float* p = v + wk.j * 64 + cq * EPT;
@@ -476,8 +480,8 @@ template <int NT>
 __device__ __forceinline__ void sym_prime(BlockStream<float, NT>& st, const float* __restrict__ Hs,
                                           const int first, const int S) {
 #pragma unroll
-    for (int i = 0; i < LQP_PF; ++i)
-        if (first + i < S) st.buf[i] = frag_load<float, NT>(Hs + (size_t)(first + i) * LQP_BLK);
+    for (int i = 0; i < LQP_PF; ++i)                        // (slots past the end get block `first` again: never used)
+        st.buf[i] = frag_load<float, NT>(Hs + (size_t)(first + i < S ? first + i : (first < S ? first : 0)) * LQP_BLK);
 }
 
 // y[e] for e = 64 i + r: the row sums of blocks (i, j <= i) plus the column partials of the NW waves
@@ -523,15 +527,20 @@ __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, NT>& st, const Re
 #pragma unroll
         for (int i = 0; i < LQP_PF; ++i) {
             const int s = s0 + i;
-            if (s < Sr) {
+            if constexpr (RES) {
+                // EVERY step takes its slot and refills it (padding steps re-load block R0 and drop it): with
+                // conditional loads the compiler cannot count what is in flight and drains the ring
+                // (s_waitcnt vmcnt(0)) before each block; like this it waits for the oldest load only.
                 const Frag<float, NT> blk = st.buf[i];
                 int nx = s + LQP_PF;
-                if (RES && nx >= Sv) nx -= Sv;
-                if (nx < Sr) st.buf[i] = frag_load<float, NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
+                if (nx >= Sv) nx -= Sv;                     // wraps into the next product
+                st.buf[i] = frag_load<float, NT>(Hs + (size_t)(R0 + (nx < Sr ? nx : 0)) * LQP_BLK);
+                if (s < Sr) sym_block<NT>(wk, blk, K, Np, v, ylds, part);
+            } else if (s < Sr) {
+                const Frag<float, NT> blk = st.buf[i];
+                const int nx = s + LQP_PF;
+                if (nx < Sr) st.buf[i] = frag_load<float, NT>(Hs + (size_t)nx * LQP_BLK);
                 sym_block<NT>(wk, blk, K, Np, v, ylds, part);
-            } else if (RES) {
-                const int nx = s + LQP_PF - Sv;             // padding slot: only refill it for the next call
-                if (nx >= 0 && nx < Sr) st.buf[i] = frag_load<float, NT>(Hs + (size_t)(R0 + nx) * LQP_BLK);
             }
         }
     }
