@@ -215,8 +215,8 @@ template <int NT, typename T> __device__ __forceinline__ T rowgroup_sum(T v) {
 template <typename T, int NT = LQP_NT>
 __device__ __forceinline__ void stream_prime(BlockStream<T, NT>& st, const T* __restrict__ packed, const int S) {
 #pragma unroll
-    for (int i = 0; i < LQP_PF; ++i)
-        if (i < S) st.buf[i] = frag_load<T, NT>(packed + (size_t)i * LQP_BLK);
+    for (int i = 0; i < LQP_PF; ++i)                 // (slots past the end get block 0 again: never used)
+        st.buf[i] = frag_load<T, NT>(packed + (size_t)(i < S ? i : 0) * LQP_BLK);
 }
 
 // ---- on-chip residency of the head of the stream --------------------------------------------
@@ -263,6 +263,9 @@ __device__ __forceinline__ void solve_block(SolveWalk<T>& wk, const Frag<T, NT>&
     constexpr int EPT = LQP_BLK / NT;               // elements per thread per block
     constexpr int LPR = LQP_NB / EPT;               // lanes per block row
     const int row = threadIdx.x / LPR, cq = threadIdx.x % LPR, col0 = cq * EPT;
+    wk.phase = __builtin_amdgcn_readfirstlane(wk.phase);       // (the walk is uniform: SGPRs, scalar branches)
+    wk.k = __builtin_amdgcn_readfirstlane(wk.k);
+    wk.j = __builtin_amdgcn_readfirstlane(wk.j);
     if (wk.j != wk.k) {
         wk.acc += frag_dot<T, NT>(blk, v + wk.j * LQP_NB, col0);
         wk.j += wk.phase ? -1 : 1;
@@ -288,8 +291,8 @@ template <typename T, int NT>
 __device__ __forceinline__ void stream_prime_from(BlockStream<T, NT>& st, const T* __restrict__ packed, const int first,
                                                   const int S) {
 #pragma unroll
-    for (int i = 0; i < LQP_PF; ++i)
-        if (first + i < S) st.buf[i] = frag_load<T, NT>(packed + (size_t)(first + i) * LQP_BLK);
+    for (int i = 0; i < LQP_PF; ++i)                 // (slots past the end get a valid block too: never used)
+        st.buf[i] = frag_load<T, NT>(packed + (size_t)(first + i < S ? first + i : 0) * LQP_BLK);
 }
 
 // solve with a resident head: blocks [0, RREG) from registers, [RREG, R0) from LDS, [R0, S) streamed
@@ -308,20 +311,19 @@ __device__ __forceinline__ void wg_packed_solve_resident(BlockStream<T, NT>& st,
         const Frag<T, NT> blk = frag_load<T, NT>(lds_res + (size_t)s * LQP_BLK);
         solve_block<T, NT>(wk, blk, K, v, tmp);
     }
-    const int Sr = S - R0;                           // streamed blocks
+    const int Sr = S - R0;                           // streamed blocks, a multiple of LQP_PF (loop_resident_ok)
+    (void)cyclic;                                    // (always: the ring wraps into the next solve)
     for (int s0 = 0; s0 < Sr; s0 += LQP_PF) {
 #pragma unroll
         for (int i = 0; i < LQP_PF; ++i) {
             const int s = s0 + i;
-            if (s < Sr) {
-                const Frag<T, NT> blk = st.buf[i];
-                {
-                    int nx = s + LQP_PF;
-                    if (nx >= Sr && cyclic) nx -= Sr;
-                    if (nx < Sr) st.buf[i] = frag_load<T, NT>(packed + (size_t)(R0 + nx) * LQP_BLK);
-                }
-                solve_block<T, NT>(wk, blk, K, v, tmp);
-            }
+            // one unconditional refill per step: the compiler can count the loads in flight and waits for the
+            // oldest one only (conditional refills made it drain the ring, s_waitcnt vmcnt(0), before every block)
+            const Frag<T, NT> blk = st.buf[i];
+            int nx = s + LQP_PF;
+            if (nx >= Sr) nx -= Sr;
+            st.buf[i] = frag_load<T, NT>(packed + (size_t)(R0 + nx) * LQP_BLK);
+            solve_block<T, NT>(wk, blk, K, v, tmp);
         }
     }
 }
@@ -338,15 +340,12 @@ __device__ __forceinline__ void wg_packed_solve(BlockStream<T, NT>& st, const T*
 #pragma unroll
         for (int i = 0; i < LQP_PF; ++i) {
             const int s = s0 + i;
-            if (s < S) {
-                const Frag<T, NT> blk = st.buf[i];
-                {
-                    int nx = s + LQP_PF;
-                    if (nx >= S && cyclic) nx -= S;
-                    if (nx < S) st.buf[i] = frag_load<T, NT>(packed + (size_t)nx * LQP_BLK);
-                }
-                solve_block<T, NT>(wk, blk, K, v, tmp);
-            }
+            // one unconditional refill per step (exact vmcnt, see above); past the end it re-loads block 0
+            const Frag<T, NT> blk = st.buf[i];
+            int nx = s + LQP_PF;
+            if (nx >= S && cyclic) nx -= S;
+            st.buf[i] = frag_load<T, NT>(packed + (size_t)(nx < S ? nx : 0) * LQP_BLK);
+            if (s < S) solve_block<T, NT>(wk, blk, K, v, tmp);
         }
     }
 }
