@@ -425,7 +425,8 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
 #pragma unroll
     for (int q = 0; q < EPT / 4; ++q) d += dot4(blk.q[q], wk.wj.q[q]);
     const float s1 = rowgroup_sum<NT>(d);
-    if (cq == 0) ylds[wk.s * 64 + r] = s1;           // one slot per block: write-only, no read-modify-write stall
+    ylds[wk.s * 64 + r] = s1;                        // one slot per block, write-only; all 16 lanes of the row group hold
+                                                     // s1 and store it (same address): no predicated branch in the block
     wk.s = __builtin_amdgcn_readfirstlane(wk.s + 1);     // (the walk is uniform: keep it in SGPRs, scalar branches)
     if (wk.i != wk.j) {
 #pragma unroll
