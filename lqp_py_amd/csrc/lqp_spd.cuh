@@ -420,7 +420,8 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
     wk.i = __builtin_amdgcn_readfirstlane(wk.i);     // (the walk is uniform: keep it in SGPRs, scalar branches)
     wk.j = __builtin_amdgcn_readfirstlane(wk.j);
     wk.s = __builtin_amdgcn_readfirstlane(wk.s);
-    const float wi = v[wk.i * 64 + r];               // (requested first: its LDS latency hides under the row sum)
+    float wi = v[wk.i * 64 + r];                     // requested first: its LDS latency hides under the row sum
+    asm volatile("" : "+v"(wi));                      // (keeps the read from being sunk into the i != j branch)
     float d = 0.f;
 #pragma unroll
     for (int q = 0; q < EPT / 4; ++q) d += dot4(blk.q[q], wk.wj.q[q]);
@@ -439,7 +440,8 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
         for (int e = 0; e < EPT; ++e) {
             float a = wk.acc2[e];
 #pragma unroll
-            for (int off = LPR; off < 64; off <<= 1) a += __shfl_xor(a, off);
+            for (int off = LPR; off < 64; off <<= 1)         // lanes l, l ^ off hold the same columns of other rows
+                a += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ off) << 2, __builtin_bit_cast(int, a)));
             wk.acc2[e] = a;
         }
         if (lane < LPR) {
