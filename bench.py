@@ -28,6 +28,7 @@ sys.path.insert(0, REPO)
 B_PER_GPU, N_X, N_EQ = 128, 500, 1
 TOL = 1e-5
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
 def parse():
@@ -68,7 +69,7 @@ def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True):
 
 LOOP_KERNEL = {1: "lqp::k_admm_loop<float, true, false, 1024, false>",
                2: "lqp::k_admm_loop<float, true, false, 1024, true>"}
-TRAFFIC_FILE = "profiles/r01_f_traffic.json"
+TRAFFIC_FILE = "profiles/r01_g_traffic.json"
 
 
 def measured_traffic(kernel, mode, B, n):
@@ -228,6 +229,16 @@ def main():
                 "reference_algorithm_bytes": loop_ref_b * B,
                 "reference_algorithm_equiv_GBs": round(gbs(loop_ref_b), 1),
                 "whole_step_frac_of_hbm_roofline": round(((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)}
+    # second kernel of comparable weight on the symmetric path: the factorisation (MFMA block sweep).  Algorithmic
+    # flops of inverting an SPD matrix: n^3 (Cholesky n^3/3 + inverse of the factor and product 2n^3/3).
+    roofline_factor = None
+    if ls == 2 and prof.get("spd_inverse", (0, 0))[1]:
+        f_ms = prof["spd_inverse"][0] / max(solves, 1)
+        tfl = B * float(n) ** 3 / (f_ms * 1e-3) / 1e12
+        roofline_factor = {"bound": "mfma", "kernel": "lqp::k_spd_inverse", "achieved": round(tfl, 2),
+                           "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+                           "traffic": measured_traffic("lqp::k_spd_inverse", 3 if not args.sync else st["mode_used"], B, n)[0],
+                           "algorithmic_flops": B * float(n) ** 3, "ms": round(f_ms, 4)}
     breakdown = {k: round(v[0] / max(solves, 1), 4) for k, v in prof.items() if v[1]}
 
     out = {"metric": "QPs/sec forward+backward, batch=128 dz=500 tol=1e-5", "value": round(value, 1),
@@ -238,7 +249,7 @@ def main():
                                   "ADMM forward + fixed-point backward, eps 1e-5, scale+adaptive_rho defaults",
                       "global_batch": world * B, "iters": st["iters"], "checks": st["n_check"],
                       "launch_mode": st["mode_used"], "parallelism": f"batch-sharded x{world}"},
-           "roofline": roofline, "kernel_ms_per_step": breakdown,
+           "roofline": roofline, "roofline_factorisation": roofline_factor, "kernel_ms_per_step": breakdown,
            "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
