@@ -22,7 +22,6 @@ template <typename T> struct FwdParams {
                                          // (continuation kernel / 512-thread first launch)
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
-    int skip_symcheck;                   // experiment only (LQP_SKIP_SYMCHECK): time the factorisation without the symmetry check
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in;
@@ -585,7 +584,7 @@ __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const i
     float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
     const float* Qs = P.scale ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
     const int ldq = P.scale ? P.ldq : P.n;
-    if (check_sym && !P.skip_symcheck) {
+    if (check_sym) {
         float* red = (float*)smem;
         const float asym = wg_sym_asymmetry(Qs, ldq, P.n, P.Ks, red);
         if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
