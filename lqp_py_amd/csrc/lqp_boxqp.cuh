@@ -143,16 +143,31 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cm[q][e] = T(0);
-#pragma unroll 4
-            for (int i = w; i < n; i += LQP_NW) {
-                const T* qr = Q + (size_t)i * n;
+            // Loads are UNCONDITIONAL (lanes past the row end re-read column 0 and their values are masked out):
+            // a per-lane `if (j < n)` around a load becomes a branch with s_waitcnt vmcnt(0) right behind it, i.e.
+            // one 1-KB load in flight per wave.  Four rows' loads are issued before any is used.
+            const int nq = (n + 255) / 256;               // column quads of 256 that exist (uniform)
+            int jq[4]; bool okq[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = (lane + 64 * q) * 4;
-                    if (j < n) {
-                        const V4<T> v = *(const V4<T>*)(qr + j);
+            for (int q = 0; q < 4; ++q) { const int j = (lane + 64 * q) * 4; okq[q] = j < n; jq[q] = okq[q] ? j : 0; }
+            for (int i0 = w; i0 < n; i0 += 4 * LQP_NW) {
+                V4<T> v[4][4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) cm[q][e] = tmax(cm[q][e], tabs(v.v[e]));
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = i0 + rr * LQP_NW;
+                    const T* qr = Q + (size_t)(i < n ? i : i0) * n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < nq) v[rr][q] = *(const V4<T>*)(qr + jq[q]);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q < nq) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) cm[q][e] = tmax(cm[q][e], okq[q] ? tabs(v[rr][q].v[e]) : T(0));
+                        }
                     }
                 }
             }
@@ -240,19 +255,43 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         T* Qw = P.Qs + (size_t)b * n * ldq;
         T* Mw = P.M + (size_t)b * Np * Np;
         if (qvec) {
-#pragma unroll 2
-            for (int i = w; i < n; i += LQP_NW) {
-                const T* qr = Q + (size_t)i * n;
-                T* qo = Qw + (size_t)i * ldq;
-                T* mo = Mw + (size_t)i * Np;
-                const T di = d[i];
-                for (int j = lane * 4; j < n; j += 256) {
-                    V4<T> v = *(const V4<T>*)(qr + j);
-                    const V4<T> dj = *(const V4<T>*)(d + j);
+            // same load discipline as the column-max pass: unconditional, four rows in flight
+            const int nq = (n + 255) / 256;
+            int jq[4]; bool okq[4]; V4<T> dj[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v.v[e] = (di * v.v[e]) * dj.v[e]; fro2 += v.v[e] * v.v[e]; }
-                    *(V4<T>*)(qo + j) = v;
-                    if (!P.spd) *(V4<T>*)(mo + j) = v;
+            for (int q = 0; q < 4; ++q) {
+                const int j = (lane + 64 * q) * 4;
+                okq[q] = j < n; jq[q] = okq[q] ? j : 0;
+                dj[q] = *(const V4<T>*)(d + jq[q]);
+            }
+            for (int i0 = w; i0 < n; i0 += 4 * LQP_NW) {
+                V4<T> v[4][4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = i0 + rr * LQP_NW;
+                    const T* qr = Q + (size_t)(i < n ? i : i0) * n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < nq) v[rr][q] = *(const V4<T>*)(qr + jq[q]);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = i0 + rr * LQP_NW;
+                    if (i < n) {
+                        T* qo = Qw + (size_t)i * ldq;
+                        T* mo = Mw + (size_t)i * Np;
+                        const T di = d[i];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (q < nq && okq[q]) {
+                                V4<T> o;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { o.v[e] = (di * v[rr][q].v[e]) * dj[q].v[e]; fro2 += o.v[e] * o.v[e]; }
+                                *(V4<T>*)(qo + jq[q]) = o;
+                                if (!P.spd) *(V4<T>*)(mo + jq[q]) = o;
+                            }
+                        }
+                    }
                 }
             }
         } else {
