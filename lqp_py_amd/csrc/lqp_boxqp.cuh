@@ -1247,15 +1247,22 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
         while (sym_idx(j + 1, j + 1, Kb) <= t && j + 1 < Kb) ++j;      // block column of stream position t
         const int i = j + (t - sym_idx(j, j, Kb));
         const int a = i * 64 + r;
+        // (unconditional gathers with clamped indices, then a select: a guarded load costs a branch and a full
+        //  s_waitcnt per element)
+        const bool rok = a < nf;
+        const size_t rowoff = (size_t)fl[rok ? a : 0] * n;
+        float q4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = j * 64 + c4 + e;
+            q4[e] = Q[rowoff + fl[c < nf ? c : 0]];
+        }
         V4<float> v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = j * 64 + c4 + e;
             float val = (a == c) ? 1.f : 0.f;
-            if (a < nf && c < nf) {
-                val = Q[(size_t)fl[a] * n + fl[c]];
-                if (a == c) val += 1e-8f;
-            }
+            if (rok && c < nf) val = q4[e] + (a == c ? 1e-8f : 0.f);
             v.v[e] = val;
         }
         *(V4<float>*)(Ls + (size_t)t * LQP_BLK + tid * 4) = v;
