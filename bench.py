@@ -69,7 +69,7 @@ def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True):
 
 LOOP_KERNEL = {1: "lqp::k_admm_loop<float, true, false, 1024, false>",
                2: "lqp::k_admm_loop<float, true, false, 1024, true>"}
-TRAFFIC_FILE = "profiles/r01_g_traffic.json"
+TRAFFIC_FILE = "profiles/r01_h_traffic.json"
 
 
 def measured_traffic(kernel, mode, B, n):
