@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="QPs per GPU")
     ap.add_argument("--n", type=int, default=N_X)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the forward-only extras (configs 2 and 4)")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sync", action="store_true", help="layer calls wait for the GPU (reference-style error timing)")
@@ -251,6 +252,34 @@ def main():
                       "launch_mode": st["mode_used"], "parallelism": f"batch-sharded x{world}"},
            "roofline": roofline, "roofline_factorisation": roofline_factor, "kernel_ms_per_step": breakdown,
            "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4)}
+    # "also report forward-only for configs 2 and 4" (B=128, n=100 box-only / n=1000 with the
+    # equality row) -- extras next to the headline number, single GPU only, inputs drawn on the device
+    if world == 1 and not args.no_other_configs and B == B_PER_GPU and n == N_X:
+        extras = {}
+        for name, (nn, with_eq) in {"config2_fwd_n100_box": (100, False), "config4_fwd_n1000_eq": (1000, True)}.items():
+            gen = torch.Generator(device=dev).manual_seed(4242 + nn)
+            Lm = torch.randn(B, 2 * nn, nn, device=dev, generator=gen)
+            Qx = torch.matmul(Lm.transpose(1, 2), Lm) / (2 * nn)
+            del Lm
+            px = torch.randn(B, nn, 1, device=dev, generator=gen)
+            Ax = torch.ones(B, 1, nn, device=dev) if with_eq else None
+            bx = torch.ones(B, 1, 1, device=dev) if with_eq else None
+            lbx = -(torch.rand(B, nn, 1, device=dev, generator=gen) + 1)
+            ubx = torch.rand(B, nn, 1, device=dev, generator=gen) + 1
+            fwd = lambda: qp(Qx, px, Ax, bx, lbx, ubx)
+            for _ in range(2):
+                fwd()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                fwd()
+            torch.cuda.synchronize(dev)
+            dtx = (time.perf_counter() - t1) / reps
+            extras[name] = {"QPs_per_sec": round(B / dtx, 1), "ms": round(dtx * 1e3, 4), "batch": B}
+            del Qx
+        L.synchronize()
+        out["other_configs_forward_only"] = extras
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
