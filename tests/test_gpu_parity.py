@@ -553,3 +553,32 @@ def test_unsupported_sizes_fail_loudly(dev):
     with pytest.raises(RuntimeError, match="unsupported"):
         L.torch_solve_box_qp(torch.zeros(1, 1100, 1100, device=dev), torch.zeros(1, 1100, 1, device=dev), None, None,
                              -torch.ones(1, 1100, 1, device=dev), torch.ones(1, 1100, 1, device=dev), {})
+
+
+# ---------------------------------------------------------------- bench.py contract
+def test_bench_json_contract(dev):
+    """bench.py prints ONE JSON line with the keys the driver reads, the roofline objects and (on request) the CPU
+    baseline; values are sane for a short run."""
+    import json
+    import subprocess
+    import sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([_sys.executable, os.path.join(repo, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "QPs/sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 1000 and abs(d["value"] - 128 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["roofline_factorisation"]["bound"] == "mfma" and 0 < d["roofline_factorisation"]["frac"] < 1.0
