@@ -582,3 +582,33 @@ def test_bench_json_contract(dev):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["roofline_factorisation"]["bound"] == "mfma" and 0 < d["roofline_factorisation"]["frac"] < 1.0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_problems_vs_cpu_oracle(dev, seed):
+    """Randomised sizes / constraint counts / controls against the CPU oracle, on both x-updates.  The stopping
+    check is a floating-point threshold: a borderline problem may stop one check later on one side, so iteration
+    counts may differ by one check interval (then only the KKT conditions are compared)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    n = int(torch.randint(2, 90, (1,), generator=g))
+    m = int(torch.randint(0, 4, (1,), generator=g))
+    B = int(torch.randint(1, 7, (1,), generator=g))
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=seed, with_eq=False)
+    A = torch.randn(B, m, n, generator=g) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
+    extra = [dict(), dict(scale=False), dict(adaptive_rho=False), dict(rho=1.5), dict(scale=False, rho=0.8),
+             dict(check_solved=3)][seed % 6]
+    ctl = O.make_control(**TOL)
+    ctl.update(extra)
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, dict(ctl))
+    interval = O.resolve_control(ctl, n).check_solved
+    for ls in ("lu", "spd"):
+        c2 = dict(ctl)
+        c2["linsolve"] = ls
+        sol, _ = solve(dev, (Q, p, A, b, lb, ub), c2)
+        assert abs(sol["iter"] - ref["iter"]) <= interval, (ls, sol["iter"], ref["iter"])
+        if sol["iter"] == ref["iter"]:
+            for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+                assert err(sol[k], ref[k]) < 5e-5, (ls, k)
+        res = O.kkt_residuals(Q, p, A, b, lb, ub, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sol.items()})
+        assert float(res["box"].max()) < 1e-6 and float(res["x_minus_z"].max()) < 1e-3
