@@ -143,14 +143,14 @@ def main():
     import lqp_py_amd as L
     from lqp_py_amd import _lib
     from lqp_py_amd.dist import ShardedBoxQP
-    from oracle import boxqp_oracle as O        # data generator only (restated experiments/utils.py)
+    from lqp_py_amd.synthetic import create_qp_data
 
     B, n, m = args.batch, args.n, N_EQ
     # a few distinct batches (different seeds, like the reference's per-simulation data), HBM resident
     n_sets = 3
     data = []
     for s in range(n_sets):
-        Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=1000 * rank + s)
+        Q, p, A, b, lb, ub = create_qp_data(n, B, seed=1000 * rank + s)
         data.append([t.to(dev) for t in (Q, p, A, b, lb, ub)])
     ones = torch.ones(B, n, 1, device=dev)
     control = L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, reduce='max')

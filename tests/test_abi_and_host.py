@@ -80,3 +80,30 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("the oracle", ""), f"{f} mentions the oracle"
+
+
+def test_oracle_is_only_used_as_a_checker():
+    """tools/ and examples/ never import it; bench.py does so only inside its cpu_baseline leg."""
+    for sub in ("tools", "examples"):
+        for f in os.listdir(os.path.join(REPO, sub)):
+            if f.endswith((".py", ".sh")):
+                assert "oracle" not in open(os.path.join(REPO, sub, f)).read(), f"{sub}/{f}"
+    src = open(os.path.join(REPO, "bench.py")).read()
+    start = src.index("def cpu_baseline_worker")
+    end = src.index("\ndef ", start + 1)
+    outside = src[:start] + src[end:]
+    assert "import oracle" not in outside and "from oracle" not in outside
+
+
+def test_synthetic_generator_matches_the_oracle_and_the_golden_inputs():
+    from conftest import load_golden
+    from lqp_py_amd.synthetic import create_qp_data
+    from oracle import boxqp_oracle as O
+    for kw in (dict(n_x=12, n_batch=5, seed=3), dict(n_x=9, n_batch=4, seed=1, with_eq=False),
+               dict(n_x=10, n_batch=32, seed=0, with_eq=False, unit_box=True),
+               dict(n_x=7, n_batch=3, seed=2, dtype=torch.float64)):
+        for a, b in zip(create_qp_data(**kw), O.create_qp_data(**kw)):
+            assert (a is None and b is None) or (a.dtype == b.dtype and torch.equal(a, b))
+    g = load_golden("g1_b32_n10_box")
+    Q, p, _, _, lb, ub = create_qp_data(10, 32, seed=0, with_eq=False, unit_box=True)
+    assert torch.equal(Q, g["Q"]) and torch.equal(p, g["p"]) and torch.equal(lb, g["lb"]) and torch.equal(ub, g["ub"])

@@ -2,7 +2,7 @@
 """LU kernel timing + in-kernel phase breakdown (debug counters) on KKT-like matrices."""
 import os, sys, time
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from lqp_py_amd import _lib, lu_layer
 from oracle import boxqp_oracle as O

@@ -2,7 +2,7 @@
 """For the borderline cases of tools/gpu_sweep.py: which x-update agrees with the CPU oracle's iteration count?"""
 import os, sys
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 import lqp_py_amd.solve_box_qp_admm_torch as L
 from oracle import boxqp_oracle as O

@@ -6,7 +6,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from lqp_py_amd import _lib
 import lqp_py_amd.solve_box_qp_admm_torch as L
-from oracle import boxqp_oracle as O
+from lqp_py_amd.synthetic import create_qp_data
+from lqp_py_amd.control import box_qp_control
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
@@ -26,11 +27,11 @@ for n, B in ((10, 3), (64, 2), (65, 2), (100, 4), (300, 3), (500, 8), (512, 4)):
 
 TOL = dict(eps_abs=1e-5, eps_rel=1e-5)
 for (n, B, eq) in ((10, 32, False), (50, 8, True), (100, 128, False), (500, 128, True)):
-    inp = O.create_qp_data(n, B, seed=0, with_eq=eq)
+    inp = create_qp_data(n, B, seed=0, with_eq=eq)
     a = [None if t is None else t.to(dev) for t in inp]
     sols = {}
     for ls in ("lu", "spd"):
-        sols[ls] = L.torch_solve_box_qp(*a, O.make_control(linsolve=ls, **TOL))
+        sols[ls] = L.torch_solve_box_qp(*a, box_qp_control(linsolve=ls, **TOL))
     s0, s1 = sols["lu"], sols["spd"]
     d = {k: float((s0[k] - s1[k]).abs().max()) for k in ("x", "z", "u", "lams") }
     if eq: d["nus"] = float((s0["nus"] - s1["nus"]).abs().max())

@@ -6,12 +6,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from lqp_py_amd import _lib
 import lqp_py_amd.solve_box_qp_admm_torch as L
-from oracle import boxqp_oracle as O
+from lqp_py_amd.synthetic import create_qp_data
+from lqp_py_amd.control import box_qp_control
 dev = torch.device("cuda:0")
 lib = _lib.load()
 B, n = int(os.environ.get("BATCH", "128")), int(os.environ.get("N_X", "500"))
-inp = [t.to(dev) for t in O.create_qp_data(n, B, seed=0)]
-ctl = O.make_control(eps_abs=1e-5, eps_rel=1e-5, linsolve="spd")
+inp = [t.to(dev) for t in create_qp_data(n, B, seed=0)]
+ctl = box_qp_control(eps_abs=1e-5, eps_rel=1e-5, linsolve="spd")
 sol = L.torch_solve_box_qp(*inp, dict(ctl))
 dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
 lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))

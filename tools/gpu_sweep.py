@@ -7,7 +7,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import lqp_py_amd as LA
 import lqp_py_amd.solve_box_qp_admm_torch as L
-from oracle import boxqp_oracle as O
+from lqp_py_amd.synthetic import create_qp_data
+from lqp_py_amd.control import box_qp_control
 
 dev = torch.device("cuda:0")
 TOL = dict(eps_abs=1e-5, eps_rel=1e-5)
@@ -16,7 +17,7 @@ cases = 0
 for (n, m, B) in [(1, 0, 1), (2, 1, 3), (3, 0, 2), (7, 2, 5), (33, 1, 1), (63, 0, 2), (64, 3, 2), (65, 1, 2), (127, 5, 3),
                   (129, 0, 2), (255, 16, 2), (257, 1, 2), (500, 1, 9), (511, 2, 1), (512, 16, 3)]:
     torch.manual_seed(n * 31 + m)
-    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + 7, with_eq=False)
+    Q, p, _, _, lb, ub = create_qp_data(n, B, seed=n + 7, with_eq=False)
     A = torch.randn(B, m, n) if m else None
     b = 0.05 * torch.randn(B, m, 1) if m else None
     for opts in (dict(), dict(scale=False), dict(adaptive_rho=False), dict(rho=0.7), dict(scale=False, rho=2.0),
@@ -27,7 +28,7 @@ for (n, m, B) in [(1, 0, 1), (2, 1, 3), (3, 0, 2), (7, 2, 5), (33, 1, 1), (63, 0
             a = [None if t is None else t.to(dev) for t in (Q, p, A, b, lbx, ubx)]
             s = {}
             for ls in ("lu", "spd"):
-                ctl = O.make_control(linsolve=ls, **TOL)
+                ctl = box_qp_control(linsolve=ls, **TOL)
                 ctl.update(opts)
                 s[ls] = L.torch_solve_box_qp(*a, ctl)
             assert s["spd"]["_stats"]["linsolve_used"] == 2 and s["lu"]["_stats"]["linsolve_used"] == 1
@@ -48,7 +49,7 @@ def timeit(fn, reps=10):
 
 for (n, B, eq, bwd) in [(100, 128, False, False), (1000, 128, True, False), (500, 1024, True, True), (500, 16, True, True),
                         (500, 64, True, True), (250, 128, True, True)]:
-    inp = [None if t is None else t.to(dev) for t in O.create_qp_data(n, B, seed=0, with_eq=eq)]
+    inp = [None if t is None else t.to(dev) for t in create_qp_data(n, B, seed=0, with_eq=eq)]
     for ls in ("lu", "auto"):
         ctl = LA.box_qp_control(linsolve=ls, **TOL)
         layer = LA.SolveBoxQP(control=ctl)

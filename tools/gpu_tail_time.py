@@ -6,11 +6,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from lqp_py_amd import _lib
 import lqp_py_amd.solve_box_qp_admm_torch as L
-from oracle import boxqp_oracle as O
+from lqp_py_amd.synthetic import create_qp_data
+from lqp_py_amd.control import box_qp_control
 dev = torch.device("cuda:0")
-inp = [t.to(dev) for t in O.create_qp_data(500, 128, seed=0)]
+inp = [t.to(dev) for t in create_qp_data(500, 128, seed=0)]
 for ls in ("spd", "lu"):
-    ctl = O.make_control(eps_abs=1e-5, eps_rel=1e-5, rho=100.0, linsolve=ls)
+    ctl = box_qp_control(eps_abs=1e-5, eps_rel=1e-5, rho=100.0, linsolve=ls)
     sol = L.torch_solve_box_qp(*inp, dict(ctl))
     torch.cuda.synchronize()
     _lib.profile(enable=True, reset=True)
