@@ -281,6 +281,10 @@ def main():
         L.synchronize()
         out["other_configs_forward_only"] = extras
     if rank == 0:
+        # no number is published for a GPU; the reference's own chart for this config (6-core i7
+        # CPU, images_paper/dz_500.pdf) reads 112.6 QPs/s -- quoted for orientation, vs_baseline stays null
+        out["reference_published_other_hardware"] = {"value": 112.6, "unit": "QPs/sec", "hardware": "6-core i7 2.6 GHz CPU",
+                                                     "source": "BASELINE.md §1 (bar chart of the reference)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         elif not args.no_cpu_baseline:
