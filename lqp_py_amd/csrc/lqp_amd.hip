@@ -278,6 +278,17 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         ++n_launch;
     }
     int rc = LQP_OK;
+    // symmetric path with fewer problems than half the CUs: share each matrix between SPD_NP workgroups
+    bool spd_split = false;
+    const int spd_pivot_tasks = env_int("LQP_SPD_PTASKS", 48);
+    if (spd && P.Ks >= 3) {
+        int dev_ = 0, cus_ = 0;
+        if (hipGetDevice(&dev_) == hipSuccess &&
+            hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess)
+            spd_split = B * SPD_NP <= cus_;
+        spd_split = env_int("LQP_SPD_SPLIT", spd_split ? 1 : 0) != 0;
+        spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
+    }
     // factorise (gate == nullptr) or refactorise under the device-side gate of k_rho_update
     auto factor_step = [&](const int* gate) -> int {
         if constexpr (sizeof(T) == 4) {
@@ -286,6 +297,19 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 const int r2 = ensure_lds((const void*)k_spd_inverse, lds);
                 if (r2) return r2;
                 ProfScope ps(st, PC_SPD_INV);
+                if (spd_split) {
+                    // few problems: SPD_NP workgroups per matrix, one launch per pivot step (k_spd_begin/step/end)
+                    int r3 = ensure_lds((const void*)k_spd_begin, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_step, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_end, lds);
+                    if (r3) return r3;
+                    hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
+                    for (int k = 0; k < P.Ks; ++k)
+                        hipLaunchKernelGGL(k_spd_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
+                    hipLaunchKernelGGL(k_spd_end, dim3(B), dim3(LQP_NT), lds, st, P, gate);
+                    n_launch += P.Ks + 2;
+                    return LQP_OK;
+                }
                 hipLaunchKernelGGL(k_spd_inverse, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                 ++n_launch;
                 return LQP_OK;

@@ -109,6 +109,99 @@ __device__ __forceinline__ void assemble_kkt_rows(const FwdParams<T>& P, const i
     }
 }
 
+// ---- the two passes of the scaling over Q (16-B row pieces).  NQ: column quads of 256 per lane, RIF: rows in
+//      flight per wave.  Loads are UNCONDITIONAL (lanes past the row end re-read column 0 and their values are masked
+//      out): a per-lane `if (j < n)` around a load becomes a branch with s_waitcnt vmcnt(0) right behind it, i.e. one
+//      1-KB load in flight per wave.  All RIF rows' loads are issued before any is used. ----
+template <typename T, int NQ, int RIF>
+__device__ __forceinline__ void setup_colmax(const T* __restrict__ Q, const int n, T* __restrict__ red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T cm[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cm[q][e] = T(0);
+    const int nq = (n + 255) / 256;               // column quads of 256 that exist (uniform)
+    int jq[NQ]; bool okq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int j = (lane + 64 * q) * 4; okq[q] = j < n; jq[q] = okq[q] ? j : 0; }
+    for (int i0 = w; i0 < n; i0 += RIF * LQP_NW) {
+        V4<T> v[RIF][NQ];
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr) {
+            const int i = i0 + rr * LQP_NW;
+            const T* qr = Q + (size_t)(i < n ? i : i0) * n;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nq) v[rr][q] = *(const V4<T>*)(qr + jq[q]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q < nq) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cm[q][e] = tmax(cm[q][e], okq[q] ? tabs(v[rr][q].v[e]) : T(0));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = (lane + 64 * q) * 4;
+        if (j < n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(size_t)w * n + j + e] = cm[q][e];
+        }
+    }
+}
+// Qs = (D_i Q_ij) D_j (and the top-left KKT block when with_m); returns this thread's share of ||Qs||_F^2
+template <typename T, int NQ, int RIF>
+__device__ __forceinline__ T setup_scale(const T* __restrict__ Q, const int n, const T* __restrict__ d, T* __restrict__ Qw,
+                                         const int ldq, T* __restrict__ Mw, const int Np, const bool with_m) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nq = (n + 255) / 256;
+    int jq[NQ]; bool okq[NQ]; V4<T> dj[NQ];
+    T fro2 = T(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = (lane + 64 * q) * 4;
+        okq[q] = j < n; jq[q] = okq[q] ? j : 0;
+        dj[q] = *(const V4<T>*)(d + jq[q]);
+    }
+    for (int i0 = w; i0 < n; i0 += RIF * LQP_NW) {
+        V4<T> v[RIF][NQ];
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr) {
+            const int i = i0 + rr * LQP_NW;
+            const T* qr = Q + (size_t)(i < n ? i : i0) * n;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nq) v[rr][q] = *(const V4<T>*)(qr + jq[q]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr) {
+            const int i = i0 + rr * LQP_NW;
+            if (i < n) {
+                T* qo = Qw + (size_t)i * ldq;
+                T* mo = Mw + (size_t)i * Np;
+                const T di = d[i];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q < nq && okq[q]) {
+                        V4<T> o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o.v[e] = (di * v[rr][q].v[e]) * dj[q].v[e]; fro2 += o.v[e] * o.v[e]; }
+                        *(V4<T>*)(qo + jq[q]) = o;
+                        if (with_m) *(V4<T>*)(mo + jq[q]) = o;
+                    }
+                }
+            }
+        }
+    }
+    return fro2;
+}
+
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -138,47 +231,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         // ---- column max of |Q| (:163): wave w sweeps rows w, w+16, ...; 16 B per lane per load ----
         const bool qvec = (n % 4 == 0) && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
         if (qvec) {
-            T cm[4][4];                                   // up to 4 column quads per lane (n <= 1024)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cm[q][e] = T(0);
-            // Loads are UNCONDITIONAL (lanes past the row end re-read column 0 and their values are masked out):
-            // a per-lane `if (j < n)` around a load becomes a branch with s_waitcnt vmcnt(0) right behind it, i.e.
-            // one 1-KB load in flight per wave.  Four rows' loads are issued before any is used.
-            const int nq = (n + 255) / 256;               // column quads of 256 that exist (uniform)
-            int jq[4]; bool okq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int j = (lane + 64 * q) * 4; okq[q] = j < n; jq[q] = okq[q] ? j : 0; }
-            for (int i0 = w; i0 < n; i0 += 4 * LQP_NW) {
-                V4<T> v[4][4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int i = i0 + rr * LQP_NW;
-                    const T* qr = Q + (size_t)(i < n ? i : i0) * n;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (q < nq) v[rr][q] = *(const V4<T>*)(qr + jq[q]);
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (q < nq) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) cm[q][e] = tmax(cm[q][e], okq[q] ? tabs(v[rr][q].v[e]) : T(0));
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = (lane + 64 * q) * 4;
-                if (j < n) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) red[(size_t)w * n + j + e] = cm[q][e];
-                }
-            }
+            setup_colmax<T, 4, 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster)
         } else {
             T cm[16];
 #pragma unroll
@@ -255,45 +308,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         T* Qw = P.Qs + (size_t)b * n * ldq;
         T* Mw = P.M + (size_t)b * Np * Np;
         if (qvec) {
-            // same load discipline as the column-max pass: unconditional, four rows in flight
-            const int nq = (n + 255) / 256;
-            int jq[4]; bool okq[4]; V4<T> dj[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = (lane + 64 * q) * 4;
-                okq[q] = j < n; jq[q] = okq[q] ? j : 0;
-                dj[q] = *(const V4<T>*)(d + jq[q]);
-            }
-            for (int i0 = w; i0 < n; i0 += 4 * LQP_NW) {
-                V4<T> v[4][4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int i = i0 + rr * LQP_NW;
-                    const T* qr = Q + (size_t)(i < n ? i : i0) * n;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (q < nq) v[rr][q] = *(const V4<T>*)(qr + jq[q]);
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int i = i0 + rr * LQP_NW;
-                    if (i < n) {
-                        T* qo = Qw + (size_t)i * ldq;
-                        T* mo = Mw + (size_t)i * Np;
-                        const T di = d[i];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (q < nq && okq[q]) {
-                                V4<T> o;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { o.v[e] = (di * v[rr][q].v[e]) * dj[q].v[e]; fro2 += o.v[e] * o.v[e]; }
-                                *(V4<T>*)(qo + jq[q]) = o;
-                                if (!P.spd) *(V4<T>*)(mo + jq[q]) = o;
-                            }
-                        }
-                    }
-                }
-            }
+            fro2 += setup_scale<T, 4, 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
         } else {
             for (int i = w; i < n; i += LQP_NW) {
                 const T* qr = Q + (size_t)i * n;
@@ -647,6 +662,40 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P
     if (gate && *gate == 0) return;
     const int b = blockIdx.x;
     wg_spd_factor(P, b, P.scal[(size_t)b * SC_WORDS + SC_RHO], smem, gate == nullptr);
+}
+
+// ---- the same factorisation spread over launches: with fewer problems than half the CUs, SPD_NP workgroups share
+//      one matrix.  begin (symmetry check, Qs + rho I -> blocks) | one launch per pivot step, out of place between
+//      the two halves of the problem's packed area (K(K+1) >= 2 sym_blocks(Ks) blocks) | end (equality correction).
+//      The parity of the first buffer is chosen so that the last step writes the half the loop reads. ----
+constexpr int SPD_NP = 2;
+__device__ __forceinline__ float* spd_half(const FwdParams<float>& P, const int b, const int which) {
+    return P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK + (size_t)which * sym_blocks(P.Ks) * LQP_BLK;
+}
+__global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
+    const float* Qs = P.scale ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
+    const float asym = wg_sym_check_init<SPD_NP>(spd_half(P, b, P.Ks & 1), Qs, P.scale ? P.ldq : P.n, P.n, P.Ks,
+                                                 P.scal[(size_t)b * SC_WORDS + SC_RHO], (float*)smem, gate == nullptr, part);
+    if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
+}
+__global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, const int* __restrict__ gate, const int k,
+                                                      const int pivot_tasks) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD, the panel is shared in its L2
+    // W, W^T of the next pivot block travel between the launches in the (unused on this path) KKT matrix area
+    wg_spd_sweep<SPD_NP>(spd_half(P, b, (P.Ks - k) & 1), P.Ks, P.info + b, smem, nullptr, spd_half(P, b, (P.Ks - k - 1) & 1),
+                         k, k + 1, part, P.M + (size_t)b * P.Np * P.Np, pivot_tasks);
+}
+__global__ __launch_bounds__(LQP_NT) void k_spd_end(const FwdParams<float> P, const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
+    if (P.m > 0) wg_eq_correct(P, b, smem);
 }
 
 // equality duals of the last x-update.  LU path: the tail of the solve vector.  Symmetric path:

@@ -114,6 +114,76 @@ __device__ __forceinline__ float wg_sym_asymmetry(const float* __restrict__ src,
     return dmax > 1e-5f * vmax ? dmax : 0.f;
 }
 
+// wg_sym_init and (when `check`) wg_sym_asymmetry in ONE pass over src, for the blocks part, part + NP, ... of the
+// stream: workgroup `part` of NP.  The symmetry verdict then is per workgroup (difference above 1e-5 of the largest
+// entry among ITS blocks and their mirrors; consecutive blocks alternate between the workgroups, so each of them
+// sees diagonal blocks).  smem as wg_sym_asymmetry.
+template <int NP>
+__device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const float* __restrict__ src, const int ld,
+                                                   const int n, const int K, const float rho_add,
+                                                   float* __restrict__ smem_f, const bool check, const int part) {
+    const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
+    float* tile = smem_f;                                   // [2][64][SPD_LS]
+    float* red = smem_f + 2 * 64 * SPD_LS;
+    const bool vec_ok = (ld % 4 == 0) && ((((uintptr_t)src) & 15) == 0);
+    auto load4 = [&](const int row, const int col) -> V4<float> {      // zero outside the matrix
+        V4<float> v;
+        if (row < n && col + 3 < n && vec_ok) {
+            v = *(const V4<float>*)(src + (size_t)row * ld + col);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = (row < n && col + e < n) ? src[(size_t)row * ld + col + e] : 0.f;
+        }
+        return v;
+    };
+    auto block_of = [&](const int t, int& i, int& j) {
+        int rem = t;
+        j = 0;
+        while (rem >= K - j) { rem -= K - j; ++j; }
+        i = j + rem;
+    };
+    float dmax = 0.f, vmax = 0.f;
+    const int nblk = sym_blocks(K);
+    int i = 0, j = 0;
+    V4<float> a, bm;
+    if (part < nblk) {
+        block_of(part, i, j);
+        a = load4(i * 64 + r, j * 64 + c4);
+        if (check) bm = load4(j * 64 + r, i * 64 + c4);
+    }
+    int cnt = 0;
+    for (int t = part; t < nblk; t += NP, ++cnt) {
+        float* T = tile + (cnt & 1) * 64 * SPD_LS;
+        if (check) *(V4<float>*)(T + r * SPD_LS + c4) = bm;
+        const V4<float> ac = a;
+        const int ci = i, cj = j;
+        if (t + NP < nblk) {                                // the next block is requested before this one is used
+            block_of(t + NP, i, j);
+            a = load4(i * 64 + r, j * 64 + c4);
+            if (check) bm = load4(j * 64 + r, i * 64 + c4);
+        }
+        V4<float> v = ac;
+        const int gr = ci * 64 + r, gc = cj * 64 + c4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (gr == gc + e) v.v[e] += gr < n ? rho_add : 1.f;     // identity on the padding
+        *(V4<float>*)(Hs + (size_t)sym_idx(ci, cj, K) * LQP_BLK + tid * 4) = v;
+        if (check) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bt = T[(c4 + e) * SPD_LS + r];
+                dmax = tmax(dmax, tabs(ac.v[e] - bt));
+                vmax = tmax(vmax, tmax(tabs(ac.v[e]), tabs(bt)));
+            }
+        }
+    }
+    if (!check) return 0.f;
+    __syncthreads();
+    dmax = wg_max(dmax, red);
+    vmax = wg_max(vmax, red + LQP_NW);
+    return dmax > 1e-5f * vmax ? dmax : 0.f;
+}
+
 // one 32x32 output quadrant: acc = X[x0 .. x0+31][0..63] * Z[z0 .. z0+31][0..63]^T, both operands in LDS with
 // row stride SPD_LS.  Lane l feeds row l&31 and the k range 32*(l>>5) .. +31 (any pairing of k values is a
 // valid MFMA schedule as long as A and B agree).
@@ -226,8 +296,17 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
 
 // ---- block symmetric sweep: Hs (lower blocks of an SPD matrix) -> -inverse, in place ----
 // info: 0, or 1 + index of the first non-positive pivot.
+// NP == 1: the whole sweep, in place.  NP > 1: pivot steps [k0, k1) only, OUT of place (every block of the matrix
+// is rewritten by every step: read from Hs, written to Hdst), with the tile tasks of a step shared between NP
+// workgroups (`part` of NP; each of them factorises the pivot block and stages the panel for itself).  One launch
+// per step then lets NP workgroups work on one matrix with no synchronisation inside a kernel.
+template <int NP = 1>
 __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem,
-                                             unsigned long long* __restrict__ dbg = nullptr) {
+                                             unsigned long long* __restrict__ dbg = nullptr, float* Hdst = nullptr,
+                                             const int k0 = 0, const int k1 = 0, const int part = 0,
+                                             float* __restrict__ Wg = nullptr, const int pivot_tasks = 48) {
+    static_assert(NP == 1 || NP == 2, "one or two workgroups per matrix");
+    float* const Hd = NP == 1 ? Hs : Hdst;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = tid >> 4, cq = tid & 15, li = lane & 31, lh = lane >> 5;
     const int nslot = K > 1 ? K - 1 : 1;
@@ -239,7 +318,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
     if (tid == 0) flag[0] = 0;
     unsigned long long tp = 0, ty = 0, tu = 0, t0 = 0, tb = dbg ? clock64() : 0;   // debug cycle counters
 
-    for (int k = 0; k < K; ++k) {
+    for (int k = (NP == 1 ? 0 : k0); k < (NP == 1 ? K : k1); ++k) {
         if (dbg) t0 = clock64();
         // ---- panel blocks A_ik (i != k) into registers; they land while the pivot block is factorised ----
         V4<float> preg[SPD_MAXK - 1];
@@ -251,7 +330,11 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                 preg[s] = *(const V4<float>*)(Hs + (size_t)blk * LQP_BLK + tid * 4);
             }
         }
-        wg_pivot_block(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        if (NP == 1 || k == 0) {
+            wg_pivot_block(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        } else {      // W, W^T of this pivot block were prepared by the previous launch (lookahead below)
+            for (int i = tid * 4; i < 2 * 64 * SPD_LS; i += LQP_NT * 4) *(V4<float>*)(W + i) = *(const V4<float>*)(Wg + i);
+        }
         // ---- panel to LDS: slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k ----
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s) {
@@ -303,34 +386,72 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             const int nupd = npair * 4, nrest = (K - 1) * 4 + 4;
             // update tiles: the C quadrant of the NEXT task is requested before the MFMA chain of this one, so the
             // waves of a SIMD do not all sit in their load phase (then all in their MFMA phase) together
-            auto upd_addr = [&](const int task, int& si, int& sj, bool& skip, bool& mirror) -> float* {
+            const int plook = (NP > 1 && k + 1 < K) ? k * (k + 1) / 2 + k : -1;      // pair (slot k, slot k) = tile (k+1, k+1)
+            auto upd_addr = [&](const int task, int& si, int& sj, bool& skip, bool& mirror) -> size_t {
                 const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
                 si = 0;
                 while ((si + 1) * (si + 2) / 2 <= p) ++si;
                 sj = p - si * (si + 1) / 2;
                 skip = si == sj && qi == 0 && qj == 1;          // diagonal tile: mirrored from its (1,0) quadrant
+                if (NP > 1 && p == plook) skip = true;          // the next pivot tile is the lookahead's
                 mirror = si == sj && qi == 1 && qj == 0;
                 const int i = si < k ? si : si + 1, j = sj < k ? sj : sj + 1;
-                return Hs + (size_t)sym_idx(i, j, K) * LQP_BLK;
+                return (size_t)sym_idx(i, j, K) * LQP_BLK;
             };
             auto upd_load = [&](const float* T0, const int task, f32x16& c) {
                 const float* C = T0 + (32 * ((task >> 1) & 1)) * 64 + 32 * (task & 1) + li;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) c[q] = C[quad_row(q, lh) * 64];
             };
-            int task = __builtin_amdgcn_readfirstlane(w);
+            // NP == 2: workgroup 0 takes the head of the update list and the panel / pivot tasks (they need W, W^T of
+            // this step), workgroup 1 the tail -- after it has updated the NEXT pivot tile, factorised it and left
+            // its W, W^T in Wg for the next launch (that costs about as much as `pivot_tasks` tile tasks)
+            int ulo = 0, uhi = nupd;
+            bool do_rest = true;
+            if (NP > 1) {
+                // workgroup 1's share of the update list: half of what is left of (all tasks - the pivot's worth)
+                int n1 = (nupd + nrest - (k + 1 < K ? pivot_tasks : 0)) / 2;
+                n1 = n1 < 0 ? 0 : (n1 > nupd ? nupd : n1);
+                const int cut = nupd - n1;
+                if (part == 0) uhi = cut; else { ulo = cut; do_rest = false; }
+                if (part == 1 && k + 1 < K) {
+                    float* Tn = Hd + (size_t)sym_idx(k + 1, k + 1, K) * LQP_BLK;
+                    if (w < 4 && w != 1) {                      // quadrants (0,0), (1,0) + mirror, (1,1); slot of k+1 is k
+                        const int qi = w >> 1, qj = w & 1;
+                        const float* Cs = Hs + (size_t)sym_idx(k + 1, k + 1, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+                        f32x16 cur;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) cur[q] = Cs[quad_row(q, lh) * 64];
+                        const f32x16 acc = spd_quadrant(Y + ((size_t)k * 64 + 32 * qi) * SPD_LS, Y + ((size_t)k * 64 + 32 * qj) * SPD_LS);
+                        cur -= acc;
+                        float* C = Tn + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                        if (w == 2) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) Tn[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    wg_pivot_block(Tn, W, WT, pcol, flag, (k + 1) * 64);
+                    __syncthreads();
+                    for (int i = tid * 4; i < 2 * 64 * SPD_LS; i += LQP_NT * 4) *(V4<float>*)(Wg + i) = *(const V4<float>*)(W + i);
+                }
+            }
+            int task = ulo + __builtin_amdgcn_readfirstlane(w);
             int si = 0, sj = 0; bool skip = false, mirror = false;
-            float* T0 = nullptr;
+            size_t T0 = 0;
             f32x16 nxt;
-            if (task < nupd) { T0 = upd_addr(task, si, sj, skip, mirror); if (!skip) upd_load(T0, task, nxt); }
-            while (task < nupd) {
+            if (task < uhi) { T0 = upd_addr(task, si, sj, skip, mirror); if (!skip) upd_load(Hs + T0, task, nxt); }
+            while (task < uhi) {
                 const int qi = (task >> 1) & 1, qj = task & 1;
                 f32x16 cur = nxt;
-                float* Tc = T0;
+                float* Tc = Hd + T0;
                 const int csi = si, csj = sj;
                 const bool cskip = skip, cmirror = mirror;
                 const int ntask = task + LQP_NW;
-                if (ntask < nupd) { T0 = upd_addr(ntask, si, sj, skip, mirror); if (!skip) upd_load(T0, ntask, nxt); }
+                if (ntask < uhi) { T0 = upd_addr(ntask, si, sj, skip, mirror); if (!skip) upd_load(Hs + T0, ntask, nxt); }
                 if (!cskip) {
                     const f32x16 acc = spd_quadrant(Y + ((size_t)csi * 64 + 32 * qi) * SPD_LS,
                                                     Y + ((size_t)csj * 64 + 32 * qj) * SPD_LS);
@@ -346,7 +467,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                 task = ntask;
             }
             // the new panel column and the pivot block (stores only)
-            for (int t2 = __builtin_amdgcn_readfirstlane(w); t2 < nrest; t2 += LQP_NW) {
+            for (int t2 = do_rest ? __builtin_amdgcn_readfirstlane(w) : nrest; t2 < nrest; t2 += LQP_NW) {
                 const int qi = (t2 >> 1) & 1, qj = t2 & 1;
                 if (t2 < nrest - 4) {
                     const int s = t2 >> 2;
@@ -357,11 +478,11 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                     if (i > k) {          // Y W: column c >= 32 (qj == 1) only sees k >= 32
                         acc = qj == 1 ? spd_quadrant<1, true>(Ys + (32 * qi) * SPD_LS, WT + 32 * SPD_LS)
                                       : spd_quadrant(Ys + (32 * qi) * SPD_LS, WT);
-                        C = Hs + (size_t)sym_idx(i, k, K) * LQP_BLK;
+                        C = Hd + (size_t)sym_idx(i, k, K) * LQP_BLK;
                     } else {              // W^T Y^T: row r >= 32 (qi == 1) only sees k >= 32
                         acc = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Ys + (32 * qj) * SPD_LS)
                                       : spd_quadrant(WT, Ys + (32 * qj) * SPD_LS);
-                        C = Hs + (size_t)sym_idx(k, i, K) * LQP_BLK;
+                        C = Hd + (size_t)sym_idx(k, i, K) * LQP_BLK;
                     }
                     C += (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
@@ -369,7 +490,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                 } else {
                     const f32x16 acc = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
                                                  : spd_quadrant(WT, WT);
-                    float* C = Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+                    float* C = Hd + (size_t)sym_idx(k, k, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = -acc[q];
                 }

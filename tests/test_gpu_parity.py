@@ -612,3 +612,32 @@ def test_random_small_problems_vs_cpu_oracle(dev, seed):
                 assert err(sol[k], ref[k]) < 5e-5, (ls, k)
         res = O.kkt_residuals(Q, p, A, b, lb, ub, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sol.items()})
         assert float(res["box"].max()) < 1e-6 and float(res["x_minus_z"].max()) < 1e-3
+
+
+@pytest.mark.parametrize("n,B,m", [(200, 3, 1), (330, 5, 2), (512, 2, 0)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeypatch, n, B, m, mode):
+    """Small batches share each matrix between two workgroups (one launch per pivot step, lookahead pivot block).
+    The arithmetic per tile is the same as in the single-launch sweep -> identical bits; rho = 100 forces the
+    adaptive-rho refactorisation (gated launches in mode 1, in-kernel in mode 2); the CPU oracle is the checker."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
+    sols = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("LQP_SPD_SPLIT", split)
+        for rho in (None, 100.0):
+            ctl = O.make_control(rho=rho, linsolve="spd", launch_mode=mode, **TOL)
+            sols[split, rho], _ = solve(dev, (Q, p, A, b, lb, ub), ctl)
+            assert sols[split, rho]["_stats"]["linsolve_used"] == 2
+    for rho in (None, 100.0):
+        s1, s0 = sols["1", rho], sols["0", rho]
+        assert s1["iter"] == s0["iter"] and s1["_stats"]["n_factor"] == s0["_stats"]["n_factor"]
+        assert s1["_stats"]["n_launch"] > s0["_stats"]["n_launch"]        # really the multi-launch path
+        for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+            assert torch.equal(s1[k], s0[k]), (rho, k)
+        ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(rho=rho, **TOL))
+        assert abs(s1["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
+        assert err(s1["x"], ref["x"]) < 5e-4 * max(1.0, float(ref["x"].abs().max()))
+    assert sols["1", 100.0]["_stats"]["n_factor"] >= 2
