@@ -88,7 +88,8 @@ typedef struct lqp_boxqp_stats {
     int32_t n_launch;       /* kernel launches issued                                  */
     int32_t mode_used;      /* 1 segmented, 2 persistent, 3 persistent without host sync */
     int32_t linsolve_used;  /* 1 pivoted LU, 2 symmetric inverse (what linsolve 0 / a fallback resolved to) */
-    int32_t reserved;
+    int32_t factor_launches; /* kernel launches per (re)factorisation: 1, 2 (LU + pack) or Ks + 2 when a small batch
+                              * shares each matrix between two workgroups (one launch per pivot step) */
 } lqp_boxqp_stats;
 
 int lqp_abi_version(void);

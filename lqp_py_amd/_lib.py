@@ -35,7 +35,7 @@ class BoxQPCtrl(ctypes.Structure):
 class BoxQPStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in (
         "iters", "n_factor", "n_solve", "n_check", "rho_updated", "fail_index", "n_launch", "mode_used", "linsolve_used",
-        "reserved")]
+        "factor_launches")]
 
 
 # every symbol include/lqp_amd.h declares: name -> (restype, argtypes)

@@ -437,6 +437,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
                 stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
                 stats->linsolve_used = spd ? 2 : 1;
+                stats->factor_launches = spd ? (spd_split ? P.Ks + 2 : 1) : 2;
             }
             return LQP_OK;
         }
@@ -537,7 +538,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->n_launch = n_launch;
         stats->mode_used = mode;
         stats->linsolve_used = spd ? 2 : 1;
-        stats->reserved = 0;
+        stats->factor_launches = spd ? (spd_split ? P.Ks + 2 : 1) : 2;
     }
     return LQP_OK;
 }
@@ -623,7 +624,8 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         rc = ensure_lds((const void*)fn, lds);
         if (rc) return rc;
         ProfScope ps(st, PC_BWD_EPILOGUE);
-        hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
+        const int slabs = env_int("LQP_EPI_SLABS", B <= 128 ? 2 : 1);      // row slabs per problem: fill the chip when the batch is small
+        hipLaunchKernelGGL(fn, dim3(B, slabs), dim3(LQP_NT), lds, st, P);
     }
     if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
     if (fail_index) {

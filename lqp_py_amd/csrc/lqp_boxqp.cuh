@@ -1469,9 +1469,11 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
         for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[n + r];
     }
     __syncthreads();
-    if (P.dp) for (int i = tid; i < n; i += LQP_NT) P.dp[(size_t)b * n + i] = dv[i];
-    if (P.db) for (int r = tid; r < m; r += LQP_NT) P.db[(size_t)b * m + r] = -dnu[r];
-    if (P.dA && m > 0) {
+    // gridDim.y workgroups share the rows of one problem (dQ is a pure 4 n^2-byte write); the small outputs: slab 0
+    const bool first = blockIdx.y == 0;
+    if (P.dp && first) for (int i = tid; i < n; i += LQP_NT) P.dp[(size_t)b * n + i] = dv[i];
+    if (P.db && first) for (int r = tid; r < m; r += LQP_NT) P.db[(size_t)b * m + r] = -dnu[r];
+    if (P.dA && m > 0 && first) {
         const T* nus = P.nus + (size_t)b * m;
         for (int t = tid; t < m * n; t += LQP_NT) {
             const int r = t / n, j = t - r * n;
@@ -1482,7 +1484,18 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     const T* A = P.A ? P.A + (size_t)b * m * n : nullptr;
     const bool need_kkt = P.dlb || P.dub;
     T* dQ = P.dQ ? P.dQ + (size_t)b * n * n : nullptr;
-    for (int i = w; i < n; i += LQP_NW) {
+    // 16-B stores; a lane's columns are the same in every row, so their x_j and dv_j / 2 stay in registers
+    const bool vec = (n % 4 == 0) && n <= 1024 && dQ && ((((uintptr_t)dQ) % sizeof(V4<T>)) == 0);
+    V4<T> xj[4], hj[4];
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane * 4 + 256 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xj[q].v[e] = j < n ? xs[j + e] : T(0); hj[q].v[e] = j < n ? T(0.5) * dv[j + e] : T(0); }
+        }
+    }
+    for (int i = w + LQP_NW * blockIdx.y; i < n; i += LQP_NW * gridDim.y) {
         const T hi = T(0.5) * dv[i], xi = xs[i];
         T acc = T(0);
         if (need_kkt) {
@@ -1492,7 +1505,20 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
         }
         if (dQ) {
             T* o = dQ + (size_t)i * n;
-            for (int j = lane; j < n; j += 64) o[j] = hi * xs[j] + (T(0.5) * dv[j]) * xi;
+            if (vec) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = lane * 4 + 256 * q;
+                    if (j < n) {
+                        V4<T> ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov.v[e] = hi * xj[q].v[e] + hj[q].v[e] * xi;
+                        *(V4<T>*)(o + j) = ov;
+                    }
+                }
+            } else {
+                for (int j = lane; j < n; j += 64) o[j] = hi * xs[j] + (T(0.5) * dv[j]) * xi;
+            }
         }
         if (need_kkt && lane == 0) {
             T kkt = -P.g[(size_t)b * n + i] - acc;
