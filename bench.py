@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="QPs per GPU")
     ap.add_argument("--n", type=int, default=N_X)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--linsolve", choices=["auto", "lu", "spd"], default="auto",
+                    help="x-update of the forward solve (control['linsolve']); lu = the reference's cached pivoted LU")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the forward-only extras (configs 2 and 4)")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -70,7 +72,7 @@ def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True):
 
 LOOP_KERNEL = {1: "lqp::k_admm_loop<float, true, false, 1024, false>",
                2: "lqp::k_admm_loop<float, true, false, 1024, true>"}
-TRAFFIC_FILE = "profiles/r01_h_traffic.json"
+TRAFFIC_FILE = "profiles/r01_i_traffic.json"
 
 
 def measured_traffic(kernel, mode, B, n):
@@ -154,6 +156,8 @@ def main():
         data.append([t.to(dev) for t in (Q, p, A, b, lb, ub)])
     ones = torch.ones(B, n, 1, device=dev)
     control = L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, reduce='max')
+    if args.linsolve != "auto":
+        control['linsolve'] = args.linsolve
     if args.sync:
         control['sync'] = True
     layer = ShardedBoxQP(control) if world > 1 else None
