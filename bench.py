@@ -158,8 +158,7 @@ def main():
     control = L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, reduce='max')
     if args.linsolve != "auto":
         control['linsolve'] = args.linsolve
-    if args.sync:
-        control['sync'] = True
+    control['sync'] = bool(args.sync)     # False: the pipelined training-loop mode (errors reported late, NaN on failure)
     layer = ShardedBoxQP(control) if world > 1 else None
     qp = L.SolveBoxQP(control=control)
     last = {}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 3
+#define LQP_ABI_VERSION 4
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -55,7 +55,8 @@ typedef struct lqp_boxqp_ctrl {
     int32_t any_ub;                  /* 0/1: min(ub) < +inf over the WHOLE batch (:130)*/
     int32_t rho_mode;                /* 0 auto (||Q||_F/sqrt(n), :200-203), 1 scalar rho_value,
                                         2 per-problem array `rho_in` (B values)        */
-    int32_t beta_mode;               /* 0 auto (quantile rule :171-174), 1 scalar beta_value */
+    int32_t beta_mode;               /* 0 auto (quantile rule :171-174), 1 scalar beta_value, 2 per-problem array
+                                        `beta_in` (B values; the reference accepts a (B,1) tensor, :171-175)  */
     int32_t launch_mode;             /* 0 auto, 1 one launch per check segment,
                                         2 persistent loop kernel with in-kernel grid barrier */
     int32_t reserved;                /* 1: do not synchronise with the host (needs persistent launches and a
@@ -75,6 +76,18 @@ typedef struct lqp_boxqp_ctrl {
     double adaptive_rho_tol;
     double adaptive_rho_threshold;
     double beta_value;
+    const void* beta_in;             /* beta_mode == 2: B values of the tensors' dtype (device pointer), else NULL */
+    /* Strict global stopping across batch shards (one process per GPU): when set, the solve runs one
+     * launch per check segment and, right after the launch that holds check number `check_index`, calls
+     *     check_hook(check_hook_user, stream, counters, check_index)
+     * on the host with the DEVICE address of that check's three uint32 counters {problems not yet optimal,
+     * problems that want a rho update, problems whose residual ratio triggers one} (:310-312, :244-246).  The hook
+     * must enqueue, ordered on `stream`, an in-place SUM all-reduce of those three words over the ranks (RCCL); every
+     * consumer of the counters (stop test, adaptive-rho decision) is enqueued after it, so all ranks take the
+     * single-process decisions and report the single-process iteration count.  Non-zero return aborts the solve
+     * (LQP_ERR_HIP).  NULL: decisions are per call (per shard).                                                  */
+    int (*check_hook)(void* user, void* stream, void* counters_dev, int check_index);
+    void* check_hook_user;
 } lqp_boxqp_ctrl;
 
 /* Host-side bookkeeping returned by the forward solve. */

@@ -17,10 +17,15 @@ LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQ
 SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
 
 LQP_F32, LQP_F64 = 0, 1
+ABI_VERSION = 4
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
           5: "grid barrier timeout", 6: "unsupported size"}
 
 c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
+
+
+# int check_hook(void* user, void* stream, void* counters_dev, int check_index)   (include/lqp_amd.h)
+CHECK_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
 
 
 class BoxQPCtrl(ctypes.Structure):
@@ -29,7 +34,8 @@ class BoxQPCtrl(ctypes.Structure):
         "any_lb", "any_ub", "rho_mode", "beta_mode", "launch_mode", "reserved", "linsolve", "reserved2")] + [
         (k, ctypes.c_double) for k in (
             "eps_abs", "eps_rel", "rho_value", "rho_min", "rho_max", "adaptive_rho_tol",
-            "adaptive_rho_threshold", "beta_value")]
+            "adaptive_rho_threshold", "beta_value")] + [
+        ("beta_in", ctypes.c_void_p), ("check_hook", CHECK_HOOK), ("check_hook_user", ctypes.c_void_p)]
 
 
 class BoxQPStats(ctypes.Structure):
@@ -108,7 +114,7 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.lqp_abi_version() != 3:
+        if lib.lqp_abi_version() != ABI_VERSION:
             raise RuntimeError("lqp_py_amd: ABI version mismatch")
         _lib = lib
         return lib
@@ -168,6 +174,7 @@ class _Pending:
 
 
 _pending = []
+_pending_lock = threading.Lock()
 
 
 def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes):
@@ -178,20 +185,25 @@ def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes):
     info.copy_(ws[info_off:info_off + info_bytes].view(torch.int32), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(ws.device))
-    _pending.append(_Pending(what, ev, status, info))
-    if len(_pending) > 64:
+    with _pending_lock:
+        _pending.append(_Pending(what, ev, status, info))
+        backlog = len(_pending)
+    if backlog > 64:
         poll_errors(block=True)
 
 
 def poll_errors(block=False):
     """Raise the first error of an earlier un-synchronised call whose results have arrived.
     block=True waits for all of them (``lqp_py_amd.synchronize()``)."""
-    while _pending:
-        p = _pending[0]
-        if not block and not p.event.query():
-            return
+    while True:
+        with _pending_lock:
+            if not _pending:
+                return
+            p = _pending[0]
+            if not block and not p.event.query():
+                return
+            _pending.pop(0)
         p.event.synchronize()
-        _pending.pop(0)
         bad = torch.nonzero(p.info)
         if p.status is not None and int(p.status[7]):
             raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): Q + rho I is not "
@@ -206,16 +218,20 @@ def poll_errors(block=False):
 
 
 _ws_cache = {}
+_ws_lock = threading.Lock()
 
 
 def workspace(device, nbytes, tag):
-    """Reusable device scratch buffer per (device, tag); grows monotonically."""
-    key = (device.index, tag)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf
+    """Reusable device scratch buffer per (device, STREAM, tag); grows monotonically.  Kernels of one stream are
+    ordered, so re-using the buffer call after call is safe; two streams (pipelined layers, threads) never share
+    one -- a persistent loop of one stream would otherwise read factors another stream is overwriting."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    with _ws_lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            _ws_cache[key] = buf
+        return buf
 
 
 def norm(t, dtype):

@@ -19,6 +19,7 @@ namespace {
 constexpr int kRing = 1024;          // per-check counter slots
 constexpr int kMaxN = 1024;          // one panel row per thread
 constexpr size_t kAlign = 256;
+constexpr int kSplitMaxB = 256;      // two-workgroup loop: batches up to half the CUs of any device we know of
 
 struct Carver {
     char* base;
@@ -225,6 +226,8 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.Qs = c.take<T>((size_t)B * n * P.ldq);
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
+    // granules of the two-workgroup loop (only ever used when 2 B workgroups fit the chip)
+    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * XCHG_WORDS) : nullptr;
     L.bytes = c.off + kAlign;
     return L;
 }
@@ -238,7 +241,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     if (ws_bytes < L.bytes) return LQP_ERR_WORKSPACE;
     FwdParams<T>& P = L.P;
     P.Q = (const T*)Q; P.p = (const T*)p; P.A = (const T*)A; P.b = (const T*)b;
-    P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in;
+    P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in; P.beta_in = (const T*)ctl->beta_in;
     P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
     P.scale = ctl->scale; P.any_lb = ctl->any_lb; P.any_ub = ctl->any_ub;
     P.dbg = g_lu_dbg;
@@ -372,14 +375,44 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     if (rc) return rc;
     int mode = ctl->launch_mode;
     if (mode == 0) mode = env_int("LQP_LAUNCH_MODE", 2);     // auto: persistent when every workgroup is resident
+    if (ctl->check_hook) mode = 1;                           // the hook sits between the check segments
     if (mode == 2) {
-        int dev = 0, cus = 0, per_cu = 0;
+        // the grid barrier needs EVERY workgroup resident -- of the hot kernel and of the continuation kernel
+        // (own block size and LDS footprint): take the smaller of the two answers
+        int dev = 0, cus = 0, per_cu = 0, per_cu_tail = 0;
         HIP_OK(hipGetDevice(&dev));
         HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_fn, loop_nt, loop_lds));
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tail, tail_fn, LQP_NT, tail_lds));
+        per_cu = std::min(per_cu, per_cu_tail);
         if (per_cu < 1 || B > cus * per_cu) mode = 1;     // not every workgroup resident: no grid barrier
     }
     const int max_checks_per_launch = kRing / 4;
+    // two workgroups per QP for the first (hot) launch: symmetric path, persistent mode, 2 B workgroups resident
+    bool loop_split = false;
+    int split_lds = 0;
+    if constexpr (sizeof(T) == 4) {
+        if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && env_int("LQP_LOOP_SPLIT", 1) != 0) {
+            split_lds = sym_loop_lds_bytes(n, m, P.Ks, split_lds_blocks(P.Ks));
+            int dev = 0, cus = 0, per_cu = 0;
+            HIP_OK(hipGetDevice(&dev));
+            HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (split_lds <= 160 * 1024 && ensure_lds((const void*)k_admm_loop_split, split_lds) == LQP_OK &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_admm_loop_split, LQP_NT, split_lds) == hipSuccess)
+                loop_split = per_cu >= 1 && 2 * B <= cus * per_cu;
+        }
+    }
+    // the first launch of the persistent modes
+    auto launch_hot = [&](const int it, const int e, const int ctr_base, const int prev_slot, const int flags) {
+        ProfScope ps(st, PC_LOOP);
+        if constexpr (sizeof(T) == 4) {
+            if (loop_split && it == 0) {
+                hipLaunchKernelGGL(k_admm_loop_split, dim3(2 * B), dim3(LQP_NT), split_lds, st, P, it, e, ctr_base);
+                return;
+            }
+        }
+        hipLaunchKernelGGL(loop_fn, dim3(B), dim3(loop_nt), loop_lds, st, P, it, e, ctr_base, prev_slot, flags);
+    };
 
     // ---- no-host-sync plan (ctrl.reserved == 1, persistent launches): enqueue the WHOLE schedule.
     //      Every kernel exits at once when the device-side DONE flag is up, the refactor chains are
@@ -422,9 +455,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     }
                 }
                 const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
-                { ProfScope ps(st, it == 0 ? PC_LOOP : PC_LOOP_TAIL);
-                  hipLaunchKernelGGL(it == 0 ? loop_fn : tail_fn, dim3(B), dim3(it == 0 ? loop_nt : LQP_NT), it == 0 ? loop_lds : tail_lds, st,
-                                     P, it, e, (int)(c_first % kRing), prev_slot, (event || (spd && it > 0)) ? 3 : 1); }
+                if (it == 0) {
+                    launch_hot(it, e, (int)(c_first % kRing), prev_slot, 1);
+                } else {
+                    ProfScope ps(st, PC_LOOP_TAIL);
+                    hipLaunchKernelGGL(tail_fn, dim3(B), dim3(LQP_NT), tail_lds, st,
+                                       P, it, e, (int)(c_first % kRing), prev_slot, (event || spd) ? 3 : 1);
+                }
                 ++n_launch;
                 it = e;
             }
@@ -449,6 +486,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     int it = 0;
     long long zeroed_upto = kRing;     // check indices [0, zeroed_upto) have clean slots
     bool done = false, singular_checked = false;
+    int nfactor_seen = 0;
     int chunk_cap = env_int("LQP_SPEC_LAUNCHES", 6);
     int fail_index = -1;
     while (it < max_iters && !done) {
@@ -486,12 +524,23 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             const int ctr_base = (int)(c_first % kRing);
             const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
             { const bool first = (mode == 2 && it == 0) || mode == 1;
-              ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);
-              hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(first ? loop_nt : LQP_NT), first ? loop_lds : tail_lds, st, P, it, e,
-                                 ctr_base, prev_slot, mode == 2 ? ((tail_events && !first) ? 3 : 1) : 0); }
+              if (first && mode == 2) {
+                  launch_hot(it, e, ctr_base, prev_slot, 1);
+              } else {
+                  ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);
+                  hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(first ? loop_nt : LQP_NT), first ? loop_lds : tail_lds, st, P, it, e,
+                                     ctr_base, prev_slot, mode == 2 ? ((tail_events && !first) ? 3 : 1) : 0);
+              } }
             ++n_launch;
             ++in_chunk;
             it = e;
+            if (ctl->check_hook && mode == 1 && ((e - 1) % check) == 0) {
+                // strict global stop: all-reduce this check's counters over the ranks before anything reads them
+                const long long c_idx = (e - 1) / check;
+                if (ctl->check_hook(ctl->check_hook_user, (void*)st, (void*)(P.counters + (size_t)(c_idx % kRing) * CT_WORDS),
+                                    (int)c_idx) != 0)
+                    return LQP_ERR_HIP;
+            }
         }
         // ---- close the chunk: did the last check stop the loop? ----
         if (it > 0 && ((it - 1) % check) == 0) {
@@ -520,7 +569,19 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             if (rc) return rc;
         } else {
             HIP_OK(hipStreamSynchronize(st));
+            if (h_status[ST_NFACTOR] != nfactor_seen) {      // an adaptive-rho refactorisation ran in this chunk
+                rc = first_failure(st, P.info, B, &fail_index);
+                if (rc == LQP_ERR_SINGULAR && spd)
+                    return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
+                                           ws, ws_bytes, true);
+                if (rc == LQP_ERR_SINGULAR) {
+                    if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
+                    return rc;
+                }
+                if (rc) return rc;
+            }
         }
+        nfactor_seen = h_status[ST_NFACTOR];
         if (h_status[ST_TIMEOUT]) return LQP_ERR_TIMEOUT;
         done = h_status[ST_DONE] != 0;
         chunk_cap = std::min(chunk_cap * 2, 64);
@@ -823,6 +884,7 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m, const void* 
         return LQP_ERR_INVALID;
     if (m > 0 && (!A || !b || !nus)) return LQP_ERR_INVALID;
     if (ctrl->rho_mode == 2 && !rho_in) return LQP_ERR_INVALID;
+    if (ctrl->beta_mode == 2 && !ctrl->beta_in) return LQP_ERR_INVALID;
     if (ctrl->max_iters < 1) return LQP_ERR_INVALID;
     if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;

@@ -24,7 +24,7 @@ template <typename T> struct FwdParams {
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
-    const T *Q, *p, *A, *b, *lb, *ub, *rho_in;
+    const T *Q, *p, *A, *b, *lb, *ub, *rho_in, *beta_in;
     // outputs
     T *x, *z, *u, *lams, *nus, *rho_out;
     // workspace
@@ -38,6 +38,7 @@ template <typename T> struct FwdParams {
     int* info;        // B
     int* status;      // ST_WORDS
     unsigned int* counters;   // ring of CT_WORDS per check
+    unsigned long long* xchg; // B * XCHG_WORDS granules: partial-product exchange of the two-workgroup loop (or null)
     size_t vstride;
     // controls
     int scale, any_lb, any_ub, rho_mode, beta_mode, check_solved, adaptive_rho;
@@ -216,6 +217,10 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
     if (tid == 0) P.info[b] = 0;
+    if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
+        unsigned long long* xq = P.xchg + (size_t)b * (2 * 2 * SPD_MAXK * LQP_NB);
+        for (int i = tid; i < 2 * 2 * SPD_MAXK * LQP_NB; i += LQP_NT) xq[i] = 0ull;
+    }
 
     // ---- ||p||_inf on the unscaled p (:127) ----
     T pm = T(0);
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         }
         const T dmean = wg_sum(part, scratch) / T(n);     // also makes d[] visible
         // ---- beta = 1 - q10(D) / q90(D), linear-interpolated quantiles (:171-174) ----
-        T beta = P.beta_value;
+        T beta = P.beta_mode == 2 ? P.beta_in[b] : P.beta_value;
         if (P.beta_mode == 0) {
             const T pos0 = T(0.10) * T(n - 1), pos1 = T(0.90) * T(n - 1);
             const int lo0 = (int)tfloor(pos0), hi0 = (int)tceil(pos0);
@@ -1032,6 +1037,203 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same loop with TWO workgroups per QP (symmetric x-update, f32, 2 B <= #CUs, Ks >= SPLIT_MINK): workgroups b
+// and b + B hold one half of the blocks of H each, ALL of them on chip for the whole launch (lqp_spd.cuh,
+// wg_sym_gemv_split), and exchange their partial products every iteration:
+//   thread e < Nps combines its element of this workgroup's partial, publishes it as ONE 8-byte granule
+//   {tag = iteration + 1, value} (agent-scope relaxed atomic store = sc1 write-through store), polls the partner's
+//   granule of the same element (sc1 loads, L1 bypassed) until the tag matches, and adds the two partials in the
+//   fixed order part 0 + part 1 -- both workgroups then hold bit-identical iterates and run the element-wise
+//   update, the checks and the stop decision redundantly (part 0 alone reports to the counters / writes state).
+// Two granule buffers alternate by iteration parity: a workgroup can be at most one exchange ahead of its
+// partner, so a granule is never overwritten before it was read.  The area is zeroed by k_fwd_setup of the same
+// forward (tags start at 1).  Spins are bounded (0.5 s): a timeout sets ST_TIMEOUT and the kernel still drains.
+// LDS: as the symmetric loop with rl = split_lds_blocks(Ks).
+// ---------------------------------------------------------------------------
+constexpr int XCHG_WORDS = 2 * 2 * SPD_MAXK * LQP_NB;       // granules per QP: [parity][part][element]
+
+__global__ __launch_bounds__(LQP_NT) void k_admm_loop_split(const FwdParams<float> P, const int it0, const int it1,
+                                                            const int ctr_base) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    typedef float T;
+    constexpr int NT = LQP_NT;
+    const int b = blockIdx.x % P.B, part_id = blockIdx.x / P.B;
+    const int n = P.n, m = P.m, Ks = P.Ks;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (it0 >= it1) return;
+    const int Nps = Ks * LQP_NB;
+    const int rl = split_lds_blocks(Ks);
+    const int nloc = split_count(Ks, part_id);
+    T* lds_res = (T*)smem;
+    T* v = lds_res + (size_t)rl * LQP_BLK;
+    T* xs = v + Nps;
+    T* ylds = xs + Nps;
+    T* cvl = ylds + sym_blocks(Ks) * 64;
+    T* part = cvl + Nps;
+    T* z = part + (size_t)(NT / 64) * Nps;
+    T* u = z + n;
+    T* ps = u + n;
+    T* lb = ps + n;
+    T* ub = lb + n;
+    T* D = ub + n;
+    T* bs = D + n;
+    T* red = bs + 2 * m;
+    int* dead = (int*)(red + (NT / 64) * 8 + 4);            // sticky exchange-timeout flag of this workgroup
+
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    T* scal = P.scal + (size_t)b * SC_WORDS;
+    const T* packed = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+    unsigned long long* xq = P.xchg + (size_t)b * XCHG_WORDS;
+    const T rho = scal[SC_RHO];
+    const T pnorm = scal[SC_PNORM];
+
+    SplitResident rr;
+    split_resident_load(rr, lds_res, packed, Ks, part_id, nloc);
+    for (int i = tid; i < n; i += NT) {
+        z[i] = V.z[i]; u[i] = V.u[i]; ps[i] = V.ps[i]; lb[i] = V.lbs[i]; ub[i] = V.ubs[i]; D[i] = V.D[i];
+    }
+    for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
+    for (int i = tid; i < Nps; i += NT) cvl[i] = (i < n && m > 0) ? V.cv[i] : T(0);
+    for (int i = tid; i < sym_blocks(Ks) * 64; i += NT) ylds[i] = T(0);       // slots / columns of the partner stay zero
+    for (int i = tid; i < (NT / 64) * Nps; i += NT) part[i] = T(0);
+    if (tid == 0) dead[0] = 0;
+    __syncthreads();
+    for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
+    wg_barrier_lds();
+
+    int slot = ctr_base;
+    T* nus_l = bs + m;
+    for (int it = it0; it < it1; ++it) {
+        const bool check = (it % P.check_solved) == 0;
+        T mx[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) mx[q] = T(0);
+        wg_sym_gemv_split(rr, lds_res, Ks, Nps, part_id, nloc, v, ylds, part);
+        wg_barrier_lds();
+        if ((check || it + 1 == it1) && m > 0) {             // nu = T^T w - s0 while v is still w
+            for (int r = w; r < m; r += (NT / 64)) {
+                T acc = T(0);
+                for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
+                acc = wave_sum(acc);
+                if (lane == 0) nus_l[r] = acc - V.s0[r];
+            }
+            wg_barrier_lds();
+        }
+        if (tid < Nps) {
+            const int i = tid;
+            const T own = sym_combine<NT>(i, Ks, Nps, ylds, part);
+            // ---- exchange: publish this element's partial, fetch the partner's ----
+            const unsigned int tag = (unsigned int)(it + 1);
+            unsigned long long* base = xq + (size_t)(it & 1) * (2 * SPD_MAXK * LQP_NB);
+            __hip_atomic_store(base + (size_t)part_id * (SPD_MAXK * LQP_NB) + i,
+                               ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, own),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long* src = base + (size_t)(1 - part_id) * (SPD_MAXK * LQP_NB) + i;
+            unsigned long long g = 0;
+            if (!dead[0]) {
+                unsigned int spins = 0;
+                unsigned long long t0 = 0;
+                for (;;) {
+                    g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(g >> 32) == tag) break;
+                    if ((++spins & 1023u) == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up
+                            __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            dead[0] = 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            const T other = __builtin_bit_cast(float, (unsigned int)g);
+            const T y = part_id == 0 ? own + other : other + own;      // same order on both workgroups
+            const T xi = cvl[i] - y;
+            xs[i] = xi;
+            T wn = T(0);
+            if (i < n) {
+                const T zp = z[i];
+                const T ui = u[i];
+                T zn = xi + ui;
+                if (P.any_lb) zn = tmax(zn, lb[i]);
+                if (P.any_ub) zn = tmin(zn, ub[i]);
+                const T r = xi - zn;
+                const T s = rho * (zn - zp);
+                const T un = ui + r;
+                z[i] = zn;
+                u[i] = un;
+                if (check) {
+                    const T di = D[i];
+                    mx[0] = tmax(mx[0], tabs(di * r));
+                    mx[1] = tmax(mx[1], tabs(di * s));
+                    mx[2] = tmax(mx[2], tabs(di * xi));
+                    mx[3] = tmax(mx[3], tabs(di * zn));
+                    mx[4] = tmax(mx[4], tabs((rho * di) * un));
+                    T qx = v[i] - rho * xi;
+                    for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nus_l[q];
+                    mx[5] = tmax(mx[5], tabs(qx / di));
+                }
+                wn = -ps[i] + rho * (zn - un);
+            }
+            v[i] = wn;
+        }
+        if (check) {
+            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], mx[5]};
+            wg_max_n<T, 6, NT / 64>(mv, red);
+            const T tiny = T(1e-16);
+            const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
+            const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
+            const T dua_scale = tmax(tmax(tmax(mv[4], mv[5]), pnorm), tiny);
+            const T tol_d = P.eps_abs + P.eps_rel * dua_scale;
+            const bool solved = (mv[0] < tol_p) && (mv[1] < tol_d);
+            const bool wants = (mv[0] > tmax(tol_p, P.ar_thr)) || (mv[1] > tmax(tol_d, P.ar_thr));
+            const T num = tmax(mv[0] / pri_scale, tiny);
+            const T den = tmax(mv[1] / dua_scale, tiny);
+            const T ratio = tsqrt(num / den);
+            const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
+            unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
+            if (tid == 0) {
+                if (part_id == 0) {                          // (the partner computed the very same numbers)
+                    scal[SC_RATIO] = ratio;
+                    scal[SC_WANTS] = wants ? T(1) : T(0);
+                    scal[SC_PRI] = mv[0];
+                    scal[SC_DUA] = mv[1];
+                    if (!solved) atomicAdd(ct + CT_NOTOPT, 1u);
+                    if (wants) atomicAdd(ct + CT_WANTS, 1u);
+                    if (trig) atomicAdd(ct + CT_TRIG, 1u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(ct + CT_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ++slot;
+            grid_wait(ct + CT_ARRIVE, gridDim.x, P.status);
+            const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (notopt == 0 || tmo) {
+                if (blockIdx.x == 0 && tid == 0) {
+                    P.status[ST_FINAL_ITER] = it;
+                    __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (part_id == 0) {
+                    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }
+                    for (int r = tid; r < m; r += NT) V.nu[r] = nus_l[r];
+                }
+                return;
+            }
+        }
+        wg_barrier_lds();
+    }
+    if (part_id == 0) {
+        for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }
+        for (int r = tid; r < m; r += NT) V.nu[r] = nus_l[r];
+    }
+}
+
 // all problems optimal at the check held in `slot` (iteration `it_check`)?  -> DONE
 __global__ void k_check_done(int* status, const unsigned int* counters, const int slot, const int it_check) {
     if (threadIdx.x == 0 && status[ST_DONE] == 0 && counters[(size_t)slot * CT_WORDS + CT_NOTOPT] == 0) {
@@ -1090,9 +1292,13 @@ __global__ __launch_bounds__(256) void k_fwd_epilogue(const FwdParams<T> P) {
     const int b = blockIdx.x, n = P.n, m = P.m;
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     const T rho = P.scal[(size_t)b * SC_WORDS + SC_RHO];
+    // a failed factorisation (singular KKT matrix / Q + rho I not positive definite) or a barrier timeout must not
+    // leave plausible-looking numbers behind: callers that did not wait for the status see NaN
+    const bool bad = P.info[b] != 0 || P.status[ST_NOTSPD] != 0 || P.status[ST_TIMEOUT] != 0;
+    const T poison = bad ? T(__builtin_nanf("")) : T(0);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const T d = V.D[i];
-        const T xo = d * V.x[i], zo = d * V.z[i], uo = V.u[i] / d;
+        const T xo = d * V.x[i] + poison, zo = d * V.z[i] + poison, uo = V.u[i] / d + poison;
         P.x[(size_t)b * n + i] = xo;
         P.z[(size_t)b * n + i] = zo;
         P.u[(size_t)b * n + i] = uo;
@@ -1100,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_fwd_epilogue(const FwdParams<T> P) {
         P.lams[(size_t)b * 2 * n + i] = (-y > T(0)) ? -y : T(0);
         P.lams[(size_t)b * 2 * n + n + i] = (y > T(0)) ? y : T(0);
     }
-    for (int r = threadIdx.x; r < m; r += blockDim.x) P.nus[(size_t)b * m + r] = V.nu[r] * V.E[r];
+    for (int r = threadIdx.x; r < m; r += blockDim.x) P.nus[(size_t)b * m + r] = V.nu[r] * V.E[r] + poison;
     if (threadIdx.x == 0) P.rho_out[b] = rho;
 }
 
@@ -1457,16 +1663,18 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     const T rho = (P.rho_mode == 2) ? P.rho_in[b] : P.rho_value;
     const T* d = P.rhs + (size_t)b * Np;
     const T* x = P.x + (size_t)b * n;
+    // singular system / Q_FF not positive definite: gradients come out as NaN, never as plausible garbage
+    const T poison = P.info[b] != 0 ? T(__builtin_nanf("")) : T(0);
     if (P.reduced) {
         const int nf = P.nred[b] - m;
         const int* fl = P.fidx + (size_t)b * n;
-        for (int i = tid; i < n; i += LQP_NT) { dv[i] = T(0); xs[i] = x[i]; }
+        for (int i = tid; i < n; i += LQP_NT) { dv[i] = poison; xs[i] = x[i]; }
         __syncthreads();
-        for (int a = tid; a < nf; a += LQP_NT) dv[fl[a]] = d[a];
-        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[nf + r];
+        for (int a = tid; a < nf; a += LQP_NT) dv[fl[a]] = d[a] + poison;
+        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[nf + r] + poison;
     } else {
-        for (int i = tid; i < n; i += LQP_NT) { dv[i] = d[i]; xs[i] = x[i]; }
-        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[n + r];
+        for (int i = tid; i < n; i += LQP_NT) { dv[i] = d[i] + poison; xs[i] = x[i]; }
+        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[n + r] + poison;
     }
     __syncthreads();
     // gridDim.y workgroups share the rows of one problem (dQ is a pure 4 n^2-byte write); the small outputs: slab 0

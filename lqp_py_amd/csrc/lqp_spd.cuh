@@ -671,6 +671,125 @@ __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, NT>& st, const Re
 }
 
 // ---------------------------------------------------------------------------
+// The same product shared by TWO workgroups (small batches: 2 B <= #CUs, so the second half of the chip is free).
+// Block columns are dealt out in pairs (j, K-1-j) -- together K+1 blocks -- alternately to the two workgroups:
+// K = 8: {0,2,5,7} and {1,3,4,6}, 18 blocks each.  A workgroup keeps ALL its blocks on chip for the whole
+// launch (SPLIT_RR in registers, the rest in LDS: nothing is streamed inside the loop), computes the partial
+// product of its blocks with the same walk as above (row sums to the block's own ylds slot, column sums to
+// part[w][.]; slots / columns of the other workgroup stay zero) and the two partial vectors are exchanged through
+// global memory by the caller (k_admm_loop_split).
+// ---------------------------------------------------------------------------
+constexpr int SPLIT_RR = 12;        // register-resident blocks per workgroup
+constexpr int SPLIT_MINK = 5;       // below that one workgroup holds the whole matrix in registers anyway
+__host__ __device__ constexpr int split_owner(int j, int K) { return (j < K - 1 - j ? j : K - 1 - j) & 1; }
+__host__ __device__ constexpr int split_count(int K, int part) {
+    int c = 0;
+    for (int j = 0; j < K; ++j) if (split_owner(j, K) == part) c += K - j;
+    return c;
+}
+// stream index (in the packed lower triangle) of the `l`-th block of workgroup `part`, columns ascending
+__host__ __device__ inline int split_block_index(int l, int K, int part) {
+    for (int j = 0; j < K; ++j) {
+        if (split_owner(j, K) != part) continue;
+        if (l < K - j) return sym_idx(j + l, j, K);
+        l -= K - j;
+    }
+    return 0;
+}
+__host__ __device__ inline int split_lds_blocks(int K) {
+    const int a = split_count(K, 0), b = split_count(K, 1);
+    const int c = (a > b ? a : b) - SPLIT_RR;
+    return c > 0 ? c : 0;
+}
+
+struct SplitResident {
+    Frag<float, LQP_NT> r[SPLIT_RR];
+};
+
+__device__ __forceinline__ int split_next_col(int j, const int K, const int part) {
+    ++j;
+    while (j < K && split_owner(j, K) != part) ++j;
+    return j;
+}
+
+__device__ __forceinline__ void split_resident_load(SplitResident& rr, float* __restrict__ lds_res,
+                                                    const float* __restrict__ Hs, const int K, const int part,
+                                                    const int nloc) {
+#pragma unroll
+    for (int l = 0; l < SPLIT_RR; ++l) {
+        const int g = __builtin_amdgcn_readfirstlane(split_block_index(l < nloc ? l : 0, K, part));
+        rr.r[l] = frag_load<float, LQP_NT>(Hs + (size_t)g * LQP_BLK);
+    }
+    for (int l = SPLIT_RR; l < nloc; ++l) {
+        const int g = __builtin_amdgcn_readfirstlane(split_block_index(l, K, part));
+        frag_store<float, LQP_NT>(lds_res + (size_t)(l - SPLIT_RR) * LQP_BLK, frag_load<float, LQP_NT>(Hs + (size_t)g * LQP_BLK));
+    }
+}
+
+// one block of the split walk: as sym_block, with the column advance over this workgroup's columns and the
+// ylds slot taken from the block's GLOBAL stream index
+__device__ __forceinline__ void split_block(SymWalk<LQP_NT>& wk, const Frag<float, LQP_NT>& blk, const int K, const int Np,
+                                            const int part_id, const float* __restrict__ v, float* __restrict__ ylds,
+                                            float* __restrict__ part) {
+    const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
+    wk.i = __builtin_amdgcn_readfirstlane(wk.i);
+    wk.j = __builtin_amdgcn_readfirstlane(wk.j);
+    wk.s = __builtin_amdgcn_readfirstlane(wk.s);
+    float wi = v[wk.i * 64 + r];
+    asm volatile("" : "+v"(wi));
+    const float s1 = rowgroup_sum<LQP_NT>(dot4(blk.q[0], wk.wj.q[0]));
+    ylds[wk.s * 64 + r] = s1;
+    wk.s = __builtin_amdgcn_readfirstlane(wk.s + 1);
+    if (wk.i != wk.j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wk.acc2[e] += blk.q[0].v[e] * wi;
+    }
+    wk.i = __builtin_amdgcn_readfirstlane(wk.i + 1);
+    if (wk.i == K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = wk.acc2[e];
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1)
+                a += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ off) << 2, __builtin_bit_cast(int, a)));
+            wk.acc2[e] = a;
+        }
+        if (lane < 16) {
+            V4<float> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[e] = wk.acc2[e];
+            *(V4<float>*)(part + (size_t)w * Np + wk.j * 64 + cq * 4) = o;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wk.acc2[e] = 0.f;
+        wk.j = __builtin_amdgcn_readfirstlane(split_next_col(wk.j, K, part_id));
+        wk.i = wk.j;
+        wk.s = __builtin_amdgcn_readfirstlane(sym_idx(wk.j < K ? wk.j : 0, wk.j < K ? wk.j : 0, K));
+        if (wk.j < K) wk.wj.q[0] = *(const V4<float>*)(v + wk.j * 64 + cq * 4);
+    }
+}
+
+// partial product of workgroup `part_id`: every block from registers / LDS
+__device__ __forceinline__ void wg_sym_gemv_split(const SplitResident& rr, const float* __restrict__ lds_res, const int K,
+                                                  const int Np, const int part_id, const int nloc,
+                                                  const float* __restrict__ v, float* __restrict__ ylds,
+                                                  float* __restrict__ part) {
+    SymWalk<LQP_NT> wk;
+    const int j0 = split_owner(0, K) == part_id ? 0 : split_next_col(0, K, part_id);
+    wk.i = j0; wk.j = j0; wk.s = sym_idx(j0, j0, K);
+    wk.wj.q[0] = *(const V4<float>*)(v + j0 * 64 + (threadIdx.x & 15) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wk.acc2[e] = 0.f;
+#pragma unroll
+    for (int l = 0; l < SPLIT_RR; ++l)
+        if (l < nloc) split_block(wk, rr.r[l], K, Np, part_id, v, ylds, part);
+    for (int l = SPLIT_RR; l < nloc; ++l) {
+        const Frag<float, LQP_NT> blk = frag_load<float, LQP_NT>(lds_res + (size_t)(l - SPLIT_RR) * LQP_BLK);
+        split_block(wk, blk, K, Np, part_id, v, ylds, part);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Blocked Cholesky of an SPD matrix held as packed lower blocks, in place (the symmetric backward system):
 //   block (i,k), i > k  <-  L_ik;   block (k,k)  <-  W_k = L_kk^-1   (so the solves below need no substitution
 //   inside a block).  Same machinery as the sweep, restricted to the trailing part: pivot block through

@@ -44,13 +44,17 @@ class SolveBoxQPLayer(torch.autograd.Function):
         has_lb, has_ub = _finite_bounds(lb, ub)
         if not (has_lb or has_ub):
             control['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
-        # the module path never exposes iter/stats, so it does not wait for the GPU: the whole schedule
-        # is enqueued and a singular-KKT error, if any, is raised by a later call (or lqp_py_amd.synchronize())
-        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=(has_lb, has_ub),
-                             sync=bool(control.get('sync', False)))
+        # Default (control['sync'] absent or True): the reference's semantics -- the call waits for the solve, a
+        # singular KKT matrix raises HERE (:215), a Q outside the symmetric x-update falls back to LU by itself.
+        # control['sync'] = False (extension, for training loops): the whole schedule is enqueued and the call
+        # returns at once; an error is raised by a later call / lqp_py_amd.synchronize(), and the outputs of a
+        # failed solve are NaN, never plausible numbers.
+        sync = bool(control.get('sync', True))
+        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=(has_lb, has_ub), sync=sync,
+                             check_hook=control.get('_check_hook'))
         ctx.rho = sol['rho']
         ctx.linsolve = int(sol['_stats']['linsolve_used'])     # 2: Q was checked symmetric by the forward
-        ctx.sync = bool(control.get('sync', False))
+        ctx.sync = sync
         ctx.backward_method = control.get('backward', 'fixed_point')
         ctx.save_for_backward(sol['x'], sol['u'], sol['lams'], sol['nus'], Q, A, lb, ub)
         return sol['x']
@@ -233,7 +237,21 @@ def _bad(msg):
     raise ValueError("lqp_py_amd: " + msg)
 
 
-def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False):
+def _beta_argument(beta, B, like):
+    """-> (mode, scalar value, device tensor or None): 0 quantile rule, 1 scalar, 2 one value per problem
+    (the reference broadcasts a (B,1) tensor against D (B,n), :171-175)"""
+    if beta is None:
+        return 0, 0.0, None
+    if not torch.is_tensor(beta):
+        return 1, float(beta), None
+    if beta.numel() == 1:
+        return 1, float(beta), None
+    if beta.numel() != B:
+        _bad("a beta tensor must hold one value per problem, e.g. shape (B,1)")
+    return 2, 0.0, beta.detach().to(device=like.device, dtype=like.dtype).reshape(B).contiguous()
+
+
+def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None):
     _lib.require_gpu(Q, p, A, b, lb, ub)
     lib = _lib.load()
     _lib.poll_errors()
@@ -246,11 +264,12 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     rho = r['rho']
     if not (has_lb or has_ub):
         rho = 0                                     # one iteration solves it (:157-158)
-    if r['beta'] is not None and torch.is_tensor(r['beta']) and r['beta'].numel() != 1:
-        _bad("per-problem beta tensors are not supported; pass a float or None")
-
     Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
     rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, p)
+    beta_mode, beta_value, beta_tensor = _beta_argument(r['beta'], B, p)
+    hook_c = None
+    if check_hook is not None:
+        sync = True                                   # the strict global stop is host-driven (one launch per check)
 
     if r['linsolve'] not in _LINSOLVE:
         _bad("control['linsolve'] must be 'auto', 'lu' or 'spd'")
@@ -260,12 +279,12 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
         adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),
         any_lb=int(has_lb), any_ub=int(has_ub), rho_mode=rho_mode,
-        beta_mode=0 if r['beta'] is None else 1, launch_mode=int(r['launch_mode']), reserved=0 if sync else 1,
+        beta_mode=beta_mode, launch_mode=int(r['launch_mode']), reserved=0 if sync else 1,
         eps_abs=float(r['eps_abs']), eps_rel=float(r['eps_rel']), rho_value=rho_value,
         rho_min=float(r['rho_min']), rho_max=float(r['rho_max']),
         adaptive_rho_tol=float(r['adaptive_rho_tol']),
         adaptive_rho_threshold=float(r['adaptive_rho_threshold']),
-        beta_value=0.0 if r['beta'] is None else float(r['beta']))
+        beta_value=beta_value, beta_in=None if beta_tensor is None else beta_tensor.data_ptr())
     stats = _lib.BoxQPStats()
 
     x = torch.empty((B, n, 1), dtype=p.dtype, device=dev)
@@ -276,12 +295,29 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     rho_out = torch.empty((B,), dtype=p.dtype, device=dev)
     nbytes = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
     ws = _lib.workspace(dev, nbytes, "fwd")
+    if check_hook is not None:
+        # check_hook(counters) all-reduces the three uint32 counters of a check in place; it gets a tensor VIEW of
+        # the workspace at the device address the library names
+        hook_error = []
+
+        def _c_hook(_user, _stream, counters_ptr, check_index):
+            try:
+                off = int(counters_ptr) - ws.data_ptr()
+                check_hook(ws[off:off + 12].view(torch.int32), int(check_index))
+                return 0
+            except Exception as exc:                  # never let an exception cross the C frame
+                hook_error.append(exc)
+                return 1
+        hook_c = _lib.CHECK_HOOK(_c_hook)
+        ctl.check_hook = hook_c
     with torch.cuda.device(dev):
         st = lib.lqp_boxqp_forward(_lib.stream_ptr(dev), dt, B, n, m,
                                    _lib.ptr(Qc), _lib.ptr(pc), _lib.ptr(Ac), _lib.ptr(bc), _lib.ptr(lbc), _lib.ptr(ubc),
                                    ctypes.byref(ctl), _lib.ptr(rho_tensor),
                                    _lib.ptr(x), _lib.ptr(z), _lib.ptr(u), _lib.ptr(lams), _lib.ptr(nus), _lib.ptr(rho_out),
                                    ctypes.byref(stats), _lib.ptr(ws), ws.numel())
+    if check_hook is not None and hook_error:
+        raise hook_error[0]
     if st == 3:
         # the reference's torch.linalg.lu_factor raises on an exactly singular KKT matrix (:215)
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "

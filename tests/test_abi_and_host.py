@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/lqp_amd.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
-    assert _lib.load().lqp_abi_version() == 3
+    assert _lib.load().lqp_abi_version() == 4
 
 
 def test_workspace_queries_and_argument_checks_without_gpu():
