@@ -390,15 +390,22 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     const int max_checks_per_launch = kRing / 4;
     // two workgroups per QP for the first (hot) launch: symmetric path, persistent mode, 2 B workgroups resident
     bool loop_split = false;
-    int split_lds = 0;
+    int split_lds = 0, split_nt = 512;
+    void (*split_fn)(const FwdParams<float>, const int, const int, const int) = nullptr;
     if constexpr (sizeof(T) == 4) {
-        if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && env_int("LQP_LOOP_SPLIT", 1) != 0) {
-            split_lds = sym_loop_lds_bytes(n, m, P.Ks, split_lds_blocks(P.Ks));
+        if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && check >= 4 && env_int("LQP_LOOP_SPLIT", 1) != 0) {
+            // 512 threads x 256 VGPRs: every block of the workgroup's half lives in registers.  (The 1024-thread
+            // build -- 12 blocks in 128 VGPRs, 6 in LDS, 16 waves -- spills ~60 VGPRs into the hot loop and measured
+            // 0.38 ms against 0.28 ms at B = 128, n = 500; the template still takes NT = 1024.)
+            split_nt = 512;
+            split_lds = split_loop_lds_bytes<512>(P.Ks, m);
             int dev = 0, cus = 0, per_cu = 0;
             HIP_OK(hipGetDevice(&dev));
             HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            if (split_lds <= 160 * 1024 && ensure_lds((const void*)k_admm_loop_split, split_lds) == LQP_OK &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_admm_loop_split, LQP_NT, split_lds) == hipSuccess)
+            split_fn = P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
+                     : P.Ks == 7 ? k_admm_loop_split<7, 512> : (g_lu_dbg ? k_admm_loop_split<8, 512, true> : k_admm_loop_split<8, 512>);
+            if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, split_fn, split_nt, split_lds) == hipSuccess)
                 loop_split = per_cu >= 1 && 2 * B <= cus * per_cu;
         }
     }
@@ -407,7 +414,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         ProfScope ps(st, PC_LOOP);
         if constexpr (sizeof(T) == 4) {
             if (loop_split && it == 0) {
-                hipLaunchKernelGGL(k_admm_loop_split, dim3(2 * B), dim3(LQP_NT), split_lds, st, P, it, e, ctr_base);
+                hipLaunchKernelGGL(split_fn, dim3(2 * B), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
                 return;
             }
         }

@@ -1,6 +1,7 @@
 // Kernels of the box-QP ADMM layer (forward setup / loop / epilogue, adaptive
 // rho, fixed-point backward, KKT solve).  One 1024-thread workgroup per QP.
 #pragma once
+#include <type_traits>
 #include "lqp_common.cuh"
 #include "lqp_lu.cuh"
 #include "lqp_trsv.cuh"
@@ -11,8 +12,9 @@ namespace lqp {
 // ---- device-side status block (ints) ---------------------------------------
 enum { ST_DONE = 0, ST_FINAL_ITER = 1, ST_GATE = 2, ST_NFACTOR = 3, ST_RHO_UPDATED = 4,
        ST_TIMEOUT = 5, ST_NCHECK = 6, ST_NOTSPD = 7, ST_WORDS = 16 };
-// per-check counters (uint32 x 4): not-optimal, wants-rho, ratio-trigger, arrivals
-enum { CT_NOTOPT = 0, CT_WANTS = 1, CT_TRIG = 2, CT_ARRIVE = 3, CT_WORDS = 4 };
+// per-check counters (uint32 x 4): not-optimal, arrivals, wants-rho, ratio-trigger
+// (NOTOPT and ARRIVE share one aligned 64-bit word: the two-workgroup loop adds to and reads both with ONE atomic)
+enum { CT_NOTOPT = 0, CT_ARRIVE = 1, CT_WANTS = 2, CT_TRIG = 3, CT_WORDS = 4 };
 // per-problem scalars
 enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_PRI = 4, SC_DUA = 5, SC_WORDS = 8 };   // PRI/DUA: errors of the last check
 
@@ -1042,45 +1044,64 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
 // and b + B hold one half of the blocks of H each, ALL of them on chip for the whole launch (lqp_spd.cuh,
 // wg_sym_gemv_split), and exchange their partial products every iteration:
 //   thread e < Nps combines its element of this workgroup's partial, publishes it as ONE 8-byte granule
-//   {tag = iteration + 1, value} (agent-scope relaxed atomic store = sc1 write-through store), polls the partner's
-//   granule of the same element (sc1 loads, L1 bypassed) until the tag matches, and adds the two partials in the
-//   fixed order part 0 + part 1 -- both workgroups then hold bit-identical iterates and run the element-wise
-//   update, the checks and the stop decision redundantly (part 0 alone reports to the counters / writes state).
+//   {tag, value} (agent-scope relaxed atomic store = sc1 write-through store), polls the partner's granule of the
+//   same element (sc1 loads, L1 bypassed) until the tag matches, and adds the two partials in the fixed order
+//   part 0 + part 1 -- both workgroups then hold bit-identical iterates and run the element-wise update and the
+//   checks redundantly (part 0 alone reports to the counters / writes state).
 // Two granule buffers alternate by iteration parity: a workgroup can be at most one exchange ahead of its
 // partner, so a granule is never overwritten before it was read.  The area is zeroed by k_fwd_setup of the same
-// forward (tags start at 1).  Spins are bounded (0.5 s): a timeout sets ST_TIMEOUT and the kernel still drains.
-// LDS: as the symmetric loop with rl = split_lds_blocks(Ks).
+// forward (tags start at 1).  Spins are bounded: a timeout sets ST_TIMEOUT and the kernel still drains.
+//
+// The global stop (torch.all(is_optimal), :312) does not block the loop.  At a check, part 0 adds {not optimal?,
+// arrival} to the check's counter word with ONE 64-bit atomic, both workgroups keep a snapshot of the iterate and go
+// on iterating; in the following iterations part 0 reads the counter word while its product runs (the load's latency
+// is hidden), and once all B arrivals are in, the verdict travels to the partner in the top bits of that iteration's
+// granule tags.  "All optimal" -> both restore the snapshot, part 0 stores it and the kernel exits with the
+// reference's iteration count (the 1-3 speculative iterations are dropped); otherwise the snapshot is forgotten.
+// A verdict still open at the next check or at the last iteration of the launch is waited for (bounded spin).
+//
+// LDS (floats; every offset but the last three arrays is a compile-time constant):
+//   [rl blocks] v yrow cvl part[NW][Nps] z u ps lb ub D xs sz su sx (Nps each) red[NW*8+8] flags[8] | bs nus snu (m each)
 // ---------------------------------------------------------------------------
 constexpr int XCHG_WORDS = 2 * 2 * SPD_MAXK * LQP_NB;       // granules per QP: [parity][part][element]
+template <int NT> __host__ __device__ constexpr int split_loop_lds_floats(int Ks) {
+    return split_lds_blocks<NT>(Ks) * LQP_BLK + (3 + NT / 64 + 10) * Ks * LQP_NB + (NT / 64) * 8 + 8 + 8;
+}
+template <int NT> __host__ __device__ inline int split_loop_lds_bytes(int Ks, int m) {
+    return (split_loop_lds_floats<NT>(Ks) + 3 * m + 8) * 4;
+}
 
-__global__ __launch_bounds__(LQP_NT) void k_admm_loop_split(const FwdParams<float> P, const int it0, const int it1,
-                                                            const int ctr_base) {
+template <int KS, int NT, bool DBG = false>
+__global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P, const int it0, const int it1,
+                                                        const int ctr_base) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     typedef float T;
-    constexpr int NT = LQP_NT;
+    constexpr int NWV = NT / 64, Ks = KS, Nps = KS * LQP_NB, rl = split_lds_blocks<NT>(KS);
     const int b = blockIdx.x % P.B, part_id = blockIdx.x / P.B;
-    const int n = P.n, m = P.m, Ks = P.Ks;
+    const int n = P.n, m = P.m;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     if (it0 >= it1) return;
-    const int Nps = Ks * LQP_NB;
-    const int rl = split_lds_blocks(Ks);
-    const int nloc = split_count(Ks, part_id);
-    T* lds_res = (T*)smem;
-    T* v = lds_res + (size_t)rl * LQP_BLK;
-    T* xs = v + Nps;
-    T* ylds = xs + Nps;
-    T* cvl = ylds + sym_blocks(Ks) * 64;
-    T* part = cvl + Nps;
-    T* z = part + (size_t)(NT / 64) * Nps;
-    T* u = z + n;
-    T* ps = u + n;
-    T* lb = ps + n;
-    T* ub = lb + n;
-    T* D = ub + n;
-    T* bs = D + n;
-    T* red = bs + 2 * m;
-    int* dead = (int*)(red + (NT / 64) * 8 + 4);            // sticky exchange-timeout flag of this workgroup
+    T* const lds_res = (T*)smem;
+    T* const v = lds_res + (size_t)rl * LQP_BLK;
+    T* const yrow = v + Nps;
+    T* const cvl = yrow + Nps;
+    T* const part = cvl + Nps;
+    T* const z = part + (size_t)NWV * Nps;
+    T* const u = z + Nps;
+    T* const ps = u + Nps;
+    T* const lb = ps + Nps;
+    T* const ub = lb + Nps;
+    T* const D = ub + Nps;
+    T* const xs = D + Nps;
+    T* const sz = xs + Nps;                                  // snapshot of (z, u, x) at the last check
+    T* const su = sz + Nps;
+    T* const sx = su + Nps;
+    T* const red = sx + Nps;
+    int* const flags = (int*)(red + NWV * 8 + 8);             // [0] exchange timed out (sticky), [1] verdict of this iteration
+    T* const bs = (T*)(flags + 8);
+    T* const nus_l = bs + m;
+    T* const snu = nus_l + m;
 
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
@@ -1089,144 +1110,253 @@ __global__ __launch_bounds__(LQP_NT) void k_admm_loop_split(const FwdParams<floa
     const T rho = scal[SC_RHO];
     const T pnorm = scal[SC_PNORM];
 
-    SplitResident rr;
-    split_resident_load(rr, lds_res, packed, Ks, part_id, nloc);
-    for (int i = tid; i < n; i += NT) {
-        z[i] = V.z[i]; u[i] = V.u[i]; ps[i] = V.ps[i]; lb[i] = V.lbs[i]; ub[i] = V.ubs[i]; D[i] = V.D[i];
+    SplitResident<NT> rr;
+    if (part_id == 0) split_resident_load<KS, 0, NT>(rr, lds_res, packed);
+    else split_resident_load<KS, 1, NT>(rr, lds_res, packed);
+    for (int i = tid; i < Nps; i += NT) {
+        const bool in = i < n;
+        z[i] = in ? V.z[i] : T(0); u[i] = in ? V.u[i] : T(0); ps[i] = in ? V.ps[i] : T(0);
+        lb[i] = in ? V.lbs[i] : T(0); ub[i] = in ? V.ubs[i] : T(0); D[i] = in ? V.D[i] : T(1);
+        cvl[i] = (in && m > 0) ? V.cv[i] : T(0);
+        yrow[i] = T(0);                                       // rows / columns of the partner stay zero
     }
     for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
-    for (int i = tid; i < Nps; i += NT) cvl[i] = (i < n && m > 0) ? V.cv[i] : T(0);
-    for (int i = tid; i < sym_blocks(Ks) * 64; i += NT) ylds[i] = T(0);       // slots / columns of the partner stay zero
-    for (int i = tid; i < (NT / 64) * Nps; i += NT) part[i] = T(0);
-    if (tid == 0) dead[0] = 0;
+    for (int i = tid; i < NWV * Nps; i += NT) part[i] = T(0);
+    if (tid < 8) flags[tid] = 0;
     __syncthreads();
     for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
     wg_barrier_lds();
 
     int slot = ctr_base;
-    T* nus_l = bs + m;
-    for (int it = it0; it < it1; ++it) {
-        const bool check = (it % P.check_solved) == 0;
-        T mx[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) mx[q] = T(0);
-        wg_sym_gemv_split(rr, lds_res, Ks, Nps, part_id, nloc, v, ylds, part);
-        wg_barrier_lds();
-        if ((check || it + 1 == it1) && m > 0) {             // nu = T^T w - s0 while v is still w
-            for (int r = w; r < m; r += (NT / 64)) {
-                T acc = T(0);
-                for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
-                acc = wave_sum(acc);
-                if (lane == 0) nus_l[r] = acc - V.s0[r];
+    bool pending = false;                                     // a check's verdict is still open (uniform)
+    int pend_it = 0;
+    const unsigned long long* pend_word = nullptr;
+    unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;  // debug: cycles of wave 0 (part 0) per phase
+    const bool dbg_on = DBG && P.dbg != nullptr && part_id == 0;
+    // 64-bit word {low: problems not optimal, high: arrivals} of a check -> 0 unknown, 1 all optimal, 2 go on
+    auto verdict_of = [&](const unsigned long long cw) -> int {
+        if ((unsigned int)(cw >> 32) < (unsigned int)P.B) return 0;
+        return (unsigned int)cw == 0u ? 1 : 2;
+    };
+    auto wait_verdict = [&]() -> int {                        // (one thread) bounded spin, 2 s
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const int vd = verdict_of(__hip_atomic_load(pend_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (vd) return vd;
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {
+                __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 1;
             }
-            wg_barrier_lds();
         }
+    };
+    auto leave_with_snapshot = [&]() {                        // every problem was optimal at iteration pend_it
+        if (blockIdx.x == 0 && tid == 0) {
+            P.status[ST_FINAL_ITER] = pend_it;
+            __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (part_id == 0) {
+            for (int i = tid; i < n; i += NT) { V.z[i] = sz[i]; V.u[i] = su[i]; V.x[i] = sx[i]; }
+            for (int r = tid; r < m; r += NT) V.nu[r] = snu[r];
+        }
+    };
+
+    // One iteration.  COLD = std::true_type: a check iteration or the last one of the launch (nu, the six norms, the
+    // counters, the snapshot, a blocking wait for an open verdict); std::false_type: everything else -- the hot
+    // variant carries none of that code, and the hot iterations run in an inner loop of their own below, so the
+    // register allocator keeps the resident blocks (and everything else the product needs) out of scratch there.
+    // Returns 1 when the workgroup is done (all problems were optimal at the last check).
+    auto iterate = [&](auto cold_tag, const int it, const bool check) -> int {
+        constexpr bool COLD = decltype(cold_tag)::value;
+        if (dbg_on) dt0 = clock64();
+        // ---- part 0: look at the open verdict while the product runs ----
+        unsigned long long cw = 0;
+        const bool look = pending && part_id == 0 && tid == 0;
+        if (look) cw = __hip_atomic_load(pend_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (part_id == 0) wg_sym_gemv_split<KS, 0, NT>(rr, lds_res, Nps, v, yrow, part);
+        else wg_sym_gemv_split<KS, 1, NT>(rr, lds_res, Nps, v, yrow, part);
+        if (look) {
+            int vd = verdict_of(cw);
+            if constexpr (COLD) { if (vd == 0) vd = wait_verdict(); }
+            flags[1] = vd;
+        }
+        wg_barrier_lds();
+        if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
+        int verdict = (pending && part_id == 0) ? flags[1] : 0;
+        if constexpr (COLD) {
+            if (m > 0) {                                      // nu = T^T w - s0 while v is still w
+                for (int r = w; r < m; r += NWV) {
+                    T acc = T(0);
+                    for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
+                    acc = wave_sum(acc);
+                    if (lane == 0) nus_l[r] = acc - V.s0[r];
+                }
+                wg_barrier_lds();
+            }
+        }
+        T xi = T(0);
         if (tid < Nps) {
             const int i = tid;
-            const T own = sym_combine<NT>(i, Ks, Nps, ylds, part);
-            // ---- exchange: publish this element's partial, fetch the partner's ----
+            const T own = split_combine<NT>(i, Nps, yrow, part);
+            // ---- exchange: publish this element's partial (part 0: with the verdict), fetch the partner's ----
             const unsigned int tag = (unsigned int)(it + 1);
             unsigned long long* base = xq + (size_t)(it & 1) * (2 * SPD_MAXK * LQP_NB);
             __hip_atomic_store(base + (size_t)part_id * (SPD_MAXK * LQP_NB) + i,
-                               ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, own),
+                               ((unsigned long long)(tag | ((unsigned int)verdict << 30)) << 32) |
+                                   (unsigned long long)__builtin_bit_cast(unsigned int, own),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long* src = base + (size_t)(1 - part_id) * (SPD_MAXK * LQP_NB) + i;
             unsigned long long g = 0;
-            if (!dead[0]) {
+            if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
+            if (!(verdict == 1 && part_id == 0) && !flags[0]) {      // (part 0 leaving: nothing to fetch)
                 unsigned int spins = 0;
                 unsigned long long t0 = 0;
                 for (;;) {
                     g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned int)(g >> 32) == tag) break;
+                    if (((unsigned int)(g >> 32) & 0x3FFFFFFFu) == tag) break;
                     if ((++spins & 1023u) == 0) {
                         const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
                         if (t0 == 0) t0 = now;
                         else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up
                             __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            dead[0] = 1;
+                            flags[0] = 1;
                             break;
                         }
                     }
                 }
             }
+            if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
+            if (part_id == 1 && pending) {
+                verdict = (int)((unsigned int)(g >> 62));
+                if (tid == 0) flags[1] = verdict;
+            }
             const T other = __builtin_bit_cast(float, (unsigned int)g);
             const T y = part_id == 0 ? own + other : other + own;      // same order on both workgroups
-            const T xi = cvl[i] - y;
-            xs[i] = xi;
-            T wn = T(0);
-            if (i < n) {
-                const T zp = z[i];
-                const T ui = u[i];
-                T zn = xi + ui;
-                if (P.any_lb) zn = tmax(zn, lb[i]);
-                if (P.any_ub) zn = tmin(zn, ub[i]);
-                const T r = xi - zn;
-                const T s = rho * (zn - zp);
-                const T un = ui + r;
-                z[i] = zn;
-                u[i] = un;
-                if (check) {
-                    const T di = D[i];
-                    mx[0] = tmax(mx[0], tabs(di * r));
-                    mx[1] = tmax(mx[1], tabs(di * s));
-                    mx[2] = tmax(mx[2], tabs(di * xi));
-                    mx[3] = tmax(mx[3], tabs(di * zn));
-                    mx[4] = tmax(mx[4], tabs((rho * di) * un));
-                    T qx = v[i] - rho * xi;
-                    for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nus_l[q];
-                    mx[5] = tmax(mx[5], tabs(qx / di));
-                }
-                wn = -ps[i] + rho * (zn - un);
-            }
-            v[i] = wn;
+            xi = cvl[i] - y;
         }
-        if (check) {
-            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], mx[5]};
-            wg_max_n<T, 6, NT / 64>(mv, red);
-            const T tiny = T(1e-16);
-            const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
-            const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
-            const T dua_scale = tmax(tmax(tmax(mv[4], mv[5]), pnorm), tiny);
-            const T tol_d = P.eps_abs + P.eps_rel * dua_scale;
-            const bool solved = (mv[0] < tol_p) && (mv[1] < tol_d);
-            const bool wants = (mv[0] > tmax(tol_p, P.ar_thr)) || (mv[1] > tmax(tol_d, P.ar_thr));
-            const T num = tmax(mv[0] / pri_scale, tiny);
-            const T den = tmax(mv[1] / dua_scale, tiny);
-            const T ratio = tsqrt(num / den);
-            const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
-            unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
-            if (tid == 0) {
-                if (part_id == 0) {                          // (the partner computed the very same numbers)
+        if (pending) {
+            // the verdict is uniform over both workgroups: part 0 read it before the exchange, part 1 found it in the tags
+            if (part_id == 1) { wg_barrier_lds(); verdict = flags[1]; }
+            if (verdict == 1) return 1;
+            if (verdict == 2) pending = false;
+        }
+        T mx[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) mx[q] = T(0);
+        if (tid < Nps) {
+            const int i = tid;
+            xs[i] = xi;
+            const T zp = z[i];
+            const T ui = u[i];
+            T zn = xi + ui;
+            if (P.any_lb) zn = tmax(zn, lb[i]);
+            if (P.any_ub) zn = tmin(zn, ub[i]);
+            const T r = xi - zn;
+            const T s = rho * (zn - zp);
+            const T un = ui + r;
+            const bool in = i < n;
+            if (in) { z[i] = zn; u[i] = un; }
+            if constexpr (COLD) {
+                if (check) {
+                    sz[i] = zn; su[i] = un; sx[i] = xi;      // snapshot for a late "all optimal"
+                    if (in) {
+                        const T di = D[i];
+                        mx[0] = tabs(di * r);
+                        mx[1] = tabs(di * s);
+                        mx[2] = tabs(di * xi);
+                        mx[3] = tabs(di * zn);
+                        mx[4] = tabs((rho * di) * un);
+                        T qx = v[i] - rho * xi;
+                        for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nus_l[q];
+                        mx[5] = tabs(qx / di);
+                    }
+                }
+            }
+            v[i] = in ? -ps[i] + rho * (zn - un) : T(0);     // next iteration's right-hand side
+        }
+        if (dbg_on) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
+        if constexpr (COLD) {
+            if (check) {
+                for (int r = tid; r < m; r += NT) snu[r] = nus_l[r];
+                // six inf-norms: per wave by DPP, then ONE thread folds the 16 wave results
+#pragma unroll
+                for (int q = 0; q < 6; ++q) mx[q] = wave_max(mx[q]);
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) red[w * 8 + q] = mx[q];
+                }
+                __syncthreads();
+                if (part_id == 0 && tid == 0) {               // (the partner computed the very same numbers)
+                    T mv[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) mv[q] = red[q];
+#pragma unroll 1
+                    for (int ww = 1; ww < NWV; ++ww) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) mv[q] = tmax(mv[q], red[ww * 8 + q]);
+                    }
+                    const T tiny = T(1e-16);
+                    const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
+                    const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
+                    const T dua_scale = tmax(tmax(tmax(mv[4], mv[5]), pnorm), tiny);
+                    const T tol_d = P.eps_abs + P.eps_rel * dua_scale;
+                    const bool solved = (mv[0] < tol_p) && (mv[1] < tol_d);
+                    const bool wants = (mv[0] > tmax(tol_p, P.ar_thr)) || (mv[1] > tmax(tol_d, P.ar_thr));
+                    const T num = tmax(mv[0] / pri_scale, tiny);
+                    const T den = tmax(mv[1] / dua_scale, tiny);
+                    const T ratio = tsqrt(num / den);
+                    const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
+                    unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
                     scal[SC_RATIO] = ratio;
                     scal[SC_WANTS] = wants ? T(1) : T(0);
                     scal[SC_PRI] = mv[0];
                     scal[SC_DUA] = mv[1];
-                    if (!solved) atomicAdd(ct + CT_NOTOPT, 1u);
                     if (wants) atomicAdd(ct + CT_WANTS, 1u);
                     if (trig) atomicAdd(ct + CT_TRIG, 1u);
+                    atomicAdd((unsigned long long*)ct, (1ull << 32) | (solved ? 0ull : 1ull));   // {not optimal, arrival}
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(ct + CT_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ++slot;
-            grid_wait(ct + CT_ARRIVE, gridDim.x, P.status);
-            const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (notopt == 0 || tmo) {
-                if (blockIdx.x == 0 && tid == 0) {
-                    P.status[ST_FINAL_ITER] = it;
-                    __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                if (part_id == 0) {
-                    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }
-                    for (int r = tid; r < m; r += NT) V.nu[r] = nus_l[r];
-                }
-                return;
+                pend_word = (const unsigned long long*)(P.counters + (size_t)slot * CT_WORDS);
+                pend_it = it;
+                pending = true;
+                ++slot;
             }
         }
+        if (dbg_on) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
         wg_barrier_lds();
+        if (dbg_on) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
+        return 0;
+    };
+
+    int left = 0;
+    for (int it = it0; it < it1 && !left;) {
+        const bool check = (it % P.check_solved) == 0;
+        if (check || it + 1 == it1) {
+            left = iterate(std::true_type(), it, check);
+            ++it;
+        } else {
+            int e = (it / P.check_solved + 1) * P.check_solved;      // next special iteration: a check or the last one
+            if (e > it1 - 1) e = it1 - 1;
+#pragma unroll 1
+            for (; it < e; ++it) {
+                left = iterate(std::false_type(), it, false);
+                if (left) break;
+            }
+        }
+    }
+    if (left) {
+        leave_with_snapshot();
+        if (dbg_on && tid == 0)
+            for (int q = 0; q < 6; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
+        return;
+    }
+    if (dbg_on && tid == 0)
+        for (int q = 0; q < 6; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
+    // ---- end of the launch: a verdict still open is for the state we hold (the check ran in the last iteration) ----
+    if (pending && blockIdx.x == 0 && tid == 0) {
+        if (wait_verdict() == 1 && !__hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            P.status[ST_FINAL_ITER] = pend_it;
+            __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (part_id == 0) {
         for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }

@@ -679,7 +679,9 @@ __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, NT>& st, const Re
 // part[w][.]; slots / columns of the other workgroup stay zero) and the two partial vectors are exchanged through
 // global memory by the caller (k_admm_loop_split).
 // ---------------------------------------------------------------------------
-constexpr int SPLIT_RR = 12;        // register-resident blocks per workgroup
+// register-resident blocks per workgroup: 1024 threads (128 VGPRs each, 4 per block) keep 12 and the rest in LDS;
+// 512 threads (256 VGPRs each, 8 per block) keep all 18
+template <int NT> __host__ __device__ constexpr int split_rr() { return NT == 512 ? 18 : 12; }
 constexpr int SPLIT_MINK = 5;       // below that one workgroup holds the whole matrix in registers anyway
 __host__ __device__ constexpr int split_owner(int j, int K) { return (j < K - 1 - j ? j : K - 1 - j) & 1; }
 __host__ __device__ constexpr int split_count(int K, int part) {
@@ -687,106 +689,140 @@ __host__ __device__ constexpr int split_count(int K, int part) {
     for (int j = 0; j < K; ++j) if (split_owner(j, K) == part) c += K - j;
     return c;
 }
-// stream index (in the packed lower triangle) of the `l`-th block of workgroup `part`, columns ascending
-__host__ __device__ inline int split_block_index(int l, int K, int part) {
-    for (int j = 0; j < K; ++j) {
-        if (split_owner(j, K) != part) continue;
-        if (l < K - j) return sym_idx(j + l, j, K);
-        l -= K - j;
-    }
-    return 0;
-}
-__host__ __device__ inline int split_lds_blocks(int K) {
+template <int NT> __host__ __device__ constexpr int split_lds_blocks(int K) {
     const int a = split_count(K, 0), b = split_count(K, 1);
-    const int c = (a > b ? a : b) - SPLIT_RR;
+    const int c = (a > b ? a : b) - split_rr<NT>();
     return c > 0 ? c : 0;
 }
 
-struct SplitResident {
-    Frag<float, LQP_NT> r[SPLIT_RR];
+template <int NT> struct SplitResident {
+    Frag<float, NT> r[split_rr<NT>()];
 };
 
-__device__ __forceinline__ int split_next_col(int j, const int K, const int part) {
-    ++j;
-    while (j < K && split_owner(j, K) != part) ++j;
-    return j;
-}
-
-__device__ __forceinline__ void split_resident_load(SplitResident& rr, float* __restrict__ lds_res,
-                                                    const float* __restrict__ Hs, const int K, const int part,
-                                                    const int nloc) {
-#pragma unroll
-    for (int l = 0; l < SPLIT_RR; ++l) {
-        const int g = __builtin_amdgcn_readfirstlane(split_block_index(l < nloc ? l : 0, K, part));
-        rr.r[l] = frag_load<float, LQP_NT>(Hs + (size_t)g * LQP_BLK);
-    }
-    for (int l = SPLIT_RR; l < nloc; ++l) {
-        const int g = __builtin_amdgcn_readfirstlane(split_block_index(l, K, part));
-        frag_store<float, LQP_NT>(lds_res + (size_t)(l - SPLIT_RR) * LQP_BLK, frag_load<float, LQP_NT>(Hs + (size_t)g * LQP_BLK));
-    }
-}
-
-// one block of the split walk: as sym_block, with the column advance over this workgroup's columns and the
-// ylds slot taken from the block's GLOBAL stream index
-__device__ __forceinline__ void split_block(SymWalk<LQP_NT>& wk, const Frag<float, LQP_NT>& blk, const int K, const int Np,
-                                            const int part_id, const float* __restrict__ v, float* __restrict__ ylds,
-                                            float* __restrict__ part) {
-    const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
-    wk.i = __builtin_amdgcn_readfirstlane(wk.i);
-    wk.j = __builtin_amdgcn_readfirstlane(wk.j);
-    wk.s = __builtin_amdgcn_readfirstlane(wk.s);
-    float wi = v[wk.i * 64 + r];
-    asm volatile("" : "+v"(wi));
-    const float s1 = rowgroup_sum<LQP_NT>(dot4(blk.q[0], wk.wj.q[0]));
-    ylds[wk.s * 64 + r] = s1;
-    wk.s = __builtin_amdgcn_readfirstlane(wk.s + 1);
-    if (wk.i != wk.j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wk.acc2[e] += blk.q[0].v[e] * wi;
-    }
-    wk.i = __builtin_amdgcn_readfirstlane(wk.i + 1);
-    if (wk.i == K) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float a = wk.acc2[e];
-#pragma unroll
-            for (int off = 16; off < 64; off <<= 1)
-                a += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ off) << 2, __builtin_bit_cast(int, a)));
-            wk.acc2[e] = a;
+// compile-time map of workgroup PART's share of a K-block matrix: local block l <-> (i, j), columns ascending
+template <int K, int PART> struct SplitMap {
+    static constexpr int count() { return split_count(K, PART); }
+    static constexpr int col_of(int l) {
+        for (int j = 0; j < K; ++j) {
+            if (split_owner(j, K) != PART) continue;
+            if (l < K - j) return j;
+            l -= K - j;
         }
-        if (lane < 16) {
-            V4<float> o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o.v[e] = wk.acc2[e];
-            *(V4<float>*)(part + (size_t)w * Np + wk.j * 64 + cq * 4) = o;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wk.acc2[e] = 0.f;
-        wk.j = __builtin_amdgcn_readfirstlane(split_next_col(wk.j, K, part_id));
-        wk.i = wk.j;
-        wk.s = __builtin_amdgcn_readfirstlane(sym_idx(wk.j < K ? wk.j : 0, wk.j < K ? wk.j : 0, K));
-        if (wk.j < K) wk.wj.q[0] = *(const V4<float>*)(v + wk.j * 64 + cq * 4);
+        return 0;
     }
+    static constexpr int row_of(int l) {
+        for (int j = 0; j < K; ++j) {
+            if (split_owner(j, K) != PART) continue;
+            if (l < K - j) return j + l;
+            l -= K - j;
+        }
+        return 0;
+    }
+    // local index of block (i, j), j owned
+    static constexpr int local_of(int i, int j) {
+        int l = 0;
+        for (int c = 0; c < j; ++c) if (split_owner(c, K) == PART) l += K - c;
+        return l + (i - j);
+    }
+};
+
+template <int K, int PART, int NT>
+__device__ __forceinline__ void split_resident_load(SplitResident<NT>& rr, float* __restrict__ lds_res, const float* __restrict__ Hs) {
+    typedef SplitMap<K, PART> M;
+    constexpr int nloc = M::count(), RR = split_rr<NT>();
+#pragma unroll
+    for (int l = 0; l < RR; ++l)
+        if (l < nloc) rr.r[l] = frag_load<float, NT>(Hs + (size_t)sym_idx(M::row_of(l), M::col_of(l), K) * LQP_BLK);
+#pragma unroll
+    for (int l = RR; l < nloc; ++l)
+        frag_store<float, NT>(lds_res + (size_t)(l - RR) * LQP_BLK,
+                              frag_load<float, NT>(Hs + (size_t)sym_idx(M::row_of(l), M::col_of(l), K) * LQP_BLK));
 }
 
-// partial product of workgroup `part_id`: every block from registers / LDS
-__device__ __forceinline__ void wg_sym_gemv_split(const SplitResident& rr, const float* __restrict__ lds_res, const int K,
-                                                  const int Np, const int part_id, const int nloc,
-                                                  const float* __restrict__ v, float* __restrict__ ylds,
+// Partial product of workgroup PART, fully static: every block from registers / LDS at compile-time positions.
+// Thread t owns EPT = 4096 / NT consecutive elements of a block: row t / LPR, columns EPT (t % LPR) ..
+//   row product   d_i += B_ij . w_j  accumulated per block ROW over this workgroup's columns, ONE reduction over the
+//                 LPR lanes of a row per block row, result in yrow[64 i + r] (rows that get no contribution are
+//                 never written: stay zero)
+//   column product a_j += B_ij^T w_i accumulated over the block column, folded over the rows the wave holds and
+//                 written to this wave's slice part[w][64 j ..]
+// No walk state, no branches: the compiler interleaves the independent chains.
+template <int K, int PART, int NT>
+__device__ __forceinline__ void wg_sym_gemv_split(const SplitResident<NT>& rr, const float* __restrict__ lds_res, const int Np,
+                                                  const float* __restrict__ v, float* __restrict__ yrow,
                                                   float* __restrict__ part) {
-    SymWalk<LQP_NT> wk;
-    const int j0 = split_owner(0, K) == part_id ? 0 : split_next_col(0, K, part_id);
-    wk.i = j0; wk.j = j0; wk.s = sym_idx(j0, j0, K);
-    wk.wj.q[0] = *(const V4<float>*)(v + j0 * 64 + (threadIdx.x & 15) * 4);
+    typedef SplitMap<K, PART> M;
+    constexpr int EPT = LQP_BLK / NT, LPR = LQP_NB / EPT, NV = EPT / 4, RR = split_rr<NT>();
+    const int tid = threadIdx.x, r = tid / LPR, cq = tid % LPR, lane = tid & 63, w = tid >> 6;
+    // two-wide arithmetic (v_pk_fma_f32: two FMAs per instruction and lane): the product is bound by VALU issue
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float wrow[K];
+    f2 d[K];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wk.acc2[e] = 0.f;
+    for (int i = 0; i < K; ++i) { wrow[i] = v[i * 64 + r]; d[i] = f2{0.f, 0.f}; }
 #pragma unroll
-    for (int l = 0; l < SPLIT_RR; ++l)
-        if (l < nloc) split_block(wk, rr.r[l], K, Np, part_id, v, ylds, part);
-    for (int l = SPLIT_RR; l < nloc; ++l) {
-        const Frag<float, LQP_NT> blk = frag_load<float, LQP_NT>(lds_res + (size_t)(l - SPLIT_RR) * LQP_BLK);
-        split_block(wk, blk, K, Np, part_id, v, ylds, part);
+    for (int j = 0; j < K; ++j) {
+        if (split_owner(j, K) != PART) continue;
+        f2 wj[2 * NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const V4<float> t = *(const V4<float>*)(v + j * 64 + cq * EPT + 4 * q);
+            wj[2 * q] = f2{t.v[0], t.v[1]};
+            wj[2 * q + 1] = f2{t.v[2], t.v[3]};
+        }
+        f2 a2[EPT / 2];
+#pragma unroll
+        for (int e = 0; e < EPT / 2; ++e) a2[e] = f2{0.f, 0.f};
+#pragma unroll
+        for (int i = j; i < K; ++i) {
+            const int l = M::local_of(i, j);
+            Frag<float, NT> blk;
+            if (l < RR) blk = rr.r[l < RR ? l : 0];
+            else blk = frag_load<float, NT>(lds_res + (size_t)(l - RR) * LQP_BLK);
+            const f2 wi = f2{wrow[i], wrow[i]};
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const f2 b01 = f2{blk.q[q].v[0], blk.q[q].v[1]}, b23 = f2{blk.q[q].v[2], blk.q[q].v[3]};
+                d[i] = __builtin_elementwise_fma(b01, wj[2 * q], d[i]);
+                d[i] = __builtin_elementwise_fma(b23, wj[2 * q + 1], d[i]);
+                if (i != j) {
+                    a2[2 * q] = __builtin_elementwise_fma(b01, wi, a2[2 * q]);
+                    a2[2 * q + 1] = __builtin_elementwise_fma(b23, wi, a2[2 * q + 1]);
+                }
+            }
+        }
+        float a1[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            float a = a2[e >> 1][e & 1];
+            if constexpr (LPR == 8) a += dpp<0x128>(a);          // row_ror:8 = lane ^ 8 inside a 16-lane DPP row
+            a += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, a)));
+            a += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, a)));
+            a1[e] = a;
+        }
+        if (lane < LPR) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                V4<float> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.v[e] = a1[4 * q + e];
+                *(V4<float>*)(part + (size_t)w * Np + j * 64 + cq * EPT + 4 * q) = o;
+            }
+        }
     }
+    constexpr int first_row = PART == 0 ? 0 : 1;       // the lowest owned column: rows below it get nothing
+#pragma unroll
+    for (int i = first_row; i < K; ++i) yrow[i * 64 + r] = rowgroup_sum<NT>(d[i][0] + d[i][1]);
+}
+
+// y[e] of this workgroup's partial: the block-row sum plus the column partials of the waves
+template <int NT>
+__device__ __forceinline__ float split_combine(const int e, const int Np, const float* __restrict__ yrow,
+                                               const float* __restrict__ part) {
+    float y = yrow[e];
+#pragma unroll
+    for (int ww = 0; ww < NT / 64; ++ww) y += part[(size_t)ww * Np + e];
+    return y;
 }
 
 // ---------------------------------------------------------------------------
