@@ -5,57 +5,80 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted
 on): batch=128 per GPU, dz=500, one equality constraint (A = ones), random
 box bounds, fp32, eps_abs = eps_rel = 1e-5, default box_qp_control
 (scale=True, adaptive_rho=True, rho=None); synthetic inputs drawn exactly like
-experiments/utils.py:41-61 of the reference, resident in HBM before timing.
-One step = SolveBoxQP forward + x.backward(ones) (experiments/experiment_1.py:
-69-78) on one batch, plus -- for N > 1 -- the single all-gather of x.
+experiments/utils.py:41-61 of the reference with seeds 0..9 (one batch per
+seed, experiments/experiment_1.py:53-58), resident in HBM before timing.
+One step = SolveBoxQP forward + x.backward(ones) (experiment_1.py:69-78) on
+one batch, plus -- for N > 1 -- the single all-gather of x.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.
+With N > 1 and no torchrun environment this process touches no GPU: it starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+as a child (one rank per GPU over RCCL) and exits with its code.  Rank 0
+prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 B_PER_GPU, N_X, N_EQ = 128, 500, 1
 TOL = 1e-5
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+N_SEEDS = 10                  # experiment_1.py: n_sims = 10, seed = simulation index
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+INFINITY_CACHE_BYTES = 256 * 2 ** 20
+TRAFFIC_FILE = "profiles/r02_traffic.json"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="QPs per GPU")
     ap.add_argument("--n", type=int, default=N_X)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--linsolve", choices=["auto", "lu", "spd"], default="auto",
                     help="x-update of the forward solve (control['linsolve']); lu = the reference's cached pivoted LU")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the forward-only extras (configs 2 and 4)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extras (configs 2 and 4, LU step, sync step)")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--sync", action="store_true", help="layer calls wait for the GPU (reference-style error timing)")
+    ap.add_argument("--sync", action="store_true",
+                    help="time the layer with its default control (calls wait for the GPU and raise at the call, like the "
+                         "reference); default here: control['sync']=False, the pipelined training-loop mode")
     return ap.parse_args()
 
 
-def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True):
+# ---------------------------------------------------------------------------------------------------
+# N > 1 without a torchrun environment: spawn the ranks; this parent makes no GPU call
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True, bwd_chol=False, n_free=None):
     """Per-QP algorithmic bytes of forward / backward / the loop kernel alone.
 
-    linsolve 1 (pivoted LU, the reference's algorithm): SURVEY.md 8(d) -- every x-update streams the N x N
-    factor; the convergence check no longer reads Q (KKT identity), so its C n^2 term is gone.
-    linsolve 2 (symmetric inverse): every x-update is a symmetric product with H = (Qs + rho I)^-1 (corrected for
-    the equality rows), whose lower triangle n(n+1)/2 is all that has to move; the factorisation reads the lower
-    triangle of Qs and writes that of H."""
+    linsolve 1 (pivoted LU, the reference's algorithm): SURVEY.md 8(d) -- every x-update streams the N x N factor;
+    the convergence check no longer reads Q (KKT identity), so its C n^2 term is gone.
+    linsolve 2 (symmetric inverse): every x-update is a symmetric product with H = (Qs + rho I)^-1 (corrected for the
+    equality rows), whose lower triangle n(n+1)/2 is all that has to move; the factorisation reads the lower triangle
+    of Qs and writes that of H.  Backward: the LU form (3 n^2 + 4 N^2) or, when the Cholesky form ran,
+    n^2 (gather of Q_FF, at most) + f(f+1) (its factor, written and read) + n^2 (Q dv) + n^2 (dQ), f = free set."""
     N = n + m
     I = iters + 1
     S = 1 if scale else 0
@@ -66,23 +89,24 @@ def algorithmic_bytes(es, n, m, iters, n_refactor, linsolve, scale=True):
     else:
         loop = es * I * N * N
         fwd = es * (2 * S * n * n + n * n + N * N + 2 * N * N + n_refactor * (n * n + 3 * N * N)) + loop
-    bwd = es * (3 * n * n + 4 * N * N)
+    if bwd_chol:
+        f = n if n_free is None else n_free
+        bwd = es * (3 * n * n + f * (f + 1))
+    else:
+        bwd = es * (3 * n * n + 4 * N * N)
     return fwd, bwd, loop, es * I * N * N
 
 
-LOOP_KERNEL = {1: "lqp::k_admm_loop<float, true, false, 1024, false>",
-               2: "lqp::k_admm_loop<float, true, false, 1024, true>"}
-TRAFFIC_FILE = "profiles/r01_i_traffic.json"
-
-
-def measured_traffic(kernel, mode, B, n):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE / WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  Only valid for the configuration it was measured on; otherwise null."""
+def measured_traffic(kernel, B, n):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
+    in separate runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  Only valid for the
+    configuration it was measured on; otherwise null.  Kernel names are matched by prefix (template arguments vary)."""
     try:
         d = json.load(open(os.path.join(REPO, TRAFFIC_FILE)))
-        if d.get("launch_mode") == mode and B == B_PER_GPU and n == N_X:
-            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], TRAFFIC_FILE + " (rocprofv3 --pmc)"
+        if B == B_PER_GPU and n == N_X:
+            for name, rec in d["kernels"].items():
+                if name.startswith(kernel):
+                    return rec["hbm_bytes_per_launch_corrected"], TRAFFIC_FILE + " (rocprofv3 --pmc)"
     except Exception:
         pass
     return None, None
@@ -90,6 +114,7 @@ def measured_traffic(kernel, mode, B, n):
 
 def cpu_baseline_worker(args):
     """(child process, OMP/MKL threads pinned by the environment before torch was imported)"""
+    import torch
     from oracle import boxqp_oracle as O
     B, n = args.batch, args.n
     Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=0)
@@ -106,16 +131,14 @@ def cpu_baseline_worker(args):
         once()
     dt = (time.perf_counter() - t0) / args.cpu_reps
     print(json.dumps({"value": B / dt, "unit": "QPs/sec", "cores": torch.get_num_threads(), "kind": "port",
-                      "sample": f"{args.cpu_reps} x (forward+backward of one batch={B} dz={n} m=1 tol=1e-5), "
+                      "sample": f"{args.cpu_reps} x (forward+backward of one batch={B} dz={n} m=1 tol=1e-5, seed 0), "
                                 f"{dt:.2f} s each, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}))
 
 
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference, torch CPU) timed on this host's cores, in a child
-    process whose OMP/MKL thread count is the box's CPU share for one GPU (16).  (Changing the thread
-    count of an already-imported torch breaks MKL's batched getrf on this image, and all 256 hardware
-    threads make small batched LAPACK slower, not faster.)"""
-    import subprocess
+    """The oracle (CPU restatement of the reference, torch CPU) timed on this host's cores, in a child process whose
+    OMP/MKL thread count is the box's CPU share for one GPU (16).  (Changing the thread count of an already-imported
+    torch breaks MKL's batched getrf on this image, and all 256 hardware threads make small batched LAPACK slower.)"""
     threads = str(min(16, os.cpu_count() or 1))
     env = dict(os.environ, OMP_NUM_THREADS=threads, MKL_NUM_THREADS=threads, HIP_VISIBLE_DEVICES="")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--batch", str(args.batch),
@@ -127,13 +150,25 @@ def cpu_baseline(args):
     return {"value": None, "error": (res.stderr or res.stdout)[-300:]}
 
 
+def median(v):
+    s = sorted(v)
+    k = len(s)
+    return s[k // 2] if k % 2 else 0.5 * (s[k // 2 - 1] + s[k // 2])
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))             # (no GPU call was made by this process)
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     torch.cuda.set_device(local_rank)
@@ -142,37 +177,39 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()           # the RCCL world actually formed
     import lqp_py_amd as L
     from lqp_py_amd import _lib
     from lqp_py_amd.dist import ShardedBoxQP
+    from lqp_py_amd.solve_box_qp_admm_torch import last_forward_status
     from lqp_py_amd.synthetic import create_qp_data
 
     B, n, m = args.batch, args.n, N_EQ
-    # a few distinct batches (different seeds, like the reference's per-simulation data), HBM resident
-    n_sets = 3
+    # one batch per simulation seed (rank r draws seeds 100 r + 0..9), HBM resident
     data = []
-    for s in range(n_sets):
-        Q, p, A, b, lb, ub = create_qp_data(n, B, seed=1000 * rank + s)
+    for s in range(N_SEEDS):
+        Q, p, A, b, lb, ub = create_qp_data(n, B, seed=100 * rank + s)
         data.append([t.to(dev) for t in (Q, p, A, b, lb, ub)])
     ones = torch.ones(B, n, 1, device=dev)
-    control = L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, reduce='max')
-    if args.linsolve != "auto":
-        control['linsolve'] = args.linsolve
-    control['sync'] = bool(args.sync)     # False: the pipelined training-loop mode (errors reported late, NaN on failure)
-    layer = ShardedBoxQP(control) if world > 1 else None
-    qp = L.SolveBoxQP(control=control)
-    last = {}
 
-    def step(i):
-        Q, p, A, b, lb, ub = data[i % n_sets]
+    def make_layer(linsolve, sync):
+        control = L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, reduce='max')
+        if linsolve != "auto":
+            control['linsolve'] = linsolve
+        control['sync'] = bool(sync)     # False: the pipelined training-loop mode (errors reported late, NaN on failure)
+        return control, (ShardedBoxQP(control) if world > 1 else L.SolveBoxQP(control=control))
+
+    control, layer = make_layer(args.linsolve, args.sync)
+
+    def forward(i, lay=None):
+        Q, p, A, b, lb, ub = data[i % N_SEEDS]
         Q = Q.detach().requires_grad_(True)          # experiment_1 differentiates w.r.t. Q and p
         p = p.detach().requires_grad_(True)
-        if world > 1:
-            x, x_all = layer(Q, p, A, b, lb, ub)
-        else:
-            x = qp(Q, p, A, b, lb, ub)
-        x.backward(ones)
-        last["x"] = x
+        out = (lay or layer)(Q, p, A, b, lb, ub)
+        return out[0] if world > 1 else out
+
+    def step(i, lay=None):
+        forward(i, lay).backward(ones)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -180,27 +217,20 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize(dev)
 
+    def timed(k_steps, lay=None, first=0):
+        sync()
+        t0 = time.perf_counter()
+        for i in range(k_steps):
+            step(first + i, lay)
+        sync()
+        return time.perf_counter() - t0
+
     for i in range(args.warmup):
         step(i)
-    sync()
     # ---- timed region: exactly K steps, nothing else on the stream ----
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
+    dt = timed(args.steps, first=args.warmup)
     L.synchronize()                       # surface any deferred error of the un-synchronised layer calls
-    # ---- the same K steps again with every library launch bracketed by HIP events on its stream:
-    #      per-kernel device times for the roofline (kept out of the timed region: the event pairs
-    #      cost a few microseconds per launch) ----
-    _lib.profile(enable=True, reset=True)
-    tp = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    sync()
-    dt_prof = time.perf_counter() - tp
-    prof = _lib.profile()
-    _lib.profile(enable=False)
+    st_timed = last_forward_status(dev)   # iteration count / checks of the LAST timed forward, read from the device
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -208,51 +238,93 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B / (dt / args.steps)
 
-    # ---- roofline of the dominant kernel (the persistent / segmented ADMM loop) ----
-    Q, p, A, b, lb, ub = data[0]
-    sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, dict(control))
-    st = sol["_stats"]
+    # ---- the reference's protocol (experiment_1.py:53-94): one simulation per seed 0..9, forward and
+    #      backward timed separately (device events on the launch stream), medians over the simulations ----
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    t_fwd, t_bwd = [], []
+    for s in range(N_SEEDS):
+        e0, e1, e2 = ev(), ev(), ev()
+        torch.cuda.synchronize(dev)
+        e0.record()
+        x = forward(s)
+        e1.record()
+        x.backward(ones)
+        e2.record()
+        torch.cuda.synchronize(dev)
+        t_fwd.append(e0.elapsed_time(e1))
+        t_bwd.append(e1.elapsed_time(e2))
+    L.synchronize()
+    protocol = {"simulations": N_SEEDS, "seeds": f"{100 * rank}..{100 * rank + N_SEEDS - 1}",
+                "median_forward_ms": round(median(t_fwd), 4), "median_backward_ms": round(median(t_bwd), 4),
+                "QPs_per_sec_median": round(B / ((median(t_fwd) + median(t_bwd)) * 1e-3), 1),
+                "QPs_per_sec_mean": round(B / ((sum(t_fwd) + sum(t_bwd)) / N_SEEDS * 1e-3), 1),
+                "timing": "device events around each phase, one isolated simulation at a time (per GPU)"}
+
+    # ---- the same K steps again with every library launch bracketed by HIP events on its stream: per-kernel
+    #      device times for the roofline (kept out of the timed region: the event pairs cost microseconds) ----
+    _lib.profile(enable=True, reset=True)
+    dt_prof = timed(args.steps, first=args.warmup)
+    prof = _lib.profile()
+    _lib.profile(enable=False)
+    solves = max(args.steps, 1)
+    per_solve = lambda cls: prof.get(cls, (0.0, 0))[0] / solves
+    breakdown = {k: round(v[0] / solves, 4) for k, v in prof.items() if v[1]}
+
+    # ---- roofline objects ----
     es = 4
-    ls = st["linsolve_used"]
-    fwd_b, bwd_b, loop_b, loop_ref_b = algorithmic_bytes(es, n, m, st["iters"], st["n_factor"] - 1, ls)
-    loop_ms, loop_launches = prof["admm_loop"]
-    solves = args.steps
-    loop_ms_per_solve = loop_ms / max(solves, 1)
-    gbs = lambda nbytes: (nbytes * B) / (loop_ms_per_solve * 1e-3) / 1e9 if loop_ms_per_solve > 0 else 0.0
-    achieved = gbs(loop_b)
-    traffic, traffic_src = measured_traffic(LOOP_KERNEL[ls], 3 if not args.sync else st["mode_used"], B, n)
-    roofline = {"bound": "hbm", "kernel": LOOP_KERNEL[ls], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
-                "per": "the first (hot) loop launch of one forward solve of one batch",
-                "algorithmic_bytes": loop_b * B, "ms": round(loop_ms_per_solve, 4),
-                "launches_per_solve": loop_launches / max(solves, 1),
-                "linsolve": {1: "lu", 2: "spd"}[ls],
-                # the same launch priced with the REFERENCE algorithm's bytes (I * N^2 * es, the
-                # cached-LU stream this kernel replaces): not a bandwidth, a like-for-like speed figure
-                "reference_algorithm_bytes": loop_ref_b * B,
-                "reference_algorithm_equiv_GBs": round(gbs(loop_ref_b), 1),
-                "whole_step_frac_of_hbm_roofline": round(((fwd_b + bwd_b) * B / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)}
-    # second kernel of comparable weight on the symmetric path: the factorisation (MFMA block sweep).  Algorithmic
-    # flops of inverting an SPD matrix: n^3 (Cholesky n^3/3 + inverse of the factor and product 2n^3/3).
-    roofline_factor = None
+    ls = st_timed["linsolve_used"]
+    iters = st_timed["iters"]
+    fwd_b, bwd_b, loop_b, loop_ref_b = algorithmic_bytes(es, n, m, iters, st_timed["n_factor"] - 1, ls,
+                                                         bwd_chol=(ls == 2 and prof.get("bwd_cholesky", (0, 0))[1] > 0),
+                                                         n_free=int(0.63 * n))
+    loop_ms = per_solve("admm_loop")
+    gbs = lambda nbytes, ms: (nbytes * B) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    split = st_timed["loop_workgroups_per_qp"] == 2
+    loop_kernel = ("lqp::k_admm_loop_split" if split else
+                   "lqp::k_admm_loop<float, true, false, 1024, true>" if ls == 2 else "lqp::k_admm_loop<float, true, false, 1024, false>")
+    traffic, traffic_src = measured_traffic(loop_kernel, B, n)
+    working_set = B * (n * (n + 1) // 2 if ls == 2 else (n + m) ** 2) * es
+    roof_loop = {"bound": "hbm", "kernel": loop_kernel, "achieved": round(gbs(loop_b, loop_ms), 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(gbs(loop_b, loop_ms) / HBM_PEAK_GBS, 4),
+                 "traffic": traffic, "traffic_source": traffic_src,
+                 "frac_of_peak_by_traffic": None if traffic is None or loop_ms <= 0 else round(traffic / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "per": "the first (hot) loop launch of one forward solve of one batch",
+                 "algorithmic_bytes": loop_b * B, "ms": round(loop_ms, 4),
+                 "launches_per_solve": prof.get("admm_loop", (0, 0))[1] / solves, "linsolve": {1: "lu", 2: "spd"}[ls],
+                 "iterations": iters + 1,
+                 "residency": ("two workgroups per QP, every block of H in registers: the algorithmic bytes never leave the "
+                               "chip after the first read, so the algorithmic rate is not a memory bandwidth (frac may exceed 1)"
+                               if split else
+                               f"working set {working_set / 2**20:.0f} MiB vs {INFINITY_CACHE_BYTES // 2**20} MiB Infinity Cache: "
+                               "a MALL-resident rate, not DRAM bandwidth" if working_set < INFINITY_CACHE_BYTES else "streamed from HBM"),
+                 # the same launch priced with the REFERENCE algorithm's bytes (I * N^2 * es, the cached-LU
+                 # stream this kernel replaces): not a bandwidth, a like-for-like speed figure
+                 "reference_algorithm_bytes": loop_ref_b * B,
+                 "reference_algorithm_equiv_GBs": round(gbs(loop_ref_b, loop_ms), 1)}
+    # factorisation of the symmetric path (MFMA block sweep).  Algorithmic flops of inverting an SPD matrix: n^3
+    # (Cholesky n^3/3 + inverse of the factor and product 2n^3/3).
+    roof_factor = None
     if ls == 2 and prof.get("spd_inverse", (0, 0))[1]:
-        f_ms = prof["spd_inverse"][0] / max(solves, 1)
+        f_ms = per_solve("spd_inverse")
         tfl = B * float(n) ** 3 / (f_ms * 1e-3) / 1e12
-        mode_t = 3 if not args.sync else st["mode_used"]
-        if st.get("factor_launches", 1) > 1:
-            # small batch: two workgroups per matrix, one launch per pivot step (begin | Ks steps | end)
-            Ks = (n + 63) // 64
-            parts = [measured_traffic(k, mode_t, B, n)[0] for k in ("lqp::k_spd_begin", "lqp::k_spd_step", "lqp::k_spd_end")]
+        Ks = (n + 63) // 64
+        if st_timed["factor_launches"] > 1:
+            parts = [measured_traffic(k, B, n)[0] for k in ("lqp::k_spd_begin", "lqp::k_spd_step", "lqp::k_spd_end")]
             f_traffic = None if any(t is None for t in parts) else parts[0] + Ks * parts[1] + parts[2]
             f_kernel = f"lqp::k_spd_begin + {Ks} x lqp::k_spd_step + lqp::k_spd_end"
         else:
-            f_traffic, f_kernel = measured_traffic("lqp::k_spd_inverse", mode_t, B, n)[0], "lqp::k_spd_inverse"
-        roofline_factor = {"bound": "mfma", "kernel": f_kernel, "achieved": round(tfl, 2),
-                           "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
-                           "traffic": f_traffic, "algorithmic_flops": B * float(n) ** 3, "ms": round(f_ms, 4),
-                           "per": "one factorisation of the batch (all its launches)"}
-    breakdown = {k: round(v[0] / max(solves, 1), 4) for k, v in prof.items() if v[1]}
+            f_traffic, f_kernel = measured_traffic("lqp::k_spd_inverse", B, n)[0], "lqp::k_spd_inverse"
+        roof_factor = {"bound": "mfma", "kernel": f_kernel, "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": f_traffic,
+                       "algorithmic_flops": B * float(n) ** 3, "ms": round(f_ms, 4),
+                       "minimum_traffic_bytes": 2 * B * (n * (n + 1) // 2) * es,
+                       "per": "one factorisation of the batch (all its launches)"}
+    # `roofline` describes the kernel (group) that takes the largest share of the step
+    dominant_is_factor = roof_factor is not None and roof_factor["ms"] > loop_ms
+    roofline = dict(roof_factor if dominant_is_factor else roof_loop)
+    step_bytes = (fwd_b + bwd_b) * B
+    roofline["whole_step_frac_of_hbm_roofline"] = round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)
+    roofline["whole_step_algorithmic_bytes"] = step_bytes
 
     out = {"metric": "QPs/sec forward+backward, batch=128 dz=500 tol=1e-5", "value": round(value, 1),
            "unit": "QPs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -260,14 +332,33 @@ def main():
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[2]: batch={B}/GPU dz={n} m={m} box+equality QP, "
                                   "ADMM forward + fixed-point backward, eps 1e-5, scale+adaptive_rho defaults",
-                      "global_batch": world * B, "iters": st["iters"], "checks": st["n_check"],
-                      "launch_mode": st["mode_used"], "parallelism": f"batch-sharded x{world}"},
-           "roofline": roofline, "roofline_factorisation": roofline_factor, "kernel_ms_per_step": breakdown,
-           "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4)}
-    # "also report forward-only for configs 2 and 4" (B=128, n=100 box-only / n=1000 with the
-    # equality row) -- extras next to the headline number, single GPU only, inputs drawn on the device
+                      "global_batch": world * B, "seeds": f"{N_SEEDS} batches, seeds 0..{N_SEEDS - 1} per rank, cycled",
+                      "iters": iters, "checks": st_timed["n_check"], "launch_mode": st_timed["mode_used"],
+                      "stats_source": "device status block of the last timed forward",
+                      "sync": bool(args.sync), "linsolve": {1: "lu", 2: "spd"}[ls],
+                      "loop_workgroups_per_qp": st_timed["loop_workgroups_per_qp"],
+                      "parallelism": f"batch-sharded x{world}", "rccl_world_size": world},
+           "experiment_1_protocol": protocol,
+           "roofline": roofline, "roofline_loop": roof_loop, "roofline_factorisation": roof_factor,
+           "kernel_ms_per_step": breakdown, "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4)}
+
     if world == 1 and not args.no_other_configs and B == B_PER_GPU and n == N_X:
+        # ---- the same step on the north-star-named algorithm (cached pivoted LU) and with the layer's default
+        #      synchronous calls, driver-measured every round ----
+        for key, (lsv, syncv) in {"step_linsolve_lu": ("lu", args.sync), "step_sync_default": (args.linsolve, True)}.items():
+            if (lsv, syncv) == (args.linsolve, bool(args.sync)):
+                continue
+            _, lay = make_layer(lsv, syncv)
+            for i in range(3):
+                step(i, lay)
+            k = 10
+            dtx = timed(k, lay)
+            L.synchronize()
+            out[key] = {"value": round(B / (dtx / k), 1), "unit": "QPs/sec", "ms_per_step": round(dtx / k * 1e3, 4), "steps": k}
+        # ---- forward-only for configs 2 and 4 (B=128, n=100 box-only / n=1000 with the equality row),
+        #      inputs drawn on the device, roofline terms from the run itself ----
         extras = {}
+        qp_fwd = L.SolveBoxQP(control=dict(control, sync=False))
         for name, (nn, with_eq) in {"config2_fwd_n100_box": (100, False), "config4_fwd_n1000_eq": (1000, True)}.items():
             gen = torch.Generator(device=dev).manual_seed(4242 + nn)
             Lm = torch.randn(B, 2 * nn, nn, device=dev, generator=gen)
@@ -278,7 +369,7 @@ def main():
             bx = torch.ones(B, 1, 1, device=dev) if with_eq else None
             lbx = -(torch.rand(B, nn, 1, device=dev, generator=gen) + 1)
             ubx = torch.rand(B, nn, 1, device=dev, generator=gen) + 1
-            fwd = lambda: qp(Qx, px, Ax, bx, lbx, ubx)
+            fwd = lambda: qp_fwd(Qx, px, Ax, bx, lbx, ubx)
             for _ in range(2):
                 fwd()
             torch.cuda.synchronize(dev)
@@ -288,7 +379,17 @@ def main():
                 fwd()
             torch.cuda.synchronize(dev)
             dtx = (time.perf_counter() - t1) / reps
-            extras[name] = {"QPs_per_sec": round(B / dtx, 1), "ms": round(dtx * 1e3, 4), "batch": B}
+            stx = last_forward_status(dev)
+            mm = 1 if with_eq else 0
+            fb = algorithmic_bytes(es, nn, mm, stx["iters"], stx["n_factor"] - 1, stx["linsolve_used"])[0]
+            fb_ref = algorithmic_bytes(es, nn, mm, stx["iters"], stx["n_factor"] - 1, 1)[0]
+            extras[name] = {"QPs_per_sec": round(B / dtx, 1), "ms": round(dtx * 1e3, 4), "batch": B,
+                            "iters": stx["iters"], "checks": stx["n_check"], "linsolve": {1: "lu", 2: "spd"}[stx["linsolve_used"]],
+                            "forward_algorithmic_bytes": fb * B,
+                            "forward_frac_of_hbm_roofline": round(fb * B / dtx / 1e9 / HBM_PEAK_GBS, 4),
+                            "forward_frac_of_hbm_roofline_reference_algorithm_bytes": round(fb_ref * B / dtx / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": ("whole factor resident on chip (registers / LDS) for the loop: counter bytes << algorithmic"
+                                     if nn <= 128 else "")}
             del Qx
         L.synchronize()
         out["other_configs_forward_only"] = extras

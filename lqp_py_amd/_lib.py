@@ -41,7 +41,7 @@ class BoxQPCtrl(ctypes.Structure):
 class BoxQPStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in (
         "iters", "n_factor", "n_solve", "n_check", "rho_updated", "fail_index", "n_launch", "mode_used", "linsolve_used",
-        "factor_launches")]
+        "factor_launches", "loop_workgroups")]
 
 
 # every symbol include/lqp_amd.h declares: name -> (restype, argtypes)

@@ -482,6 +482,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
                 stats->linsolve_used = spd ? 2 : 1;
                 stats->factor_launches = spd ? (spd_split ? P.Ks + 2 : 1) : 2;
+                stats->loop_workgroups = loop_split ? 2 : 1;
             }
             return LQP_OK;
         }
@@ -607,6 +608,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->mode_used = mode;
         stats->linsolve_used = spd ? 2 : 1;
         stats->factor_launches = spd ? (spd_split ? P.Ks + 2 : 1) : 2;
+        stats->loop_workgroups = (loop_split && mode == 2) ? 2 : 1;
     }
     return LQP_OK;
 }
@@ -623,6 +625,7 @@ size_t carve_backward(void* ws, int B, int n, int m, BwdParams<T>& P) {
     P.piv = c.take<int>((size_t)B * P.Np);
     P.dest = c.take<int>((size_t)B * P.Np);
     P.rhs = c.take<T>((size_t)B * P.Np);
+    P.rhs2 = c.take<T>((size_t)B * P.Np);
     P.fidx = c.take<int>((size_t)B * n);
     P.nred = c.take<int>(B);
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
@@ -685,6 +688,15 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (rc) return rc;
         rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);
         if (rc) return rc;
+        if (P.reduced && env_int("LQP_BWD_REFINE", 1)) {
+            // one refinement step: residual with the original entries (double accumulation), correction solve
+            const int lds = (round_up(n, 8) + round_up(m > 0 ? m : 1, 8)) * (int)sizeof(T) + round_up(n, 8) * 4;
+            { ProfScope ps(st, PC_BWD_BUILD);
+              hipLaunchKernelGGL(k_bwd_residual<T>, dim3(B), dim3(LQP_NT), lds, st, P); }
+            rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs2, 1, (size_t)P.Np, 1, 0, nvec);
+            if (rc) return rc;
+            P.refine = 1;
+        }
     }
     {
         const int lds = (2 * n + m + 8) * (int)sizeof(T);

@@ -1457,6 +1457,8 @@ template <typename T> struct BwdParams {
     int* nred;   // B     : size of the reduced system = #free + m
     int reduced; // 1: solve on the free set only
     int chol;    // 1: the reduced system is solved through a blocked Cholesky of Q_FF (f32, symmetric Q)
+    T* rhs2;     // B * Np: residual / correction of the one refinement step of the LU form (or null)
+    int refine;  // 1: the epilogue adds rhs2 to rhs
 };
 
 template <typename T>
@@ -1746,6 +1748,52 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     for (int q = tid; q < m; q += LQP_NT) rhs[nf + q] = dn[q];
 }
 
+// One step of iterative refinement for the LU form of the reduced system: r = rhs - M d with the ORIGINAL entries
+// (Q, A gathered again; M itself was factored in place), dot products accumulated in double.  The cached solve uses
+// explicitly inverted 64x64 diagonal blocks, which -- like any fp32 LU of this bordered, nearly singular-cornered
+// matrix -- leaves 1e-5 ... 1e-4 of error when the exact dv is ~0 (dl_dz in the row space of A); one correction
+// solve with the same factor brings it to the fp32 rounding level.  LDS: dvf[n] | dn[m] | fl[n] (int)
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_bwd_residual(const BwdParams<T> P) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T* dvf = (T*)smem;                     // dv scattered to all n variables (0 on the active set)
+    T* dn = dvf + round_up(n, 8);
+    int* fl = (int*)(dn + round_up(m > 0 ? m : 1, 8));
+    const int nf = P.nred[b] - m;
+    const T* d = P.rhs + (size_t)b * Np;
+    T* r = P.rhs2 + (size_t)b * Np;
+    const T* Q = P.Q + (size_t)b * n * n;
+    const T* A = P.A ? P.A + (size_t)b * m * n : nullptr;
+    const T* g = P.g + (size_t)b * n;
+    for (int i = tid; i < n; i += LQP_NT) dvf[i] = T(0);
+    for (int a = tid; a < nf; a += LQP_NT) fl[a] = P.fidx[(size_t)b * n + a];
+    for (int q = tid; q < m; q += LQP_NT) dn[q] = d[nf + q];
+    __syncthreads();
+    for (int a = tid; a < nf; a += LQP_NT) dvf[fl[a]] = d[a];
+    __syncthreads();
+    for (int a = w; a < nf + m; a += LQP_NW) {
+        const bool eq = a >= nf;
+        const T* row = eq ? A + (size_t)(a - nf) * n : Q + (size_t)fl[a] * n;
+        double acc = 0.0;
+        for (int j = lane; j < n; j += 64) acc += (double)row[j] * (double)dvf[j];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            double res;
+            if (!eq) {
+                const int i = fl[a];
+                res = -(double)g[i] - acc - 1e-8 * (double)d[a];
+                for (int q = 0; q < m; ++q) res -= (double)A[(size_t)q * n + i] * (double)dn[q];
+            } else {
+                res = -acc - 1e-8 * (double)dn[a - nf];
+            }
+            r[a] = (T)res;
+        }
+    }
+    for (int a = nf + m + tid; a < Np; a += LQP_NT) r[a] = T(0);
+}
+
 // solve with the packed factor (one rhs per problem, in global memory, in place)
 // LDS: v[Np] | tmp[64] | dest[Np]
 template <typename T> __host__ __device__ inline int solve_lds_bytes(int Np) { return (Np + 64) * (int)sizeof(T) + Np * 4; }
@@ -1798,10 +1846,11 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     if (P.reduced) {
         const int nf = P.nred[b] - m;
         const int* fl = P.fidx + (size_t)b * n;
+        const T* d2 = P.rhs2 + (size_t)b * Np;           // correction of the refinement step (LU form)
         for (int i = tid; i < n; i += LQP_NT) { dv[i] = poison; xs[i] = x[i]; }
         __syncthreads();
-        for (int a = tid; a < nf; a += LQP_NT) dv[fl[a]] = d[a] + poison;
-        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[nf + r] + poison;
+        for (int a = tid; a < nf; a += LQP_NT) dv[fl[a]] = d[a] + (P.refine ? d2[a] : T(0)) + poison;
+        for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[nf + r] + (P.refine ? d2[nf + r] : T(0)) + poison;
     } else {
         for (int i = tid; i < n; i += LQP_NT) { dv[i] = d[i] + poison; xs[i] = x[i]; }
         for (int r = tid; r < m; r += LQP_NT) dnu[r] = d[n + r] + poison;

@@ -4,11 +4,16 @@ Every QP of a batch is independent, so each rank solves its own contiguous
 slice with no data-path communication; the only exchanges are
   * one 2-flag MAX all-reduce before the solve, because the reference's
     ``any_lb``/``any_ub`` (and hence the rho=0 shortcut) are global over the
-    whole batch (lqp_py/solve_box_qp_admm_torch.py:33-38, 129-131), and
+    whole batch (lqp_py/solve_box_qp_admm_torch.py:33-38, 129-131);
   * ONE all-gather of the solutions ``x`` (B_local, n, 1) at the end of the
-    forward (RCCL over xGMI when the backend is "nccl").
-The global stopping rule (:312) is evaluated per shard: a shard stops when all
-of ITS problems are optimal, so iteration counts may differ between shards
+    forward (RCCL over xGMI when the backend is "nccl"); shards may be of
+    different sizes (B not a multiple of the world size);
+  * only with ``control['dist_strict_stop'] = True``: one 4-word SUM all-reduce
+    per convergence check, which makes the stop test (:312) and the adaptive-rho
+    decision (:244-246) global like in the single-process reference -- every
+    rank then reports the single-process iteration count.
+Default: the stopping rule is evaluated per shard -- a shard stops when all of
+ITS problems are optimal, so iteration counts may differ between shards
 (results agree with the single-process solve within the tolerances).
 ``dl_dQ`` is never gathered.
 """
@@ -20,30 +25,40 @@ from .solve_box_qp_admm_torch import SolveBoxQPLayer
 _INF = float("inf")
 
 
-_flag_cache = []     # [(weakref(lb), version, weakref(ub), version, group, result)]
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def _needs_host_staging(t, group=None):
+    """gloo moves host memory: device tensors are staged through the CPU (tests on a one-GPU box run two ranks
+    over gloo; production uses "nccl" = RCCL, which takes device tensors as they are)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_(t, op, group=None):
+    """in-place all-reduce that also works for device tensors under the gloo backend"""
+    if not _active(group):
+        return t
+    if _needs_host_staging(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
 
 
 def global_bound_flags(lb, ub, group=None):
-    """(any_lb, any_ub) over the batches of ALL ranks.  Two reductions, one tiny all-reduce and a host
-    sync -- remembered for the same live tensor objects at the same in-place version.  (Every rank
-    runs the same program on its own shard, so all ranks hit or miss together and the collective
-    stays matched; set LQP_DIST_NO_CACHE=1 if your ranks do not pass bounds in lockstep.)"""
-    import os
-    import weakref
-    use_cache = not os.environ.get("LQP_DIST_NO_CACHE")
-    if use_cache:
-        for rl, vl, ru, vu, g, res in _flag_cache:
-            if rl() is lb and ru() is ub and vl == lb._version and vu == ub._version and g is group:
-                return res
-    flags = torch.stack(((torch.max(lb) > -_INF), (torch.min(ub) < _INF))).to(torch.int32)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    """(any_lb, any_ub) over the batches of ALL ranks: the local reduction (remembered for the same live bound
+    tensors by the layer's own cache) and one tiny MAX all-reduce.  The collective itself is issued on EVERY call:
+    a rank-local cache hit must never decide whether a collective happens."""
+    local = _local_flags(lb, ub)
+    if not _active(group):
+        return local
+    flags = torch.tensor([int(local[0]), int(local[1])], dtype=torch.int32, device=lb.device)
+    all_reduce_(flags, dist.ReduceOp.MAX, group)
     f = flags.tolist()
-    res = (bool(f[0]), bool(f[1]))
-    if use_cache:
-        _flag_cache[:] = [e for e in _flag_cache if e[0]() is not None and e[2]() is not None][-7:]
-        _flag_cache.append((weakref.ref(lb), lb._version, weakref.ref(ub), ub._version, group, res))
-    return res
+    return bool(f[0]), bool(f[1])
 
 
 def _local_flags(lb, ub):
@@ -54,14 +69,33 @@ def _local_flags(lb, ub):
 
 
 def all_gather_solutions(x_local, group=None):
-    """(B_local, n, 1) on every rank -> (world * B_local, n, 1) on every rank, one collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    """(B_r, n, 1) on rank r -> (sum_r B_r, n, 1) on every rank, rank order.  Equal shards: one
+    all_gather_into_tensor.  Unequal shards: the sizes travel first (one small all-gather), the payloads are padded
+    to the largest shard for the single payload collective and trimmed afterwards."""
+    if not _active(group):
         return x_local
     world = dist.get_world_size(group)
-    out = torch.empty((world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype,
-                      device=x_local.device)
-    dist.all_gather_into_tensor(out, x_local.contiguous(), group=group)
-    return out
+    x_local = x_local.contiguous()
+    stage = _needs_host_staging(x_local, group)
+    src = x_local.cpu() if stage else x_local
+    sizes = torch.zeros(world, dtype=torch.int64, device=src.device)
+    mine = torch.tensor([src.shape[0]], dtype=torch.int64, device=src.device)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = sizes.tolist()
+    bmax = max(sizes)
+    tail = tuple(src.shape[1:])
+    if all(s == bmax for s in sizes):
+        out = torch.empty((world * bmax,) + tail, dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=group)
+    else:
+        padded = src
+        if src.shape[0] < bmax:
+            padded = torch.zeros((bmax,) + tail, dtype=src.dtype, device=src.device)
+            padded[:src.shape[0]] = src
+        buf = torch.empty((world * bmax,) + tail, dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(buf, padded, group=group)
+        out = torch.cat([buf[r * bmax:r * bmax + sizes[r]] for r in range(world)], dim=0)
+    return out.to(x_local.device) if stage else out
 
 
 def shard_slice(n_total, rank, world):
@@ -74,7 +108,10 @@ def shard_slice(n_total, rank, world):
 class ShardedBoxQP(torch.nn.Module):
     """Same call signature as ``SolveBoxQP`` but the tensors passed in are this rank's
     slice of the batch.  ``forward`` returns (x_local, x_all): x_local carries the autograd
-    graph (fixed-point backward on this rank's problems), x_all is the gathered solution."""
+    graph (fixed-point backward on this rank's problems), x_all is the gathered solution.
+
+    ``control['dist_strict_stop'] = True`` reproduces the single-process stopping rule and adaptive-rho decision
+    exactly (one small all-reduce per convergence check); every rank must then pass the same control."""
 
     def __init__(self, control, group=None, layer_apply=None):
         super().__init__()
@@ -82,15 +119,22 @@ class ShardedBoxQP(torch.nn.Module):
         self.group = group
         self._apply = layer_apply or SolveBoxQPLayer.apply      # tests inject a CPU stand-in here
 
+    def _check_hook(self, counters, check_index):
+        """counters: 4 int32 {not optimal, arrivals, wants rho, ratio trigger} of one check, in place"""
+        all_reduce_(counters, dist.ReduceOp.SUM, self.group)
+
     def forward(self, Q, p, A, b, lb, ub):
         has_lb, has_ub = global_bound_flags(lb, ub, self.group)
         ctl = self.control
         if not (has_lb or has_ub):
             ctl['rho'] = 0
-        elif _local_flags(lb, ub) == (False, False):
-            # this shard alone has no finite bound but another rank does: keep the ADMM path
-            # (a private copy of the dict protects the caller's rho from the layer's side effect)
+        if _active(self.group):
+            # private keys for the layer: the GLOBAL bound flags (a shard without any finite bound must still run
+            # the ADMM path with the clamps the whole batch uses) and, in strict mode, the per-check all-reduce
             ctl = dict(ctl)
+            ctl['_global_bounds'] = (has_lb, has_ub)
+            if ctl.get('dist_strict_stop', False) and (has_lb or has_ub):
+                ctl['_check_hook'] = self._check_hook
         x_local = self._apply(Q, p, A, b, lb, ub, ctl)
         with torch.no_grad():
             x_all = all_gather_solutions(x_local.detach(), self.group)

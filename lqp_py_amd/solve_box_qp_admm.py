@@ -44,19 +44,13 @@ class BoxQP:
         return None
 
 
-def prep_bound(x, n_x, default=None):
-    """lqp_py/solve_box_qp_admm.py:270-277."""
-    if x is None:
-        x = default
-    x = make_matrix(x)
-    if x.shape[0] < n_x:
-        x = x.repeat(n_x)
-        x = make_matrix(x)
-    return x
-
-
-def clamp(x, x_min=-float('inf'), x_max=float('inf')):
-    return min(max(x, x_min), x_max)
+def _bound_vector(value, n_x, fallback):
+    """A bound given as None, a scalar or an array -> float vector of length n_x (the reference broadcasts a short
+    bound over all variables, lqp_py/solve_box_qp_admm.py:270-277)."""
+    arr = np.asarray(fallback if value is None else value, dtype=float).reshape(-1)
+    if arr.size < n_x:
+        arr = np.tile(arr, n_x)
+    return arr
 
 
 def solve_box_qp(Q, p, A=None, b=None, lb=-float("inf"), ub=float("inf"), control=None):
@@ -69,8 +63,8 @@ def solve_box_qp(Q, p, A=None, b=None, lb=-float("inf"), ub=float("inf"), contro
     if b is not None:
         b = make_matrix(b)[:, 0]
     n_x = p.shape[0]
-    lb = prep_bound(lb, n_x=n_x, default=-float("inf"))[:, 0]
-    ub = prep_bound(ub, n_x=n_x, default=float("inf"))[:, 0]
+    lb = _bound_vector(lb, n_x, -float("inf"))
+    ub = _bound_vector(ub, n_x, float("inf"))
     any_eq = A is not None
     any_ineq = (lb.max() > -float("inf")) or (ub.max() < float("inf"))        # (:72-74, ub.max() as there)
     if not any_ineq:

@@ -41,7 +41,8 @@ class SolveBoxQPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Q, p, A, b, lb, ub, control):
-        has_lb, has_ub = _finite_bounds(lb, ub)
+        # (lqp_py_amd.dist passes the flags of the WHOLE batch when this call holds one shard of it)
+        has_lb, has_ub = control.get('_global_bounds') or _finite_bounds(lb, ub)
         if not (has_lb or has_ub):
             control['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
         # Default (control['sync'] absent or True): the reference's semantics -- the call waits for the solve, a
@@ -346,7 +347,31 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
                                                     _lib.ptr(pri), _lib.ptr(dua)), "last_residuals")
         sol["primal_error"], sol["dual_error"] = pri, dua
     sol["_stats"] = {k: getattr(stats, k) for k, _ in stats._fields_}
+    _last_forward[dev.index] = (ws, dt, B, n, m, dict(sol["_stats"]), int(r['check_solved']), int(r['max_iters']))
     return sol
+
+
+_last_forward = {}
+
+
+def last_forward_status(device):
+    """Bookkeeping of the most recent forward solve on `device`: {"iters", "n_check", "n_factor", "mode_used",
+    "linsolve_used", "factor_launches", "loop_workgroups_per_qp"}.  A call that did not wait for the GPU
+    (control['sync'] = False) could not report its iteration count; it is read here from the device-side status
+    block of that call's workspace (this waits for the device).  Valid until the next forward on the same stream."""
+    device = torch.device(device)
+    ws, dt, B, n, m, st, check, max_iters = _last_forward[device.index]
+    if st["mode_used"] == 3:
+        lib = _lib.load()
+        so, sb, io, ib = (ctypes.c_size_t() for _ in range(4))
+        _lib.check(lib.lqp_boxqp_forward_layout(dt, B, n, m, ctypes.byref(so), ctypes.byref(sb), ctypes.byref(io),
+                                                ctypes.byref(ib)), "forward_layout")
+        torch.cuda.synchronize(device)
+        status = ws[so.value:so.value + sb.value].view(torch.int32).cpu().tolist()
+        iters = status[1] if status[0] else max_iters - 1          # [0] done, [1] final iteration, [3] refactorisations
+        st = dict(st, iters=iters, n_check=iters // check + 1, n_factor=1 + status[3], n_solve=iters + 1)
+    st["loop_workgroups_per_qp"] = st.pop("loop_workgroups")
+    return st
 
 
 def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1):

@@ -38,3 +38,12 @@ def golden():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU sessions leave the measured parity errors behind (tests/parity_report.py)."""
+    try:
+        import parity_report
+        parity_report.dump()
+    except Exception:
+        pass

@@ -107,3 +107,51 @@ def test_synthetic_generator_matches_the_oracle_and_the_golden_inputs():
     g = load_golden("g1_b32_n10_box")
     Q, p, _, _, lb, ub = create_qp_data(10, 32, seed=0, with_eq=False, unit_box=True)
     assert torch.equal(Q, g["Q"]) and torch.equal(p, g["p"]) and torch.equal(lb, g["lb"]) and torch.equal(ub, g["ub"])
+
+
+def test_lqp_py_import_path_is_an_alias_of_the_hip_package():
+    """callers import lqp_py.<module>; every such module IS the lqp_py_amd module of that name."""
+    import lqp_py_amd
+    from lqp_py.solve_box_qp_admm_torch import SolveBoxQP, SolveBoxQPLayer, torch_solve_box_qp, torch_solve_box_qp_grad
+    from lqp_py.control import box_qp_control
+    from lqp_py.lu_layer import TorchLU
+    from lqp_py.solve_qp_eqcon_torch import torch_solve_qp_eqcon
+    from lqp_py.utils import get_ncon
+    import lqp_py.solve_box_qp_admm_torch as mod
+    assert mod is lqp_py_amd.solve_box_qp_admm_torch and mod.__name__ == "lqp_py_amd.solve_box_qp_admm_torch"
+    assert SolveBoxQP is lqp_py_amd.SolveBoxQP and SolveBoxQPLayer is lqp_py_amd.SolveBoxQPLayer
+    assert torch_solve_box_qp is lqp_py_amd.torch_solve_box_qp and torch_solve_box_qp_grad is lqp_py_amd.torch_solve_box_qp_grad
+    assert box_qp_control is lqp_py_amd.box_qp_control and TorchLU is lqp_py_amd.TorchLU
+    assert torch_solve_qp_eqcon is lqp_py_amd.torch_solve_qp_eqcon and get_ncon is lqp_py_amd.get_ncon
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert sorted(os.listdir(os.path.join(here, "lqp_py"))) in (["__init__.py"], ["__init__.py", "__pycache__"])
+
+
+def test_bench_spawns_its_own_ranks_without_touching_the_gpu(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` with no torchrun environment: the parent only builds the torchrun command line
+    (one rank per GPU, 127.0.0.1 rendezvous) and relays the child's exit code."""
+    import importlib.util
+    import subprocess
+    import sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched by the parent")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

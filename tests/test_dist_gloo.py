@@ -1,7 +1,8 @@
-"""world_size-2 gloo test of the batch-sharded path (host logic only): the
-sharding helper, the global any_lb/any_ub reduction and the single all-gather.
-The per-rank solver is injected (the CPU oracle stands in for the HIP layer,
-which needs a GPU)."""
+"""world_size-2 gloo tests of the batch-sharded path (host logic): the sharding
+helper, the global any_lb/any_ub reduction, the single all-gather with unequal
+shards, and the strict global stop (one all-reduce per convergence check).
+The per-rank solver is injected: the CPU oracle stands in for the HIP layer,
+which needs a GPU (tests/test_gpu_dist.py drives the real layer the same way)."""
 import os
 import socket
 
@@ -19,47 +20,88 @@ def _free_port():
         return s.getsockname()[1]
 
 
+_seen = {}
+
+
 def _oracle_layer(Q, p, A, b, lb, ub, control):
-    return O.layer_forward(Q, p, A, b, lb, ub, control)["x"]
+    """what SolveBoxQPLayer.forward does with the private keys lqp_py_amd.dist adds to the control dict"""
+    bounds = control.get('_global_bounds')
+    if bounds is None:
+        bounds = (bool(torch.max(lb) > -O.INF), bool(torch.min(ub) < O.INF))
+    if not (bounds[0] or bounds[1]):
+        control["rho"] = 0
+    sol = O.solve_box_qp(Q, p, A, b, lb, ub, control, bounds=bounds, check_hook=control.get('_check_hook'))
+    _seen["iter"] = sol["iter"]
+    return sol["x"]
 
 
-def _worker(rank, world, port, B, n, out_dir, no_bounds_rank):
+def _data(n, B, no_bounds_rank, world, spread=False):
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=5)
+    if spread:                  # make the problems converge at different checks: scale half of them
+        Q[B // 2:] *= 40.0
+        p[B // 2:] *= 3.0
+    if no_bounds_rank is not None:        # one shard without any finite bound: flags must still be global
+        from lqp_py_amd.dist import shard_slice
+        lo, hi = shard_slice(B, no_bounds_rank, world)
+        lb[lo:hi] = -float("inf")
+        ub[lo:hi] = float("inf")
+    return Q, p, A, b, lb, ub
+
+
+def _worker(rank, world, port, B, n, out_dir, no_bounds_rank, strict, spread):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from lqp_py_amd.dist import ShardedBoxQP, shard_slice
-    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=5)
-    if no_bounds_rank is not None:        # one shard without any finite bound: flags must still be global
-        lo, hi = shard_slice(B, no_bounds_rank, world)
-        lb[lo:hi] = -float("inf")
-        ub[lo:hi] = float("inf")
+    Q, p, A, b, lb, ub = _data(n, B, no_bounds_rank, world, spread)
     lo, hi = shard_slice(B, rank, world)
-    ctl = O.make_control(eps_abs=1e-5, eps_rel=1e-5)
+    ctl = O.make_control(eps_abs=1e-5, eps_rel=1e-5, check_solved=5 if spread else None)
+    if spread:
+        ctl["check_solved"] = 5
+    if strict:
+        ctl["dist_strict_stop"] = True
     layer = ShardedBoxQP(ctl, layer_apply=_oracle_layer)
     x_local, x_all = layer(Q[lo:hi], p[lo:hi], A[lo:hi], b[lo:hi], lb[lo:hi], ub[lo:hi])
     assert x_all.shape == (B, n, 1)
     assert torch.equal(x_all[lo:hi], x_local)
     assert ctl.get("rho") is None, "caller's dict must not be touched when any rank has a finite bound"
-    if rank == 0:
-        torch.save(x_all, os.path.join(out_dir, "x_all.pt"))
+    assert "_check_hook" not in ctl and "_global_bounds" not in ctl, "private keys must stay in the layer's copy"
+    torch.save({"x_all": x_all, "iter": _seen["iter"]}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _run(tmp_path, B, n, world, no_bounds_rank=None, strict=False, spread=False):
+    mp.spawn(_worker, args=(world, _free_port(), B, n, str(tmp_path), no_bounds_rank, strict, spread), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    for o in outs[1:]:
+        assert torch.equal(o["x_all"], outs[0]["x_all"])
+    Q, p, A, b, lb, ub = _data(n, B, no_bounds_rank, world, spread)
+    ctl = O.make_control(eps_abs=1e-5, eps_rel=1e-5)
+    if spread:
+        ctl["check_solved"] = 5
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, ctl)
+    return outs, ref
+
+
+@pytest.mark.parametrize("B", [6, 7])               # 7: unequal shards (4 + 3)
 @pytest.mark.parametrize("no_bounds_rank", [None, 1])
-def test_sharded_equals_single_process(tmp_path, no_bounds_rank):
-    B, n, world = 6, 24, 2
-    mp.spawn(_worker, args=(world, _free_port(), B, n, str(tmp_path), no_bounds_rank), nprocs=world, join=True)
-    x_all = torch.load(os.path.join(tmp_path, "x_all.pt"))
-    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=5)
-    if no_bounds_rank is not None:
-        from lqp_py_amd.dist import shard_slice
-        lo, hi = shard_slice(B, no_bounds_rank, world)
-        lb[lo:hi] = -float("inf")
-        ub[lo:hi] = float("inf")
-    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(eps_abs=1e-5, eps_rel=1e-5))
+def test_sharded_equals_single_process(tmp_path, no_bounds_rank, B):
+    outs, ref = _run(tmp_path, B, 24, 2, no_bounds_rank)
     # per-shard stopping may run a shard a few checks longer/shorter than the global rule: tolerance, not equality
-    torch.testing.assert_close(x_all, ref["x"], atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(outs[0]["x_all"], ref["x"], atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("B", [6, 7])
+def test_strict_stop_reproduces_the_single_process_iteration_count(tmp_path, B):
+    """control['dist_strict_stop']: one all-reduce of the check counters per convergence check -> every rank stops
+    at the single-process iteration (reference :312) and takes its adaptive-rho decisions (:244-246)."""
+    loose, ref = _run(tmp_path, B, 24, 2, strict=False, spread=True)
+    strict, _ = _run(tmp_path, B, 24, 2, strict=True, spread=True)
+    assert all(o["iter"] == ref["iter"] for o in strict), ([o["iter"] for o in strict], ref["iter"])
+    torch.testing.assert_close(strict[0]["x_all"], ref["x"], atol=1e-6, rtol=1e-6)
+    # the test is only meaningful if per-shard stopping really differs on this data
+    assert any(o["iter"] != ref["iter"] for o in loose), "pick data whose shards stop at different checks"
 
 
 def test_shard_slices_cover_the_batch():

@@ -1,0 +1,89 @@
+"""Two ranks drive the REAL ``ShardedBoxQP`` (HIP layer, C ABI) on one GPU box.
+
+The box has one GPU, and RCCL refuses two ranks on one device, so the process
+group is gloo (``lqp_py_amd.dist`` stages the few small collective payloads
+through the host for that backend; under "nccl" = RCCL they stay on the
+device).  Everything else is the production path: each rank solves its shard
+with the HIP library, the all-gather returns the full solution, the backward
+runs per shard, and -- in strict mode -- the library calls back after every
+convergence check for the all-reduce of its counters."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import boxqp_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(eps_abs=1e-5, eps_rel=1e-5)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _data(n, B):
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=11)
+    Q[B // 2:] *= 40.0                      # the two halves of the batch converge at different checks
+    p[B // 2:] *= 3.0
+    return Q, p, A, b, lb, ub
+
+
+def _worker(rank, world, port, B, n, out_dir, strict):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lqp_py_amd as L
+    from lqp_py_amd.dist import ShardedBoxQP, shard_slice
+    from lqp_py_amd.solve_box_qp_admm_torch import last_forward_status
+    dev = torch.device("cuda:0")
+    lo, hi = shard_slice(B, rank, world)
+    Q, p, A, b, lb, ub = (t[lo:hi].to(dev) for t in _data(n, B))
+    ctl = L.box_qp_control(**TOL)
+    ctl["check_solved"] = 5
+    if strict:
+        ctl["dist_strict_stop"] = True
+    Qg = Q.clone().requires_grad_(True)
+    pg = p.clone().requires_grad_(True)
+    x_local, x_all = ShardedBoxQP(ctl)(Qg, pg, A, b, lb, ub)
+    st = last_forward_status(dev)
+    cot = torch.ones_like(x_local)
+    x_local.backward(cot)
+    torch.cuda.synchronize()
+    assert x_all.shape == (B, n, 1) and torch.equal(x_all[lo:hi], x_local.detach())
+    assert "_check_hook" not in ctl and "_global_bounds" not in ctl
+    torch.save({"x_all": x_all.cpu(), "iter": st["iters"], "mode": st["mode_used"], "dp": pg.grad.cpu(),
+                "dQ_fro": torch.linalg.matrix_norm(Qg.grad).cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_two_ranks_drive_the_hip_layer(tmp_path, strict):
+    assert torch.cuda.is_available()
+    B, n, world = 7, 96, 2                   # unequal shards (4 + 3)
+    mp.spawn(_worker, args=(world, _free_port(), B, n, str(tmp_path), strict), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    assert torch.equal(outs[0]["x_all"], outs[1]["x_all"])
+    Q, p, A, b, lb, ub = _data(n, B)
+    ctl = O.make_control(**TOL)
+    ctl["check_solved"] = 5
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, ctl)
+    err = float((outs[0]["x_all"] - ref["x"]).abs().max())
+    if strict:
+        # one all-reduce per check: the single-process stopping rule, hence its iteration count, on every rank
+        assert [o["iter"] for o in outs] == [ref["iter"]] * world and all(o["mode"] == 1 for o in outs)
+        assert err < 2e-5, err
+    else:
+        assert err < 1e-3 * max(1.0, float(ref["x"].abs().max())), err      # per-shard stop: within the stopping tolerance
+    # gradients of each shard against the oracle's for the same problems
+    g = O.solve_box_qp_grad(torch.ones(B, n, 1), ref["x"], ref["u"], ref["lams"], ref["nus"], Q, A, lb, ub, ref["rho"])
+    from lqp_py_amd.dist import shard_slice
+    for r, o in enumerate(outs):
+        lo, hi = shard_slice(B, r, world)
+        scale = max(1.0, float(g[1][lo:hi].abs().max()))
+        assert float((o["dp"] - g[1][lo:hi]).abs().max()) < (1e-3 if not strict else 2e-4) * scale

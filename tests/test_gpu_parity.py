@@ -1,9 +1,13 @@
 """Parity of the HIP path (through the C ABI, via the Python shim) against the
 CPU oracle and the golden vectors made from the reference.  GPU only.
 
-Tolerances: fp32 solutions to 5e-5 absolute (north_star: residuals to 1e-5 with
-eps_abs = eps_rel = 1e-5), gradients to rtol 1e-4 of the gradient's scale
-(2e-3 where the stopping tolerance itself limits agreement); fp64 to 1e-9.
+Tolerances (north_star: residuals to 1e-5 with eps_abs = eps_rel = 1e-5, gradients
+rtol 1e-4): fp32 iterates within 1e-5 of the reference-made golden vectors,
+gradients within 1e-4 of the gradient's scale; fp64 to 1e-9.  Where fp32
+rounding alone exceeds that (the reference's own fp32 result is no closer to an
+fp64 solve of the same inputs), the fp64 criterion applies instead:
+|HIP - fp64| <= |reference fp32 golden - fp64| + eps.  Every measured error goes to
+gpurun_out/parity_report.json (tests/parity_report.py).
 """
 import os
 
@@ -14,6 +18,7 @@ import lqp_py_amd as L
 from lqp_py_amd import _lib, lu_layer
 from oracle import boxqp_oracle as O
 from conftest import load_golden
+import parity_report as P
 import lqp_py_amd.solve_box_qp_admm_torch as SB
 
 pytestmark = pytest.mark.gpu
@@ -35,6 +40,32 @@ def err(a, b):
 def rel(a, b):
     b = b.detach().cpu().double()
     return err(a, b) / (float(b.abs().max()) + 1e-300)
+
+
+X_TOL, G_RTOL = 1e-5, 1e-4           # north_star
+
+
+def close_or_fp64(case, name, hip, golden, truth64, tol, **tags):
+    """north_star tolerance against the golden vector, or -- when fp32 rounding alone is larger than that -- no
+    further from an fp64 solve of the same inputs than the reference's own fp32 result (+ tol).  Records both."""
+    scale = max(1.0, float(golden.abs().max()))
+    e_direct = err(hip, golden)
+    e_hip64 = e_ref64 = None
+    if truth64 is not None:
+        e_hip64, e_ref64 = err(hip, truth64), err(golden, truth64)
+    P.record(case, name, e_direct, scale, hip_vs_fp64=e_hip64, reference_fp32_vs_fp64=e_ref64, tol=tol * scale, **tags)
+    ok = e_direct <= tol * scale or (e_hip64 is not None and e_hip64 <= e_ref64 + tol * scale)
+    assert ok, (case, name, tags, dict(direct=e_direct, hip_vs_fp64=e_hip64, ref_vs_fp64=e_ref64, tol=tol * scale))
+
+
+def fp64_truth(inp, iters, cots=()):
+    """The same solve in float64 with the iteration count pinned (eps tiny, max_iters = iters + 1): what is left
+    between this and an fp32 result is rounding.  Returns (solution dict, [gradient tuples])."""
+    d = [None if t is None else t.double() for t in inp]
+    sol = O.solve_box_qp(*d, O.make_control(eps_abs=1e-12, eps_rel=1e-12, max_iters=iters + 1))
+    grads = [O.solve_box_qp_grad(c.double(), sol["x"], sol["u"], sol["lams"], sol["nus"], d[0], d[2], d[4], d[5], sol["rho"])
+             for c in cots]
+    return sol, grads
 
 
 def solve(dev, inputs, ctl):
@@ -109,7 +140,8 @@ def test_g1_config1_box_only(dev):
     sol, _ = solve(dev, (g["Q"], g["p"], None, None, g["lb"], g["ub"]), O.make_control(**TOL))
     assert sol["iter"] == g["iter"] and sol["nus"] is None
     for k in ("x", "z", "u", "lams", "rho"):
-        assert err(sol[k], g[k]) < 2e-5, k
+        P.record("g1_b32_n10_box", k, err(sol[k], g[k]))
+        assert err(sol[k], g[k]) < X_TOL, k
 
 
 @pytest.mark.parametrize("linsolve", ["lu", "spd"])
@@ -120,12 +152,15 @@ def test_g2_forward_and_all_fp_grads(dev, mode, linsolve):
     sol, a = solve(dev, tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")), ctl)
     assert sol["iter"] == g["iter"] and sol["_stats"]["mode_used"] == mode
     for k in ("x", "z", "u", "lams", "nus", "rho"):
-        assert err(sol[k], g[k]) < 2e-5, k
+        P.record("g2_b8_n50_eq", k, err(sol[k], g[k]), linsolve=linsolve, mode=mode)
+        assert err(sol[k], g[k]) < X_TOL, k
     for tag, cot in (("ones", torch.ones(8, 50, 1)), ("rand", g["g_rand"])):
         gr = L.torch_solve_box_qp_grad(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
         assert gr[6] is None
         for nm, t in zip(GRADS, gr):
-            assert err(t, g[f"{nm}_{tag}"]) < 1e-4 * max(1.0, float(g[f"{nm}_{tag}"].abs().max())), (tag, nm)
+            scale = max(1.0, float(g[f"{nm}_{tag}"].abs().max()))
+            P.record("g2_b8_n50_eq", f"{nm}_{tag}", err(t, g[f"{nm}_{tag}"]), scale, linsolve=linsolve, mode=mode)
+            assert err(t, g[f"{nm}_{tag}"]) < G_RTOL * scale, (tag, nm)
 
 
 def test_g8_fp64(dev):
@@ -148,12 +183,20 @@ def test_g6_adaptive_rho_refactorises(dev, tag, linsolve, mode):
     sol, a = solve(dev, tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub")), ctl)
     assert sol["iter"] == g["iter"] == 100 and sol["_stats"]["n_factor"] == 2
     assert torch.is_tensor(sol["rho"]) and sol["rho"].shape == (16, 1, 1)
+    # fp64 run of the same 101 iterations: rho after the refactorisation is sqrt(ratio of two residuals at the 1e-6
+    # level), i.e. fp32 rounding noise amplified -- the reference's own fp32 result sits equally far from fp64
+    inp = tuple(g[k] for k in ("Q", "p", "A", "b", "lb", "ub"))
+    d = [t.double() for t in inp]
+    c64 = O.make_control(rho=100.0, scale=(tag == "scale"), eps_abs=1e-12, eps_rel=1e-12, max_iters=101)
+    s64 = O.solve_box_qp(*d, c64)
+    g64 = O.solve_box_qp_grad(g["g"].double(), s64["x"], s64["u"], s64["lams"], s64["nus"], d[0], d[2], d[4], d[5], s64["rho"])
+    case = f"g6_adaptive_{tag}"
     for k in ("x", "z", "lams", "nus"):
-        assert err(sol[k], g[k]) < 5e-5, k
-    assert rel(sol["rho"], g["rho"]) < 2e-3            # rho = sqrt(ratio of tiny residuals): fp32-noise sensitive
+        close_or_fp64(case, k, sol[k], g[k], s64[k], X_TOL, linsolve=linsolve, mode=mode)
+    close_or_fp64(case, "rho", sol["rho"], g["rho"], s64["rho"], 1e-4, linsolve=linsolve, mode=mode)
     gr = L.torch_solve_box_qp_grad(g["g"].to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
-    for nm, t in zip(GRADS, gr):
-        assert rel(t, g[nm]) < 2e-3, nm
+    for nm, t, t64 in zip(GRADS, gr, g64):
+        close_or_fp64(case, nm, t, g[nm], t64, G_RTOL, linsolve=linsolve, mode=mode)
 
 
 def test_g7_no_inequality_rho0_and_dict_mutation(dev):
@@ -206,28 +249,85 @@ def test_g3_config2(dev):
     Q, p, _, _, lb, ub = O.create_qp_data(100, 128, seed=0, with_eq=False)
     sol, _ = solve(dev, (Q, p, None, None, lb, ub), O.make_control(**TOL))
     assert sol["iter"] == g["iter"] == 70
-    assert err(sol["x"], g["x"]) < 5e-5 and err(sol["u"], g["u"]) < 5e-5
+    for k in ("x", "u"):
+        P.record("g3_b128_n100_box", k, err(sol[k], g[k]))
+        assert err(sol[k], g[k]) < X_TOL, k
+
+
+_G4_TRUTH = {}
+
+
+def g4_truth():
+    """fp64 solve (CPU oracle) of the headline batch with the reference's iteration count, and its gradients for the
+    two cotangents of the golden file -- computed once per session (~10 s on the box's host cores)."""
+    if not _G4_TRUTH:
+        inp = O.create_qp_data(500, 128, seed=0)
+        torch.manual_seed(7)
+        cots = {"ones": torch.ones(128, 500, 1), "rand": torch.randn(128, 500, 1)}
+        sol, grads = fp64_truth(inp, 60, list(cots.values()))
+        _G4_TRUTH.update(inp=inp, cots=cots, sol=sol, grads=dict(zip(cots, grads)))
+    return _G4_TRUTH
+
+
+def check_g4_grads(case, g, gr, tag, t64, rtol=G_RTOL, **tags):
+    """dp, dA, db, dlb, dub in full; dQ by its per-problem Frobenius norm and 64 sampled entries (128 MB otherwise)"""
+    for idx, nm in enumerate(GRADS):
+        if nm == "dQ" or gr[idx] is None:
+            continue
+        close_or_fp64(case, f"{nm}_{tag}", gr[idx], g[f"{nm}_{tag}"], t64[idx], rtol, **tags)
+    dQ = gr[0]
+    if dQ is not None:
+        fro64 = torch.linalg.matrix_norm(t64[0])
+        close_or_fp64(case, f"dQ_fro_{tag}", torch.linalg.matrix_norm(dQ), g[f"dQ_fro_{tag}"], fro64, G_RTOL, **tags)
+        sb, si, sj = g["sb"].long(), g["si"].long(), g["sj"].long()
+        close_or_fp64(case, f"dQ_samples_{tag}", dQ[sb.to(dQ.device), si.to(dQ.device), sj.to(dQ.device)],
+                      g[f"dQ_samples_{tag}"], t64[0][sb, si, sj], G_RTOL, **tags)
 
 
 @pytest.mark.parametrize("linsolve", ["lu", "spd"])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_g4_headline_config3(dev, mode, linsolve):
     g = load_golden("g4_b128_n500_eq")
-    inp = O.create_qp_data(500, 128, seed=0)
-    sol, a = solve(dev, inp, O.make_control(launch_mode=mode, linsolve=linsolve, **TOL))
+    T = g4_truth()
+    sol, a = solve(dev, T["inp"], O.make_control(launch_mode=mode, linsolve=linsolve, **TOL))
     assert sol["iter"] == g["iter"] == 60 and sol["_stats"]["n_check"] == 4 and sol["_stats"]["n_factor"] == 1
+    case = "g4_b128_n500_eq"
     for k in ("x", "u", "nus"):
-        assert err(sol[k], g[k]) < 5e-5, k
-    torch.manual_seed(7)
-    for tag, cot in (("ones", torch.ones(128, 500, 1)), ("rand", torch.randn(128, 500, 1))):
+        close_or_fp64(case, k, sol[k], g[k], T["sol"][k], X_TOL, linsolve=linsolve, mode=mode)
+    for tag, cot in T["cots"].items():
         gr = L.torch_solve_box_qp_grad(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
-        for nm, t in zip(GRADS[1:], gr[1:6]):
-            scale = max(1.0, float(g[f"{nm}_{tag}"].abs().max()))
-            assert err(t, g[f"{nm}_{tag}"]) < 2e-3 * scale, (tag, nm)
-        dQ = gr[0]
-        assert rel(torch.linalg.matrix_norm(dQ), g[f"dQ_fro_{tag}"]) < 2e-3 or tag == "ones"
-        samp = dQ[g["sb"].long(), g["si"].long(), g["sj"].long()]
-        assert err(samp, g[f"dQ_samples_{tag}"]) < 2e-3 * max(1.0, float(g[f"dQ_samples_{tag}"].abs().max()))
+        # (the functional backward = pivoted LU of the bordered system like the reference's linalg.solve (:393), plus
+        #  one refinement step: without it dl_dz = ones -- in the row space of A, dv = 0 exactly, all cancellation --
+        #  comes out with 1e-4 of fp32 LU noise, as it does from LAPACK's sgetrf/sgetrs on the same matrices:
+        #  tests/tools/gpu_lu_accuracy.py)
+        check_g4_grads(case, g, gr, tag, T["grads"][tag], linsolve=linsolve, mode=mode, backward="lu")
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_the_benched_step_matches_g4(dev, sync):
+    """Exactly what bench.py times: SolveBoxQP module call with bench.py's control (sync=False: the whole schedule
+    enqueued without waiting, two-workgroup factorisation and loop, Cholesky backward), B=128 n=500 seed 0,
+    x.backward(ones) and a random cotangent -- against the reference-made G4 vectors."""
+    g = load_golden("g4_b128_n500_eq")
+    T = g4_truth()
+    Q, p, A, b, lb, ub = (t.to(dev) for t in T["inp"])
+    control = L.box_qp_control(eps_rel=1e-5, eps_abs=1e-5, verbose=False, reduce='max')
+    control['sync'] = sync
+    layer = L.SolveBoxQP(control=control)
+    case = "g4_benched_step"
+    for tag, cot in T["cots"].items():
+        Qg, pg = Q.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        Ag, bg = A.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        lbg, ubg = lb.clone().requires_grad_(True), ub.clone().requires_grad_(True)
+        x = layer(Qg, pg, Ag, bg, lbg, ubg)
+        st = SB.last_forward_status(dev)
+        assert st["iters"] == 60 and st["linsolve_used"] == 2 and st["mode_used"] == (2 if sync else 3)
+        assert st["loop_workgroups_per_qp"] == 2 and st["factor_launches"] > 1      # the small-batch schedules
+        x.backward(cot.to(dev))
+        L.synchronize()
+        close_or_fp64(case, "x", x, g["x"], T["sol"]["x"], X_TOL, sync=sync)
+        gr = (Qg.grad, pg.grad, Ag.grad, bg.grad, lbg.grad, ubg.grad)
+        check_g4_grads(case, g, gr, tag, T["grads"][tag], sync=sync, backward="cholesky")
 
 
 def test_g5_config4_n1000(dev):
@@ -235,7 +335,8 @@ def test_g5_config4_n1000(dev):
     inp = O.create_qp_data(1000, 128, seed=0)
     sol, _ = solve(dev, inp, O.make_control(**TOL))
     assert sol["iter"] == g["iter"] == 60
-    assert err(sol["x"], g["x"]) < 5e-5 and rel(sol["rho"], g["rho"]) < 1e-4
+    P.record("g5_b128_n1000_eq", "x", err(sol["x"], g["x"]), linsolve=sol["_stats"]["linsolve_used"])
+    assert err(sol["x"], g["x"]) < 2 * X_TOL and rel(sol["rho"], g["rho"]) < 1e-4
 
 
 
@@ -284,9 +385,10 @@ def test_spd_and_lu_paths_agree(dev, n, m, B):
 
 
 def test_spd_path_falls_back_to_lu(dev):
-    """A Q that is not symmetric, or Q + rho I that is not positive definite, is outside the symmetric
-    x-update: the synchronous call repeats on the LU path by itself (same answer as linsolve='lu'); the
-    un-synchronised module call reports it late."""
+    """A Q that is not symmetric, or Q + rho I that is not positive definite, is outside the symmetric x-update.
+    Default (synchronous) calls -- functional AND module -- repeat on the LU path by themselves (same answer as
+    linsolve='lu', like the reference, which accepts any nonsingular KKT matrix); an un-synchronised module call
+    (control['sync']=False) returns NaN, never plausible numbers, and reports the error late."""
     Q, p, A, b, lb, ub = O.create_qp_data(40, 4, seed=5)
     Qn = Q.clone()
     Qn[:, 3, 17] += 0.05                                   # not symmetric
@@ -295,15 +397,27 @@ def test_spd_path_falls_back_to_lu(dev):
         ctl = dict(max_iters=200, **TOL)
         s_auto, _ = solve(dev, (Qx, p, A, b, lb, ub), O.make_control(**ctl))
         s_lu, _ = solve(dev, (Qx, p, A, b, lb, ub), O.make_control(linsolve="lu", **ctl))
-        assert s_auto["iter"] == s_lu["iter"]
+        assert s_auto["iter"] == s_lu["iter"] and s_auto["_stats"]["linsolve_used"] == 1
         assert torch.equal(torch.nan_to_num(s_auto["x"]), torch.nan_to_num(s_lu["x"]))   # (indefinite: may diverge)
-    L.SolveBoxQP(control=L.box_qp_control(**TOL))(*(t.to(dev) for t in (Qn, p, A, b, lb, ub)))
+    args = [t.to(dev) for t in (Qn, p, A, b, lb, ub)]
+    # the module's default path: non-symmetric Q solved (LU fallback), gradients through the LU backward
+    Qg = args[0].clone().requires_grad_(True)
+    x_def = L.SolveBoxQP(control=L.box_qp_control(**TOL))(Qg, *args[1:])
+    x_lu = L.SolveBoxQP(control=L.box_qp_control(linsolve="lu", **TOL))(*args)
+    assert torch.isfinite(x_def).all() and torch.equal(x_def.detach(), x_lu)
+    ref = O.solve_box_qp(Qn, p, A, b, lb, ub, O.make_control(**TOL))
+    assert err(x_def, ref["x"]) < 5e-5
+    x_def.sum().backward()
+    assert torch.isfinite(Qg.grad).all()
+    # pipelined mode: NaN + late error, then the queue is clean again
+    x_async = L.SolveBoxQP(control=L.box_qp_control(sync=False, **TOL))(*args)
     with pytest.raises(RuntimeError, match="linsolve"):
         L.synchronize()
+    assert torch.isnan(x_async).all()
     L.synchronize()
-    x = L.SolveBoxQP(control=L.box_qp_control(linsolve="lu", **TOL))(*(t.to(dev) for t in (Qn, p, A, b, lb, ub)))
+    x = L.SolveBoxQP(control=L.box_qp_control(linsolve="lu", sync=False, **TOL))(*args)
     L.synchronize()
-    assert torch.isfinite(x).all()
+    assert torch.isfinite(x).all() and torch.equal(x, x_lu)
 
 
 @pytest.mark.parametrize("case", ["g2", "g4", "g6"])
@@ -334,11 +448,17 @@ def test_cholesky_backward_matches_goldens_and_lu(dev, case):
                    sync=True, linsolve=2)
     used = _lib.profile(); _lib.profile(enable=False)
     assert used["bwd_cholesky"][1] == 1 and used["lu_factor"][1] == 0          # really the Cholesky path
+    # fp64 gradients from the fp64 forward of the same inputs (same iteration count)
+    d = [t.double() for t in inp]
+    c64 = dict(ctl, eps_abs=1e-12, eps_rel=1e-12, max_iters=sol["iter"] + 1)
+    s64 = O.solve_box_qp(*d, c64)
+    g64 = O.solve_box_qp_grad(cot.double(), s64["x"], s64["u"], s64["lams"], s64["nus"], d[0], d[2], d[4], d[5], s64["rho"])
     for idx, nm in enumerate(GRADS):
         scale = max(1.0, float(out[1][idx].abs().max()))
+        P.record(f"chol_vs_lu_{case}", nm, err(out[2][idx], out[1][idx]), scale)
         assert err(out[2][idx], out[1][idx]) < 2e-4 * scale, nm
         if nm in ref:
-            assert err(out[2][idx], ref[nm]) < 2e-3 * max(1.0, float(ref[nm].abs().max())), nm
+            close_or_fp64(f"chol_backward_{case}", nm, out[2][idx], ref[nm], g64[idx], G_RTOL)
 
 
 def test_cholesky_backward_falls_back(dev):
@@ -465,23 +585,27 @@ def test_module_path_does_not_sync_and_defers_errors(dev):
     """SolveBoxQP (autograd path) enqueues the whole schedule without waiting for the GPU; results are
     the same as the synchronous path, errors surface at a later call / lqp_py_amd.synchronize()."""
     inp = [t.to(dev) for t in O.create_qp_data(48, 6, seed=2)]
-    x_async = L.SolveBoxQP(control=L.box_qp_control(**TOL))(*inp)
-    x_sync = L.SolveBoxQP(control=L.box_qp_control(sync=True, **TOL))(*inp)
+    x_async = L.SolveBoxQP(control=L.box_qp_control(sync=False, **TOL))(*inp)
+    x_sync = L.SolveBoxQP(control=L.box_qp_control(**TOL))(*inp)            # default: waits, raises at the call
     L.synchronize()
     assert torch.equal(x_async, x_sync)
     # adaptive rho firing inside the speculative schedule (G6): still the reference's answer
     g = load_golden("g6_adaptive_scale")
     a = [g[k].to(dev) for k in ("Q", "p", "A", "b", "lb", "ub")]
-    xa = L.SolveBoxQP(control=L.box_qp_control(rho=100.0, scale=True, **TOL))(*a)
+    xa = L.SolveBoxQP(control=L.box_qp_control(rho=100.0, scale=True, sync=False, **TOL))(*a)
     L.synchronize()
     assert err(xa, g["x"]) < 5e-5
-    # singular KKT: no exception at the call, RuntimeError when the status arrives
+    # singular KKT.  Default: RuntimeError at the call, like torch.linalg.lu_factor in the reference (:215) ...
     Qz = torch.zeros(2, 6, 6, device=dev)
     pz = torch.ones(2, 6, 1, device=dev)
     lbz, ubz = -torch.ones(2, 6, 1, device=dev), torch.ones(2, 6, 1, device=dev)
-    L.SolveBoxQP(control={"rho": 0.0, "scale": False})(Qz, pz, None, None, lbz, ubz)
+    with pytest.raises(RuntimeError, match="singular"):
+        L.SolveBoxQP(control={"rho": 0.0, "scale": False})(Qz, pz, None, None, lbz, ubz)
+    # ... pipelined: no exception at the call, NaN results, RuntimeError when the status arrives
+    xz = L.SolveBoxQP(control={"rho": 0.0, "scale": False, "sync": False})(Qz, pz, None, None, lbz, ubz)
     with pytest.raises(RuntimeError, match="singular"):
         L.synchronize()
+    assert torch.isnan(xz).all()
     L.synchronize()          # queue drained
 
 
@@ -564,7 +688,7 @@ def test_bench_json_contract(dev):
     import sys as _sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([_sys.executable, os.path.join(repo, "bench.py"), "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=300)
+                          "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -579,9 +703,13 @@ def test_bench_json_contract(dev):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.0
+    assert r["bound"] in ("hbm", "mfma") and r["peak"] in (8000.0, 157.3) and r["frac"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["roofline_factorisation"]["bound"] == "mfma" and 0 < d["roofline_factorisation"]["frac"] < 1.0
+    assert d["roofline_loop"]["bound"] == "hbm" and d["roofline_loop"]["iterations"] == 61
+    assert d["config"]["iters"] == 60 and d["config"]["checks"] == 4 and d["config"]["launch_mode"] == 3
+    e1 = d["experiment_1_protocol"]
+    assert e1["simulations"] == 10 and e1["QPs_per_sec_median"] > 1000
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -641,3 +769,124 @@ def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeyp
         assert abs(s1["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
         assert err(s1["x"], ref["x"]) < 5e-4 * max(1.0, float(ref["x"].abs().max()))
     assert sols["1", 100.0]["_stats"]["n_factor"] >= 2
+
+
+# ---------------------------------------------------------------- config 5: the per-GPU shard of B=8192 over 8 GPUs
+def test_config5_shard_b1024_n500(dev):
+    """BASELINE configs[4]: batch 8192 dz 500 sharded over 8 GPUs = 1024 QPs per GPU, forward + backward through the
+    module.  B > 256 CUs: one launch per check segment, one workgroup per QP.  Checked against the CPU oracle on 16
+    problems (its iteration count pinned to the GPU's: the stop is decided by ALL 1024 problems) and, at full size,
+    through the KKT conditions."""
+    B, n = 1024, 500
+    inp = O.create_qp_data(n, B, seed=0)
+    Q, p, A, b, lb, ub = (t.to(dev) for t in inp)
+    Qg, pg = Q.clone().requires_grad_(True), p.clone().requires_grad_(True)
+    x = L.SolveBoxQP(control=L.box_qp_control(**TOL))(Qg, pg, A, b, lb, ub)
+    st = SB.last_forward_status(dev)
+    assert st["mode_used"] == 1 and st["linsolve_used"] == 2 and st["loop_workgroups_per_qp"] == 1
+    assert 40 <= st["iters"] <= 100 and st["iters"] % 20 == 0
+    torch.manual_seed(3)
+    cot = torch.randn(B, n, 1)
+    x.backward(cot.to(dev))
+    sol = L.torch_solve_box_qp(Q, p, A, b, lb, ub, L.box_qp_control(**TOL))
+    assert sol["iter"] == st["iters"] and torch.equal(sol["x"], x.detach())
+    # ---- 16 problems against the oracle at the same iteration count ----
+    idx = torch.arange(0, B, B // 16)
+    sub = [t[idx] for t in inp]
+    ref = O.solve_box_qp(*sub, O.make_control(eps_abs=1e-12, eps_rel=1e-12, max_iters=st["iters"] + 1))
+    for k in ("x", "u", "nus", "lams"):
+        e = err(sol[k][idx.to(dev)], ref[k])
+        P.record("config5_shard_b1024_n500", k, e)
+        assert e < 2 * X_TOL, k
+    gref = O.solve_box_qp_grad(cot[idx], ref["x"], ref["u"], ref["lams"], ref["nus"], sub[0], sub[2], sub[4], sub[5], ref["rho"])
+    for nm, t, r in (("dp", pg.grad, gref[1]), ("dQ", Qg.grad, gref[0])):
+        scale = max(1.0, float(r.abs().max()))
+        e = err(t[idx.to(dev)], r)
+        P.record("config5_shard_b1024_n500", nm, e, scale)
+        assert e < 5 * G_RTOL * scale, nm
+    # ---- full size: KKT conditions ----
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sol.items()}
+    res = O.kkt_residuals(*inp, cpu)
+    assert float(res["stationarity"].max()) < 2e-3 and float(res["equality"].max()) < 2e-4
+    assert float(res["box"].max()) < 1e-6 and float(res["x_minus_z"].max()) < 2e-4
+    assert float((cpu["lams"] < 0).sum()) == 0 and torch.isfinite(Qg.grad).all()
+
+
+# ---------------------------------------------------------------- the reference's "hard" distribution in float32
+@pytest.mark.parametrize("shift", [1e-2, 1e-3, 1e-4, 0.0])
+def test_hard_distribution_fp32_and_conditioning_sweep(dev, shift):
+    """experiments/utils.py:64-131 (sparse G, Q = G^T G + shift I, sqrt(n) equality rows) in FLOAT32.  shift = 1e-2
+    is the reference's generator; smaller shifts push the condition number of Q up.  Both x-updates are checked
+    against an fp64 solve of the same inputs, next to the fp32 CPU oracle (= the reference's arithmetic): the explicit
+    inverse of the default path must not be further from fp64 than 4x the pivoted LU's error (+1e-4), or it must
+    have fallen back to LU by itself.  Conditioning and errors go to the parity report."""
+    n, seeds = 100, list(range(8))
+    inp64 = list(O.create_hard_qp_data(n, 0.85, seeds))
+    inp64[0] = inp64[0] + (shift - 1e-2) * torch.eye(n, dtype=torch.float64)
+    inp32 = [t.float() for t in inp64]
+    cond = float(torch.linalg.cond(inp64[0]).max())
+    ctl = O.make_control(**TOL)
+    o32 = O.solve_box_qp(*inp32, dict(ctl))
+    s64 = O.solve_box_qp(*inp64, dict(ctl))
+    scale = max(1.0, float(s64["x"].abs().max()))
+    e_o32 = err(o32["x"], s64["x"])
+    errs, used = {}, {}
+    for ls in ("lu", "auto"):
+        sol, _ = solve(dev, inp32, dict(ctl, linsolve=ls))
+        assert torch.isfinite(sol["x"]).all()
+        errs[ls], used[ls] = err(sol["x"], s64["x"]), sol["_stats"]["linsolve_used"]
+        res = O.kkt_residuals(*inp32, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sol.items()})
+        P.record("hard_fp32", "x", errs[ls], scale, linsolve=ls, linsolve_used=used[ls], shift=shift, cond_Q=cond,
+                 iters=sol["iter"], iters_oracle_fp32=o32["iter"], iters_fp64=s64["iter"], oracle_fp32_vs_fp64=e_o32,
+                 stationarity=float(res["stationarity"].max()), equality=float(res["equality"].max()))
+        assert float(res["box"].max()) < 1e-5
+    assert used["lu"] == 1
+    # the stopping test is an fp32 threshold: all three fp32 runs land within the tolerance band of fp64
+    band = 50 * TOL["eps_abs"] * scale + 4 * e_o32
+    assert errs["lu"] < band, (errs, e_o32)
+    assert used["auto"] == 1 or errs["auto"] < 4 * errs["lu"] + 1e-4 * scale, (errs, used, cond)
+
+
+def test_per_problem_beta_tensor(dev):
+    """control['beta'] may be a (B,1) tensor (reference :171-175 broadcasts it against D)."""
+    inp = O.create_qp_data(30, 5, seed=2)
+    beta = torch.tensor([[0.1], [0.3], [0.5], [0.7], [0.9]])
+    ref = O.solve_box_qp(*inp, O.make_control(beta=beta, **TOL))
+    for ls in ("lu", "spd"):
+        sol, _ = solve(dev, inp, O.make_control(beta=beta.to(dev), linsolve=ls, **TOL))
+        assert sol["iter"] == ref["iter"]
+        for k in ("x", "u", "lams", "nus", "rho"):
+            assert err(sol[k], ref[k]) < 2e-5, (ls, k)
+    one = O.solve_box_qp(*inp, O.make_control(beta=0.3, **TOL))
+    sol, _ = solve(dev, inp, O.make_control(beta=torch.tensor(0.3), **TOL))
+    assert err(sol["x"], one["x"]) < 2e-5
+    with pytest.raises(ValueError, match="beta"):
+        solve(dev, inp, O.make_control(beta=torch.ones(3, 1), **TOL))
+
+
+def test_two_streams_do_not_share_a_workspace(dev):
+    """Workspaces are keyed by (device, stream, tag): two forwards in flight on two streams keep their own factors."""
+    a = [t.to(dev) for t in O.create_qp_data(300, 16, seed=1)]
+    b = [t.to(dev) for t in O.create_qp_data(300, 16, seed=2)]
+    ctl = dict(L.box_qp_control(**TOL), sync=False)
+    ref_a = L.SolveBoxQP(control=dict(ctl))(*a)
+    ref_b = L.SolveBoxQP(control=dict(ctl))(*b)
+    L.synchronize()
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(s1):
+        xa = L.SolveBoxQP(control=dict(ctl))(*a)
+    with torch.cuda.stream(s2):
+        xb = L.SolveBoxQP(control=dict(ctl))(*b)
+    torch.cuda.synchronize(dev)
+    L.synchronize()
+    assert torch.equal(xa, ref_a) and torch.equal(xb, ref_b)
+
+
+def test_lqp_py_alias_resolves_to_the_hip_layer(dev):
+    from lqp_py.solve_box_qp_admm_torch import SolveBoxQP, torch_solve_box_qp
+    from lqp_py.control import box_qp_control
+    assert SolveBoxQP is L.SolveBoxQP and torch_solve_box_qp is L.torch_solve_box_qp
+    inp = [t.to(dev) for t in O.create_qp_data(20, 3, seed=0)]
+    x = SolveBoxQP(control=box_qp_control(**TOL))(*inp)
+    assert x.is_cuda and err(x, O.solve_box_qp(*O.create_qp_data(20, 3, seed=0), O.make_control(**TOL))["x"]) < 2e-5
