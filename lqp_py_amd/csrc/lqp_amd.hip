@@ -218,7 +218,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     Carver c(ws);
     P.status = c.take<int>(ST_WORDS);
     P.counters = c.take<unsigned int>((size_t)kRing * CT_WORDS);
-    P.info = c.take<int>(B);
+    P.info = c.take<int>(B);            // (status | counters | info: one contiguous region for the deferred error fetch)
     P.scal = c.take<T>((size_t)B * SC_WORDS);
     P.vecs = c.take<T>((size_t)B * P.vstride);
     P.piv = c.take<int>((size_t)B * P.Np);

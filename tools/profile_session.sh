@@ -1,11 +1,10 @@
 #!/bin/bash
 # regenerates the material of profiles/<tag>_* under gpurun_out/<tag>/ (run on the GPU box from the repo root)
-# usage: tools/profile_session.sh r01_i ; then copy bench*.log, bench_kernel_stats.csv, traffic.json to profiles/<tag>_*
-root=$(pwd); tag=${1:-r01_x}; out=$root/gpurun_out/$tag; mkdir -p $out
+# usage: tools/profile_session.sh r02_a ; then copy bench*.log, bench_kernel_stats.csv, traffic.json, pmc_sq_raw.json to profiles/<tag>_*
+root=$(pwd); tag=${1:-r02_x}; out=$root/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"
-timeout -k 10 300 python3 $root/bench.py --steps 20 --warmup 5 > $out/bench.json.log 2>$out/bench.err || exit 1
-timeout -k 10 200 python3 $root/bench.py --steps 20 --warmup 5 --linsolve lu --no-cpu-baseline --no-other-configs > $out/bench_linsolve_lu.json.log 2>>$out/bench.err || exit 1
+timeout -k 10 400 python3 $root/bench.py > $out/bench.json.log 2>$out/bench.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $out/kt.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- $B > $out/write.log 2>&1 || exit 1
