@@ -33,8 +33,10 @@ constexpr int SPD_MAXM = 16;        // equality rows handled by the rank-m corre
 __host__ __device__ constexpr int sym_blocks(int K) { return K * (K + 1) / 2; }
 // stream index of lower block (i, j), i >= j: column-major over the lower triangle
 __host__ __device__ constexpr int sym_idx(int i, int j, int K) { return j * K - j * (j - 1) / 2 + (i - j); }
+constexpr int PIV_NB = 4;                            // pivot columns per LDS exchange of the pivot-block elimination
+constexpr int PIV_LDS = 2 * PIV_NB * 64 + 64;        // floats: coefficients [2][PIV_NB][64] | scales [64]
 __host__ __device__ inline int spd_lds_bytes(int K) {
-    return ((K > 1 ? K - 1 : 1) + 2) * 64 * SPD_LS * 4 + 4 * 64 * 4 + 16;
+    return ((K > 1 ? K - 1 : 1) + 2) * 64 * SPD_LS * 4 + PIV_LDS * 4 + 16;
 }
 
 // ---- packed lower blocks <- K = src (+ rho on the diagonal), identity on the padding ----
@@ -227,6 +229,8 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
     // the barrier count.
     const int prw = tid & 63, pq = w;            // (waves 0..3 sit on four different SIMDs: 0,4,8,12 measured 2x slower)
     const bool pwork = pq < 4;
+    float* const coefs = pcol;                   // [2][PIV_NB][64]: elimination coefficients of the current panel
+    float* const svals = pcol + 2 * PIV_NB * 64; // [64]: 1 / sqrt(pivot)
     float xq[16];
     if (pwork) {
         const float* src = src_blk + prw * 64 + pq * 16;
@@ -238,42 +242,67 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
         }
     }
     __syncthreads();                           // previous step's LDS reads are over
+    // Columns are eliminated in PANELS of PIV_NB: the wave that holds the panel's columns (all 64 rows of them, in
+    // registers) runs its PIV_NB column steps alone -- pivot from its own lane c by v_readlane, no LDS -- and
+    // publishes the PIV_NB coefficient columns once; after ONE barrier every wave applies the PIV_NB rank-1 updates to
+    // its own 16 columns (pivot rows again from its own lane c).  Every element sees the same operations in the
+    // same order as in the column-by-column form (64 barriers, measured 48k cycles per block): identical bits,
+    // a quarter of the synchronisations.
     if (pwork) {
-        int bad = 0;                           // first non-positive pivot of this block (+1)
-        float srow = 1.f;                      // scale of this lane's row once it has been the pivot row
 #pragma unroll 1
         for (int qc = 0; qc < 4; ++qc) {
 #pragma unroll
-            for (int ec = 0; ec < 16; ++ec) {
-                const int c = qc * 16 + ec;
-                const int par = ec & 1;
-                if (pq == qc) pcol[par * 64 + prw] = xq[ec];
+            for (int pp = 0; pp < 16 / PIV_NB; ++pp) {
+                const int c0 = qc * 16 + pp * PIV_NB;
+                float* cf = coefs + (pp & 1) * PIV_NB * 64;
+                if (pq == qc) {
+#pragma unroll
+                    for (int t = 0; t < PIV_NB; ++t) {
+                        const int ec = pp * PIV_NB + t, c = c0 + t;
+                        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[ec]), c));
+                        const bool ok = d > 0.f;
+                        if (!ok && prw == 0 && flag[0] == 0) flag[0] = kbase + c + 1;     // first non-positive pivot
+                        const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
+                        const bool below = prw > c, on = prw == c;
+                        // rows below the pivot: x -= (x_rc / d) * (pivot row); the pivot row keeps its raw values and
+                        // is scaled by s when W is written (it is final: nobody reads it again)
+                        const float coef = below ? xq[ec] * s * s : 0.f;
+                        float pr[PIV_NB];
+#pragma unroll
+                        for (int t2 = 0; t2 < PIV_NB; ++t2)
+                            pr[t2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[pp * PIV_NB + t2]), c));
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t2 = 0; t2 < PIV_NB; ++t2) xq[pp * PIV_NB + t2] -= coef * pr[t2];
+                        xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
+                        cf[t * 64 + prw] = coef;
+                        if (prw == 0) svals[c] = s;
+                    }
+                }
                 wg_barrier_lds();
-                const float d = pcol[par * 64 + c];
-                const float pc = pcol[par * 64 + prw];
-                const bool ok = d > 0.f;
-                if (!ok && bad == 0) bad = kbase + c + 1;
-                const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
-                const bool below = prw > c, on = prw == c;
-                // rows below the pivot: x -= (x_rc / d) * (pivot row); the pivot row keeps its raw values and
-                // remembers its scale s (it is final: nobody reads it again), applied when W is written
-                const float coef = below ? pc * s * s : 0.f;
-                if (on) srow = s;
-                // the pivot row comes from this wave's own lane c: all 16 v_readlane first, into 16 different
-                // SGPRs (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
-                // readlane -> fma -> readlane chain then costs ~35 cycles per element)
-                float pr[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < PIV_NB; ++t) {
+                    const int c = c0 + t;
+                    const float coef = cf[t * 64 + prw];
+                    // the pivot row comes from this wave's own lane c: all 16 v_readlane first, into 16 different
+                    // SGPRs (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
+                    // readlane -> fma -> readlane chain then costs ~35 cycles per element)
+                    float pr[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) xq[e] -= coef * pr[e];
-                __builtin_amdgcn_sched_barrier(0);
-                if (pq == qc) xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
+                    for (int e = 0; e < 16; ++e)
+                        pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float upd = xq[e] - coef * pr[e];
+                        if (e / PIV_NB == pp) xq[e] = (pq == qc) ? xq[e] : upd;      // (the owner's panel columns are done)
+                        else xq[e] = upd;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
-        if (bad != 0 && tid == 0 && flag[0] == 0) flag[0] = bad;
+        const float srow = svals[prw];             // scale of this lane's row (written before the last barrier)
         // W (lower, zero above the diagonal) and W^T
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -290,7 +319,7 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
         }
     } else {
 #pragma unroll 1
-        for (int c = 0; c < 64; ++c) wg_barrier_lds();
+        for (int c = 0; c < 64 / PIV_NB; ++c) wg_barrier_lds();
     }
 }
 
@@ -314,7 +343,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
     float* W = Y + (size_t)nslot * 64 * SPD_LS;    // L^-1 of the pivot block (lower)
     float* WT = W + 64 * SPD_LS;                   // its transpose
     float* pcol = WT + 64 * SPD_LS;                // [2][64] pivot column, by column parity
-    int* flag = (int*)(pcol + 256);
+    int* flag = (int*)(pcol + PIV_LDS);
     if (tid == 0) flag[0] = 0;
     unsigned long long tp = 0, ty = 0, tu = 0, t0 = 0, tb = dbg ? clock64() : 0;   // debug cycle counters
 
@@ -840,7 +869,7 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
     float* W = Y + (size_t)nslot * 64 * SPD_LS;
     float* WT = W + 64 * SPD_LS;
     float* pcol = WT + 64 * SPD_LS;
-    int* flag = (int*)(pcol + 256);
+    int* flag = (int*)(pcol + PIV_LDS);
     if (tid == 0) flag[0] = 0;
     for (int k = 0; k < K; ++k) {
         const int np = K - 1 - k;                           // panel blocks below the pivot: slot s <-> row k+1+s
