@@ -227,7 +227,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
     // granules of the two-workgroup loop (only ever used when 2 B workgroups fit the chip)
-    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * XCHG_WORDS) : nullptr;
+    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + 1)) : nullptr;
     L.bytes = c.off + kAlign;
     return L;
 }
@@ -292,6 +292,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd_split = env_int("LQP_SPD_SPLIT", spd_split ? 1 : 0) != 0;
         spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
     }
+    // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
+    const bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK &&
+                              env_int("LQP_SPD_RESIDENT", 1) != 0;
     // factorise (gate == nullptr) or refactorise under the device-side gate of k_rho_update
     auto factor_step = [&](const int* gate) -> int {
         if constexpr (sizeof(T) == 4) {
@@ -307,10 +310,22 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     if (!r3) r3 = ensure_lds((const void*)k_spd_end, lds);
                     if (r3) return r3;
                     hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
-                    for (int k = 0; k < P.Ks; ++k)
-                        hipLaunchKernelGGL(k_spd_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
+                    if (spd_resident) {
+                        // all pivot steps in one launch, the matrix in the registers of its two workgroups
+                        auto rfn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6>
+                                 : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
+                        const int rlds = spd_lds_bytes(P.Ks);
+                        r3 = ensure_lds((const void*)rfn, rlds);
+                        if (r3) return r3;
+                        hipLaunchKernelGGL(rfn, dim3(B * SPD_NP), dim3(RS_NT), rlds, st, P, gate);
+                        n_launch += 1;
+                    } else {
+                        for (int k = 0; k < P.Ks; ++k)
+                            hipLaunchKernelGGL(k_spd_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
+                        n_launch += P.Ks;
+                    }
                     hipLaunchKernelGGL(k_spd_end, dim3(B), dim3(LQP_NT), lds, st, P, gate);
-                    n_launch += P.Ks + 2;
+                    n_launch += 2;
                     return LQP_OK;
                 }
                 hipLaunchKernelGGL(k_spd_inverse, dim3(B), dim3(LQP_NT), lds, st, P, gate);

@@ -18,6 +18,8 @@ enum { CT_NOTOPT = 0, CT_ARRIVE = 1, CT_WANTS = 2, CT_TRIG = 3, CT_WORDS = 4 };
 // per-problem scalars
 enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_PRI = 4, SC_DUA = 5, SC_WORDS = 8 };   // PRI/DUA: errors of the last check
 
+constexpr int XCHG_WORDS = 2 * 2 * SPD_MAXK * LQP_NB;       // exchange granules per QP of the two-workgroup loop: [parity][part][element]
+
 template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
     int Ks, sym_rl, sym_rl_hot;          // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * (2 * 2 * SPD_MAXK * LQP_NB);
         for (int i = tid; i < 2 * 2 * SPD_MAXK * LQP_NB; i += LQP_NT) xq[i] = 0ull;
+        if (tid == 0) P.xchg[(size_t)P.B * (2 * 2 * SPD_MAXK * LQP_NB) + b] = 0ull;      // step flags of the resident sweep
     }
 
     // ---- ||p||_inf on the unscaled p (:127) ----
@@ -697,6 +700,19 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, c
     wg_spd_sweep<SPD_NP>(spd_half(P, b, (P.Ks - k) & 1), P.Ks, P.info + b, smem, nullptr, spd_half(P, b, (P.Ks - k - 1) & 1),
                          k, k + 1, part, P.M + (size_t)b * P.Np * P.Np, pivot_tasks);
 }
+// all pivot steps in ONE launch, the matrix resident in the registers of its two workgroups (lqp_spd.cuh).  Reads the
+// blocks k_spd_begin built (half Ks & 1 of the packed area), leaves -(Qs + rho I)^-1 in half 0, where the loop reads it.
+// Exchange buffer: the (unused on this path) KKT-matrix area; step flags: behind the loop's exchange granules.
+template <int KS>
+__global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P, const int* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD
+    unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 2;
+    const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
+    wg_spd_sweep_resident<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
+                              P.info + b, P.status + ST_TIMEOUT, smem);
+}
 __global__ __launch_bounds__(LQP_NT) void k_spd_end(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
@@ -1063,7 +1079,6 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
 // LDS (floats; every offset but the last three arrays is a compile-time constant):
 //   [rl blocks] v yrow cvl part[NW][Nps] z u ps lb ub D xs sz su sx (Nps each) red[NW*8+8] flags[8] | bs nus snu (m each)
 // ---------------------------------------------------------------------------
-constexpr int XCHG_WORDS = 2 * 2 * SPD_MAXK * LQP_NB;       // granules per QP: [parity][part][element]
 template <int NT> __host__ __device__ constexpr int split_loop_lds_floats(int Ks) {
     return split_lds_blocks<NT>(Ks) * LQP_BLK + (3 + NT / 64 + 10) * Ks * LQP_NB + (NT / 64) * 8 + 8 + 8;
 }

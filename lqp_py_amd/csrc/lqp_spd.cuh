@@ -855,6 +855,187 @@ __device__ __forceinline__ float split_combine(const int e, const int Np, const 
 }
 
 // ---------------------------------------------------------------------------
+// Register-resident sweep (small batches: 2 B <= #CUs): the same block symmetric sweep with the matrix held ON CHIP
+// for all K pivot steps.  Two workgroups of 512 threads share a matrix; each keeps its half of the tiles (the
+// column pairs of the two-workgroup loop, 18 tiles at K = 8) in registers in the MFMA accumulator layout -- tile =
+// four 32x32 quadrants, quadrant q of the workgroup's list sits in slot q / 8 of wave q % 8: 9 slots x 16 = 144 of
+// the 256 VGPRs a 512-thread workgroup has.  Per pivot step only the pivot tile and the 7 panel tiles travel:
+//   publish   owners store them (write-through, sc1) to an exchange buffer (two parities: a workgroup is at most one
+//             step ahead of its partner), every wave drains its stores, one lane raises the workgroup's step flag;
+//   acquire   one lane polls the partner's flag, ONE agent-scope acquire drops the CU's stale L1 lines, barrier;
+//   stage     pivot tile -> W = L^-1, W^T (wg_pivot_block, both workgroups for themselves), panel tiles -> LDS,
+//             Y_i = P_i W^T in place;
+//   update    every resident quadrant by its kind: A_ij -= Y_i Y_j^T | A_ik = Y_i W | A_ki = W^T Y_i^T | A_kk = -W^T W.
+// The multi-launch form (k_spd_begin/step/end) moved all 36 tiles through L2/HBM in every step (1.24 GB per batch of
+// 128 at n = 500, 13x the minimum); this one reads the matrix once and writes it once.
+// ---------------------------------------------------------------------------
+constexpr int RS_NT = 512, RS_NW = RS_NT / 64;
+template <int K> __host__ __device__ constexpr int rs_slots() {
+    const int a = split_count(K, 0), b = split_count(K, 1);
+    return (4 * (a > b ? a : b) + RS_NW - 1) / RS_NW;
+}
+// (i, j) of local tile l of workgroup `part` (columns ascending, as SplitMap)
+__device__ __forceinline__ void rs_tile_of(int l, const int K, const int part, int& ti, int& tj) {
+    ti = 0; tj = 0;
+    for (int j = 0; j < K; ++j) {
+        if (split_owner(j, K) != part) continue;
+        if (l < K - j) { ti = j + l; tj = j; return; }
+        l -= K - j;
+    }
+}
+
+// xb: exchange buffer of this matrix, [2][K][4096] floats; fl: step flags of the two workgroups; epoch: added to the
+// step numbers (a refactorisation in the same forward must not match the flags of the first one)
+template <int K>
+__device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ Hsrc, float* __restrict__ Hdst,
+                                                      float* __restrict__ xb, unsigned int* __restrict__ fl,
+                                                      const unsigned int epoch, const int part, int* __restrict__ info,
+                                                      int* __restrict__ status_timeout, char* smem, const int dbg_stop = -1) {
+    constexpr int NS = rs_slots<K>();
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
+    const int nloc = split_count(K, part);
+    float* Y = (float*)smem;
+    float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
+    float* WT = W + 64 * SPD_LS;
+    float* pcol = WT + 64 * SPD_LS;
+    int* flag = (int*)(pcol + PIV_LDS);
+    if (tid == 0) flag[0] = 0;
+
+    // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
+    f32x16 T[NS];
+    int ti[NS], tj[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int l = 2 * s + (w >> 2);
+        int a, b;
+        rs_tile_of(l < nloc ? l : 0, K, part, a, b);
+        ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
+        tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
+        if (ti[s] >= 0) {
+            const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
+            if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
+                // upper-right quadrant of a diagonal tile := transpose of its lower-left one.  (Q is symmetric only to
+                // rounding; the multi-launch sweep mirrors these quadrants after every step, so this keeps the two
+                // schedules bit-identical.  Tile (0,0) is the first pivot: both use it as given.)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
+            } else {
+                const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
+            }
+        }
+    }
+
+    for (int k = 0; k < K; ++k) {
+        float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
+        // ---- publish the pivot tile and the panel tiles this workgroup holds ----
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = ti[s], j = tj[s];
+            if (i >= 0 && (i == k || j == k)) {
+                const int slot = (i == k && j == k) ? K - 1 : (j == k ? i - 1 : j);      // P_i: i > k -> i - 1, i < k -> i
+                unsigned int* dst = (unsigned int*)(xbk + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float tv = T[s][q];      // (bit_cast straight from the vector element stores element 0 sixteen times)
+                    __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(fl + part, epoch + (unsigned int)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(fl + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + (unsigned int)k + 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
+                    __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (k == dbg_stop) return;
+        // ---- pivot tile -> W, W^T; panel tiles -> LDS (slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k) ----
+        wg_pivot_block(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        {
+            const int r = tid >> 3, c8 = (tid & 7) * 8;
+#pragma unroll
+            for (int s0 = 0; s0 < K - 1; ++s0) {
+                const float* src = xbk + (size_t)s0 * LQP_BLK + tid * 8;
+                const V4<float> a = *(const V4<float>*)src, b = *(const V4<float>*)(src + 4);
+                float* Ys = Y + (size_t)s0 * 64 * SPD_LS;
+                if (s0 >= k) {
+                    *(V4<float>*)(Ys + r * SPD_LS + c8) = a;
+                    *(V4<float>*)(Ys + r * SPD_LS + c8 + 4) = b;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { Ys[(c8 + e) * SPD_LS + r] = a.v[e]; Ys[(c8 + 4 + e) * SPD_LS + r] = b.v[e]; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves), so nobody else reads
+        //      the rows it overwrites ----
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
+            if (rb < 2 * (K - 1)) {
+                float* Xp = Y + ((size_t)(rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
+                const f32x16 a0 = spd_quadrant<1, false>(Xp, W);
+                const f32x16 a1 = spd_quadrant(Xp, W + 32 * SPD_LS);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    Xp[quad_row(q, lh) * SPD_LS + li] = a0[q];
+                    Xp[quad_row(q, lh) * SPD_LS + 32 + li] = a1[q];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- every resident quadrant by its kind ----
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = ti[s], j = tj[s];
+            if (i < 0) continue;
+            if (i != k && j != k) {
+                const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
+                T[s] -= spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS, Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
+            } else if (i == k && j == k) {    // (W^T is upper triangular: rows >= 32 only see k >= 32 -- same halves,
+                                              //  hence the same summation order and bits, as the multi-launch sweep)
+                const f32x16 a = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
+                                           : spd_quadrant(WT, WT);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
+            } else if (j == k) {              // tile (i, k), i > k: Y_i W
+                const float* Yi = Y + ((size_t)(i - 1) * 64 + 32 * qi) * SPD_LS;
+                T[s] = qj == 1 ? spd_quadrant<1, true>(Yi, WT + 32 * SPD_LS) : spd_quadrant(Yi, WT);
+            } else {                          // tile (k, j), j < k: W^T Y_j^T
+                const float* Yj = Y + ((size_t)j * 64 + 32 * qj) * SPD_LS;
+                T[s] = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Yj) : spd_quadrant(WT, Yj);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the finished tiles to their home blocks ----
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (ti[s] >= 0) {
+            float* C = Hdst + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
+        }
+    }
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
+// ---------------------------------------------------------------------------
 // Blocked Cholesky of an SPD matrix held as packed lower blocks, in place (the symmetric backward system):
 //   block (i,k), i > k  <-  L_ik;   block (k,k)  <-  W_k = L_kk^-1   (so the solves below need no substitution
 //   inside a block).  Same machinery as the sweep, restricted to the trailing part: pivot block through
