@@ -33,7 +33,16 @@ constexpr int SPD_MAXM = 16;        // equality rows handled by the rank-m corre
 __host__ __device__ constexpr int sym_blocks(int K) { return K * (K + 1) / 2; }
 // stream index of lower block (i, j), i >= j: column-major over the lower triangle
 __host__ __device__ constexpr int sym_idx(int i, int j, int K) { return j * K - j * (j - 1) / 2 + (i - j); }
-constexpr int PIV_NB = 4;                            // pivot columns per LDS exchange of the pivot-block elimination
+#ifndef LQP_PIV_WAVES
+#define LQP_PIV_WAVES 16        // waves that eliminate a pivot block in a 1024-thread workgroup (4, 8 or 16)
+#endif
+#ifndef LQP_PIV_WAVES_RS
+#define LQP_PIV_WAVES_RS 8      // ... in the 512-thread resident sweep (4 or 8)
+#endif
+#ifndef LQP_PIV_NB
+#define LQP_PIV_NB 4
+#endif
+constexpr int PIV_NB = LQP_PIV_NB;                            // pivot columns per LDS exchange of the pivot-block elimination
 constexpr int PIV_LDS = 2 * PIV_NB * 64 + 64;        // floats: coefficients [2][PIV_NB][64] | scales [64]
 __host__ __device__ inline int spd_lds_bytes(int K) {
     return ((K > 1 ? K - 1 : 1) + 2) * 64 * SPD_LS * 4 + PIV_LDS * 4 + 16;
@@ -215,54 +224,65 @@ __device__ __forceinline__ int quad_row(int q, int lh) { return (q & 3) + 8 * (q
 // ---- pivot block: in-place forward elimination of [A | I] -> W = L^-1 (A = L L^T), W and W^T left in LDS ----
 // src: the 64x64 block in global memory (row-major); kbase: 64 * (index of the pivot block), for the error code.
 // Contains workgroup barriers: every thread of the workgroup must call it.
+//
+// Column c switches role from "A" to "augmented" at step c, so one 64x64 array is enough.  NWP waves work (lane = row,
+// wave = a group of CW = 64 / NWP columns): the pivot row reaches a wave through v_readlane from its own lane c, the
+// elimination coefficients through LDS.  Columns are eliminated in PANELS of PIV_NB: the wave that holds the panel's
+// columns (all 64 rows of them, in registers) runs its PIV_NB column steps alone -- pivot from its own lane c by
+// v_readlane, no LDS -- and publishes the PIV_NB coefficient columns once; after ONE barrier every wave applies the
+// PIV_NB rank-1 updates to its own columns.  Every element sees the same operations in the same order whatever NWP
+// and PIV_NB are: identical bits.  Measured per block (1024-thread workgroup, one per CU): column-by-column with a
+// barrier per column and 4 waves 48k cycles (16 waves: 57k); panels of 4 with 4 waves 36k; the per-pivot work of a
+// wave is ~2.6 instructions per column it holds, and one wave alone on its SIMD issues a VALU instruction every 4
+// cycles where two or more issue one every 2: more waves with fewer columns each run the same update sooner.
+template <int NWP>
 __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk, float* __restrict__ W,
                                                float* __restrict__ WT, float* __restrict__ pcol,
-                                               int* __restrict__ flag, const int kbase) {
+                                               int* __restrict__ flag, const int kbase,
+                                               unsigned long long* __restrict__ dbgp = nullptr) {
+    static_assert(NWP == 4 || NWP == 8 || NWP == 16, "4, 8 or 16 pivot waves");
+    unsigned long long tP = 0, tB = 0, tU = 0, tt = 0;
+    constexpr int CW = 64 / NWP;                 // columns per wave
+    static_assert(CW % PIV_NB == 0, "a panel lives in one wave");
     const int tid = threadIdx.x, w = tid >> 6;
-    // ---- pivot block: in-place forward elimination of [A_kk | I] -> W = L^-1 (A_kk = L L^T) ----
-    // Column c switches role from "A" to "augmented" at step c, so one 64x64 array is enough.  Only waves
-    // 0..3 work (lane = row, wave = 16-column quarter): the pivot row reaches a wave through v_readlane
-    // from its own lane c, the pivot column through LDS.  Measured per pivot block: 57k cycles with all 16
-    // waves on 4 elements each and a barrier per column, 48k with 4 waves and a barrier per column, 63k with
-    // the row broadcast through LDS too, 45-55k with barrier-free producer/consumer hand-overs (progress
-    // counter or sentinel slots in LDS): the barrier is not the expensive part.  The other waves only keep
-    // the barrier count.
-    const int prw = tid & 63, pq = w;            // (waves 0..3 sit on four different SIMDs: 0,4,8,12 measured 2x slower)
-    const bool pwork = pq < 4;
+    const int prw = tid & 63, pq = w;
+    const bool pwork = pq < NWP;
     float* const coefs = pcol;                   // [2][PIV_NB][64]: elimination coefficients of the current panel
     float* const svals = pcol + 2 * PIV_NB * 64; // [64]: 1 / sqrt(pivot)
-    float xq[16];
+    float xq[CW];
     if (pwork) {
-        const float* src = src_blk + prw * 64 + pq * 16;
+        const float* src = src_blk + prw * 64 + pq * CW;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < CW / 4; ++t) {
             const V4<float> v4 = *(const V4<float>*)(src + 4 * t);
 #pragma unroll
             for (int e = 0; e < 4; ++e) xq[4 * t + e] = v4.v[e];
         }
     }
     __syncthreads();                           // previous step's LDS reads are over
-    // Columns are eliminated in PANELS of PIV_NB: the wave that holds the panel's columns (all 64 rows of them, in
-    // registers) runs its PIV_NB column steps alone -- pivot from its own lane c by v_readlane, no LDS -- and
-    // publishes the PIV_NB coefficient columns once; after ONE barrier every wave applies the PIV_NB rank-1 updates to
-    // its own 16 columns (pivot rows again from its own lane c).  Every element sees the same operations in the
-    // same order as in the column-by-column form (64 barriers, measured 48k cycles per block): identical bits,
-    // a quarter of the synchronisations.
     if (pwork) {
 #pragma unroll 1
-        for (int qc = 0; qc < 4; ++qc) {
+        for (int qc = 0; qc < NWP; ++qc) {
 #pragma unroll
-            for (int pp = 0; pp < 16 / PIV_NB; ++pp) {
-                const int c0 = qc * 16 + pp * PIV_NB;
-                float* cf = coefs + (pp & 1) * PIV_NB * 64;
+            for (int pp = 0; pp < CW / PIV_NB; ++pp) {
+                const int c0 = qc * CW + pp * PIV_NB;
+                // (double buffer by panel parity: a wave is at most one barrier ahead of the slowest reader)
+                float* cf = coefs + (((qc * (CW / PIV_NB)) + pp) & 1) * PIV_NB * 64;
+                if (dbgp) tt = clock64();
                 if (pq == qc) {
+                    // the panel's column steps: one wave, everything in registers; this chain is the critical path of the
+                    // whole block, so nothing but the arithmetic sits in it (error flag and scales leave after the panel)
+                    float sreg[PIV_NB];
+                    int badc = 0;
 #pragma unroll
                     for (int t = 0; t < PIV_NB; ++t) {
                         const int ec = pp * PIV_NB + t, c = c0 + t;
                         const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[ec]), c));
-                        const bool ok = d > 0.f;
-                        if (!ok && prw == 0 && flag[0] == 0) flag[0] = kbase + c + 1;     // first non-positive pivot
-                        const float s = ok ? __builtin_amdgcn_rsqf(d) : 0.f;
+                        // (a non-positive pivot is only RECORDED here: the matrix is then not positive definite, the
+                        //  caller falls back to LU or poisons its results; keeping the test out of the arithmetic saves
+                        //  two VALU <-> SGPR round trips per column on this dependent chain)
+                        badc = (!(d > 0.f) && badc == 0) ? c + 1 : badc;
+                        const float s = __builtin_amdgcn_rsqf(d);
                         const bool below = prw > c, on = prw == c;
                         // rows below the pivot: x -= (x_rc / d) * (pivot row); the pivot row keeps its raw values and
                         // is scaled by s when W is written (it is final: nobody reads it again)
@@ -276,46 +296,55 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
                         for (int t2 = 0; t2 < PIV_NB; ++t2) xq[pp * PIV_NB + t2] -= coef * pr[t2];
                         xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
                         cf[t * 64 + prw] = coef;
-                        if (prw == 0) svals[c] = s;
+                        sreg[t] = s;
                     }
+                    float sv = sreg[0];
+#pragma unroll
+                    for (int t = 1; t < PIV_NB; ++t) sv = prw == t ? sreg[t] : sv;
+                    if (prw < PIV_NB) svals[c0 + prw] = sv;
+                    if (badc != 0 && prw == 0 && flag[0] == 0) flag[0] = kbase + badc;
                 }
+                if (dbgp) { const unsigned long long t = clock64(); tP += t - tt; tt = t; }
                 wg_barrier_lds();
+                if (dbgp) { const unsigned long long t = clock64(); tB += t - tt; tt = t; }
 #pragma unroll
                 for (int t = 0; t < PIV_NB; ++t) {
                     const int c = c0 + t;
                     const float coef = cf[t * 64 + prw];
-                    // the pivot row comes from this wave's own lane c: all 16 v_readlane first, into 16 different
-                    // SGPRs (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
+                    // the pivot row comes from this wave's own lane c: all v_readlane first, into different SGPRs
+                    // (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
                     // readlane -> fma -> readlane chain then costs ~35 cycles per element)
-                    float pr[16];
+                    float pr[CW];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
+                    for (int e = 0; e < CW; ++e)
                         pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
+                    for (int e = 0; e < CW; ++e) {
                         const float upd = xq[e] - coef * pr[e];
                         if (e / PIV_NB == pp) xq[e] = (pq == qc) ? xq[e] : upd;      // (the owner's panel columns are done)
                         else xq[e] = upd;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (dbgp) { const unsigned long long t = clock64(); tU += t - tt; }
             }
         }
+        if (dbgp && prw == 0) { dbgp[3 * pq] = tP; dbgp[3 * pq + 1] = tB; dbgp[3 * pq + 2] = tU; }
         const float srow = svals[prw];             // scale of this lane's row (written before the last barrier)
         // W (lower, zero above the diagonal) and W^T
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int q = pq * 16 + e;
+        for (int e = 0; e < CW; ++e) {
+            const int q = pq * CW + e;
             xq[e] = (q > prw) ? 0.f : xq[e] * srow;
             WT[q * SPD_LS + prw] = xq[e];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < CW / 4; ++t) {
             V4<float> v4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v4.v[e] = xq[4 * t + e];
-            *(V4<float>*)(W + prw * SPD_LS + pq * 16 + 4 * t) = v4;
+            *(V4<float>*)(W + prw * SPD_LS + pq * CW + 4 * t) = v4;
         }
     } else {
 #pragma unroll 1
@@ -360,7 +389,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             }
         }
         if (NP == 1 || k == 0) {
-            wg_pivot_block(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+            wg_pivot_block<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
         } else {      // W, W^T of this pivot block were prepared by the previous launch (lookahead below)
             for (int i = tid * 4; i < 2 * 64 * SPD_LS; i += LQP_NT * 4) *(V4<float>*)(W + i) = *(const V4<float>*)(Wg + i);
         }
@@ -463,7 +492,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                     }
                     __threadfence_block();
                     __syncthreads();
-                    wg_pivot_block(Tn, W, WT, pcol, flag, (k + 1) * 64);
+                    wg_pivot_block<LQP_PIV_WAVES>(Tn, W, WT, pcol, flag, (k + 1) * 64);
                     __syncthreads();
                     for (int i = tid * 4; i < 2 * 64 * SPD_LS; i += LQP_NT * 4) *(V4<float>*)(Wg + i) = *(const V4<float>*)(W + i);
                 }
@@ -890,7 +919,8 @@ template <int K>
 __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ Hsrc, float* __restrict__ Hdst,
                                                       float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                       const unsigned int epoch, const int part, int* __restrict__ info,
-                                                      int* __restrict__ status_timeout, char* smem, const int dbg_stop = -1) {
+                                                      int* __restrict__ status_timeout, char* smem, const int dbg_stop = -1,
+                                                      unsigned long long* __restrict__ dbg = nullptr) {
     constexpr int NS = rs_slots<K>();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -929,7 +959,9 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
         }
     }
 
+    unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
     for (int k = 0; k < K; ++k) {
+        if (dbg) dt0 = clock64();
         float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
         // ---- publish the pivot tile and the panel tiles this workgroup holds ----
 #pragma unroll
@@ -963,8 +995,10 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
         }
         __syncthreads();
         if (k == dbg_stop) return;
+        if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
         // ---- pivot tile -> W, W^T; panel tiles -> LDS (slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k) ----
-        wg_pivot_block(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        wg_pivot_block<LQP_PIV_WAVES_RS>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
         {
             const int r = tid >> 3, c8 = (tid & 7) * 8;
 #pragma unroll
@@ -982,6 +1016,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
             }
         }
         __syncthreads();
+        if (dbg) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
         // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves), so nobody else reads
         //      the rows it overwrites ----
 #pragma unroll
@@ -999,6 +1034,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
             }
         }
         __syncthreads();
+        if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
         // ---- every resident quadrant by its kind ----
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -1021,8 +1057,12 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
                 T[s] = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Yj) : spd_quadrant(WT, Yj);
             }
         }
+        if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
         __syncthreads();
+        if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
     }
+    if (dbg && tid == 0)
+        for (int q = 0; q < 6; ++q) dbg[q] = dbt[q];
     // ---- the finished tiles to their home blocks ----
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -1058,7 +1098,7 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s)
             if (s < np) preg[s] = *(const V4<float>*)(Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK + tid * 4);
-        wg_pivot_block(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        wg_pivot_block<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s)
             if (s < np) *(V4<float>*)(Y + ((size_t)s * 64 + r) * SPD_LS + cq * 4) = preg[s];
