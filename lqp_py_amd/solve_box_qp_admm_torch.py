@@ -189,7 +189,9 @@ def _finite_bounds(lb, ub):
             return res
     flags = torch.stack((torch.max(lb) > -_INF, torch.min(ub) < _INF)).tolist()
     res = (bool(flags[0]), bool(flags[1]))
-    _bounds_cache[:] = [e for e in _bounds_cache if e[0]() is not None and e[2]() is not None][-7:]
+    # (64 live pairs: a training loop that cycles over a few dozen batches must not fall back to the two reductions and
+    #  the host synchronisation of a miss on every step -- with 8 entries and 10 cycled batches every call missed)
+    _bounds_cache[:] = [e for e in _bounds_cache if e[0]() is not None and e[2]() is not None][-63:]
     _bounds_cache.append((weakref.ref(lb), lb._version, weakref.ref(ub), ub._version, res))
     return res
 
