@@ -661,6 +661,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     P.Q = (const T*)Q; P.A = (const T*)A; P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in;
     P.rho_value = (T)rho_value; P.rho_mode = rho_mode;
     P.dQ = (T*)dQ; P.dp = (T*)dp; P.dA = (T*)dA; P.db = (T*)db; P.dlb = (T*)dlb; P.dub = (T*)dub;
+    P.dbg = g_lu_dbg;
     // default: solve on the free set only (see k_bwd_build_reduced); LQP_BWD_FULL=1 keeps the full system
     P.reduced = env_int("LQP_BWD_FULL", 0) ? 0 : 1;
     const int* nvec = P.reduced ? P.nred : nullptr;

@@ -1474,6 +1474,7 @@ template <typename T> struct BwdParams {
     int chol;    // 1: the reduced system is solved through a blocked Cholesky of Q_FF (f32, symmetric Q)
     T* rhs2;     // B * Np: residual / correction of the one refinement step of the LU form (or null)
     int refine;  // 1: the epilogue adds rhs2 to rhs
+    unsigned long long* dbg;   // optional cycle counters (8 per problem), debug only
 };
 
 template <typename T>
@@ -1694,8 +1695,10 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     float* Ls = P.packed + (size_t)b * sym_blocks(Kmax) * LQP_BLK;
     const float* AF = P.M + (size_t)b * Np * Np;
     float* rhs = P.rhs + (size_t)b * Np;
+    unsigned long long dt0 = P.dbg ? clock64() : 0;
     if (Kb > 0) wg_chol_factor(Ls, Kb, P.info + b, smem);
     __syncthreads();
+    if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 0] = t - dt0; dt0 = t; P.dbg[(size_t)b * 8 + 3] = Kb; }
     float* v = (float*)smem;
     float* acc = v + Npm;
     float* u0 = acc + Npm;
@@ -1717,6 +1720,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
         for (int e = tid; e < Nb; e += LQP_NT) G[(size_t)q * Npm + e] = v[e];
         __syncthreads();
     }
+    if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 1] = t - dt0; dt0 = t; }
     if (m > 0) {
         // S = A_F G - eps I,  wv = A_F u0  (one wave per entry)
         for (int e = w; e < m * m + m; e += LQP_NW) {
@@ -1761,6 +1765,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
         rhs[a] = d;
     }
     for (int q = tid; q < m; q += LQP_NT) rhs[nf + q] = dn[q];
+    if (P.dbg && tid == 0) P.dbg[(size_t)b * 8 + 2] = clock64() - dt0;
 }
 
 // One step of iterative refinement for the LU form of the reduced system: r = rhs - M d with the ORIGINAL entries
