@@ -680,6 +680,10 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
                 hipLaunchKernelGGL(k_bwd_build_chol, dim3(B, split), dim3(LQP_NT), lds, st, P);
             }
             const int lds = bwd_chol_lds_bytes(n, m);
+            {
+                const int Kmax = round_up(n, LQP_NB) / LQP_NB;
+                P.la_maxk = !env_int("LQP_BWD_LOOKAHEAD", 1) ? 0 : (Kmax < SPD_MAXK ? Kmax : Kmax - 1);
+            }
             int r2 = ensure_lds((const void*)k_bwd_chol_solve, lds);
             if (r2) return r2;
             ProfScope ps(st, PC_BWD_CHOL);

@@ -1475,6 +1475,7 @@ template <typename T> struct BwdParams {
     T* rhs2;     // B * Np: residual / correction of the one refinement step of the LU form (or null)
     int refine;  // 1: the epilogue adds rhs2 to rhs
     unsigned long long* dbg;   // optional cycle counters (8 per problem), debug only
+    int la_maxk;               // largest block count the look-ahead Cholesky may take (LDS of the launch), 0 = off
 };
 
 template <typename T>
@@ -1681,7 +1682,8 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
 // LDS: wg_chol_factor's layout, then v | acc | u0 | G[m][Npm] | t[64] | part[NW*64] | S[m*m] | wv[m] | dn[m]
 __host__ __device__ inline int bwd_chol_lds_bytes(int n, int m) {
     const int Kmax = round_up(n, LQP_NB) / LQP_NB, Npm = Kmax * LQP_NB;
-    const int a = spd_lds_bytes(Kmax);
+    const int a0 = spd_lds_bytes(Kmax);
+    const int a = (Kmax < SPD_MAXK && chol_la_lds_bytes(Kmax) > a0) ? chol_la_lds_bytes(Kmax) : a0;
     const int c = ((3 + m) * Npm + 64 + LQP_NW * 64 + m * m + 2 * m + 8) * 4;
     return a > c ? a : c;
 }
@@ -1696,7 +1698,10 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     const float* AF = P.M + (size_t)b * Np * Np;
     float* rhs = P.rhs + (size_t)b * Np;
     unsigned long long dt0 = P.dbg ? clock64() : 0;
-    if (Kb > 0) wg_chol_factor(Ls, Kb, P.info + b, smem);
+    if (Kb > 0) {
+        if (Kb <= P.la_maxk) wg_chol_factor_la(Ls, Kb, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
+        else wg_chol_factor(Ls, Kb, P.info + b, smem);
+    }
     __syncthreads();
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 0] = t - dt0; dt0 = t; P.dbg[(size_t)b * 8 + 3] = Kb; }
     float* v = (float*)smem;

@@ -235,13 +235,45 @@ __device__ __forceinline__ int quad_row(int q, int lh) { return (q & 3) + 8 * (q
 // barrier per column and 4 waves 48k cycles (16 waves: 57k); panels of 4 with 4 waves 36k; the per-pivot work of a
 // wave is ~2.6 instructions per column it holds, and one wave alone on its SIMD issues a VALU instruction every 4
 // cycles where two or more issue one every 2: more waves with fewer columns each run the same update sooner.
-template <int NWP>
+// Synchronisation of a GROUP of waves of one workgroup through an LDS counter (the other waves of the workgroup do
+// something else meanwhile, so s_barrier cannot be used): every wave of the group adds 1 and waits until the counter
+// has reached `target` (= group size x number of syncs so far).  All waves of a workgroup are resident, so the wait
+// always ends.
+template <bool TIGHT = false>
+__device__ __forceinline__ void lds_group_sync(int* cnt, const int target) {
+    if constexpr (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS traffic only (the pivot chain)
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+        if constexpr (!TIGHT) __builtin_amdgcn_s_sleep(1);
+    if constexpr (TIGHT) asm volatile("" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_wait_ge(int* word, const int target) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// GSYNC = false: called by all waves of the workgroup (waves >= NWP only take part in the barriers).
+// GSYNC = true : called ONLY by waves 0..NWP-1 while the other waves of the workgroup do something else (s_barrier is
+//                not available then): they synchronise among themselves through the LDS counter `gaux`, `gseq` is the
+//                group's running target.  The caller guarantees that nobody still reads W / W^T and that the source
+//                block is complete.  (Measured alternative, slower: coefficients carrying a tag that the readers
+//                poll, with acknowledgements for the double buffer -- 230 k cycles for the 5.3 blocks of a backward
+//                factorisation against 195 k with the counter.)
+#ifndef LQP_PIV_PRIO
+#define LQP_PIV_PRIO 1
+#endif
+#ifndef LQP_PIV_EXP
+#define LQP_PIV_EXP 0      // timing experiments only: 1 = no panel sync, 2 = no update phase, 4 = no column steps
+#endif
+template <int NWP, bool GSYNC = false>
 __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk, float* __restrict__ W,
                                                float* __restrict__ WT, float* __restrict__ pcol,
                                                int* __restrict__ flag, const int kbase,
-                                               unsigned long long* __restrict__ dbgp = nullptr) {
+                                               int* __restrict__ gaux = nullptr, int* __restrict__ gseq = nullptr) {
     static_assert(NWP == 4 || NWP == 8 || NWP == 16, "4, 8 or 16 pivot waves");
-    unsigned long long tP = 0, tB = 0, tU = 0, tt = 0;
     constexpr int CW = 64 / NWP;                 // columns per wave
     static_assert(CW % PIV_NB == 0, "a panel lives in one wave");
     const int tid = threadIdx.x, w = tid >> 6;
@@ -259,7 +291,7 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
             for (int e = 0; e < 4; ++e) xq[4 * t + e] = v4.v[e];
         }
     }
-    __syncthreads();                           // previous step's LDS reads are over
+    if constexpr (!GSYNC) __syncthreads();     // previous step's LDS reads are over
     if (pwork) {
 #pragma unroll 1
         for (int qc = 0; qc < NWP; ++qc) {
@@ -268,8 +300,8 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
                 const int c0 = qc * CW + pp * PIV_NB;
                 // (double buffer by panel parity: a wave is at most one barrier ahead of the slowest reader)
                 float* cf = coefs + (((qc * (CW / PIV_NB)) + pp) & 1) * PIV_NB * 64;
-                if (dbgp) tt = clock64();
-                if (pq == qc) {
+                float cv[PIV_NB];
+                if (pq == qc && !(LQP_PIV_EXP & 4)) {
                     // the panel's column steps: one wave, everything in registers; this chain is the critical path of the
                     // whole block, so nothing but the arithmetic sits in it (error flag and scales leave after the panel)
                     float sreg[PIV_NB];
@@ -303,34 +335,58 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
                     for (int t = 1; t < PIV_NB; ++t) sv = prw == t ? sreg[t] : sv;
                     if (prw < PIV_NB) svals[c0 + prw] = sv;
                     if (badc != 0 && prw == 0 && flag[0] == 0) flag[0] = kbase + badc;
+                    if constexpr (!GSYNC && LQP_PIV_PRIO) __builtin_amdgcn_s_setprio(0);
                 }
-                if (dbgp) { const unsigned long long t = clock64(); tP += t - tt; tt = t; }
-                wg_barrier_lds();
-                if (dbgp) { const unsigned long long t = clock64(); tB += t - tt; tt = t; }
+                if constexpr (LQP_PIV_EXP & 1) {}
+                else if constexpr (GSYNC) lds_group_sync<true>(gaux, *gseq += NWP);
+                else wg_barrier_lds();
+                // the wave that owns the NEXT panel goes first on its SIMD: its update + column steps are the critical
+                // path, the other waves' updates fill the gaps
+                if constexpr (!GSYNC && LQP_PIV_PRIO)
+                    if (pq == ((pp + 1 < CW / PIV_NB) ? qc : qc + 1)) __builtin_amdgcn_s_setprio(3);
+                if constexpr (!(LQP_PIV_EXP & 2)) {
+                    // all coefficients of the panel in one LDS round trip (one at a time, each read's latency sits in
+                    // the dependent chain of the columns)
 #pragma unroll
-                for (int t = 0; t < PIV_NB; ++t) {
-                    const int c = c0 + t;
-                    const float coef = cf[t * 64 + prw];
-                    // the pivot row comes from this wave's own lane c: all v_readlane first, into different SGPRs
-                    // (interleaved with their FMAs the compiler funnels them through ONE SGPR, and the
-                    // readlane -> fma -> readlane chain then costs ~35 cycles per element)
-                    float pr[CW];
+                    for (int t = 0; t < PIV_NB; ++t) cv[t] = cf[t * 64 + prw];
+                    // the pivot row comes from this wave's own lane c: all v_readlane of a column first, into
+                    // different SGPRs (interleaved with their FMAs the compiler funnels them through ONE SGPR, and
+                    // the readlane -> fma -> readlane chain then costs ~35 cycles per element).  The owner's own panel
+                    // columns are final: it skips them (wave-uniform branch, no selects in the chain).
+                    if (pq == qc) {
+                        if constexpr (CW > PIV_NB) {
 #pragma unroll
-                    for (int e = 0; e < CW; ++e)
-                        pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
-                    __builtin_amdgcn_sched_barrier(0);
+                            for (int t = 0; t < PIV_NB; ++t) {
+                                const int c = c0 + t;
+                                float pr[CW];
 #pragma unroll
-                    for (int e = 0; e < CW; ++e) {
-                        const float upd = xq[e] - coef * pr[e];
-                        if (e / PIV_NB == pp) xq[e] = (pq == qc) ? xq[e] : upd;      // (the owner's panel columns are done)
-                        else xq[e] = upd;
+                                for (int e = 0; e < CW; ++e)
+                                    if (e / PIV_NB != pp)
+                                        pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int e = 0; e < CW; ++e)
+                                    if (e / PIV_NB != pp) xq[e] -= cv[t] * pr[e];
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < PIV_NB; ++t) {
+                            const int c = c0 + t;
+                            float pr[CW];
+#pragma unroll
+                            for (int e = 0; e < CW; ++e)
+                                pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int e = 0; e < CW; ++e) xq[e] -= cv[t] * pr[e];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (dbgp) { const unsigned long long t = clock64(); tU += t - tt; }
             }
         }
-        if (dbgp && prw == 0) { dbgp[3 * pq] = tP; dbgp[3 * pq + 1] = tB; dbgp[3 * pq + 2] = tU; }
         const float srow = svals[prw];             // scale of this lane's row (written before the last barrier)
         // W (lower, zero above the diagonal) and W^T
 #pragma unroll
@@ -346,7 +402,7 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
             for (int e = 0; e < 4; ++e) v4.v[e] = xq[4 * t + e];
             *(V4<float>*)(W + prw * SPD_LS + pq * CW + 4 * t) = v4;
         }
-    } else {
+    } else if constexpr (!GSYNC) {
 #pragma unroll 1
         for (int c = 0; c < 64 / PIV_NB; ++c) wg_barrier_lds();
     }
@@ -1161,6 +1217,155 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
         }
         __syncthreads();
     }
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
+// ---- the same factorisation with a LOOK-AHEAD pivot chain ---------------------------------------------------
+// The 64-column elimination chain of a diagonal block (wg_pivot_block) is latency bound and keeps four waves busy
+// for ~15 us while the other twelve wait; the panel product and the tile updates of a step take about as long again.
+// Here the workgroup is split by role: waves 0..3 run the chain of block k+1 as soon as tile (k+1,k+1) has received
+// step k's update (always the first tile the others touch), waves 4..15 do everything else of step k meanwhile.  The two
+// groups meet only through LDS words:
+//   pv   (count)  3 quadrant writers per step have put the next diagonal tile into the LDS staging tile St
+//   wrd  (step)   W / W^T of step k are in LDS
+//   ydn  (step)   the tile waves are done reading W / W^T of step k (they may be overwritten)
+// Results are bit-identical to wg_chol_factor: same products, same order inside every tile.
+// LDS: the layout of wg_chol_factor for K blocks plus the 64x64 staging tile; K <= SPD_MAXK - 1 keeps it inside
+// spd_lds_bytes(SPD_MAXK).
+constexpr int CHOL_LA_CHAIN = 4;
+__host__ __device__ inline int chol_la_lds_bytes(int K) { return spd_lds_bytes(K) + 64 + 64 * 64 * 4; }
+
+#ifndef LQP_LA_EXP
+#define LQP_LA_EXP 0
+#endif
+__device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem,
+                                                  unsigned long long* __restrict__ dbg = nullptr) {
+    constexpr int NCH = CHOL_LA_CHAIN, NTW = LQP_NW - NCH, NTT = NTW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nslot = K > 1 ? K - 1 : 1;
+    float* Y = (float*)smem;
+    float* W = Y + (size_t)nslot * 64 * SPD_LS;
+    float* WT = W + 64 * SPD_LS;
+    float* pcol = WT + 64 * SPD_LS;
+    int* flag = (int*)(pcol + PIV_LDS);
+    int* sy = flag + 4;                                     // [0] chain sync, [1] tile sync, [2] pv, [3] wrd, [4] ydn
+    float* St = (float*)(flag + 20);
+    if (tid < 20) flag[tid] = 0;
+    *(V4<float>*)(St + tid * 4) = *(const V4<float>*)(Hs + (size_t)sym_idx(0, 0, K) * LQP_BLK + tid * 4);
+    __syncthreads();
+    if (w < NCH) {
+        // ================= the chain waves =================
+        __builtin_amdgcn_s_setprio(3);
+        int gt = 0;
+        for (int k = 0; k < K; ++k) {
+            unsigned long long c0 = dbg ? clock64() : 0;
+            lds_wait_ge(sy + 2, 3 * k);                     // tile (k,k) is in St
+            lds_wait_ge(sy + 4, k);                         // W / W^T of step k-1 are no longer read
+            if (dbg && tid == 0) { const unsigned long long c1 = clock64(); dbg[4] += c1 - c0; c0 = c1; }
+            wg_pivot_block<NCH, true>(St, W, WT, pcol, flag, k * 64, sy + 0, &gt);
+            lds_group_sync<true>(sy + 0, gt += NCH);        // all four wrote their part of W / W^T
+            if (tid == 0) __hip_atomic_store(sy + 3, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the pre-inverted diagonal block (read again only by the solves, after the factorisation's last barrier)
+            for (int v = tid; v < 1024; v += NCH * 64)
+                *(V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + v * 4) = *(const V4<float>*)(W + (v >> 4) * SPD_LS + (v & 15) * 4);
+            if (dbg && tid == 0) dbg[5] += clock64() - c0;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        // ================= the tile waves =================
+        const int tw = w - NCH, tt = tid - NCH * 64;
+        int gt = 0;
+        for (int k = 0; k < K; ++k) {
+            const int np = K - 1 - k;                       // panel blocks below the pivot: slot s <-> row k+1+s
+            for (int s = 0; s < np; ++s) {
+                const float* src = Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK;
+                for (int v = tt; v < 1024; v += NTT)
+                    *(V4<float>*)(Y + ((size_t)s * 64 + (v >> 4)) * SPD_LS + (v & 15) * 4) = *(const V4<float>*)(src + v * 4);
+            }
+            // this wave's first tile of the step (tile (k+1,k+1) for the first three waves) is fetched while the chain
+            // waves still work on W
+            const int nupd = np * (np + 1) / 2 * 4;
+            f32x16 pre;
+            if (tw < nupd && !(tw == 1)) {                  // (task 1 = the mirrored quadrant of a diagonal tile)
+                const int qi = (tw >> 1) & 1, qj = tw & 1, p = tw >> 2;
+                int si = 0;
+                while ((si + 1) * (si + 2) / 2 <= p) ++si;
+                const int sj = p - si * (si + 1) / 2;
+                if (!(si == sj && qi == 0 && qj == 1)) {
+                    const float* C = Hs + (size_t)sym_idx(k + 1 + si, k + 1 + sj, K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) pre[q] = C[quad_row(q, lh) * 64];
+                }
+            }
+            unsigned long long c0 = dbg ? clock64() : 0;
+            lds_wait_ge(sy + 3, k + 1);                     // W / W^T of this step
+            if (dbg && tt == 0) { const unsigned long long c1 = clock64(); dbg[6] += c1 - c0; c0 = c1; }
+            lds_group_sync(sy + 1, gt += NTW);              // the panel is staged
+            // ---- Y_i = P_i W^T, in place: a wave owns 32 rows of a panel block and reads nothing else of Y ----
+            for (int task = tw; task < np * 2 && !(LQP_LA_EXP & 1); task += NTW) {
+                const int s = task >> 1, qi = task & 1;
+                float* Xp = Y + ((size_t)s * 64 + 32 * qi) * SPD_LS;
+                const f32x16 a0 = spd_quadrant<1, false>(Xp, W);
+                const f32x16 a1 = spd_quadrant(Xp, W + 32 * SPD_LS);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    Xp[quad_row(q, lh) * SPD_LS + li] = a0[q];
+                    Xp[quad_row(q, lh) * SPD_LS + 32 + li] = a1[q];
+                }
+            }
+            lds_group_sync(sy + 1, gt += NTW);              // Y complete, W / W^T free
+            if (tt == 0) __hip_atomic_store(sy + 4, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- L_ik = Y_i to its block; trailing tiles A_ij -= Y_i Y_j^T (i >= j > k), tile (k+1,k+1) first ----
+            {
+                for (int task = tw; task < nupd; task += NTW) {
+                    const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
+                    int si = 0;
+                    while ((si + 1) * (si + 2) / 2 <= p) ++si;
+                    const int sj = p - si * (si + 1) / 2;
+                    if (si == sj && qi == 0 && qj == 1) continue;      // diagonal tile: mirrored from its (1,0) quadrant
+                    float* T0 = Hs + (size_t)sym_idx(k + 1 + si, k + 1 + sj, K) * LQP_BLK;
+                    float* C = T0 + (32 * qi) * 64 + 32 * qj + li;
+                    f32x16 cur;
+                    if (task == tw) cur = pre;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];
+                    }
+                    if (!(LQP_LA_EXP & 1) || p == 0) {
+                    const f32x16 acc = spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS,
+                                                    Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
+                    cur -= acc;
+                    }
+                    if (p == 0) {                                      // the next diagonal tile also goes to the chain waves
+                        float* Sq = St + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) Sq[quad_row(q, lh) * 64] = cur[q];
+                        if (qi == 1 && qj == 0) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) St[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_fetch_add(sy + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                    if (si == sj && qi == 1 && qj == 0) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) T0[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                    }
+                }
+                for (int s = 0; s < np; ++s) {
+                    float* dst = Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK;
+                    for (int v = tt; v < 1024; v += NTT)
+                        *(V4<float>*)(dst + v * 4) = *(const V4<float>*)(Y + ((size_t)s * 64 + (v >> 4)) * SPD_LS + (v & 15) * 4);
+                }
+            }
+            lds_group_sync(sy + 1, gt += NTW);              // all tiles of this step are written (the next staging reads them)
+            if (dbg && tt == 0) dbg[7] += clock64() - c0;
+        }
+    }
+    __syncthreads();
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
 

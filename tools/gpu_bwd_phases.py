@@ -11,14 +11,23 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 B, n = 128, 500
 inp = [t.to(dev) for t in create_qp_data(n, B, seed=0)]
-Q = inp[0].clone().requires_grad_(True)
 ctl = L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5)
-x = L.SolveBoxQP(control=ctl)(Q, *inp[1:])
-dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
-lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
-x.backward(torch.ones_like(x))
-torch.cuda.synchronize()
-lib.lqp_debug_set_lu_counters(None)
-c = dbg.view(B, 8).double()
-print("mean cycles: factor %.0f  solves %.0f  schur+finish %.0f   mean Kb %.2f (min %d max %d)" % (
-    c[:, 0].mean(), c[:, 1].mean(), c[:, 2].mean(), c[:, 3].mean(), int(c[:, 3].min()), int(c[:, 3].max())))
+grads = {}
+for la in (0, 1):
+    os.environ["LQP_BWD_LOOKAHEAD"] = str(la)
+    Q = inp[0].clone().requires_grad_(True)
+    p = inp[1].clone().requires_grad_(True)
+    x = L.SolveBoxQP(control=ctl)(Q, p, *inp[2:])
+    dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
+    lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
+    x.backward(torch.ones_like(x))
+    torch.cuda.synchronize()
+    lib.lqp_debug_set_lu_counters(None)
+    grads[la] = (Q.grad.clone(), p.grad.clone())
+    c = dbg.view(B, 8).double()
+    print("lookahead %d  mean cycles: factor %.0f  solves %.0f  schur+finish %.0f   mean Kb %.2f (min %d max %d)" % (
+        la, c[:, 0].mean(), c[:, 1].mean(), c[:, 2].mean(), c[:, 3].mean(), int(c[:, 3].min()), int(c[:, 3].max())))
+    print("   chain: waits %.0f  pivot blocks %.0f   tile waves: wait for W %.0f  rest of step %.0f" % (
+        c[:, 4].mean(), c[:, 5].mean(), c[:, 6].mean(), c[:, 7].mean()))
+print("bit-identical gradients:", torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1]),
+      " finite:", bool(torch.isfinite(grads[1][0]).all()))
