@@ -267,6 +267,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_MAXK && m <= SPD_MAXM;
     }
     P.spd = spd ? 1 : 0;
+    P.qs_lazy = (spd && env_int("LQP_QS_LAZY", 1)) ? 1 : 0;
     P.ar_iter = ar_iter; P.ar_max = ctl->adaptive_rho_max_iter; P.ring = kRing;
 
     // ---- zero status + counter ring, setup, factor, pack ----

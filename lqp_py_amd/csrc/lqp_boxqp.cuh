@@ -26,6 +26,7 @@ template <typename T> struct FwdParams {
                                          // (continuation kernel / 512-thread first launch)
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
+    int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in, *beta_in;
@@ -197,7 +198,7 @@ __device__ __forceinline__ T setup_scale(const T* __restrict__ Q, const int n, c
                         V4<T> o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { o.v[e] = (di * v[rr][q].v[e]) * dj[q].v[e]; fro2 += o.v[e] * o.v[e]; }
-                        *(V4<T>*)(qo + jq[q]) = o;
+                        if (Qw) *(V4<T>*)(qo + jq[q]) = o;
                         if (with_m) *(V4<T>*)(mo + jq[q]) = o;
                     }
                 }
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         __syncthreads();
         // ---- Qs = (D_i Q_ij) D_j, its Frobenius norm (:176, :201), and the top-left KKT block ----
         ldq = P.ldq;
-        T* Qw = P.Qs + (size_t)b * n * ldq;
+        // (symmetric path: the scaled matrix is not stored, its readers scale Q as they load it)
+        T* Qw = P.qs_lazy ? nullptr : P.Qs + (size_t)b * n * ldq;
         T* Mw = P.M + (size_t)b * Np * Np;
         if (qvec) {
             fro2 += setup_scale<T, 4, 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
                 const T di = d[i];
                 for (int j = lane; j < n; j += 64) {
                     const T v = (di * qr[j]) * d[j];
-                    qo[j] = v;
+                    if (Qw) qo[j] = v;
                     if (!P.spd) mo[j] = v;
                     fro2 += v * v;
                 }
@@ -646,15 +648,17 @@ __device__ __forceinline__ void wg_eq_correct(const FwdParams<float>& P, const i
 __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const int b, const float rho, char* smem,
                                               const bool check_sym) {
     float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
-    const float* Qs = P.scale ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
-    const int ldq = P.scale ? P.ldq : P.n;
+    const bool lazy = P.scale && P.qs_lazy;
+    const float* Qs = (P.scale && !lazy) ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
+    const int ldq = (P.scale && !lazy) ? P.ldq : P.n;
+    const float* dsc = lazy ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
     if (check_sym) {
         float* red = (float*)smem;
-        const float asym = wg_sym_asymmetry(Qs, ldq, P.n, P.Ks, red);
+        const float asym = wg_sym_asymmetry(Qs, ldq, P.n, P.Ks, red, dsc);
         if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
         __syncthreads();
     }
-    wg_sym_init(Hs, Qs, ldq, P.n, P.Ks, rho);
+    wg_sym_init(Hs, Qs, ldq, P.n, P.Ks, rho, dsc);
     __syncthreads();
     wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
     if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
@@ -686,9 +690,11 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, 
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
-    const float* Qs = P.scale ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
-    const float asym = wg_sym_check_init<SPD_NP>(spd_half(P, b, P.Ks & 1), Qs, P.scale ? P.ldq : P.n, P.n, P.Ks,
-                                                 P.scal[(size_t)b * SC_WORDS + SC_RHO], (float*)smem, gate == nullptr, part);
+    const bool lazy = P.scale && P.qs_lazy;
+    const float* Qs = (P.scale && !lazy) ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
+    const float* dsc = lazy ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
+    const float asym = wg_sym_check_init<SPD_NP>(spd_half(P, b, P.Ks & 1), Qs, (P.scale && !lazy) ? P.ldq : P.n, P.n, P.Ks,
+                                                 P.scal[(size_t)b * SC_WORDS + SC_RHO], (float*)smem, gate == nullptr, part, dsc);
     if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
 }
 __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, const int* __restrict__ gate, const int k,

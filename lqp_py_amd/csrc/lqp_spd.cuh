@@ -49,8 +49,24 @@ __host__ __device__ inline int spd_lds_bytes(int K) {
 }
 
 // ---- packed lower blocks <- K = src (+ rho on the diagonal), identity on the padding ----
+// dsc != nullptr: src is the UNSCALED matrix and the value taken is (dsc[row] * src[row][col]) * dsc[col] -- what the
+// scaling pass would have stored (same operations, same order): the scaled copy is then never written.
+__device__ __forceinline__ void sym_scale4(V4<float>& v, const float* __restrict__ dsc, const int row, const int col, const int n) {
+    if (dsc && row < n) {
+        const float di = dsc[row];
+        if (col + 3 < n && ((((uintptr_t)(dsc + col)) & 15) == 0)) {
+            const V4<float> dj = *(const V4<float>*)(dsc + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = (di * v.v[e]) * dj.v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < n) v.v[e] = (di * v.v[e]) * dsc[col + e];
+        }
+    }
+}
 __device__ __forceinline__ void wg_sym_init(float* __restrict__ Hs, const float* __restrict__ src, const int ld,
-                                            const int n, const int K, const float rho_add) {
+                                            const int n, const int K, const float rho_add,
+                                            const float* __restrict__ dsc = nullptr) {
     const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
     const bool vec_ok = (ld % 4 == 0) && ((((uintptr_t)src) & 15) == 0);
     for (int j = 0; j < K; ++j)
@@ -64,6 +80,7 @@ __device__ __forceinline__ void wg_sym_init(float* __restrict__ Hs, const float*
                 for (int e = 0; e < 4; ++e)
                     v.v[e] = (gr < n && gc + e < n) ? src[(size_t)gr * ld + gc + e] : (gr == gc + e ? 1.f : 0.f);
             }
+            sym_scale4(v, dsc, gr, gc, n);
             if (gr < n) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (gr == gc + e) v.v[e] += rho_add;
@@ -79,7 +96,7 @@ __device__ __forceinline__ void wg_sym_init(float* __restrict__ Hs, const float*
 // launch at n = 500: 16-B pieces of 64 different rows per load instruction.)
 // smem: 2 * 64 * SPD_LS + 2 * LQP_NW floats.
 __device__ __forceinline__ float wg_sym_asymmetry(const float* __restrict__ src, const int ld, const int n, const int K,
-                                                  float* __restrict__ smem_f) {
+                                                  float* __restrict__ smem_f, const float* __restrict__ dsc = nullptr) {
     const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
     float* tile = smem_f;                                   // [2][64][SPD_LS]
     float* red = smem_f + 2 * 64 * SPD_LS;
@@ -93,6 +110,7 @@ __device__ __forceinline__ float wg_sym_asymmetry(const float* __restrict__ src,
 #pragma unroll
             for (int e = 0; e < 4; ++e) v.v[e] = (row < n && col + e < n) ? src[(size_t)row * ld + col + e] : 0.f;
         }
+        sym_scale4(v, dsc, row, col, n);
         return v;
     };
     float dmax = 0.f, vmax = 0.f;
@@ -132,7 +150,8 @@ __device__ __forceinline__ float wg_sym_asymmetry(const float* __restrict__ src,
 template <int NP>
 __device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const float* __restrict__ src, const int ld,
                                                    const int n, const int K, const float rho_add,
-                                                   float* __restrict__ smem_f, const bool check, const int part) {
+                                                   float* __restrict__ smem_f, const bool check, const int part,
+                                                   const float* __restrict__ dsc = nullptr) {
     const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
     float* tile = smem_f;                                   // [2][64][SPD_LS]
     float* red = smem_f + 2 * 64 * SPD_LS;
@@ -145,6 +164,7 @@ __device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const
 #pragma unroll
             for (int e = 0; e < 4; ++e) v.v[e] = (row < n && col + e < n) ? src[(size_t)row * ld + col + e] : 0.f;
         }
+        sym_scale4(v, dsc, row, col, n);
         return v;
     };
     auto block_of = [&](const int t, int& i, int& j) {
