@@ -270,18 +270,6 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.qs_lazy = (spd && env_int("LQP_QS_LAZY", 1)) ? 1 : 0;
     P.ar_iter = ar_iter; P.ar_max = ctl->adaptive_rho_max_iter; P.ring = kRing;
 
-    // ---- zero status + counter ring, setup, factor, pack ----
-    HIP_OK(hipMemsetAsync(P.status, 0, (char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status, st));
-    {
-        const int lds = setup_lds_bytes<T>(n);
-        auto fn = k_fwd_setup<T>;
-        int rc = ensure_lds((const void*)fn, lds);
-        if (rc) return rc;
-        ProfScope ps(st, PC_SETUP);
-        hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
-        ++n_launch;
-    }
-    int rc = LQP_OK;
     // symmetric path with fewer problems than half the CUs: share each matrix between SPD_NP workgroups
     bool spd_split = false;
     const int spd_pivot_tasks = env_int("LQP_SPD_PTASKS", 48);
@@ -294,8 +282,23 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
-    const bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK &&
+    const bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK + 2 &&
                               env_int("LQP_SPD_RESIDENT", 1) != 0;
+    // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
+    // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
+    P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && env_int("LQP_RHO_LATE", 1)) ? 1 : 0;
+
+    // ---- zero status + counter ring, setup, factor, pack ----
+    HIP_OK(hipMemsetAsync(P.status, 0, (char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status, st));
+    {
+        const int lds = setup_lds_bytes<T>(n);
+        auto fn = k_fwd_setup<T>;
+        int rc = ensure_lds((const void*)fn, lds);
+        if (rc) return rc;
+        ProfScope ps(st, PC_SETUP);
+        hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P);
+        ++n_launch;
+    }
     // factorise (gate == nullptr) or refactorise under the device-side gate of k_rho_update
     auto factor_step = [&](const int* gate) -> int {
         if constexpr (sizeof(T) == 4) {
@@ -340,7 +343,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         n_launch += 2;
         return r2;
     };
-    rc = factor_step(nullptr);
+    int rc = factor_step(nullptr);
     if (rc) return rc;
 
     // ---- launch mode ----
@@ -497,7 +500,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
                 stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
                 stats->linsolve_used = spd ? 2 : 1;
-                stats->factor_launches = spd ? (spd_split ? P.Ks + 2 : 1) : 2;
+                stats->factor_launches = spd ? (spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
                 stats->loop_workgroups = loop_split ? 2 : 1;
             }
             return LQP_OK;
@@ -623,7 +626,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->n_launch = n_launch;
         stats->mode_used = mode;
         stats->linsolve_used = spd ? 2 : 1;
-        stats->factor_launches = spd ? (spd_split ? P.Ks + 2 : 1) : 2;
+        stats->factor_launches = spd ? (spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
         stats->loop_workgroups = (loop_split && mode == 2) ? 2 : 1;
     }
     return LQP_OK;

@@ -27,6 +27,7 @@ template <typename T> struct FwdParams {
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
+    int rho_late;                        // 1: rho = ||Qs||_F / sqrt(n) from the sums k_spd_begin leaves, added by k_spd_resident
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in, *beta_in;
@@ -319,7 +320,9 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         // (symmetric path: the scaled matrix is not stored, its readers scale Q as they load it)
         T* Qw = P.qs_lazy ? nullptr : P.Qs + (size_t)b * n * ldq;
         T* Mw = P.M + (size_t)b * Np * Np;
-        if (qvec) {
+        if (P.rho_late && P.qs_lazy && P.spd) {
+            // nothing to store here and the norm is taken by k_spd_begin: no second pass over Q
+        } else if (qvec) {
             fro2 += setup_scale<T, 4, 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
         } else {
             for (int i = w; i < n; i += LQP_NW) {
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         for (int i = tid; i < n; i += LQP_NT) V.ps[i] = d[i] * p[i];       // (:177)
     } else {
         for (int i = tid; i < n; i += LQP_NT) { V.D[i] = T(1); V.ps[i] = p[i]; }
-        if (P.rho_mode == 0) {
+        if (P.rho_mode == 0 && !(P.rho_late && P.spd)) {
             for (int i = w; i < n; i += LQP_NW) {
                 const T* qr = Q + (size_t)i * n;
                 for (int j = lane; j < n; j += 64) { const T v = qr[j]; fro2 += v * v; }
@@ -693,8 +696,13 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, 
     const bool lazy = P.scale && P.qs_lazy;
     const float* Qs = (P.scale && !lazy) ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
     const float* dsc = lazy ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
+    // rho_late (first factorisation only): this workgroup's share of ||Qs||_F^2 goes behind the sweep's exchange buffer,
+    // the blocks are written without rho
+    const bool late = gate == nullptr && P.rho_late;
+    float* fro_out = late ? (P.M + (size_t)b * P.Np * P.Np + (size_t)2 * P.Ks * LQP_BLK + part) : nullptr;
     const float asym = wg_sym_check_init<SPD_NP>(spd_half(P, b, P.Ks & 1), Qs, (P.scale && !lazy) ? P.ldq : P.n, P.n, P.Ks,
-                                                 P.scal[(size_t)b * SC_WORDS + SC_RHO], (float*)smem, gate == nullptr, part, dsc);
+                                                 late ? 0.f : P.scal[(size_t)b * SC_WORDS + SC_RHO], (float*)smem,
+                                                 gate == nullptr, part, dsc, fro_out);
     if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
 }
 __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, const int* __restrict__ gate, const int k,
@@ -716,8 +724,12 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD
     unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 2;
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
+    RsLateRho lr;
+    lr.on = (gate == nullptr && P.rho_late) ? 1 : 0;
+    lr.n = P.n; lr.rho_min = P.rho_min; lr.rho_max = P.rho_max;
+    lr.rho_out = part == 0 ? P.scal + (size_t)b * SC_WORDS + SC_RHO : nullptr;
     wg_spd_sweep_resident<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
-                              P.info + b, P.status + ST_TIMEOUT, smem);
+                              P.info + b, P.status + ST_TIMEOUT, smem, lr);
 }
 __global__ __launch_bounds__(LQP_NT) void k_spd_end(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];

@@ -151,7 +151,8 @@ template <int NP>
 __device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const float* __restrict__ src, const int ld,
                                                    const int n, const int K, const float rho_add,
                                                    float* __restrict__ smem_f, const bool check, const int part,
-                                                   const float* __restrict__ dsc = nullptr) {
+                                                   const float* __restrict__ dsc = nullptr,
+                                                   float* __restrict__ fro_out = nullptr) {
     const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
     float* tile = smem_f;                                   // [2][64][SPD_LS]
     float* red = smem_f + 2 * 64 * SPD_LS;
@@ -173,7 +174,7 @@ __device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const
         while (rem >= K - j) { rem -= K - j; ++j; }
         i = j + rem;
     };
-    float dmax = 0.f, vmax = 0.f;
+    float dmax = 0.f, vmax = 0.f, fro2 = 0.f;
     const int nblk = sym_blocks(K);
     int i = 0, j = 0;
     V4<float> a, bm;
@@ -188,6 +189,10 @@ __device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const
         if (check) *(V4<float>*)(T + r * SPD_LS + c4) = bm;
         const V4<float> ac = a;
         const int ci = i, cj = j;
+        if (fro_out) {                                      // (needs `check`: the mirrors are only loaded then)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fro2 += ac.v[e] * ac.v[e] + (ci != cj ? bm.v[e] * bm.v[e] : 0.f);
+        }
         if (t + NP < nblk) {                                // the next block is requested before this one is used
             block_of(t + NP, i, j);
             a = load4(i * 64 + r, j * 64 + c4);
@@ -210,6 +215,10 @@ __device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const
     }
     if (!check) return 0.f;
     __syncthreads();
+    if (fro_out) {
+        fro2 = wg_sum(fro2, red);
+        if (tid == 0) *fro_out = fro2;
+    }
     dmax = wg_max(dmax, red);
     vmax = wg_max(vmax, red + LQP_NW);
     return dmax > 1e-5f * vmax ? dmax : 0.f;
@@ -991,11 +1000,21 @@ __device__ __forceinline__ void rs_tile_of(int l, const int K, const int part, i
 
 // xb: exchange buffer of this matrix, [2][K][4096] floats; fl: step flags of the two workgroups; epoch: added to the
 // step numbers (a refactorisation in the same forward must not match the flags of the first one)
+// rho not known when the blocks were built (FwdParams::rho_late): the two halves of ||Qs||_F^2 wait behind the exchange
+// buffer (k_spd_begin left them there), rho = clamp(||Qs||_F / sqrt(n)) as the setup kernel would have computed it
+// (reference :200-203) is added to the diagonal in registers and stored for the loop.
+struct RsLateRho {
+    int on, n;
+    float rho_min, rho_max;
+    float* rho_out;           // workgroup 0 only
+};
 template <int K>
 __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ Hsrc, float* __restrict__ Hdst,
                                                       float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                       const unsigned int epoch, const int part, int* __restrict__ info,
-                                                      int* __restrict__ status_timeout, char* smem, const int dbg_stop = -1,
+                                                      int* __restrict__ status_timeout, char* smem,
+                                                      const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr},
+                                                      const int dbg_stop = -1,
                                                       unsigned long long* __restrict__ dbg = nullptr) {
     constexpr int NS = rs_slots<K>();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1031,6 +1050,21 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
                 const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
+            }
+        }
+    }
+
+    if (lr.on) {
+        const float* xw = xb + (size_t)2 * K * LQP_BLK;
+        float rho = sqrtf(xw[0] + xw[1]) / (float)sqrt((double)lr.n);
+        rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
+        if (tid == 0 && lr.rho_out) *lr.rho_out = rho;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (quad_row(q, lh) == li && ti[s] * 64 + 32 * qi + li < lr.n) T[s][q] += rho;
             }
         }
     }

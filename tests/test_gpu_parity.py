@@ -753,6 +753,9 @@ def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeyp
     A = torch.randn(B, m, n, generator=g) if m else None
     b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
     sols = {}
+    # (the resident sweep normally takes rho = ||Qs||_F / sqrt(n) from sums k_spd_begin leaves -- another summation
+    #  order than the setup pass, i.e. another last bit of rho; test_late_rho_matches_the_setup_pass covers that)
+    monkeypatch.setenv("LQP_RHO_LATE", "0")
     for split in ("1", "0"):
         monkeypatch.setenv("LQP_SPD_SPLIT", split)
         for rho in (None, 100.0):
@@ -769,6 +772,27 @@ def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeyp
         assert abs(s1["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
         assert err(s1["x"], ref["x"]) < 5e-4 * max(1.0, float(ref["x"].abs().max()))
     assert sols["1", 100.0]["_stats"]["n_factor"] >= 2
+
+
+@pytest.mark.parametrize("n,B,scale", [(500, 4, True), (330, 3, True), (448, 2, False)])
+def test_late_rho_matches_the_setup_pass(dev, monkeypatch, n, B, scale):
+    """rho = ||Qs||_F / sqrt(n) (reference :200-203): with the resident sweep the squares are summed by k_spd_begin
+    (which reads Q anyway) and rho is added by the sweep, instead of a second pass over Q in the setup kernel.  Same
+    number up to the summation order; fixed iteration count so that the comparison is not about the stopping rule."""
+    inp = O.create_qp_data(n, B, seed=n)
+    out = {}
+    for late in ("1", "0"):
+        monkeypatch.setenv("LQP_RHO_LATE", late)
+        ctl = O.make_control(max_iters=41, eps_abs=1e-12, eps_rel=1e-12, linsolve="spd", scale=scale)
+        out[late], _ = solve(dev, inp, ctl)
+        assert out[late]["_stats"]["linsolve_used"] == 2 and out[late]["_stats"]["factor_launches"] == 3
+    r1, r0 = out["1"]["rho"].flatten().double().cpu(), out["0"]["rho"].flatten().double().cpu()
+    assert float(((r1 - r0).abs() / r0).max()) < 1e-6
+    ref = O.solve_box_qp(*inp, O.make_control(max_iters=41, eps_abs=1e-12, eps_rel=1e-12, scale=scale))
+    assert float((r1 - ref["rho"].flatten().double()).abs().max() / ref["rho"].max()) < 1e-5
+    for k in ("x", "u", "lams"):
+        assert err(out["1"][k], out["0"][k]) < 1e-5, k
+        assert err(out["1"][k], ref[k]) < 2 * X_TOL, k
 
 
 # ---------------------------------------------------------------- config 5: the per-GPU shard of B=8192 over 8 GPUs
