@@ -122,6 +122,7 @@ __device__ __forceinline__ void assemble_kkt_rows(const FwdParams<T>& P, const i
 //      1-KB load in flight per wave.  All RIF rows' loads are issued before any is used. ----
 template <typename T, int NQ, int RIF>
 __device__ __forceinline__ void setup_colmax(const T* __restrict__ Q, const int n, T* __restrict__ red) {
+    const int row0 = 0, row1 = n;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     T cm[NQ][4];
 #pragma unroll
@@ -132,12 +133,12 @@ __device__ __forceinline__ void setup_colmax(const T* __restrict__ Q, const int 
     int jq[NQ]; bool okq[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int j = (lane + 64 * q) * 4; okq[q] = j < n; jq[q] = okq[q] ? j : 0; }
-    for (int i0 = w; i0 < n; i0 += RIF * LQP_NW) {
+    for (int i0 = row0 + w; i0 < row1; i0 += RIF * LQP_NW) {
         V4<T> v[RIF][NQ];
 #pragma unroll
         for (int rr = 0; rr < RIF; ++rr) {
             const int i = i0 + rr * LQP_NW;
-            const T* qr = Q + (size_t)(i < n ? i : i0) * n;
+            const T* qr = Q + (size_t)(i < row1 ? i : i0) * n;
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 if (q < nq) v[rr][q] = *(const V4<T>*)(qr + jq[q]);
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
     if (tid == 0) P.info[b] = 0;
+    unsigned long long tst = clock64();
+#define SETUP_STAMP(i) do { if (P.dbg && tid == 0) { const unsigned long long t_ = clock64(); P.dbg[(size_t)b * 8 + (i)] = t_ - tst; tst = t_; } } while (0)
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * (2 * 2 * SPD_MAXK * LQP_NB);
         for (int i = tid; i < 2 * 2 * SPD_MAXK * LQP_NB; i += LQP_NT) xq[i] = 0ull;
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     pm = wg_max(pm, scratch);
     if (tid == 0) scal[SC_PNORM] = pm;
 
+    SETUP_STAMP(0);
     const T* Qs = Q;
     int ldq = n;
     T fro2 = T(0);
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         // ---- column max of |Q| (:163): wave w sweeps rows w, w+16, ...; 16 B per lane per load ----
         const bool qvec = (n % 4 == 0) && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
         if (qvec) {
+            // (several workgroups per QP for this pass: no faster -- 128 MB in 38 us either way, the HBM rate)
             setup_colmax<T, 4, 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster)
         } else {
             T cm[16];
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             }
         }
         __syncthreads();
+        SETUP_STAMP(1);
         T part = T(0);
         for (int j = tid; j < n; j += LQP_NT) {
             T v = red[j];
@@ -283,24 +289,55 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             part += v;
         }
         const T dmean = wg_sum(part, scratch) / T(n);     // also makes d[] visible
+        SETUP_STAMP(2);
         // ---- beta = 1 - q10(D) / q90(D), linear-interpolated quantiles (:171-174) ----
         T beta = P.beta_mode == 2 ? P.beta_in[b] : P.beta_value;
         if (P.beta_mode == 0) {
             const T pos0 = T(0.10) * T(n - 1), pos1 = T(0.90) * T(n - 1);
             const int lo0 = (int)tfloor(pos0), hi0 = (int)tceil(pos0);
             const int lo1 = (int)tfloor(pos1), hi1 = (int)tceil(pos1);
-            for (int j = tid; j < n; j += LQP_NT) {
-                const T dj = d[j];
-                int rank = 0;
-                for (int k = 0; k < n; ++k) {
-                    const T dk = d[k];
-                    rank += (dk < dj || (dk == dj && k < j)) ? 1 : 0;
+            // the four order statistics behind the two quantiles: bitonic sort of D, padded with +inf to a power of two.
+            // One element per thread while that fits: partners closer than 64 are reached by a wave shuffle, only the
+            // far ones (6 of the 45 rounds at n = 500) go through LDS and a barrier.  (Counting every element's rank
+            // costs n^2 comparisons: 10 us at n = 500 even over all 1024 threads; every round through LDS: 12 us.)
+            T* sb = red;                                      // the column maxima are no longer needed
+            int N2 = 1;
+            while (N2 < n) N2 <<= 1;
+            __syncthreads();
+            if (N2 <= LQP_NT) {
+                T v = tid < n ? d[tid] : T(INFINITY);
+                for (int k = 2; k <= N2; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        T other;
+                        if (j >= 64) {
+                            if (tid < N2) sb[tid] = v;
+                            __syncthreads();
+                            other = tid < N2 ? sb[tid ^ j] : v;
+                            __syncthreads();
+                        } else {
+                            other = __shfl_xor(v, j);
+                        }
+                        const bool keep_min = ((tid & j) == 0) == ((tid & k) == 0);
+                        v = keep_min ? tmin(v, other) : tmax(v, other);
+                    }
                 }
-                if (rank == lo0) sel[0] = dj;
-                if (rank == hi0) sel[1] = dj;
-                if (rank == lo1) sel[2] = dj;
-                if (rank == hi1) sel[3] = dj;
+                if (tid < N2) sb[tid] = v;
+                __syncthreads();
+            } else {
+                for (int i = tid; i < N2; i += LQP_NT) sb[i] = i < n ? d[i] : T(INFINITY);
+                __syncthreads();
+                for (int k = 2; k <= N2; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int t = tid; t < (N2 >> 1); t += LQP_NT) {
+                            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                            const T x0 = sb[i], x1 = sb[l];
+                            if ((x0 > x1) == ((i & k) == 0)) { sb[i] = x1; sb[l] = x0; }
+                        }
+                        __syncthreads();
+                    }
+                }
             }
+            if (tid == 0) { sel[0] = sb[lo0]; sel[1] = sb[hi0]; sel[2] = sb[lo1]; sel[3] = sb[hi1]; }
             __syncthreads();
             const T w0 = pos0 - tfloor(pos0), w1 = pos1 - tfloor(pos1);
             // torch lerp: w < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
@@ -315,6 +352,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             V.D[j] = v;
         }
         __syncthreads();
+        SETUP_STAMP(3);
         // ---- Qs = (D_i Q_ij) D_j, its Frobenius norm (:176, :201), and the top-left KKT block ----
         ldq = P.ldq;
         // (symmetric path: the scaled matrix is not stored, its readers scale Q as they load it)
@@ -350,6 +388,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             }
         }
     }
+    SETUP_STAMP(4);
     // ---- rho (:140, :157-158, :200-203) ----
     T rho;
     if (P.rho_mode == 0) {
@@ -395,6 +434,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             for (int r = tid; r < m; r += LQP_NT) { V.E[r] = T(1); V.bs[r] = bb[r]; }
         }
     }
+    SETUP_STAMP(5);
     // ---- bounds (:192-194) and state ----
     const T* lb = P.lb + (size_t)b * n;
     const T* ub = P.ub + (size_t)b * n;
@@ -407,6 +447,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     }
     for (int r = tid; r < m; r += LQP_NT) V.nu[r] = T(0);
     __syncthreads();
+    SETUP_STAMP(6);
     if (!P.spd) assemble_kkt_rows(P, b, Qs, ldq, V, rho, !q_in_m);
 }
 
