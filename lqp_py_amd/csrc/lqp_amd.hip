@@ -328,7 +328,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                             hipLaunchKernelGGL(k_spd_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
                         n_launch += P.Ks;
                     }
-                    hipLaunchKernelGGL(k_spd_end, dim3(B), dim3(LQP_NT), lds, st, P, gate);
+                    if (!(gate == nullptr && P.eq_in_loop)) hipLaunchKernelGGL(k_spd_end, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                     n_launch += 2;
                     return LQP_OK;
                 }
@@ -343,8 +343,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         n_launch += 2;
         return r2;
     };
-    int rc = factor_step(nullptr);
-    if (rc) return rc;
+    int rc = LQP_OK;
 
     // ---- launch mode ----
     // hot (first) launch: optional 512-thread build (256 VGPRs per thread: 16 register-resident blocks instead
@@ -428,6 +427,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 loop_split = per_cu >= 1 && 2 * B <= cus * per_cu;
         }
     }
+    // the equality correction of the first factorisation moves into that kernel (its blocks are in registers there)
+    if constexpr (sizeof(T) == 4) P.eq_in_loop = (loop_split && spd_resident && m > 0 && env_int("LQP_EQ_IN_LOOP", 1)) ? 1 : 0;
+    rc = factor_step(nullptr);
+    if (rc) return rc;
     // the first launch of the persistent modes
     auto launch_hot = [&](const int it, const int e, const int ctr_base, const int prev_slot, const int flags) {
         ProfScope ps(st, PC_LOOP);

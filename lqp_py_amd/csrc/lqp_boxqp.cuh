@@ -27,6 +27,7 @@ template <typename T> struct FwdParams {
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
+    int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
     int rho_late;                        // 1: rho = ||Qs||_F / sqrt(n) from the sums k_spd_begin leaves, added by k_spd_resident
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
@@ -1142,7 +1143,8 @@ template <int NT> __host__ __device__ constexpr int split_loop_lds_floats(int Ks
     return split_lds_blocks<NT>(Ks) * LQP_BLK + (3 + NT / 64 + 10) * Ks * LQP_NB + (NT / 64) * 8 + 8 + 8;
 }
 template <int NT> __host__ __device__ inline int split_loop_lds_bytes(int Ks, int m) {
-    return (split_loop_lds_floats<NT>(Ks) + 3 * m + 8) * 4;
+    // + the equality block: G, T (m x Nps each), S, S^-1 (m x m), s0, b, nu, nu snapshot
+    return (split_loop_lds_floats<NT>(Ks) + 2 * m * Ks * LQP_NB + 2 * m * m + 4 * m + 8) * 4;
 }
 
 template <int KS, int NT, bool DBG = false>
@@ -1173,7 +1175,12 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     T* const sx = su + Nps;
     T* const red = sx + Nps;
     int* const flags = (int*)(red + NWV * 8 + 8);             // [0] exchange timed out (sticky), [1] verdict of this iteration
-    T* const bs = (T*)(flags + 8);
+    T* const Gl = (T*)(flags + 8);                            // equality block: G = K^-1 As^T, T = G S^-1 (m x Nps each)
+    T* const Tl = Gl + (size_t)m * Nps;
+    T* const Sm = Tl + (size_t)m * Nps;
+    T* const Si = Sm + m * m;
+    T* const s0l = Si + m * m;
+    T* const bs = s0l + m;
     T* const nus_l = bs + m;
     T* const snu = nus_l + m;
 
@@ -1198,6 +1205,111 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     for (int i = tid; i < NWV * Nps; i += NT) part[i] = T(0);
     if (tid < 8) flags[tid] = 0;
     __syncthreads();
+
+    // ---- equality constraints: H <- H + T G^T with G = K^-1 As^T, S = As G, T = G S^-1 (what wg_eq_correct does to the
+    //      blocks in global memory, three passes over them in a launch of its own) applied to the blocks in REGISTERS:
+    //      m products with the blocks this kernel holds anyway, the partner's half through the exchange granules.  The
+    //      corrected blocks only go back to global memory if a continuation launch needs them (end of the kernel). ----
+    const bool eq_here = m > 0 && P.eq_in_loop;
+    const int moff = eq_here ? m : 0;                         // the iterations' exchanges follow these m in buffer parity
+    if (m > 0 && !eq_here) {
+        for (int i = tid; i < m * Nps; i += NT) { const int q = i / Nps, e = i - q * Nps; Tl[i] = e < n ? V.Tm[(size_t)q * n + e] : T(0); }
+        for (int r = tid; r < m; r += NT) s0l[r] = V.s0[r];
+    }
+    if (eq_here) {
+        if (part_id == 0 && tid == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;      // (k_spd_end did not run)
+        for (int q = 0; q < m; ++q) {
+            for (int i = tid; i < Nps; i += NT) v[i] = i < n ? V.As[(size_t)q * n + i] : T(0);
+            wg_barrier_lds();
+            if (part_id == 0) wg_sym_gemv_split<KS, 0, NT>(rr, lds_res, Nps, v, yrow, part);
+            else wg_sym_gemv_split<KS, 1, NT>(rr, lds_res, Nps, v, yrow, part);
+            wg_barrier_lds();
+            if (tid < Nps) {
+                const int i = tid;
+                const T own = split_combine<NT>(i, Nps, yrow, part);
+                const unsigned int tag = 0x20000000u + (unsigned int)q;
+                unsigned long long* base = xq + (size_t)(q & 1) * (2 * SPD_MAXK * LQP_NB);
+                __hip_atomic_store(base + (size_t)part_id * (SPD_MAXK * LQP_NB) + i,
+                                   ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, own),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long* src = base + (size_t)(1 - part_id) * (SPD_MAXK * LQP_NB) + i;
+                unsigned long long g = 0;
+                if (!flags[0]) {
+                    unsigned int spins = 0;
+                    unsigned long long t0 = 0;
+                    for (;;) {
+                        g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (((unsigned int)(g >> 32) & 0x3FFFFFFFu) == tag) break;
+                        if ((++spins & 1023u) == 0) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                            if (t0 == 0) t0 = now;
+                            else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up
+                                __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                flags[0] = 1;
+                                break;
+                            }
+                        }
+                    }
+                }
+                const T other = __builtin_bit_cast(float, (unsigned int)g);
+                const T y = part_id == 0 ? own + other : other + own;      // same order on both workgroups
+                Gl[(size_t)q * Nps + i] = -y;
+            }
+            wg_barrier_lds();
+        }
+        // S = As G (m x m), one wave per entry
+        for (int t = w; t < m * m; t += NWV) {
+            const int q = t / m, q2 = t - q * m;
+            T acc = T(0);
+            for (int i = lane; i < n; i += 64) acc += V.As[(size_t)q * n + i] * Gl[(size_t)q2 * Nps + i];
+            acc = wave_sum(acc);
+            if (lane == 0) Sm[t] = acc;
+        }
+        wg_barrier_lds();
+        if (tid == 0) {                                       // S^-1 by Gauss-Jordan (S is SPD: no pivoting), m <= 16
+            for (int i = 0; i < m * m; ++i) Si[i] = T(0);
+            for (int i = 0; i < m; ++i) Si[i * m + i] = T(1);
+            int bad = 0;
+            for (int c = 0; c < m; ++c) {
+                const T d = Sm[c * m + c];
+                if (!(d > T(0))) bad = 1;
+                const T inv = d > T(0) ? T(1) / d : T(0);
+                for (int j = 0; j < m; ++j) { Sm[c * m + j] *= inv; Si[c * m + j] *= inv; }
+                for (int r = 0; r < m; ++r) {
+                    if (r == c) continue;
+                    const T f = Sm[r * m + c];
+                    for (int j = 0; j < m; ++j) { Sm[r * m + j] -= f * Sm[c * m + j]; Si[r * m + j] -= f * Si[c * m + j]; }
+                }
+            }
+            if (bad) { if (P.info[b] == 0) P.info[b] = Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient
+        }
+        wg_barrier_lds();
+        // T = G S^-1, c = T b, s0 = S^-1 b (both workgroups hold them; the copies in global memory are for later launches)
+        for (int t = tid; t < m * Nps; t += NT) {
+            const int q = t / Nps, e = t - q * Nps;
+            T acc = T(0);
+            for (int q2 = 0; q2 < m; ++q2) acc += Gl[(size_t)q2 * Nps + e] * Si[q2 * m + q];
+            Tl[t] = acc;
+            if (part_id == 0 && e < n) V.Tm[(size_t)q * n + e] = acc;
+        }
+        for (int q = tid; q < m; q += NT) {
+            T acc = T(0);
+            for (int q2 = 0; q2 < m; ++q2) acc += Si[q * m + q2] * bs[q2];
+            s0l[q] = acc;
+            if (part_id == 0) V.s0[q] = acc;
+        }
+        wg_barrier_lds();
+        for (int e = tid; e < Nps; e += NT) {
+            T acc = T(0);
+            for (int q = 0; q < m; ++q) acc += Tl[(size_t)q * Nps + e] * bs[q];
+            cvl[e] = e < n ? acc : T(0);
+            if (part_id == 0 && e < n) V.cv[e] = acc;
+        }
+        // the blocks: thread t holds EPT consecutive elements of row t / LPR of every block
+        if (part_id == 0) split_eq_update<KS, 0, NT>(rr, lds_res, Gl, Tl, m, Nps);
+        else split_eq_update<KS, 1, NT>(rr, lds_res, Gl, Tl, m, Nps);
+        wg_barrier_lds();
+    }
     for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
     wg_barrier_lds();
 
@@ -1261,9 +1373,9 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             if (m > 0) {                                      // nu = T^T w - s0 while v is still w
                 for (int r = w; r < m; r += NWV) {
                     T acc = T(0);
-                    for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)r * n + i] * v[i];
+                    for (int i = lane; i < n; i += 64) acc += Tl[(size_t)r * Nps + i] * v[i];
                     acc = wave_sum(acc);
-                    if (lane == 0) nus_l[r] = acc - V.s0[r];
+                    if (lane == 0) nus_l[r] = acc - s0l[r];
                 }
                 wg_barrier_lds();
             }
@@ -1274,7 +1386,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             const T own = split_combine<NT>(i, Nps, yrow, part);
             // ---- exchange: publish this element's partial (part 0: with the verdict), fetch the partner's ----
             const unsigned int tag = (unsigned int)(it + 1);
-            unsigned long long* base = xq + (size_t)(it & 1) * (2 * SPD_MAXK * LQP_NB);
+            unsigned long long* base = xq + (size_t)((it + moff) & 1) * (2 * SPD_MAXK * LQP_NB);
             __hip_atomic_store(base + (size_t)part_id * (SPD_MAXK * LQP_NB) + i,
                                ((unsigned long long)(tag | ((unsigned int)verdict << 30)) << 32) |
                                    (unsigned long long)__builtin_bit_cast(unsigned int, own),
@@ -1435,6 +1547,13 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     if (part_id == 0) {
         for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }
         for (int r = tid; r < m; r += NT) V.nu[r] = nus_l[r];
+    }
+    // the loop goes on in a continuation launch, which reads the blocks from global memory: there they still lack the
+    // equality correction
+    if (eq_here) {
+        T* packed_w = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+        if (part_id == 0) split_resident_store<KS, 0, NT>(rr, lds_res, packed_w);
+        else split_resident_store<KS, 1, NT>(rr, lds_res, packed_w);
     }
 }
 

@@ -882,6 +882,47 @@ __device__ __forceinline__ void split_resident_load(SplitResident<NT>& rr, float
                               frag_load<float, NT>(Hs + (size_t)sym_idx(M::row_of(l), M::col_of(l), K) * LQP_BLK));
 }
 
+template <int K, int PART, int NT>
+__device__ __forceinline__ void split_resident_store(const SplitResident<NT>& rr, const float* __restrict__ lds_res, float* __restrict__ Hs) {
+    typedef SplitMap<K, PART> M;
+    constexpr int nloc = M::count(), RR = split_rr<NT>();
+#pragma unroll
+    for (int l = 0; l < RR; ++l)
+        if (l < nloc) frag_store<float, NT>(Hs + (size_t)sym_idx(M::row_of(l), M::col_of(l), K) * LQP_BLK, rr.r[l]);
+#pragma unroll
+    for (int l = RR; l < nloc; ++l)
+        frag_store<float, NT>(Hs + (size_t)sym_idx(M::row_of(l), M::col_of(l), K) * LQP_BLK,
+                              frag_load<float, NT>(lds_res + (size_t)(l - RR) * LQP_BLK));
+}
+
+// B_ij += sum_q T_q[64 i + r] G_q[64 j + c] on every block workgroup PART holds (registers and LDS): the rank-m
+// equality correction H + T G^T.  Tl, Gl: [m][Np] in LDS.
+template <int K, int PART, int NT>
+__device__ __forceinline__ void split_eq_update(SplitResident<NT>& rr, float* __restrict__ lds_res, const float* __restrict__ Gl,
+                                                const float* __restrict__ Tl, const int m, const int Np) {
+    typedef SplitMap<K, PART> M;
+    constexpr int nloc = M::count(), RR = split_rr<NT>(), EPT = LQP_BLK / NT, LPR = LQP_NB / EPT, NV = EPT / 4;
+    const int tid = threadIdx.x, r = tid / LPR, c0 = (tid % LPR) * EPT;
+#pragma unroll
+    for (int l = 0; l < nloc; ++l) {
+        const int bi = M::row_of(l), bj = M::col_of(l);
+        Frag<float, NT> blk;
+        if (l < RR) blk = rr.r[l < RR ? l : 0];
+        else blk = frag_load<float, NT>(lds_res + (size_t)(l - RR) * LQP_BLK);
+        for (int q = 0; q < m; ++q) {
+            const float t = Tl[(size_t)q * Np + bi * 64 + r];
+#pragma unroll
+            for (int v4 = 0; v4 < NV; ++v4) {
+                const V4<float> g = *(const V4<float>*)(Gl + (size_t)q * Np + bj * 64 + c0 + 4 * v4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) blk.q[v4].v[e] += t * g.v[e];
+            }
+        }
+        if (l < RR) rr.r[l < RR ? l : 0] = blk;
+        else frag_store<float, NT>(lds_res + (size_t)(l - RR) * LQP_BLK, blk);
+    }
+}
+
 // Partial product of workgroup PART, fully static: every block from registers / LDS at compile-time positions.
 // Thread t owns EPT = 4096 / NT consecutive elements of a block: row t / LPR, columns EPT (t % LPR) ..
 //   row product   d_i += B_ij . w_j  accumulated per block ROW over this workgroup's columns, ONE reduction over the

@@ -756,6 +756,9 @@ def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeyp
     # (the resident sweep normally takes rho = ||Qs||_F / sqrt(n) from sums k_spd_begin leaves -- another summation
     #  order than the setup pass, i.e. another last bit of rho; test_late_rho_matches_the_setup_pass covers that)
     monkeypatch.setenv("LQP_RHO_LATE", "0")
+    # (... and applies the equality correction inside the loop kernel, with the summation order of its own products:
+    #  test_equality_correction_in_the_loop_kernel)
+    monkeypatch.setenv("LQP_EQ_IN_LOOP", "0")
     for split in ("1", "0"):
         monkeypatch.setenv("LQP_SPD_SPLIT", split)
         for rho in (None, 100.0):
@@ -793,6 +796,37 @@ def test_late_rho_matches_the_setup_pass(dev, monkeypatch, n, B, scale):
     for k in ("x", "u", "lams"):
         assert err(out["1"][k], out["0"][k]) < 1e-5, k
         assert err(out["1"][k], ref[k]) < 2 * X_TOL, k
+
+
+@pytest.mark.parametrize("n,B,m", [(500, 4, 1), (330, 3, 2), (448, 2, 5)])
+def test_equality_correction_in_the_loop_kernel(dev, monkeypatch, n, B, m):
+    """With two workgroups per QP the equality correction H + T G^T of the first factorisation is applied to the blocks
+    in the loop kernel's registers (no k_spd_end launch, no three passes over H in global memory).  Same mathematics as
+    wg_eq_correct, another summation order: compared at a fixed iteration count with that path and with the oracle, and
+    through the constraint itself.  rho = 100 forces refactorisations: the continuation launches must find corrected
+    blocks in global memory."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g)
+    b = 0.1 * torch.randn(B, m, 1, generator=g)
+    for kw in (dict(max_iters=41, eps_abs=1e-12, eps_rel=1e-12), dict(rho=100.0, **TOL)):
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("LQP_EQ_IN_LOOP", flag)
+            out[flag], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve="spd", **kw))
+            assert out[flag]["_stats"]["linsolve_used"] == 2 and out[flag]["_stats"]["loop_workgroups"] == 2
+        ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**kw))
+        scale = max(1.0, float(ref["x"].abs().max()))
+        if "rho" in kw:
+            assert out["1"]["_stats"]["n_factor"] >= 2 and abs(out["1"]["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
+            tol = 5e-4
+        else:
+            tol = 2 * X_TOL
+        # (with the stopping rule live the duals are only as good as the tolerance: compare the primal solution)
+        for k in (("x",) if "rho" in kw else ("x", "u", "lams", "nus")):
+            assert err(out["1"][k], out["0"][k]) < tol * scale, (kw, k)
+            assert err(out["1"][k], ref[k]) < tol * scale, (kw, k)
+        assert float((A.to(dev) @ out["1"]["x"] - b.to(dev)).abs().max()) < 1e-4
 
 
 # ---------------------------------------------------------------- config 5: the per-GPU shard of B=8192 over 8 GPUs
