@@ -771,7 +771,8 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     lr.n = P.n; lr.rho_min = P.rho_min; lr.rho_max = P.rho_max;
     lr.rho_out = part == 0 ? P.scal + (size_t)b * SC_WORDS + SC_RHO : nullptr;
     wg_spd_sweep_resident<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
-                              P.info + b, P.status + ST_TIMEOUT, smem, lr);
+                              P.info + b, P.status + ST_TIMEOUT, smem, lr, -1,
+                              (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
 }
 __global__ __launch_bounds__(LQP_NT) void k_spd_end(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -1862,7 +1863,7 @@ __host__ __device__ inline int bwd_chol_lds_bytes(int n, int m) {
     const int Kmax = round_up(n, LQP_NB) / LQP_NB, Npm = Kmax * LQP_NB;
     const int a0 = spd_lds_bytes(Kmax);
     const int a = (Kmax < SPD_MAXK && chol_la_lds_bytes(Kmax) > a0) ? chol_la_lds_bytes(Kmax) : a0;
-    const int c = ((3 + m) * Npm + 64 + LQP_NW * 64 + m * m + 2 * m + 8) * 4;
+    const int c = ((3 + m) * Npm + 2 * 64 + 2 * LQP_NW * 64 + m * m + 2 * m + 8) * 4;
     return a > c ? a : c;
 }
 __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float> P) {
@@ -1882,27 +1883,23 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     }
     __syncthreads();
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 0] = t - dt0; dt0 = t; P.dbg[(size_t)b * 8 + 3] = Kb; }
-    float* v = (float*)smem;
-    float* acc = v + Npm;
-    float* u0 = acc + Npm;
+    // right-hand sides [rhs | A_F^T] as rows of X (u0 = X[0], G = X[1 ..]), solved two at a time
+    constexpr int NR = 2;
+    float* acc = (float*)smem;
+    float* u0 = acc + (size_t)NR * Npm;
     float* G = u0 + Npm;
     float* t = G + (size_t)m * Npm;
-    float* part = t + 64;
-    float* S = part + LQP_NW * 64;
+    float* part = t + NR * 64;
+    float* S = part + NR * LQP_NW * 64;
     float* wv = S + m * m;
     float* dn = wv + m;
-    for (int e = tid; e < Nb; e += LQP_NT) v[e] = rhs[e];
+    for (int e = tid; e < Nb; e += LQP_NT) u0[e] = rhs[e];
+    for (int q = 0; q < m; ++q)
+        for (int e = tid; e < Nb; e += LQP_NT) G[(size_t)q * Npm + e] = AF[(size_t)q * Npm + e];
     __syncthreads();
-    if (Kb > 0) wg_chol_solve(Ls, Kb, v, acc, t, part);
-    for (int e = tid; e < Nb; e += LQP_NT) u0[e] = v[e];
-    __syncthreads();
-    for (int q = 0; q < m; ++q) {
-        for (int e = tid; e < Nb; e += LQP_NT) v[e] = AF[(size_t)q * Npm + e];
-        __syncthreads();
-        if (Kb > 0) wg_chol_solve(Ls, Kb, v, acc, t, part);
-        for (int e = tid; e < Nb; e += LQP_NT) G[(size_t)q * Npm + e] = v[e];
-        __syncthreads();
-    }
+    if (Kb > 0)
+        for (int c0 = 0; c0 < 1 + m; c0 += NR)
+            wg_chol_solve_n<NR>(Ls, Kb, u0 + (size_t)c0 * Npm, Npm, (1 + m - c0) < NR ? (1 + m - c0) : NR, acc, t, part);
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 1] = t - dt0; dt0 = t; }
     if (m > 0) {
         // S = A_F G - eps I,  wv = A_F u0  (one wave per entry)

@@ -1464,32 +1464,51 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
 
-// L L^T x = v with the factor above, v (LDS, 64 K values) in place.  acc: 64 K floats, t: 64, part: NW * 64 of LDS.
-__device__ __forceinline__ void wg_chol_solve(const float* __restrict__ Ls, const int K, float* __restrict__ v,
-                                              float* __restrict__ acc, float* __restrict__ t, float* __restrict__ part) {
+// L L^T X = V with the factor above for up to NR right-hand sides at once: X[c * xs + ..] (LDS, 64 K values each),
+// c < nc <= NR, solved in place.  Every block of the factor is loaded once for all of them and the 7 barriers per block column are shared: the solve is bound by those
+// round trips, not by arithmetic (1 + m separate solves of the backward pass: 73 k cycles at n = 500, m = 1).
+// acc: NR * 64 K floats, t: NR * 64, part: NR * NW * 64 of LDS.
+template <int NR>
+__device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, const int K, float* __restrict__ X, const int xs,
+                                                const int nc, float* __restrict__ acc, float* __restrict__ t,
+                                                float* __restrict__ part) {
     const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < K * 64; e += LQP_NT) acc[e] = 0.f;
+    const int K64 = K * 64;
+    const int tc = tid >> 6, te = tid & 63;                  // (column, element) of the per-column 64-vectors
+    for (int e = tid; e < NR * K64; e += LQP_NT) acc[e] = 0.f;
     __syncthreads();
     // ---- L y = v, column by column ----
     for (int j = 0; j < K; ++j) {
-        if (tid < 64) t[tid] = v[j * 64 + tid] - acc[j * 64 + tid];
+        if (tc < nc) t[tc * 64 + te] = X[(size_t)tc * xs + j * 64 + te] - acc[tc * K64 + j * 64 + te];
         __syncthreads();
         {
             const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(j, j, K) * LQP_BLK + tid * 4);
-            const float s1 = rowgroup_sum<LQP_NT>(dot4(b, *(const V4<float>*)(t + cq * 4)));
-            if (cq == 0) v[j * 64 + r] = s1;
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                if (c < nc) {
+                    const float s1 = rowgroup_sum<LQP_NT>(dot4(b, *(const V4<float>*)(t + c * 64 + cq * 4)));
+                    if (cq == 0) X[(size_t)c * xs + j * 64 + r] = s1;
+                }
+            }
         }
         __syncthreads();
-        const V4<float> yj = *(const V4<float>*)(v + j * 64 + cq * 4);
+        V4<float> yj[NR];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) yj[c] = *(const V4<float>*)(X + (size_t)(c < nc ? c : 0) * xs + j * 64 + cq * 4);
         for (int i = j + 1; i < K; ++i) {
             const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4);
-            const float s1 = rowgroup_sum<LQP_NT>(dot4(b, yj));
-            if (cq == 0) acc[i * 64 + r] += s1;              // (row r of block row i always belongs to this thread)
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                if (c < nc) {
+                    const float s1 = rowgroup_sum<LQP_NT>(dot4(b, yj[c]));
+                    if (cq == 0) acc[c * K64 + i * 64 + r] += s1;      // (row r of block row i always belongs to this thread)
+                }
+            }
         }
         __syncthreads();
     }
     // ---- L^T x = y, from the last block column up ----
-    auto fold = [&](float (&a2)[4]) {                        // column sums of this wave's 4 rows -> part[w][64]
+    auto fold = [&](float (&a2)[4], const int c) {           // column sums of this wave's 4 rows -> part[c][w][64]
         V4<float> o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1498,38 +1517,49 @@ __device__ __forceinline__ void wg_chol_solve(const float* __restrict__ Ls, cons
             a += __shfl_xor(a, 32);
             o.v[e] = a;
         }
-        if (lane < 16) *(V4<float>*)(part + w * 64 + cq * 4) = o;
+        if (lane < 16) *(V4<float>*)(part + ((size_t)c * LQP_NW + w) * 64 + cq * 4) = o;
     };
     for (int j = K - 1; j >= 0; --j) {
-        float a2[4] = {0.f, 0.f, 0.f, 0.f};
+        float a2[NR][4];
+#pragma unroll
+        for (int c = 0; c < NR; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a2[c][e] = 0.f;
         for (int i = j + 1; i < K; ++i) {
             const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4);
-            const float xi = v[i * 64 + r];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a2[e] += b.v[e] * xi;
+            for (int c = 0; c < NR; ++c) {
+                const float xi = X[(size_t)(c < nc ? c : 0) * xs + i * 64 + r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a2[c][e] += b.v[e] * xi;
+            }
         }
-        fold(a2);
+#pragma unroll
+        for (int c = 0; c < NR; ++c) fold(a2[c], c);
         __syncthreads();
-        if (tid < 64) {
+        if (tc < nc) {
             float sum = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < LQP_NW; ++ww) sum += part[ww * 64 + tid];
-            t[tid] = v[j * 64 + tid] - sum;
+            for (int ww = 0; ww < LQP_NW; ++ww) sum += part[((size_t)tc * LQP_NW + ww) * 64 + te];
+            t[tc * 64 + te] = X[(size_t)tc * xs + j * 64 + te] - sum;
         }
         __syncthreads();
         {
             const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(j, j, K) * LQP_BLK + tid * 4);
-            const float tr = t[r];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a2[e] = b.v[e] * tr;
-            fold(a2);
+            for (int c = 0; c < NR; ++c) {
+                const float tr = t[c * 64 + r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a2[c][e] = b.v[e] * tr;
+                fold(a2[c], c);
+            }
         }
         __syncthreads();
-        if (tid < 64) {
+        if (tc < nc) {
             float sum = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < LQP_NW; ++ww) sum += part[ww * 64 + tid];
-            v[j * 64 + tid] = sum;
+            for (int ww = 0; ww < LQP_NW; ++ww) sum += part[((size_t)tc * LQP_NW + ww) * 64 + te];
+            X[(size_t)tc * xs + j * 64 + te] = sum;
         }
         __syncthreads();
     }

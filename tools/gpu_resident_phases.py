@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""In-kernel cycle breakdown of the register-resident sweep k_spd_resident (thread 0 of workgroup 0 of every QP)."""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import lqp_py_amd as L
+from lqp_py_amd import _lib
+from lqp_py_amd.synthetic import create_qp_data
+dev = torch.device("cuda:0")
+lib = _lib.load()
+B, n = 128, 500
+inp = [t.to(dev) for t in create_qp_data(n, B, seed=0)]
+ctl = L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5, max_iters=1)
+os.environ["LQP_LOOP_SPLIT"] = "0"          # (its debug build would add its own counters to the same words)
+dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
+L.torch_solve_box_qp(*inp, dict(ctl))
+lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
+L.torch_solve_box_qp(*inp, dict(ctl))
+torch.cuda.synchronize()
+lib.lqp_debug_set_lu_counters(None)
+c = dbg.view(B, 8).double()
+names = ["publish + wait for the partner", "pivot block", "panel tiles -> LDS", "Y = P W^T", "tile updates", "closing barrier"]
+tot = c[:, :6].sum(1).mean()
+for i, nm in enumerate(names):
+    print("%-32s %9.0f cycles  (%4.1f %%)" % (nm, c[:, i].mean(), 100 * c[:, i].mean() / tot))
+print("total of the 8 steps %.0f cycles" % tot)
