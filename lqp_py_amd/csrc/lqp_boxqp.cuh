@@ -1899,7 +1899,8 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     __syncthreads();
     if (Kb > 0)
         for (int c0 = 0; c0 < 1 + m; c0 += NR)
-            wg_chol_solve_n<NR>(Ls, Kb, u0 + (size_t)c0 * Npm, Npm, (1 + m - c0) < NR ? (1 + m - c0) : NR, acc, t, part);
+            wg_chol_solve_n<NR>(Ls, Kb, u0 + (size_t)c0 * Npm, Npm, (1 + m - c0) < NR ? (1 + m - c0) : NR, acc, t, part,
+                                (P.dbg && P.la_maxk == 0) ? P.dbg + (size_t)b * 8 : nullptr);
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 1] = t - dt0; dt0 = t; }
     if (m > 0) {
         // S = A_F G - eps I,  wv = A_F u0  (one wave per entry)

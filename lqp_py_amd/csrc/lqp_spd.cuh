@@ -1471,37 +1471,50 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
 template <int NR>
 __device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, const int K, float* __restrict__ X, const int xs,
                                                 const int nc, float* __restrict__ acc, float* __restrict__ t,
-                                                float* __restrict__ part) {
+                                                float* __restrict__ part, unsigned long long* __restrict__ dbg = nullptr) {
+    constexpr int MC = SPD_MAXK - 1;
+    unsigned long long c0 = dbg ? clock64() : 0;                         // blocks below a diagonal block, at most
     const int tid = threadIdx.x, r = tid >> 4, cq = tid & 15, lane = tid & 63, w = tid >> 6;
     const int K64 = K * 64;
     const int tc = tid >> 6, te = tid & 63;                  // (column, element) of the per-column 64-vectors
+    auto blk4 = [&](const int i, const int j) -> V4<float> {
+        return *(const V4<float>*)(Ls + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4);
+    };
     for (int e = tid; e < NR * K64; e += LQP_NT) acc[e] = 0.f;
+    // All blocks of a block column are requested together, the next diagonal block one step ahead: one after the other
+    // (a loop with a run-time trip count) every load's L2 latency sat in the chain.
+    V4<float> bd = blk4(0, 0);
     __syncthreads();
     // ---- L y = v, column by column ----
     for (int j = 0; j < K; ++j) {
+        V4<float> bc[MC];
+#pragma unroll
+        for (int u = 0; u < MC; ++u)
+            if (j + 1 + u < K) bc[u] = blk4(j + 1 + u, j);
         if (tc < nc) t[tc * 64 + te] = X[(size_t)tc * xs + j * 64 + te] - acc[tc * K64 + j * 64 + te];
         __syncthreads();
-        {
-            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(j, j, K) * LQP_BLK + tid * 4);
 #pragma unroll
-            for (int c = 0; c < NR; ++c) {
-                if (c < nc) {
-                    const float s1 = rowgroup_sum<LQP_NT>(dot4(b, *(const V4<float>*)(t + c * 64 + cq * 4)));
-                    if (cq == 0) X[(size_t)c * xs + j * 64 + r] = s1;
-                }
+        for (int c = 0; c < NR; ++c) {
+            if (c < nc) {
+                const float s1 = rowgroup_sum<LQP_NT>(dot4(bd, *(const V4<float>*)(t + c * 64 + cq * 4)));
+                if (cq == 0) X[(size_t)c * xs + j * 64 + r] = s1;
             }
         }
+        if (j + 1 < K) bd = blk4(j + 1, j + 1);
         __syncthreads();
         V4<float> yj[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) yj[c] = *(const V4<float>*)(X + (size_t)(c < nc ? c : 0) * xs + j * 64 + cq * 4);
-        for (int i = j + 1; i < K; ++i) {
-            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4);
 #pragma unroll
-            for (int c = 0; c < NR; ++c) {
-                if (c < nc) {
-                    const float s1 = rowgroup_sum<LQP_NT>(dot4(b, yj[c]));
-                    if (cq == 0) acc[c * K64 + i * 64 + r] += s1;      // (row r of block row i always belongs to this thread)
+        for (int u = 0; u < MC; ++u) {
+            const int i = j + 1 + u;
+            if (i < K) {
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    if (c < nc) {
+                        const float s1 = rowgroup_sum<LQP_NT>(dot4(bc[u], yj[c]));
+                        if (cq == 0) acc[c * K64 + i * 64 + r] += s1;  // (row r of block row i always belongs to this thread)
+                    }
                 }
             }
         }
@@ -1519,19 +1532,28 @@ __device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, co
         }
         if (lane < 16) *(V4<float>*)(part + ((size_t)c * LQP_NW + w) * 64 + cq * 4) = o;
     };
+    if (dbg && threadIdx.x == 0) { const unsigned long long c1 = clock64(); dbg[4] += c1 - c0; c0 = c1; }
+    bd = blk4(K - 1, K - 1);
     for (int j = K - 1; j >= 0; --j) {
+        V4<float> bc[MC];
+#pragma unroll
+        for (int u = 0; u < MC; ++u)
+            if (j + 1 + u < K) bc[u] = blk4(j + 1 + u, j);
         float a2[NR][4];
 #pragma unroll
         for (int c = 0; c < NR; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) a2[c][e] = 0.f;
-        for (int i = j + 1; i < K; ++i) {
-            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(i, j, K) * LQP_BLK + tid * 4);
 #pragma unroll
-            for (int c = 0; c < NR; ++c) {
-                const float xi = X[(size_t)(c < nc ? c : 0) * xs + i * 64 + r];
+        for (int u = 0; u < MC; ++u) {
+            const int i = j + 1 + u;
+            if (i < K) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a2[c][e] += b.v[e] * xi;
+                for (int c = 0; c < NR; ++c) {
+                    const float xi = X[(size_t)(c < nc ? c : 0) * xs + i * 64 + r];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a2[c][e] += bc[u].v[e] * xi;
+                }
             }
         }
 #pragma unroll
@@ -1544,16 +1566,14 @@ __device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, co
             t[tc * 64 + te] = X[(size_t)tc * xs + j * 64 + te] - sum;
         }
         __syncthreads();
-        {
-            const V4<float> b = *(const V4<float>*)(Ls + (size_t)sym_idx(j, j, K) * LQP_BLK + tid * 4);
 #pragma unroll
-            for (int c = 0; c < NR; ++c) {
-                const float tr = t[c * 64 + r];
+        for (int c = 0; c < NR; ++c) {
+            const float tr = t[c * 64 + r];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a2[c][e] = b.v[e] * tr;
-                fold(a2[c], c);
-            }
+            for (int e = 0; e < 4; ++e) a2[c][e] = bd.v[e] * tr;
+            fold(a2[c], c);
         }
+        if (j > 0) bd = blk4(j - 1, j - 1);
         __syncthreads();
         if (tc < nc) {
             float sum = 0.f;
@@ -1563,6 +1583,7 @@ __device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, co
         }
         __syncthreads();
     }
+    if (dbg && threadIdx.x == 0) dbg[5] += clock64() - c0;
 }
 
 }  // namespace lqp

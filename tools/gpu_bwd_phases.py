@@ -27,7 +27,10 @@ for la in (0, 1):
     c = dbg.view(B, 8).double()
     print("lookahead %d  mean cycles: factor %.0f  solves %.0f  schur+finish %.0f   mean Kb %.2f (min %d max %d)" % (
         la, c[:, 0].mean(), c[:, 1].mean(), c[:, 2].mean(), c[:, 3].mean(), int(c[:, 3].min()), int(c[:, 3].max())))
-    print("   chain: waits %.0f  pivot blocks %.0f   tile waves: wait for W %.0f  rest of step %.0f" % (
-        c[:, 4].mean(), c[:, 5].mean(), c[:, 6].mean(), c[:, 7].mean()))
+    if la:
+        print("   chain waves: waits %.0f  pivot blocks %.0f   tile waves: wait for W %.0f  rest of step %.0f" % (
+            c[:, 4].mean(), c[:, 5].mean(), c[:, 6].mean(), c[:, 7].mean()))
+    else:       # (the same words then hold the two halves of the solves)
+        print("   solves: forward substitution %.0f  backward substitution %.0f" % (c[:, 4].mean(), c[:, 5].mean()))
 print("bit-identical gradients:", torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1]),
       " finite:", bool(torch.isfinite(grads[1][0]).all()))
