@@ -264,7 +264,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         int want = ctl->linsolve;
         if (want == 0) want = env_int("LQP_LINSOLVE", 0);
         const bool rho_pos = !(ctl->rho_mode == 1 && !(ctl->rho_value > 0.0));
-        spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_MAXK && m <= SPD_MAXM;
+        // (512 < n <= 1024: the sweep parks its panel in the M area, see wg_spd_sweep_big)
+        spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_BIGK && m <= SPD_MAXM &&
+              (P.Ks <= SPD_MAXK || ((size_t)P.Np * P.Np >= (size_t)P.Ks * LQP_BLK && env_int("LQP_SPD_BIG", 1)));
     }
     P.spd = spd ? 1 : 0;
     P.qs_lazy = (spd && env_int("LQP_QS_LAZY", 1)) ? 1 : 0;
@@ -273,13 +275,21 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // symmetric path with fewer problems than half the CUs: share each matrix between SPD_NP workgroups
     bool spd_split = false;
     const int spd_pivot_tasks = env_int("LQP_SPD_PTASKS", 48);
-    if (spd && P.Ks >= 3) {
+    if (spd && P.Ks >= 3 && P.Ks <= SPD_MAXK) {
         int dev_ = 0, cus_ = 0;
         if (hipGetDevice(&dev_) == hipSuccess &&
             hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess)
             spd_split = B * SPD_NP <= cus_;
         spd_split = env_int("LQP_SPD_SPLIT", spd_split ? 1 : 0) != 0;
         spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
+    }
+    bool spd_big_split = false;
+    if (spd && P.Ks > SPD_MAXK) {
+        int dev_ = 0, cus_ = 0;
+        if (hipGetDevice(&dev_) == hipSuccess &&
+            hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess)
+            spd_big_split = B * SPD_NP <= cus_;
+        spd_big_split = env_int("LQP_SPD_SPLIT", spd_big_split ? 1 : 0) != 0;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
     const bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK + 2 &&
@@ -307,6 +317,21 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 const int r2 = ensure_lds((const void*)k_spd_inverse, lds);
                 if (r2) return r2;
                 ProfScope ps(st, PC_SPD_INV);
+                if (spd_big_split) {
+                    // 512 < n <= 1024, few problems: two workgroups per matrix, a launch per phase of a pivot step
+                    int r3 = ensure_lds((const void*)k_spd_begin, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_big_step, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_end, lds);
+                    if (r3) return r3;
+                    hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
+                    for (int k = 0; k < P.Ks; ++k) {
+                        hipLaunchKernelGGL(k_spd_big_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 1);
+                        hipLaunchKernelGGL(k_spd_big_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 2);
+                    }
+                    hipLaunchKernelGGL(k_spd_end, dim3(B), dim3(LQP_NT), lds, st, P, gate);
+                    n_launch += 2 * P.Ks + 2;
+                    return LQP_OK;
+                }
                 if (spd_split) {
                     // few problems: SPD_NP workgroups per matrix, one launch per pivot step (k_spd_begin/step/end)
                     int r3 = ensure_lds((const void*)k_spd_begin, lds);
@@ -411,7 +436,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     int split_lds = 0, split_nt = 512;
     void (*split_fn)(const FwdParams<float>, const int, const int, const int) = nullptr;
     if constexpr (sizeof(T) == 4) {
-        if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && check >= 4 && env_int("LQP_LOOP_SPLIT", 1) != 0) {
+        if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && env_int("LQP_LOOP_SPLIT", 1) != 0) {
             // 512 threads x 256 VGPRs: every block of the workgroup's half lives in registers.  (The 1024-thread
             // build -- 12 blocks in 128 VGPRs, 6 in LDS, 16 waves -- spills ~60 VGPRs into the hot loop and measured
             // 0.38 ms against 0.28 ms at B = 128, n = 500; the template still takes NT = 1024.)
@@ -503,7 +528,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
                 stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
                 stats->linsolve_used = spd ? 2 : 1;
-                stats->factor_launches = spd ? (spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
+                stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
                 stats->loop_workgroups = loop_split ? 2 : 1;
             }
             return LQP_OK;
@@ -629,7 +654,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->n_launch = n_launch;
         stats->mode_used = mode;
         stats->linsolve_used = spd ? 2 : 1;
-        stats->factor_launches = spd ? (spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
+        stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
         stats->loop_workgroups = (loop_split && mode == 2) ? 2 : 1;
     }
     return LQP_OK;
@@ -982,7 +1007,8 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const vo
 size_t lqp_spd_inverse_workspace_bytes(int dtype, int B, int n) {
     if (dtype != LQP_F32 || B < 0 || n < 1) return 0;
     const int Ks = round_up(n, LQP_NB) / LQP_NB;
-    return (size_t)B * sym_blocks(Ks) * LQP_BLK * sizeof(float) + kAlign;
+    // (above 512: + the panel scratch of wg_spd_sweep_big)
+    return (size_t)B * (sym_blocks(Ks) + (Ks > SPD_MAXK ? Ks - 1 : 0)) * LQP_BLK * sizeof(float) + 2 * kAlign;
 }
 
 int lqp_spd_inverse_batched(void* stream, int dtype, int B, int n, const void* K_in, void* Kinv_out, int32_t* info_out,
@@ -990,18 +1016,19 @@ int lqp_spd_inverse_batched(void* stream, int dtype, int B, int n, const void* K
     if (dtype != LQP_F32) return LQP_ERR_UNSUPPORTED;
     if (B < 0 || n < 1 || !K_in || !Kinv_out || !info_out || !workspace) return LQP_ERR_INVALID;
     const int Ks = round_up(n, LQP_NB) / LQP_NB;
-    if (Ks > SPD_MAXK) return LQP_ERR_UNSUPPORTED;
+    if (Ks > SPD_BIGK) return LQP_ERR_UNSUPPORTED;
     if (workspace_bytes < lqp_spd_inverse_workspace_bytes(dtype, B, n)) return LQP_ERR_WORKSPACE;
     if (B == 0) return LQP_OK;
     hipStream_t st = (hipStream_t)stream;
     Carver c(workspace);
     float* Hs = c.take<float>((size_t)B * sym_blocks(Ks) * LQP_BLK);
-    const int lds = spd_lds_bytes(Ks);
+    float* Yg = Ks > SPD_MAXK ? c.take<float>((size_t)B * (Ks - 1) * LQP_BLK) : nullptr;
+    const int lds = spd_lds_bytes(Ks > SPD_MAXK ? SPD_MAXK : Ks);
     int rc = ensure_lds((const void*)k_spd_inverse_dense, lds);
     if (rc) return rc;
     { ProfScope ps(st, PC_SPD_INV);
       hipLaunchKernelGGL(k_spd_inverse_dense, dim3(B), dim3(LQP_NT), lds, st, (const float*)K_in, (float*)Kinv_out, Hs,
-                         (int*)info_out, n, Ks); }
+                         (int*)info_out, n, Ks, Yg); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 

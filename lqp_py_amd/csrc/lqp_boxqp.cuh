@@ -559,14 +559,15 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
 // standalone SPD inverse (test / utility entry lqp_spd_inverse_batched): dense (B,n,n) in, dense inverse out
 __global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __restrict__ Kin, float* __restrict__ out,
                                                               float* __restrict__ Hs_all, int* __restrict__ info,
-                                                              const int n, const int Ks) {
+                                                              const int n, const int Ks, float* __restrict__ Yg_all) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     float* Hs = Hs_all + (size_t)b * sym_blocks(Ks) * LQP_BLK;
     if (tid == 0) info[b] = 0;
     wg_sym_init(Hs, Kin + (size_t)b * n * n, n, n, Ks, 0.f);
     __syncthreads();
-    wg_spd_sweep(Hs, Ks, info + b, smem);
+    if (Ks > SPD_MAXK) wg_spd_sweep_big(Hs, Ks, info + b, smem, Yg_all + (size_t)b * (Ks - 1) * LQP_BLK);
+    else wg_spd_sweep(Hs, Ks, info + b, smem);
     __syncthreads();
     float* o = out + (size_t)b * n * n;
     const int r = tid >> 4, c4 = (tid & 15) * 4;
@@ -705,7 +706,8 @@ __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const i
     }
     wg_sym_init(Hs, Qs, ldq, P.n, P.Ks, rho, dsc);
     __syncthreads();
-    wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
+    if (P.Ks > SPD_MAXK) wg_spd_sweep_big(Hs, P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np);   // (M: unused on this path)
+    else wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
     if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
     if (P.m > 0) {
         __syncthreads();
@@ -713,7 +715,7 @@ __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const i
     }
 }
 __host__ __device__ inline int spd_factor_lds_bytes(int m, int Ks) {
-    const int a = spd_lds_bytes(Ks), c = m > 0 ? eqc_lds_bytes(m, Ks) : 0;
+    const int a = spd_lds_bytes(Ks > SPD_MAXK ? SPD_MAXK : Ks), c = m > 0 ? eqc_lds_bytes(m, Ks) : 0;
     return a > c ? a : c;
 }
 __global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P, const int* __restrict__ gate) {
@@ -742,7 +744,8 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, 
     // the blocks are written without rho
     const bool late = gate == nullptr && P.rho_late;
     float* fro_out = late ? (P.M + (size_t)b * P.Np * P.Np + (size_t)2 * P.Ks * LQP_BLK + part) : nullptr;
-    const float asym = wg_sym_check_init<SPD_NP>(spd_half(P, b, P.Ks & 1), Qs, (P.scale && !lazy) ? P.ldq : P.n, P.n, P.Ks,
+    // (K <= 8: the launches after this one go back and forth between the two halves and end in half 0; above: in place)
+    const float asym = wg_sym_check_init<SPD_NP>(spd_half(P, b, P.Ks > SPD_MAXK ? 0 : (P.Ks & 1)), Qs, (P.scale && !lazy) ? P.ldq : P.n, P.n, P.Ks,
                                                  late ? 0.f : P.scal[(size_t)b * SC_WORDS + SC_RHO], (float*)smem,
                                                  gate == nullptr, part, dsc, fro_out);
     if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
@@ -755,6 +758,15 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, c
     // W, W^T of the next pivot block travel between the launches in the (unused on this path) KKT matrix area
     wg_spd_sweep<SPD_NP>(spd_half(P, b, (P.Ks - k) & 1), P.Ks, P.info + b, smem, nullptr, spd_half(P, b, (P.Ks - k - 1) & 1),
                          k, k + 1, part, P.M + (size_t)b * P.Np * P.Np, pivot_tasks);
+}
+// 512 < n <= 1024, few problems: one launch per PHASE of a pivot step (1: pivot block + Y phase, 2: tile updates), two
+// workgroups per matrix, in place in half 0; the panel scratch is the (unused on this path) KKT matrix area.
+__global__ __launch_bounds__(LQP_NT) void k_spd_big_step(const FwdParams<float> P, const int* __restrict__ gate, const int k,
+                                                          const int phases) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
+    wg_spd_sweep_big<SPD_NP>(spd_half(P, b, 0), P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np, k, k + 1, phases, part);
 }
 // all pivot steps in ONE launch, the matrix resident in the registers of its two workgroups (lqp_spd.cuh).  Reads the
 // blocks k_spd_begin built (half Ks & 1 of the packed area), leaves -(Qs + rho I)^-1 in half 0, where the loop reads it.

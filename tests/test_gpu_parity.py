@@ -334,15 +334,16 @@ def test_g5_config4_n1000(dev):
     g = load_golden("g5_b128_n1000_eq")
     inp = O.create_qp_data(1000, 128, seed=0)
     sol, _ = solve(dev, inp, O.make_control(**TOL))
-    assert sol["iter"] == g["iter"] == 60
+    assert sol["iter"] == g["iter"] == 60 and sol["_stats"]["linsolve_used"] == 2      # symmetric path up to n = 1024
     P.record("g5_b128_n1000_eq", "x", err(sol["x"], g["x"]), linsolve=sol["_stats"]["linsolve_used"])
     assert err(sol["x"], g["x"]) < 2 * X_TOL and rel(sol["rho"], g["rho"]) < 1e-4
 
 
 
 # ---------------------------------------------------------------- symmetric-inverse x-update (linsolve 'spd')
-@pytest.mark.parametrize("n,B", [(1, 2), (10, 3), (64, 2), (65, 2), (300, 3), (512, 2)])
+@pytest.mark.parametrize("n,B", [(1, 2), (10, 3), (64, 2), (65, 2), (300, 3), (512, 2), (513, 2), (700, 2), (1000, 3), (1024, 1)])
 def test_spd_inverse_entry(dev, n, B):
+    """n <= 512: the panel of a pivot step lives in LDS; 512 < n <= 1024: wg_spd_sweep_big parks it in global scratch."""
     lib = _lib.load()
     torch.manual_seed(n)
     Lm = torch.randn(B, 2 * n + 2, n)
@@ -361,8 +362,8 @@ def test_spd_inverse_entry(dev, n, B):
     st = lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 0, B, n, _lib.ptr(K2), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), nb)
     assert st == 0 and int(info[0]) > 0 and info[1:].tolist() == [0] * (B - 1)
     assert lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 1, B, n, _lib.ptr(K), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), nb) == 6
-    assert lib.lqp_spd_inverse_workspace_bytes(0, 1, 513) > 0 and \
-        lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 0, 1, 513, _lib.ptr(K), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), 1 << 40) == 6
+    assert lib.lqp_spd_inverse_workspace_bytes(0, 1, 1025) > 0 and \
+        lib.lqp_spd_inverse_batched(_lib.stream_ptr(dev), 0, 1, 1025, _lib.ptr(K), _lib.ptr(out), _lib.ptr(info), _lib.ptr(ws), 1 << 40) == 6
 
 
 @pytest.mark.parametrize("n,m,B", [(10, 0, 5), (64, 1, 3), (100, 3, 4), (448, 16, 2), (512, 2, 2)])
