@@ -65,7 +65,7 @@ typedef struct lqp_boxqp_ctrl {
                                         status / info later (lqp_boxqp_forward_layout)                       */
     int32_t linsolve;                /* x-update linear algebra: 0 auto, 1 pivoted LU of the KKT matrix (the
                                         reference's, :214-215/:267), 2 symmetric inverse of Qs + rho I with a
-                                        rank-m equality correction (f32, n <= 512, m <= 16, rho > 0; anything
+                                        rank-m equality correction (f32, n <= 1024, m <= 16, rho > 0; anything
                                         else, or a matrix that is not positive definite, runs on LU)            */
     int32_t reserved2;
     double eps_abs;
@@ -202,7 +202,7 @@ int lqp_lu_pack(void* stream, int dtype, int B, int N,
 int lqp_lu_solve_packed(void* stream, int dtype, int B, int N, int k,
                         const void* packed, void* rhs_inout);
 
-/* ---- batched SPD inverse (f32, n <= 512) ---------------------------------
+/* ---- batched SPD inverse (f32, n <= 1024) ---------------------------------
  * Building block of linsolve 2 (the x-update x = H w + c replaces the cached LU solve of
  * solve_box_qp_admm_torch.py:267): Kinv_out (B,n,n) = K_in^-1 for symmetric positive definite K_in (B,n,n);
  * info (B) int32: 0, or 1 + index of the first non-positive pivot (K_in not positive definite).           */
