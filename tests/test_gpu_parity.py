@@ -830,6 +830,37 @@ def test_equality_correction_in_the_loop_kernel(dev, monkeypatch, n, B, m):
         assert float((A.to(dev) @ out["1"]["x"] - b.to(dev)).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("n,B,m", [(576, 3, 2), (1000, 2, 1), (1024, 2, 0)])
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_symmetric_path_above_512(dev, monkeypatch, n, B, m, split):
+    """512 < n <= 1024: the sweep parks its panel in L2 (wg_spd_sweep_big) -- one workgroup per matrix in one launch, or
+    two per matrix with a launch per phase of a pivot step.  Against the oracle, and against the LU path of the same
+    call; rho = 100 forces adaptive-rho refactorisations (in-kernel in the persistent mode)."""
+    monkeypatch.setenv("LQP_SPD_SPLIT", split)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
+    for kw in (dict(max_iters=41, eps_abs=1e-12, eps_rel=1e-12), dict(rho=100.0, **TOL)):
+        sol, _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(**kw))
+        assert sol["_stats"]["linsolve_used"] == 2
+        assert sol["_stats"]["factor_launches"] == (2 * ((n + 63) // 64) + 2 if split == "1" else 1)
+        lu, _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve="lu", **kw))
+        ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**kw))
+        scale = max(1.0, float(ref["x"].abs().max()))
+        if "rho" in kw:
+            assert sol["_stats"]["n_factor"] >= 2 and abs(sol["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
+            assert err(sol["x"], ref["x"]) < 5e-4 * scale
+        else:
+            # (41 iterations from a cold start at n = 1000: fp32 rounding of either factorisation shows in the scaled
+            #  dual u at the 5e-5 level -- the LU path is as far from the fp32 oracle as this one)
+            for k in ("x", "u", "lams") + (("nus",) if m else ()):
+                tol = (2 if k == "x" else 8) * X_TOL * scale
+                P.record(f"symmetric_above_512_n{n}_split{split}", k, err(sol[k], ref[k]), lu_path=err(lu[k], ref[k]))
+                assert err(sol[k], ref[k]) < tol, k
+                assert err(sol[k], lu[k]) < tol, k
+
+
 # ---------------------------------------------------------------- config 5: the per-GPU shard of B=8192 over 8 GPUs
 def test_config5_shard_b1024_n500(dev):
     """BASELINE configs[4]: batch 8192 dz 500 sharded over 8 GPUs = 1024 QPs per GPU, forward + backward through the
