@@ -245,6 +245,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
     P.scale = ctl->scale; P.any_lb = ctl->any_lb; P.any_ub = ctl->any_ub;
     P.dbg = g_lu_dbg;
+    P.dbg_setup = nullptr;
+    if (g_lu_dbg && env_int("LQP_DBG_SETUP", 0)) { P.dbg_setup = g_lu_dbg; P.dbg = nullptr; }
     P.rho_mode = ctl->rho_mode; P.beta_mode = ctl->beta_mode;
     P.check_solved = ctl->check_solved < 1 ? 1 : ctl->check_solved;
     P.adaptive_rho = ctl->adaptive_rho;

@@ -25,6 +25,7 @@ template <typename T> struct FwdParams {
     int Ks, sym_rl, sym_rl_hot;          // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
                                          // (continuation kernel / 512-thread first launch)
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
+    unsigned long long* dbg_setup;       // the same words for k_fwd_setup's stamps (LQP_DBG_SETUP=1: then only those)
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
@@ -226,18 +227,19 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     T* scal = P.scal + (size_t)b * SC_WORDS;
     if (tid == 0) P.info[b] = 0;
     unsigned long long tst = clock64();
-#define SETUP_STAMP(i) do { if (P.dbg && tid == 0) { const unsigned long long t_ = clock64(); P.dbg[(size_t)b * 8 + (i)] = t_ - tst; tst = t_; } } while (0)
+#define SETUP_STAMP(i) do { if (P.dbg_setup && tid == 0) { const unsigned long long t_ = clock64(); P.dbg_setup[(size_t)b * 8 + (i)] = t_ - tst; tst = t_; } } while (0)
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * (2 * 2 * SPD_MAXK * LQP_NB);
         for (int i = tid; i < 2 * 2 * SPD_MAXK * LQP_NB; i += LQP_NT) xq[i] = 0ull;
         if (tid == 0) P.xchg[(size_t)P.B * (2 * 2 * SPD_MAXK * LQP_NB) + b] = 0ull;      // step flags of the resident sweep
     }
 
-    // ---- ||p||_inf on the unscaled p (:127) ----
-    T pm = T(0);
-    for (int i = tid; i < n; i += LQP_NT) pm = tmax(pm, tabs(p[i]));
-    pm = wg_max(pm, scratch);
-    if (tid == 0) scal[SC_PNORM] = pm;
+    // the small vectors are requested now and used after the pass over Q (n <= 1024: one element per thread; a load
+    // issued where it is needed costs a full memory latency each time, ~2 us, with nothing to hide it behind)
+    const T* lb = P.lb + (size_t)b * n;
+    const T* ub = P.ub + (size_t)b * n;
+    const T p0 = tid < n ? p[tid] : T(0), lb0 = tid < n ? lb[tid] : T(0), ub0 = tid < n ? ub[tid] : T(0);
+    const T a0 = (m > 0 && tid < n) ? P.A[(size_t)b * m * n + tid] : T(0);          // first equality row
 
     SETUP_STAMP(0);
     const T* Qs = Q;
@@ -379,9 +381,9 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         }
         q_in_m = true;
         Qs = Qw;
-        for (int i = tid; i < n; i += LQP_NT) V.ps[i] = d[i] * p[i];       // (:177)
+        for (int i = tid; i < n; i += LQP_NT) V.ps[i] = d[i] * (i == tid ? p0 : p[i]);       // (:177)
     } else {
-        for (int i = tid; i < n; i += LQP_NT) { V.D[i] = T(1); V.ps[i] = p[i]; }
+        for (int i = tid; i < n; i += LQP_NT) { V.D[i] = T(1); V.ps[i] = i == tid ? p0 : p[i]; }
         if (P.rho_mode == 0 && !(P.rho_late && P.spd)) {
             for (int i = w; i < n; i += LQP_NW) {
                 const T* qr = Q + (size_t)i * n;
@@ -390,6 +392,13 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         }
     }
     SETUP_STAMP(4);
+    // ---- ||p||_inf on the unscaled p (:127) ----
+    {
+        T pm = tabs(p0);
+        for (int i = tid + LQP_NT; i < n; i += LQP_NT) pm = tmax(pm, tabs(p[i]));
+        pm = wg_max(pm, scratch);
+        if (tid == 0) scal[SC_PNORM] = pm;
+    }
     // ---- rho (:140, :157-158, :200-203) ----
     T rho;
     if (P.rho_mode == 0) {
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             for (int r = 0; r < m; ++r) {
                 T am = T(0);
                 for (int j = tid; j < n; j += LQP_NT) {
-                    const T v = A[(size_t)r * n + j] * d[j];
+                    const T v = ((r == 0 && j == tid) ? a0 : A[(size_t)r * n + j]) * d[j];
                     V.As[(size_t)r * n + j] = v;
                     am = tmax(am, tabs(v));
                 }
@@ -437,13 +446,11 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     }
     SETUP_STAMP(5);
     // ---- bounds (:192-194) and state ----
-    const T* lb = P.lb + (size_t)b * n;
-    const T* ub = P.ub + (size_t)b * n;
     const bool any_ineq = P.any_lb || P.any_ub;
     for (int i = tid; i < n; i += LQP_NT) {
         const T di = (P.scale && any_ineq) ? V.D[i] : T(1);
-        V.lbs[i] = lb[i] / di;
-        V.ubs[i] = ub[i] / di;
+        V.lbs[i] = (i == tid ? lb0 : lb[i]) / di;
+        V.ubs[i] = (i == tid ? ub0 : ub[i]) / di;
         V.z[i] = T(0); V.u[i] = T(0); V.x[i] = T(0);
     }
     for (int r = tid; r < m; r += LQP_NT) V.nu[r] = T(0);

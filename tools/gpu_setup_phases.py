@@ -8,6 +8,7 @@ import lqp_py_amd as L
 from lqp_py_amd import _lib
 from lqp_py_amd.synthetic import create_qp_data
 dev = torch.device("cuda:0")
+os.environ["LQP_DBG_SETUP"] = "1"          # only the setup kernel writes the debug words
 lib = _lib.load()
 B, n = 128, 500
 inp = [t.to(dev) for t in create_qp_data(n, B, seed=0)]
