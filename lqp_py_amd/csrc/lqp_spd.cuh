@@ -299,6 +299,7 @@ __device__ __forceinline__ void lds_wait_ge(int* word, const int target) {
 #ifndef LQP_PIV_EXP
 #define LQP_PIV_EXP 0      // timing experiments only: 1 = no panel sync, 2 = no update phase, 4 = no column steps
 #endif
+typedef float piv_f2 __attribute__((ext_vector_type(2)));
 template <int NWP, bool GSYNC = false>
 __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk, float* __restrict__ W,
                                                float* __restrict__ WT, float* __restrict__ pcol,
@@ -306,7 +307,7 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
                                                int* __restrict__ gaux = nullptr, int* __restrict__ gseq = nullptr) {
     static_assert(NWP == 4 || NWP == 8 || NWP == 16, "4, 8 or 16 pivot waves");
     constexpr int CW = 64 / NWP;                 // columns per wave
-    static_assert(CW % PIV_NB == 0, "a panel lives in one wave");
+    static_assert(CW % PIV_NB == 0 && PIV_NB % 2 == 0, "a panel lives in one wave; columns are updated in pairs");
     const int tid = threadIdx.x, w = tid >> 6;
     const int prw = tid & 63, pq = w;
     const bool pwork = pq < NWP;
@@ -355,8 +356,15 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
                         for (int t2 = 0; t2 < PIV_NB; ++t2)
                             pr[t2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[pp * PIV_NB + t2]), c));
                         __builtin_amdgcn_sched_barrier(0);
+                        {
+                            const piv_f2 nc = piv_f2{-coef, -coef};
 #pragma unroll
-                        for (int t2 = 0; t2 < PIV_NB; ++t2) xq[pp * PIV_NB + t2] -= coef * pr[t2];
+                            for (int t2 = 0; t2 < PIV_NB; t2 += 2) {
+                                piv_f2 x = piv_f2{xq[pp * PIV_NB + t2], xq[pp * PIV_NB + t2 + 1]};
+                                x = __builtin_elementwise_fma(nc, piv_f2{pr[t2], pr[t2 + 1]}, x);
+                                xq[pp * PIV_NB + t2] = x[0]; xq[pp * PIV_NB + t2 + 1] = x[1];
+                            }
+                        }
                         xq[ec] = below ? -coef : (on ? 1.f : xq[ec]);
                         cf[t * 64 + prw] = coef;
                         sreg[t] = s;
@@ -395,9 +403,17 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
                                     if (e / PIV_NB != pp)
                                         pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
                                 __builtin_amdgcn_sched_barrier(0);
+                                {
+                                    const piv_f2 nc = piv_f2{-cv[t], -cv[t]};
 #pragma unroll
-                                for (int e = 0; e < CW; ++e)
-                                    if (e / PIV_NB != pp) xq[e] -= cv[t] * pr[e];
+                                    for (int e = 0; e < CW; e += 2) {
+                                        if (e / PIV_NB != pp) {
+                                            piv_f2 x = piv_f2{xq[e], xq[e + 1]};
+                                            x = __builtin_elementwise_fma(nc, piv_f2{pr[e], pr[e + 1]}, x);
+                                            xq[e] = x[0]; xq[e + 1] = x[1];
+                                        }
+                                    }
+                                }
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -410,8 +426,17 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
                             for (int e = 0; e < CW; ++e)
                                 pr[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xq[e]), c));
                             __builtin_amdgcn_sched_barrier(0);
+                            // two columns per v_pk_fma_f32 (the pivot-row pair straight from the SGPR pair the two
+                            // v_readlane wrote; same rounding as the scalar FMA): the update phase is issue bound
+                            {
+                                const piv_f2 nc = piv_f2{-cv[t], -cv[t]};
 #pragma unroll
-                            for (int e = 0; e < CW; ++e) xq[e] -= cv[t] * pr[e];
+                                for (int e = 0; e < CW; e += 2) {
+                                    piv_f2 x = piv_f2{xq[e], xq[e + 1]};
+                                    x = __builtin_elementwise_fma(nc, piv_f2{pr[e], pr[e + 1]}, x);
+                                    xq[e] = x[0]; xq[e + 1] = x[1];
+                                }
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
