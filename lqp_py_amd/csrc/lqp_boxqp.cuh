@@ -1163,8 +1163,8 @@ template <int NT> __host__ __device__ constexpr int split_loop_lds_floats(int Ks
     return split_lds_blocks<NT>(Ks) * LQP_BLK + (3 + NT / 64 + 10) * Ks * LQP_NB + (NT / 64) * 8 + 8 + 8;
 }
 template <int NT> __host__ __device__ inline int split_loop_lds_bytes(int Ks, int m) {
-    // + the equality block: G, T (m x Nps each), S, S^-1 (m x m), s0, b, nu, nu snapshot
-    return (split_loop_lds_floats<NT>(Ks) + 2 * m * Ks * LQP_NB + 2 * m * m + 4 * m + 8) * 4;
+    // + the equality block: As, G, T (m x Nps each), S, S^-1 (m x m), s0, b, nu, nu snapshot
+    return (split_loop_lds_floats<NT>(Ks) + 3 * m * Ks * LQP_NB + 2 * m * m + 4 * m + 8) * 4;
 }
 
 template <int KS, int NT, bool DBG = false>
@@ -1197,7 +1197,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     int* const flags = (int*)(red + NWV * 8 + 8);             // [0] exchange timed out (sticky), [1] verdict of this iteration
     T* const Gl = (T*)(flags + 8);                            // equality block: G = K^-1 As^T, T = G S^-1 (m x Nps each)
     T* const Tl = Gl + (size_t)m * Nps;
-    T* const Sm = Tl + (size_t)m * Nps;
+    T* const Asl = Tl + (size_t)m * Nps;                      // the scaled equality rows (read at every check)
+    T* const Sm = Asl + (size_t)m * Nps;
     T* const Si = Sm + m * m;
     T* const s0l = Si + m * m;
     T* const bs = s0l + m;
@@ -1222,6 +1223,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
         yrow[i] = T(0);                                       // rows / columns of the partner stay zero
     }
     for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
+    for (int i = tid; i < m * Nps; i += NT) { const int q = i / Nps, e = i - q * Nps; Asl[i] = e < n ? V.As[(size_t)q * n + e] : T(0); }
     for (int i = tid; i < NWV * Nps; i += NT) part[i] = T(0);
     if (tid < 8) flags[tid] = 0;
     __syncthreads();
@@ -1239,10 +1241,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     if (eq_here) {
         if (part_id == 0 && tid == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;      // (k_spd_end did not run)
         for (int q = 0; q < m; ++q) {
-            for (int i = tid; i < Nps; i += NT) v[i] = i < n ? V.As[(size_t)q * n + i] : T(0);
-            wg_barrier_lds();
-            if (part_id == 0) wg_sym_gemv_split<KS, 0, NT>(rr, lds_res, Nps, v, yrow, part);
-            else wg_sym_gemv_split<KS, 1, NT>(rr, lds_res, Nps, v, yrow, part);
+            if (part_id == 0) wg_sym_gemv_split<KS, 0, NT>(rr, lds_res, Nps, Asl + (size_t)q * Nps, yrow, part);
+            else wg_sym_gemv_split<KS, 1, NT>(rr, lds_res, Nps, Asl + (size_t)q * Nps, yrow, part);
             wg_barrier_lds();
             if (tid < Nps) {
                 const int i = tid;
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
         for (int t = w; t < m * m; t += NWV) {
             const int q = t / m, q2 = t - q * m;
             T acc = T(0);
-            for (int i = lane; i < n; i += 64) acc += V.As[(size_t)q * n + i] * Gl[(size_t)q2 * Nps + i];
+            for (int i = lane; i < n; i += 64) acc += Asl[(size_t)q * Nps + i] * Gl[(size_t)q2 * Nps + i];
             acc = wave_sum(acc);
             if (lane == 0) Sm[t] = acc;
         }
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
                         mx[3] = tabs(di * zn);
                         mx[4] = tabs((rho * di) * un);
                         T qx = v[i] - rho * xi;
-                        for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + i] * nus_l[q];
+                        for (int q = 0; q < m; ++q) qx -= Asl[(size_t)q * Nps + i] * nus_l[q];
                         mx[5] = tabs(qx / di);
                     }
                 }
