@@ -830,6 +830,26 @@ def test_equality_correction_in_the_loop_kernel(dev, monkeypatch, n, B, m):
         assert float((A.to(dev) @ out["1"]["x"] - b.to(dev)).abs().max()) < 1e-4
 
 
+def test_continuation_launch_finds_corrected_blocks(dev):
+    """The two-workgroup loop kernel applies the equality correction to its register blocks; when the loop has to go on in
+    a continuation launch (here: tolerances that are never met, more iterations than one launch may hold, no adaptive rho
+    so that nothing is refactorised) the blocks must have been written back WITH the correction: the continuation reads
+    them from global memory."""
+    n, B, m = 300, 2, 2
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=77, with_eq=False)
+    g = torch.Generator().manual_seed(77)
+    A = torch.randn(B, m, n, generator=g)
+    b = 0.1 * torch.randn(B, m, 1, generator=g)
+    kw = dict(max_iters=5135, eps_abs=1e-30, eps_rel=1e-30, adaptive_rho=False)
+    sol, _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(**kw))
+    st = sol["_stats"]
+    assert st["linsolve_used"] == 2 and st["loop_workgroups"] == 2 and st["n_factor"] == 1 and sol["iter"] == 5134
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(max_iters=400, eps_abs=1e-30, eps_rel=1e-30, adaptive_rho=False))
+    for k in ("x", "u", "nus"):
+        assert err(sol[k], ref[k]) < 5e-5 * max(1.0, float(ref[k].abs().max())), k        # (both sit at the fixed point)
+    assert float((A.to(dev) @ sol["x"] - b.to(dev)).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("n,B,m", [(576, 3, 2), (1000, 2, 1), (1024, 2, 0)])
 @pytest.mark.parametrize("split", ["1", "0"])
 def test_symmetric_path_above_512(dev, monkeypatch, n, B, m, split):
