@@ -22,6 +22,8 @@ for c in range(cases):
     A = torch.randn(B, m, n, generator=g) if m else None
     b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
     kw = dict(max_iters=its, eps_abs=1e-12, eps_rel=1e-12)
+    if os.environ.get("FUZZ_CONVERGE"):       # run to the tolerance instead, with a rho that forces refactorisations
+        kw = dict(eps_abs=1e-5, eps_rel=1e-5, rho=rng.choice([None, 100.0, 0.01]))
     ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**kw))
     args = [None if t is None else t.to(dev) for t in (Q, p, A, b, lb, ub)]
     Qg = args[0].clone().requires_grad_(True); pg = args[1].clone().requires_grad_(True)
@@ -39,7 +41,10 @@ for c in range(cases):
     ep = float((pg.grad.cpu() - gr[1])[okb].abs().max()) / gs if okb.any() else 0.0
     qs = max(1.0, float(gr[0].abs().max()))
     eq = float((Qg.grad.cpu() - gr[0])[okb].abs().max()) / qs if okb.any() else 0.0
-    bad = not (ex < 5e-5 and ep < 2e-3 and eq < 2e-3) or not torch.isfinite(x).all()
+    if os.environ.get("FUZZ_CONVERGE"):       # (the stop may fall on another check: tolerance-level agreement)
+        bad = not (ex < 1e-3) or not torch.isfinite(x).all()
+    else:
+        bad = not (ex < 5e-5 and ep < 2e-3 and eq < 2e-3) or not torch.isfinite(x).all()
     print("%s n=%4d m=%2d B=%d its=%d  x %.1e  dp %.1e  dQ %.1e" % ("BAD" if bad else "ok ", n, m, B, its, ex, ep, eq), flush=True)
     worst[(n, m)] = max(worst.get((n, m), 0.0), ex)
 print("done in %.0f s" % (time.time() - t0))
