@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Random shapes through the layer (forward + backward) against the CPU oracle at a fixed iteration count.
-usage: python tools/gpu_fuzz.py [cases] [seed]"""
+usage: python tests/tools/gpu_fuzz.py [cases] [seed]   (FUZZ_BIG_B=1: batches above the two-workgroup limit; FUZZ_CONVERGE=1: run to the
+tolerance with a rho that forces refactorisations).  Test infrastructure: the oracle is the checker."""
 import os, sys, random, time
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 import lqp_py_amd as L
 from oracle import boxqp_oracle as O
