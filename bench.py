@@ -197,7 +197,7 @@ def main():
         if linsolve != "auto":
             control['linsolve'] = linsolve
         control['sync'] = bool(sync)     # False: the pipelined training-loop mode (errors reported late, NaN on failure)
-        return control, (ShardedBoxQP(control) if world > 1 else L.SolveBoxQP(control=control))
+        return control, (ShardedBoxQP(control, shard_sizes=[B] * world) if world > 1 else L.SolveBoxQP(control=control))
 
     control, layer = make_layer(args.linsolve, args.sync)
 

@@ -57,6 +57,10 @@ def global_bound_flags(lb, ub, group=None):
         return local
     flags = torch.tensor([int(local[0]), int(local[1])], dtype=torch.int32, device=lb.device)
     all_reduce_(flags, dist.ReduceOp.MAX, group)
+    if local[0] and local[1]:
+        # MAX over the ranks of a flag that is already 1 here is 1: nothing to read back, the collective (issued all
+        # the same, so that every rank takes part in it) stays asynchronous -- no host round trip in the steady state
+        return True, True
     f = flags.tolist()
     return bool(f[0]), bool(f[1])
 
@@ -68,20 +72,26 @@ def _local_flags(lb, ub):
     return _finite_bounds(lb, ub)
 
 
-def all_gather_solutions(x_local, group=None):
+def all_gather_solutions(x_local, group=None, sizes=None):
     """(B_r, n, 1) on rank r -> (sum_r B_r, n, 1) on every rank, rank order.  Equal shards: one
     all_gather_into_tensor.  Unequal shards: the sizes travel first (one small all-gather), the payloads are padded
-    to the largest shard for the single payload collective and trimmed afterwards."""
+    to the largest shard for the single payload collective and trimmed afterwards.  `sizes`: the shard sizes of all
+    ranks when the caller knows them (it cut the batch): no size exchange, hence no host round trip per call."""
     if not _active(group):
         return x_local
     world = dist.get_world_size(group)
     x_local = x_local.contiguous()
     stage = _needs_host_staging(x_local, group)
     src = x_local.cpu() if stage else x_local
-    sizes = torch.zeros(world, dtype=torch.int64, device=src.device)
-    mine = torch.tensor([src.shape[0]], dtype=torch.int64, device=src.device)
-    dist.all_gather_into_tensor(sizes, mine, group=group)
-    sizes = sizes.tolist()
+    if sizes is not None:
+        sizes = [int(v) for v in sizes]
+        if len(sizes) != world or sizes[dist.get_rank(group)] != src.shape[0]:
+            raise ValueError(f"shard_sizes {sizes} do not describe this rank's shard of {src.shape[0]} problems")
+    else:
+        szt = torch.zeros(world, dtype=torch.int64, device=src.device)
+        mine = torch.tensor([src.shape[0]], dtype=torch.int64, device=src.device)
+        dist.all_gather_into_tensor(szt, mine, group=group)
+        sizes = szt.tolist()
     bmax = max(sizes)
     tail = tuple(src.shape[1:])
     if all(s == bmax for s in sizes):
@@ -111,12 +121,15 @@ class ShardedBoxQP(torch.nn.Module):
     graph (fixed-point backward on this rank's problems), x_all is the gathered solution.
 
     ``control['dist_strict_stop'] = True`` reproduces the single-process stopping rule and adaptive-rho decision
-    exactly (one small all-reduce per convergence check); every rank must then pass the same control."""
+    exactly (one small all-reduce per convergence check); every rank must then pass the same control.
+    ``shard_sizes`` (the number of problems on every rank, rank order): spares the size exchange of every forward; with it
+    and finite bounds on this rank a pipelined forward (``control['sync'] = False``) has no host round trip."""
 
-    def __init__(self, control, group=None, layer_apply=None):
+    def __init__(self, control, group=None, layer_apply=None, shard_sizes=None):
         super().__init__()
         self.control = control
         self.group = group
+        self.shard_sizes = shard_sizes      # sizes of all ranks' shards, if the caller knows them (see all_gather_solutions)
         self._apply = layer_apply or SolveBoxQPLayer.apply      # tests inject a CPU stand-in here
 
     def _check_hook(self, counters, check_index):
@@ -137,5 +150,5 @@ class ShardedBoxQP(torch.nn.Module):
                 ctl['_check_hook'] = self._check_hook
         x_local = self._apply(Q, p, A, b, lb, ub, ctl)
         with torch.no_grad():
-            x_all = all_gather_solutions(x_local.detach(), self.group)
+            x_all = all_gather_solutions(x_local.detach(), self.group, self.shard_sizes)
         return x_local, x_all

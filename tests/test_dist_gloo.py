@@ -48,7 +48,7 @@ def _data(n, B, no_bounds_rank, world, spread=False):
     return Q, p, A, b, lb, ub
 
 
-def _worker(rank, world, port, B, n, out_dir, no_bounds_rank, strict, spread):
+def _worker(rank, world, port, B, n, out_dir, no_bounds_rank, strict, spread, hint=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -60,7 +60,15 @@ def _worker(rank, world, port, B, n, out_dir, no_bounds_rank, strict, spread):
         ctl["check_solved"] = 5
     if strict:
         ctl["dist_strict_stop"] = True
-    layer = ShardedBoxQP(ctl, layer_apply=_oracle_layer)
+    sizes = [shard_slice(B, r, world)[1] - shard_slice(B, r, world)[0] for r in range(world)] if hint else None
+    layer = ShardedBoxQP(ctl, layer_apply=_oracle_layer, shard_sizes=sizes)
+    if hint:        # sizes that do not describe this rank's shard are refused before any collective
+        from lqp_py_amd.dist import all_gather_solutions
+        try:
+            all_gather_solutions(torch.zeros(hi - lo, n, 1), None, [s + 1 for s in sizes])
+            raise AssertionError("wrong shard sizes accepted")
+        except ValueError:
+            pass
     x_local, x_all = layer(Q[lo:hi], p[lo:hi], A[lo:hi], b[lo:hi], lb[lo:hi], ub[lo:hi])
     assert x_all.shape == (B, n, 1)
     assert torch.equal(x_all[lo:hi], x_local)
@@ -71,8 +79,8 @@ def _worker(rank, world, port, B, n, out_dir, no_bounds_rank, strict, spread):
     dist.destroy_process_group()
 
 
-def _run(tmp_path, B, n, world, no_bounds_rank=None, strict=False, spread=False):
-    mp.spawn(_worker, args=(world, _free_port(), B, n, str(tmp_path), no_bounds_rank, strict, spread), nprocs=world, join=True)
+def _run(tmp_path, B, n, world, no_bounds_rank=None, strict=False, spread=False, hint=False):
+    mp.spawn(_worker, args=(world, _free_port(), B, n, str(tmp_path), no_bounds_rank, strict, spread, hint), nprocs=world, join=True)
     outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
     for o in outs[1:]:
         assert torch.equal(o["x_all"], outs[0]["x_all"])
@@ -89,6 +97,13 @@ def _run(tmp_path, B, n, world, no_bounds_rank=None, strict=False, spread=False)
 def test_sharded_equals_single_process(tmp_path, no_bounds_rank, B):
     outs, ref = _run(tmp_path, B, 24, 2, no_bounds_rank)
     # per-shard stopping may run a shard a few checks longer/shorter than the global rule: tolerance, not equality
+    torch.testing.assert_close(outs[0]["x_all"], ref["x"], atol=2e-4, rtol=2e-4)
+
+
+def test_shard_sizes_hint_skips_the_size_exchange(tmp_path):
+    """The caller that cut the batch knows every rank's shard size: with `shard_sizes` the forward has no size exchange
+    (and, with finite bounds on the rank, no host read of the bound-flag all-reduce): same result, unequal shards."""
+    outs, ref = _run(tmp_path, 7, 24, 2, hint=True)
     torch.testing.assert_close(outs[0]["x_all"], ref["x"], atol=2e-4, rtol=2e-4)
 
 
