@@ -700,162 +700,162 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
     int* flag = (int*)(pcol + PIV_LDS);
     if (tid == 0) flag[0] = 0;
     for (int k = (NP == 1 ? 0 : k0); k < (NP == 1 ? K : k1); ++k) {
-      if (phases & 1) {
-        wg_pivot_block<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
-        __syncthreads();
-        // this workgroup's part of the panel: slots [s_lo, s_hi)
-        const int s_half = (K - 1 + 1) / 2;
-        const int s_lo = NP == 1 ? 0 : (part == 0 ? 0 : s_half), s_hi = NP == 1 ? K - 1 : (part == 0 ? s_half : K - 1);
-        // ---- Y phase: chunk of the panel -> LDS, Y_i = P_i W^T in place, Y_i -> Yg, A_ik = Y_i W -> its block ----
-        for (int c0 = s_lo; c0 < s_hi; c0 += CH) {
-            const int cn = (s_hi - c0) < CH ? (s_hi - c0) : CH;
-            for (int u = 0; u < cn; ++u) {
-                const int sl = c0 + u, i = sl < k ? sl : sl + 1;
-                const int blk = i > k ? sym_idx(i, k, K) : sym_idx(k, i, K);
-                const V4<float> pv = *(const V4<float>*)(Hs + (size_t)blk * LQP_BLK + tid * 4);
-                float* Ys = Y + (size_t)u * 64 * SPD_LS;
-                if (i > k) {
-                    *(V4<float>*)(Ys + r * SPD_LS + cq * 4) = pv;
-                } else {                                    // block (k, i), i < k: P_i is its transpose
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Ys[(cq * 4 + e) * SPD_LS + r] = pv.v[e];
-                }
-            }
+        if (phases & 1) {
+            wg_pivot_block<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
             __syncthreads();
-            {
-                const int ntask = cn * 4;                   // <= 28: at most two quadrants per wave
-                f32x16 acc[2];
+            // this workgroup's part of the panel: slots [s_lo, s_hi)
+            const int s_half = (K - 1 + 1) / 2;
+            const int s_lo = NP == 1 ? 0 : (part == 0 ? 0 : s_half), s_hi = NP == 1 ? K - 1 : (part == 0 ? s_half : K - 1);
+            // ---- Y phase: chunk of the panel -> LDS, Y_i = P_i W^T in place, Y_i -> Yg, A_ik = Y_i W -> its block ----
+            for (int c0 = s_lo; c0 < s_hi; c0 += CH) {
+                const int cn = (s_hi - c0) < CH ? (s_hi - c0) : CH;
+                for (int u = 0; u < cn; ++u) {
+                    const int sl = c0 + u, i = sl < k ? sl : sl + 1;
+                    const int blk = i > k ? sym_idx(i, k, K) : sym_idx(k, i, K);
+                    const V4<float> pv = *(const V4<float>*)(Hs + (size_t)blk * LQP_BLK + tid * 4);
+                    float* Ys = Y + (size_t)u * 64 * SPD_LS;
+                    if (i > k) {
+                        *(V4<float>*)(Ys + r * SPD_LS + cq * 4) = pv;
+                    } else {                                    // block (k, i), i < k: P_i is its transpose
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
-                    if (task < ntask) {
-                        const int sl = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
-                        const float* Xp = Y + ((size_t)sl * 64 + 32 * qi) * SPD_LS;
-                        acc[u] = qj == 0 ? spd_quadrant<1, false>(Xp, W) : spd_quadrant(Xp, W + 32 * SPD_LS);
+                        for (int e = 0; e < 4; ++e) Ys[(cq * 4 + e) * SPD_LS + r] = pv.v[e];
                     }
                 }
                 __syncthreads();
+                {
+                    const int ntask = cn * 4;                   // <= 28: at most two quadrants per wave
+                    f32x16 acc[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
-                    if (task < ntask) {
-                        const int sl = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
-                        float* dst = Y + ((size_t)sl * 64 + 32 * qi) * SPD_LS + 32 * qj + li;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) dst[quad_row(q, lh) * SPD_LS] = acc[u][q];
-                    }
-                }
-                __syncthreads();
-            }
-            for (int u = 0; u < cn; ++u)
-                *(V4<float>*)(Yg + (size_t)(c0 + u) * LQP_BLK + tid * 4) = *(const V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4);
-            for (int t2 = __builtin_amdgcn_readfirstlane(w); t2 < cn * 4; t2 += LQP_NW) {
-                const int u = t2 >> 2, qi = (t2 >> 1) & 1, qj = t2 & 1;
-                const int sl = c0 + u, i = sl < k ? sl : sl + 1;
-                const float* Ys = Y + (size_t)u * 64 * SPD_LS;
-                f32x16 acc;
-                float* C;
-                if (i > k) {              // Y W: column c >= 32 (qj == 1) only sees k >= 32
-                    acc = qj == 1 ? spd_quadrant<1, true>(Ys + (32 * qi) * SPD_LS, WT + 32 * SPD_LS)
-                                  : spd_quadrant(Ys + (32 * qi) * SPD_LS, WT);
-                    C = Hs + (size_t)sym_idx(i, k, K) * LQP_BLK;
-                } else {                  // W^T Y^T: row r >= 32 (qi == 1) only sees k >= 32
-                    acc = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Ys + (32 * qj) * SPD_LS)
-                                  : spd_quadrant(WT, Ys + (32 * qj) * SPD_LS);
-                    C = Hs + (size_t)sym_idx(k, i, K) * LQP_BLK;
-                }
-                C += (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = acc[q];
-            }
-            __syncthreads();
-        }
-        if (w < 4 && part == 0) {                           // A_kk = -(W^T W)
-            const int qi = (w >> 1) & 1, qj = w & 1;
-            const f32x16 acc = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
-                                         : spd_quadrant(WT, WT);
-            float* C = (NP == 1 ? Hs + (size_t)sym_idx(k, k, K) * LQP_BLK : Yg + (size_t)(K - 1) * LQP_BLK) + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = -acc[q];
-        }
-        __threadfence_block();
-        __syncthreads();
-      }
-      if (phases & 2) {
-        if (NP > 1 && part == 0)
-            *(V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4) = *(const V4<float>*)(Yg + (size_t)(K - 1) * LQP_BLK + tid * 4);
-        // ---- update phase: A_ij -= Y_i Y_j^T for all i >= j, both != k, by pairs of panel groups ----
-        const int ng = (K - 1 + BIG_G - 1) / BIG_G;
-        int pair_no = 0;
-        for (int ga = 0; ga < ng; ++ga) {
-            for (int gb = 0; gb <= ga; ++gb, ++pair_no) {
-                if (NP > 1 && (pair_no & 1) != part) continue;
-                const int a0 = BIG_G * ga, b0 = BIG_G * gb;
-                const int an = (K - 1 - a0) < BIG_G ? (K - 1 - a0) : BIG_G, bn = (K - 1 - b0) < BIG_G ? (K - 1 - b0) : BIG_G;
-                const int boff = gb == ga ? 0 : BIG_G;
-                for (int u = 0; u < an; ++u)
-                    *(V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4) = *(const V4<float>*)(Yg + (size_t)(a0 + u) * LQP_BLK + tid * 4);
-                if (gb != ga)
-                    for (int u = 0; u < bn; ++u)
-                        *(V4<float>*)(Y + ((size_t)(BIG_G + u) * 64 + r) * SPD_LS + cq * 4) =
-                            *(const V4<float>*)(Yg + (size_t)(b0 + u) * LQP_BLK + tid * 4);
-                __syncthreads();
-                const int npair = gb == ga ? an * (an + 1) / 2 : an * bn;
-                // (the C quadrant of a wave's NEXT task is requested before the MFMA chain of this one)
-                auto decode = [&](const int task, int& ua, int& ub, bool& skip, bool& mirror) -> float* {
-                    const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
-                    if (gb == ga) {
-                        ua = 0;
-                        while ((ua + 1) * (ua + 2) / 2 <= p) ++ua;
-                        ub = p - ua * (ua + 1) / 2;
-                    } else {
-                        ua = p / bn;
-                        ub = p - ua * bn;
-                    }
-                    const int si = a0 + ua, sj = b0 + ub;                  // si >= sj
-                    skip = si == sj && qi == 0 && qj == 1;                  // diagonal tile: mirrored from its (1,0) quadrant
-                    mirror = si == sj && qi == 1 && qj == 0;
-                    const int i = si < k ? si : si + 1, j = sj < k ? sj : sj + 1;
-                    return Hs + (size_t)sym_idx(i, j, K) * LQP_BLK;
-                };
-                auto load_c = [&](const float* T0, const int task, f32x16& c) {
-                    const float* C = T0 + (32 * ((task >> 1) & 1)) * 64 + 32 * (task & 1) + li;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) c[q] = C[quad_row(q, lh) * 64];
-                };
-                const int ntask = npair * 4;
-                int task = __builtin_amdgcn_readfirstlane(w);
-                int ua = 0, ub = 0; bool skip = false, mirror = false;
-                float* T0 = nullptr;
-                f32x16 nxt;
-                if (task < ntask) { T0 = decode(task, ua, ub, skip, mirror); if (!skip) load_c(T0, task, nxt); }
-                while (task < ntask) {
-                    const int qi = (task >> 1) & 1, qj = task & 1;
-                    f32x16 cur = nxt;
-                    float* Tc = T0;
-                    const int cua = ua, cub = ub;
-                    const bool cskip = skip, cmirror = mirror;
-                    const int nt = task + LQP_NW;
-                    if (nt < ntask) { T0 = decode(nt, ua, ub, skip, mirror); if (!skip) load_c(T0, nt, nxt); }
-                    if (!cskip) {
-                        const f32x16 acc = spd_quadrant(Y + ((size_t)cua * 64 + 32 * qi) * SPD_LS,
-                                                        Y + ((size_t)(boff + cub) * 64 + 32 * qj) * SPD_LS);
-                        cur -= acc;
-                        float* C = Tc + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
-                        if (cmirror) {
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) Tc[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                    for (int u = 0; u < 2; ++u) {
+                        const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                        if (task < ntask) {
+                            const int sl = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                            const float* Xp = Y + ((size_t)sl * 64 + 32 * qi) * SPD_LS;
+                            acc[u] = qj == 0 ? spd_quadrant<1, false>(Xp, W) : spd_quadrant(Xp, W + 32 * SPD_LS);
                         }
                     }
-                    task = nt;
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                        if (task < ntask) {
+                            const int sl = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                            float* dst = Y + ((size_t)sl * 64 + 32 * qi) * SPD_LS + 32 * qj + li;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) dst[quad_row(q, lh) * SPD_LS] = acc[u][q];
+                        }
+                    }
+                    __syncthreads();
+                }
+                for (int u = 0; u < cn; ++u)
+                    *(V4<float>*)(Yg + (size_t)(c0 + u) * LQP_BLK + tid * 4) = *(const V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4);
+                for (int t2 = __builtin_amdgcn_readfirstlane(w); t2 < cn * 4; t2 += LQP_NW) {
+                    const int u = t2 >> 2, qi = (t2 >> 1) & 1, qj = t2 & 1;
+                    const int sl = c0 + u, i = sl < k ? sl : sl + 1;
+                    const float* Ys = Y + (size_t)u * 64 * SPD_LS;
+                    f32x16 acc;
+                    float* C;
+                    if (i > k) {              // Y W: column c >= 32 (qj == 1) only sees k >= 32
+                        acc = qj == 1 ? spd_quadrant<1, true>(Ys + (32 * qi) * SPD_LS, WT + 32 * SPD_LS)
+                                      : spd_quadrant(Ys + (32 * qi) * SPD_LS, WT);
+                        C = Hs + (size_t)sym_idx(i, k, K) * LQP_BLK;
+                    } else {                  // W^T Y^T: row r >= 32 (qi == 1) only sees k >= 32
+                        acc = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Ys + (32 * qj) * SPD_LS)
+                                      : spd_quadrant(WT, Ys + (32 * qj) * SPD_LS);
+                        C = Hs + (size_t)sym_idx(k, i, K) * LQP_BLK;
+                    }
+                    C += (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = acc[q];
                 }
                 __syncthreads();
             }
+            if (w < 4 && part == 0) {                           // A_kk = -(W^T W)
+                const int qi = (w >> 1) & 1, qj = w & 1;
+                const f32x16 acc = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
+                                             : spd_quadrant(WT, WT);
+                float* C = (NP == 1 ? Hs + (size_t)sym_idx(k, k, K) * LQP_BLK : Yg + (size_t)(K - 1) * LQP_BLK) + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = -acc[q];
+            }
+            __threadfence_block();
+            __syncthreads();
         }
-        __threadfence_block();
-      }
+        if (phases & 2) {
+            if (NP > 1 && part == 0)
+                *(V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4) = *(const V4<float>*)(Yg + (size_t)(K - 1) * LQP_BLK + tid * 4);
+            // ---- update phase: A_ij -= Y_i Y_j^T for all i >= j, both != k, by pairs of panel groups ----
+            const int ng = (K - 1 + BIG_G - 1) / BIG_G;
+            int pair_no = 0;
+            for (int ga = 0; ga < ng; ++ga) {
+                for (int gb = 0; gb <= ga; ++gb, ++pair_no) {
+                    if (NP > 1 && (pair_no & 1) != part) continue;
+                    const int a0 = BIG_G * ga, b0 = BIG_G * gb;
+                    const int an = (K - 1 - a0) < BIG_G ? (K - 1 - a0) : BIG_G, bn = (K - 1 - b0) < BIG_G ? (K - 1 - b0) : BIG_G;
+                    const int boff = gb == ga ? 0 : BIG_G;
+                    for (int u = 0; u < an; ++u)
+                        *(V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4) = *(const V4<float>*)(Yg + (size_t)(a0 + u) * LQP_BLK + tid * 4);
+                    if (gb != ga)
+                        for (int u = 0; u < bn; ++u)
+                            *(V4<float>*)(Y + ((size_t)(BIG_G + u) * 64 + r) * SPD_LS + cq * 4) =
+                                *(const V4<float>*)(Yg + (size_t)(b0 + u) * LQP_BLK + tid * 4);
+                    __syncthreads();
+                    const int npair = gb == ga ? an * (an + 1) / 2 : an * bn;
+                    // (the C quadrant of a wave's NEXT task is requested before the MFMA chain of this one)
+                    auto decode = [&](const int task, int& ua, int& ub, bool& skip, bool& mirror) -> float* {
+                        const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
+                        if (gb == ga) {
+                            ua = 0;
+                            while ((ua + 1) * (ua + 2) / 2 <= p) ++ua;
+                            ub = p - ua * (ua + 1) / 2;
+                        } else {
+                            ua = p / bn;
+                            ub = p - ua * bn;
+                        }
+                        const int si = a0 + ua, sj = b0 + ub;                  // si >= sj
+                        skip = si == sj && qi == 0 && qj == 1;                  // diagonal tile: mirrored from its (1,0) quadrant
+                        mirror = si == sj && qi == 1 && qj == 0;
+                        const int i = si < k ? si : si + 1, j = sj < k ? sj : sj + 1;
+                        return Hs + (size_t)sym_idx(i, j, K) * LQP_BLK;
+                    };
+                    auto load_c = [&](const float* T0, const int task, f32x16& c) {
+                        const float* C = T0 + (32 * ((task >> 1) & 1)) * 64 + 32 * (task & 1) + li;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) c[q] = C[quad_row(q, lh) * 64];
+                    };
+                    const int ntask = npair * 4;
+                    int task = __builtin_amdgcn_readfirstlane(w);
+                    int ua = 0, ub = 0; bool skip = false, mirror = false;
+                    float* T0 = nullptr;
+                    f32x16 nxt;
+                    if (task < ntask) { T0 = decode(task, ua, ub, skip, mirror); if (!skip) load_c(T0, task, nxt); }
+                    while (task < ntask) {
+                        const int qi = (task >> 1) & 1, qj = task & 1;
+                        f32x16 cur = nxt;
+                        float* Tc = T0;
+                        const int cua = ua, cub = ub;
+                        const bool cskip = skip, cmirror = mirror;
+                        const int nt = task + LQP_NW;
+                        if (nt < ntask) { T0 = decode(nt, ua, ub, skip, mirror); if (!skip) load_c(T0, nt, nxt); }
+                        if (!cskip) {
+                            const f32x16 acc = spd_quadrant(Y + ((size_t)cua * 64 + 32 * qi) * SPD_LS,
+                                                            Y + ((size_t)(boff + cub) * 64 + 32 * qj) * SPD_LS);
+                            cur -= acc;
+                            float* C = Tc + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                            if (cmirror) {
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) Tc[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                            }
+                        }
+                        task = nt;
+                    }
+                    __syncthreads();
+                }
+            }
+            __threadfence_block();
+        }
     }
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
@@ -1544,9 +1544,6 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
 constexpr int CHOL_LA_CHAIN = 4;
 __host__ __device__ inline int chol_la_lds_bytes(int K) { return spd_lds_bytes(K) + 64 + 64 * 64 * 4; }
 
-#ifndef LQP_LA_EXP
-#define LQP_LA_EXP 0
-#endif
 __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem,
                                                   unsigned long long* __restrict__ dbg = nullptr) {
     constexpr int NCH = CHOL_LA_CHAIN, NTW = LQP_NW - NCH, NTT = NTW * 64;
@@ -1612,7 +1609,7 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
             if (dbg && tt == 0) { const unsigned long long c1 = clock64(); dbg[6] += c1 - c0; c0 = c1; }
             lds_group_sync(sy + 1, gt += NTW);              // the panel is staged
             // ---- Y_i = P_i W^T, in place: a wave owns 32 rows of a panel block and reads nothing else of Y ----
-            for (int task = tw; task < np * 2 && !(LQP_LA_EXP & 1); task += NTW) {
+            for (int task = tw; task < np * 2; task += NTW) {
                 const int s = task >> 1, qi = task & 1;
                 float* Xp = Y + ((size_t)s * 64 + 32 * qi) * SPD_LS;
                 const f32x16 a0 = spd_quadrant<1, false>(Xp, W);
@@ -1641,11 +1638,9 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
 #pragma unroll
                         for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];
                     }
-                    if (!(LQP_LA_EXP & 1) || p == 0) {
                     const f32x16 acc = spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS,
                                                     Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
                     cur -= acc;
-                    }
                     if (p == 0) {                                      // the next diagonal tile also goes to the chain waves
                         float* Sq = St + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
