@@ -1604,10 +1604,10 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
                     for (int q = 0; q < 16; ++q) pre[q] = C[quad_row(q, lh) * 64];
                 }
             }
+            lds_group_sync(sy + 1, gt += NTW);              // the panel is staged (while the chain waves still work on W)
             unsigned long long c0 = dbg ? clock64() : 0;
             lds_wait_ge(sy + 3, k + 1);                     // W / W^T of this step
             if (dbg && tt == 0) { const unsigned long long c1 = clock64(); dbg[6] += c1 - c0; c0 = c1; }
-            lds_group_sync(sy + 1, gt += NTW);              // the panel is staged
             // ---- Y_i = P_i W^T, in place: a wave owns 32 rows of a panel block and reads nothing else of Y ----
             for (int task = tw; task < np * 2; task += NTW) {
                 const int s = task >> 1, qi = task & 1;
