@@ -1325,16 +1325,16 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
     }
 
     unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
-    for (int k = 0; k < K; ++k) {
-        if (dbg) dt0 = clock64();
-        float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
-        // ---- publish the pivot tile and the panel tiles this workgroup holds ----
+    // publish the pivot tile and the panel tiles of step kk this workgroup holds.  A wave does so as soon as ITS quadrants
+    // have step kk-1's update (end of the step body): the store drain then overlaps with the wait for the slowest wave.
+    auto publish = [&](const int kk) {
+        float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = ti[s], j = tj[s];
-            if (i >= 0 && (i == k || j == k)) {
-                const int slot = (i == k && j == k) ? K - 1 : (j == k ? i - 1 : j);      // P_i: i > k -> i - 1, i < k -> i
-                unsigned int* dst = (unsigned int*)(xbk + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
+            if (i >= 0 && (i == kk || j == kk)) {
+                const int slot = (i == kk && j == kk) ? K - 1 : (j == kk ? i - 1 : j);      // P_i: i > kk -> i - 1, i < kk -> i
+                unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const float tv = T[s][q];      // (bit_cast straight from the vector element stores element 0 sixteen times)
@@ -1343,8 +1343,13 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
                 }
             }
         }
+    };
+    publish(0);
+    for (int k = 0; k < K; ++k) {
+        if (dbg) dt0 = clock64();
+        float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                       // (also closes step k-1: every wave is done with the LDS panel)
         if (tid == 0) {
             __hip_atomic_store(fl + part, epoch + (unsigned int)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1423,7 +1428,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ 
             }
         }
         if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
-        __syncthreads();
+        if (k + 1 < K) publish(k + 1);
         if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
     }
     if (dbg && tid == 0)
