@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 4
+#define LQP_ABI_VERSION 5
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -51,8 +51,12 @@ typedef struct lqp_boxqp_ctrl {
     int32_t adaptive_rho_iter;       /* already rounded to a multiple of check_solved */
     int32_t adaptive_rho_max_iter;
     int32_t scale;                   /* 0/1 auto-scaling (:160-197)                    */
-    int32_t any_lb;                  /* 0/1: max(lb) > -inf over the WHOLE batch (:129)*/
-    int32_t any_ub;                  /* 0/1: min(ub) < +inf over the WHOLE batch (:130)*/
+    int32_t any_lb;                  /* not read since ABI 5: whether max(lb) > -inf / min(ub) < +inf over the batch  */
+    int32_t any_ub;                  /* (:129-130) is found on the DEVICE (the clamps always run -- an infinite bound
+                                        is an exact no-op -- and the answer comes back in lqp_boxqp_stats.any_lb/ub
+                                        or, for un-synchronised calls, in status words 12/13).  What the caller must
+                                        still decide itself is the reference's rho = 0 shortcut for a batch without any
+                                        finite bound (:157-158): pass rho_mode 1, rho_value 0 for it.              */
     int32_t rho_mode;                /* 0 auto (||Q||_F/sqrt(n), :200-203), 1 scalar rho_value,
                                         2 per-problem array `rho_in` (B values)        */
     int32_t beta_mode;               /* 0 auto (quantile rule :171-174), 1 scalar beta_value, 2 per-problem array
@@ -80,14 +84,20 @@ typedef struct lqp_boxqp_ctrl {
     /* Strict global stopping across batch shards (one process per GPU): when set, the solve runs one
      * launch per check segment and, right after the launch that holds check number `check_index`, calls
      *     check_hook(check_hook_user, stream, counters, check_index)
-     * on the host with the DEVICE address of that check's three uint32 counters {problems not yet optimal,
-     * problems that want a rho update, problems whose residual ratio triggers one} (:310-312, :244-246).  The hook
-     * must enqueue, ordered on `stream`, an in-place SUM all-reduce of those three words over the ranks (RCCL); every
-     * consumer of the counters (stop test, adaptive-rho decision) is enqueued after it, so all ranks take the
-     * single-process decisions and report the single-process iteration count.  Non-zero return aborts the solve
-     * (LQP_ERR_HIP).  NULL: decisions are per call (per shard).                                                  */
+     * on the host with the DEVICE address of that check's FOUR uint32 words {problems not yet optimal, arrivals
+     * (unused in this mode), problems that want a rho update, problems whose residual ratio triggers one} (:310-312,
+     * :244-246).  The hook must enqueue, ordered on `stream`, an in-place SUM all-reduce of all four words over the
+     * ranks (RCCL); every consumer of the counters (stop test, adaptive-rho decision) is enqueued after it, so all
+     * ranks take the single-process decisions and report the single-process iteration count.
+     * check_index == -1: the same reduction over the four-word failure vote of a factorisation {ranks whose matrix
+     * left the symmetric x-update, ranks with an exactly singular KKT matrix, 0, 0}: every rank then repeats the solve
+     * on the LU path, or fails, together -- the sequence of collectives stays the same on all ranks.
+     * Non-zero return aborts the solve (LQP_ERR_HIP).  NULL: decisions are per call (per shard).                  */
     int (*check_hook)(void* user, void* stream, void* counters_dev, int check_index);
     void* check_hook_user;
+    const void* bound_flags_in;      /* optional: two int32 on the device {any_lb, any_ub} of a LARGER batch this call
+                                        holds one shard of (one all-reduce MAX over the ranks); they are
+                                        OR-ed into the answer reported back.  NULL: this call is the whole batch.    */
 } lqp_boxqp_ctrl;
 
 /* Host-side bookkeeping returned by the forward solve. */
@@ -105,6 +115,8 @@ typedef struct lqp_boxqp_stats {
                               * shares each matrix between two workgroups (one launch per pivot step) */
     int32_t loop_workgroups; /* workgroups per QP in the first (hot) loop launch: 1, or 2 when a small batch (2 B <= CUs)
                               * on the symmetric path splits every product between two CUs */
+    int32_t any_lb;          /* 1: some lower bound of the batch is finite (:129), 0: none, -1: not known on the host */
+    int32_t any_ub;          /* the same for the upper bounds (:130)                                                 */
 } lqp_boxqp_stats;
 
 int lqp_abi_version(void);
@@ -135,7 +147,8 @@ void lqp_debug_set_lu_counters(void* device_buf);
 size_t lqp_boxqp_forward_workspace_bytes(int dtype, int B, int n, int m);
 /* Where, inside the workspace, the device-side status block (16 int32: [0] done, [1] final iteration,
  * [3] adaptive-rho refactorisations, [4] rho updated, [5] grid-barrier timeout, [7] linsolve 2 met a matrix
- * that is not positive definite: results invalid, repeat with linsolve 1) and the per-problem LU
+ * that is not positive definite: results invalid, repeat with linsolve 1, [12] / [13] some lower / upper bound of the
+ * batch is finite) and the per-problem LU
  * info array (B int32, non-zero = exactly singular) live -- for callers that skipped the host sync
  * (ctrl.reserved = 1) and fetch them asynchronously. */
 int lqp_boxqp_forward_layout(int dtype, int B, int n, int m, size_t* status_offset, size_t* status_bytes,

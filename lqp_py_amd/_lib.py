@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQ
 SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
 
 LQP_F32, LQP_F64 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
           5: "grid barrier timeout", 6: "unsupported size"}
 
@@ -35,13 +35,14 @@ class BoxQPCtrl(ctypes.Structure):
         (k, ctypes.c_double) for k in (
             "eps_abs", "eps_rel", "rho_value", "rho_min", "rho_max", "adaptive_rho_tol",
             "adaptive_rho_threshold", "beta_value")] + [
-        ("beta_in", ctypes.c_void_p), ("check_hook", CHECK_HOOK), ("check_hook_user", ctypes.c_void_p)]
+        ("beta_in", ctypes.c_void_p), ("check_hook", CHECK_HOOK), ("check_hook_user", ctypes.c_void_p),
+        ("bound_flags_in", ctypes.c_void_p)]
 
 
 class BoxQPStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in (
         "iters", "n_factor", "n_solve", "n_check", "rho_updated", "fail_index", "n_launch", "mode_used", "linsolve_used",
-        "factor_launches", "loop_workgroups")]
+        "factor_launches", "loop_workgroups", "any_lb", "any_ub")]
 
 
 # every symbol include/lqp_amd.h declares: name -> (restype, argtypes)
@@ -167,17 +168,19 @@ def stream_ptr(device):
 # ---- deferred error reporting for calls that did not synchronise with the host -----------------
 class _Pending:
     """status / LU-info words of an un-synchronised call, copied to pinned memory on the call's stream"""
-    __slots__ = ("what", "event", "status", "info")
+    __slots__ = ("what", "event", "status", "info", "bounds_check")
 
-    def __init__(self, what, event, status, info):
-        self.what, self.event, self.status, self.info = what, event, status, info
+    def __init__(self, what, event, status, info, bounds_check=None):
+        self.what, self.event, self.status, self.info, self.bounds_check = what, event, status, info, bounds_check
 
 
 _pending = []
 _pending_lock = threading.Lock()
 
 
-def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes):
+def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes, bounds_check=None):
+    """bounds_check = (assumed, control, mutate, remember): the call was enqueued ASSUMING that the batch holds some /
+    no finite bound; status words 12 / 13 hold what the setup kernel found."""
     if status_bytes and status_off <= info_off and info_off + info_bytes - status_off <= 65536:
         # one copy for the whole region [status .. info] (every device-to-host copy costs ~4 us of GPU time)
         span = torch.empty((info_off + info_bytes - status_off) // 4, dtype=torch.int32, pin_memory=True)
@@ -193,7 +196,7 @@ def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes):
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(ws.device))
     with _pending_lock:
-        _pending.append(_Pending(what, ev, status, info))
+        _pending.append(_Pending(what, ev, status, info, bounds_check))
         backlog = len(_pending)
     if backlog > 64:
         poll_errors(block=True)
@@ -212,6 +215,20 @@ def poll_errors(block=False):
             _pending.pop(0)
         p.event.synchronize()
         bad = torch.nonzero(p.info)
+        if p.bounds_check is not None and p.status is not None:
+            assumed, control, mutate, remember = p.bounds_check
+            seen = bool(int(p.status[12]) or int(p.status[13]))
+            remember(control, seen)
+            if seen != assumed:
+                if mutate and not seen:
+                    control['rho'] = 0      # the reference layer's dict side effect (:37-38), applied late
+                raise RuntimeError(
+                    f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): the batch held "
+                    f"{'a' if seen else 'NO'} finite bound while the previous solve with this control "
+                    f"{'had none' if seen else 'had some'}; the reference switches between its ADMM loop and the "
+                    "rho = 0 one-shot solve on that (:157-158), and this call was enqueued for the other one -- its outputs "
+                    "are not the reference's.  Repeat the call (the layer now assumes what it saw), or pass "
+                    "control['sync']=True, which repeats by itself")
         if p.status is not None and int(p.status[7]):
             raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): Q + rho I is not "
                                f"positive definite in float32 (batch index {int(bad[0]) if bad.numel() else -1}); the "
@@ -239,6 +256,15 @@ def workspace(device, nbytes, tag):
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             _ws_cache[key] = buf
         return buf
+
+
+def release_workspaces(device=None):
+    """Drop the cached scratch buffers (all devices, or one).  A long-lived process that used many streams holds one
+    forward and one backward workspace per (device, stream); nothing else ever frees them.  Only call this when no
+    solve is in flight on the streams concerned (``lqp_py_amd.synchronize()`` first)."""
+    with _ws_lock:
+        for key in [k for k in _ws_cache if device is None or k[0] == torch.device(device).index]:
+            del _ws_cache[key]
 
 
 def norm(t, dtype):

@@ -243,7 +243,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.Q = (const T*)Q; P.p = (const T*)p; P.A = (const T*)A; P.b = (const T*)b;
     P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in; P.beta_in = (const T*)ctl->beta_in;
     P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
-    P.scale = ctl->scale; P.any_lb = ctl->any_lb; P.any_ub = ctl->any_ub;
+    P.scale = ctl->scale; P.bound_flags_in = (const int*)ctl->bound_flags_in;
     P.dbg = g_lu_dbg;
     P.dbg_setup = nullptr;
     if (g_lu_dbg && env_int("LQP_DBG_SETUP", 0)) { P.dbg_setup = g_lu_dbg; P.dbg = nullptr; }
@@ -269,6 +269,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         // (512 < n <= 1024: the sweep parks its panel in the M area, see wg_spd_sweep_big)
         spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_BIGK && m <= SPD_MAXM &&
               (P.Ks <= SPD_MAXK || ((size_t)P.Np * P.Np >= (size_t)P.Ks * LQP_BLK && env_int("LQP_SPD_BIG", 1)));
+        // the equality correction (G, T: 2 m rows of 64 Ks floats next to the product's scratch) and the loop's vectors must
+        // fit the 160 KB of LDS: large n with many equality rows (n > 960 at m >= 8, ...) stays on the LU path
+        spd = spd && spd_factor_lds_bytes(m, P.Ks) <= 160 * 1024 && sym_loop_lds_bytes(n, m, P.Ks, 0) <= 160 * 1024;
     }
     P.spd = spd ? 1 : 0;
     P.qs_lazy = (spd && env_int("LQP_QS_LAZY", 1)) ? 1 : 0;
@@ -529,6 +532,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 memset(stats, 0, sizeof(*stats));
                 stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
                 stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
+                stats->any_lb = stats->any_ub = -1;
                 stats->linsolve_used = spd ? 2 : 1;
                 stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
                 stats->loop_workgroups = loop_split ? 2 : 1;
@@ -613,28 +617,43 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
           hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P); }
         ++n_launch;
         HIP_OK(hipMemcpyAsync(h_status, P.status, sizeof(h_status), hipMemcpyDeviceToHost, st));
+        // A failed factorisation ends or restarts the solve.  With a check hook (strict global stop over batch shards)
+        // that decision must be the same on every rank -- a rank that restarted alone would pair its collectives with
+        // other checks of its peers -- so the local verdict goes through the hook (SUM over the ranks) first.
+        // returns LQP_OK, an error, or -1: repeat the solve on the LU path
+        auto after_factorisation = [&]() -> int {
+            int rcf = first_failure(st, P.info, B, &fail_index);      // synchronises
+            if (rcf != LQP_OK && rcf != LQP_ERR_SINGULAR) return rcf;
+            bool leave_spd = rcf == LQP_ERR_SINGULAR && spd, singular = rcf == LQP_ERR_SINGULAR && !spd;
+            if (ctl->check_hook) {
+                int vote[CT_WORDS] = {leave_spd ? 1 : 0, singular ? 1 : 0, 0, 0};
+                HIP_OK(hipMemcpyAsync(P.status + ST_VOTE, vote, sizeof(vote), hipMemcpyHostToDevice, st));
+                if (ctl->check_hook(ctl->check_hook_user, (void*)st, (void*)(P.status + ST_VOTE), -1) != 0) return LQP_ERR_HIP;
+                HIP_OK(hipMemcpyAsync(vote, P.status + ST_VOTE, sizeof(vote), hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                leave_spd = vote[0] > 0;
+                singular = vote[1] > 0;
+            }
+            if (singular) {                                           // (fail_index -1: the singular problem is on another rank)
+                if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
+                return LQP_ERR_SINGULAR;
+            }
+            return leave_spd ? -1 : LQP_OK;
+        };
         if (!singular_checked) {
-            rc = first_failure(st, P.info, B, &fail_index);      // synchronises
             singular_checked = true;
-            if (rc == LQP_ERR_SINGULAR && spd)      // Qs + rho I not positive definite in f32: the LU path takes it
+            rc = after_factorisation();
+            if (rc == -1)       // Qs + rho I not positive definite in f32 (on some rank): the LU path takes it
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
                                        ws, ws_bytes, true);
-            if (rc == LQP_ERR_SINGULAR) {
-                if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
-                return rc;
-            }
             if (rc) return rc;
         } else {
             HIP_OK(hipStreamSynchronize(st));
             if (h_status[ST_NFACTOR] != nfactor_seen) {      // an adaptive-rho refactorisation ran in this chunk
-                rc = first_failure(st, P.info, B, &fail_index);
-                if (rc == LQP_ERR_SINGULAR && spd)
+                rc = after_factorisation();
+                if (rc == -1)
                     return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
                                            ws, ws_bytes, true);
-                if (rc == LQP_ERR_SINGULAR) {
-                    if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
-                    return rc;
-                }
                 if (rc) return rc;
             }
         }
@@ -658,6 +677,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->linsolve_used = spd ? 2 : 1;
         stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
         stats->loop_workgroups = (loop_split && mode == 2) ? 2 : 1;
+        stats->any_lb = h_status[ST_ANY_LB]; stats->any_ub = h_status[ST_ANY_UB];
     }
     return LQP_OK;
 }

@@ -11,7 +11,10 @@ namespace lqp {
 
 // ---- device-side status block (ints) ---------------------------------------
 enum { ST_DONE = 0, ST_FINAL_ITER = 1, ST_GATE = 2, ST_NFACTOR = 3, ST_RHO_UPDATED = 4,
-       ST_TIMEOUT = 5, ST_NCHECK = 6, ST_NOTSPD = 7, ST_WORDS = 16 };
+       ST_TIMEOUT = 5, ST_NCHECK = 6, ST_NOTSPD = 7,
+       ST_VOTE = 8,      // 4 words: {ranks leaving the symmetric path, ranks with a singular KKT matrix, -, -} (strict global stop)
+       ST_ANY_LB = 12, ST_ANY_UB = 13,      // some lower / upper bound of the batch is finite (:129-130), found by k_fwd_setup
+       ST_WORDS = 16 };
 // per-check counters (uint32 x 4): not-optimal, arrivals, wants-rho, ratio-trigger
 // (NOTOPT and ARRIVE share one aligned 64-bit word: the two-workgroup loop adds to and reads both with ONE atomic)
 enum { CT_NOTOPT = 0, CT_ARRIVE = 1, CT_WANTS = 2, CT_TRIG = 3, CT_WORDS = 4 };
@@ -33,6 +36,7 @@ template <typename T> struct FwdParams {
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in, *beta_in;
+    const int* bound_flags_in;           // optional {any_lb, any_ub} of a LARGER batch this call is a shard of (device), or null
     // outputs
     T *x, *z, *u, *lams, *nus, *rho_out;
     // workspace
@@ -49,7 +53,7 @@ template <typename T> struct FwdParams {
     unsigned long long* xchg; // B * XCHG_WORDS granules: partial-product exchange of the two-workgroup loop (or null)
     size_t vstride;
     // controls
-    int scale, any_lb, any_ub, rho_mode, beta_mode, check_solved, adaptive_rho;
+    int scale, rho_mode, beta_mode, check_solved, adaptive_rho;
     T eps_abs, eps_rel, rho_value, rho_min, rho_max, ar_tol, ar_inv_tol, ar_thr, beta_value;
 };
 
@@ -240,6 +244,20 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     const T* ub = P.ub + (size_t)b * n;
     const T p0 = tid < n ? p[tid] : T(0), lb0 = tid < n ? lb[tid] : T(0), ub0 = tid < n ? ub[tid] : T(0);
     const T a0 = (m > 0 && tid < n) ? P.A[(size_t)b * m * n + tid] : T(0);          // first equality row
+    // any finite bound in the batch?  (:129-130: a HOST decision in the reference -- it selects the rho = 0 shortcut and
+    // the clamps.  Here the clamps always run (an infinite bound is an exact no-op) and the answer is left in the status
+    // block: the host compares it with what it assumed when it chose the schedule.)
+    {
+        bool flb = false, fub = false;
+        for (int i = tid; i < n; i += LQP_NT) {
+            flb |= (i == tid ? lb0 : lb[i]) > -T(INFINITY);
+            fub |= (i == tid ? ub0 : ub[i]) < T(INFINITY);
+        }
+        if (b == 0 && tid < 2 && P.bound_flags_in && P.bound_flags_in[tid] != 0)
+            __hip_atomic_store(P.status + ST_ANY_LB + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(flb) != 0ull && lane == 0) __hip_atomic_store(P.status + ST_ANY_LB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(fub) != 0ull && lane == 0) __hip_atomic_store(P.status + ST_ANY_UB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     SETUP_STAMP(0);
     const T* Qs = Q;
@@ -446,9 +464,8 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     }
     SETUP_STAMP(5);
     // ---- bounds (:192-194) and state ----
-    const bool any_ineq = P.any_lb || P.any_ub;
     for (int i = tid; i < n; i += LQP_NT) {
-        const T di = (P.scale && any_ineq) ? V.D[i] : T(1);
+        const T di = P.scale ? V.D[i] : T(1);                // (:192-194; +-inf / D stays +-inf)
         V.lbs[i] = (i == tid ? lb0 : lb[i]) / di;
         V.ubs[i] = (i == tid ? ub0 : ub[i]) / di;
         V.z[i] = T(0); V.u[i] = T(0); V.x[i] = T(0);
@@ -1003,8 +1020,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
                     const T zp = z[i];
                     const T ui = u[i];
                     T zn = xi + ui;
-                    if (P.any_lb) zn = tmax(zn, lb[i]);
-                    if (P.any_ub) zn = tmin(zn, ub[i]);
+                    zn = tmin(tmax(zn, lb[i]), ub[i]);     // (:273-276; an infinite bound is a no-op)
                     const T r = xi - zn;
                     const T s = rho * (zn - zp);
                     const T un = ui + r;
@@ -1048,8 +1064,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
                 const T zp = z[i];
                 const T ui = u[i];
                 T zn = xi + ui;
-                if (P.any_lb) zn = tmax(zn, lb[i]);
-                if (P.any_ub) zn = tmin(zn, ub[i]);
+                zn = tmin(tmax(zn, lb[i]), ub[i]);
                 const T r = xi - zn;
                 const T s = rho * (zn - zp);
                 const T un = ui + r;
@@ -1455,8 +1470,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             const T zp = z[i];
             const T ui = u[i];
             T zn = xi + ui;
-            if (P.any_lb) zn = tmax(zn, lb[i]);
-            if (P.any_ub) zn = tmin(zn, ub[i]);
+            zn = tmin(tmax(zn, lb[i]), ub[i]);
             const T r = xi - zn;
             const T s = rho * (zn - zp);
             const T un = ui + r;

@@ -1264,7 +1264,8 @@ struct RsLateRho {
     float* rho_out;           // workgroup 0 only
 };
 template <int K>
-__device__ __forceinline__ void wg_spd_sweep_resident(const float* __restrict__ Hsrc, float* __restrict__ Hdst,
+// (Hsrc and Hdst may be the same buffer -- even K: the blocks are all loaded before the first store, barriers in between)
+__device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* Hdst,
                                                       float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                       const unsigned int epoch, const int part, int* __restrict__ info,
                                                       int* __restrict__ status_timeout, char* smem,

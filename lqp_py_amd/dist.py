@@ -4,7 +4,8 @@ Every QP of a batch is independent, so each rank solves its own contiguous
 slice with no data-path communication; the only exchanges are
   * one 2-flag MAX all-reduce before the solve, because the reference's
     ``any_lb``/``any_ub`` (and hence the rho=0 shortcut) are global over the
-    whole batch (lqp_py/solve_box_qp_admm_torch.py:33-38, 129-131);
+    whole batch (lqp_py/solve_box_qp_admm_torch.py:33-38, 129-131); the flags
+    stay on the device (the layer's setup kernel consumes them), nobody waits;
   * ONE all-gather of the solutions ``x`` (B_local, n, 1) at the end of the
     forward (RCCL over xGMI when the backend is "nccl"); shards may be of
     different sizes (B not a multiple of the world size);
@@ -49,27 +50,25 @@ def all_reduce_(t, op, group=None):
 
 
 def global_bound_flags(lb, ub, group=None):
-    """(any_lb, any_ub) over the batches of ALL ranks: the local reduction (remembered for the same live bound
-    tensors by the layer's own cache) and one tiny MAX all-reduce.  The collective itself is issued on EVERY call:
-    a rank-local cache hit must never decide whether a collective happens."""
-    local = _local_flags(lb, ub)
+    """(any_lb, any_ub) over the batches of ALL ranks as HOST booleans: the local reductions and one tiny MAX
+    all-reduce, read back (a host round trip).  Used for CPU tensors (the gloo tests' stand-in solver); device tensors go
+    through device_bound_flags, which nobody waits for."""
+    local = (bool(torch.max(lb) > -_INF), bool(torch.min(ub) < _INF))
     if not _active(group):
         return local
     flags = torch.tensor([int(local[0]), int(local[1])], dtype=torch.int32, device=lb.device)
     all_reduce_(flags, dist.ReduceOp.MAX, group)
-    if local[0] and local[1]:
-        # MAX over the ranks of a flag that is already 1 here is 1: nothing to read back, the collective (issued all
-        # the same, so that every rank takes part in it) stays asynchronous -- no host round trip in the steady state
-        return True, True
     f = flags.tolist()
     return bool(f[0]), bool(f[1])
 
 
-def _local_flags(lb, ub):
-    if not lb.is_cuda:                      # CPU stand-in used by the gloo tests
-        return bool(torch.max(lb) > -_INF), bool(torch.min(ub) < _INF)
-    from .solve_box_qp_admm_torch import _finite_bounds
-    return _finite_bounds(lb, ub)
+def device_bound_flags(lb, ub, group=None):
+    """int32 [any_lb, any_ub] over the batches of ALL ranks, ON THE DEVICE: two reductions and one 8-byte MAX all-reduce
+    (RCCL), all asynchronous.  The layer's setup kernel ORs them into what it reports back (lqp_boxqp_ctrl.bound_flags_in),
+    so every rank verifies its schedule against the flags of the whole batch, as the reference would see them
+    (:33-38, :129-131).  The collective is issued on EVERY call of every rank."""
+    flags = torch.stack((torch.max(lb) > -_INF, torch.min(ub) < _INF)).to(torch.int32)
+    return all_reduce_(flags, dist.ReduceOp.MAX, group)
 
 
 def all_gather_solutions(x_local, group=None, sizes=None):
@@ -137,18 +136,20 @@ class ShardedBoxQP(torch.nn.Module):
         all_reduce_(counters, dist.ReduceOp.SUM, self.group)
 
     def forward(self, Q, p, A, b, lb, ub):
-        has_lb, has_ub = global_bound_flags(lb, ub, self.group)
         ctl = self.control
-        if not (has_lb or has_ub):
-            ctl['rho'] = 0
         if _active(self.group):
-            # private keys for the layer: the GLOBAL bound flags (a shard without any finite bound must still run
-            # the ADMM path with the clamps the whole batch uses) and, in strict mode, the per-check all-reduce
+            # private keys for the layer: the flags of the WHOLE batch (a shard without any finite bound must still run
+            # the ADMM path the whole batch runs) and, in strict mode, the per-check all-reduce
             ctl = dict(ctl)
-            ctl['_global_bounds'] = (has_lb, has_ub)
-            if ctl.get('dist_strict_stop', False) and (has_lb or has_ub):
+            if lb.is_cuda:
+                ctl['_bound_flags_dev'] = device_bound_flags(lb, ub, self.group)
+            else:                               # CPU stand-in solver of the gloo tests: host flags
+                ctl['_global_bounds'] = global_bound_flags(lb, ub, self.group)
+            if ctl.get('dist_strict_stop', False) and any(ctl.get('_global_bounds', (True,))):
                 ctl['_check_hook'] = self._check_hook
         x_local = self._apply(Q, p, A, b, lb, ub, ctl)
+        if ctl is not self.control and ctl.get('rho', None) is not self.control.get('rho', None):
+            self.control['rho'] = ctl['rho']    # the layer's dict side effect (:37-38) belongs to the caller's dict
         with torch.no_grad():
             x_all = all_gather_solutions(x_local.detach(), self.group, self.shard_sizes)
         return x_local, x_all

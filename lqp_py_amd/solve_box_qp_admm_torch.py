@@ -12,7 +12,6 @@ control dict -- including its key-name traps and the caller-dict side effect --
 and moves pointers.  Tensors must be on the GPU; there is no CPU fallback.
 """
 import ctypes
-import weakref
 
 import torch
 import torch.nn as nn
@@ -41,18 +40,17 @@ class SolveBoxQPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Q, p, A, b, lb, ub, control):
-        # (lqp_py_amd.dist passes the flags of the WHOLE batch when this call holds one shard of it)
-        has_lb, has_ub = control.get('_global_bounds') or _finite_bounds(lb, ub)
-        if not (has_lb or has_ub):
-            control['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
         # Default (control['sync'] absent or True): the reference's semantics -- the call waits for the solve, a
         # singular KKT matrix raises HERE (:215), a Q outside the symmetric x-update falls back to LU by itself.
         # control['sync'] = False (extension, for training loops): the whole schedule is enqueued and the call
         # returns at once; an error is raised by a later call / lqp_py_amd.synchronize(), and the outputs of a
         # failed solve are NaN, never plausible numbers.
+        # Whether any bound is finite (:33-38) is found on the device; when none is, control['rho'] = 0 is written into
+        # the CALLER's dict as the reference does (_forward_solve, mutate=True).
+        # (lqp_py_amd.dist passes the flags of the WHOLE batch when this call holds one shard of it.)
         sync = bool(control.get('sync', True))
-        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=(has_lb, has_ub), sync=sync,
-                             check_hook=control.get('_check_hook'))
+        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=control.get('_global_bounds'), sync=sync,
+                             check_hook=control.get('_check_hook'), mutate=True)
         ctx.rho = sol['rho']
         ctx.linsolve = int(sol['_stats']['linsolve_used'])     # 2: Q was checked symmetric by the forward
         ctx.sync = sync
@@ -177,23 +175,33 @@ def torch_qp_int_grads_admm(x, lams, nus, dx, dlam, dnu, any_lb, any_ub):
 # ---------------------------------------------------------------------------
 # internals
 # ---------------------------------------------------------------------------
-_bounds_cache = []      # [(weakref(lb), lb._version, weakref(ub), ub._version, (any_lb, any_ub))]
-
-
 def _finite_bounds(lb, ub):
-    """(any_lb, any_ub): global over the whole batch, as in the reference (:33-34, :129-130).
-    Costs two reductions and a host sync, so the answer is remembered for the SAME live tensor
-    objects at the same in-place version -- training loops pass the same bounds every step."""
-    for rl, vl, ru, vu, res in _bounds_cache:
-        if rl() is lb and ru() is ub and vl == lb._version and vu == ub._version:
-            return res
+    """(any_lb, any_ub): global over the whole batch, as in the reference (:33-34, :129-130) -- two reductions and a
+    host round trip.  Only the cold paths (``unroll``, ``backward='kkt'``, the first un-synchronised call of a
+    process) use it; the layer itself learns the answer from the device (see _forward_solve)."""
     flags = torch.stack((torch.max(lb) > -_INF, torch.min(ub) < _INF)).tolist()
-    res = (bool(flags[0]), bool(flags[1]))
-    # (64 live pairs: a training loop that cycles over a few dozen batches must not fall back to the two reductions and
-    #  the host synchronisation of a miss on every step -- with 8 entries and 10 cycled batches every call missed)
-    _bounds_cache[:] = [e for e in _bounds_cache if e[0]() is not None and e[2]() is not None][-63:]
-    _bounds_cache.append((weakref.ref(lb), lb._version, weakref.ref(ub), ub._version, res))
-    return res
+    return bool(flags[0]), bool(flags[1])
+
+
+# "Does the batch hold any finite bound?" selects the schedule (rho = 0: one KKT solve, :157-158) and is a host decision
+# in the reference.  Here the setup kernel answers it from the data of EVERY call (status words 12/13); the host only
+# assumes an answer when it enqueues -- what the last solve with the same control dict saw, else the last solve at all --
+# and compares afterwards: a call that waits for the GPU repeats itself on the other schedule, an un-synchronised one
+# reports the mismatch late (its outputs are then not the reference's and must not be used).
+_assumed_any = {}       # id(control dict) -> bool
+_assumed_last = [None]
+
+
+def _assume_any_bound(control):
+    v = _assumed_any.get(id(control))
+    return _assumed_last[0] if v is None else v
+
+
+def _remember_any_bound(control, any_bound):
+    if len(_assumed_any) > 256:
+        _assumed_any.clear()
+    _assumed_any[id(control)] = bool(any_bound)
+    _assumed_last[0] = bool(any_bound)
 
 
 def resolve_control(control, n_x):
@@ -254,7 +262,9 @@ def _beta_argument(beta, B, like):
     return 2, 0.0, beta.detach().to(device=like.device, dtype=like.dtype).reshape(B).contiguous()
 
 
-def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None):
+def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None, mutate=False):
+    """bounds: (any_lb, any_ub) when the caller KNOWS them (a shard of a larger batch with host-side flags); None: found
+    on the device.  mutate: apply the reference layer's dict side effect control['rho'] = 0 (:37-38)."""
     _lib.require_gpu(Q, p, A, b, lb, ub)
     lib = _lib.load()
     _lib.poll_errors()
@@ -262,18 +272,24 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     m = get_ncon(A, dim=1)
     dt = _lib.dtype_code(p)
     dev = p.device
-    has_lb, has_ub = bounds if bounds is not None else _finite_bounds(lb, ub)
+    if check_hook is not None:
+        sync = True                                   # the strict global stop is host-driven (one launch per check)
+    known = bounds is not None
+    if known:
+        any_bound = bool(bounds[0] or bounds[1])
+    else:
+        any_bound = _assume_any_bound(control)
+        if any_bound is None:                         # first solve of the process
+            any_bound = True if sync else any(_finite_bounds(lb, ub))
     r = resolve_control(control, n)
     rho = r['rho']
-    if not (has_lb or has_ub):
+    if not any_bound:
         rho = 0                                     # one iteration solves it (:157-158)
     Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
     rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, p)
     beta_mode, beta_value, beta_tensor = _beta_argument(r['beta'], B, p)
     hook_c = None
-    if check_hook is not None:
-        sync = True                                   # the strict global stop is host-driven (one launch per check)
-
+    flags_dev = control.get('_bound_flags_dev')       # (lqp_py_amd.dist: device-side flags of the whole batch)
     if r['linsolve'] not in _LINSOLVE:
         _bad("control['linsolve'] must be 'auto', 'lu' or 'spd'")
     ctl = _lib.BoxQPCtrl(
@@ -281,13 +297,14 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         max_iters=int(r['max_iters']), check_solved=int(r['check_solved']),
         adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
         adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),
-        any_lb=int(has_lb), any_ub=int(has_ub), rho_mode=rho_mode,
+        any_lb=int(any_bound), any_ub=int(any_bound), rho_mode=rho_mode,
         beta_mode=beta_mode, launch_mode=int(r['launch_mode']), reserved=0 if sync else 1,
         eps_abs=float(r['eps_abs']), eps_rel=float(r['eps_rel']), rho_value=rho_value,
         rho_min=float(r['rho_min']), rho_max=float(r['rho_max']),
         adaptive_rho_tol=float(r['adaptive_rho_tol']),
         adaptive_rho_threshold=float(r['adaptive_rho_threshold']),
-        beta_value=beta_value, beta_in=None if beta_tensor is None else beta_tensor.data_ptr())
+        beta_value=beta_value, beta_in=None if beta_tensor is None else beta_tensor.data_ptr(),
+        bound_flags_in=None if flags_dev is None else flags_dev.data_ptr())
     stats = _lib.BoxQPStats()
 
     x = torch.empty((B, n, 1), dtype=p.dtype, device=dev)
@@ -299,14 +316,15 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     nbytes = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
     ws = _lib.workspace(dev, nbytes, "fwd")
     if check_hook is not None:
-        # check_hook(counters) all-reduces the three uint32 counters of a check in place; it gets a tensor VIEW of
-        # the workspace at the device address the library names
+        # check_hook(counters) all-reduces (SUM) the four uint32 words of a check -- {not optimal, arrivals, wants rho,
+        # ratio trigger} -- in place; it gets a tensor VIEW of the workspace at the device address the library names.
+        # check_index -1: the same reduction over the failure vote of a factorisation (include/lqp_amd.h)
         hook_error = []
 
         def _c_hook(_user, _stream, counters_ptr, check_index):
             try:
                 off = int(counters_ptr) - ws.data_ptr()
-                check_hook(ws[off:off + 12].view(torch.int32), int(check_index))
+                check_hook(ws[off:off + 16].view(torch.int32), int(check_index))
                 return 0
             except Exception as exc:                  # never let an exception cross the C frame
                 hook_error.append(exc)
@@ -330,7 +348,17 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         so, sb, io, ib = (ctypes.c_size_t() for _ in range(4))
         _lib.check(lib.lqp_boxqp_forward_layout(dt, B, n, m, ctypes.byref(so), ctypes.byref(sb), ctypes.byref(io),
                                                 ctypes.byref(ib)), "forward_layout")
-        _lib.defer_check("SolveBoxQP.forward", ws, so.value, sb.value, io.value, ib.value)
+        _lib.defer_check("SolveBoxQP.forward", ws, so.value, sb.value, io.value, ib.value,
+                         bounds_check=None if known else (any_bound, control, mutate, _remember_any_bound))
+    elif not known and stats.any_lb >= 0:
+        # the device looked at the bounds: did the schedule we enqueued fit them?
+        seen = bool(stats.any_lb or stats.any_ub)
+        _remember_any_bound(control, seen)
+        if seen != any_bound:
+            return _forward_solve(Q, p, A, b, lb, ub, control, bounds=(bool(stats.any_lb), bool(stats.any_ub)), sync=sync,
+                                  residuals=residuals, check_hook=check_hook, mutate=mutate)
+    if mutate and not any_bound:
+        control['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
     if r['verbose']:
         print(f'iteration = {stats.iters}  (checks: {stats.n_check}, factorisations: {stats.n_factor})')
 
@@ -349,7 +377,8 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
                                                     _lib.ptr(pri), _lib.ptr(dua)), "last_residuals")
         sol["primal_error"], sol["dual_error"] = pri, dua
     sol["_stats"] = {k: getattr(stats, k) for k, _ in stats._fields_}
-    _last_forward[dev.index] = (ws, dt, B, n, m, dict(sol["_stats"]), int(r['check_solved']), int(r['max_iters']))
+    _last_forward[(dev.index, torch.cuda.current_stream(dev).cuda_stream)] = (
+        ws, dt, B, n, m, dict(sol["_stats"]), int(r['check_solved']), int(r['max_iters']))
     return sol
 
 
@@ -357,12 +386,14 @@ _last_forward = {}
 
 
 def last_forward_status(device):
-    """Bookkeeping of the most recent forward solve on `device`: {"iters", "n_check", "n_factor", "mode_used",
+    """Bookkeeping of the most recent forward solve on `device`, on the CURRENT stream (workspaces are per stream): {"iters", "n_check", "n_factor", "mode_used",
     "linsolve_used", "factor_launches", "loop_workgroups_per_qp"}.  A call that did not wait for the GPU
     (control['sync'] = False) could not report its iteration count; it is read here from the device-side status
     block of that call's workspace (this waits for the device).  Valid until the next forward on the same stream."""
     device = torch.device(device)
-    ws, dt, B, n, m, st, check, max_iters = _last_forward[device.index]
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    ws, dt, B, n, m, st, check, max_iters = _last_forward[(device.index, torch.cuda.current_stream(device).cuda_stream)]
     if st["mode_used"] == 3:
         lib = _lib.load()
         so, sb, io, ib = (ctypes.c_size_t() for _ in range(4))
@@ -371,7 +402,8 @@ def last_forward_status(device):
         torch.cuda.synchronize(device)
         status = ws[so.value:so.value + sb.value].view(torch.int32).cpu().tolist()
         iters = status[1] if status[0] else max_iters - 1          # [0] done, [1] final iteration, [3] refactorisations
-        st = dict(st, iters=iters, n_check=iters // check + 1, n_factor=1 + status[3], n_solve=iters + 1)
+        st = dict(st, iters=iters, n_check=iters // check + 1, n_factor=1 + status[3], n_solve=iters + 1,
+                  any_lb=status[12], any_ub=status[13])
     st["loop_workgroups_per_qp"] = st.pop("loop_workgroups")
     return st
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/lqp_amd.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
-    assert _lib.load().lqp_abi_version() == 4
+    assert _lib.load().lqp_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define LQP_ABI_VERSION (\d+)", open(os.path.join(REPO, "include", "lqp_amd.h")).read()).group(1))
 
 
 def test_workspace_queries_and_argument_checks_without_gpu():
@@ -104,6 +104,10 @@ def test_synthetic_generator_matches_the_oracle_and_the_golden_inputs():
                dict(n_x=7, n_batch=3, seed=2, dtype=torch.float64)):
         for a, b in zip(create_qp_data(**kw), O.create_qp_data(**kw)):
             assert (a is None and b is None) or (a.dtype == b.dtype and torch.equal(a, b))
+    from lqp_py_amd.synthetic import create_hard_qp_data
+    for a, b in zip(create_hard_qp_data(30, 0.15, [0, 1, 7]), O.create_hard_qp_data(30, 0.15, [0, 1, 7])):
+        assert a.dtype == b.dtype == torch.float64 and torch.equal(a, b)
+    # (tests/golden/make_golden.py holds the oracle's generator equal to the reference's generate_hard_qp_torch)
     g = load_golden("g1_b32_n10_box")
     Q, p, _, _, lb, ub = create_qp_data(10, 32, seed=0, with_eq=False, unit_box=True)
     assert torch.equal(Q, g["Q"]) and torch.equal(p, g["p"]) and torch.equal(lb, g["lb"]) and torch.equal(ub, g["ub"])

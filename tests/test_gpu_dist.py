@@ -87,3 +87,49 @@ def test_two_ranks_drive_the_hip_layer(tmp_path, strict):
         lo, hi = shard_slice(B, r, world)
         scale = max(1.0, float(g[1][lo:hi].abs().max()))
         assert float((o["dp"] - g[1][lo:hi]).abs().max()) < (1e-3 if not strict else 2e-4) * scale
+
+
+def _trigger_data(n=50, B=8):
+    """first half: G6-like problems whose residual ratio asks for a new rho at iteration 100; second half: problems that
+    are optimal after 20 iterations and never trigger anything"""
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=3)
+    Q = Q * 50
+    Q[B // 2:] = 100 * torch.eye(n)
+    return Q, p, A, b, lb, ub
+
+
+def _trigger_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lqp_py_amd as L
+    from lqp_py_amd.dist import ShardedBoxQP, shard_slice
+    from lqp_py_amd.solve_box_qp_admm_torch import last_forward_status
+    dev = torch.device("cuda:0")
+    Qa, pa, Aa, ba, lba, uba = _trigger_data()
+    lo, hi = shard_slice(Qa.shape[0], rank, world)
+    Q, p, A, b, lb, ub = (t[lo:hi].to(dev) for t in (Qa, pa, Aa, ba, lba, uba))
+    ctl = L.box_qp_control(rho=100.0, scale=False, dist_strict_stop=True, **TOL)
+    x_local, x_all = ShardedBoxQP(ctl)(Q, p, A, b, lb, ub)
+    st = last_forward_status(dev)
+    torch.cuda.synchronize()
+    torch.save({"x_all": x_all.cpu(), "iter": st["iters"], "n_factor": st["n_factor"]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strict_stop_shares_the_ratio_trigger(tmp_path):
+    """Only rank 0 holds problems whose residual ratio triggers the adaptive-rho step at iteration 100 (:244-246); the
+    decision is global in the reference, so BOTH ranks refactorise (all four counter words are all-reduced) and both
+    report the single-process iteration count."""
+    world = 2
+    mp.spawn(_trigger_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    Q, p, A, b, lb, ub = _trigger_data()
+    tr = {}
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(rho=100.0, scale=False, **TOL), trace=tr)
+    assert tr["n_factor"] == 2 and ref["iter"] == 100
+    assert [o["iter"] for o in outs] == [ref["iter"]] * world, [o["iter"] for o in outs]
+    assert [o["n_factor"] for o in outs] == [2] * world, [o["n_factor"] for o in outs]
+    assert torch.equal(outs[0]["x_all"], outs[1]["x_all"])
+    e = float((outs[0]["x_all"] - ref["x"]).abs().max())
+    assert e < 5e-5 * max(1.0, float(ref["x"].abs().max())), e

@@ -1000,3 +1000,86 @@ def test_lqp_py_alias_resolves_to_the_hip_layer(dev):
     inp = [t.to(dev) for t in O.create_qp_data(20, 3, seed=0)]
     x = SolveBoxQP(control=box_qp_control(**TOL))(*inp)
     assert x.is_cuda and err(x, O.solve_box_qp(*O.create_qp_data(20, 3, seed=0), O.make_control(**TOL))["x"]) < 2e-5
+
+
+@pytest.mark.parametrize("n,m", [(1000, 10), (760, 16), (960, 8)])
+def test_many_equality_rows_at_large_n_take_the_lu_path(dev, n, m):
+    """The rank-m equality correction keeps G and T (2 m rows of 64 Ks floats) in LDS next to the product's scratch:
+    above 160 KB (n > 960 at m >= 8, n > 896 at m >= 9, n > 704 at m >= 15) 'auto' must stay on the pivoted LU instead
+    of failing with 'unsupported size'.  Results against the CPU oracle."""
+    B = 2
+    torch.manual_seed(n + m)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    A = torch.randn(B, m, n)
+    b = 0.1 * torch.randn(B, m, 1)
+    sol, _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(**TOL))
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+    assert sol["iter"] == ref["iter"]
+    assert sol["_stats"]["linsolve_used"] in (1, 2)
+    if n * 1 > 960 or m >= 15:
+        assert sol["_stats"]["linsolve_used"] == 1
+    P.record("lds_budget", "x", err(sol["x"], ref["x"]), 1.0, n=n, m=m)
+    assert err(sol["x"], ref["x"]) < 3e-5
+    assert err(sol["nus"], ref["nus"]) < 2e-3 * max(1.0, float(ref["nus"].abs().max()))
+
+
+def test_bound_flags_come_from_the_device(dev):
+    """Whether any bound is finite (:33-38, :129-131) is found by the setup kernel from the DATA of every call: fresh
+    tensors cost no host look, a tensor rewritten through .data is seen, and a batch without any finite bound takes the
+    reference's rho = 0 one-shot solve (with the dict side effect) whatever the previous call looked like."""
+    n, B = 40, 5
+    Q, p, A, b, lb, ub = (t.to(dev) for t in O.create_qp_data(n, B, seed=9))
+    ref = O.solve_box_qp(*(t.cpu() for t in (Q, p, A, b, lb, ub)), O.make_control(**TOL))
+    inf = float("inf")
+    lb_none, ub_none = torch.full_like(lb, -inf), torch.full_like(ub, inf)
+    ref0 = O.solve_box_qp(Q.cpu(), p.cpu(), A.cpu(), b.cpu(), lb_none.cpu(), ub_none.cpu(), O.make_control(**TOL))
+    ctl = L.box_qp_control(**TOL)
+    layer = L.SolveBoxQP(control=ctl)
+    x1 = layer(Q, p, A, b, lb, ub)
+    assert "rho" not in ctl or ctl["rho"] is None
+    assert err(x1, ref["x"]) < 2e-5
+    st = SB.last_forward_status(dev)
+    assert st["any_lb"] == 1 and st["any_ub"] == 1 and st["iters"] == ref["iter"]
+    # the same dict, now a batch without bounds: one-shot solve, dict mutated -- although the layer assumed bounds
+    x0 = layer(Q, p, A, b, lb_none, ub_none)
+    assert ctl["rho"] == 0
+    assert SB.last_forward_status(dev)["iters"] == ref0["iter"] == 0
+    assert err(x0, ref0["x"]) < 2e-5
+    # only one side finite: the other clamp is an exact no-op
+    ref_lb = O.solve_box_qp(Q.cpu(), p.cpu(), A.cpu(), b.cpu(), lb.cpu(), ub_none.cpu(), O.make_control(**TOL))
+    sol_lb = L.torch_solve_box_qp(Q, p, A, b, lb, ub_none, L.box_qp_control(**TOL))
+    assert sol_lb["iter"] == ref_lb["iter"] and err(sol_lb["x"], ref_lb["x"]) < 2e-5
+    assert sol_lb["_stats"]["any_lb"] == 1 and sol_lb["_stats"]["any_ub"] == 0
+    # a tensor rewritten through .data (same object, same _version) is looked at again
+    ctl2 = L.box_qp_control(**TOL)
+    lbm, ubm = lb.clone(), ub.clone()
+    xa = L.SolveBoxQP(control=ctl2)(Q, p, A, b, lbm, ubm)
+    lbm.data.fill_(-inf)
+    ubm.data.fill_(inf)
+    xb = L.SolveBoxQP(control=ctl2)(Q, p, A, b, lbm, ubm)
+    assert ctl2["rho"] == 0 and err(xa, ref["x"]) < 2e-5 and err(xb, ref0["x"]) < 2e-5
+
+
+def test_pipelined_calls_verify_the_bound_assumption_late(dev):
+    """control['sync'] = False cannot repeat a solve: a batch whose 'any finite bound?' differs from what the previous
+    solve with the same control saw is reported late; the next call then runs the right schedule."""
+    n, B = 40, 5
+    Q, p, A, b, lb, ub = (t.to(dev) for t in O.create_qp_data(n, B, seed=9))
+    inf = float("inf")
+    lb_none, ub_none = torch.full_like(lb, -inf), torch.full_like(ub, inf)
+    ref = O.solve_box_qp(*(t.cpu() for t in (Q, p, A, b, lb, ub)), O.make_control(**TOL))
+    ref0 = O.solve_box_qp(Q.cpu(), p.cpu(), A.cpu(), b.cpu(), lb_none.cpu(), ub_none.cpu(), O.make_control(**TOL))
+    ctl = L.box_qp_control(sync=False, **TOL)
+    layer = L.SolveBoxQP(control=ctl)
+    for _ in range(3):                                   # fresh clones every call: nothing to remember, nothing to wait for
+        x = layer(Q, p, A, b, lb.clone(), ub.clone())
+    L.synchronize()
+    assert err(x, ref["x"]) < 2e-5
+    layer(Q, p, A, b, lb_none, ub_none)                  # enqueued for the ADMM loop; the device finds no bound
+    with pytest.raises(RuntimeError, match="finite bound"):
+        L.synchronize()
+    assert ctl["rho"] == 0                               # the reference's side effect, applied when the status arrived
+    x0 = layer(Q, p, A, b, lb_none, ub_none)             # now assumed right
+    L.synchronize()
+    assert err(x0, ref0["x"]) < 2e-5
+    L.synchronize()
