@@ -244,21 +244,6 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     const T* ub = P.ub + (size_t)b * n;
     const T p0 = tid < n ? p[tid] : T(0), lb0 = tid < n ? lb[tid] : T(0), ub0 = tid < n ? ub[tid] : T(0);
     const T a0 = (m > 0 && tid < n) ? P.A[(size_t)b * m * n + tid] : T(0);          // first equality row
-    // any finite bound in the batch?  (:129-130: a HOST decision in the reference -- it selects the rho = 0 shortcut and
-    // the clamps.  Here the clamps always run (an infinite bound is an exact no-op) and the answer is left in the status
-    // block: the host compares it with what it assumed when it chose the schedule.)
-    {
-        bool flb = false, fub = false;
-        for (int i = tid; i < n; i += LQP_NT) {
-            flb |= (i == tid ? lb0 : lb[i]) > -T(INFINITY);
-            fub |= (i == tid ? ub0 : ub[i]) < T(INFINITY);
-        }
-        if (b == 0 && tid < 2 && P.bound_flags_in && P.bound_flags_in[tid] != 0)
-            __hip_atomic_store(P.status + ST_ANY_LB + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__ballot(flb) != 0ull && lane == 0) __hip_atomic_store(P.status + ST_ANY_LB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__ballot(fub) != 0ull && lane == 0) __hip_atomic_store(P.status + ST_ANY_UB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
     SETUP_STAMP(0);
     const T* Qs = Q;
     int ldq = n;
@@ -464,6 +449,24 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     }
     SETUP_STAMP(5);
     // ---- bounds (:192-194) and state ----
+    // any finite bound in the batch?  (:129-130: a HOST decision in the reference -- it selects the rho = 0 shortcut and
+    // the clamps.  Here the clamps always run (an infinite bound is an exact no-op) and the answer is left in the status
+    // block: the host compares it with what it assumed when it chose the schedule.)
+    {
+        bool flb = false, fub = false;
+        for (int i = tid; i < n; i += LQP_NT) {
+            flb |= (i == tid ? lb0 : lb[i]) > -T(INFINITY);
+            fub |= (i == tid ? ub0 : ub[i]) < T(INFINITY);
+        }
+        // one store per workgroup at most, none once the word is up (thousands of waves storing to one address queue
+        // behind each other at the memory side: 55 us per launch when every wave did it)
+        const int wg_lb = __syncthreads_or(flb ? 1 : 0), wg_ub = __syncthreads_or(fub ? 1 : 0);
+        if (tid < 2) {
+            const bool mine = (tid == 0 ? wg_lb : wg_ub) != 0 || (b == 0 && P.bound_flags_in && P.bound_flags_in[tid] != 0);
+            if (mine && __hip_atomic_load(P.status + ST_ANY_LB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(P.status + ST_ANY_LB + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     for (int i = tid; i < n; i += LQP_NT) {
         const T di = P.scale ? V.D[i] : T(1);                // (:192-194; +-inf / D stays +-inf)
         V.lbs[i] = (i == tid ? lb0 : lb[i]) / di;

@@ -464,6 +464,301 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
     }
 }
 
+// ---- the same pivot block on the matrix cores ---------------------------------------------------------------
+// wg_pivot_block spends half of its time in 4096 (v_readlane, FMA) pairs -- the rank-1 updates of the 64 columns,
+// pivot-row entries broadcast one by one -- and a sixth in LDS write -> barrier -> read round trips, 16 waves busy
+// with work that is a rank-4 update per panel.  Here a panel's update IS one matrix instruction pair per 32x32
+// quadrant (v_mfma_f32_32x32x2_f32: exact f32, an fma chain over k), the working array lives in MFMA accumulators,
+// and four waves work, each on the quadrants it owns:
+//   wave 0  chain, panels 0..7.  S = the Schur complement, quadrants (0,0), (0,1).  Per panel of 4 columns: rows
+//           c0..c0+3 of S come out of the accumulators as lane vectors (register q of lane half h holds one row of a
+//           quadrant across 32 lanes: ONE v_permlane32_swap joins the two quadrants of a row); by symmetry they are the
+//           panel's columns; the four column steps run on them as before (pivot by v_readlane, rsq, coefficient column,
+//           the later panel columns updated); the coefficient columns (lane = row) and the transformed pivot rows
+//           (lane = column) are exactly the A and B operands of the rank-4 update once their halves are paired
+//           (v_permlane32_swap again): no LDS, no barrier on the chain.  Both also go to LDS queues (the W^T area and
+//           the upper half of the W area, free until the end).
+//   wave 3  quadrant (1,1) of S: follows the queues through panels 0..7, then IS the chain for panels 8..15.
+//   wave 1, wave 2  the augmented part (W under construction, unit lower triangular until the final scaling): column
+//           block 0 = quadrants (0,0), (1,0) | column block 1 = quadrant (1,1).  They follow the coefficient queue: the
+//           coefficient columns are the A operand, the pivot rows of the panel come from their OWN accumulators
+//           (transformed by the panel's 4x4 unit triangle first: 6 FMAs), so nothing but the queue is shared.
+// The other waves of the workgroup leave after the staging barrier.  W, W^T as wg_pivot_block leaves them (W = L^-1
+// row-scaled by 1/sqrt(pivot), zero above the diagonal).  Rounding differs from wg_pivot_block in the last bits (the
+// pivot rows are taken as the symmetric counterpart of the columns); every caller uses one of the two, never both.
+// Measured: see DESIGN.md section 5 (tools/microbench/piv_bench.hip).
+#ifndef LQP_PIV_MFMA
+#define LQP_PIV_MFMA 1
+#endif
+__device__ __forceinline__ float piv_readlane(const float v, const int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// lo = [a(lanes 0-31) | b(lanes 0-31)], hi = [a(lanes 32-63) | b(lanes 32-63)]
+// (v_permlane32_swap through inline assembly: with __builtin_amdgcn_permlane32_swap hipcc 7.2 handed the FIRST result to
+//  users of the second one as soon as both were live across other code -- both MFMAs of a panel then got the same B
+//  operand.  The s_nops cover the wait states the swap needs behind a VALU write of its operands and before its results are read; the assembler
+//  block is invisible to the compiler's hazard recogniser.)
+__device__ __forceinline__ void piv_pair(float a, float b, float& lo, float& hi) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+}
+// GSYNC = false: called by ALL waves of the workgroup; W, W^T and pcol must be free (a barrier since their last use).
+// GSYNC = true : called by waves 0..3 while the rest of the workgroup does something else; src_blk is a 64x64 tile in
+//                LDS (row stride 64), gwords two LDS ints zeroed at kernel start, gcall the number of earlier calls in
+//                this kernel.  The caller synchronises afterwards.
+template <bool GSYNC = false>
+__device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ src_blk, float* __restrict__ W,
+                                                    float* __restrict__ WT, float* __restrict__ pcol,
+                                                    int* __restrict__ flag, const int kbase,
+                                                    int* __restrict__ gwords = nullptr, const int gcall = 0) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    float* const svals = pcol;                                        // [64]: 1 / sqrt(pivot)
+    int* const words = GSYNC ? gwords : (int*)(pcol + 64);            // [0] panels published, [1] consumers done
+    float* const queue = WT;                                          // [16][4][64] coefficient columns
+    float* const xqueue = W;                                          // [8][4][64] pivot rows of panels 0..7 (over rows 0..31 of the staged tile)
+    const int rbase = GSYNC ? 16 * gcall : 0, dbase = GSYNC ? 2 * gcall : 0;
+    if constexpr (!GSYNC) {
+        // the tile into the W area (row stride SPD_LS): one coalesced pass by the whole workgroup
+        for (int i = tid * 4; i < LQP_BLK; i += (int)blockDim.x * 4)
+            *(V4<float>*)(W + (i >> 6) * SPD_LS + (i & 63)) = *(const V4<float>*)(src_blk + i);
+        if (tid == 0) { words[0] = 0; words[1] = 0; }
+        __syncthreads();
+    }
+    if (w > 3) return;
+    const float* const Tl = GSYNC ? src_blk : W;
+    constexpr int ld = GSYNC ? 64 : SPD_LS;
+    auto mfma = [](const float a, const float b, const f32x16 c) -> f32x16 {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    };
+    auto wait_published = [&](const int target) {
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    // the panel's column steps on its four columns x[] (lane = row): coefficient columns, transformed columns, scales
+    auto column_steps = [&](const int c0, float (&x)[4], float (&coef)[4], int& badc) {
+        int lane_p = lane;                     // (opaque per panel: the lane > c masks must neither be computed up front for the
+        asm volatile("" : "+v"(lane_p));       //  whole block nor be hoisted out of the CALLER's loop over pivot steps: 128
+                                               //  scalar registers held for the whole kernel)
+        float sreg[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = c0 + t;
+            const float d = piv_readlane(x[t], c);
+            badc = (!(d > 0.f) && badc == 0) ? c + 1 : badc;         // (only recorded: see wg_pivot_block)
+            const float s = __builtin_amdgcn_rsqf(d);
+            coef[t] = lane_p > c ? x[t] * s * s : 0.f;
+#pragma unroll
+            for (int t2 = t + 1; t2 < 4; ++t2) x[t2] = __builtin_fmaf(-coef[t], piv_readlane(x[t2], c), x[t2]);
+            sreg[t] = s;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float sv = sreg[0];
+#pragma unroll
+        for (int t = 1; t < 4; ++t) sv = lane_p == t ? sreg[t] : sv;
+        if (lane_p < 4) svals[c0 + lane_p] = sv;
+    };
+    int pub = rbase;                            // (a running count, opaque: sixteen constants in sixteen registers otherwise)
+    asm volatile("" : "+v"(pub));
+    auto publish = [&](const int count) {      // (the queue writes of that panel have long landed where this is called)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pub += 1;
+        (void)count;
+        if (lane == 0) __hip_atomic_store(words, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (w == 0) {
+        // ================= chain, upper half: quadrants (0,0), (0,1) of the Schur complement =================
+        f32x16 S00, S01;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float* r0 = Tl + quad_row(q, lh) * ld + li;
+            S00[q] = r0[0];
+            S01[q] = r0[32];
+        }
+        if constexpr (!GSYNC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the pivot-row queue overwrites these rows)
+        int badc = 0;
+#pragma unroll
+        for (int P = 0; P < 8; ++P) {
+            const int c0 = 4 * P, q0 = 4 * (c0 / 8), LH = (c0 / 4) & 1;
+            __builtin_amdgcn_sched_barrier(0);                       // (one scheduling region per panel)
+            // rows c0 .. c0+3 of S as lane vectors (lane = column; by symmetry = the panel's columns, lane = row)
+            float x[4], coef[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float lo, hi;
+                piv_pair(S00[q0 + t], S01[q0 + t], lo, hi);
+                x[t] = LH ? hi : lo;
+            }
+            if (P > 0) publish(P);
+            column_steps(c0, x, coef, badc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                queue[(P * 4 + t) * 64 + lane] = coef[t];
+                xqueue[(P * 4 + t) * 64 + lane] = x[t];
+            }
+            if (P < 7) {
+                // rank-4 update of the rows still to come: A = -(coefficient columns), B = the pivot rows
+                float a0_01, a0_23, b0_01, b1_01, b0_23, b1_23, unused;
+                piv_pair(-coef[0], -coef[1], a0_01, unused);
+                piv_pair(-coef[2], -coef[3], a0_23, unused);
+                piv_pair(x[0], x[1], b0_01, b1_01);
+                piv_pair(x[2], x[3], b0_23, b1_23);
+                S00 = mfma(a0_01, b0_01, S00);
+                S01 = mfma(a0_01, b1_01, S01);
+                S00 = mfma(a0_23, b0_23, S00);
+                S01 = mfma(a0_23, b1_23, S01);
+            }
+        }
+        publish(8);
+        if (badc != 0 && lane == 0 && flag[0] == 0) flag[0] = kbase + badc;
+        return;
+    }
+    if (w == 3) {
+        // ================= quadrant (1,1) of the Schur complement: follows panels 0..7, then the chain =================
+        f32x16 S11;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) S11[q] = Tl[(32 + quad_row(q, lh)) * ld + 32 + li];
+#pragma unroll
+        for (int P = 0; P < 8; ++P) {
+            __builtin_amdgcn_sched_barrier(0);
+            wait_published(rbase + P + 1);
+            float cf[4], xr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { cf[t] = queue[(P * 4 + t) * 64 + lane]; xr[t] = xqueue[(P * 4 + t) * 64 + lane]; }
+            float a1_01, a1_23, b1_01, b1_23, unused;
+            piv_pair(-cf[0], -cf[1], unused, a1_01);
+            piv_pair(-cf[2], -cf[3], unused, a1_23);
+            piv_pair(xr[0], xr[1], unused, b1_01);
+            piv_pair(xr[2], xr[3], unused, b1_23);
+            S11 = mfma(a1_01, b1_01, S11);
+            S11 = mfma(a1_23, b1_23, S11);
+        }
+        int badc = 0;
+        pub += 8;
+#pragma unroll
+        for (int P = 8; P < 16; ++P) {
+            const int c0 = 4 * P, rr = c0 - 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            float x[4], coef[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (LH) x[t] = S11[q0 + t];                        // (lanes 0-31: columns the elimination has left)
+                else { float lo, hi; piv_pair(S11[q0 + t], S11[q0 + t], lo, hi); x[t] = lo; }
+            }
+            if (P > 8) publish(P);
+            column_steps(c0, x, coef, badc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) queue[(P * 4 + t) * 64 + lane] = coef[t];
+            if (P < 15) {
+                float a1_01, a1_23, b1_01, b1_23, unused;
+                piv_pair(-coef[0], -coef[1], unused, a1_01);
+                piv_pair(-coef[2], -coef[3], unused, a1_23);
+                piv_pair(x[0], x[1], unused, b1_01);
+                piv_pair(x[2], x[3], unused, b1_23);
+                S11 = mfma(a1_01, b1_01, S11);
+                S11 = mfma(a1_23, b1_23, S11);
+            }
+        }
+        publish(16);
+        if (badc != 0 && lane == 0 && flag[0] == 0) flag[0] = kbase + badc;
+        return;
+    }
+    // ================= waves 1, 2: the augmented part =================
+    // (one instantiation per role: which quadrant a panel's rows come from and which ones it updates are then
+    //  compile-time facts of straight-line code)
+    auto consumer = [&](auto colblock0_tag) {
+        constexpr bool CB0 = decltype(colblock0_tag)::value;
+        f32x16 Wa, Wb;                   // wave 1: quadrants (0,0), (1,0); wave 2: (1,1), -
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { Wa[q] = quad_row(q, lh) == li ? 1.f : 0.f; Wb[q] = 0.f; }
+#pragma unroll
+        for (int P = CB0 ? 0 : 8; P < 16; ++P) {                 // (column block 1 is untouched by the upper half)
+            const int c0 = 4 * P, I = c0 / 32, rr = c0 % 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            wait_published(rbase + P + 1);
+            float cf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) cf[t] = queue[(P * 4 + t) * 64 + lane];
+            // the panel's 4x4 unit lower triangle: coefficient of row c0+k at column step j
+            const float t10 = piv_readlane(cf[0], c0 + 1), t20 = piv_readlane(cf[0], c0 + 2), t30 = piv_readlane(cf[0], c0 + 3);
+            const float t21 = piv_readlane(cf[1], c0 + 2), t31 = piv_readlane(cf[1], c0 + 3), t32 = piv_readlane(cf[2], c0 + 3);
+            // the panel's rows of this column block, as the column steps leave them (half LH of registers q0 .. q0+3)
+            float r0, r1, r2, r3;
+            if (CB0 && I == 1) { r0 = Wb[q0]; r1 = Wb[q0 + 1]; r2 = Wb[q0 + 2]; r3 = Wb[q0 + 3]; }
+            else { r0 = Wa[q0]; r1 = Wa[q0 + 1]; r2 = Wa[q0 + 2]; r3 = Wa[q0 + 3]; }
+            r1 = __builtin_fmaf(-t10, r0, r1);
+            r2 = __builtin_fmaf(-t21, r1, __builtin_fmaf(-t20, r0, r2));
+            r3 = __builtin_fmaf(-t32, r2, __builtin_fmaf(-t31, r1, __builtin_fmaf(-t30, r0, r3)));
+            float lo, hi, b_01, b_23, a0_01, a1_01, a0_23, a1_23;
+            piv_pair(r0, r1, lo, hi); b_01 = LH ? hi : lo;
+            piv_pair(r2, r3, lo, hi); b_23 = LH ? hi : lo;
+            piv_pair(-cf[0], -cf[1], a0_01, a1_01);
+            piv_pair(-cf[2], -cf[3], a0_23, a1_23);
+            if (CB0) {
+                if (I == 0) {
+                    Wa = mfma(a0_01, b_01, Wa);
+                    Wb = mfma(a1_01, b_01, Wb);
+                    Wa = mfma(a0_23, b_23, Wa);
+                    Wb = mfma(a1_23, b_23, Wb);
+                } else {
+                    Wb = mfma(a1_01, b_01, Wb);
+                    Wb = mfma(a1_23, b_23, Wb);
+                }
+            } else {
+                Wa = mfma(a1_01, b_01, Wa);
+                Wa = mfma(a1_23, b_23, Wa);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_published(rbase + 16);                              // (all scales are in svals)
+        // the queue sits in the W^T area: both consumers must be through with it before anybody writes W^T
+        if (lane == 0) __hip_atomic_fetch_add(words + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < dbase + 2)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+#ifdef LQP_PIV_DEBUG_STOP
+        return;
+#endif
+        // W = (row scale) x (unit lower triangle), zero above the diagonal; W^T
+        auto store_quadrant = [&](const f32x16& v, const int I, const int J) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const V4<float> sv = *(const V4<float>*)(svals + 32 * I + 8 * a + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // (above the diagonal the unit triangle is exactly zero: 0 - coef * 0 at every step, no select needed)
+                    const int row = 32 * I + 8 * a + 4 * lh + e, col = 32 * J + li;
+                    const float val = v[4 * a + e] * sv.v[e];
+                    W[row * SPD_LS + col] = val;
+                    WT[col * SPD_LS + row] = val;
+                }
+            }
+        };
+        if (CB0) {
+            store_quadrant(Wa, 0, 0);
+            store_quadrant(Wb, 1, 0);
+        } else {
+            store_quadrant(Wa, 1, 1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {                       // quadrant (0,1) of W = quadrant (1,0) of W^T = 0
+                W[quad_row(q, lh) * SPD_LS + 32 + li] = 0.f;
+                WT[(32 + quad_row(q, lh)) * SPD_LS + li] = 0.f;
+            }
+        }
+    };
+    if (w == 1) consumer(std::true_type());
+    else consumer(std::false_type());
+}
+
+// the pivot block of every factorisation below: on the matrix cores unless built with -DLQP_PIV_MFMA=0
+template <int NWP, bool MFMA = (LQP_PIV_MFMA != 0)>
+__device__ __forceinline__ void wg_pivot(const float* __restrict__ src_blk, float* __restrict__ W, float* __restrict__ WT,
+                                         float* __restrict__ pcol, int* __restrict__ flag, const int kbase) {
+    if constexpr (MFMA) wg_pivot_block_mfma<false>(src_blk, W, WT, pcol, flag, kbase);
+    else wg_pivot_block<NWP>(src_blk, W, WT, pcol, flag, kbase);
+}
+
 // ---- block symmetric sweep: Hs (lower blocks of an SPD matrix) -> -inverse, in place ----
 // info: 0, or 1 + index of the first non-positive pivot.
 // NP == 1: the whole sweep, in place.  NP > 1: pivot steps [k0, k1) only, OUT of place (every block of the matrix
@@ -501,7 +796,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
             }
         }
         if (NP == 1 || k == 0) {
-            wg_pivot_block<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+            wg_pivot<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
         } else {      // W, W^T of this pivot block were prepared by the previous launch (lookahead below)
             for (int i = tid * 4; i < 2 * 64 * SPD_LS; i += LQP_NT * 4) *(V4<float>*)(W + i) = *(const V4<float>*)(Wg + i);
         }
@@ -604,7 +899,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                     }
                     __threadfence_block();
                     __syncthreads();
-                    wg_pivot_block<LQP_PIV_WAVES>(Tn, W, WT, pcol, flag, (k + 1) * 64);
+                    wg_pivot<LQP_PIV_WAVES>(Tn, W, WT, pcol, flag, (k + 1) * 64);
                     __syncthreads();
                     for (int i = tid * 4; i < 2 * 64 * SPD_LS; i += LQP_NT * 4) *(V4<float>*)(Wg + i) = *(const V4<float>*)(W + i);
                 }
@@ -701,7 +996,7 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
     if (tid == 0) flag[0] = 0;
     for (int k = (NP == 1 ? 0 : k0); k < (NP == 1 ? K : k1); ++k) {
         if (phases & 1) {
-            wg_pivot_block<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+            wg_pivot<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
             __syncthreads();
             // this workgroup's part of the panel: slots [s_lo, s_hi)
             const int s_half = (K - 1 + 1) / 2;
@@ -1238,6 +1533,9 @@ __device__ __forceinline__ float split_combine(const int e, const int Np, const 
 // The multi-launch form (k_spd_begin/step/end) moved all 36 tiles through L2/HBM in every step (1.24 GB per batch of
 // 128 at n = 500, 13x the minimum); this one reads the matrix once and writes it once.
 // ---------------------------------------------------------------------------
+#ifndef LQP_RS_PIV_MFMA
+#define LQP_RS_PIV_MFMA 0
+#endif
 constexpr int RS_NT = 512, RS_NW = RS_NT / 64;
 template <int K> __host__ __device__ constexpr int rs_slots() {
     const int a = split_count(K, 0), b = split_count(K, 1);
@@ -1368,7 +1666,9 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* 
         if (k == dbg_stop) return;
         if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
         // ---- pivot tile -> W, W^T; panel tiles -> LDS (slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k) ----
-        wg_pivot_block<LQP_PIV_WAVES_RS>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        // (the matrix-core pivot block needs 32 accumulator registers next to the 144 this kernel keeps its tiles in: the
+        //  compiler then spills 245 registers and the sweep takes 0.55 ms instead of 0.36 -- see LQP_RS_PARK)
+        wg_pivot<LQP_PIV_WAVES_RS, (LQP_PIV_MFMA != 0 && LQP_RS_PIV_MFMA != 0)>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
         if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
         {
             const int r = tid >> 3, c8 = (tid & 7) * 8;
@@ -1469,7 +1769,7 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s)
             if (s < np) preg[s] = *(const V4<float>*)(Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK + tid * 4);
-        wg_pivot_block<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        wg_pivot<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s)
             if (s < np) *(V4<float>*)(Y + ((size_t)s * 64 + r) * SPD_LS + cq * 4) = preg[s];
@@ -1575,7 +1875,11 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
             lds_wait_ge(sy + 2, 3 * k);                     // tile (k,k) is in St
             lds_wait_ge(sy + 4, k);                         // W / W^T of step k-1 are no longer read
             if (dbg && tid == 0) { const unsigned long long c1 = clock64(); dbg[4] += c1 - c0; c0 = c1; }
+#if LQP_PIV_MFMA
+            wg_pivot_block_mfma<true>(St, W, WT, pcol, flag, k * 64, sy + 5, k);
+#else
             wg_pivot_block<NCH, true>(St, W, WT, pcol, flag, k * 64, sy + 0, &gt);
+#endif
             lds_group_sync<true>(sy + 0, gt += NCH);        // all four wrote their part of W / W^T
             if (tid == 0) __hip_atomic_store(sy + 3, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // the pre-inverted diagonal block (read again only by the solves, after the factorisation's last barrier)

@@ -141,6 +141,7 @@ class ShardedBoxQP(torch.nn.Module):
             # private keys for the layer: the flags of the WHOLE batch (a shard without any finite bound must still run
             # the ADMM path the whole batch runs) and, in strict mode, the per-check all-reduce
             ctl = dict(ctl)
+            ctl['_owner'] = self.control        # (what the layer remembers between calls, it remembers there)
             if lb.is_cuda:
                 ctl['_bound_flags_dev'] = device_bound_flags(lb, ub, self.group)
             else:                               # CPU stand-in solver of the gloo tests: host flags
@@ -149,7 +150,7 @@ class ShardedBoxQP(torch.nn.Module):
                 ctl['_check_hook'] = self._check_hook
         x_local = self._apply(Q, p, A, b, lb, ub, ctl)
         if ctl is not self.control and ctl.get('rho', None) is not self.control.get('rho', None):
-            self.control['rho'] = ctl['rho']    # the layer's dict side effect (:37-38) belongs to the caller's dict
+            self.control['rho'] = ctl['rho']        # the layer's dict side effect (:37-38) belongs to the caller's dict
         with torch.no_grad():
             x_all = all_gather_solutions(x_local.detach(), self.group, self.shard_sizes)
         return x_local, x_all

@@ -185,23 +185,19 @@ def _finite_bounds(lb, ub):
 
 # "Does the batch hold any finite bound?" selects the schedule (rho = 0: one KKT solve, :157-158) and is a host decision
 # in the reference.  Here the setup kernel answers it from the data of EVERY call (status words 12/13); the host only
-# assumes an answer when it enqueues -- what the last solve with the same control dict saw, else the last solve at all --
-# and compares afterwards: a call that waits for the GPU repeats itself on the other schedule, an un-synchronised one
-# reports the mismatch late (its outputs are then not the reference's and must not be used).
-_assumed_any = {}       # id(control dict) -> bool
-_assumed_last = [None]
+# assumes an answer when it enqueues -- what the last solve with the same control dict saw (kept in the dict under a
+# private key; unknown keys are carried and ignored like the reference's `reduce`) -- and compares afterwards: a call
+# that waits for the GPU repeats itself on the other schedule, an un-synchronised one reports the mismatch late (its
+# outputs are then not the reference's and must not be used).
+_SEEN = '_any_bound_seen'
 
 
 def _assume_any_bound(control):
-    v = _assumed_any.get(id(control))
-    return _assumed_last[0] if v is None else v
+    return control.get(_SEEN)
 
 
 def _remember_any_bound(control, any_bound):
-    if len(_assumed_any) > 256:
-        _assumed_any.clear()
-    _assumed_any[id(control)] = bool(any_bound)
-    _assumed_last[0] = bool(any_bound)
+    control[_SEEN] = bool(any_bound)
 
 
 def resolve_control(control, n_x):
@@ -275,11 +271,12 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     if check_hook is not None:
         sync = True                                   # the strict global stop is host-driven (one launch per check)
     known = bounds is not None
+    owner = control.get('_owner') or control          # (lqp_py_amd.dist hands the layer a copy of the caller's dict)
     if known:
         any_bound = bool(bounds[0] or bounds[1])
     else:
-        any_bound = _assume_any_bound(control)
-        if any_bound is None:                         # first solve of the process
+        any_bound = _assume_any_bound(owner)
+        if any_bound is None:                         # first solve with this control dict
             any_bound = True if sync else any(_finite_bounds(lb, ub))
     r = resolve_control(control, n)
     rho = r['rho']
@@ -349,16 +346,16 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         _lib.check(lib.lqp_boxqp_forward_layout(dt, B, n, m, ctypes.byref(so), ctypes.byref(sb), ctypes.byref(io),
                                                 ctypes.byref(ib)), "forward_layout")
         _lib.defer_check("SolveBoxQP.forward", ws, so.value, sb.value, io.value, ib.value,
-                         bounds_check=None if known else (any_bound, control, mutate, _remember_any_bound))
+                         bounds_check=None if known else (any_bound, owner, mutate, _remember_any_bound))
     elif not known and stats.any_lb >= 0:
         # the device looked at the bounds: did the schedule we enqueued fit them?
         seen = bool(stats.any_lb or stats.any_ub)
-        _remember_any_bound(control, seen)
+        _remember_any_bound(owner, seen)
         if seen != any_bound:
             return _forward_solve(Q, p, A, b, lb, ub, control, bounds=(bool(stats.any_lb), bool(stats.any_ub)), sync=sync,
                                   residuals=residuals, check_hook=check_hook, mutate=mutate)
     if mutate and not any_bound:
-        control['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
+        control['rho'] = owner['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
     if r['verbose']:
         print(f'iteration = {stats.iters}  (checks: {stats.n_check}, factorisations: {stats.n_factor})')
 
