@@ -809,9 +809,15 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     lr.on = (gate == nullptr && P.rho_late) ? 1 : 0;
     lr.n = P.n; lr.rho_min = P.rho_min; lr.rho_max = P.rho_max;
     lr.rho_out = part == 0 ? P.scal + (size_t)b * SC_WORDS + SC_RHO : nullptr;
+#if LQP_PIV_MFMA && LQP_RS_V2
+    wg_spd_sweep_resident_v2<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
+                                 P.info + b, P.status + ST_TIMEOUT, smem, lr,
+                                 (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
+#else
     wg_spd_sweep_resident<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                               P.info + b, P.status + ST_TIMEOUT, smem, lr, -1,
                               (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
+#endif
 }
 __global__ __launch_bounds__(LQP_NT) void k_spd_end(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];

@@ -507,7 +507,10 @@ __device__ __forceinline__ void piv_pair(float a, float b, float& lo, float& hi)
 // GSYNC = true : called by waves 0..3 while the rest of the workgroup does something else; src_blk is a 64x64 tile in
 //                LDS (row stride 64), gwords two LDS ints zeroed at kernel start, gcall the number of earlier calls in
 //                this kernel.  The caller synchronises afterwards.
-template <bool GSYNC = false>
+// ROLES = false: this instantiation is only ever executed by waves 4.. of the workgroup (they stage the tile, join the
+//                barrier and leave): the role code is not even compiled in -- a caller that has already branched on the
+//                wave number keeps the roles' registers out of its other branch this way.
+template <bool GSYNC = false, bool ROLES = true>
 __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ src_blk, float* __restrict__ W,
                                                     float* __restrict__ WT, float* __restrict__ pcol,
                                                     int* __restrict__ flag, const int kbase,
@@ -525,9 +528,24 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         if (tid == 0) { words[0] = 0; words[1] = 0; }
         __syncthreads();
     }
+    if constexpr (!ROLES) return;
     if (w > 3) return;
     const float* const Tl = GSYNC ? src_blk : W;
     constexpr int ld = GSYNC ? 64 : SPD_LS;
+    // Lane-dependent address parts, made opaque once per call: everything below is base + compile-time offset (the
+    // offset field of the LDS instructions).  Left to itself the compiler forms each of the ~200 addresses (and the 16
+    // values of the identity) as a loop invariant of the CALLER's pivot-step loop, keeps them in registers for the whole
+    // kernel and spills the caller's tiles: 245 spilled registers in the resident sweep.
+    int lane_o = lane, li_o = li, lh_o = lh;
+    asm volatile("" : "+v"(lane_o), "+v"(li_o), "+v"(lh_o));
+    float* const qcoef = queue + lane_o;                              // coefficient column t of panel P: qcoef[(4 P + t) * 64]
+    float* const qrow = xqueue + lane_o;
+    const float* const tile_o = Tl + (4 * lh_o) * ld + li_o;          // element (quad_row(q, lh), li) at + ((q&3) + 8 (q>>2)) * ld
+    float* const w_o = W + (4 * lh_o) * SPD_LS + li_o;                // W[8 a + 4 lh + e][li] at + (8 a + e) * SPD_LS
+    float* const wt_o = WT + li_o * SPD_LS + 4 * lh_o;                // W^T[li][8 a + 4 lh + e] at + 8 a + e
+    float* const wtz_o = WT + (4 * lh_o) * SPD_LS + li_o;             // W^T[8 a + 4 lh + e][li] (the zero quadrant)
+    const float* const sv_o = svals + 4 * lh_o;
+    constexpr auto qoff = [](const int q) { return (q & 3) + 8 * (q >> 2); };
     auto mfma = [](const float a, const float b, const f32x16 c) -> f32x16 {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
     };
@@ -572,9 +590,8 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         f32x16 S00, S01;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const float* r0 = Tl + quad_row(q, lh) * ld + li;
-            S00[q] = r0[0];
-            S01[q] = r0[32];
+            S00[q] = tile_o[qoff(q) * ld];
+            S01[q] = tile_o[qoff(q) * ld + 32];
         }
         if constexpr (!GSYNC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the pivot-row queue overwrites these rows)
         int badc = 0;
@@ -594,8 +611,8 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             column_steps(c0, x, coef, badc);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                queue[(P * 4 + t) * 64 + lane] = coef[t];
-                xqueue[(P * 4 + t) * 64 + lane] = x[t];
+                qcoef[(P * 4 + t) * 64] = coef[t];
+                qrow[(P * 4 + t) * 64] = x[t];
             }
             if (P < 7) {
                 // rank-4 update of the rows still to come: A = -(coefficient columns), B = the pivot rows
@@ -618,14 +635,14 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         // ================= quadrant (1,1) of the Schur complement: follows panels 0..7, then the chain =================
         f32x16 S11;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) S11[q] = Tl[(32 + quad_row(q, lh)) * ld + 32 + li];
+        for (int q = 0; q < 16; ++q) S11[q] = tile_o[(32 + qoff(q)) * ld + 32];
 #pragma unroll
         for (int P = 0; P < 8; ++P) {
             __builtin_amdgcn_sched_barrier(0);
             wait_published(rbase + P + 1);
             float cf[4], xr[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { cf[t] = queue[(P * 4 + t) * 64 + lane]; xr[t] = xqueue[(P * 4 + t) * 64 + lane]; }
+            for (int t = 0; t < 4; ++t) { cf[t] = qcoef[(P * 4 + t) * 64]; xr[t] = qrow[(P * 4 + t) * 64]; }
             float a1_01, a1_23, b1_01, b1_23, unused;
             piv_pair(-cf[0], -cf[1], unused, a1_01);
             piv_pair(-cf[2], -cf[3], unused, a1_23);
@@ -649,7 +666,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             if (P > 8) publish(P);
             column_steps(c0, x, coef, badc);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) queue[(P * 4 + t) * 64 + lane] = coef[t];
+            for (int t = 0; t < 4; ++t) qcoef[(P * 4 + t) * 64] = coef[t];
             if (P < 15) {
                 float a1_01, a1_23, b1_01, b1_23, unused;
                 piv_pair(-coef[0], -coef[1], unused, a1_01);
@@ -671,7 +688,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         constexpr bool CB0 = decltype(colblock0_tag)::value;
         f32x16 Wa, Wb;                   // wave 1: quadrants (0,0), (1,0); wave 2: (1,1), -
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { Wa[q] = quad_row(q, lh) == li ? 1.f : 0.f; Wb[q] = 0.f; }
+        for (int q = 0; q < 16; ++q) { Wa[q] = qoff(q) + 4 * lh_o == li_o ? 1.f : 0.f; Wb[q] = 0.f; }
 #pragma unroll
         for (int P = CB0 ? 0 : 8; P < 16; ++P) {                 // (column block 1 is untouched by the upper half)
             const int c0 = 4 * P, I = c0 / 32, rr = c0 % 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
@@ -679,7 +696,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             wait_published(rbase + P + 1);
             float cf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) cf[t] = queue[(P * 4 + t) * 64 + lane];
+            for (int t = 0; t < 4; ++t) cf[t] = qcoef[(P * 4 + t) * 64];
             // the panel's 4x4 unit lower triangle: coefficient of row c0+k at column step j
             const float t10 = piv_readlane(cf[0], c0 + 1), t20 = piv_readlane(cf[0], c0 + 2), t30 = piv_readlane(cf[0], c0 + 3);
             const float t21 = piv_readlane(cf[1], c0 + 2), t31 = piv_readlane(cf[1], c0 + 3), t32 = piv_readlane(cf[2], c0 + 3);
@@ -724,14 +741,13 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         auto store_quadrant = [&](const f32x16& v, const int I, const int J) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const V4<float> sv = *(const V4<float>*)(svals + 32 * I + 8 * a + 4 * lh);
+                const V4<float> sv = *(const V4<float>*)(sv_o + 32 * I + 8 * a);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // (above the diagonal the unit triangle is exactly zero: 0 - coef * 0 at every step, no select needed)
-                    const int row = 32 * I + 8 * a + 4 * lh + e, col = 32 * J + li;
                     const float val = v[4 * a + e] * sv.v[e];
-                    W[row * SPD_LS + col] = val;
-                    WT[col * SPD_LS + row] = val;
+                    w_o[(32 * I + 8 * a + e) * SPD_LS + 32 * J] = val;
+                    wt_o[(32 * J) * SPD_LS + 32 * I + 8 * a + e] = val;
                 }
             }
         };
@@ -742,8 +758,8 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             store_quadrant(Wa, 1, 1);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {                       // quadrant (0,1) of W = quadrant (1,0) of W^T = 0
-                W[quad_row(q, lh) * SPD_LS + 32 + li] = 0.f;
-                WT[(32 + quad_row(q, lh)) * SPD_LS + li] = 0.f;
+                w_o[qoff(q) * SPD_LS + 32] = 0.f;
+                wtz_o[(32 + qoff(q)) * SPD_LS] = 0.f;
             }
         }
     };
@@ -1534,7 +1550,10 @@ __device__ __forceinline__ float split_combine(const int e, const int Np, const 
 // 128 at n = 500, 13x the minimum); this one reads the matrix once and writes it once.
 // ---------------------------------------------------------------------------
 #ifndef LQP_RS_PIV_MFMA
-#define LQP_RS_PIV_MFMA 0
+#define LQP_RS_PIV_MFMA 0      // (the first resident sweep with the matrix-core pivot block: spills, see wg_spd_sweep_resident_v2)
+#endif
+#ifndef LQP_RS_V2
+#define LQP_RS_V2 1            // k_spd_resident runs wg_spd_sweep_resident_v2
 #endif
 constexpr int RS_NT = 512, RS_NW = RS_NT / 64;
 template <int K> __host__ __device__ constexpr int rs_slots() {
@@ -1743,6 +1762,205 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* 
             for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
         }
     }
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
+// ---- the same resident sweep with the pivot block on the matrix cores --------------------------------------------
+// wg_pivot_block_mfma keeps 32 accumulator registers per working wave next to the tiles; with 9 x 16 tile registers in
+// every wave the compiler spilled 245 of them.  Here the tiles are dealt out unevenly: waves 0..3 (the pivot block's four
+// working waves) hold NA tiles each, waves 4..7 NB = nloc - NA (8 and 10 of 18 at K = 8).  Wave w and wave w + 4 share a
+// SIMD, so every SIMD still carries 18 quadrant updates per step: the update phase stays MFMA-bound.  While waves 0..3 run
+// the pivot block, waves 4..7 stage the panel (it used to be staged by everybody afterwards).  Same exchange protocol,
+// same arithmetic per tile as wg_spd_sweep_resident; results differ from it only through the pivot block's rounding.
+template <int K> __host__ __device__ constexpr int rs2_na() {
+    const int a = split_count(K, 0), b = split_count(K, 1);
+    return ((a > b ? a : b) * 4) / 9;
+}
+template <int K> __host__ __device__ constexpr int rs2_nb() {
+    const int a = split_count(K, 0), b = split_count(K, 1);
+    return (a > b ? a : b) - rs2_na<K>();
+}
+template <int K>
+__device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, float* Hdst,
+                                                         float* __restrict__ xb, unsigned int* __restrict__ fl,
+                                                         const unsigned int epoch, const int part, int* __restrict__ info,
+                                                         int* __restrict__ status_timeout, char* smem,
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr},
+                                                         unsigned long long* __restrict__ dbg = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
+    const int nloc = split_count(K, part);
+    float* Y = (float*)smem;
+    float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
+    float* WT = W + 64 * SPD_LS;
+    float* pcol = WT + 64 * SPD_LS;
+    int* flag = (int*)(pcol + PIV_LDS);
+    if (tid == 0) flag[0] = 0;
+
+    auto body = [&](auto pivot_tag) {
+        constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
+        constexpr int NS = PIVOT ? rs2_na<K>() : rs2_nb<K>(), FIRST = PIVOT ? 0 : rs2_na<K>();
+        // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
+        f32x16 T[NS];
+        int ti[NS], tj[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int l = FIRST + s;
+            int a, b;
+            rs_tile_of(l < nloc ? l : 0, K, part, a, b);
+            ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
+            tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
+            if (ti[s] >= 0) {
+                const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
+                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
+                    // upper-right quadrant of a diagonal tile := transpose of its lower-left one (see wg_spd_sweep_resident)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
+                } else {
+                    const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
+                }
+            }
+        }
+        if (lr.on) {
+            const float* xw = xb + (size_t)2 * K * LQP_BLK;
+            float rho = sqrtf(xw[0] + xw[1]) / (float)sqrt((double)lr.n);
+            rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
+            if (tid == 0 && lr.rho_out) *lr.rho_out = rho;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (quad_row(q, lh) == li && ti[s] * 64 + 32 * qi + li < lr.n) T[s][q] += rho;
+                }
+            }
+        }
+        unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
+        // publish the pivot tile and the panel tiles of step kk this wave holds (as soon as ITS quadrants have step kk-1's
+        // update: the store drain then overlaps with the wait for the slowest wave)
+        auto publish = [&](const int kk) {
+            float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i >= 0 && (i == kk || j == kk)) {
+                    const int slot = (i == kk && j == kk) ? K - 1 : (j == kk ? i - 1 : j);      // P_i: i > kk -> i - 1, i < kk -> i
+                    unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float tv = T[s][q];
+                        __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        };
+        publish(0);
+        for (int k = 0; k < K; ++k) {
+            if (dbg) dt0 = clock64();
+            float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // (also closes step k-1: every wave is done with the LDS panel)
+            if (tid == 0) {
+                __hip_atomic_store(fl + part, epoch + (unsigned int)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(fl + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + (unsigned int)k + 1u) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
+                        __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
+            // ---- pivot tile -> W, W^T by waves 0..3 | panel tiles -> LDS by waves 4..7 (slot s holds P_i = A_ik, i.e.
+            //      block (k, i) transposed when i < k) ----
+            wg_pivot_block_mfma<false, PIVOT>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
+            if constexpr (!PIVOT) {
+                const int tt = tid - 256, r0 = tt >> 3, c8 = (tt & 7) * 8;
+#pragma unroll
+                for (int s0 = 0; s0 < K - 1; ++s0) {
+                    float* Ys = Y + (size_t)s0 * 64 * SPD_LS;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int r = r0 + 32 * hf;
+                        const float* src = xbk + (size_t)s0 * LQP_BLK + r * 64 + c8;
+                        const V4<float> a = *(const V4<float>*)src, b = *(const V4<float>*)(src + 4);
+                        if (s0 >= k) {
+                            *(V4<float>*)(Ys + r * SPD_LS + c8) = a;
+                            *(V4<float>*)(Ys + r * SPD_LS + c8 + 4) = b;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { Ys[(c8 + e) * SPD_LS + r] = a.v[e]; Ys[(c8 + 4 + e) * SPD_LS + r] = b.v[e]; }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
+            // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves) ----
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
+                if (rb < 2 * (K - 1)) {
+                    float* Xp = Y + ((size_t)(rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
+                    const f32x16 a0 = spd_quadrant<1, false>(Xp, W);
+                    const f32x16 a1 = spd_quadrant(Xp, W + 32 * SPD_LS);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        Xp[quad_row(q, lh) * SPD_LS + li] = a0[q];
+                        Xp[quad_row(q, lh) * SPD_LS + 32 + li] = a1[q];
+                    }
+                }
+            }
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
+            // ---- every resident quadrant by its kind ----
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i < 0) continue;
+                if (i != k && j != k) {
+                    const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
+                    T[s] -= spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS, Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
+                } else if (i == k && j == k) {
+                    const f32x16 a = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
+                                               : spd_quadrant(WT, WT);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
+                } else if (j == k) {              // tile (i, k), i > k: Y_i W
+                    const float* Yi = Y + ((size_t)(i - 1) * 64 + 32 * qi) * SPD_LS;
+                    T[s] = qj == 1 ? spd_quadrant<1, true>(Yi, WT + 32 * SPD_LS) : spd_quadrant(Yi, WT);
+                } else {                          // tile (k, j), j < k: W^T Y_j^T
+                    const float* Yj = Y + ((size_t)j * 64 + 32 * qj) * SPD_LS;
+                    T[s] = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Yj) : spd_quadrant(WT, Yj);
+                }
+            }
+            if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
+            if (k + 1 < K) publish(k + 1);
+            if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
+        }
+        if (dbg && tid == 0)
+            for (int q = 0; q < 6; ++q) dbg[q] = dbt[q];
+        // ---- the finished tiles to their home blocks ----
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (ti[s] >= 0) {
+                float* C = Hdst + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
+            }
+        }
+    };
+    if (w < 4) body(std::true_type());
+    else body(std::false_type());
+    __syncthreads();
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
 
