@@ -247,6 +247,23 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
     }
     return acc;
 }
+// the same product with the lane parts of the operand addresses made by the caller: xa = X + (l&31) * SPD_LS + kb,
+// zb = Z + (l&31) * SPD_LS + kb, kb = 32 (l>>5) for the full k range, 16 (l>>5) [+ 32: upper half] with HALF
+template <int HALF = 0>
+__device__ __forceinline__ f32x16 spd_quadrant_lp(const float* __restrict__ xa, const float* __restrict__ zb) {
+    constexpr int KL = HALF ? 16 : 32;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KL / 4; ++t) {
+        const V4<float> a = *(const V4<float>*)(xa + 4 * t);
+        const V4<float> b = *(const V4<float>*)(zb + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[e], b.v[e], acc, 0, 0, 0);
+    }
+    return acc;
+}
 // accumulator register q of lane l is element (row = (q&3) + 8 (q>>2) + 4 (l>>5), col = l&31) of the quadrant
 __device__ __forceinline__ int quad_row(int q, int lh) { return (q & 3) + 8 * (q >> 2) + 4 * lh; }
 
@@ -1882,22 +1899,30 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             // ---- pivot tile -> W, W^T by waves 0..3 | panel tiles -> LDS by waves 4..7 (slot s holds P_i = A_ik, i.e.
             //      block (k, i) transposed when i < k) ----
             wg_pivot_block_mfma<false, PIVOT>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
+            // (lane parts of every LDS / global address of this step, opaque: as loop invariants of the step loop they
+            //  would be formed once, held in registers -- one per distinct address -- and spilled with the tiles)
+            int li_s = li, lh_s = lh, tid_s = tid;
+            asm volatile("" : "+v"(li_s), "+v"(lh_s), "+v"(tid_s));
             if constexpr (!PIVOT) {
-                const int tt = tid - 256, r0 = tt >> 3, c8 = (tt & 7) * 8;
+                const int tt = tid_s - 256, r0 = tt >> 3, c8 = (tt & 7) * 8;
+                const float* const src_l = xbk + r0 * 64 + c8;
+                float* const yrow_l = Y + r0 * SPD_LS + c8;            // row-major destination
+                float* const ycol_l = Y + c8 * SPD_LS + r0;            // transposed destination
 #pragma unroll
                 for (int s0 = 0; s0 < K - 1; ++s0) {
-                    float* Ys = Y + (size_t)s0 * 64 * SPD_LS;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
-                        const int r = r0 + 32 * hf;
-                        const float* src = xbk + (size_t)s0 * LQP_BLK + r * 64 + c8;
+                        const float* src = src_l + s0 * LQP_BLK + 32 * hf * 64;
                         const V4<float> a = *(const V4<float>*)src, b = *(const V4<float>*)(src + 4);
                         if (s0 >= k) {
-                            *(V4<float>*)(Ys + r * SPD_LS + c8) = a;
-                            *(V4<float>*)(Ys + r * SPD_LS + c8 + 4) = b;
+                            *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS) = a;
+                            *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS + 4) = b;
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { Ys[(c8 + e) * SPD_LS + r] = a.v[e]; Ys[(c8 + 4 + e) * SPD_LS + r] = b.v[e]; }
+                            for (int e = 0; e < 4; ++e) {
+                                ycol_l[(s0 * 64 + e) * SPD_LS + 32 * hf] = a.v[e];
+                                ycol_l[(s0 * 64 + 4 + e) * SPD_LS + 32 * hf] = b.v[e];
+                            }
                         }
                     }
                 }
@@ -1905,41 +1930,47 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             __syncthreads();
             if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
             // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves) ----
+            constexpr int WOFF = (K - 1) * 64 * SPD_LS, WTOFF = WOFF + 64 * SPD_LS;      // W, W^T behind the panel
+            const float* const yF = Y + li_s * SPD_LS + 32 * lh_s;     // operand row li at the lane's k range (full)
+            const float* const yH = Y + li_s * SPD_LS + 16 * lh_s;     // ... (half k range; + 32: the upper half)
+            float* const yC = Y + (4 * lh_s) * SPD_LS + li_s;          // element (quad_row(q, lh), li) at + ((q&3) + 8 (q>>2)) * SPD_LS
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
                 if (rb < 2 * (K - 1)) {
-                    float* Xp = Y + ((size_t)(rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
-                    const f32x16 a0 = spd_quadrant<1, false>(Xp, W);
-                    const f32x16 a1 = spd_quadrant(Xp, W + 32 * SPD_LS);
+                    const int xoff = ((rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
+                    const f32x16 a0 = spd_quadrant_lp<1>(yH + xoff, yH + WOFF);
+                    const f32x16 a1 = spd_quadrant_lp<0>(yF + xoff, yF + WOFF + 32 * SPD_LS);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        Xp[quad_row(q, lh) * SPD_LS + li] = a0[q];
-                        Xp[quad_row(q, lh) * SPD_LS + 32 + li] = a1[q];
+                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS] = a0[q];
+                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS + 32] = a1[q];
                     }
                 }
             }
             __syncthreads();
             if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
             // ---- every resident quadrant by its kind ----
+            const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int i = ti[s], j = tj[s];
                 if (i < 0) continue;
                 if (i != k && j != k) {
                     const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
-                    T[s] -= spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS, Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
-                } else if (i == k && j == k) {
-                    const f32x16 a = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
-                                               : spd_quadrant(WT, WT);
+                    T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
+                } else if (i == k && j == k) {    // (W^T is upper triangular: rows >= 32 only see k >= 32 -- same halves,
+                                                  //  hence the same summation order and bits, as the multi-launch sweep)
+                    const f32x16 a = (qi | qj) ? spd_quadrant_lp<1>(yH + 32 + WTOFF + oi, yH + 32 + WTOFF + oj)
+                                               : spd_quadrant_lp<0>(yF + WTOFF, yF + WTOFF);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
                 } else if (j == k) {              // tile (i, k), i > k: Y_i W
-                    const float* Yi = Y + ((size_t)(i - 1) * 64 + 32 * qi) * SPD_LS;
-                    T[s] = qj == 1 ? spd_quadrant<1, true>(Yi, WT + 32 * SPD_LS) : spd_quadrant(Yi, WT);
+                    const int yo = (i - 1) * 64 * SPD_LS + oi;
+                    T[s] = qj == 1 ? spd_quadrant_lp<1>(yH + 32 + yo, yH + 32 + WTOFF + 32 * SPD_LS) : spd_quadrant_lp<0>(yF + yo, yF + WTOFF);
                 } else {                          // tile (k, j), j < k: W^T Y_j^T
-                    const float* Yj = Y + ((size_t)j * 64 + 32 * qj) * SPD_LS;
-                    T[s] = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Yj) : spd_quadrant(WT, Yj);
+                    const int yo = j * 64 * SPD_LS + oj;
+                    T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
                 }
             }
             if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
