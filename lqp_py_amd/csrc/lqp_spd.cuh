@@ -507,6 +507,12 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
 #ifndef LQP_PIV_MFMA
 #define LQP_PIV_MFMA 1
 #endif
+#ifdef LQP_PIV_STAMPS          // timing builds of tools/microbench only: cycle stamps of the working waves of workgroup 0
+__device__ unsigned long long* g_piv_stamps = nullptr;
+#define PIV_STAMP(slot) do { if (g_piv_stamps && blockIdx.x == 0 && lane == 0) g_piv_stamps[(slot)] = clock64(); } while (0)
+#else
+#define PIV_STAMP(slot) do { } while (0)
+#endif
 __device__ __forceinline__ float piv_readlane(const float v, const int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
@@ -547,6 +553,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
     }
     if constexpr (!ROLES) return;
     if (w > 3) return;
+    PIV_STAMP(w * 32);
     const float* const Tl = GSYNC ? src_blk : W;
     constexpr int ld = GSYNC ? 64 : SPD_LS;
     // Lane-dependent address parts, made opaque once per call: everything below is base + compile-time offset (the
@@ -561,8 +568,11 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
     float* const w_o = W + (4 * lh_o) * SPD_LS + li_o;                // W[8 a + 4 lh + e][li] at + (8 a + e) * SPD_LS
     float* const wt_o = WT + li_o * SPD_LS + 4 * lh_o;                // W^T[li][8 a + 4 lh + e] at + 8 a + e
     float* const wtz_o = WT + (4 * lh_o) * SPD_LS + li_o;             // W^T[8 a + 4 lh + e][li] (the zero quadrant)
-    const float* const sv_o = svals + 4 * lh_o;
+    const float* const dg_o = xqueue + (4 * lh_o) * 65;               // pivot of row r: xqueue[r * 64 + r]
     constexpr auto qoff = [](const int q) { return (q & 3) + 8 * (q >> 2); };
+    // queue entry (panel P, column t): 64 floats.  Panels 8..15 start at row 32 of their area (68-float rows), so that rows
+    // 0..31 of W and W^T carry nothing of the lower half: quadrant (0,0) can be stored while the lower half is eliminated.
+    constexpr auto qidx = [](const int P, const int t) { return (P * 4 + t) * 64 + (P >= 8 ? 32 * SPD_LS - 2048 : 0); };
     auto mfma = [](const float a, const float b, const f32x16 c) -> f32x16 {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
     };
@@ -571,28 +581,41 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
     };
-    // the panel's column steps on its four columns x[] (lane = row): coefficient columns, transformed columns, scales
-    auto column_steps = [&](const int c0, float (&x)[4], float (&coef)[4], int& badc) {
-        int lane_p = lane;                     // (opaque per panel: the lane > c masks must neither be computed up front for the
-        asm volatile("" : "+v"(lane_p));       //  whole block nor be hoisted out of the CALLER's loop over pivot steps: 128
-                                               //  scalar registers held for the whole kernel)
-        float sreg[4];
+    // The panel's column steps on its four columns x[] (lane = row).  The dependent chain of a column is
+    //   v_readlane (pivot) -> v_rcp -> v_mul (coefficient column) -> v_fma (next column) -> v_readlane (next pivot).
+    // The chain wave is bound by instruction issue (one wave: a VALU instruction every 4-5 cycles, a v_readlane ~12), so
+    // it carries nothing else: the mask that zeroes the coefficients of the rows above the pivot (the columns' own entries
+    // there are dead, only the augmented part needs it), the scales 1 / sqrt(pivot) and the sign check of the pivots are
+    // left to the consumer waves, which find the pivots on the diagonal of the pivot-row queue.
+    // cu: the coefficient columns WITHOUT the mask.
+    auto column_steps = [&](const int c0, float (&x)[4], float (&cu)[4], auto&& after_second) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int c = c0 + t;
-            const float d = piv_readlane(x[t], c);
-            badc = (!(d > 0.f) && badc == 0) ? c + 1 : badc;         // (only recorded: see wg_pivot_block)
-            const float s = __builtin_amdgcn_rsqf(d);
-            coef[t] = lane_p > c ? x[t] * s * s : 0.f;
+            cu[t] = x[t] * __builtin_amdgcn_rcpf(piv_readlane(x[t], c));
 #pragma unroll
-            for (int t2 = t + 1; t2 < 4; ++t2) x[t2] = __builtin_fmaf(-coef[t], piv_readlane(x[t2], c), x[t2]);
-            sreg[t] = s;
+            for (int t2 = t + 1; t2 < 4; ++t2) x[t2] = __builtin_fmaf(-cu[t], piv_readlane(x[t2], c), x[t2]);
+            // (columns 0, 1 and their pivot rows are final: their half of the rank-4 update goes to the matrix cores now and
+            //  runs under the last two column steps; issued with the other half, the second instruction on an accumulator
+            //  would stall the wave until the first has left the pipe)
+            if (t == 1) after_second();
             __builtin_amdgcn_sched_barrier(0);
         }
-        float sv = sreg[0];
+    };
+    // Rows r0 .. r0+3 of the Schur complement THROUGH the panel just eliminated.  y[] comes out of the accumulators, which
+    // hold the panels before and the first half (columns 0, 1: issued under the column steps) of this one; the second
+    // half is applied here on the vector unit: y_t -= sum_{k = 2, 3} coef_k[r0 + t] * (pivot row k) -- the same update
+    // reaches the accumulators through the matrix instructions issued next, but the chain need not wait for them.  The 8
+    // coefficients come back from the queue just written, four per broadcast read (a v_readlane costs ~12 issue cycles).
+    // Same products, same order as the matrix instructions' fma chain.
+    auto look_ahead = [&](const int P, const int r0, float (&y)[4], const float (&x)[4]) {
+        V4<float> c4[2];
 #pragma unroll
-        for (int t = 1; t < 4; ++t) sv = lane_p == t ? sreg[t] : sv;
-        if (lane_p < 4) svals[c0 + lane_p] = sv;
+        for (int k = 0; k < 2; ++k) c4[k] = *(const V4<float>*)(queue + qidx(P, 2 + k) + r0);      // (uniform address)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(-c4[k].v[t], x[2 + k], y[t]);
     };
     int pub = rbase;                            // (a running count, opaque: sixteen constants in sixteen registers otherwise)
     asm volatile("" : "+v"(pub));
@@ -611,41 +634,56 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             S01[q] = tile_o[qoff(q) * ld + 32];
         }
         if constexpr (!GSYNC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the pivot-row queue overwrites these rows)
-        int badc = 0;
+        // rows c0 .. c0+3 of S as lane vectors (lane = column; by symmetry = the panel's columns, lane = row)
+        float x[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { float hi; piv_pair(S00[t], S01[t], x[t], hi); }
+        PIV_STAMP(1);
 #pragma unroll
         for (int P = 0; P < 8; ++P) {
-            const int c0 = 4 * P, q0 = 4 * (c0 / 8), LH = (c0 / 4) & 1;
+            const int c0 = 4 * P;
             __builtin_amdgcn_sched_barrier(0);                       // (one scheduling region per panel)
-            // rows c0 .. c0+3 of S as lane vectors (lane = column; by symmetry = the panel's columns, lane = row)
-            float x[4], coef[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float lo, hi;
-                piv_pair(S00[q0 + t], S01[q0 + t], lo, hi);
-                x[t] = LH ? hi : lo;
-            }
+            float cu[4];
             if (P > 0) publish(P);
-            column_steps(c0, x, coef, badc);
+            column_steps(c0, x, cu, [&]() {
+                if (P < 7) {
+                    float a0_01, b0_01, b1_01, unused;
+                    piv_pair(-cu[0], -cu[1], a0_01, unused);
+                    piv_pair(x[0], x[1], b0_01, b1_01);
+                    S00 = mfma(a0_01, b0_01, S00);
+                    S01 = mfma(a0_01, b1_01, S01);
+                }
+            });
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                qcoef[(P * 4 + t) * 64] = coef[t];
-                qrow[(P * 4 + t) * 64] = x[t];
+                qcoef[qidx(P, t)] = cu[t];
+                qrow[qidx(P, t)] = x[t];
             }
             if (P < 7) {
-                // rank-4 update of the rows still to come: A = -(coefficient columns), B = the pivot rows
-                float a0_01, a0_23, b0_01, b1_01, b0_23, b1_23, unused;
-                piv_pair(-coef[0], -coef[1], a0_01, unused);
-                piv_pair(-coef[2], -coef[3], a0_23, unused);
-                piv_pair(x[0], x[1], b0_01, b1_01);
+                // the next panel's rows, ahead of the matrix instructions
+                const int n0 = c0 + 4, q0 = 4 * (n0 / 8), LH = (n0 / 4) & 1;
+                float y[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float lo, hi;
+                    piv_pair(S00[q0 + t], S01[q0 + t], lo, hi);
+                    y[t] = LH ? hi : lo;
+                }
+                look_ahead(P, n0, y, x);
+                // the other half of the rank-4 update of the rows still to come: A = -(coefficient columns), B = the pivot
+                // rows (the rows above the pivots get updates too -- cu is not masked -- but nobody reads them again)
+                float a0_23, b0_23, b1_23, unused;
+                piv_pair(-cu[2], -cu[3], a0_23, unused);
                 piv_pair(x[2], x[3], b0_23, b1_23);
-                S00 = mfma(a0_01, b0_01, S00);
-                S01 = mfma(a0_01, b1_01, S01);
                 S00 = mfma(a0_23, b0_23, S00);
                 S01 = mfma(a0_23, b1_23, S01);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x[t] = y[t];
             }
+            PIV_STAMP(2 + P);
         }
         publish(8);
-        if (badc != 0 && lane == 0 && flag[0] == 0) flag[0] = kbase + badc;
+        PIV_STAMP(20);
         return;
     }
     if (w == 3) {
@@ -659,7 +697,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             wait_published(rbase + P + 1);
             float cf[4], xr[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { cf[t] = qcoef[(P * 4 + t) * 64]; xr[t] = qrow[(P * 4 + t) * 64]; }
+            for (int t = 0; t < 4; ++t) { cf[t] = qcoef[qidx(P, t)]; xr[t] = qrow[qidx(P, t)]; }
             float a1_01, a1_23, b1_01, b1_23, unused;
             piv_pair(-cf[0], -cf[1], unused, a1_01);
             piv_pair(-cf[2], -cf[3], unused, a1_23);
@@ -668,34 +706,51 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             S11 = mfma(a1_01, b1_01, S11);
             S11 = mfma(a1_23, b1_23, S11);
         }
-        int badc = 0;
         pub += 8;
+        // rows 32 .. 35 (lanes 0-31: columns the elimination has left; the consumers' mask zeroes what they produce)
+        float x[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { float hi; piv_pair(S11[t], S11[t], x[t], hi); }
+        PIV_STAMP(96 + 1);
 #pragma unroll
         for (int P = 8; P < 16; ++P) {
-            const int c0 = 4 * P, rr = c0 - 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
+            const int c0 = 4 * P;
             __builtin_amdgcn_sched_barrier(0);
-            float x[4], coef[4];
+            float cu[4];
+            if (P > 8) publish(P);
+            column_steps(c0, x, cu, [&]() {
+                if (P < 15) {
+                    float a1_01, b1_01, unused;
+                    piv_pair(-cu[0], -cu[1], unused, a1_01);
+                    piv_pair(x[0], x[1], unused, b1_01);
+                    S11 = mfma(a1_01, b1_01, S11);
+                }
+            });
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (LH) x[t] = S11[q0 + t];                        // (lanes 0-31: columns the elimination has left)
-                else { float lo, hi; piv_pair(S11[q0 + t], S11[q0 + t], lo, hi); x[t] = lo; }
+                qcoef[qidx(P, t)] = cu[t];
+                qrow[qidx(P, t)] = x[t];
             }
-            if (P > 8) publish(P);
-            column_steps(c0, x, coef, badc);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) qcoef[(P * 4 + t) * 64] = coef[t];
             if (P < 15) {
-                float a1_01, a1_23, b1_01, b1_23, unused;
-                piv_pair(-coef[0], -coef[1], unused, a1_01);
-                piv_pair(-coef[2], -coef[3], unused, a1_23);
-                piv_pair(x[0], x[1], unused, b1_01);
+                const int n0 = c0 + 4, rr = n0 - 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
+                float y[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (LH) y[t] = S11[q0 + t];
+                    else { float hi; piv_pair(S11[q0 + t], S11[q0 + t], y[t], hi); }
+                }
+                look_ahead(P, n0, y, x);
+                float a1_23, b1_23, unused;
+                piv_pair(-cu[2], -cu[3], unused, a1_23);
                 piv_pair(x[2], x[3], unused, b1_23);
-                S11 = mfma(a1_01, b1_01, S11);
                 S11 = mfma(a1_23, b1_23, S11);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x[t] = y[t];
             }
+            PIV_STAMP(96 + 2 + (P - 8));
         }
         publish(16);
-        if (badc != 0 && lane == 0 && flag[0] == 0) flag[0] = kbase + badc;
+        PIV_STAMP(96 + 20);
         return;
     }
     // ================= waves 1, 2: the augmented part =================
@@ -712,8 +767,15 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             __builtin_amdgcn_sched_barrier(0);
             wait_published(rbase + P + 1);
             float cf[4];
+            {
+                int lane_p = lane_o;               // (opaque per panel: see the lane bases above)
+                asm volatile("" : "+v"(lane_p));
 #pragma unroll
-            for (int t = 0; t < 4; ++t) cf[t] = qcoef[(P * 4 + t) * 64];
+                for (int t = 0; t < 4; ++t) {      // the rows above a pivot take no part in its elimination
+                    const float c = qcoef[qidx(P, t)];
+                    cf[t] = lane_p > c0 + t ? c : 0.f;
+                }
+            }
             // the panel's 4x4 unit lower triangle: coefficient of row c0+k at column step j
             const float t10 = piv_readlane(cf[0], c0 + 1), t20 = piv_readlane(cf[0], c0 + 2), t30 = piv_readlane(cf[0], c0 + 3);
             const float t21 = piv_readlane(cf[1], c0 + 2), t31 = piv_readlane(cf[1], c0 + 3), t32 = piv_readlane(cf[2], c0 + 3);
@@ -745,8 +807,25 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        wait_published(rbase + 16);                              // (all scales are in svals)
-        // the queue sits in the W^T area: both consumers must be through with it before anybody writes W^T
+        wait_published(rbase + 16);
+        // row scales 1 / sqrt(pivot): pivot r sits on the diagonal of the pivot-row queue (entry r of row r).  They are
+        // read before anybody's final stores (the queue lives in the W area); a pivot that is not positive (the matrix is
+        // not positive definite) is recorded like in wg_pivot_block.
+        float sc[CB0 ? 32 : 16];
+        int bad = 0;
+#pragma unroll
+        for (int u = 0; u < (CB0 ? 32 : 16); ++u) {
+            const int rowc = (CB0 ? 0 : 32) + 32 * (u >> 4) + 8 * ((u & 15) >> 2) + (u & 3);      // row = rowc + 4 lh
+            const float d = dg_o[rowc * 65 + (rowc >= 32 ? 32 * SPD_LS - 2048 : 0)];
+            bad = (!(d > 0.f) && bad == 0) ? rowc + 4 * lh_o + 1 : bad;
+            sc[u] = __builtin_amdgcn_rsqf(d);
+        }
+        {
+            const unsigned long long mb = __ballot(bad != 0);
+            if (mb != 0ull && lane == 0 && flag[0] == 0) flag[0] = kbase + __builtin_amdgcn_readlane(bad, (int)__builtin_ctzll(mb));
+        }
+        // the queues sit in the W and W^T areas: both consumers must be through with them before anybody writes there
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(words + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < dbase + 2)
             __builtin_amdgcn_s_sleep(1);
@@ -755,24 +834,25 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         return;
 #endif
         // W = (row scale) x (unit lower triangle), zero above the diagonal; W^T
-        auto store_quadrant = [&](const f32x16& v, const int I, const int J) {
+        auto store_quadrant = [&](const f32x16& v, const int I, const int J, const float* scq) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const V4<float> sv = *(const V4<float>*)(sv_o + 32 * I + 8 * a);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // (above the diagonal the unit triangle is exactly zero: 0 - coef * 0 at every step, no select needed)
-                    const float val = v[4 * a + e] * sv.v[e];
+                    const float val = v[4 * a + e] * scq[4 * a + e];
                     w_o[(32 * I + 8 * a + e) * SPD_LS + 32 * J] = val;
                     wt_o[(32 * J) * SPD_LS + 32 * I + 8 * a + e] = val;
                 }
             }
         };
-        if (CB0) {
-            store_quadrant(Wa, 0, 0);
-            store_quadrant(Wb, 1, 0);
+        PIV_STAMP(w * 32 + 1);
+        if constexpr (CB0) {
+            store_quadrant(Wa, 0, 0, sc);
+            store_quadrant(Wb, 1, 0, sc + 16);
+            PIV_STAMP(w * 32 + 2);
         } else {
-            store_quadrant(Wa, 1, 1);
+            store_quadrant(Wa, 1, 1, sc);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {                       // quadrant (0,1) of W = quadrant (1,0) of W^T = 0
                 w_o[qoff(q) * SPD_LS + 32] = 0.f;
@@ -818,7 +898,29 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
 
     for (int k = (NP == 1 ? 0 : k0); k < (NP == 1 ? K : k1); ++k) {
         if (dbg) t0 = clock64();
-        // ---- panel blocks A_ik (i != k) into registers; they land while the pivot block is factorised ----
+        // ---- pivot block -> W, W^T | panel blocks A_ik (i != k) -> LDS: slot s holds P_i = A_ik, i.e. block (k, i)
+        //      transposed when i < k ----
+        if constexpr (NP == 1 && LQP_PIV_MFMA != 0) {
+            // the matrix-core pivot block works on waves 0..3; the other twelve stage the panel meanwhile (nothing is held
+            // in registers across the pivot block: its accumulators need them)
+            wg_pivot<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+            if (w >= 4) {
+                for (int v0 = tid - 256; v0 < 1024 * (K - 1); v0 += LQP_NT - 256) {
+                    const int s = v0 >> 10, v = v0 & 1023, rr = v >> 4, cc = v & 15;
+                    const int i = s < k ? s : s + 1;
+                    const int blk = i > k ? sym_idx(i, k, K) : sym_idx(k, i, K);
+                    const V4<float> pv = *(const V4<float>*)(Hs + (size_t)blk * LQP_BLK + v * 4);
+                    float* Ys = Y + (size_t)s * 64 * SPD_LS;
+                    if (s >= k) {
+                        *(V4<float>*)(Ys + rr * SPD_LS + cc * 4) = pv;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Ys[(cc * 4 + e) * SPD_LS + rr] = pv.v[e];
+                    }
+                }
+            }
+        } else {
+        // (panel blocks into registers; they land while the pivot block is factorised)
         V4<float> preg[SPD_MAXK - 1];
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s) {
@@ -833,7 +935,6 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
         } else {      // W, W^T of this pivot block were prepared by the previous launch (lookahead below)
             for (int i = tid * 4; i < 2 * 64 * SPD_LS; i += LQP_NT * 4) *(V4<float>*)(W + i) = *(const V4<float>*)(Wg + i);
         }
-        // ---- panel to LDS: slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k ----
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s) {
             if (s < K - 1) {
@@ -845,6 +946,7 @@ __device__ __forceinline__ void wg_spd_sweep(float* __restrict__ Hs, const int K
                     for (int e = 0; e < 4; ++e) Ys[(cq * 4 + e) * SPD_LS + r] = preg[s].v[e];
                 }
             }
+        }
         }
         __syncthreads();
         if (dbg) { const unsigned long long t = clock64(); tp += t - t0; t0 = t; }
@@ -2014,6 +2116,17 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
     if (tid == 0) flag[0] = 0;
     for (int k = 0; k < K; ++k) {
         const int np = K - 1 - k;                           // panel blocks below the pivot: slot s <-> row k+1+s
+#if LQP_PIV_MFMA
+        // (matrix-core pivot block on waves 0..3; the other twelve stage the panel meanwhile)
+        wg_pivot<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        if (w >= 4) {
+            for (int v0 = tid - 256; v0 < 1024 * np; v0 += LQP_NT - 256) {
+                const int s = v0 >> 10, v = v0 & 1023;
+                *(V4<float>*)(Y + ((size_t)s * 64 + (v >> 4)) * SPD_LS + (v & 15) * 4) =
+                    *(const V4<float>*)(Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK + v * 4);
+            }
+        }
+#else
         V4<float> preg[SPD_MAXK - 1];
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s)
@@ -2022,6 +2135,7 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
 #pragma unroll
         for (int s = 0; s < SPD_MAXK - 1; ++s)
             if (s < np) *(V4<float>*)(Y + ((size_t)s * 64 + r) * SPD_LS + cq * 4) = preg[s];
+#endif
         __syncthreads();
         // the pre-inverted diagonal block
         *(V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4) = *(const V4<float>*)(W + r * SPD_LS + cq * 4);

@@ -33,6 +33,12 @@ __global__ __launch_bounds__(BENCH_NT) void k_piv(const float* src, float* out, 
 }
 int main() {
     const int B = 256;
+#ifdef LQP_PIV_STAMPS
+    {
+        unsigned long long* st; (void)hipMalloc(&st, 128 * 8); (void)hipMemset(st, 0, 128 * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_piv_stamps), &st, sizeof(st));
+    }
+#endif
     std::vector<float> h(B * 4096);
     for (int b = 0; b < B; ++b) for (int i = 0; i < 64; ++i) for (int j = 0; j <= i; ++j) {
         float v = 0.3f * std::cos(0.37f * (i + 1) * (j + 1) + b) / (1.f + 0.1f * std::abs(i - j));
@@ -88,5 +94,19 @@ int main() {
         printf("%s: max |W - L^-1 (double)| = %.3g, max |W^T - W'| = %.3g, max above the diagonal = %.3g, W[0][0]=%g W[63][0]=%g W[63][63]=%g\n",
                mf ? "mfma" : "valu", emax, etr, upper, r[0], r[63 * 64], r[63 * 64 + 63]);
     }
+#ifdef LQP_PIV_STAMPS
+    {
+        unsigned long long* st; (void)hipMemcpyFromSymbol(&st, HIP_SYMBOL(g_piv_stamps), sizeof(st));
+        unsigned long long h2[128]; (void)hipMemcpy(h2, st, sizeof(h2), hipMemcpyDeviceToHost);
+        const unsigned long long t0 = h2[0];
+        printf("stamps (cycles since wave 0 entered its role; last call of workgroup 0)\n wave0:");
+        for (int i = 0; i <= 9; ++i) printf(" %lld", (long long)(h2[i] - t0));
+        printf(" | end %lld", (long long)(h2[20] - t0));
+        printf("\n wave3:"); for (int i = 0; i <= 9; ++i) printf(" %lld", (long long)(h2[96 + i] - t0));
+        printf(" | end %lld", (long long)(h2[96 + 20] - t0));
+        printf("\n wave1: enter %lld stores-begin %lld stores-end %lld; wave2: enter %lld stores-begin %lld\n", (long long)(h2[32] - t0),
+               (long long)(h2[33] - t0), (long long)(h2[34] - t0), (long long)(h2[64] - t0), (long long)(h2[65] - t0));
+    }
+#endif
     return 0;
 }
