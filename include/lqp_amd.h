@@ -135,6 +135,9 @@ int lqp_profile_get(double* total_ms, long long* launches, int n);
 /* debug: device buffer of 4 uint64 per problem; every LU launch then writes its shader-clock
  * cycles spent in (panel, swaps+U12, trailing update, total).  NULL switches it off. */
 void lqp_debug_set_lu_counters(void* device_buf);
+/* test aid: occupies `blocks` workgroups (512 threads, `lds_bytes` of LDS each) for `usec` microseconds on `stream`:
+ * the co-residency tests run the two-workgroup schedules of the forward solve beside it. */
+int lqp_debug_spin(void* stream, int blocks, int usec, int lds_bytes);
 
 /* ---- forward ADMM solve ------------------------------------------------
  * Replaces torch_solve_box_qp (lqp_py/solve_box_qp_admm_torch.py:108-333):

@@ -297,8 +297,19 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd_big_split = env_int("LQP_SPD_SPLIT", spd_big_split ? 1 : 0) != 0;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
-    const bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK + 2 &&
-                              env_int("LQP_SPD_RESIDENT", 1) != 0;
+    bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK + 2 &&
+                        env_int("LQP_SPD_RESIDENT", 1) != 0;
+    if (spd_resident) {
+        // its two workgroups per matrix wait for each other inside the launch: every one of the 2 B workgroups must be
+        // resident -- ask the occupancy calculator for THIS kernel (block size, registers, LDS), not just the CU count
+        auto rfn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6> : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
+        int dev_ = 0, cus_ = 0, per_cu = 0;
+        const int rlds = spd_lds_bytes(P.Ks);
+        spd_resident = ensure_lds((const void*)rfn, rlds) == LQP_OK && hipGetDevice(&dev_) == hipSuccess &&
+                       hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rfn, RS_NT, rlds) == hipSuccess &&
+                       per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
+    }
     // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
     P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && env_int("LQP_RHO_LATE", 1)) ? 1 : 0;
@@ -910,6 +921,22 @@ void lqp_profile_reset(void) {
 }
 
 void lqp_debug_set_lu_counters(void* device_buf) { g_lu_dbg = (unsigned long long*)device_buf; }
+
+// test aid: occupy `blocks` workgroups of 512 threads (one CU each when LDS-bound kernels run next to it) for `usec`
+// microseconds on `stream` -- the co-residency tests run the two-workgroup schedules beside it
+__global__ __launch_bounds__(512) void k_debug_spin(const unsigned long long ticks) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    smem[threadIdx.x] = 0;                  // (touch the LDS so that the allocation is real)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int lqp_debug_spin(void* stream, int blocks, int usec, int lds_bytes) {
+    if (blocks < 1 || usec < 0 || usec > 2000000 || lds_bytes < 512) return LQP_ERR_INVALID;
+    const int rc = ensure_lds((const void*)k_debug_spin, lds_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream, (unsigned long long)usec * 100ull);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
 
 int lqp_profile_classes(void) { return PC_COUNT; }
 

@@ -133,3 +133,63 @@ def test_strict_stop_shares_the_ratio_trigger(tmp_path):
     assert torch.equal(outs[0]["x_all"], outs[1]["x_all"])
     e = float((outs[0]["x_all"] - ref["x"]).abs().max())
     assert e < 5e-5 * max(1.0, float(ref["x"].abs().max())), e
+
+
+def _nccl_one_rank_worker(port, out_path):
+    """child process: a process group of ONE rank over "nccl" (= RCCL) on the only GPU of the box; the sharded layer is
+    told to issue its collectives all the same (lqp_py_amd.dist._ALWAYS), so the RCCL initialisation, the device-tensor
+    all-reduce of the bound flags, all_gather_into_tensor and the pipelined (sync=False) path run for real"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import lqp_py_amd as L
+    import lqp_py_amd.dist as D
+    D._ALWAYS[0] = True
+    n, B = 96, 6
+    Q, p, A, b, lb, ub = (t.to(dev) for t in O.create_qp_data(n, B, seed=13))
+    out = {}
+    for sync in (True, False):
+        ctl = L.box_qp_control(sync=sync, **TOL)
+        layer = D.ShardedBoxQP(ctl, shard_sizes=[B])
+        Qg = Q.clone().requires_grad_(True)
+        pg = p.clone().requires_grad_(True)
+        for _ in range(3):                                   # steady state of a pipelined loop: nothing waits for the host
+            x_local, x_all = layer(Qg, pg, A, b, lb.clone(), ub.clone())
+        x_local.backward(torch.ones_like(x_local))
+        L.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(x_all, x_local.detach())
+        out[f"x_{int(sync)}"] = x_all.cpu()
+        out[f"dp_{int(sync)}"] = pg.grad.cpu()
+    # unequal-shard code path (sizes exchanged on the device) and the strict stop's all-reduce hook
+    ctl = L.box_qp_control(dist_strict_stop=True, **TOL)
+    x_local, x_all = D.ShardedBoxQP(ctl)(Q, p, A, b, lb, ub)
+    torch.cuda.synchronize()
+    out["x_strict"] = x_all.cpu()
+    out["backend"] = dist.get_backend()
+    torch.save(out, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_nccl_group_drives_the_sharded_layer(tmp_path):
+    """The production backend on the hardware at hand: RCCL with a world of one rank (a one-GPU box cannot form a larger
+    one).  Every collective of lqp_py_amd.dist is issued on device tensors; results equal the CPU oracle's."""
+    out_path = os.path.join(tmp_path, "nccl1.pt")
+    ctx = mp.get_context("spawn")
+    pr = ctx.Process(target=_nccl_one_rank_worker, args=(_free_port(), out_path))
+    pr.start()
+    pr.join(300)
+    assert pr.exitcode == 0, f"child exit code {pr.exitcode}"
+    out = torch.load(out_path)
+    assert out["backend"] == "nccl"
+    n, B = 96, 6
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=13)
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+    g = O.solve_box_qp_grad(torch.ones(B, n, 1), ref["x"], ref["u"], ref["lams"], ref["nus"], Q, A, lb, ub, ref["rho"])
+    for key in ("x_1", "x_0", "x_strict"):
+        assert float((out[key] - ref["x"]).abs().max()) < 2e-5, key
+    assert torch.equal(out["x_1"], out["x_0"])
+    for key in ("dp_1", "dp_0"):
+        assert float((out[key] - g[1]).abs().max()) < 2e-4 * max(1.0, float(g[1].abs().max())), key

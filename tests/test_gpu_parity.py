@@ -1083,3 +1083,38 @@ def test_pipelined_calls_verify_the_bound_assumption_late(dev):
     L.synchronize()
     assert err(x0, ref0["x"]) < 2e-5
     L.synchronize()
+
+
+def test_two_workgroup_schedules_beside_a_foreign_kernel(dev):
+    """B = 128, n = 500: the register-resident sweep and the two-workgroup loop hold 256 workgroups that wait for each
+    other inside a launch.  A kernel of another stream that sits on 48 CUs for 8 ms (its workgroups take the whole LDS of
+    a CU) delays some of them; the schedules must come through with the SAME bits and no timeout."""
+    lib = _lib.load()
+    B, n = 128, 500
+    inp = [t.to(dev) for t in O.create_qp_data(n, B, seed=1)]
+    ctl = L.box_qp_control(**TOL)
+    ref = L.torch_solve_box_qp(*inp, dict(ctl))
+    assert ref["_stats"]["loop_workgroups"] == 2 and ref["_stats"]["factor_launches"] == 3
+    side = torch.cuda.Stream(device=dev)
+    spin = lambda: _lib.check(lib.lqp_debug_spin(_lib.stream_ptr(dev), 48, 8000, 150 * 1024), "debug_spin")
+    # (1) the foreign kernel is there first: 48 of the 256 workgroups of every two-workgroup launch start 8 ms late
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(side):
+        spin()
+    sol = L.torch_solve_box_qp(*inp, dict(ctl))
+    torch.cuda.synchronize(dev)
+    assert sol["iter"] == ref["iter"]
+    for k in ("x", "z", "u", "lams", "nus"):
+        assert torch.equal(sol[k], ref[k]), k
+    # (2) it arrives while the (pipelined) solve is in flight
+    layer = L.SolveBoxQP(control=L.box_qp_control(sync=False, **TOL))
+    x0 = layer(*inp)
+    L.synchronize()
+    for _ in range(3):
+        x1 = layer(*inp)
+        with torch.cuda.stream(side):
+            spin()
+        x2 = layer(*inp)
+        torch.cuda.synchronize(dev)
+        L.synchronize()
+        assert torch.equal(x1, x0) and torch.equal(x2, x0) and torch.equal(x0, ref["x"])
