@@ -227,7 +227,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
     // granules of the two-workgroup loop (only ever used when 2 B workgroups fit the chip)
-    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + 1)) : nullptr;
+    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + 2)) : nullptr;
     L.bytes = c.off + kAlign;
     return L;
 }
@@ -297,7 +297,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd_big_split = env_int("LQP_SPD_SPLIT", spd_big_split ? 1 : 0) != 0;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
-    bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK + 2 &&
+    bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= rs3_xb_floats(P.Ks) &&
                         env_int("LQP_SPD_RESIDENT", 1) != 0;
     if (spd_resident) {
         // its two workgroups per matrix wait for each other inside the launch: every one of the 2 B workgroups must be

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * (2 * 2 * SPD_MAXK * LQP_NB);
         for (int i = tid; i < 2 * 2 * SPD_MAXK * LQP_NB; i += LQP_NT) xq[i] = 0ull;
-        if (tid == 0) P.xchg[(size_t)P.B * (2 * 2 * SPD_MAXK * LQP_NB) + b] = 0ull;      // step flags of the resident sweep
+        if (tid < 2) P.xchg[(size_t)P.B * (2 * 2 * SPD_MAXK * LQP_NB) + 2 * b + tid] = 0ull;      // step flags of the resident sweep (4 words)
     }
 
     // the small vectors are requested now and used after the pass over Q (n <= 1024: one element per thread; a load
@@ -803,13 +803,17 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD
-    unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 2;
+    unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 4;
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
     RsLateRho lr;
     lr.on = (gate == nullptr && P.rho_late) ? 1 : 0;
     lr.n = P.n; lr.rho_min = P.rho_min; lr.rho_max = P.rho_max;
     lr.rho_out = part == 0 ? P.scal + (size_t)b * SC_WORDS + SC_RHO : nullptr;
-#if LQP_PIV_MFMA && LQP_RS_V2
+#if LQP_PIV_MFMA && LQP_RS_V2 == 3
+    wg_spd_sweep_resident_v3<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
+                                 P.info + b, P.status + ST_TIMEOUT, smem, lr,
+                                 (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
+#elif LQP_PIV_MFMA && LQP_RS_V2
     wg_spd_sweep_resident_v2<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
                                  (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);

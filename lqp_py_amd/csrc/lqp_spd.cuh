@@ -533,7 +533,8 @@ __device__ __forceinline__ void piv_pair(float a, float b, float& lo, float& hi)
 // ROLES = false: this instantiation is only ever executed by waves 4.. of the workgroup (they stage the tile, join the
 //                barrier and leave): the role code is not even compiled in -- a caller that has already branched on the
 //                wave number keeps the roles' registers out of its other branch this way.
-template <bool GSYNC = false, bool ROLES = true>
+// IN_W (with GSYNC): the tile already sits in the W area (row stride SPD_LS), src_blk is not read.
+template <bool GSYNC = false, bool ROLES = true, bool IN_W = false>
 __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ src_blk, float* __restrict__ W,
                                                     float* __restrict__ WT, float* __restrict__ pcol,
                                                     int* __restrict__ flag, const int kbase,
@@ -554,8 +555,8 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
     if constexpr (!ROLES) return;
     if (w > 3) return;
     PIV_STAMP(w * 32);
-    const float* const Tl = GSYNC ? src_blk : W;
-    constexpr int ld = GSYNC ? 64 : SPD_LS;
+    const float* const Tl = (GSYNC && !IN_W) ? src_blk : W;
+    constexpr int ld = (GSYNC && !IN_W) ? 64 : SPD_LS;
     // Lane-dependent address parts, made opaque once per call: everything below is base + compile-time offset (the
     // offset field of the LDS instructions).  Left to itself the compiler forms each of the ~200 addresses (and the 16
     // values of the identity) as a loop invariant of the CALLER's pivot-step loop, keeps them in registers for the whole
@@ -633,7 +634,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             S00[q] = tile_o[qoff(q) * ld];
             S01[q] = tile_o[qoff(q) * ld + 32];
         }
-        if constexpr (!GSYNC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the pivot-row queue overwrites these rows)
+        if constexpr (!GSYNC || IN_W) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the pivot-row queue overwrites these rows)
         // rows c0 .. c0+3 of S as lane vectors (lane = column; by symmetry = the panel's columns, lane = row)
         float x[4];
 #pragma unroll
@@ -1672,7 +1673,7 @@ __device__ __forceinline__ float split_combine(const int e, const int Np, const 
 #define LQP_RS_PIV_MFMA 0      // (the first resident sweep with the matrix-core pivot block: spills, see wg_spd_sweep_resident_v2)
 #endif
 #ifndef LQP_RS_V2
-#define LQP_RS_V2 1            // k_spd_resident runs wg_spd_sweep_resident_v2
+#define LQP_RS_V2 2            // k_spd_resident runs wg_spd_sweep_resident_v2 (2) / _v3 (3: measured slower, see there); 0: the first form
 #endif
 constexpr int RS_NT = 512, RS_NW = RS_NT / 64;
 template <int K> __host__ __device__ constexpr int rs_slots() {
@@ -2078,6 +2079,322 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
             if (k + 1 < K) publish(k + 1);
             if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
+        }
+        if (dbg && tid == 0)
+            for (int q = 0; q < 6; ++q) dbg[q] = dbt[q];
+        // ---- the finished tiles to their home blocks ----
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (ti[s] >= 0) {
+                float* C = Hdst + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
+            }
+        }
+    };
+    if (w < 4) body(std::true_type());
+    else body(std::false_type());
+    __syncthreads();
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
+// ---- resident sweep, third form: the pivot block of step k+1 runs BESIDE the tile updates of step k ------------------
+// In wg_spd_sweep_resident_v2 the matrix pipes idle while the pivot block is eliminated (24 k of 87 k cycles per step)
+// and both workgroups eliminate every pivot block.  Here
+//   * pivot block k is eliminated by ONE workgroup, the one that holds tile (k, k) (its four quadrants sit in waves 0..3:
+//     the diagonal tiles come first in a workgroup's tile list), and W, W^T travel to the partner through the exchange
+//     buffer (32 KB, write-through stores + flag) -- the pivot tile itself no longer travels;
+//   * inside step k the tiles that need W_k (row / column k) and the tiles of the NEXT panel (row / column k+1, tile
+//     (k+1, k+1) among them) are updated first; the next panel is published at once; then waves 0..3 of the owner of
+//     pivot block k+1 eliminate it while everybody else -- waves 4..7 there, all eight waves of the partner -- goes on
+//     with the remaining rank-64 updates: the elimination's latency chain runs beside matrix instructions instead of in
+//     front of them.  The pivot waves take their own remaining tiles afterwards.
+// Same tile arithmetic as v2 (bit-identical results); only the order of independent updates and who computes W differ.
+// MEASURED (B = 128, n = 500): 0.47 ms against 0.36 ms for v2 -- kept for the record, not built in by default
+// (LQP_RS_V2 = 3).  Per step (cycles of wave 0): waiting for the partner 21 k (v2: 7.6 k), staging 12 k (v2: hidden behind
+// the pivot block), Y 18 k, W_k tiles 12.6 k, pivot block + the rest 44 k.  The pivot block cannot start before every
+// tile that reads W_k / W_k^T is done (it eliminates IN the W / W^T areas: there is no LDS for a second pair), so the
+// chain W_k -> Y -> W_k tiles -> pivot block k+1 -> 32 KB to the partner -> its staging is still serial, and what the
+// overlap hides (the partner's updates beside the owner's elimination) is less than what the hand-over adds.  What would
+// pay: the pivot block in ONE scratch area (ring queues instead of 16-panel queues) and the W_k tiles reading W
+// transposed, so that W^T's area is free and block k+1 starts right behind tile (k+1, k+1).
+template <int K> __host__ __device__ constexpr int rs3_na() { return rs2_na<K>(); }
+template <int K> __host__ __device__ constexpr int rs3_nb() { return rs2_nb<K>(); }
+// (i, j) of local tile l of workgroup `part`: its diagonal tiles first (columns ascending), then the others
+__device__ __forceinline__ void rs3_tile_of(int l, const int K, const int part, int& ti, int& tj) {
+    ti = 0; tj = 0;
+    for (int j = 0; j < K; ++j) {
+        if (split_owner(j, K) != part) continue;
+        if (l == 0) { ti = j; tj = j; return; }
+        --l;
+    }
+    for (int j = 0; j < K; ++j) {
+        if (split_owner(j, K) != part) continue;
+        if (l < K - 1 - j) { ti = j + 1 + l; tj = j; return; }
+        l -= K - 1 - j;
+    }
+}
+constexpr int RS3_XW = 1024;        // floats between the panel slots (+ the late-rho words) and the W slots of the exchange buffer
+__host__ __device__ constexpr size_t rs3_xb_floats(int K) { return (size_t)2 * K * LQP_BLK + RS3_XW + (size_t)2 * 2 * LQP_BLK; }
+
+// xb: [2][K][4096] panel slots by step parity | 2 words of ||Qs||_F^2 (rho_late) | ... | [2][2][4096] W, W^T by pivot parity
+// fl: four words of this matrix: [part] panel flag, [2 + part] W flag of the workgroups
+template <int K>
+__device__ __forceinline__ void wg_spd_sweep_resident_v3(const float* Hsrc, float* Hdst,
+                                                         float* __restrict__ xb, unsigned int* __restrict__ fl,
+                                                         const unsigned int epoch, const int part, int* __restrict__ info,
+                                                         int* __restrict__ status_timeout, char* smem,
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr},
+                                                         unsigned long long* __restrict__ dbg = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
+    const int nloc = split_count(K, part);
+    float* Y = (float*)smem;
+    float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
+    float* WT = W + 64 * SPD_LS;
+    float* pcol = WT + 64 * SPD_LS;
+    int* flag = (int*)(pcol + PIV_LDS);
+    int* gw = (int*)(pcol + 66);                              // [0..1] the pivot block's words, [2] sync of waves 0..3
+    float* xw = xb + (size_t)2 * K * LQP_BLK + RS3_XW;        // W, W^T slots
+    if (tid == 0) { flag[0] = 0; gw[0] = 0; gw[1] = 0; gw[2] = 0; }
+    __syncthreads();
+
+    auto body = [&](auto pivot_tag) {
+        constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
+        constexpr int NS = PIVOT ? rs3_na<K>() : rs3_nb<K>(), FIRST = PIVOT ? 0 : rs3_na<K>();
+        f32x16 T[NS];
+        int ti[NS], tj[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int l = FIRST + s;
+            int a, b;
+            rs3_tile_of(l < nloc ? l : 0, K, part, a, b);
+            ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
+            tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
+            if (ti[s] >= 0) {
+                const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
+                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
+                } else {
+                    const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
+                }
+            }
+        }
+        if (lr.on) {
+            const float* xr = xb + (size_t)2 * K * LQP_BLK;
+            float rho = sqrtf(xr[0] + xr[1]) / (float)sqrt((double)lr.n);
+            rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
+            if (tid == 0 && lr.rho_out) *lr.rho_out = rho;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (quad_row(q, lh) == li && ti[s] * 64 + 32 * qi + li < lr.n) T[s][q] += rho;
+                }
+            }
+        }
+        unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
+        int gsync = 0, pcall = 0;                              // running targets of the 4-wave sync / calls of the pivot block
+        // the panel tiles of step kk this wave holds -> exchange buffer (not the pivot tile)
+        auto publish = [&](const int kk) {
+            float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i >= 0 && (i == kk || j == kk) && i != j) {
+                    const int slot = j == kk ? i - 1 : j;      // P_i: i > kk -> i - 1, i < kk -> i
+                    unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float tv = T[s][q];
+                        __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        };
+        // pivot block kk by this workgroup's waves 0..3 (it holds tile (kk, kk): slot of that tile = its rank among the
+        // workgroup's diagonal tiles); W, W^T stay in LDS and go to the partner
+        auto eliminate = [&](const int kk) {
+            if constexpr (PIVOT) {
+                int sd = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) if (ti[s] == kk && tj[s] == kk) sd = s;
+                // this wave's quadrant of the tile into the W area (row stride SPD_LS)
+                {
+                    int li_s = li, lh_s = lh;
+                    asm volatile("" : "+v"(li_s), "+v"(lh_s));
+                    float* dst = W + (32 * qi + 4 * lh_s) * SPD_LS + 32 * qj + li_s;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        if (s == sd) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * SPD_LS] = T[s][q];
+                        }
+                    }
+                }
+                lds_group_sync<true>(gw + 2, gsync += 4);
+                wg_pivot_block_mfma<true, true, true>(nullptr, W, WT, pcol, flag, kk * 64, gw, pcall);
+                ++pcall;
+                lds_group_sync<true>(gw + 2, gsync += 4);          // W, W^T complete
+                // -> the partner: 2 x 4096 floats by 256 threads, write-through
+                {
+                    unsigned int* dstg = (unsigned int*)(xw + (size_t)(kk & 1) * 2 * LQP_BLK);
+                    for (int v = tid; v < 2 * 1024; v += 256) {
+                        const int m = v >> 10, e = v & 1023, rr = e >> 4, cc = (e & 15) * 4;
+                        const V4<float> val = *(const V4<float>*)((m ? WT : W) + rr * SPD_LS + cc);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            __hip_atomic_store(dstg + m * LQP_BLK + e * 4 + q, __builtin_bit_cast(unsigned int, val.v[q]),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lds_group_sync<true>(gw + 2, gsync += 4);
+                    if (tid == 0) __hip_atomic_store(fl + 2 + part, epoch + (unsigned int)kk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        // one lane waits for a flag of the partner, then ONE agent-scope acquire for the workgroup (bounded spin)
+        auto wait_flag = [&](unsigned int* word, const unsigned int target) {
+            if (tid == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
+                        __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        };
+        auto update_slot = [&](const int s, const int k, const float* yF, const float* yH) {
+            constexpr int WOFF = (K - 1) * 64 * SPD_LS, WTOFF = WOFF + 64 * SPD_LS;
+            const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
+            const int i = ti[s], j = tj[s];
+            if (i != k && j != k) {
+                const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
+                T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
+            } else if (i == k && j == k) {
+                const f32x16 a = (qi | qj) ? spd_quadrant_lp<1>(yH + 32 + WTOFF + oi, yH + 32 + WTOFF + oj)
+                                           : spd_quadrant_lp<0>(yF + WTOFF, yF + WTOFF);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
+            } else if (j == k) {              // tile (i, k), i > k: Y_i W
+                const int yo = (i - 1) * 64 * SPD_LS + oi;
+                T[s] = qj == 1 ? spd_quadrant_lp<1>(yH + 32 + yo, yH + 32 + WTOFF + 32 * SPD_LS) : spd_quadrant_lp<0>(yF + yo, yF + WTOFF);
+            } else {                          // tile (k, j), j < k: W^T Y_j^T
+                const int yo = j * 64 * SPD_LS + oj;
+                T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
+            }
+        };
+
+        // ---- prologue: panel of step 0 out, pivot block 0 by its owner ----
+        publish(0);
+        if (split_owner(0, K) == part) eliminate(0);
+        for (int k = 0; k < K; ++k) {
+            if (dbg) dt0 = clock64();
+            const bool own_k = split_owner(k, K) == part;
+            const bool own_next = k + 1 < K && split_owner(k + 1, K) == part;
+            float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // (closes step k-1: every wave is done with the LDS panel; this wave's
+                                                   //  panel tiles of step k have left)
+            if (tid == 0) __hip_atomic_store(fl + part, epoch + (unsigned int)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wait_flag(fl + (1 - part), epoch + (unsigned int)k + 1u);
+            if (!own_k) wait_flag(fl + 2 + (1 - part), epoch + (unsigned int)k + 1u);
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
+            int li_s = li, lh_s = lh, tid_s = tid;
+            asm volatile("" : "+v"(li_s), "+v"(lh_s), "+v"(tid_s));
+            // ---- panel tiles -> LDS (slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k); W, W^T of the
+            //      partner's pivot block -> LDS ----
+            {
+                const int r0 = tid_s >> 3, c8 = (tid_s & 7) * 8;
+                const float* const src_l = xbk + r0 * 64 + c8;
+                float* const yrow_l = Y + r0 * SPD_LS + c8;            // row-major destination
+                float* const ycol_l = Y + c8 * SPD_LS + r0;            // transposed destination
+#pragma unroll
+                for (int s0 = 0; s0 < K - 1; ++s0) {
+                    const float* src = src_l + s0 * LQP_BLK;
+                    const V4<float> a = *(const V4<float>*)src, b = *(const V4<float>*)(src + 4);
+                    if (s0 >= k) {
+                        *(V4<float>*)(yrow_l + (s0 * 64) * SPD_LS) = a;
+                        *(V4<float>*)(yrow_l + (s0 * 64) * SPD_LS + 4) = b;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ycol_l[(s0 * 64 + e) * SPD_LS] = a.v[e];
+                            ycol_l[(s0 * 64 + 4 + e) * SPD_LS] = b.v[e];
+                        }
+                    }
+                }
+                if (!own_k) {
+                    const float* wsrc = xw + (size_t)(k & 1) * 2 * LQP_BLK + r0 * 64 + c8;
+                    constexpr int WOFF = (K - 1) * 64 * SPD_LS;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const V4<float> a = *(const V4<float>*)(wsrc + m * LQP_BLK), b = *(const V4<float>*)(wsrc + m * LQP_BLK + 4);
+                        *(V4<float>*)(yrow_l + WOFF + m * 64 * SPD_LS) = a;
+                        *(V4<float>*)(yrow_l + WOFF + m * 64 * SPD_LS + 4) = b;
+                    }
+                }
+            }
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
+            // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves) ----
+            constexpr int WOFF = (K - 1) * 64 * SPD_LS;
+            const float* const yF = Y + li_s * SPD_LS + 32 * lh_s;     // operand row li at the lane's k range (full)
+            const float* const yH = Y + li_s * SPD_LS + 16 * lh_s;     // ... (half k range; + 32: the upper half)
+            float* const yC = Y + (4 * lh_s) * SPD_LS + li_s;          // element (quad_row(q, lh), li) at + ((q&3) + 8 (q>>2)) * SPD_LS
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
+                if (rb < 2 * (K - 1)) {
+                    const int xoff = ((rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
+                    const f32x16 a0 = spd_quadrant_lp<1>(yH + xoff, yH + WOFF);
+                    const f32x16 a1 = spd_quadrant_lp<0>(yF + xoff, yF + WOFF + 32 * SPD_LS);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS] = a0[q];
+                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS + 32] = a1[q];
+                    }
+                }
+            }
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
+            // ---- first: the tiles that need W_k (row / column k); tile (k+1, k+1) with them ----
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i < 0) continue;
+                if (i == k || j == k || (i == k + 1 && j == k + 1)) update_slot(s, k, yF, yH);
+            }
+            __syncthreads();                       // W, W^T of step k are free
+            if (dbg) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
+            // ---- pivot block k+1 (its owner's waves 0..3) beside the remaining rank-64 updates: the next panel first (it
+            //      leaves for the partner at once), then the rest ----
+            if (own_next) eliminate(k + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i < 0) continue;
+                if (!(i == k || j == k) && (i == k + 1 || j == k + 1) && i != j) update_slot(s, k, yF, yH);
+            }
+            if (k + 1 < K) publish(k + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i < 0) continue;
+                if (!(i == k || j == k || i == k + 1 || j == k + 1)) update_slot(s, k, yF, yH);
+            }
+            if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
         }
         if (dbg && tid == 0)
             for (int q = 0; q < 6; ++q) dbg[q] = dbt[q];
