@@ -169,7 +169,7 @@ def stream_ptr(device):
 # ---- deferred error reporting for calls that did not synchronise with the host -----------------
 class _Pending:
     """status / LU-info words of an un-synchronised call, copied to pinned memory on the call's stream"""
-    __slots__ = ("what", "event", "status", "info", "bounds_check")
+    __slots__ = ("what", "event", "status", "info", "bounds_check", "keep")
 
     def __init__(self, what, event, status, info, bounds_check=None):
         self.what, self.event, self.status, self.info, self.bounds_check = what, event, status, info, bounds_check
@@ -179,25 +179,37 @@ _pending = []
 _pending_lock = threading.Lock()
 
 
+_pinned_free = {}        # number of int32 words -> pinned host buffers waiting for re-use (cudaHostAlloc costs ~50 us)
+
+
+def _pinned(words):
+    pool = _pinned_free.setdefault(words, [])
+    return pool.pop() if pool else torch.empty(words, dtype=torch.int32, pin_memory=True)
+
+
 def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes, bounds_check=None):
     """bounds_check = (assumed, control, mutate, remember): the call was enqueued ASSUMING that the batch holds some /
     no finite bound; status words 12 / 13 hold what the setup kernel found."""
     if status_bytes and status_off <= info_off and info_off + info_bytes - status_off <= 65536:
         # one copy for the whole region [status .. info] (every device-to-host copy costs ~4 us of GPU time)
-        span = torch.empty((info_off + info_bytes - status_off) // 4, dtype=torch.int32, pin_memory=True)
+        span = _pinned((info_off + info_bytes - status_off) // 4)
         span.copy_(ws[status_off:info_off + info_bytes].view(torch.int32), non_blocking=True)
         status = span[:status_bytes // 4]
         info = span[(info_off - status_off) // 4:]
+        keep = (span,)
     else:
-        status = torch.empty(status_bytes // 4, dtype=torch.int32, pin_memory=True) if status_bytes else None
-        info = torch.empty(info_bytes // 4, dtype=torch.int32, pin_memory=True)
+        status = _pinned(status_bytes // 4) if status_bytes else None
+        info = _pinned(info_bytes // 4)
         if status is not None:
             status.copy_(ws[status_off:status_off + status_bytes].view(torch.int32), non_blocking=True)
         info.copy_(ws[info_off:info_off + info_bytes].view(torch.int32), non_blocking=True)
+        keep = tuple(t for t in (status, info) if t is not None)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(ws.device))
     with _pending_lock:
-        _pending.append(_Pending(what, ev, status, info, bounds_check))
+        p = _Pending(what, ev, status, info, bounds_check)
+        p.keep = keep
+        _pending.append(p)
         backlog = len(_pending)
     if backlog > 64:
         poll_errors(block=True)
@@ -216,9 +228,14 @@ def poll_errors(block=False):
             _pending.pop(0)
         p.event.synchronize()
         bad = torch.nonzero(p.info)
+        status7 = int(p.status[7]) if p.status is not None else 0
+        status5 = int(p.status[5]) if p.status is not None else 0
+        seen_words = (int(p.status[12]), int(p.status[13])) if p.status is not None else (1, 1)
+        for t in getattr(p, "keep", ()):            # (values are read: the pinned buffers can serve the next call)
+            _pinned_free.setdefault(t.numel(), []).append(t)
         if p.bounds_check is not None and p.status is not None:
             assumed, control, mutate, remember = p.bounds_check
-            seen = bool(int(p.status[12]) or int(p.status[13]))
+            seen = bool(seen_words[0] or seen_words[1])
             remember(control, seen)
             if seen != assumed:
                 if mutate and not seen:
@@ -230,7 +247,7 @@ def poll_errors(block=False):
                     "rho = 0 one-shot solve on that (:157-158), and this call was enqueued for the other one -- its outputs "
                     "are not the reference's.  Repeat the call (the layer now assumes what it saw), or pass "
                     "control['sync']=True, which repeats by itself")
-        if p.status is not None and int(p.status[7]):
+        if status7:
             raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): Q + rho I is not "
                                f"positive definite in float32 (batch index {int(bad[0]) if bad.numel() else -1}); the "
                                f"symmetric-inverse x-update does not apply: pass control['linsolve']='lu' (or "
@@ -238,7 +255,7 @@ def poll_errors(block=False):
         if bad.numel():
             raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): LU hit an exactly "
                                f"zero pivot for batch index {int(bad[0])}; the matrix is singular")
-        if p.status is not None and int(p.status[5]):
+        if status5:
             raise RuntimeError(f"lqp_py_amd.{p.what}: in-kernel grid barrier timed out")
 
 

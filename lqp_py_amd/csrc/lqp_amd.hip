@@ -55,6 +55,32 @@ int ensure_lds(const void* fn, int bytes) {
     return LQP_OK;
 }
 
+// Occupancy answers and CU counts do not change for a (kernel, block size, LDS) on a device: the runtime calls cost
+// microseconds each and a forward used to make nine of them.
+struct OccKey { const void* fn; int nt, lds, dev; bool operator==(const OccKey& o) const { return fn == o.fn && nt == o.nt && lds == o.lds && dev == o.dev; } };
+struct OccHash { size_t operator()(const OccKey& k) const { return std::hash<const void*>()(k.fn) ^ ((size_t)k.nt * 1315423911u) ^ ((size_t)k.lds << 7) ^ (size_t)k.dev; } };
+std::unordered_map<OccKey, int, OccHash> g_occ;
+int g_cus[64];
+bool current_device_cus(int* dev, int* cus) {
+    if (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    if (g_cus[*dev] == 0 && hipDeviceGetAttribute(&g_cus[*dev], hipDeviceAttributeMultiprocessorCount, *dev) != hipSuccess) return false;
+    *cus = g_cus[*dev];
+    return true;
+}
+template <typename F> bool blocks_per_cu(int* per_cu, F fn, int nt, int lds, int dev) {
+    const OccKey key{(const void*)fn, nt, lds, dev};
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mutex);
+        auto it = g_occ.find(key);
+        if (it != g_occ.end()) { *per_cu = it->second; return true; }
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, fn, nt, lds) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    g_occ[key] = *per_cu;
+    return true;
+}
+
 // ---- optional per-kernel-class timing with HIP events on the launch stream ----
 enum { PC_SETUP = 0, PC_LU, PC_PACK, PC_LOOP, PC_RHO, PC_EPILOGUE, PC_BWD_BUILD, PC_SOLVE, PC_BWD_EPILOGUE,
        PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_BWD_CHOL, PC_COUNT };
@@ -82,9 +108,20 @@ struct ProfScope {
     }
 };
 
+// (environment knobs are read once: a forward consults two dozen of them; tests that flip one do so in a fresh process
+//  or through LQP_ENV_NOCACHE=1)
 int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s ? atoi(s) : dflt;
+    static const bool nocache = getenv("LQP_ENV_NOCACHE") != nullptr;
+    if (nocache) { const char* s = getenv(name); return s ? atoi(s) : dflt; }
+    static std::mutex m;
+    static std::unordered_map<std::string, std::pair<bool, int>> cache;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = cache.find(name);
+    if (it == cache.end()) {
+        const char* s = getenv(name);
+        it = cache.emplace(name, std::make_pair(s != nullptr, s ? atoi(s) : 0)).first;
+    }
+    return it->second.first ? it->second.second : dflt;
 }
 
 unsigned long long* g_lu_dbg = nullptr;     // optional device buffer (4 counters per problem), debug only
@@ -282,18 +319,14 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     const int spd_pivot_tasks = env_int("LQP_SPD_PTASKS", 48);
     if (spd && P.Ks >= 3 && P.Ks <= SPD_MAXK) {
         int dev_ = 0, cus_ = 0;
-        if (hipGetDevice(&dev_) == hipSuccess &&
-            hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess)
-            spd_split = B * SPD_NP <= cus_;
+        if (current_device_cus(&dev_, &cus_)) spd_split = B * SPD_NP <= cus_;
         spd_split = env_int("LQP_SPD_SPLIT", spd_split ? 1 : 0) != 0;
         spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
     }
     bool spd_big_split = false;
     if (spd && P.Ks > SPD_MAXK) {
         int dev_ = 0, cus_ = 0;
-        if (hipGetDevice(&dev_) == hipSuccess &&
-            hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess)
-            spd_big_split = B * SPD_NP <= cus_;
+        if (current_device_cus(&dev_, &cus_)) spd_big_split = B * SPD_NP <= cus_;
         spd_big_split = env_int("LQP_SPD_SPLIT", spd_big_split ? 1 : 0) != 0;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
@@ -305,10 +338,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         auto rfn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6> : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
         int dev_ = 0, cus_ = 0, per_cu = 0;
         const int rlds = spd_lds_bytes(P.Ks);
-        spd_resident = ensure_lds((const void*)rfn, rlds) == LQP_OK && hipGetDevice(&dev_) == hipSuccess &&
-                       hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess &&
-                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rfn, RS_NT, rlds) == hipSuccess &&
-                       per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
+        spd_resident = ensure_lds((const void*)rfn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
+                       blocks_per_cu(&per_cu, rfn, RS_NT, rlds, dev_) && per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
     }
     // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
@@ -439,10 +470,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         // the grid barrier needs EVERY workgroup resident -- of the hot kernel and of the continuation kernel
         // (own block size and LDS footprint): take the smaller of the two answers
         int dev = 0, cus = 0, per_cu = 0, per_cu_tail = 0;
-        HIP_OK(hipGetDevice(&dev));
-        HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_fn, loop_nt, loop_lds));
-        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tail, tail_fn, LQP_NT, tail_lds));
+        if (!current_device_cus(&dev, &cus) || !blocks_per_cu(&per_cu, loop_fn, loop_nt, loop_lds, dev) ||
+            !blocks_per_cu(&per_cu_tail, tail_fn, LQP_NT, tail_lds, dev))
+            return LQP_ERR_HIP;
         per_cu = std::min(per_cu, per_cu_tail);
         if (per_cu < 1 || B > cus * per_cu) mode = 1;     // not every workgroup resident: no grid barrier
     }
@@ -459,12 +489,11 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             split_nt = 512;
             split_lds = split_loop_lds_bytes<512>(P.Ks, m);
             int dev = 0, cus = 0, per_cu = 0;
-            HIP_OK(hipGetDevice(&dev));
-            HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (!current_device_cus(&dev, &cus)) return LQP_ERR_HIP;
             split_fn = P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
                      : P.Ks == 7 ? k_admm_loop_split<7, 512> : (g_lu_dbg ? k_admm_loop_split<8, 512, true> : k_admm_loop_split<8, 512>);
             if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, split_fn, split_nt, split_lds) == hipSuccess)
+                blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev))
                 loop_split = per_cu >= 1 && 2 * B <= cus * per_cu;
         }
     }

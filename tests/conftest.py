@@ -10,6 +10,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+# the library reads its environment knobs once per process; the tests flip them between solves
+os.environ.setdefault("LQP_ENV_NOCACHE", "1")
 
 
 def pytest_configure(config):
