@@ -763,8 +763,8 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     // reduced system goes through a blocked Cholesky of Q_FF instead of the pivoted LU of the bordered matrix
     bool chol = false;
     if constexpr (sizeof(T) == 4) {
-        chol = P.reduced && linsolve == 2 && env_int("LQP_BWD_CHOL", 1) && round_up(n, LQP_NB) / LQP_NB <= SPD_MAXK &&
-               m <= SPD_MAXM;
+        chol = P.reduced && linsolve == 2 && env_int("LQP_BWD_CHOL", 1) && round_up(n, LQP_NB) / LQP_NB <= SPD_BIGK &&
+               m <= SPD_MAXM && bwd_chol_lds_bytes(n, m) <= 160 * 1024;
         if (chol) {
             P.chol = 1;
             {
@@ -776,7 +776,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             const int lds = bwd_chol_lds_bytes(n, m);
             {
                 const int Kmax = round_up(n, LQP_NB) / LQP_NB;
-                P.la_maxk = !env_int("LQP_BWD_LOOKAHEAD", 1) ? 0 : (Kmax < SPD_MAXK ? Kmax : Kmax - 1);
+                P.la_maxk = !env_int("LQP_BWD_LOOKAHEAD", 1) ? 0 : (Kmax < SPD_MAXK ? Kmax : SPD_MAXK - 1);
             }
             int r2 = ensure_lds((const void*)k_bwd_chol_solve, lds);
             if (r2) return r2;

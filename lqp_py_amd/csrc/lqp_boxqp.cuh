@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
 }
 
 // ---------------------------------------------------------------------------
-// Cholesky form of the reduced backward system (f32, Q symmetric, n <= 512, m <= 16):
+// Cholesky form of the reduced backward system (f32, Q symmetric, n <= 1024, m <= 16):
 //   [[Kf, A_F^T], [A_F, eps I]] [dv_F; dnu] = [-g_F; 0],   Kf = Q_FF + eps I  (eps = 1e-8, :378-392)
 //   dv_F = u0 - G dnu,  u0 = Kf^-1 (-g_F),  G = Kf^-1 A_F^T,  (A_F G - eps I) dnu = A_F u0.
 // Build: ordered compaction of the free set, Kf as packed lower 64x64 blocks (identity padding), -g_F -> rhs,
@@ -1907,7 +1907,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
 // LDS: wg_chol_factor's layout, then v | acc | u0 | G[m][Npm] | t[64] | part[NW*64] | S[m*m] | wv[m] | dn[m]
 __host__ __device__ inline int bwd_chol_lds_bytes(int n, int m) {
     const int Kmax = round_up(n, LQP_NB) / LQP_NB, Npm = Kmax * LQP_NB;
-    const int a0 = spd_lds_bytes(Kmax);
+    const int a0 = spd_lds_bytes(Kmax > SPD_MAXK ? SPD_MAXK : Kmax);      // (above: wg_chol_factor_big, panel in chunks)
     const int a = (Kmax < SPD_MAXK && chol_la_lds_bytes(Kmax) > a0) ? chol_la_lds_bytes(Kmax) : a0;
     const int c = ((3 + m) * Npm + 2 * 64 + 2 * LQP_NW * 64 + m * m + 2 * m + 8) * 4;
     return a > c ? a : c;
@@ -1925,7 +1925,8 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     unsigned long long dt0 = P.dbg ? clock64() : 0;
     if (Kb > 0) {
         if (Kb <= P.la_maxk) wg_chol_factor_la(Ls, Kb, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
-        else wg_chol_factor(Ls, Kb, P.info + b, smem);
+        else if (Kb <= SPD_MAXK) wg_chol_factor(Ls, Kb, P.info + b, smem);
+        else wg_chol_factor_big(Ls, Kb, P.info + b, smem);
     }
     __syncthreads();
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 0] = t - dt0; dt0 = t; P.dbg[(size_t)b * 8 + 3] = Kb; }

@@ -2515,6 +2515,139 @@ __device__ __forceinline__ void wg_chol_factor(float* __restrict__ Hs, const int
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
 
+// ---- the same factorisation for SPD_MAXK < K <= SPD_BIGK (free sets above 512 variables): the panel of a step (up to
+// K - 1 blocks) no longer fits the LDS next to W and W^T.  Y_i = L_ik is formed in chunks of SPD_MAXK - 1 blocks and goes
+// straight to its final block (i, k) (it stays in L2); the trailing updates A_ij -= L_ik L_jk^T then walk over pairs of
+// GROUPS of BIG_G panel blocks staged from there (over W and W^T, dead in that phase), as in wg_spd_sweep_big.
+// In place, one workgroup per matrix; LDS as wg_chol_factor at K = SPD_MAXK.
+__device__ __forceinline__ void wg_chol_factor_big(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem) {
+    constexpr int CH = SPD_MAXK - 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = tid >> 4, cq = tid & 15, li = lane & 31, lh = lane >> 5;
+    float* Y = (float*)smem;
+    float* W = Y + (size_t)CH * 64 * SPD_LS;
+    float* WT = W + 64 * SPD_LS;
+    float* pcol = WT + 64 * SPD_LS;
+    int* flag = (int*)(pcol + PIV_LDS);
+    if (tid == 0) flag[0] = 0;
+    for (int k = 0; k < K; ++k) {
+        const int np = K - 1 - k;                           // panel blocks below the pivot: index a <-> row k+1+a
+        wg_pivot<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
+        __syncthreads();
+        // the pre-inverted diagonal block
+        *(V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4) = *(const V4<float>*)(W + r * SPD_LS + cq * 4);
+        // ---- Y phase: chunk of the panel -> LDS, Y_i = P_i W^T in place, L_ik = Y_i -> its block ----
+        for (int c0 = 0; c0 < np; c0 += CH) {
+            const int cn = (np - c0) < CH ? (np - c0) : CH;
+            for (int u = 0; u < cn; ++u)
+                *(V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4) =
+                    *(const V4<float>*)(Hs + (size_t)sym_idx(k + 1 + c0 + u, k, K) * LQP_BLK + tid * 4);
+            __syncthreads();
+            {
+                const int ntask = cn * 4;                   // <= 28: at most two quadrants per wave
+                f32x16 acc[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                    if (task < ntask) {
+                        const int sl = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                        const float* Xp = Y + ((size_t)sl * 64 + 32 * qi) * SPD_LS;
+                        acc[u] = qj == 0 ? spd_quadrant<1, false>(Xp, W) : spd_quadrant(Xp, W + 32 * SPD_LS);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int task = __builtin_amdgcn_readfirstlane(w + 16 * u);
+                    if (task < ntask) {
+                        const int sl = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                        float* dst = Y + ((size_t)sl * 64 + 32 * qi) * SPD_LS + 32 * qj + li;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) dst[quad_row(q, lh) * SPD_LS] = acc[u][q];
+                    }
+                }
+                __syncthreads();
+            }
+            for (int u = 0; u < cn; ++u)
+                *(V4<float>*)(Hs + (size_t)sym_idx(k + 1 + c0 + u, k, K) * LQP_BLK + tid * 4) =
+                    *(const V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4);
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- update phase: A_ij -= L_ik L_jk^T for i >= j > k, by pairs of panel groups ----
+        const int ng = (np + BIG_G - 1) / BIG_G;
+        for (int ga = 0; ga < ng; ++ga) {
+            for (int gb = 0; gb <= ga; ++gb) {
+                const int a0 = BIG_G * ga, b0 = BIG_G * gb;
+                const int an = (np - a0) < BIG_G ? (np - a0) : BIG_G, bn = (np - b0) < BIG_G ? (np - b0) : BIG_G;
+                const int boff = gb == ga ? 0 : BIG_G;
+                for (int u = 0; u < an; ++u)
+                    *(V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4) =
+                        *(const V4<float>*)(Hs + (size_t)sym_idx(k + 1 + a0 + u, k, K) * LQP_BLK + tid * 4);
+                if (gb != ga)
+                    for (int u = 0; u < bn; ++u)
+                        *(V4<float>*)(Y + ((size_t)(BIG_G + u) * 64 + r) * SPD_LS + cq * 4) =
+                            *(const V4<float>*)(Hs + (size_t)sym_idx(k + 1 + b0 + u, k, K) * LQP_BLK + tid * 4);
+                __syncthreads();
+                const int npair = gb == ga ? an * (an + 1) / 2 : an * bn;
+                auto decode = [&](const int task, int& ua, int& ub, bool& skip, bool& mirror) -> float* {
+                    const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
+                    if (gb == ga) {
+                        ua = 0;
+                        while ((ua + 1) * (ua + 2) / 2 <= p) ++ua;
+                        ub = p - ua * (ua + 1) / 2;
+                    } else {
+                        ua = p / bn;
+                        ub = p - ua * bn;
+                    }
+                    const int si = a0 + ua, sj = b0 + ub;                  // si >= sj
+                    skip = si == sj && qi == 0 && qj == 1;                  // diagonal tile: mirrored from its (1,0) quadrant
+                    mirror = si == sj && qi == 1 && qj == 0;
+                    return Hs + (size_t)sym_idx(k + 1 + si, k + 1 + sj, K) * LQP_BLK;
+                };
+                auto load_c = [&](const float* T0, const int task, f32x16& c) {
+                    const float* C = T0 + (32 * ((task >> 1) & 1)) * 64 + 32 * (task & 1) + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) c[q] = C[quad_row(q, lh) * 64];
+                };
+                const int ntask = npair * 4;
+                int task = __builtin_amdgcn_readfirstlane(w);
+                int ua = 0, ub = 0; bool skip = false, mirror = false;
+                float* T0 = nullptr;
+                f32x16 nxt;
+                if (task < ntask) { T0 = decode(task, ua, ub, skip, mirror); if (!skip) load_c(T0, task, nxt); }
+                while (task < ntask) {
+                    const int qi = (task >> 1) & 1, qj = task & 1;
+                    f32x16 cur = nxt;
+                    float* Tc = T0;
+                    const int cua = ua, cub = ub;
+                    const bool cskip = skip, cmirror = mirror;
+                    const int nt = task + LQP_NW;
+                    if (nt < ntask) { T0 = decode(nt, ua, ub, skip, mirror); if (!skip) load_c(T0, nt, nxt); }
+                    if (!cskip) {
+                        const f32x16 acc = spd_quadrant(Y + ((size_t)cua * 64 + 32 * qi) * SPD_LS,
+                                                        Y + ((size_t)(boff + cub) * 64 + 32 * qj) * SPD_LS);
+                        cur -= acc;
+                        float* C = Tc + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                        if (cmirror) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) Tc[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                        }
+                    }
+                    task = nt;
+                }
+                __syncthreads();
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
 // ---- the same factorisation with a LOOK-AHEAD pivot chain ---------------------------------------------------
 // The 64-column elimination chain of a diagonal block (wg_pivot_block) is latency bound and keeps four waves busy
 // for ~15 us while the other twelve wait; the panel product and the tile updates of a step take about as long again.
@@ -2704,15 +2837,22 @@ __device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, co
         V4<float> yj[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) yj[c] = *(const V4<float>*)(X + (size_t)(c < nc ? c : 0) * xs + j * 64 + cq * 4);
+        for (int u0 = 0; j + 1 + u0 < K; u0 += MC) {         // (more than MC blocks below: K > SPD_MAXK, chunk by chunk)
+            if (u0 > 0) {
 #pragma unroll
-        for (int u = 0; u < MC; ++u) {
-            const int i = j + 1 + u;
-            if (i < K) {
+                for (int u = 0; u < MC; ++u)
+                    if (j + 1 + u0 + u < K) bc[u] = blk4(j + 1 + u0 + u, j);
+            }
 #pragma unroll
-                for (int c = 0; c < NR; ++c) {
-                    if (c < nc) {
-                        const float s1 = rowgroup_sum<LQP_NT>(dot4(bc[u], yj[c]));
-                        if (cq == 0) acc[c * K64 + i * 64 + r] += s1;  // (row r of block row i always belongs to this thread)
+            for (int u = 0; u < MC; ++u) {
+                const int i = j + 1 + u0 + u;
+                if (i < K) {
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) {
+                        if (c < nc) {
+                            const float s1 = rowgroup_sum<LQP_NT>(dot4(bc[u], yj[c]));
+                            if (cq == 0) acc[c * K64 + i * 64 + r] += s1;  // (row r of block row i always belongs to this thread)
+                        }
                     }
                 }
             }
@@ -2743,15 +2883,22 @@ __device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, co
         for (int c = 0; c < NR; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) a2[c][e] = 0.f;
+        for (int u0 = 0; j + 1 + u0 < K; u0 += MC) {
+            if (u0 > 0) {
 #pragma unroll
-        for (int u = 0; u < MC; ++u) {
-            const int i = j + 1 + u;
-            if (i < K) {
+                for (int u = 0; u < MC; ++u)
+                    if (j + 1 + u0 + u < K) bc[u] = blk4(j + 1 + u0 + u, j);
+            }
 #pragma unroll
-                for (int c = 0; c < NR; ++c) {
-                    const float xi = X[(size_t)(c < nc ? c : 0) * xs + i * 64 + r];
+            for (int u = 0; u < MC; ++u) {
+                const int i = j + 1 + u0 + u;
+                if (i < K) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a2[c][e] += bc[u].v[e] * xi;
+                    for (int c = 0; c < NR; ++c) {
+                        const float xi = X[(size_t)(c < nc ? c : 0) * xs + i * 64 + r];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a2[c][e] += bc[u].v[e] * xi;
+                    }
                 }
             }
         }

@@ -1118,3 +1118,38 @@ def test_two_workgroup_schedules_beside_a_foreign_kernel(dev):
         torch.cuda.synchronize(dev)
         L.synchronize()
         assert torch.equal(x1, x0) and torch.equal(x2, x0) and torch.equal(x0, ref["x"])
+
+
+@pytest.mark.parametrize("n,m,B", [(1000, 1, 3), (700, 2, 2), (1024, 0, 2)])
+def test_cholesky_backward_above_512(dev, n, m, B):
+    """The Cholesky form of the backward for free sets above 512 variables (config-4 size: the reference's own layer demo
+    differentiates at n_x = 1000, demo/demo_solve_box_qp_torch_layer.py:25-40): wg_chol_factor_big (panel in chunks,
+    trailing updates by group pairs) + block solves over up to 16 block columns.  All six gradients against the fp64
+    oracle at the GPU's iteration count, and against the LU form of the same system."""
+    torch.manual_seed(n + m)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + 3, with_eq=False)
+    A = torch.randn(B, m, n) if m else None
+    b = 0.1 * torch.randn(B, m, 1) if m else None
+    inp = (Q, p, A, b, lb, ub)
+    ctl = O.make_control(**TOL)
+    sol, a = solve(dev, inp, ctl)
+    assert sol["_stats"]["linsolve_used"] == 2
+    cot = torch.randn(B, n, 1)
+    want = dict(dQ=True, dp=True, dA=m > 0, db=m > 0, dlb=True, dub=True)
+    out = {}
+    for ls in (1, 2):
+        _lib.profile(enable=True, reset=True)
+        out[ls] = SB._fp_backward(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"],
+                                 want, sync=True, linsolve=ls)
+        used = _lib.profile(); _lib.profile(enable=False)
+        assert (used["bwd_cholesky"][1] == 1) == (ls == 2), used
+    d = [None if t is None else t.double() for t in inp]
+    s64 = O.solve_box_qp(*d, dict(ctl, eps_abs=1e-12, eps_rel=1e-12, max_iters=sol["iter"] + 1))
+    g64 = O.solve_box_qp_grad(cot.double(), s64["x"], s64["u"], s64["lams"], s64["nus"], d[0], d[2], d[4], d[5], s64["rho"])
+    for idx, nm in enumerate(GRADS):
+        if out[2][idx] is None:
+            continue
+        scale = max(1.0, float(g64[idx].abs().max()))
+        e2, e1 = err(out[2][idx], g64[idx]), err(out[1][idx], g64[idx])
+        P.record(f"chol_backward_big_n{n}", nm, e2, scale, lu_form_vs_fp64=e1)
+        assert e2 < 5 * G_RTOL * scale, (nm, e2, e1, scale)       # (fp32 forward iterates differ from the fp64 ones at 1e-5)
