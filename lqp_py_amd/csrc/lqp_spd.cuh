@@ -295,9 +295,12 @@ __device__ __forceinline__ void lds_group_sync(int* cnt, const int target) {
     if constexpr (TIGHT) asm volatile("" ::: "memory");
     else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+#ifndef LQP_WAIT_SLEEP
+#define LQP_WAIT_SLEEP 1       // s_sleep argument of the waves that wait for another group of their workgroup (x 64 cycles)
+#endif
 __device__ __forceinline__ void lds_wait_ge(int* word, const int target) {
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(LQP_WAIT_SLEEP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 

@@ -3,6 +3,7 @@
 Not a pytest file: prints one line per check and never stops at the first
 failure (GPU box round-trips are expensive)."""
 import os
+os.environ.setdefault("LQP_ENV_NOCACHE", "1")      # (this tool flips library knobs between solves)
 import sys
 import time
 import traceback

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """LU kernel timing + in-kernel phase breakdown (debug counters) on KKT-like matrices."""
 import os, sys, time
+os.environ.setdefault("LQP_ENV_NOCACHE", "1")      # (this tool flips library knobs between solves)
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)

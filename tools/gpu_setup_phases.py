@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel cycle breakdown of k_fwd_setup (debug counters of thread 0)."""
 import os, sys
+os.environ.setdefault("LQP_ENV_NOCACHE", "1")      # (this tool flips library knobs between solves)
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)

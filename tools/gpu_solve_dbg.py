@@ -1,4 +1,5 @@
 import os, sys, ctypes, torch
+os.environ.setdefault("LQP_ENV_NOCACHE", "1")      # (this tool flips library knobs between solves)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["LQP_RESIDENT"] = "0"
 import lqp_py_amd as L
