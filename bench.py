@@ -298,7 +298,7 @@ def main():
                                                          n_free=int(0.63 * n))
     loop_ms = per_solve("admm_loop")
     gbs = lambda nbytes, ms: (nbytes * B) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    split = st_timed["loop_workgroups_per_qp"] == 2
+    split = st_timed["loop_workgroups_per_qp"] >= 2
     loop_kernel = ("lqp::k_admm_loop_split" if split else
                    "lqp::k_admm_loop<float, true, false, 1024, true>" if ls == 2 else "lqp::k_admm_loop<float, true, false, 1024, false>")
     traffic, traffic_src = measured_traffic(loop_kernel, B, n)

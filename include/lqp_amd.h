@@ -113,7 +113,7 @@ typedef struct lqp_boxqp_stats {
     int32_t linsolve_used;  /* 1 pivoted LU, 2 symmetric inverse (what linsolve 0 / a fallback resolved to) */
     int32_t factor_launches; /* kernel launches per (re)factorisation: 1, 2 (LU + pack) or Ks + 2 when a small batch
                               * shares each matrix between two workgroups (one launch per pivot step) */
-    int32_t loop_workgroups; /* workgroups per QP in the first (hot) loop launch: 1, or 2 when a small batch (2 B <= CUs)
+    int32_t loop_workgroups; /* workgroups per QP in the first (hot) loop launch: 1, 2 (2 B <= CUs) or 4 (4 B <= CUs) when a small batch
                               * on the symmetric path splits every product between two CUs */
     int32_t any_lb;          /* 1: some lower bound of the batch is finite (:129), 0: none, -1: not known on the host */
     int32_t any_ub;          /* the same for the upper bounds (:130)                                                 */

@@ -479,7 +479,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     const int max_checks_per_launch = kRing / 4;
     // two workgroups per QP for the first (hot) launch: symmetric path, persistent mode, 2 B workgroups resident
     bool loop_split = false;
-    int split_lds = 0, split_nt = 512;
+    int split_lds = 0, split_nt = 512, loop_np = 1;
     void (*split_fn)(const FwdParams<float>, const int, const int, const int) = nullptr;
     if constexpr (sizeof(T) == 4) {
         if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && env_int("LQP_LOOP_SPLIT", 1) != 0) {
@@ -487,14 +487,25 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             // build -- 12 blocks in 128 VGPRs, 6 in LDS, 16 waves -- spills ~60 VGPRs into the hot loop and measured
             // 0.38 ms against 0.28 ms at B = 128, n = 500; the template still takes NT = 1024.)
             split_nt = 512;
-            split_lds = split_loop_lds_bytes<512>(P.Ks, m);
             int dev = 0, cus = 0, per_cu = 0;
             if (!current_device_cus(&dev, &cus)) return LQP_ERR_HIP;
-            split_fn = P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
-                     : P.Ks == 7 ? k_admm_loop_split<7, 512> : (g_lu_dbg ? k_admm_loop_split<8, 512, true> : k_admm_loop_split<8, 512>);
-            if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
-                blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev))
-                loop_split = per_cu >= 1 && 2 * B <= cus * per_cu;
+            // four workgroups per QP (one column pair each) when the batch leaves room for them: B <= #CUs / 4
+            if (P.Ks >= 7 && 4 * B <= cus && env_int("LQP_LOOP_SPLIT4", 1) != 0) {
+                split_lds = split_loop_lds_bytes<512, 4>(P.Ks, m);
+                split_fn = P.Ks == 7 ? k_admm_loop_split<7, 512, false, 4> : k_admm_loop_split<8, 512, false, 4>;
+                if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
+                    blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1 && 4 * B <= cus * per_cu)
+                    loop_np = 4;
+            }
+            if (loop_np != 4) {
+                split_lds = split_loop_lds_bytes<512>(P.Ks, m);
+                split_fn = P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
+                         : P.Ks == 7 ? k_admm_loop_split<7, 512> : (g_lu_dbg ? k_admm_loop_split<8, 512, true> : k_admm_loop_split<8, 512>);
+                if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
+                    blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1 && 2 * B <= cus * per_cu)
+                    loop_np = 2;
+            }
+            loop_split = loop_np > 1;
         }
     }
     // the equality correction of the first factorisation moves into that kernel (its blocks are in registers there)
@@ -506,7 +517,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         ProfScope ps(st, PC_LOOP);
         if constexpr (sizeof(T) == 4) {
             if (loop_split && it == 0) {
-                hipLaunchKernelGGL(split_fn, dim3(2 * B), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
+                hipLaunchKernelGGL(split_fn, dim3(loop_np * B), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
                 return;
             }
         }
@@ -575,7 +586,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 stats->any_lb = stats->any_ub = -1;
                 stats->linsolve_used = spd ? 2 : 1;
                 stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
-                stats->loop_workgroups = loop_split ? 2 : 1;
+                stats->loop_workgroups = loop_split ? loop_np : 1;
             }
             return LQP_OK;
         }
@@ -716,7 +727,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->mode_used = mode;
         stats->linsolve_used = spd ? 2 : 1;
         stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
-        stats->loop_workgroups = (loop_split && mode == 2) ? 2 : 1;
+        stats->loop_workgroups = (loop_split && mode == 2) ? loop_np : 1;
         stats->any_lb = h_status[ST_ANY_LB]; stats->any_ub = h_status[ST_ANY_UB];
     }
     return LQP_OK;

@@ -21,7 +21,8 @@ enum { CT_NOTOPT = 0, CT_ARRIVE = 1, CT_WANTS = 2, CT_TRIG = 3, CT_WORDS = 4 };
 // per-problem scalars
 enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_PRI = 4, SC_DUA = 5, SC_WORDS = 8 };   // PRI/DUA: errors of the last check
 
-constexpr int XCHG_WORDS = 2 * 2 * SPD_MAXK * LQP_NB;       // exchange granules per QP of the two-workgroup loop: [parity][part][element]
+constexpr int XCHG_NPMAX = 4;                                // workgroups per QP of the shared loop, at most
+constexpr int XCHG_WORDS = 2 * XCHG_NPMAX * SPD_MAXK * LQP_NB;      // exchange granules per QP of the shared loop: [parity][part][element]
 
 template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     unsigned long long tst = clock64();
 #define SETUP_STAMP(i) do { if (P.dbg_setup && tid == 0) { const unsigned long long t_ = clock64(); P.dbg_setup[(size_t)b * 8 + (i)] = t_ - tst; tst = t_; } } while (0)
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
-        unsigned long long* xq = P.xchg + (size_t)b * (2 * 2 * SPD_MAXK * LQP_NB);
-        for (int i = tid; i < 2 * 2 * SPD_MAXK * LQP_NB; i += LQP_NT) xq[i] = 0ull;
-        if (tid < 2) P.xchg[(size_t)P.B * (2 * 2 * SPD_MAXK * LQP_NB) + 2 * b + tid] = 0ull;      // step flags of the resident sweep (4 words)
+        unsigned long long* xq = P.xchg + (size_t)b * XCHG_WORDS;
+        for (int i = tid; i < XCHG_WORDS; i += LQP_NT) xq[i] = 0ull;
+        if (tid < 2) P.xchg[(size_t)P.B * XCHG_WORDS + 2 * b + tid] = 0ull;      // step flags of the resident sweep (4 words)
     }
 
     // the small vectors are requested now and used after the pass over Q (n <= 1024: one element per thread; a load
@@ -1187,20 +1188,23 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
 // LDS (floats; every offset but the last three arrays is a compile-time constant):
 //   [rl blocks] v yrow cvl part[NW][Nps] z u ps lb ub D xs sz su sx (Nps each) red[NW*8+8] flags[8] | bs nus snu (m each)
 // ---------------------------------------------------------------------------
-template <int NT> __host__ __device__ constexpr int split_loop_lds_floats(int Ks) {
-    return split_lds_blocks<NT>(Ks) * LQP_BLK + (3 + NT / 64 + 10) * Ks * LQP_NB + (NT / 64) * 8 + 8 + 8;
+template <int NT, int NP = 2> __host__ __device__ constexpr int split_loop_lds_floats(int Ks) {
+    return split_lds_blocks<NT, NP>(Ks) * LQP_BLK + (3 + NT / 64 + 10) * Ks * LQP_NB + (NT / 64) * 8 + 8 + 8;
 }
-template <int NT> __host__ __device__ inline int split_loop_lds_bytes(int Ks, int m) {
+template <int NT, int NP = 2> __host__ __device__ inline int split_loop_lds_bytes(int Ks, int m) {
     // + the equality block: As, G, T (m x Nps each), S, S^-1 (m x m), s0, b, nu, nu snapshot
-    return (split_loop_lds_floats<NT>(Ks) + 3 * m * Ks * LQP_NB + 2 * m * m + 4 * m + 8) * 4;
+    return (split_loop_lds_floats<NT, NP>(Ks) + 3 * m * Ks * LQP_NB + 2 * m * m + 4 * m + 8) * 4;
 }
 
-template <int KS, int NT, bool DBG = false>
+// NP = 4 (batches up to a quarter of the CUs): one column pair per workgroup, every partial product published once and
+// fetched by the three others; the sum runs over the parts in their order on every workgroup (identical iterates).
+template <int KS, int NT, bool DBG = false, int NP = 2>
 __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P, const int it0, const int it1,
                                                         const int ctr_base) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     typedef float T;
-    constexpr int NWV = NT / 64, Ks = KS, Nps = KS * LQP_NB, rl = split_lds_blocks<NT>(KS);
+    constexpr int NWV = NT / 64, Ks = KS, Nps = KS * LQP_NB, rl = split_lds_blocks<NT, NP>(KS);
+    constexpr int XPART = SPD_MAXK * LQP_NB, XPAR = NP * XPART;      // granules of one part / of one parity of the exchange
     const int b = blockIdx.x % P.B, part_id = blockIdx.x / P.B;
     const int n = P.n, m = P.m;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1241,8 +1245,17 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     const T pnorm = scal[SC_PNORM];
 
     SplitResident<NT> rr;
-    if (part_id == 0) split_resident_load<KS, 0, NT>(rr, lds_res, packed);
-    else split_resident_load<KS, 1, NT>(rr, lds_res, packed);
+    // (one instantiation of the block helpers per part: which blocks a workgroup holds is a compile-time fact)
+#define LQP_BY_PART(CALL)                                                                   \
+    do {                                                                                    \
+        if (part_id == 0) { constexpr int PARTC = 0; CALL; }                                \
+        else if (part_id == 1) { constexpr int PARTC = 1; CALL; }                           \
+        else if constexpr (NP > 2) {                                                        \
+            if (part_id == 2) { constexpr int PARTC = 2; CALL; }                            \
+            else { constexpr int PARTC = 3; CALL; }                                         \
+        }                                                                                   \
+    } while (0)
+    LQP_BY_PART((split_resident_load<KS, PARTC, NT, NP>(rr, lds_res, packed)));
     for (int i = tid; i < Nps; i += NT) {
         const bool in = i < n;
         z[i] = in ? V.z[i] : T(0); u[i] = in ? V.u[i] : T(0); ps[i] = in ? V.ps[i] : T(0);
@@ -1269,38 +1282,44 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     if (eq_here) {
         if (part_id == 0 && tid == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;      // (k_spd_end did not run)
         for (int q = 0; q < m; ++q) {
-            if (part_id == 0) wg_sym_gemv_split<KS, 0, NT>(rr, lds_res, Nps, Asl + (size_t)q * Nps, yrow, part);
-            else wg_sym_gemv_split<KS, 1, NT>(rr, lds_res, Nps, Asl + (size_t)q * Nps, yrow, part);
+            LQP_BY_PART((wg_sym_gemv_split<KS, PARTC, NT, NP>(rr, lds_res, Nps, Asl + (size_t)q * Nps, yrow, part)));
             wg_barrier_lds();
             if (tid < Nps) {
                 const int i = tid;
                 const T own = split_combine<NT>(i, Nps, yrow, part);
                 const unsigned int tag = 0x20000000u + (unsigned int)q;
-                unsigned long long* base = xq + (size_t)(q & 1) * (2 * SPD_MAXK * LQP_NB);
-                __hip_atomic_store(base + (size_t)part_id * (SPD_MAXK * LQP_NB) + i,
+                unsigned long long* base = xq + (size_t)(q & 1) * XPAR;
+                __hip_atomic_store(base + (size_t)part_id * XPART + i,
                                    ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, own),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long* src = base + (size_t)(1 - part_id) * (SPD_MAXK * LQP_NB) + i;
-                unsigned long long g = 0;
-                if (!flags[0]) {
-                    unsigned int spins = 0;
-                    unsigned long long t0 = 0;
-                    for (;;) {
-                        g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (((unsigned int)(g >> 32) & 0x3FFFFFFFu) == tag) break;
-                        if ((++spins & 1023u) == 0) {
-                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
-                            if (t0 == 0) t0 = now;
-                            else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up
-                                __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                flags[0] = 1;
-                                break;
+                T y = T(0);
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {                 // same order on every workgroup
+                    T term = own;
+                    if (pp != part_id) {
+                        const unsigned long long* src = base + (size_t)pp * XPART + i;
+                        unsigned long long g = 0;
+                        if (!flags[0]) {
+                            unsigned int spins = 0;
+                            unsigned long long t0 = 0;
+                            for (;;) {
+                                g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (((unsigned int)(g >> 32) & 0x3FFFFFFFu) == tag) break;
+                                if ((++spins & 1023u) == 0) {
+                                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                                    if (t0 == 0) t0 = now;
+                                    else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up
+                                        __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        flags[0] = 1;
+                                        break;
+                                    }
+                                }
                             }
                         }
+                        term = __builtin_bit_cast(float, (unsigned int)g);
                     }
+                    y = pp == 0 ? term : y + term;
                 }
-                const T other = __builtin_bit_cast(float, (unsigned int)g);
-                const T y = part_id == 0 ? own + other : other + own;      // same order on both workgroups
                 Gl[(size_t)q * Nps + i] = -y;
             }
             wg_barrier_lds();
@@ -1354,8 +1373,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             if (part_id == 0 && e < n) V.cv[e] = acc;
         }
         // the blocks: thread t holds EPT consecutive elements of row t / LPR of every block
-        if (part_id == 0) split_eq_update<KS, 0, NT>(rr, lds_res, Gl, Tl, m, Nps);
-        else split_eq_update<KS, 1, NT>(rr, lds_res, Gl, Tl, m, Nps);
+        LQP_BY_PART((split_eq_update<KS, PARTC, NT, NP>(rr, lds_res, Gl, Tl, m, Nps)));
         wg_barrier_lds();
     }
     for (int i = tid; i < Nps; i += NT) v[i] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
@@ -1407,8 +1425,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
         unsigned long long cw = 0;
         const bool look = pending && part_id == 0 && tid == 0;
         if (look) cw = __hip_atomic_load(pend_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (part_id == 0) wg_sym_gemv_split<KS, 0, NT>(rr, lds_res, Nps, v, yrow, part);
-        else wg_sym_gemv_split<KS, 1, NT>(rr, lds_res, Nps, v, yrow, part);
+        LQP_BY_PART((wg_sym_gemv_split<KS, PARTC, NT, NP>(rr, lds_res, Nps, v, yrow, part)));
         if (look) {
             int vd = verdict_of(cw);
             if constexpr (COLD) { if (vd == 0) vd = wait_verdict(); }
@@ -1434,43 +1451,50 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             const T own = split_combine<NT>(i, Nps, yrow, part);
             // ---- exchange: publish this element's partial (part 0: with the verdict), fetch the partner's ----
             const unsigned int tag = (unsigned int)(it + 1);
-            unsigned long long* base = xq + (size_t)((it + moff) & 1) * (2 * SPD_MAXK * LQP_NB);
-            __hip_atomic_store(base + (size_t)part_id * (SPD_MAXK * LQP_NB) + i,
+            unsigned long long* base = xq + (size_t)((it + moff) & 1) * XPAR;
+            __hip_atomic_store(base + (size_t)part_id * XPART + i,
                                ((unsigned long long)(tag | ((unsigned int)verdict << 30)) << 32) |
                                    (unsigned long long)__builtin_bit_cast(unsigned int, own),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long* src = base + (size_t)(1 - part_id) * (SPD_MAXK * LQP_NB) + i;
-            unsigned long long g = 0;
             if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
-            if (!(verdict == 1 && part_id == 0) && !flags[0]) {      // (part 0 leaving: nothing to fetch)
-                unsigned int spins = 0;
-                unsigned long long t0 = 0;
-                for (;;) {
-                    g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (((unsigned int)(g >> 32) & 0x3FFFFFFFu) == tag) break;
-                    if ((++spins & 1023u) == 0) {
-                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
-                        if (t0 == 0) t0 = now;
-                        else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up
-                            __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            flags[0] = 1;
-                            break;
+            T y = T(0);
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {                     // same order on every workgroup
+                T term = own;
+                if (pp != part_id) {
+                    const unsigned long long* src = base + (size_t)pp * XPART + i;
+                    unsigned long long g = 0;
+                    if (!(verdict == 1 && part_id == 0) && !flags[0]) {      // (part 0 leaving: nothing to fetch)
+                        unsigned int spins = 0;
+                        unsigned long long t0 = 0;
+                        for (;;) {
+                            g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (((unsigned int)(g >> 32) & 0x3FFFFFFFu) == tag) break;
+                            if ((++spins & 1023u) == 0) {
+                                const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                                if (t0 == 0) t0 = now;
+                                else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up
+                                    __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    flags[0] = 1;
+                                    break;
+                                }
+                            }
                         }
                     }
+                    if (pp == 0 && pending) {                     // the verdict travels in part 0's tags
+                        verdict = (int)((unsigned int)(g >> 62));
+                        if (tid == 0) flags[1] = verdict;
+                    }
+                    term = __builtin_bit_cast(float, (unsigned int)g);
                 }
+                y = pp == 0 ? term : y + term;
             }
             if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
-            if (part_id == 1 && pending) {
-                verdict = (int)((unsigned int)(g >> 62));
-                if (tid == 0) flags[1] = verdict;
-            }
-            const T other = __builtin_bit_cast(float, (unsigned int)g);
-            const T y = part_id == 0 ? own + other : other + own;      // same order on both workgroups
             xi = cvl[i] - y;
         }
         if (pending) {
             // the verdict is uniform over both workgroups: part 0 read it before the exchange, part 1 found it in the tags
-            if (part_id == 1) { wg_barrier_lds(); verdict = flags[1]; }
+            if (part_id != 0) { wg_barrier_lds(); verdict = flags[1]; }
             if (verdict == 1) return 1;
             if (verdict == 2) pending = false;
         }
@@ -1599,8 +1623,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     // equality correction
     if (eq_here) {
         T* packed_w = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
-        if (part_id == 0) split_resident_store<KS, 0, NT>(rr, lds_res, packed_w);
-        else split_resident_store<KS, 1, NT>(rr, lds_res, packed_w);
+        LQP_BY_PART((split_resident_store<KS, PARTC, NT, NP>(rr, lds_res, packed_w)));
+#undef LQP_BY_PART
     }
 }
 

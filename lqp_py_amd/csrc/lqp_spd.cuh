@@ -1474,15 +1474,17 @@ __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, NT>& st, const Re
 // 512 threads (256 VGPRs each, 8 per block) keep all 18
 template <int NT> __host__ __device__ constexpr int split_rr() { return NT == 512 ? 18 : 12; }
 constexpr int SPLIT_MINK = 5;       // below that one workgroup holds the whole matrix in registers anyway
-__host__ __device__ constexpr int split_owner(int j, int K) { return (j < K - 1 - j ? j : K - 1 - j) & 1; }
-__host__ __device__ constexpr int split_count(int K, int part) {
+// NP workgroups per matrix (2, or 4 when 4 B <= #CUs: batches up to 64): column pair p = min(j, K-1-j) belongs to workgroup p % NP
+__host__ __device__ constexpr int split_owner(int j, int K, int NP = 2) { return (j < K - 1 - j ? j : K - 1 - j) & (NP - 1); }
+__host__ __device__ constexpr int split_count(int K, int part, int NP = 2) {
     int c = 0;
-    for (int j = 0; j < K; ++j) if (split_owner(j, K) == part) c += K - j;
+    for (int j = 0; j < K; ++j) if (split_owner(j, K, NP) == part) c += K - j;
     return c;
 }
-template <int NT> __host__ __device__ constexpr int split_lds_blocks(int K) {
-    const int a = split_count(K, 0), b = split_count(K, 1);
-    const int c = (a > b ? a : b) - split_rr<NT>();
+template <int NT, int NP = 2> __host__ __device__ constexpr int split_lds_blocks(int K) {
+    int mx = 0;
+    for (int q = 0; q < NP; ++q) { const int a = split_count(K, q, NP); mx = a > mx ? a : mx; }
+    const int c = mx - split_rr<NT>();
     return c > 0 ? c : 0;
 }
 
@@ -1491,11 +1493,11 @@ template <int NT> struct SplitResident {
 };
 
 // compile-time map of workgroup PART's share of a K-block matrix: local block l <-> (i, j), columns ascending
-template <int K, int PART> struct SplitMap {
-    static constexpr int count() { return split_count(K, PART); }
+template <int K, int PART, int NP = 2> struct SplitMap {
+    static constexpr int count() { return split_count(K, PART, NP); }
     static constexpr int col_of(int l) {
         for (int j = 0; j < K; ++j) {
-            if (split_owner(j, K) != PART) continue;
+            if (split_owner(j, K, NP) != PART) continue;
             if (l < K - j) return j;
             l -= K - j;
         }
@@ -1503,7 +1505,7 @@ template <int K, int PART> struct SplitMap {
     }
     static constexpr int row_of(int l) {
         for (int j = 0; j < K; ++j) {
-            if (split_owner(j, K) != PART) continue;
+            if (split_owner(j, K, NP) != PART) continue;
             if (l < K - j) return j + l;
             l -= K - j;
         }
@@ -1512,14 +1514,14 @@ template <int K, int PART> struct SplitMap {
     // local index of block (i, j), j owned
     static constexpr int local_of(int i, int j) {
         int l = 0;
-        for (int c = 0; c < j; ++c) if (split_owner(c, K) == PART) l += K - c;
+        for (int c = 0; c < j; ++c) if (split_owner(c, K, NP) == PART) l += K - c;
         return l + (i - j);
     }
 };
 
-template <int K, int PART, int NT>
+template <int K, int PART, int NT, int NP = 2>
 __device__ __forceinline__ void split_resident_load(SplitResident<NT>& rr, float* __restrict__ lds_res, const float* __restrict__ Hs) {
-    typedef SplitMap<K, PART> M;
+    typedef SplitMap<K, PART, NP> M;
     constexpr int nloc = M::count(), RR = split_rr<NT>();
 #pragma unroll
     for (int l = 0; l < RR; ++l)
@@ -1530,9 +1532,9 @@ __device__ __forceinline__ void split_resident_load(SplitResident<NT>& rr, float
                               frag_load<float, NT>(Hs + (size_t)sym_idx(M::row_of(l), M::col_of(l), K) * LQP_BLK));
 }
 
-template <int K, int PART, int NT>
+template <int K, int PART, int NT, int NP = 2>
 __device__ __forceinline__ void split_resident_store(const SplitResident<NT>& rr, const float* __restrict__ lds_res, float* __restrict__ Hs) {
-    typedef SplitMap<K, PART> M;
+    typedef SplitMap<K, PART, NP> M;
     constexpr int nloc = M::count(), RR = split_rr<NT>();
 #pragma unroll
     for (int l = 0; l < RR; ++l)
@@ -1545,10 +1547,10 @@ __device__ __forceinline__ void split_resident_store(const SplitResident<NT>& rr
 
 // B_ij += sum_q T_q[64 i + r] G_q[64 j + c] on every block workgroup PART holds (registers and LDS): the rank-m
 // equality correction H + T G^T.  Tl, Gl: [m][Np] in LDS.
-template <int K, int PART, int NT>
+template <int K, int PART, int NT, int NP = 2>
 __device__ __forceinline__ void split_eq_update(SplitResident<NT>& rr, float* __restrict__ lds_res, const float* __restrict__ Gl,
                                                 const float* __restrict__ Tl, const int m, const int Np) {
-    typedef SplitMap<K, PART> M;
+    typedef SplitMap<K, PART, NP> M;
     constexpr int nloc = M::count(), RR = split_rr<NT>(), EPT = LQP_BLK / NT, LPR = LQP_NB / EPT, NV = EPT / 4;
     const int tid = threadIdx.x, r = tid / LPR, c0 = (tid % LPR) * EPT;
 #pragma unroll
@@ -1579,11 +1581,11 @@ __device__ __forceinline__ void split_eq_update(SplitResident<NT>& rr, float* __
 //   column product a_j += B_ij^T w_i accumulated over the block column, folded over the rows the wave holds and
 //                 written to this wave's slice part[w][64 j ..]
 // No walk state, no branches: the compiler interleaves the independent chains.
-template <int K, int PART, int NT>
+template <int K, int PART, int NT, int NP = 2>
 __device__ __forceinline__ void wg_sym_gemv_split(const SplitResident<NT>& rr, const float* __restrict__ lds_res, const int Np,
                                                   const float* __restrict__ v, float* __restrict__ yrow,
                                                   float* __restrict__ part) {
-    typedef SplitMap<K, PART> M;
+    typedef SplitMap<K, PART, NP> M;
     constexpr int EPT = LQP_BLK / NT, LPR = LQP_NB / EPT, NV = EPT / 4, RR = split_rr<NT>();
     const int tid = threadIdx.x, r = tid / LPR, cq = tid % LPR, lane = tid & 63, w = tid >> 6;
     // two-wide arithmetic (v_pk_fma_f32: two FMAs per instruction and lane): the product is bound by VALU issue
@@ -1594,7 +1596,7 @@ __device__ __forceinline__ void wg_sym_gemv_split(const SplitResident<NT>& rr, c
     for (int i = 0; i < K; ++i) { wrow[i] = v[i * 64 + r]; d[i] = f2{0.f, 0.f}; }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        if (split_owner(j, K) != PART) continue;
+        if (split_owner(j, K, NP) != PART) continue;
         f2 wj[2 * NV];
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -1642,7 +1644,7 @@ __device__ __forceinline__ void wg_sym_gemv_split(const SplitResident<NT>& rr, c
             }
         }
     }
-    constexpr int first_row = PART == 0 ? 0 : 1;       // the lowest owned column: rows below it get nothing
+    constexpr int first_row = M::col_of(0);            // the lowest owned column: rows above it get nothing
 #pragma unroll
     for (int i = first_row; i < K; ++i) yrow[i * 64 + r] = rowgroup_sum<NT>(d[i][0] + d[i][1]);
 }

@@ -815,7 +815,7 @@ def test_equality_correction_in_the_loop_kernel(dev, monkeypatch, n, B, m):
         for flag in ("1", "0"):
             monkeypatch.setenv("LQP_EQ_IN_LOOP", flag)
             out[flag], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve="spd", **kw))
-            assert out[flag]["_stats"]["linsolve_used"] == 2 and out[flag]["_stats"]["loop_workgroups"] == 2
+            assert out[flag]["_stats"]["linsolve_used"] == 2 and out[flag]["_stats"]["loop_workgroups"] in (2, 4)
         ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**kw))
         scale = max(1.0, float(ref["x"].abs().max()))
         if "rho" in kw:
@@ -843,7 +843,7 @@ def test_continuation_launch_finds_corrected_blocks(dev):
     kw = dict(max_iters=5135, eps_abs=1e-30, eps_rel=1e-30, adaptive_rho=False)
     sol, _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(**kw))
     st = sol["_stats"]
-    assert st["linsolve_used"] == 2 and st["loop_workgroups"] == 2 and st["n_factor"] == 1 and sol["iter"] == 5134
+    assert st["linsolve_used"] == 2 and st["loop_workgroups"] in (2, 4) and st["n_factor"] == 1 and sol["iter"] == 5134
     ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(max_iters=400, eps_abs=1e-30, eps_rel=1e-30, adaptive_rho=False))
     for k in ("x", "u", "nus"):
         assert err(sol[k], ref[k]) < 5e-5 * max(1.0, float(ref[k].abs().max())), k        # (both sit at the fixed point)
@@ -1153,3 +1153,27 @@ def test_cholesky_backward_above_512(dev, n, m, B):
         e2, e1 = err(out[2][idx], g64[idx]), err(out[1][idx], g64[idx])
         P.record(f"chol_backward_big_n{n}", nm, e2, scale, lu_form_vs_fp64=e1)
         assert e2 < 5 * G_RTOL * scale, (nm, e2, e1, scale)       # (fp32 forward iterates differ from the fp64 ones at 1e-5)
+
+
+@pytest.mark.parametrize("n,B,m", [(500, 32, 1), (448, 3, 2), (512, 5, 0)])
+def test_four_workgroups_per_qp_loop(dev, monkeypatch, n, B, m):
+    """Batches up to a quarter of the CUs share every product between FOUR workgroups (one column pair each).  Same
+    iterates as the two-workgroup loop up to the order of the four partial sums: same iteration count, x within rounding,
+    and both against the CPU oracle."""
+    torch.manual_seed(n + B)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + B, with_eq=False)
+    A = torch.randn(B, m, n) if m else None
+    b = 0.1 * torch.randn(B, m, 1) if m else None
+    ctl = O.make_control(**TOL)
+    sols = {}
+    for np4 in ("1", "0"):
+        monkeypatch.setenv("LQP_LOOP_SPLIT4", np4)
+        sols[np4], _ = solve(dev, (Q, p, A, b, lb, ub), ctl)
+    assert sols["1"]["_stats"]["loop_workgroups"] == 4 and sols["0"]["_stats"]["loop_workgroups"] == 2
+    assert sols["1"]["iter"] == sols["0"]["iter"]
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, ctl)
+    assert sols["1"]["iter"] == ref["iter"]
+    for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+        P.record("loop_np4", k, err(sols["1"][k], ref[k]), 1.0, n=n, B=B, m=m)
+        assert err(sols["1"][k], sols["0"][k]) < 1e-5 * max(1.0, float(ref[k].abs().max())), k
+        assert err(sols["1"][k], ref[k]) < 2e-5 * max(1.0, float(ref[k].abs().max())), k
