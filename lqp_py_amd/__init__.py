@@ -15,16 +15,22 @@ from .solve_qp_uncon import solve_qp_uncon
 
 
 
+def release_workspaces(device=None):
+    """Free the cached per-(device, stream) scratch buffers (see ``_lib.release_workspaces``)."""
+    from . import _lib
+    _lib.release_workspaces(device)
+
+
 def synchronize():
-    """Wait for every un-synchronised layer call and raise any error it reported (singular KKT matrix,
-    barrier timeout).  ``SolveBoxQP`` (the autograd path) does not wait for the GPU by default; pass
-    ``sync=True`` in the control dict to get the reference's raise-at-the-call behaviour."""
+    """Wait for every un-synchronised layer call (``control['sync'] = False``) and raise any error it reported (singular
+    KKT matrix, matrix outside the symmetric x-update, barrier timeout, a batch whose bound flags differ from what the call
+    was enqueued for).  By default ``SolveBoxQP`` waits for the GPU and raises at the call like the reference."""
     from . import _lib
     _lib.poll_errors(block=True)
 
 
 __all__ = [
-    "synchronize", "box_qp_control", "get_ncon", "torch_qp_eqcon_mat", "SolveBoxQP", "SolveBoxQPLayer", "BoxQPTH",
+    "synchronize", "release_workspaces", "box_qp_control", "get_ncon", "torch_qp_eqcon_mat", "SolveBoxQP", "SolveBoxQPLayer", "BoxQPTH",
     "torch_solve_box_qp", "torch_solve_box_qp_grad", "torch_solve_box_qp_grad_kkt", "torch_qp_int_grads",
     "torch_qp_int_grads_admm", "TorchLU", "TorchLULayer",
     "torch_solve_qp_eqcon", "torch_solve_qp_eqcon_grad", "torch_solve_qp_uncon", "torch_solve_qp_uncon_grad",
