@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 5
+#define LQP_ABI_VERSION 6
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -98,6 +98,14 @@ typedef struct lqp_boxqp_ctrl {
     const void* bound_flags_in;      /* optional: two int32 on the device {any_lb, any_ub} of a LARGER batch this call
                                         holds one shard of (one all-reduce MAX over the ranks); they are
                                         OR-ed into the answer reported back.  NULL: this call is the whole batch.    */
+    void* host_report;               /* optional: PINNED host memory the device can write (hipHostMalloc /
+                                        torch pin_memory), 16 + 2 B int32.  The forward's last kernel then leaves
+                                        there, with no device-to-host copy: [0..16) the status block (see
+                                        lqp_boxqp_forward_layout), [16..16+B) the info word of every problem,
+                                        [16+B..16+2B) per-problem flag bits {1: a lower bound is finite, 2: an upper
+                                        bound is finite, 4: its workgroup saw a barrier timeout, 8: its matrix left the
+                                        symmetric x-update}.  Valid once the stream has passed the call (an event).
+                                        Meant for ctrl.reserved = 1 callers, who must not wait for the device.    */
 } lqp_boxqp_ctrl;
 
 /* Host-side bookkeeping returned by the forward solve. */
@@ -191,7 +199,8 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
                           void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
                           int32_t* fail_index,
                           void* workspace, size_t workspace_bytes,
-                          int linsolve);
+                          int linsolve,
+                          void* host_report);
 
 /* ---- batched LU (partial pivoting) and cached LU solve ------------------
  * Replace torch.linalg.lu_factor / lu_solve as used by lqp_py/lu_layer.py:

@@ -9,6 +9,8 @@ import os
 import subprocess
 import threading
 
+import numpy
+
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -17,7 +19,7 @@ LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQ
 SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
 
 LQP_F32, LQP_F64 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
           5: "grid barrier timeout", 6: "unsupported size"}
 
@@ -36,7 +38,7 @@ class BoxQPCtrl(ctypes.Structure):
             "eps_abs", "eps_rel", "rho_value", "rho_min", "rho_max", "adaptive_rho_tol",
             "adaptive_rho_threshold", "beta_value")] + [
         ("beta_in", ctypes.c_void_p), ("check_hook", CHECK_HOOK), ("check_hook_user", ctypes.c_void_p),
-        ("bound_flags_in", ctypes.c_void_p)]
+        ("bound_flags_in", ctypes.c_void_p), ("host_report", ctypes.c_void_p)]
 
 
 class BoxQPStats(ctypes.Structure):
@@ -65,7 +67,7 @@ SYMBOLS = {
     "lqp_boxqp_last_residuals": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
-                              [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int]),
+                              [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int, _P]),
     "lqp_lu_factor_workspace_bytes": (c_size_t, [c_int] * 3),
     "lqp_lu_factor_batched": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t]),
     "lqp_lu_solve_workspace_bytes": (c_size_t, [c_int] * 3),
@@ -169,7 +171,7 @@ def stream_ptr(device):
 # ---- deferred error reporting for calls that did not synchronise with the host -----------------
 class _Pending:
     """status / LU-info words of an un-synchronised call, copied to pinned memory on the call's stream"""
-    __slots__ = ("what", "event", "status", "info", "bounds_check", "keep")
+    __slots__ = ("what", "event", "status", "info", "bounds_check", "keep", "flags")
 
     def __init__(self, what, event, status, info, bounds_check=None):
         self.what, self.event, self.status, self.info, self.bounds_check = what, event, status, info, bounds_check
@@ -187,28 +189,30 @@ def _pinned(words):
     return pool.pop() if pool else torch.empty(words, dtype=torch.int32, pin_memory=True)
 
 
-def defer_check(what, ws, status_off, status_bytes, info_off, info_bytes, bounds_check=None):
-    """bounds_check = (assumed, control, mutate, remember): the call was enqueued ASSUMING that the batch holds some /
+ST_WORDS = 16                # status block, include/lqp_amd.h (lqp_boxqp_ctrl.host_report)
+RP_LB, RP_UB, RP_TIMEOUT, RP_NOTSPD = 1, 2, 4, 8
+
+
+def host_report(words):
+    """Pinned int32 buffer the kernels of an un-synchronised call report into (no device-to-host copy: the forward's / the
+    backward's last kernel stores the words straight into host memory).  Word 0 starts as -1 = "nothing arrived"."""
+    buf = _pinned(words)
+    buf.numpy()[0] = -1
+    return buf
+
+
+def defer_check(what, device, report, B, forward, bounds_check=None):
+    """Queue the report of an un-synchronised call: `report` is the pinned buffer given to the library as host_report
+    (forward: 16 status words | B info words | B flag words; backward: B info words).
+    bounds_check = (assumed, control, mutate, remember): the call was enqueued ASSUMING that the batch holds some /
     no finite bound; status words 12 / 13 hold what the setup kernel found."""
-    if status_bytes and status_off <= info_off and info_off + info_bytes - status_off <= 65536:
-        # one copy for the whole region [status .. info] (every device-to-host copy costs ~4 us of GPU time)
-        span = _pinned((info_off + info_bytes - status_off) // 4)
-        span.copy_(ws[status_off:info_off + info_bytes].view(torch.int32), non_blocking=True)
-        status = span[:status_bytes // 4]
-        info = span[(info_off - status_off) // 4:]
-        keep = (span,)
-    else:
-        status = _pinned(status_bytes // 4) if status_bytes else None
-        info = _pinned(info_bytes // 4)
-        if status is not None:
-            status.copy_(ws[status_off:status_off + status_bytes].view(torch.int32), non_blocking=True)
-        info.copy_(ws[info_off:info_off + info_bytes].view(torch.int32), non_blocking=True)
-        keep = tuple(t for t in (status, info) if t is not None)
     ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(ws.device))
+    ev.record(torch.cuda.current_stream(device))
     with _pending_lock:
-        p = _Pending(what, ev, status, info, bounds_check)
-        p.keep = keep
+        p = _Pending(what, ev, report[:ST_WORDS] if forward else None,
+                     report[ST_WORDS:ST_WORDS + B] if forward else report[:B], bounds_check)
+        p.keep = (report,)
+        p.flags = report[ST_WORDS + B:ST_WORDS + 2 * B] if forward else None
         _pending.append(p)
         backlog = len(_pending)
     if backlog > 64:
@@ -227,9 +231,14 @@ def poll_errors(block=False):
                 return
             _pending.pop(0)
         p.event.synchronize()
-        bad = torch.nonzero(p.info)
-        status7 = int(p.status[7]) if p.status is not None else 0
-        status5 = int(p.status[5]) if p.status is not None else 0
+        rep = p.keep[0].numpy()
+        if int(rep[0]) < 0:
+            raise RuntimeError(f"lqp_py_amd.{p.what}: the call's report never arrived in host memory")
+        info = p.info.numpy()
+        bad = info.nonzero()[0]
+        flags = int(numpy.bitwise_or.reduce(p.flags.numpy())) if p.flags is not None else 0
+        status7 = (int(p.status[7]) or (flags & RP_NOTSPD)) if p.status is not None else 0
+        status5 = (int(p.status[5]) or (flags & RP_TIMEOUT)) if p.status is not None else 0
         seen_words = (int(p.status[12]), int(p.status[13])) if p.status is not None else (1, 1)
         for t in getattr(p, "keep", ()):            # (values are read: the pinned buffers can serve the next call)
             _pinned_free.setdefault(t.numel(), []).append(t)
@@ -249,10 +258,10 @@ def poll_errors(block=False):
                     "control['sync']=True, which repeats by itself")
         if status7:
             raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): Q + rho I is not "
-                               f"positive definite in float32 (batch index {int(bad[0]) if bad.numel() else -1}); the "
+                               f"positive definite in float32 (batch index {int(bad[0]) if bad.size else -1}); the "
                                f"symmetric-inverse x-update does not apply: pass control['linsolve']='lu' (or "
                                f"control['sync']=True, which falls back by itself)")
-        if bad.numel():
+        if bad.size:
             raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): LU hit an exactly "
                                f"zero pivot for batch index {int(bad[0])}; the matrix is singular")
         if status5:
@@ -263,11 +272,27 @@ _ws_cache = {}
 _ws_lock = threading.Lock()
 
 
-def workspace(device, nbytes, tag):
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_no_switch = _NoSwitch()
+
+
+def on_device(device):
+    """`with torch.cuda.device(device)` -- skipped (it costs ~4 us around every call) when `device` is already current"""
+    return _no_switch if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
+def workspace(device, nbytes, tag, stream=None):
     """Reusable device scratch buffer per (device, STREAM, tag); grows monotonically.  Kernels of one stream are
     ordered, so re-using the buffer call after call is safe; two streams (pipelined layers, threads) never share
     one -- a persistent loop of one stream would otherwise read factors another stream is overwriting."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream if stream is None else stream, tag)
     with _ws_lock:
         buf = _ws_cache.get(key)
         if buf is None or buf.numel() < nbytes:
@@ -286,9 +311,9 @@ def release_workspaces(device=None):
 
 
 def norm(t, dtype):
-    """detached, contiguous, right dtype -- without touching tensors that already are"""
-    if t is None:
-        return None
+    """contiguous, right dtype -- the tensor itself when it already is (only its address is used)"""
+    if t is None or (t.dtype == dtype and t.is_contiguous()):
+        return t
     t = t.detach()
     if t.dtype != dtype:
         t = t.to(dtype)

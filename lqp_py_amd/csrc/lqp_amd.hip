@@ -256,6 +256,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.status = c.take<int>(ST_WORDS);
     P.counters = c.take<unsigned int>((size_t)kRing * CT_WORDS);
     P.info = c.take<int>(B);            // (status | counters | info: one contiguous region for the deferred error fetch)
+    P.bflags = c.take<int>(B);
     P.scal = c.take<T>((size_t)B * SC_WORDS);
     P.vecs = c.take<T>((size_t)B * P.vstride);
     P.piv = c.take<int>((size_t)B * P.Np);
@@ -281,6 +282,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in; P.beta_in = (const T*)ctl->beta_in;
     P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
     P.scale = ctl->scale; P.bound_flags_in = (const int*)ctl->bound_flags_in;
+    P.host_report = (int*)ctl->host_report;
+    P.zero_words = (int)(((char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status) / sizeof(int));
     P.dbg = g_lu_dbg;
     P.dbg_setup = nullptr;
     if (g_lu_dbg && env_int("LQP_DBG_SETUP", 0)) { P.dbg_setup = g_lu_dbg; P.dbg = nullptr; }
@@ -345,8 +348,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
     P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && env_int("LQP_RHO_LATE", 1)) ? 1 : 0;
 
-    // ---- zero status + counter ring, setup, factor, pack ----
-    HIP_OK(hipMemsetAsync(P.status, 0, (char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status, st));
+    // ---- setup (its workgroup 0 zeroes status + counter ring), factor, pack ----
     {
         const int lds = setup_lds_bytes<T>(n);
         auto fn = k_fwd_setup<T>;
@@ -534,6 +536,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             for (int a = ar_iter; a < max_iters && a < ctl->adaptive_rho_max_iter; a += ar_iter) ++n_events;
         if (n_events <= env_int("LQP_NOSYNC_MAX_EVENTS", 12)) {
             int it = 0;
+            const bool tail_epilogue = env_int("LQP_TAIL_EPILOGUE", 1) != 0;
+            bool epilogue_done = false;
             while (it < max_iters) {
                 // the adaptive-rho step of iteration `it` runs as the prologue of the continuation kernel
                 bool event = ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter;
@@ -565,19 +569,25 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     }
                 }
                 const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
+                bool last_tail = false;
                 if (it == 0) {
                     launch_hot(it, e, (int)(c_first % kRing), prev_slot, 1);
                 } else {
+                    // the last continuation launch ends with the epilogue (one launch and its boundary less)
+                    last_tail = e >= max_iters && tail_epilogue;
                     ProfScope ps(st, PC_LOOP_TAIL);
                     hipLaunchKernelGGL(tail_fn, dim3(B), dim3(LQP_NT), tail_lds, st,
-                                       P, it, e, (int)(c_first % kRing), prev_slot, (event || spd) ? 3 : 1);
+                                       P, it, e, (int)(c_first % kRing), prev_slot, ((event || spd) ? 3 : 1) | (last_tail ? 4 : 0));
                 }
                 ++n_launch;
                 it = e;
+                epilogue_done = last_tail;
             }
-            { ProfScope ps(st, PC_EPILOGUE);
-              hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P); }
-            ++n_launch;
+            if (!epilogue_done) {
+                ProfScope ps(st, PC_EPILOGUE);
+                hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P);
+                ++n_launch;
+            }
             if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
             if (stats) {
                 memset(stats, 0, sizeof(*stats));
@@ -757,9 +767,10 @@ template <typename T>
 int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void* x, const void* u, const void* lams,
                   const void* nus, const void* Q, const void* A, const void* lb, const void* ub, int rho_mode,
                   double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
-                  int32_t* fail_index, void* ws, size_t ws_bytes, int linsolve) {
+                  int32_t* fail_index, void* ws, size_t ws_bytes, int linsolve, void* host_report) {
     BwdParams<T> P;
     memset(&P, 0, sizeof(P));
+    P.host_report = (int*)host_report;
     const size_t need = carve_backward<T>(ws, B, n, m, P);
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
     P.g = (const T*)g; P.x = (const T*)x; P.u = (const T*)u; P.lams = (const T*)lams; P.nus = (const T*)nus;
@@ -838,7 +849,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         rc = first_failure(st, P.info, B, &fi);       // torch.linalg.solve checks info (and syncs) too
         if (rc == LQP_ERR_SINGULAR && chol)           // Q_FF not positive definite in f32: the pivoted LU takes it
             return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
-                                    db, dlb, dub, fail_index, ws, ws_bytes, 1);
+                                    db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report);
         *fail_index = fi;
         if (rc) return rc;
     }
@@ -1081,7 +1092,8 @@ size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m) {
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x, const void* u,
                           const void* lams, const void* nus, const void* Q, const void* A, const void* lb, const void* ub,
                           int rho_mode, double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db,
-                          void* dlb, void* dub, int32_t* fail_index, void* workspace, size_t workspace_bytes, int linsolve) {
+                          void* dlb, void* dub, int32_t* fail_index, void* workspace, size_t workspace_bytes, int linsolve,
+                          void* host_report) {
     if (bad_dims(dtype, B, n, m) || !dl_dz || !x || !u || !lams || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
     if (m > 0 && (!A || !nus)) return LQP_ERR_INVALID;
     if (rho_mode != 1 && rho_mode != 2) return LQP_ERR_INVALID;
@@ -1089,8 +1101,8 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const vo
     if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LQP_F32)
-        return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, linsolve);
-    return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, 1);
+        return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, linsolve, host_report);
+    return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, 1, host_report);
 }
 
 size_t lqp_spd_inverse_workspace_bytes(int dtype, int B, int n) {

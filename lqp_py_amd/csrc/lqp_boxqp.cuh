@@ -13,8 +13,12 @@ namespace lqp {
 enum { ST_DONE = 0, ST_FINAL_ITER = 1, ST_GATE = 2, ST_NFACTOR = 3, ST_RHO_UPDATED = 4,
        ST_TIMEOUT = 5, ST_NCHECK = 6, ST_NOTSPD = 7,
        ST_VOTE = 8,      // 4 words: {ranks leaving the symmetric path, ranks with a singular KKT matrix, -, -} (strict global stop)
-       ST_ANY_LB = 12, ST_ANY_UB = 13,      // some lower / upper bound of the batch is finite (:129-130), found by k_fwd_setup
+       ST_ANY_LB = 12, ST_ANY_UB = 13,      // some lower / upper bound of the batch is finite (:129-130): the per-problem
+                                            // answers of k_fwd_setup (FwdParams::bflags), OR-ed by the forward's last kernel
        ST_WORDS = 16 };
+// host report (lqp_boxqp_ctrl.host_report): [ST_WORDS status words as workgroup 0 of the forward's last kernel sees them |
+// B info words | B flag words], written straight into pinned host memory by that kernel
+enum { RP_LB = 1, RP_UB = 2, RP_TIMEOUT = 4, RP_NOTSPD = 8 };
 // per-check counters (uint32 x 4): not-optimal, arrivals, wants-rho, ratio-trigger
 // (NOTOPT and ARRIVE share one aligned 64-bit word: the two-workgroup loop adds to and reads both with ONE atomic)
 enum { CT_NOTOPT = 0, CT_ARRIVE = 1, CT_WANTS = 2, CT_TRIG = 3, CT_WORDS = 4 };
@@ -38,6 +42,8 @@ template <typename T> struct FwdParams {
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in, *beta_in;
     const int* bound_flags_in;           // optional {any_lb, any_ub} of a LARGER batch this call is a shard of (device), or null
+    int* host_report;                    // optional pinned host memory, ST_WORDS + 2 B ints (see RP_*), or null
+    int zero_words;                      // ints from `status` on (status block + counter ring) that workgroup 0 of k_fwd_setup zeroes
     // outputs
     T *x, *z, *u, *lams, *nus, *rho_out;
     // workspace
@@ -49,6 +55,7 @@ template <typename T> struct FwdParams {
     int* piv;         // B * Np
     int* dest;        // B * Np
     int* info;        // B
+    int* bflags;      // B: RP_LB | RP_UB of problem b (k_fwd_setup)
     int* status;      // ST_WORDS
     unsigned int* counters;   // ring of CT_WORDS per check
     unsigned long long* xchg; // B * XCHG_WORDS granules: partial-product exchange of the two-workgroup loop (or null)
@@ -231,6 +238,10 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
     T* scal = P.scal + (size_t)b * SC_WORDS;
     if (tid == 0) P.info[b] = 0;
+    // status block + counter ring start from zero.  Nobody else in this launch touches them (the bound flags are per
+    // problem, see below), every later launch is ordered behind this one: no separate fill launch (3.6 us + a boundary).
+    if (b == 0)
+        for (int i = tid; i < P.zero_words; i += LQP_NT) P.status[i] = 0;
     unsigned long long tst = clock64();
 #define SETUP_STAMP(i) do { if (P.dbg_setup && tid == 0) { const unsigned long long t_ = clock64(); P.dbg_setup[(size_t)b * 8 + (i)] = t_ - tst; tst = t_; } } while (0)
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
@@ -451,22 +462,17 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     SETUP_STAMP(5);
     // ---- bounds (:192-194) and state ----
     // any finite bound in the batch?  (:129-130: a HOST decision in the reference -- it selects the rho = 0 shortcut and
-    // the clamps.  Here the clamps always run (an infinite bound is an exact no-op) and the answer is left in the status
-    // block: the host compares it with what it assumed when it chose the schedule.)
+    // the clamps.  Here the clamps always run (an infinite bound is an exact no-op) and the answer goes back with the
+    // status: one word per problem here, OR-ed over the batch by the forward's last kernel (fwd_finish); the host compares
+    // it with what it assumed when it chose the schedule.)
     {
         bool flb = false, fub = false;
         for (int i = tid; i < n; i += LQP_NT) {
             flb |= (i == tid ? lb0 : lb[i]) > -T(INFINITY);
             fub |= (i == tid ? ub0 : ub[i]) < T(INFINITY);
         }
-        // one store per workgroup at most, none once the word is up (thousands of waves storing to one address queue
-        // behind each other at the memory side: 55 us per launch when every wave did it)
         const int wg_lb = __syncthreads_or(flb ? 1 : 0), wg_ub = __syncthreads_or(fub ? 1 : 0);
-        if (tid < 2) {
-            const bool mine = (tid == 0 ? wg_lb : wg_ub) != 0 || (b == 0 && P.bound_flags_in && P.bound_flags_in[tid] != 0);
-            if (mine && __hip_atomic_load(P.status + ST_ANY_LB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                __hip_atomic_store(P.status + ST_ANY_LB + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) P.bflags[b] = (wg_lb ? RP_LB : 0) | (wg_ub ? RP_UB : 0);
     }
     for (int i = tid; i < n; i += LQP_NT) {
         const T di = P.scale ? V.D[i] : T(1);                // (:192-194; +-inf / D stays +-inf)
@@ -854,6 +860,56 @@ __host__ __device__ inline int sym_resident_lds_blocks(int n, int m, int Ks, int
     return rl;
 }
 
+// ---- epilogue: undo scaling, duals (:316-327), report ----
+// Runs as the END of the forward's last kernel: k_fwd_epilogue, or the continuation loop kernel itself (`persistent & 4`:
+// one launch and its boundary less per solve).  Also ORs the per-problem bound flags into the status block and, when the
+// caller gave pinned host memory, reports there directly: every workgroup its own info / flag words, workgroup 0 the status
+// block -- no device-to-host copy behind the solve (a 1.4 us blit kernel + a boundary).  Words other workgroups of the SAME
+// launch may still write (ST_NOTSPD, ST_TIMEOUT of an in-kernel refactorisation) are therefore also kept per problem
+// (RP_NOTSPD / RP_TIMEOUT in the writer's own flag word).
+template <typename T>
+__device__ __forceinline__ void fwd_finish(const FwdParams<T>& P, const int b) {
+    const int n = P.n, m = P.m, tid = threadIdx.x, nt = blockDim.x;
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    const T rho = P.scal[(size_t)b * SC_WORDS + SC_RHO];
+    // a failed factorisation (singular KKT matrix / Q + rho I not positive definite) or a barrier timeout must not
+    // leave plausible-looking numbers behind: callers that did not wait for the status see NaN
+    const int info_b = P.info[b];
+    const int notspd = __hip_atomic_load(P.status + ST_NOTSPD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool bad = info_b != 0 || notspd != 0 || tmo != 0;
+    const T poison = bad ? T(__builtin_nanf("")) : T(0);
+    for (int i = tid; i < n; i += nt) {
+        const T d = V.D[i];
+        const T xo = d * V.x[i] + poison, zo = d * V.z[i] + poison, uo = V.u[i] / d + poison;
+        P.x[(size_t)b * n + i] = xo;
+        P.z[(size_t)b * n + i] = zo;
+        P.u[(size_t)b * n + i] = uo;
+        const T y = uo * rho;
+        P.lams[(size_t)b * 2 * n + i] = (-y > T(0)) ? -y : T(0);
+        P.lams[(size_t)b * 2 * n + n + i] = (y > T(0)) ? y : T(0);
+    }
+    for (int r = tid; r < m; r += nt) P.nus[(size_t)b * m + r] = V.nu[r] * V.E[r] + poison;
+    if (tid == 0) P.rho_out[b] = rho;
+    const int mine = P.bflags[b] | (tmo ? RP_TIMEOUT : 0) | ((notspd && P.spd && info_b != 0) ? RP_NOTSPD : 0);
+    if (P.host_report && tid == 0) {
+        __hip_atomic_store(P.host_report + ST_WORDS + b, info_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(P.host_report + ST_WORDS + P.B + b, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (b == 0) {
+        // the bound flags of the batch (the per-problem words were written by an earlier launch)
+        int f = 0;
+        for (int i = tid; i < P.B; i += nt) f |= P.bflags[i];
+        const int any_lb = __syncthreads_or(f & RP_LB) ? 1 : 0, any_ub = __syncthreads_or(f & RP_UB) ? 1 : 0;
+        if (tid < ST_WORDS) {
+            int v = __hip_atomic_load(P.status + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == ST_ANY_LB) v = (any_lb || (P.bound_flags_in && P.bound_flags_in[0] != 0)) ? 1 : 0;
+            if (tid == ST_ANY_UB) v = (any_ub || (P.bound_flags_in && P.bound_flags_in[1] != 0)) ? 1 : 0;
+            if (tid == ST_ANY_LB || tid == ST_ANY_UB) P.status[tid] = v;
+            if (P.host_report) __hip_atomic_store(P.host_report + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 // ---------------------------------------------------------------------------
 // The ADMM loop (:235-313).  RES: resident head of the factor stream (registers + LDS); SYM: symmetric-inverse
 // x-update instead of the cached triangular solves; NT: threads.
@@ -865,11 +921,10 @@ __host__ __device__ inline int sym_resident_lds_blocks(int n, int m, int Ks, int
 // (hot) launch stays lean.
 // ---------------------------------------------------------------------------
 template <typename T, bool RES, bool TAIL, int NT, bool SYM = false>
-__global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1,
-                                                      const int ctr_base,       // counter slot of check it0 / check
-                                                      const int prev_slot,      // slot of the last check before it0, -1: none / known not done
-                                                      const int persistent) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
+__device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int it0, const int it1,
+                                               const int ctr_base,       // counter slot of check it0 / check
+                                               const int prev_slot,      // slot of the last check before it0, -1: none / known not done
+                                               const int persistent, char* smem) {
     const int b = blockIdx.x, n = P.n, m = P.m, N = P.N, Np = P.Np, K = P.K;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // every problem stopped at an earlier check -> nothing to do (break at :312)
@@ -1162,6 +1217,19 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
     seg0 = seg1;
     __syncthreads();
   }
+}
+// persistent & 4 (continuation launches): this is the forward's LAST launch -- it ends with the epilogue (fwd_finish)
+template <typename T, bool RES, bool TAIL, int NT, bool SYM = false>
+__global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1, const int ctr_base,
+                                                      const int prev_slot, const int persistent) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    admm_loop_body<T, RES, TAIL, NT, SYM>(P, it0, it1, ctr_base, prev_slot, persistent, smem);
+    if constexpr (TAIL) {
+        if (persistent & 4) {
+            __syncthreads();                   // (the state the loop left in global memory: written by other threads)
+            fwd_finish(P, blockIdx.x);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1683,25 +1751,7 @@ __global__ void k_copy_residuals(const T* __restrict__ scal, T* __restrict__ pri
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_fwd_epilogue(const FwdParams<T> P) {
-    const int b = blockIdx.x, n = P.n, m = P.m;
-    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
-    const T rho = P.scal[(size_t)b * SC_WORDS + SC_RHO];
-    // a failed factorisation (singular KKT matrix / Q + rho I not positive definite) or a barrier timeout must not
-    // leave plausible-looking numbers behind: callers that did not wait for the status see NaN
-    const bool bad = P.info[b] != 0 || P.status[ST_NOTSPD] != 0 || P.status[ST_TIMEOUT] != 0;
-    const T poison = bad ? T(__builtin_nanf("")) : T(0);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const T d = V.D[i];
-        const T xo = d * V.x[i] + poison, zo = d * V.z[i] + poison, uo = V.u[i] / d + poison;
-        P.x[(size_t)b * n + i] = xo;
-        P.z[(size_t)b * n + i] = zo;
-        P.u[(size_t)b * n + i] = uo;
-        const T y = uo * rho;
-        P.lams[(size_t)b * 2 * n + i] = (-y > T(0)) ? -y : T(0);
-        P.lams[(size_t)b * 2 * n + n + i] = (y > T(0)) ? y : T(0);
-    }
-    for (int r = threadIdx.x; r < m; r += blockDim.x) P.nus[(size_t)b * m + r] = V.nu[r] * V.E[r] + poison;
-    if (threadIdx.x == 0) P.rho_out[b] = rho;
+    fwd_finish(P, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1725,6 +1775,7 @@ template <typename T> struct BwdParams {
     int refine;  // 1: the epilogue adds rhs2 to rhs
     unsigned long long* dbg;   // optional cycle counters (8 per problem), debug only
     int la_maxk;               // largest block count the look-ahead Cholesky may take (LDS of the launch), 0 = off
+    int* host_report;          // optional pinned host memory, B ints: the epilogue leaves every problem's info word there
 };
 
 template <typename T>
@@ -2115,6 +2166,8 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     const T* x = P.x + (size_t)b * n;
     // singular system / Q_FF not positive definite: gradients come out as NaN, never as plausible garbage
     const T poison = P.info[b] != 0 ? T(__builtin_nanf("")) : T(0);
+    if (P.host_report && tid == 0 && blockIdx.y == 0)      // (straight into pinned host memory: no device-to-host copy behind the call)
+        __hip_atomic_store(P.host_report + b, P.info[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (P.reduced) {
         const int nf = P.nred[b] - m;
         const int* fl = P.fidx + (size_t)b * n;

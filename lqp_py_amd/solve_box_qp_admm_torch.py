@@ -261,9 +261,11 @@ def _beta_argument(beta, B, like):
 def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None, mutate=False):
     """bounds: (any_lb, any_ub) when the caller KNOWS them (a shard of a larger batch with host-side flags); None: found
     on the device.  mutate: apply the reference layer's dict side effect control['rho'] = 0 (:37-38)."""
+    # (what stands between the call and its first kernel launch is the forward time of a step that starts from an idle
+    #  queue -- experiment_1's protocol: errors of EARLIER calls are polled after this one is enqueued, the outputs are
+    #  one allocation)
     _lib.require_gpu(Q, p, A, b, lb, ub)
     lib = _lib.load()
-    _lib.poll_errors()
     B, n = Q.shape[0], p.shape[1]
     m = get_ncon(A, dim=1)
     dt = _lib.dtype_code(p)
@@ -302,16 +304,25 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         adaptive_rho_threshold=float(r['adaptive_rho_threshold']),
         beta_value=beta_value, beta_in=None if beta_tensor is None else beta_tensor.data_ptr(),
         bound_flags_in=None if flags_dev is None else flags_dev.data_ptr())
+    # an un-synchronised call reports straight into pinned host memory (include/lqp_amd.h: host_report)
+    report = None if sync else _lib.host_report(_lib.ST_WORDS + 2 * B)
+    if report is not None:
+        ctl.host_report = report.data_ptr()
     stats = _lib.BoxQPStats()
 
-    x = torch.empty((B, n, 1), dtype=p.dtype, device=dev)
-    z = torch.empty_like(x)
-    u = torch.empty_like(x)
-    lams = torch.empty((B, 2 * n, 1), dtype=p.dtype, device=dev)
-    nus = torch.empty((B, m, 1), dtype=p.dtype, device=dev) if m > 0 else None
-    rho_out = torch.empty((B,), dtype=p.dtype, device=dev)
+    n4 = (n + 3) // 4 * 4                  # (every output starts 16-byte aligned)
+    m4 = (m + 3) // 4 * 4
+    parts = torch.empty((B * (5 * n4 + m4 + 4),), dtype=p.dtype, device=dev).split_with_sizes(
+        (B * n4, B * n4, B * n4, 2 * B * n4, B * m4, 4 * B))
+    if n4 == n:
+        x, z, u, lams = parts[0].view(B, n, 1), parts[1].view(B, n, 1), parts[2].view(B, n, 1), parts[3].view(B, 2 * n, 1)
+    else:
+        x, z, u, lams = (parts[k][:B * n * (2 if k == 3 else 1)].view(B, n * (2 if k == 3 else 1), 1) for k in range(4))
+    nus = parts[4][:B * m].view(B, m, 1) if m > 0 else None
+    rho_out = parts[5][:B]
     nbytes = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
-    ws = _lib.workspace(dev, nbytes, "fwd")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = _lib.workspace(dev, nbytes, "fwd", stream)
     if check_hook is not None:
         # check_hook(counters) all-reduces (SUM) the four uint32 words of a check -- {not optimal, arrivals, wants rho,
         # ratio trigger} -- in place; it gets a tensor VIEW of the workspace at the device address the library names.
@@ -328,8 +339,8 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
                 return 1
         hook_c = _lib.CHECK_HOOK(_c_hook)
         ctl.check_hook = hook_c
-    with torch.cuda.device(dev):
-        st = lib.lqp_boxqp_forward(_lib.stream_ptr(dev), dt, B, n, m,
+    with _lib.on_device(dev):
+        st = lib.lqp_boxqp_forward(ctypes.c_void_p(stream), dt, B, n, m,
                                    _lib.ptr(Qc), _lib.ptr(pc), _lib.ptr(Ac), _lib.ptr(bc), _lib.ptr(lbc), _lib.ptr(ubc),
                                    ctypes.byref(ctl), _lib.ptr(rho_tensor),
                                    _lib.ptr(x), _lib.ptr(z), _lib.ptr(u), _lib.ptr(lams), _lib.ptr(nus), _lib.ptr(rho_out),
@@ -341,13 +352,14 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "
                            f"(batch index {stats.fail_index}); the KKT matrix is singular")
     _lib.check(st, "torch_solve_box_qp")
-    if stats.mode_used == 3:          # nothing was waited for: fetch status / LU info asynchronously
-        so, sb, io, ib = (ctypes.c_size_t() for _ in range(4))
-        _lib.check(lib.lqp_boxqp_forward_layout(dt, B, n, m, ctypes.byref(so), ctypes.byref(sb), ctypes.byref(io),
-                                                ctypes.byref(ib)), "forward_layout")
-        _lib.defer_check("SolveBoxQP.forward", ws, so.value, sb.value, io.value, ib.value,
+    if stats.mode_used == 3:          # nothing was waited for: the report is read once the stream has passed the call
+        _lib.defer_check("SolveBoxQP.forward", dev, report, B, True,
                          bounds_check=None if known else (any_bound, owner, mutate, _remember_any_bound))
-    elif not known and stats.any_lb >= 0:
+    elif report is not None:          # (the library waited after all: nothing left to report late)
+        _lib._pinned_free.setdefault(report.numel(), []).append(report)
+        report = None
+    _lib.poll_errors()                # (an error of an EARLIER un-synchronised call surfaces here: this call is enqueued)
+    if stats.mode_used != 3 and not known and stats.any_lb >= 0:
         # the device looked at the bounds: did the schedule we enqueued fit them?
         seen = bool(stats.any_lb or stats.any_ub)
         _remember_any_bound(owner, seen)
@@ -374,7 +386,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
                                                     _lib.ptr(pri), _lib.ptr(dua)), "last_residuals")
         sol["primal_error"], sol["dual_error"] = pri, dua
     sol["_stats"] = {k: getattr(stats, k) for k, _ in stats._fields_}
-    _last_forward[(dev.index, torch.cuda.current_stream(dev).cuda_stream)] = (
+    _last_forward[(dev.index, stream)] = (
         ws, dt, B, n, m, dict(sol["_stats"]), int(r['check_solved']), int(r['max_iters']))
     return sol
 
@@ -408,7 +420,6 @@ def last_forward_status(device):
 def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1):
     _lib.require_gpu(dl_dz, x, u, lams, nus, Q, A, lb, ub)
     lib = _lib.load()
-    _lib.poll_errors()
     B, n = Q.shape[0], Q.shape[1]
     m = get_ncon(A, dim=1)
     dt = _lib.dtype_code(x)
@@ -425,18 +436,22 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, lin
     dlb = mk(want['dlb'], (B, n, 1))
     dub = mk(want['dub'], (B, n, 1))
     nbytes = lib.lqp_boxqp_backward_fp_workspace_bytes(dt, B, n, m)
-    ws = _lib.workspace(dev, nbytes, "bwd")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = _lib.workspace(dev, nbytes, "bwd", stream)
     fail = ctypes.c_int32(-1)
-    with torch.cuda.device(dev):
-        st = lib.lqp_boxqp_backward_fp(_lib.stream_ptr(dev), dt, B, n, m,
+    report = None if sync else _lib.host_report(B)      # (the info words go straight into pinned host memory)
+    with _lib.on_device(dev):
+        st = lib.lqp_boxqp_backward_fp(ctypes.c_void_p(stream), dt, B, n, m,
                                        _lib.ptr(gc), _lib.ptr(xc), _lib.ptr(uc), _lib.ptr(lc), _lib.ptr(nc),
                                        _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
                                        rho_mode, rho_value, _lib.ptr(rho_tensor),
                                        _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
-                                       ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel(), int(linsolve))
+                                       ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel(), int(linsolve),
+                                       None if report is None else ctypes.c_void_p(report.data_ptr()))
     if st == 3:
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {fail.value})")
     _lib.check(st, "torch_solve_box_qp_grad")
-    if not sync:                        # info array sits at the start of the backward workspace
-        _lib.defer_check("SolveBoxQP.backward", ws, 0, 0, 0, 4 * B)
+    if not sync:
+        _lib.defer_check("SolveBoxQP.backward", dev, report, B, False)
+    _lib.poll_errors()
     return (dQ, dp, dA, db, dlb, dub, None)
