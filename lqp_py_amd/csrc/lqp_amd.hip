@@ -347,6 +347,23 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
     P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && env_int("LQP_RHO_LATE", 1)) ? 1 : 0;
+    // auto-scaling on: ONE pass over Q for the column maxima, the symmetry verdict and the (unscaled) blocks, in front of
+    // the setup kernel (k_spd_prep); the resident sweep scales its tiles as it loads them and sums ||Qs||_F itself
+    P.prep_fused = 0;
+#if LQP_PIV_MFMA && LQP_RS_V2 == 2
+    if constexpr (sizeof(T) == 4)
+        P.prep_fused = (spd_resident && P.scale && P.qs_lazy && (ctl->rho_mode != 0 || P.rho_late) && env_int("LQP_PREP_FUSED", 1)) ? 1 : 0;
+#endif
+    if constexpr (sizeof(T) == 4) {
+        if (P.prep_fused) {
+            const int lds = (2 * 64 * SPD_LS + 2 * LQP_NW + 64 * P.Ks) * 4;
+            const int r3 = ensure_lds((const void*)k_spd_prep, lds);
+            if (r3) return r3;
+            ProfScope ps(st, PC_SPD_INV);
+            hipLaunchKernelGGL(k_spd_prep, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P);
+            ++n_launch;
+        }
+    }
 
     // ---- setup (its workgroup 0 zeroes status + counter ring), factor, pack ----
     {
@@ -387,7 +404,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     if (!r3) r3 = ensure_lds((const void*)k_spd_step, lds);
                     if (!r3) r3 = ensure_lds((const void*)k_spd_end, lds);
                     if (r3) return r3;
-                    hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
+                    if (!(gate == nullptr && P.prep_fused))      // (the first factorisation's blocks: k_spd_prep built them)
+                        hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
                     if (spd_resident) {
                         // all pivot steps in one launch, the matrix in the registers of its two workgroups
                         auto rfn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6>

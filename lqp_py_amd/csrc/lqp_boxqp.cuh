@@ -38,6 +38,9 @@ template <typename T> struct FwdParams {
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
     int rho_late;                        // 1: rho = ||Qs||_F / sqrt(n) from the sums k_spd_begin leaves, added by k_spd_resident
+    int prep_fused;                      // 1: k_spd_prep ran BEFORE the setup kernel -- one pass over Q for the column maxima, the
+                                         //    symmetry verdict and the UNSCALED blocks; the resident sweep scales them as it loads
+                                         //    them and takes ||Qs||_F (-> rho) from its own tiles
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in, *beta_in;
@@ -224,6 +227,11 @@ __device__ __forceinline__ T setup_scale(const T* __restrict__ Q, const int n, c
     return fro2;
 }
 
+// scratch of k_spd_prep for problem b (the Qs area: unused while the scaled matrix is not stored):
+// [SPD_NP][64 Ks] column maxima | [SPD_NP] ints: symmetry verdicts
+template <typename T>
+__device__ __forceinline__ T* prep_scratch(const FwdParams<T>& P, const int b) { return P.Qs + (size_t)b * P.n * P.ldq; }
+
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -264,7 +272,15 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     if (P.scale) {
         // ---- column max of |Q| (:163): wave w sweeps rows w, w+16, ...; 16 B per lane per load ----
         const bool qvec = (n % 4 == 0) && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
-        if (qvec) {
+        int nred = LQP_NW;
+        if (P.prep_fused) {
+            // k_spd_prep has been over Q: the maxima of its SPD_NP workgroups' shares, and their symmetry verdicts
+            const T* cmp = prep_scratch(P, b);
+            for (int j = tid; j < n; j += LQP_NT) red[j] = tmax(cmp[j], cmp[P.Ks * LQP_NB + j]);
+            if (tid == 0 && (((const int*)(cmp + 2 * P.Ks * LQP_NB))[0] | ((const int*)(cmp + 2 * P.Ks * LQP_NB))[1]) != 0)
+                P.info[b] = P.Ks * 64 + 2;           // not symmetric: the LU path takes it (status word: set by the loop kernel)
+            nred = 1;
+        } else if (qvec) {
             // (several workgroups per QP for this pass: no faster -- 128 MB in 38 us either way, the HBM rate)
             setup_colmax<T, 4, 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster)
         } else {
@@ -290,8 +306,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         T part = T(0);
         for (int j = tid; j < n; j += LQP_NT) {
             T v = red[j];
-#pragma unroll
-            for (int ww = 1; ww < LQP_NW; ++ww) v = tmax(v, red[(size_t)ww * n + j]);
+            for (int ww = 1; ww < nred; ++ww) v = tmax(v, red[(size_t)ww * n + j]);
             d[j] = v;
             part += v;
         }
@@ -376,8 +391,9 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         // (symmetric path: the scaled matrix is not stored, its readers scale Q as they load it)
         T* Qw = P.qs_lazy ? nullptr : P.Qs + (size_t)b * n * ldq;
         T* Mw = P.M + (size_t)b * Np * Np;
-        if (P.rho_late && P.qs_lazy && P.spd) {
-            // nothing to store here and the norm is taken by k_spd_begin: no second pass over Q
+        if (P.qs_lazy && P.spd && (P.rho_late || (P.prep_fused && P.rho_mode != 0))) {
+            // nothing to store here and the norm (when rho is derived from it) is taken by k_spd_begin / the resident
+            // sweep: no second pass over Q
         } else if (qvec) {
             fro2 += setup_scale<T, 4, 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
         } else {
@@ -784,6 +800,18 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, 
                                                  gate == nullptr, part, dsc, fro_out);
     if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
 }
+// the first factorisation's k_spd_begin, moved IN FRONT of the setup kernel (FwdParams::prep_fused): the column maxima the
+// scaling starts from come out of the same pass over Q that checks its symmetry and builds the blocks -- unscaled; the
+// resident sweep scales them as it loads them.  One pass over Q per solve instead of two.
+static_assert(SPD_NP == 2, "k_fwd_setup reads the two halves k_spd_prep leaves");
+__global__ __launch_bounds__(LQP_NT) void k_spd_prep(const FwdParams<float> P) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
+    float* sc = prep_scratch(P, b);
+    const float asym = wg_sym_prep<SPD_NP>(spd_half(P, b, P.Ks & 1), P.Q + (size_t)b * P.n * P.n, P.n, P.n, P.Ks, (float*)smem,
+                                           part, sc + (size_t)part * P.Ks * LQP_NB);
+    if (threadIdx.x == 0) ((int*)(sc + (size_t)SPD_NP * P.Ks * LQP_NB))[part] = asym > 0.f ? 1 : 0;
+}
 __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, const int* __restrict__ gate, const int k,
                                                       const int pivot_tasks) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -813,9 +841,13 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 4;
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
     RsLateRho lr;
-    lr.on = (gate == nullptr && P.rho_late) ? 1 : 0;
+    const bool fused = gate == nullptr && P.prep_fused;     // unscaled blocks from k_spd_prep (first factorisation only)
+    lr.on = (gate == nullptr && P.rho_late && !fused) ? 1 : 0;
     lr.n = P.n; lr.rho_min = P.rho_min; lr.rho_max = P.rho_max;
     lr.rho_out = part == 0 ? P.scal + (size_t)b * SC_WORDS + SC_RHO : nullptr;
+    lr.dsc = fused ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
+    lr.fro_self = (fused && P.rho_mode == 0) ? 1 : 0;
+    lr.rho_given = (fused && P.rho_mode != 0) ? P.scal[(size_t)b * SC_WORDS + SC_RHO] : 0.f;
 #if LQP_PIV_MFMA && LQP_RS_V2 == 3
     wg_spd_sweep_resident_v3<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,

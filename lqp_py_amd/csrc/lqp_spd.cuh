@@ -224,6 +224,91 @@ __device__ __forceinline__ float wg_sym_check_init(float* __restrict__ Hs, const
     return dmax > 1e-5f * vmax ? dmax : 0.f;
 }
 
+// ONE pass over an UNSCALED src for everything that needs all of it before the scaling is known: the lower blocks as they
+// are (identity on the padding, nothing on the diagonal), the symmetry verdict of wg_sym_check_init, and the column maxima
+// of |src| (what the auto-scaling starts from, reference :163) -- of this workgroup's blocks AND their mirrors, so that the
+// NP partial vectors together cover every entry.  The readers of the blocks scale them as they load them
+// (wg_spd_sweep_resident_v2, RsLateRho::dsc).  cm_out: 64 K floats (global).
+// smem: 2 * 64 * SPD_LS + 2 * LQP_NW + 64 K floats.
+template <int NP>
+__device__ __forceinline__ float wg_sym_prep(float* __restrict__ Hs, const float* __restrict__ src, const int ld,
+                                             const int n, const int K, float* __restrict__ smem_f, const int part,
+                                             float* __restrict__ cm_out) {
+    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 4, c4 = (tid & 15) * 4;
+    float* tile = smem_f;                                   // [2][64][SPD_LS]
+    float* red = smem_f + 2 * 64 * SPD_LS;
+    unsigned int* cm = (unsigned int*)(red + 2 * LQP_NW);   // column maxima as bit patterns (non-negative floats order like integers)
+    for (int i = tid; i < 64 * K; i += (int)blockDim.x) cm[i] = 0u;
+    const bool vec_ok = (ld % 4 == 0) && ((((uintptr_t)src) & 15) == 0);
+    auto load4 = [&](const int row, const int col) -> V4<float> {      // zero outside the matrix
+        V4<float> v;
+        if (row < n && col + 3 < n && vec_ok) {
+            v = *(const V4<float>*)(src + (size_t)row * ld + col);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = (row < n && col + e < n) ? src[(size_t)row * ld + col + e] : 0.f;
+        }
+        return v;
+    };
+    auto block_of = [&](const int t, int& i, int& j) {
+        int rem = t;
+        j = 0;
+        while (rem >= K - j) { rem -= K - j; ++j; }
+        i = j + rem;
+    };
+    // max over the four rows a wave holds of one column quad, then one LDS atomic per column from lanes 0..15
+    auto col_max = [&](const V4<float>& v, const int col0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = tabs(v.v[e]);
+            a = tmax(a, __shfl_xor(a, 16));
+            a = tmax(a, __shfl_xor(a, 32));
+            if (lane < 16) atomicMax(cm + col0 + c4 + e, __float_as_uint(a));
+        }
+    };
+    float dmax = 0.f, vmax = 0.f;
+    const int nblk = sym_blocks(K);
+    int i = 0, j = 0;
+    V4<float> a, bm;
+    if (part < nblk) {
+        block_of(part, i, j);
+        a = load4(i * 64 + r, j * 64 + c4);
+        bm = load4(j * 64 + r, i * 64 + c4);
+    }
+    __syncthreads();                                        // (cm is zero)
+    int cnt = 0;
+    for (int t = part; t < nblk; t += NP, ++cnt) {
+        float* T = tile + (cnt & 1) * 64 * SPD_LS;
+        *(V4<float>*)(T + r * SPD_LS + c4) = bm;
+        const V4<float> ac = a, bc = bm;
+        const int ci = i, cj = j;
+        if (t + NP < nblk) {                                // the next block is requested before this one is used
+            block_of(t + NP, i, j);
+            a = load4(i * 64 + r, j * 64 + c4);
+            bm = load4(j * 64 + r, i * 64 + c4);
+        }
+        V4<float> v = ac;
+        const int gr = ci * 64 + r, gc = cj * 64 + c4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (gr == gc + e && gr >= n) v.v[e] = 1.f;      // identity on the padding
+        *(V4<float>*)(Hs + (size_t)sym_idx(ci, cj, K) * LQP_BLK + tid * 4) = v;
+        col_max(ac, cj * 64);
+        if (ci != cj) col_max(bc, ci * 64);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bt = T[(c4 + e) * SPD_LS + r];
+            dmax = tmax(dmax, tabs(ac.v[e] - bt));
+            vmax = tmax(vmax, tmax(tabs(ac.v[e]), tabs(bt)));
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < 64 * K; c += (int)blockDim.x) cm_out[c] = __uint_as_float(cm[c]);
+    dmax = wg_max(dmax, red);
+    vmax = wg_max(vmax, red + LQP_NW);
+    return dmax > 1e-5f * vmax ? dmax : 0.f;
+}
+
 // one 32x32 output quadrant: acc = X[x0 .. x0+31][0..63] * Z[z0 .. z0+31][0..63]^T, both operands in LDS with
 // row stride SPD_LS.  Lane l feeds row l&31 and the k range 32*(l>>5) .. +31 (any pairing of k values is a
 // valid MFMA schedule as long as A and B agree).
@@ -541,7 +626,8 @@ template <bool GSYNC = false, bool ROLES = true, bool IN_W = false>
 __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ src_blk, float* __restrict__ W,
                                                     float* __restrict__ WT, float* __restrict__ pcol,
                                                     int* __restrict__ flag, const int kbase,
-                                                    int* __restrict__ gwords = nullptr, const int gcall = 0) {
+                                                    int* __restrict__ gwords = nullptr, const int gcall = 0,
+                                                    const float diag_add = 0.f) {       // (!GSYNC: added to the tile's diagonal as it is staged)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     float* const svals = pcol;                                        // [64]: 1 / sqrt(pivot)
     int* const words = GSYNC ? gwords : (int*)(pcol + 64);            // [0] panels published, [1] consumers done
@@ -550,8 +636,14 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
     const int rbase = GSYNC ? 16 * gcall : 0, dbase = GSYNC ? 2 * gcall : 0;
     if constexpr (!GSYNC) {
         // the tile into the W area (row stride SPD_LS): one coalesced pass by the whole workgroup
-        for (int i = tid * 4; i < LQP_BLK; i += (int)blockDim.x * 4)
-            *(V4<float>*)(W + (i >> 6) * SPD_LS + (i & 63)) = *(const V4<float>*)(src_blk + i);
+        for (int i = tid * 4; i < LQP_BLK; i += (int)blockDim.x * 4) {
+            V4<float> v = *(const V4<float>*)(src_blk + i);
+            if (diag_add != 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v.v[e] += ((i >> 6) == (i & 63) + e) ? diag_add : 0.f;
+            }
+            *(V4<float>*)(W + (i >> 6) * SPD_LS + (i & 63)) = v;
+        }
         if (tid == 0) { words[0] = 0; words[1] = 0; }
         __syncthreads();
     }
@@ -1704,6 +1796,11 @@ struct RsLateRho {
     int on, n;
     float rho_min, rho_max;
     float* rho_out;           // workgroup 0 only
+    // wg_spd_sweep_resident_v2 only -- the blocks are UNSCALED (k_spd_prep built them before the scaling was known):
+    const float* dsc;         // the scaling D (n values): a tile entry is taken as (D_row * v) * D_col, like sym_scale4
+    int fro_self;             // 1: rho = clamp(||Qs||_F / sqrt(n)) with the norm summed from the tiles themselves (the two
+                              //    workgroups swap their halves with the step-0 flags); 0 (with dsc): rho_given is added
+    float rho_given;
 };
 template <int K>
 // (Hsrc and Hdst may be the same buffer -- even K: the blocks are all loaded before the first store, barriers in between)
@@ -1711,7 +1808,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* 
                                                       float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                       const unsigned int epoch, const int part, int* __restrict__ info,
                                                       int* __restrict__ status_timeout, char* smem,
-                                                      const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr},
+                                                      const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f},
                                                       const int dbg_stop = -1,
                                                       unsigned long long* __restrict__ dbg = nullptr) {
     constexpr int NS = rs_slots<K>();
@@ -1910,7 +2007,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
                                                          int* __restrict__ status_timeout, char* smem,
-                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr},
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f},
                                                          unsigned long long* __restrict__ dbg = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -1922,6 +2019,15 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
     float* pcol = WT + 64 * SPD_LS;
     int* flag = (int*)(pcol + PIV_LDS);
     if (tid == 0) flag[0] = 0;
+    // unscaled blocks (k_spd_prep): the scaling vector, 1 on the padding, in LDS while the tiles are loaded (the Y area
+    // is not written before the staging of step 0, two barriers away)
+    float* const Dl = Y;
+    static_assert(64 * K <= RS_NT, "one element of the scaling vector per thread");
+    // (requested first, staged behind the tile loads: its latency then hides under theirs)
+    const float dmine = (lr.dsc && tid < lr.n) ? lr.dsc[tid] : 1.f;
+    // step flags: one 64-bit granule per workgroup {step number, payload} -- at step 0 the payload is the workgroup's
+    // half of ||Qs||_F^2 (fro_self), so the norm costs no hand-off of its own
+    unsigned long long* const fl64 = (unsigned long long*)fl;
 
     auto body = [&](auto pivot_tag) {
         constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
@@ -1948,6 +2054,49 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
                 }
             }
+        }
+        if (lr.dsc) {
+            // unscaled blocks (k_spd_prep): entry (r, c) is taken as (D_r * v) * D_c, what sym_scale4 computes
+            Dl[tid] = dmine;
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] < 0) continue;
+                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {      // (as the lower-left entry it mirrors: row 32 + li, column quad_row)
+                    const float dr = Dl[ti[s] * 64 + 32 + li];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = (dr * T[s][q]) * Dl[tj[s] * 64 + quad_row(q, lh)];
+                } else {
+                    const float dc = Dl[tj[s] * 64 + 32 * qj + li];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = (Dl[ti[s] * 64 + 32 * qi + quad_row(q, lh)] * T[s][q]) * dc;
+                }
+            }
+        }
+        if (lr.dsc && lr.fro_self) {
+            // this wave's share of ||Qs||_F^2: tiles below the diagonal count twice, a diagonal tile's four quadrants once
+            // each (its upper-right one is held as the mirror of the lower-left one); the identity on the padding is left out
+            // (lane-dependent compares against an opaque value, formed where they are used: as invariants of the step loop
+            //  the sixteen diagonal masks would be held in scalar registers -- and spilled -- for the whole kernel)
+            float fs = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] < 0) continue;
+                float t2 = 0.f;
+                if (ti[s] == tj[s] && qi == qj) {
+                    int dqp = (ti[s] * 64 + 32 * qi + li >= lr.n) ? li - 4 * lh : -1;      // register q is a padding-diagonal entry
+                    asm volatile("" : "+v"(dqp));
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) t2 += (dqp == (q & 3) + 8 * (q >> 2)) ? 0.f : T[s][q] * T[s][q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) t2 += T[s][q] * T[s][q];
+                }
+                fs += ti[s] == tj[s] ? t2 : 2.f * t2;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) fs += __shfl_xor(fs, o);
+            if (lane == 0) WT[w] = fs;                     // (summed by thread 0 behind the first barrier of step 0)
         }
         if (lr.on) {
             const float* xw = xb + (size_t)2 * K * LQP_BLK;
@@ -1990,9 +2139,14 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                       // (also closes step k-1: every wave is done with the LDS panel)
             if (tid == 0) {
-                __hip_atomic_store(fl + part, epoch + (unsigned int)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float fmine = 0.f;
+                if (k == 0 && lr.dsc && lr.fro_self)      // this workgroup's half of the norm travels in the step-0 granule
+                    for (int ww = 0; ww < RS_NW; ++ww) fmine += WT[ww];
+                __hip_atomic_store(fl64 + part, (unsigned long long)(epoch + (unsigned int)k + 1u) |
+                                   ((unsigned long long)__float_as_uint(fmine) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(fl + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + (unsigned int)k + 1u) {
+                unsigned long long got;
+                while ((unsigned int)(got = __hip_atomic_load(fl64 + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch + (unsigned int)k + 1u) {
                     __builtin_amdgcn_s_sleep(2);
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
                         __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2001,12 +2155,36 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (k == 0 && lr.dsc && lr.fro_self) {
+                    // rho = clamp(||Qs||_F / sqrt(n)) (reference :200-203), the same bits in both workgroups
+                    const float fother = __uint_as_float((unsigned int)(got >> 32));
+                    const float f0 = part == 0 ? fmine : fother, f1 = part == 0 ? fother : fmine;
+                    float rho = sqrtf(f0 + f1) / (float)sqrt((double)lr.n);
+                    rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
+                    WT[RS_NW] = rho;
+                    if (lr.rho_out) *lr.rho_out = rho;
+                }
             }
             __syncthreads();
+            float diag_add = 0.f;
+            if (k == 0 && lr.dsc) {
+                // rho on the diagonal: of the tiles in registers, and (diag_add) of the pivot tile as it is staged -- tile
+                // (0, 0) was published without it
+                diag_add = lr.fro_self ? WT[RS_NW] : lr.rho_given;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
+                        int dq = (ti[s] * 64 + 32 * qi + li < lr.n) ? li - 4 * lh : -1;      // (opaque: see the norm above)
+                        asm volatile("" : "+v"(dq));
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) T[s][q] += (dq == (q & 3) + 8 * (q >> 2)) ? diag_add : 0.f;
+                    }
+                }
+            }
             if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
             // ---- pivot tile -> W, W^T by waves 0..3 | panel tiles -> LDS by waves 4..7 (slot s holds P_i = A_ik, i.e.
             //      block (k, i) transposed when i < k) ----
-            wg_pivot_block_mfma<false, PIVOT>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
+            wg_pivot_block_mfma<false, PIVOT>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64, nullptr, 0, diag_add);
             // (lane parts of every LDS / global address of this step, opaque: as loop invariants of the step loop they
             //  would be formed once, held in registers -- one per distinct address -- and spilled with the tiles)
             int li_s = li, lh_s = lh, tid_s = tid;
@@ -2149,7 +2327,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v3(const float* Hsrc, floa
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
                                                          int* __restrict__ status_timeout, char* smem,
-                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr},
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f},
                                                          unsigned long long* __restrict__ dbg = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;

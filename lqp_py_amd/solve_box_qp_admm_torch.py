@@ -12,6 +12,7 @@ control dict -- including its key-name traps and the caller-dict side effect --
 and moves pointers.  Tensors must be on the GPU; there is no CPU fallback.
 """
 import ctypes
+import threading
 
 import torch
 import torch.nn as nn
@@ -238,6 +239,7 @@ def _rho_argument(rho, B, like):
 
 
 _LINSOLVE = {'auto': 0, 'lu': 1, 'spd': 2, 0: 0, 1: 1, 2: 2}
+_ctl_cache = threading.local()      # .d: (control items, n, any_bound, sync, dtype) -> (resolved dict, rho, lqp_boxqp_ctrl)
 
 
 def _bad(msg):
@@ -280,30 +282,51 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         any_bound = _assume_any_bound(owner)
         if any_bound is None:                         # first solve with this control dict
             any_bound = True if sync else any(_finite_bounds(lb, ub))
-    r = resolve_control(control, n)
-    rho = r['rho']
-    if not any_bound:
-        rho = 0                                     # one iteration solves it (:157-158)
-    Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
-    rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, p)
-    beta_mode, beta_value, beta_tensor = _beta_argument(r['beta'], B, p)
-    hook_c = None
+    # the control struct of the last call with the same settings is reused (resolving ~25 keys and filling the struct
+    # costs ~15 us, in front of the first kernel launch); anything that holds a tensor (per-problem rho / beta) is
+    # resolved afresh
     flags_dev = control.get('_bound_flags_dev')       # (lqp_py_amd.dist: device-side flags of the whole batch)
-    if r['linsolve'] not in _LINSOLVE:
-        _bad("control['linsolve'] must be 'auto', 'lu' or 'spd'")
-    ctl = _lib.BoxQPCtrl(
-        linsolve=_LINSOLVE[r['linsolve']],
-        max_iters=int(r['max_iters']), check_solved=int(r['check_solved']),
-        adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
-        adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),
-        any_lb=int(any_bound), any_ub=int(any_bound), rho_mode=rho_mode,
-        beta_mode=beta_mode, launch_mode=int(r['launch_mode']), reserved=0 if sync else 1,
-        eps_abs=float(r['eps_abs']), eps_rel=float(r['eps_rel']), rho_value=rho_value,
-        rho_min=float(r['rho_min']), rho_max=float(r['rho_max']),
-        adaptive_rho_tol=float(r['adaptive_rho_tol']),
-        adaptive_rho_threshold=float(r['adaptive_rho_threshold']),
-        beta_value=beta_value, beta_in=None if beta_tensor is None else beta_tensor.data_ptr(),
-        bound_flags_in=None if flags_dev is None else flags_dev.data_ptr())
+    ckey, cached = None, None
+    cache = _ctl_cache.__dict__.setdefault('d', {})   # (per thread: the struct is written to below)
+    if check_hook is None:
+        try:
+            ckey = (tuple(kv for kv in control.items() if kv[0][0] != '_'), n, bool(any_bound), bool(sync), p.dtype)
+            cached = cache.get(ckey)
+        except Exception:                             # an unhashable value, a key that is not a string: no caching
+            ckey = None
+    if cached is not None:
+        r, rho, ctl = cached
+        rho_mode, rho_value, rho_tensor, beta_tensor = ctl.rho_mode, ctl.rho_value, None, None
+        ctl.bound_flags_in = None if flags_dev is None else flags_dev.data_ptr()
+        ctl.host_report = None
+    else:
+        r = resolve_control(control, n)
+        rho = r['rho']
+        if not any_bound:
+            rho = 0                                     # one iteration solves it (:157-158)
+        rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, p)
+        beta_mode, beta_value, beta_tensor = _beta_argument(r['beta'], B, p)
+        if r['linsolve'] not in _LINSOLVE:
+            _bad("control['linsolve'] must be 'auto', 'lu' or 'spd'")
+        ctl = _lib.BoxQPCtrl(
+            linsolve=_LINSOLVE[r['linsolve']],
+            max_iters=int(r['max_iters']), check_solved=int(r['check_solved']),
+            adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
+            adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),
+            any_lb=int(any_bound), any_ub=int(any_bound), rho_mode=rho_mode,
+            beta_mode=beta_mode, launch_mode=int(r['launch_mode']), reserved=0 if sync else 1,
+            eps_abs=float(r['eps_abs']), eps_rel=float(r['eps_rel']), rho_value=rho_value,
+            rho_min=float(r['rho_min']), rho_max=float(r['rho_max']),
+            adaptive_rho_tol=float(r['adaptive_rho_tol']),
+            adaptive_rho_threshold=float(r['adaptive_rho_threshold']),
+            beta_value=beta_value, beta_in=None if beta_tensor is None else beta_tensor.data_ptr(),
+            bound_flags_in=None if flags_dev is None else flags_dev.data_ptr())
+        if ckey is not None and rho_tensor is None and beta_tensor is None and not any(torch.is_tensor(v) for v in control.values()):
+            if len(cache) > 64:
+                cache.clear()
+            cache[ckey] = (r, rho, ctl)
+    Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
+    hook_c = None
     # an un-synchronised call reports straight into pinned host memory (include/lqp_amd.h: host_report)
     report = None if sync else _lib.host_report(_lib.ST_WORDS + 2 * B)
     if report is not None:
