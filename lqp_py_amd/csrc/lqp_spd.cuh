@@ -614,6 +614,17 @@ __device__ __forceinline__ void piv_pair(float a, float b, float& lo, float& hi)
     lo = a;
     hi = b;
 }
+// the same IN PLACE (a := lo, b := hi) for two / four independent pairs behind ONE pair of wait-state nops: the chain
+// wave is bound by its instruction count (one wave issues an instruction every ~5.7 cycles, an s_nop included --
+// tools/microbench/chain_probe.hip), and operands that die in the swap need no copies
+__device__ __forceinline__ void piv_swap2(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void piv_swap4(float& a, float& b, float& c, float& d, float& e, float& f, float& g, float& h) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
+        "v_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
 // GSYNC = false: called by ALL waves of the workgroup; W, W^T and pcol must be free (a barrier since their last use).
 // GSYNC = true : called by waves 0..3 while the rest of the workgroup does something else; src_blk is a 64x64 tile in
 //                LDS (row stride 64), gwords two LDS ints zeroed at kernel start, gcall the number of earlier calls in
@@ -669,8 +680,15 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
     // queue entry (panel P, column t): 64 floats.  Panels 8..15 start at row 32 of their area (68-float rows), so that rows
     // 0..31 of W and W^T carry nothing of the lower half: quadrant (0,0) can be stored while the lower half is eliminated.
     constexpr auto qidx = [](const int P, const int t) { return (P * 4 + t) * 64 + (P >= 8 ? 32 * SPD_LS - 2048 : 0); };
+#ifndef LQP_PIV_ABL
+#define LQP_PIV_ABL 0      // timing experiments of the chain only (results wrong): 1 no matrix instructions, 2 no look-ahead reads, 4 no queue stores, 8 no swaps
+#endif
     auto mfma = [](const float a, const float b, const f32x16 c) -> f32x16 {
+#if LQP_PIV_ABL & 1
+        f32x16 r = c; r[0] += a * b; return r;
+#else
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
     };
     auto wait_published = [&](const int target) {
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
@@ -678,40 +696,38 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         asm volatile("" ::: "memory");
     };
     // The panel's column steps on its four columns x[] (lane = row).  The dependent chain of a column is
-    //   v_readlane (pivot) -> v_rcp -> v_mul (coefficient column) -> v_fma (next column) -> v_readlane (next pivot).
-    // The chain wave is bound by instruction issue (one wave: a VALU instruction every 4-5 cycles, a v_readlane ~12), so
-    // it carries nothing else: the mask that zeroes the coefficients of the rows above the pivot (the columns' own entries
-    // there are dead, only the augmented part needs it), the scales 1 / sqrt(pivot) and the sign check of the pivots are
-    // left to the consumer waves, which find the pivots on the diagonal of the pivot-row queue.
-    // cu: the coefficient columns WITHOUT the mask.
-    auto column_steps = [&](const int c0, float (&x)[4], float (&cu)[4], auto&& after_second) {
+    //   v_readlane (pivot) -> v_rcp -> v_mul (coefficient column) -> v_fma (next column) -> v_readlane (next pivot),
+    // ~33 cycles per link; but ONE wave issues an instruction only every ~5.7 cycles whatever it is (s_nop included:
+    // tools/microbench/chain_probe.hip), and a panel is ~100 instructions: the chain wave is bound by its instruction
+    // COUNT.  So it carries nothing it can leave to others -- the mask that zeroes the coefficients of the rows above the
+    // pivot (the columns' own entries there are dead, only the augmented part needs it), the scales 1 / sqrt(pivot) and
+    // the sign check of the pivots are the consumer waves' (they find the pivots on the diagonal of the pivot-row queue) --
+    // and the coefficient columns are formed, queued and used NEGATED (ncu = -column / pivot: the negation rides on the
+    // multiply as a source modifier, every user wants the negative: fma(ncu, row entry, x), A operand of the matrix
+    // instructions), without the mask.
+    // column step t of a panel: ncu[t] and the updates of the panel's later columns
+    auto column_step = [&](const int c0, const int t, float (&x)[4], float (&ncu)[4]) {
+        const int c = c0 + t;
+        ncu[t] = x[t] * -__builtin_amdgcn_rcpf(piv_readlane(x[t], c));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int c = c0 + t;
-            cu[t] = x[t] * __builtin_amdgcn_rcpf(piv_readlane(x[t], c));
-#pragma unroll
-            for (int t2 = t + 1; t2 < 4; ++t2) x[t2] = __builtin_fmaf(-cu[t], piv_readlane(x[t2], c), x[t2]);
-            // (columns 0, 1 and their pivot rows are final: their half of the rank-4 update goes to the matrix cores now and
-            //  runs under the last two column steps; issued with the other half, the second instruction on an accumulator
-            //  would stall the wave until the first has left the pipe)
-            if (t == 1) after_second();
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int t2 = t + 1; t2 < 4; ++t2) x[t2] = __builtin_fmaf(ncu[t], piv_readlane(x[t2], c), x[t2]);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    // Rows r0 .. r0+3 of the Schur complement THROUGH the panel just eliminated.  y[] comes out of the accumulators, which
-    // hold the panels before and the first half (columns 0, 1: issued under the column steps) of this one; the second
-    // half is applied here on the vector unit: y_t -= sum_{k = 2, 3} coef_k[r0 + t] * (pivot row k) -- the same update
-    // reaches the accumulators through the matrix instructions issued next, but the chain need not wait for them.  The 8
-    // coefficients come back from the queue just written, four per broadcast read (a v_readlane costs ~12 issue cycles).
-    // Same products, same order as the matrix instructions' fma chain.
-    auto look_ahead = [&](const int P, const int r0, float (&y)[4], const float (&x)[4]) {
-        V4<float> c4[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) c4[k] = *(const V4<float>*)(queue + qidx(P, 2 + k) + r0);      // (uniform address)
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(-c4[k].v[t], x[2 + k], y[t]);
+    // The matrix instructions and the chain.  A v_mfma_f32_32x32x2 holds the pipe for 64 cycles; issued by ONE wave,
+    // a second one right behind it (or a read of its result) stalls that wave until the pipe is free -- every instruction of
+    // the chain waits with it (measured: the four of a panel cost their full 4 x 64 cycles on top of the ~530 of the rest).
+    // So (1) the four are issued >= 11 instructions apart, each where its operands have just become final, and nobody reads
+    // an accumulator less than that after it was written; (2) the rows of the NEXT panel leave the accumulators BEFORE this
+    // panel's instructions touch them (they hold the updates through the previous panel) and take this panel's rank-4
+    // update on the vector unit: y_t += sum_k ncoef_k[r0 + t] * (pivot row k), k = 0..3, the coefficients read back from
+    // the queue (one broadcast ds_read_b128 per column) -- same products, same order as the matrix instructions' chain.
+    // The accumulators' own copies of those rows get the update too (ncu is not masked) but nobody reads them again.
+    auto coef4 = [&](const int P, const int k, const int r0) -> V4<float> {
+#if LQP_PIV_ABL & 2
+        return V4<float>{{0.25f, 0.5f, 0.25f, 0.5f}};
+#else
+        return *(const V4<float>*)(queue + qidx(P, k) + r0);      // (uniform address)
+#endif
     };
     int pub = rbase;                            // (a running count, opaque: sixteen constants in sixteen registers otherwise)
     asm volatile("" : "+v"(pub));
@@ -732,47 +748,66 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         if constexpr (!GSYNC || IN_W) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the pivot-row queue overwrites these rows)
         // rows c0 .. c0+3 of S as lane vectors (lane = column; by symmetry = the panel's columns, lane = row)
         float x[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { float hi; piv_pair(S00[t], S01[t], x[t], hi); }
+        {
+            float h0 = S01[0], h1 = S01[1], h2 = S01[2], h3 = S01[3];
+            x[0] = S00[0]; x[1] = S00[1]; x[2] = S00[2]; x[3] = S00[3];
+            piv_swap4(x[0], h0, x[1], h1, x[2], h2, x[3], h3);
+        }
+        float pend_a = 0.f, pend_b = 0.f;       // operands of the previous panel's last matrix instruction (on S01)
         PIV_STAMP(1);
 #pragma unroll
         for (int P = 0; P < 8; ++P) {
-            const int c0 = 4 * P;
+            const int c0 = 4 * P, n0 = c0 + 4, q0 = 4 * (n0 / 8), LH = (n0 / 4) & 1;
             __builtin_amdgcn_sched_barrier(0);                       // (one scheduling region per panel)
-            float cu[4];
-            if (P > 0) publish(P);
-            column_steps(c0, x, cu, [&]() {
-                if (P < 7) {
-                    float a0_01, b0_01, b1_01, unused;
-                    piv_pair(-cu[0], -cu[1], a0_01, unused);
-                    piv_pair(x[0], x[1], b0_01, b1_01);
-                    S00 = mfma(a0_01, b0_01, S00);
-                    S01 = mfma(a0_01, b1_01, S01);
-                }
-            });
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                qcoef[qidx(P, t)] = cu[t];
-                qrow[qidx(P, t)] = x[t];
+            float ncu[4], y[4];
+            if (P > 0) {
+                publish(P);
+                if (P < 7) S01 = mfma(pend_a, pend_b, S01);         // (second half of panel P-1, column half 1; nobody reads it after panel 6)
             }
+            column_step(c0, 0, x, ncu);
+            column_step(c0, 1, x, ncu);
             if (P < 7) {
-                // the next panel's rows, ahead of the matrix instructions
-                const int n0 = c0 + 4, q0 = 4 * (n0 / 8), LH = (n0 / 4) & 1;
-                float y[4];
+                // the next panel's rows as the accumulators hold them: through panel P-1
+                float z[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float lo, hi;
-                    piv_pair(S00[q0 + t], S01[q0 + t], lo, hi);
-                    y[t] = LH ? hi : lo;
+                for (int t = 0; t < 4; ++t) { y[t] = S00[q0 + t]; z[t] = S01[q0 + t]; }
+                piv_swap4(y[0], z[0], y[1], z[1], y[2], z[2], y[3], z[3]);
+                if (LH) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t] = z[t];
                 }
-                look_ahead(P, n0, y, x);
-                // the other half of the rank-4 update of the rows still to come: A = -(coefficient columns), B = the pivot
-                // rows (the rows above the pivots get updates too -- cu is not masked -- but nobody reads them again)
-                float a0_23, b0_23, b1_23, unused;
-                piv_pair(-cu[2], -cu[3], a0_23, unused);
-                piv_pair(x[2], x[3], b0_23, b1_23);
-                S00 = mfma(a0_23, b0_23, S00);
-                S01 = mfma(a0_23, b1_23, S01);
+            }
+            // columns 0, 1 are final: queued, then (the coefficient columns in place: they die here) turned into the operands
+            // of their half of the rank-4 update -- A = [ncu0 | ncu1] over rows 0..31, B = the pivot rows' two column halves
+            qcoef[qidx(P, 0)] = ncu[0]; qcoef[qidx(P, 1)] = ncu[1];
+            qrow[qidx(P, 0)] = x[0]; qrow[qidx(P, 1)] = x[1];
+            float b01_lo = x[0], b01_hi = x[1];
+            V4<float> k0, k1;
+            if (P < 7) {
+                k0 = coef4(P, 0, n0); k1 = coef4(P, 1, n0);
+                piv_swap2(ncu[0], ncu[1], b01_lo, b01_hi);
+                S00 = mfma(ncu[0], b01_lo, S00);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            column_step(c0, 2, x, ncu);
+            column_step(c0, 3, x, ncu);
+            qcoef[qidx(P, 2)] = ncu[2]; qcoef[qidx(P, 3)] = ncu[3];
+            qrow[qidx(P, 2)] = x[2]; qrow[qidx(P, 3)] = x[3];
+            if (P < 7) {
+                S01 = mfma(ncu[0], b01_hi, S01);
+                const V4<float> k2 = coef4(P, 2, n0), k3 = coef4(P, 3, n0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k0.v[t], x[0], y[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k1.v[t], x[1], y[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k2.v[t], x[2], y[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k3.v[t], x[3], y[t]);
+                // the other half of the rank-4 update; its second instruction waits for the start of the next panel
+                piv_swap2(ncu[2], ncu[3], x[2], x[3]);
+                S00 = mfma(ncu[2], x[2], S00);
+                pend_a = ncu[2]; pend_b = x[3];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) x[t] = y[t];
             }
@@ -794,52 +829,66 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             float cf[4], xr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { cf[t] = qcoef[qidx(P, t)]; xr[t] = qrow[qidx(P, t)]; }
-            float a1_01, a1_23, b1_01, b1_23, unused;
-            piv_pair(-cf[0], -cf[1], unused, a1_01);
-            piv_pair(-cf[2], -cf[3], unused, a1_23);
-            piv_pair(xr[0], xr[1], unused, b1_01);
-            piv_pair(xr[2], xr[3], unused, b1_23);
-            S11 = mfma(a1_01, b1_01, S11);
-            S11 = mfma(a1_23, b1_23, S11);
+            // A = [ncf0 | ncf1] over rows 32..63, B = the pivot rows' columns 32..63: the `hi` results
+            piv_swap4(cf[0], cf[1], cf[2], cf[3], xr[0], xr[1], xr[2], xr[3]);
+            S11 = mfma(cf[1], xr[1], S11);
+            S11 = mfma(cf[3], xr[3], S11);
         }
         pub += 8;
         // rows 32 .. 35 (lanes 0-31: columns the elimination has left; the consumers' mask zeroes what they produce)
         float x[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { float hi; piv_pair(S11[t], S11[t], x[t], hi); }
+        {
+            float h0 = S11[0], h1 = S11[1], h2 = S11[2], h3 = S11[3];
+            x[0] = S11[0]; x[1] = S11[1]; x[2] = S11[2]; x[3] = S11[3];
+            piv_swap4(x[0], h0, x[1], h1, x[2], h2, x[3], h3);
+        }
         PIV_STAMP(96 + 1);
 #pragma unroll
         for (int P = 8; P < 16; ++P) {
-            const int c0 = 4 * P;
+            const int c0 = 4 * P, n0 = c0 + 4, rr = n0 - 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
             __builtin_amdgcn_sched_barrier(0);
-            float cu[4];
+            float ncu[4], y[4];
             if (P > 8) publish(P);
-            column_steps(c0, x, cu, [&]() {
-                if (P < 15) {
-                    float a1_01, b1_01, unused;
-                    piv_pair(-cu[0], -cu[1], unused, a1_01);
-                    piv_pair(x[0], x[1], unused, b1_01);
-                    S11 = mfma(a1_01, b1_01, S11);
-                }
-            });
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                qcoef[qidx(P, t)] = cu[t];
-                qrow[qidx(P, t)] = x[t];
-            }
+            column_step(c0, 0, x, ncu);
+            column_step(c0, 1, x, ncu);
             if (P < 15) {
-                const int n0 = c0 + 4, rr = n0 - 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
-                float y[4];
+                // the next panel's rows as the accumulator holds them (through panel P-1)
+                if (LH) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (LH) y[t] = S11[q0 + t];
-                    else { float hi; piv_pair(S11[q0 + t], S11[q0 + t], y[t], hi); }
+                    for (int t = 0; t < 4; ++t) y[t] = S11[q0 + t];
+                } else {
+                    float z[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { y[t] = S11[q0 + t]; z[t] = S11[q0 + t]; }
+                    piv_swap4(y[0], z[0], y[1], z[1], y[2], z[2], y[3], z[3]);
                 }
-                look_ahead(P, n0, y, x);
-                float a1_23, b1_23, unused;
-                piv_pair(-cu[2], -cu[3], unused, a1_23);
-                piv_pair(x[2], x[3], unused, b1_23);
-                S11 = mfma(a1_23, b1_23, S11);
+            }
+            qcoef[qidx(P, 0)] = ncu[0]; qcoef[qidx(P, 1)] = ncu[1];
+            qrow[qidx(P, 0)] = x[0]; qrow[qidx(P, 1)] = x[1];
+            V4<float> k0, k1;
+            float b01_lo = x[0], b01_hi = x[1];
+            if (P < 15) {
+                k0 = coef4(P, 0, n0); k1 = coef4(P, 1, n0);
+                piv_swap2(ncu[0], ncu[1], b01_lo, b01_hi);
+                S11 = mfma(ncu[1], b01_hi, S11);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            column_step(c0, 2, x, ncu);
+            column_step(c0, 3, x, ncu);
+            qcoef[qidx(P, 2)] = ncu[2]; qcoef[qidx(P, 3)] = ncu[3];
+            qrow[qidx(P, 2)] = x[2]; qrow[qidx(P, 3)] = x[3];
+            if (P < 15) {
+                const V4<float> k2 = coef4(P, 2, n0), k3 = coef4(P, 3, n0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k0.v[t], x[0], y[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k1.v[t], x[1], y[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k2.v[t], x[2], y[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k3.v[t], x[3], y[t]);
+                piv_swap2(ncu[2], ncu[3], x[2], x[3]);
+                S11 = mfma(ncu[3], x[3], S11);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) x[t] = y[t];
             }
@@ -872,21 +921,20 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
                     cf[t] = lane_p > c0 + t ? c : 0.f;
                 }
             }
-            // the panel's 4x4 unit lower triangle: coefficient of row c0+k at column step j
+            // the panel's 4x4 unit lower triangle: (negated) coefficient of row c0+k at column step j
             const float t10 = piv_readlane(cf[0], c0 + 1), t20 = piv_readlane(cf[0], c0 + 2), t30 = piv_readlane(cf[0], c0 + 3);
             const float t21 = piv_readlane(cf[1], c0 + 2), t31 = piv_readlane(cf[1], c0 + 3), t32 = piv_readlane(cf[2], c0 + 3);
             // the panel's rows of this column block, as the column steps leave them (half LH of registers q0 .. q0+3)
             float r0, r1, r2, r3;
             if (CB0 && I == 1) { r0 = Wb[q0]; r1 = Wb[q0 + 1]; r2 = Wb[q0 + 2]; r3 = Wb[q0 + 3]; }
             else { r0 = Wa[q0]; r1 = Wa[q0 + 1]; r2 = Wa[q0 + 2]; r3 = Wa[q0 + 3]; }
-            r1 = __builtin_fmaf(-t10, r0, r1);
-            r2 = __builtin_fmaf(-t21, r1, __builtin_fmaf(-t20, r0, r2));
-            r3 = __builtin_fmaf(-t32, r2, __builtin_fmaf(-t31, r1, __builtin_fmaf(-t30, r0, r3)));
-            float lo, hi, b_01, b_23, a0_01, a1_01, a0_23, a1_23;
-            piv_pair(r0, r1, lo, hi); b_01 = LH ? hi : lo;
-            piv_pair(r2, r3, lo, hi); b_23 = LH ? hi : lo;
-            piv_pair(-cf[0], -cf[1], a0_01, a1_01);
-            piv_pair(-cf[2], -cf[3], a0_23, a1_23);
+            r1 = __builtin_fmaf(t10, r0, r1);
+            r2 = __builtin_fmaf(t21, r1, __builtin_fmaf(t20, r0, r2));
+            r3 = __builtin_fmaf(t32, r2, __builtin_fmaf(t31, r1, __builtin_fmaf(t30, r0, r3)));
+            // (in place: r0 := [r0.lo | r1.lo], r1 := [r0.hi | r1.hi], ...; the coefficients arrive negated)
+            piv_swap4(r0, r1, r2, r3, cf[0], cf[1], cf[2], cf[3]);
+            const float b_01 = LH ? r1 : r0, b_23 = LH ? r3 : r2;
+            const float a0_01 = cf[0], a1_01 = cf[1], a0_23 = cf[2], a1_23 = cf[3];
             if (CB0) {
                 if (I == 0) {
                     Wa = mfma(a0_01, b_01, Wa);
