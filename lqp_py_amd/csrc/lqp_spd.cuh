@@ -597,6 +597,7 @@ __device__ __forceinline__ void wg_pivot_block(const float* __restrict__ src_blk
 #endif
 #ifdef LQP_PIV_STAMPS          // timing builds of tools/microbench only: cycle stamps of the working waves of workgroup 0
 __device__ unsigned long long* g_piv_stamps = nullptr;
+// (each stamp reloads the pointer from memory: ~400 cycles -- a run with stamps is ~25 % slower, read differences with that in mind)
 #define PIV_STAMP(slot) do { if (g_piv_stamps && blockIdx.x == 0 && lane == 0) g_piv_stamps[(slot)] = clock64(); } while (0)
 #else
 #define PIV_STAMP(slot) do { } while (0)
@@ -906,6 +907,12 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         f32x16 Wa, Wb;                   // wave 1: quadrants (0,0), (1,0); wave 2: (1,1), -
 #pragma unroll
         for (int q = 0; q < 16; ++q) { Wa[q] = qoff(q) + 4 * lh_o == li_o ? 1.f : 0.f; Wb[q] = 0.f; }
+        // row scales 1 / sqrt(pivot): pivot r sits on the diagonal of the pivot-row queue (entry r of row r).  They are taken
+        // as the panels arrive -- after every second one the eight rows 8 g .. 8 g + 7 are through, every lane reads the four
+        // of its half -- so that only the last group is left behind the chain; a pivot that is not positive (the matrix is
+        // not positive definite) is recorded like in wg_pivot_block.
+        float sc[CB0 ? 32 : 16];
+        int bad = 0;
 #pragma unroll
         for (int P = CB0 ? 0 : 8; P < 16; ++P) {                 // (column block 1 is untouched by the upper half)
             const int c0 = 4 * P, I = c0 / 32, rr = c0 % 32, q0 = 4 * (rr / 8), LH = (rr / 4) & 1;
@@ -949,21 +956,19 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
                 Wa = mfma(a1_01, b_01, Wa);
                 Wa = mfma(a1_23, b_23, Wa);
             }
+            if (P & 1) {
+                const int g = P / 2;                     // rows 8 g + e + 4 lh, e = 0..3
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rowc = 8 * g + e;
+                    const float d = dg_o[rowc * 65 + (rowc >= 32 ? 32 * SPD_LS - 2048 : 0)];
+                    bad = (!(d > 0.f) && bad == 0) ? rowc + 4 * lh_o + 1 : bad;
+                    sc[(CB0 ? 4 * g : 4 * (g - 4)) + e] = __builtin_amdgcn_rsqf(d);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         wait_published(rbase + 16);
-        // row scales 1 / sqrt(pivot): pivot r sits on the diagonal of the pivot-row queue (entry r of row r).  They are
-        // read before anybody's final stores (the queue lives in the W area); a pivot that is not positive (the matrix is
-        // not positive definite) is recorded like in wg_pivot_block.
-        float sc[CB0 ? 32 : 16];
-        int bad = 0;
-#pragma unroll
-        for (int u = 0; u < (CB0 ? 32 : 16); ++u) {
-            const int rowc = (CB0 ? 0 : 32) + 32 * (u >> 4) + 8 * ((u & 15) >> 2) + (u & 3);      // row = rowc + 4 lh
-            const float d = dg_o[rowc * 65 + (rowc >= 32 ? 32 * SPD_LS - 2048 : 0)];
-            bad = (!(d > 0.f) && bad == 0) ? rowc + 4 * lh_o + 1 : bad;
-            sc[u] = __builtin_amdgcn_rsqf(d);
-        }
         {
             const unsigned long long mb = __ballot(bad != 0);
             if (mb != 0ull && lane == 0 && flag[0] == 0) flag[0] = kbase + __builtin_amdgcn_readlane(bad, (int)__builtin_ctzll(mb));
@@ -981,13 +986,14 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         auto store_quadrant = [&](const f32x16& v, const int I, const int J, const float* scq) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
+                V4<float> v4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // (above the diagonal the unit triangle is exactly zero: 0 - coef * 0 at every step, no select needed)
-                    const float val = v[4 * a + e] * scq[4 * a + e];
-                    w_o[(32 * I + 8 * a + e) * SPD_LS + 32 * J] = val;
-                    wt_o[(32 * J) * SPD_LS + 32 * I + 8 * a + e] = val;
+                    v4.v[e] = v[4 * a + e] * scq[4 * a + e];
+                    w_o[(32 * I + 8 * a + e) * SPD_LS + 32 * J] = v4.v[e];
                 }
+                *(V4<float>*)(wt_o + (32 * J) * SPD_LS + 32 * I + 8 * a) = v4;      // (four consecutive entries of a W^T row)
             }
         };
         PIV_STAMP(w * 32 + 1);
