@@ -265,7 +265,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
     // granules of the two-workgroup loop (only ever used when 2 B workgroups fit the chip)
-    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + 2)) : nullptr;
+    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + 4)) : nullptr;
     L.bytes = c.off + kAlign;
     return L;
 }
@@ -335,14 +335,28 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
     bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= rs3_xb_floats(P.Ks) &&
                         env_int("LQP_SPD_RESIDENT", 1) != 0;
+    int rs_np = SPD_NP;                 // workgroups per matrix of the resident sweep: 2, or 4 for batches up to a quarter of the CUs
+    void (*rs_fn)(const FwdParams<float>, const int*) = nullptr;
     if (spd_resident) {
-        // its two workgroups per matrix wait for each other inside the launch: every one of the 2 B workgroups must be
-        // resident -- ask the occupancy calculator for THIS kernel (block size, registers, LDS), not just the CU count
-        auto rfn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6> : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
+        // its workgroups per matrix wait for each other inside the launch: every one of them must be resident -- ask the
+        // occupancy calculator for THIS kernel (block size, registers, LDS), not just the CU count
         int dev_ = 0, cus_ = 0, per_cu = 0;
         const int rlds = spd_lds_bytes(P.Ks);
-        spd_resident = ensure_lds((const void*)rfn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
-                       blocks_per_cu(&per_cu, rfn, RS_NT, rlds, dev_) && per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
+        bool ok = false;
+#if LQP_PIV_MFMA && LQP_RS_V2 == 2
+        if (P.Ks >= 7 && current_device_cus(&dev_, &cus_) && 4 * B <= cus_ && env_int("LQP_SPD_RESIDENT4", 1) != 0) {
+            rs_fn = P.Ks == 7 ? k_spd_resident<7, 4> : k_spd_resident<8, 4>;
+            ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) &&
+                 per_cu >= 1 && 4 * B <= cus_ * per_cu;
+            if (ok) rs_np = 4;
+        }
+#endif
+        if (!ok) {
+            rs_fn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6> : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
+            ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
+                 blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
+        }
+        spd_resident = ok;
     }
     // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
@@ -408,12 +422,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                         hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
                     if (spd_resident) {
                         // all pivot steps in one launch, the matrix in the registers of its two workgroups
-                        auto rfn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6>
-                                 : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
                         const int rlds = spd_lds_bytes(P.Ks);
-                        r3 = ensure_lds((const void*)rfn, rlds);
+                        r3 = ensure_lds((const void*)rs_fn, rlds);
                         if (r3) return r3;
-                        hipLaunchKernelGGL(rfn, dim3(B * SPD_NP), dim3(RS_NT), rlds, st, P, gate);
+                        hipLaunchKernelGGL(rs_fn, dim3(B * rs_np), dim3(RS_NT), rlds, st, P, gate);
                         n_launch += 1;
                     } else {
                         for (int k = 0; k < P.Ks; ++k)

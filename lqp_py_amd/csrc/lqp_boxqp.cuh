@@ -255,7 +255,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * XCHG_WORDS;
         for (int i = tid; i < XCHG_WORDS; i += LQP_NT) xq[i] = 0ull;
-        if (tid < 2) P.xchg[(size_t)P.B * XCHG_WORDS + 2 * b + tid] = 0ull;      // step flags of the resident sweep (4 words)
+        if (tid < 4) P.xchg[(size_t)P.B * XCHG_WORDS + 4 * b + tid] = 0ull;      // step flags of the resident sweep (one granule per workgroup)
     }
 
     // the small vectors are requested now and used after the pass over Q (n <= 1024: one element per thread; a load
@@ -833,12 +833,12 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_big_step(const FwdParams<float> 
 // all pivot steps in ONE launch, the matrix resident in the registers of its two workgroups (lqp_spd.cuh).  Reads the
 // blocks k_spd_begin built (half Ks & 1 of the packed area), leaves -(Qs + rho I)^-1 in half 0, where the loop reads it.
 // Exchange buffer: the (unused on this path) KKT-matrix area; step flags: behind the loop's exchange granules.
-template <int KS>
+template <int KS, int NP = 2>
 __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD
-    unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 4;
+    unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 8;
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
     RsLateRho lr;
     const bool fused = gate == nullptr && P.prep_fused;     // unscaled blocks from k_spd_prep (first factorisation only)
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
                                  (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
 #elif LQP_PIV_MFMA && LQP_RS_V2
-    wg_spd_sweep_resident_v2<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
+    wg_spd_sweep_resident_v2<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
                                  (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
 #else

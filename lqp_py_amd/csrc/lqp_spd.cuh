@@ -2048,15 +2048,26 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* 
 // SIMD, so every SIMD still carries 18 quadrant updates per step: the update phase stays MFMA-bound.  While waves 0..3 run
 // the pivot block, waves 4..7 stage the panel (it used to be staged by everybody afterwards).  Same exchange protocol,
 // same arithmetic per tile as wg_spd_sweep_resident; results differ from it only through the pivot block's rounding.
-template <int K> __host__ __device__ constexpr int rs2_na() {
-    const int a = split_count(K, 0), b = split_count(K, 1);
-    return ((a > b ? a : b) * 4) / 9;
+template <int K, int NP = 2> __host__ __device__ constexpr int rs2_max() {
+    int mx = 0;
+    for (int q = 0; q < NP; ++q) { const int a = split_count(K, q, NP); mx = a > mx ? a : mx; }
+    return mx;
 }
-template <int K> __host__ __device__ constexpr int rs2_nb() {
-    const int a = split_count(K, 0), b = split_count(K, 1);
-    return (a > b ? a : b) - rs2_na<K>();
+template <int K, int NP = 2> __host__ __device__ constexpr int rs2_na() { return (rs2_max<K, NP>() * 4) / 9; }
+template <int K, int NP = 2> __host__ __device__ constexpr int rs2_nb() { return rs2_max<K, NP>() - rs2_na<K, NP>(); }
+// (i, j) of local tile l of workgroup `part` of NP (columns ascending, as SplitMap)
+__device__ __forceinline__ void rs2_tile_of(int l, const int K, const int part, const int NP, int& ti, int& tj) {
+    ti = 0; tj = 0;
+    for (int j = 0; j < K; ++j) {
+        if (split_owner(j, K, NP) != part) continue;
+        if (l < K - j) { ti = j + l; tj = j; return; }
+        l -= K - j;
+    }
 }
-template <int K>
+// NP = 4 (batches up to a quarter of the CUs, K >= 7): four workgroups share a matrix, one column pair each (9 tiles at
+// K = 8: 4 + 5 per wave pair); every one of them still eliminates the pivot block and computes Y for itself -- what is
+// divided is the tile updates.  Step flags: one 64-bit granule per workgroup, a workgroup waits for all the others.
+template <int K, int NP = 2>
 __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, float* Hdst,
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
@@ -2066,7 +2077,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
-    const int nloc = split_count(K, part);
+    const int nloc = split_count(K, part, NP);
     float* Y = (float*)smem;
     float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
     float* WT = W + 64 * SPD_LS;
@@ -2085,7 +2096,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 
     auto body = [&](auto pivot_tag) {
         constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
-        constexpr int NS = PIVOT ? rs2_na<K>() : rs2_nb<K>(), FIRST = PIVOT ? 0 : rs2_na<K>();
+        constexpr int NS = PIVOT ? rs2_na<K, NP>() : rs2_nb<K, NP>(), FIRST = PIVOT ? 0 : rs2_na<K, NP>();
         // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
         f32x16 T[NS];
         int ti[NS], tj[NS];
@@ -2093,7 +2104,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
         for (int s = 0; s < NS; ++s) {
             const int l = FIRST + s;
             int a, b;
-            rs_tile_of(l < nloc ? l : 0, K, part, a, b);
+            rs2_tile_of(l < nloc ? l : 0, K, part, NP, a, b);
             ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
             tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
             if (ti[s] >= 0) {
@@ -2199,21 +2210,29 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 __hip_atomic_store(fl64 + part, (unsigned long long)(epoch + (unsigned int)k + 1u) |
                                    ((unsigned long long)__float_as_uint(fmine) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                unsigned long long got;
-                while ((unsigned int)(got = __hip_atomic_load(fl64 + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch + (unsigned int)k + 1u) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
-                        __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+                float fparts[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    fparts[q] = fmine;
+                    if (q == part) continue;
+                    unsigned long long got;
+                    while ((unsigned int)(got = __hip_atomic_load(fl64 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch + (unsigned int)k + 1u) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
+                            __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
                     }
+                    fparts[q] = __uint_as_float((unsigned int)(got >> 32));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (k == 0 && lr.dsc && lr.fro_self) {
                     // rho = clamp(||Qs||_F / sqrt(n)) (reference :200-203), the same bits in both workgroups
-                    const float fother = __uint_as_float((unsigned int)(got >> 32));
-                    const float f0 = part == 0 ? fmine : fother, f1 = part == 0 ? fother : fmine;
-                    float rho = sqrtf(f0 + f1) / (float)sqrt((double)lr.n);
+                    float fsum = fparts[0];             // (summed in part order: the same bits in every workgroup)
+#pragma unroll
+                    for (int q = 1; q < NP; ++q) fsum += fparts[q];
+                    float rho = sqrtf(fsum) / (float)sqrt((double)lr.n);
                     rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
                     WT[RS_NW] = rho;
                     if (lr.rho_out) *lr.rho_out = rho;

@@ -1177,3 +1177,29 @@ def test_four_workgroups_per_qp_loop(dev, monkeypatch, n, B, m):
         P.record("loop_np4", k, err(sols["1"][k], ref[k]), 1.0, n=n, B=B, m=m)
         assert err(sols["1"][k], sols["0"][k]) < 1e-5 * max(1.0, float(ref[k].abs().max())), k
         assert err(sols["1"][k], ref[k]) < 2e-5 * max(1.0, float(ref[k].abs().max())), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,m,scale", [(500, 8, 1, True), (448, 3, 0, True), (512, 5, 2, False), (449, 2, 0, True)])
+def test_four_workgroups_per_qp_sweep(dev, monkeypatch, n, B, m, scale):
+    """Batches up to a quarter of the CUs share the register-resident factorisation between FOUR workgroups per matrix (one
+    column pair each; the halves of ||Qs||_F -- four of them -- travel in the step-0 flag granules).  Same tile arithmetic
+    as with two: same iteration count, x within rounding of the two-workgroup sweep, and both against the CPU oracle."""
+    torch.manual_seed(7 * n + B)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=3 * n + B, with_eq=False)
+    A = torch.randn(B, m, n) if m else None
+    b = 0.1 * torch.randn(B, m, 1) if m else None
+    ctl = O.make_control(**TOL)
+    ctl["scale"] = scale
+    sols = {}
+    for np4 in ("1", "0"):
+        monkeypatch.setenv("LQP_SPD_RESIDENT4", np4)
+        sols[np4], _ = solve(dev, (Q, p, A, b, lb, ub), ctl)
+        assert sols[np4]["_stats"]["linsolve_used"] == 2 and sols[np4]["_stats"]["factor_launches"] == 3
+    assert sols["1"]["iter"] == sols["0"]["iter"]
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, ctl)
+    assert sols["1"]["iter"] == ref["iter"]
+    for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+        P.record("sweep_np4", k, err(sols["1"][k], ref[k]), 1.0, n=n, B=B, m=m)
+        assert err(sols["1"][k], sols["0"][k]) < 1e-5 * max(1.0, float(ref[k].abs().max())), k
+        assert err(sols["1"][k], ref[k]) < 2e-5 * max(1.0, float(ref[k].abs().max())), k
