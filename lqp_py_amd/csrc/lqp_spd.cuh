@@ -268,24 +268,34 @@ __device__ __forceinline__ float wg_sym_prep(float* __restrict__ Hs, const float
     };
     float dmax = 0.f, vmax = 0.f;
     const int nblk = sym_blocks(K);
-    int i = 0, j = 0;
-    V4<float> a, bm;
+    // two blocks (and their mirrors) are requested ahead of the one in use: with one, the pass ran at 3.8 TB/s
+    int i = 0, j = 0, i1 = 0, j1 = 0;
+    V4<float> a, bm, a1, bm1;
     if (part < nblk) {
         block_of(part, i, j);
         a = load4(i * 64 + r, j * 64 + c4);
         bm = load4(j * 64 + r, i * 64 + c4);
     }
+    if (part + NP < nblk) {
+        block_of(part + NP, i1, j1);
+        a1 = load4(i1 * 64 + r, j1 * 64 + c4);
+        bm1 = load4(j1 * 64 + r, i1 * 64 + c4);
+    }
     __syncthreads();                                        // (cm is zero)
     int cnt = 0;
     for (int t = part; t < nblk; t += NP, ++cnt) {
+        // the mirror's LDS tile: row stride 64 with the 16-byte chunks of row R at positions chunk ^ (R >> 2) -- the 16-byte
+        // row stores stay conflict-free and the transposed reads below hit 32 different banks per wave (with padded rows a
+        // stride that keeps 16-byte alignment puts the 16 rows a wave reads on two banks: 8-way conflicts)
         float* T = tile + (cnt & 1) * 64 * SPD_LS;
-        *(V4<float>*)(T + r * SPD_LS + c4) = bm;
+        *(V4<float>*)(T + r * 64 + 4 * ((c4 >> 2) ^ ((r >> 2) & 15))) = bm;
         const V4<float> ac = a, bc = bm;
         const int ci = i, cj = j;
-        if (t + NP < nblk) {                                // the next block is requested before this one is used
-            block_of(t + NP, i, j);
-            a = load4(i * 64 + r, j * 64 + c4);
-            bm = load4(j * 64 + r, i * 64 + c4);
+        a = a1; bm = bm1; i = i1; j = j1;
+        if (t + 2 * NP < nblk) {
+            block_of(t + 2 * NP, i1, j1);
+            a1 = load4(i1 * 64 + r, j1 * 64 + c4);
+            bm1 = load4(j1 * 64 + r, i1 * 64 + c4);
         }
         V4<float> v = ac;
         const int gr = ci * 64 + r, gc = cj * 64 + c4;
@@ -297,7 +307,7 @@ __device__ __forceinline__ float wg_sym_prep(float* __restrict__ Hs, const float
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float bt = T[(c4 + e) * SPD_LS + r];
+            const float bt = T[(c4 + e) * 64 + ((r & 3) | (4 * ((r >> 2) ^ (((c4 + e) >> 2) & 15))))];
             dmax = tmax(dmax, tabs(ac.v[e] - bt));
             vmax = tmax(vmax, tmax(tabs(ac.v[e]), tabs(bt)));
         }
@@ -730,6 +740,21 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         return *(const V4<float>*)(queue + qidx(P, k) + r0);      // (uniform address)
 #endif
     };
+    // y_t += sum_k ncoef_k[t] * x_k, two rows per instruction (v_pk_fma_f32: the chain is bound by its instruction count);
+    // per row the same four fmas in the same order
+    auto rank4 = [](float (&y)[4], const V4<float>& k0, const V4<float>& k1, const V4<float>& k2, const V4<float>& k3,
+                    const float (&x)[4]) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 y01 = f2{y[0], y[1]}, y23 = f2{y[2], y[3]};
+        const V4<float>* kk[4] = {&k0, &k1, &k2, &k3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f2 xk = f2{x[k], x[k]};
+            y01 = __builtin_elementwise_fma(f2{kk[k]->v[0], kk[k]->v[1]}, xk, y01);
+            y23 = __builtin_elementwise_fma(f2{kk[k]->v[2], kk[k]->v[3]}, xk, y23);
+        }
+        y[0] = y01[0]; y[1] = y01[1]; y[2] = y23[0]; y[3] = y23[1];
+    };
     int pub = rbase;                            // (a running count, opaque: sixteen constants in sixteen registers otherwise)
     asm volatile("" : "+v"(pub));
     auto publish = [&](const int count) {      // (the queue writes of that panel have long landed where this is called)
@@ -797,14 +822,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             if (P < 7) {
                 S01 = mfma(ncu[0], b01_hi, S01);
                 const V4<float> k2 = coef4(P, 2, n0), k3 = coef4(P, 3, n0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k0.v[t], x[0], y[t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k1.v[t], x[1], y[t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k2.v[t], x[2], y[t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k3.v[t], x[3], y[t]);
+                rank4(y, k0, k1, k2, k3, x);
                 // the other half of the rank-4 update; its second instruction waits for the start of the next panel
                 piv_swap2(ncu[2], ncu[3], x[2], x[3]);
                 S00 = mfma(ncu[2], x[2], S00);
@@ -880,14 +898,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
             qrow[qidx(P, 2)] = x[2]; qrow[qidx(P, 3)] = x[3];
             if (P < 15) {
                 const V4<float> k2 = coef4(P, 2, n0), k3 = coef4(P, 3, n0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k0.v[t], x[0], y[t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k1.v[t], x[1], y[t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k2.v[t], x[2], y[t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __builtin_fmaf(k3.v[t], x[3], y[t]);
+                rank4(y, k0, k1, k2, k3, x);
                 piv_swap2(ncu[2], ncu[3], x[2], x[3]);
                 S11 = mfma(ncu[3], x[3], S11);
 #pragma unroll

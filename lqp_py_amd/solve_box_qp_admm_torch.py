@@ -375,13 +375,15 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "
                            f"(batch index {stats.fail_index}); the KKT matrix is singular")
     _lib.check(st, "torch_solve_box_qp")
-    if stats.mode_used == 3:          # nothing was waited for: the report is read once the stream has passed the call
-        _lib.defer_check("SolveBoxQP.forward", dev, report, B, True,
-                         bounds_check=None if known else (any_bound, owner, mutate, _remember_any_bound))
-    elif report is not None:          # (the library waited after all: nothing left to report late)
-        _lib._pinned_free.setdefault(report.numel(), []).append(report)
-        report = None
-    _lib.poll_errors()                # (an error of an EARLIER un-synchronised call surfaces here: this call is enqueued)
+    try:
+        _lib.poll_errors()            # (an error of an EARLIER un-synchronised call surfaces here: this call is enqueued,
+    finally:                          #  its own report is queued behind the poll -- it is never raised at its own call)
+        if stats.mode_used == 3:      # nothing was waited for: the report is read once the stream has passed the call
+            _lib.defer_check("SolveBoxQP.forward", dev, report, B, True,
+                             bounds_check=None if known else (any_bound, owner, mutate, _remember_any_bound))
+        elif report is not None:      # (the library waited after all: nothing left to report late)
+            _lib._pinned_free.setdefault(report.numel(), []).append(report)
+            report = None
     if stats.mode_used != 3 and not known and stats.any_lb >= 0:
         # the device looked at the bounds: did the schedule we enqueued fit them?
         seen = bool(stats.any_lb or stats.any_ub)
@@ -474,7 +476,9 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, lin
     if st == 3:
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {fail.value})")
     _lib.check(st, "torch_solve_box_qp_grad")
-    if not sync:
-        _lib.defer_check("SolveBoxQP.backward", dev, report, B, False)
-    _lib.poll_errors()
+    try:
+        _lib.poll_errors()              # (errors of earlier calls; this call's own report is queued behind the poll)
+    finally:
+        if not sync:
+            _lib.defer_check("SolveBoxQP.backward", dev, report, B, False)
     return (dQ, dp, dA, db, dlb, dub, None)
