@@ -1060,6 +1060,28 @@ def test_bound_flags_come_from_the_device(dev):
     assert ctl2["rho"] == 0 and err(xa, ref["x"]) < 2e-5 and err(xb, ref0["x"]) < 2e-5
 
 
+def test_control_struct_cache_follows_the_dict(dev):
+    """The resolved control struct of the last call with the same settings is reused (host time in front of the first
+    launch); a changed value -- in place or in another dict -- must reach the library, tensors are never cached."""
+    inp = [t.to(dev) for t in O.create_qp_data(40, 4, seed=11)]
+    ctl = dict(L.box_qp_control(eps_abs=1e-3, eps_rel=1e-3))
+    loose = L.torch_solve_box_qp(*inp, ctl)
+    again = L.torch_solve_box_qp(*inp, ctl)                       # served from the cache
+    assert loose["iter"] == again["iter"] and torch.equal(loose["x"], again["x"])
+    ctl["eps_abs"] = ctl["eps_rel"] = 1e-6                          # the same dict, mutated in place
+    tight = L.torch_solve_box_qp(*inp, ctl)
+    assert tight["iter"] > loose["iter"]
+    ref = O.solve_box_qp(*[t.cpu() for t in inp], O.make_control(eps_abs=1e-6, eps_rel=1e-6))
+    assert tight["iter"] == ref["iter"] and err(tight["x"], ref["x"]) < 2e-5
+    ctl["max_iters"] = 3
+    assert L.torch_solve_box_qp(*inp, ctl)["iter"] == 2
+    rho_t = torch.full((4, 1, 1), 0.7, device=dev)                 # per-problem rho: resolved afresh every call
+    a = L.torch_solve_box_qp(*inp, dict(ctl, max_iters=200, rho=rho_t))
+    rho_t.fill_(5.0)
+    b = L.torch_solve_box_qp(*inp, dict(ctl, max_iters=200, rho=rho_t))
+    assert not torch.equal(a["x"], b["x"]) or a["iter"] != b["iter"]
+
+
 def test_pipelined_calls_verify_the_bound_assumption_late(dev):
     """control['sync'] = False cannot repeat a solve: a batch whose 'any finite bound?' differs from what the previous
     solve with the same control saw is reported late; the next call then runs the right schedule."""
