@@ -104,8 +104,9 @@ typedef struct lqp_boxqp_ctrl {
                                         lqp_boxqp_forward_layout), [16..16+B) the info word of every problem,
                                         [16+B..16+2B) per-problem flag bits {1: a lower bound is finite, 2: an upper
                                         bound is finite, 4: its workgroup saw a barrier timeout, 8: its matrix left the
-                                        symmetric x-update}.  Valid once the stream has passed the call (an event).
-                                        Meant for ctrl.reserved = 1 callers, who must not wait for the device.    */
+                                        symmetric x-update}.  Valid once the stream has passed the call (an event):
+                                        ctrl.reserved = 1 callers read it then; a synchronous call reads its status
+                                        and info words from it right after its own wait instead of copying them.   */
 } lqp_boxqp_ctrl;
 
 /* Host-side bookkeeping returned by the forward solve. */
@@ -200,7 +201,9 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
                           int32_t* fail_index,
                           void* workspace, size_t workspace_bytes,
                           int linsolve,
-                          void* host_report);
+                          void* host_report);   /* NULL, or pinned host memory of B int32: the last kernel stores the
+                                                   per-problem info words there (read instead of a copy when
+                                                   fail_index is given, left for the caller when it is NULL)    */
 
 /* ---- batched LU (partial pivoting) and cached LU solve ------------------
  * Replace torch.linalg.lu_factor / lu_solve as used by lqp_py/lu_layer.py:

@@ -225,13 +225,22 @@ int launch_solve(hipStream_t st, int B, const T* packed, int N, const int* dest,
 }
 
 // first failing batch index from the per-problem info array (host side, after a sync)
-int first_failure(hipStream_t st, const int* info_dev, int B, int* fail_index) {
-    std::vector<int> h(B);
-    HIP_OK(hipMemcpyAsync(h.data(), info_dev, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+// host_info: the same words in pinned host memory, stored there by the last kernel the stream has run (host_report): the
+// stream is waited for, nothing is copied
+int first_failure(hipStream_t st, const int* info_dev, int B, int* fail_index, const int* host_info = nullptr) {
+    std::vector<int> h;
+    const int* words = host_info;
+    if (host_info) {
+        HIP_OK(hipStreamSynchronize(st));
+    } else {
+        h.resize(B);
+        HIP_OK(hipMemcpyAsync(h.data(), info_dev, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        words = h.data();
+    }
     *fail_index = -1;
     for (int i = 0; i < B; ++i)
-        if (h[i] != 0) { *fail_index = i; return LQP_ERR_SINGULAR; }
+        if (((const volatile int*)words)[i] != 0) { *fail_index = i; return LQP_ERR_SINGULAR; }
     return LQP_OK;
 }
 
@@ -707,13 +716,21 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         { ProfScope ps(st, PC_EPILOGUE);
           hipLaunchKernelGGL(k_fwd_epilogue<T>, dim3(B), dim3(256), 0, st, P); }
         ++n_launch;
-        HIP_OK(hipMemcpyAsync(h_status, P.status, sizeof(h_status), hipMemcpyDeviceToHost, st));
+        // (with a host report the epilogue has left status and info words in pinned host memory: one wait, no copies)
+        if (!P.host_report) HIP_OK(hipMemcpyAsync(h_status, P.status, sizeof(h_status), hipMemcpyDeviceToHost, st));
+        auto fetch_status = [&]() -> int {
+            HIP_OK(hipStreamSynchronize(st));
+            if (P.host_report)
+                for (int i = 0; i < ST_WORDS; ++i) h_status[i] = ((const volatile int*)P.host_report)[i];
+            return LQP_OK;
+        };
         // A failed factorisation ends or restarts the solve.  With a check hook (strict global stop over batch shards)
         // that decision must be the same on every rank -- a rank that restarted alone would pair its collectives with
         // other checks of its peers -- so the local verdict goes through the hook (SUM over the ranks) first.
         // returns LQP_OK, an error, or -1: repeat the solve on the LU path
         auto after_factorisation = [&]() -> int {
-            int rcf = first_failure(st, P.info, B, &fail_index);      // synchronises
+            int rcf = first_failure(st, P.info, B, &fail_index, P.host_report ? P.host_report + ST_WORDS : nullptr);      // synchronises
+            if (rcf == LQP_OK || rcf == LQP_ERR_SINGULAR) { const int r4 = fetch_status(); if (r4) return r4; }
             if (rcf != LQP_OK && rcf != LQP_ERR_SINGULAR) return rcf;
             bool leave_spd = rcf == LQP_ERR_SINGULAR && spd, singular = rcf == LQP_ERR_SINGULAR && !spd;
             if (ctl->check_hook) {
@@ -739,7 +756,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                                        ws, ws_bytes, true);
             if (rc) return rc;
         } else {
-            HIP_OK(hipStreamSynchronize(st));
+            { const int r4 = fetch_status(); if (r4) return r4; }
             if (h_status[ST_NFACTOR] != nfactor_seen) {      // an adaptive-rho refactorisation ran in this chunk
                 rc = after_factorisation();
                 if (rc == -1)
@@ -876,7 +893,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
     if (fail_index) {
         int fi = -1;
-        rc = first_failure(st, P.info, B, &fi);       // torch.linalg.solve checks info (and syncs) too
+        rc = first_failure(st, P.info, B, &fi, P.host_report);       // torch.linalg.solve checks info (and syncs) too
         if (rc == LQP_ERR_SINGULAR && chol)           // Q_FF not positive definite in f32: the pivoted LU takes it
             return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
                                     db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report);

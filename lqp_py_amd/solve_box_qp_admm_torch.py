@@ -327,10 +327,10 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
             cache[ckey] = (r, rho, ctl)
     Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
     hook_c = None
-    # an un-synchronised call reports straight into pinned host memory (include/lqp_amd.h: host_report)
-    report = None if sync else _lib.host_report(_lib.ST_WORDS + 2 * B)
-    if report is not None:
-        ctl.host_report = report.data_ptr()
+    # status / info words arrive in pinned host memory, stored there by the forward's last kernel (include/lqp_amd.h:
+    # host_report): an un-synchronised call reads them later, a synchronous one right after its wait -- no copies either way
+    report = _lib.host_report(_lib.ST_WORDS + 2 * B)
+    ctl.host_report = report.data_ptr()
     stats = _lib.BoxQPStats()
 
     n4 = (n + 3) // 4 * 4                  # (every output starts 16-byte aligned)
@@ -464,7 +464,7 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, lin
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = _lib.workspace(dev, nbytes, "bwd", stream)
     fail = ctypes.c_int32(-1)
-    report = None if sync else _lib.host_report(B)      # (the info words go straight into pinned host memory)
+    report = _lib.host_report(B)                        # (the info words go straight into pinned host memory)
     with _lib.on_device(dev):
         st = lib.lqp_boxqp_backward_fp(ctypes.c_void_p(stream), dt, B, n, m,
                                        _lib.ptr(gc), _lib.ptr(xc), _lib.ptr(uc), _lib.ptr(lc), _lib.ptr(nc),
@@ -481,4 +481,6 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, lin
     finally:
         if not sync:
             _lib.defer_check("SolveBoxQP.backward", dev, report, B, False)
+        else:
+            _lib._pinned_free.setdefault(report.numel(), []).append(report)
     return (dQ, dp, dA, db, dlb, dub, None)

@@ -12,7 +12,8 @@ dev = torch.device("cuda:0")
 B, n = int(os.environ.get("B", 1024)), int(os.environ.get("N", 500))
 FWD_ONLY = os.environ.get("FWD_ONLY", "0") == "1"      # (BASELINE configs 2 / 4 are forward-only)
 inp = [t.to(dev) for t in create_qp_data(n, B, seed=0)]
-qp = L.SolveBoxQP(control=dict(L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5), sync=False))
+extra = {"linsolve": os.environ["LINSOLVE"]} if os.environ.get("LINSOLVE") else {}
+qp = L.SolveBoxQP(control=dict(L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5), sync=False, **extra))
 ones = torch.ones(B, n, 1, device=dev)
 def step():
     Q = inp[0].detach().requires_grad_(True); p = inp[1].detach().requires_grad_(True)
