@@ -274,7 +274,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
     // granules of the two-workgroup loop (only ever used when 2 B workgroups fit the chip)
-    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + 4)) : nullptr;
+    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + XCHG_TAIL)) : nullptr;
     L.bytes = c.off + kAlign;
     return L;
 }
@@ -292,6 +292,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
     P.scale = ctl->scale; P.bound_flags_in = (const int*)ctl->bound_flags_in;
     P.host_report = (int*)ctl->host_report;
+    P.xcd_local = env_int("LQP_XCD_LOCAL", 1) != 0 ? 1 : 0;
     P.zero_words = (int)(((char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status) / sizeof(int));
     P.dbg = g_lu_dbg;
     P.dbg_setup = nullptr;

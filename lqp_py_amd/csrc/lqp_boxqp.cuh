@@ -27,6 +27,11 @@ enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_PRI = 4, SC_DUA 
 
 constexpr int XCHG_NPMAX = 4;                                // workgroups per QP of the shared loop, at most
 constexpr int XCHG_WORDS = 2 * XCHG_NPMAX * SPD_MAXK * LQP_NB;      // exchange granules per QP of the shared loop: [parity][part][element]
+// behind the granules of all QPs, per QP: [0..4) step granules of the resident sweep's workgroups | [4..8) the XCD ids its
+// workgroups announce | [8..12) the same for the shared loop (XCHG_TAIL words; zeroed by the setup kernel)
+constexpr int XCHG_TAIL = 12;
+// the XCD this workgroup runs on (0..7)
+__device__ __forceinline__ unsigned int my_xcd() { return (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu; }
 
 template <typename T> struct FwdParams {
     int B, n, m, N, Np, K, ldq;          // ldq: leading dim of Qs
@@ -45,6 +50,7 @@ template <typename T> struct FwdParams {
     // inputs
     const T *Q, *p, *A, *b, *lb, *ub, *rho_in, *beta_in;
     const int* bound_flags_in;           // optional {any_lb, any_ub} of a LARGER batch this call is a shard of (device), or null
+    int xcd_local;                       // 1: workgroups that share a matrix and find themselves on ONE XCD exchange through its L2
     int* host_report;                    // optional pinned host memory, ST_WORDS + 2 B ints (see RP_*), or null
     int zero_words;                      // ints from `status` on (status block + counter ring) that workgroup 0 of k_fwd_setup zeroes
     // outputs
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * XCHG_WORDS;
         for (int i = tid; i < XCHG_WORDS; i += LQP_NT) xq[i] = 0ull;
-        if (tid < 4) P.xchg[(size_t)P.B * XCHG_WORDS + 4 * b + tid] = 0ull;      // step flags of the resident sweep (one granule per workgroup)
+        if (tid < XCHG_TAIL) P.xchg[(size_t)P.B * XCHG_WORDS + XCHG_TAIL * b + tid] = 0ull;      // step granules of the resident sweep, XCD announcements
     }
 
     // the small vectors are requested now and used after the pass over Q (n <= 1024: one element per thread; a load
@@ -838,7 +844,7 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD
-    unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS) + (size_t)b * 8;
+    unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS + (size_t)XCHG_TAIL * b);
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
     RsLateRho lr;
     const bool fused = gate == nullptr && P.prep_fused;     // unscaled blocks from k_spd_prep (first factorisation only)
@@ -848,6 +854,7 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     lr.dsc = fused ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
     lr.fro_self = (fused && P.rho_mode == 0) ? 1 : 0;
     lr.rho_given = (fused && P.rho_mode != 0) ? P.scal[(size_t)b * SC_WORDS + SC_RHO] : 0.f;
+    lr.xcd_local = P.xcd_local;
 #if LQP_PIV_MFMA && LQP_RS_V2 == 3
     wg_spd_sweep_resident_v3<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
@@ -1367,7 +1374,34 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     for (int i = tid; i < m * Nps; i += NT) { const int q = i / Nps, e = i - q * Nps; Asl[i] = e < n ? V.As[(size_t)q * n + e] : T(0); }
     for (int i = tid; i < NWV * Nps; i += NT) part[i] = T(0);
     if (tid < 8) flags[tid] = 0;
+    // Which XCD are the workgroups of this QP on?  Each announces its id (write-through store, at once) and reads the
+    // others' here, a whole load phase later.  On ONE XCD its L2 is their point of coherence: the granules are then stored
+    // with workgroup scope (they stay in that L2; an sc1 store drops the line and the reader goes to memory for it) and
+    // read as before (sc1 loads bypass the reader's L1 only).  Placement is the dispatcher's: never assumed, always asked.
+    unsigned long long* const xcw = P.xchg + (size_t)P.B * XCHG_WORDS + (size_t)XCHG_TAIL * b + 8;
+    const unsigned int xcd_me = my_xcd();
+    if (tid == 0) __hip_atomic_store(xcw + part_id, 0x100ull | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    if (tid == 0) {
+        int same = P.xcd_local;
+        for (int pp = 0; pp < NP && same; ++pp) {
+            if (pp == part_id) continue;
+            unsigned long long g = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (((g = __hip_atomic_load(xcw + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x100ull) == 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ULL) { g = ~0ull; break; }      // (0.5 s: the exchange below will flag it)
+            }
+            same = (unsigned int)(g & 0xFFull) == xcd_me;
+        }
+        flags[2] = same;
+    }
+    __syncthreads();
+    const bool xlocal = flags[2] != 0;
+    auto xstore = [&](unsigned long long* ptr, const unsigned long long val) {
+        if (xlocal) __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
 
     // ---- equality constraints: H <- H + T G^T with G = K^-1 As^T, S = As G, T = G S^-1 (what wg_eq_correct does to the
     //      blocks in global memory, three passes over them in a launch of its own) applied to the blocks in REGISTERS:
@@ -1389,9 +1423,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
                 const T own = split_combine<NT>(i, Nps, yrow, part);
                 const unsigned int tag = 0x20000000u + (unsigned int)q;
                 unsigned long long* base = xq + (size_t)(q & 1) * XPAR;
-                __hip_atomic_store(base + (size_t)part_id * XPART + i,
-                                   ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, own),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xstore(base + (size_t)part_id * XPART + i,
+                       ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, own));
                 T y = T(0);
 #pragma unroll
                 for (int pp = 0; pp < NP; ++pp) {                 // same order on every workgroup
@@ -1552,10 +1585,9 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             // ---- exchange: publish this element's partial (part 0: with the verdict), fetch the partner's ----
             const unsigned int tag = (unsigned int)(it + 1);
             unsigned long long* base = xq + (size_t)((it + moff) & 1) * XPAR;
-            __hip_atomic_store(base + (size_t)part_id * XPART + i,
-                               ((unsigned long long)(tag | ((unsigned int)verdict << 30)) << 32) |
-                                   (unsigned long long)__builtin_bit_cast(unsigned int, own),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xstore(base + (size_t)part_id * XPART + i,
+                   ((unsigned long long)(tag | ((unsigned int)verdict << 30)) << 32) |
+                       (unsigned long long)__builtin_bit_cast(unsigned int, own));
             if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
             T y = T(0);
 #pragma unroll

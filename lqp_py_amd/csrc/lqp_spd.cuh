@@ -1866,6 +1866,7 @@ struct RsLateRho {
     int fro_self;             // 1: rho = clamp(||Qs||_F / sqrt(n)) with the norm summed from the tiles themselves (the two
                               //    workgroups swap their halves with the step-0 flags); 0 (with dsc): rho_given is added
     float rho_given;
+    int xcd_local;            // 1: workgroups that find themselves on ONE XCD exchange through its L2 (workgroup-scope stores)
 };
 template <int K>
 // (Hsrc and Hdst may be the same buffer -- even K: the blocks are all loaded before the first store, barriers in between)
@@ -1873,7 +1874,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* 
                                                       float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                       const unsigned int epoch, const int part, int* __restrict__ info,
                                                       int* __restrict__ status_timeout, char* smem,
-                                                      const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f},
+                                                      const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
                                                       const int dbg_stop = -1,
                                                       unsigned long long* __restrict__ dbg = nullptr) {
     constexpr int NS = rs_slots<K>();
@@ -2083,7 +2084,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
                                                          int* __restrict__ status_timeout, char* smem,
-                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f},
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
                                                          unsigned long long* __restrict__ dbg = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -2104,6 +2105,12 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
     // step flags: one 64-bit granule per workgroup {step number, payload} -- at step 0 the payload is the workgroup's
     // half of ||Qs||_F^2 (fro_self), so the norm costs no hand-off of its own
     unsigned long long* const fl64 = (unsigned long long*)fl;
+    // Which XCD are the workgroups of this matrix on?  Each announces its id now (write-through store) and reads the others'
+    // after its tile loads.  On ONE XCD its L2 is their point of coherence: tiles and step granules are then stored with
+    // workgroup scope -- they stay in that L2 instead of being written through to memory and fetched back from there
+    // (131 MB per sweep of the batch) -- and read as before behind the acquire.  Never assumed: asked at every launch.
+    const unsigned int xcd_me = (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
+    if (tid == 0) __hip_atomic_store(fl64 + 4 + part, ((unsigned long long)(epoch + 1u) << 8) | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     auto body = [&](auto pivot_tag) {
         constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
@@ -2191,6 +2198,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
         unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
         // publish the pivot tile and the panel tiles of step kk this wave holds (as soon as ITS quadrants have step kk-1's
         // update: the store drain then overlaps with the wait for the slowest wave)
+        bool xlocal_p = false;          // (set before the first publish)
         auto publish = [&](const int kk) {
             float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
 #pragma unroll
@@ -2199,15 +2207,41 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 if (i >= 0 && (i == kk || j == kk)) {
                     const int slot = (i == kk && j == kk) ? K - 1 : (j == kk ? i - 1 : j);      // P_i: i > kk -> i - 1, i < kk -> i
                     unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
+                    if (xlocal_p) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float tv = T[s][q];
-                        __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int q = 0; q < 16; ++q) {
+                            const float tv = T[s][q];
+                            __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float tv = T[s][q];
+                            __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
         };
+        if (tid == 0) {
+            int same = lr.xcd_local;
+            for (int q = 0; q < NP && same; ++q) {
+                if (q == part) continue;
+                unsigned long long g = 0;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (((g = __hip_atomic_load(fl64 + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned long long)(epoch + 1u)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) { g = ~0ull; break; }      // (1 s: the step flags below will flag it)
+                }
+                same = (unsigned int)(g & 0xFFull) == xcd_me;
+            }
+            flag[1] = same;
+        }
+        __syncthreads();
+        const bool xlocal = flag[1] != 0;
+        xlocal_p = xlocal;
         publish(0);
         for (int k = 0; k < K; ++k) {
             if (dbg) dt0 = clock64();
@@ -2218,8 +2252,9 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 float fmine = 0.f;
                 if (k == 0 && lr.dsc && lr.fro_self)      // this workgroup's half of the norm travels in the step-0 granule
                     for (int ww = 0; ww < RS_NW; ++ww) fmine += WT[ww];
-                __hip_atomic_store(fl64 + part, (unsigned long long)(epoch + (unsigned int)k + 1u) |
-                                   ((unsigned long long)__float_as_uint(fmine) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long gran = (unsigned long long)(epoch + (unsigned int)k + 1u) | ((unsigned long long)__float_as_uint(fmine) << 32);
+                if (xlocal) __hip_atomic_store(fl64 + part, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(fl64 + part, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 float fparts[NP];
 #pragma unroll
@@ -2411,7 +2446,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v3(const float* Hsrc, floa
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
                                                          int* __restrict__ status_timeout, char* smem,
-                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f},
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
                                                          unsigned long long* __restrict__ dbg = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
