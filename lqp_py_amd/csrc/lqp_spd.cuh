@@ -636,6 +636,16 @@ __device__ __forceinline__ void piv_swap4(float& a, float& b, float& c, float& d
         "v_permlane32_swap_b32 %6, %7\n\ts_nop 1"
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
 }
+// 16 bytes another workgroup of this launch has stored (and signalled): two 8-byte agent-scope loads -- they bypass this CU's
+// L1, which may still hold the line from an earlier step, so the reader needs no L1 invalidate (acquire fence) at all
+__device__ __forceinline__ V4<float> ld16_handoff(const float* __restrict__ p) {
+    const unsigned long long a = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    V4<float> v;
+    v.v[0] = __uint_as_float((unsigned int)a); v.v[1] = __uint_as_float((unsigned int)(a >> 32));
+    v.v[2] = __uint_as_float((unsigned int)b); v.v[3] = __uint_as_float((unsigned int)(b >> 32));
+    return v;
+}
 // GSYNC = false: called by ALL waves of the workgroup; W, W^T and pcol must be free (a barrier since their last use).
 // GSYNC = true : called by waves 0..3 while the rest of the workgroup does something else; src_blk is a 64x64 tile in
 //                LDS (row stride 64), gwords two LDS ints zeroed at kernel start, gcall the number of earlier calls in
@@ -649,7 +659,8 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
                                                     float* __restrict__ WT, float* __restrict__ pcol,
                                                     int* __restrict__ flag, const int kbase,
                                                     int* __restrict__ gwords = nullptr, const int gcall = 0,
-                                                    const float diag_add = 0.f) {       // (!GSYNC: added to the tile's diagonal as it is staged)
+                                                    const float diag_add = 0.f,         // (!GSYNC: added to the tile's diagonal as it is staged)
+                                                    const bool handoff = false) {       // (!GSYNC: src_blk was stored by another workgroup of this launch)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     float* const svals = pcol;                                        // [64]: 1 / sqrt(pivot)
     int* const words = GSYNC ? gwords : (int*)(pcol + 64);            // [0] panels published, [1] consumers done
@@ -659,7 +670,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
     if constexpr (!GSYNC) {
         // the tile into the W area (row stride SPD_LS): one coalesced pass by the whole workgroup
         for (int i = tid * 4; i < LQP_BLK; i += (int)blockDim.x * 4) {
-            V4<float> v = *(const V4<float>*)(src_blk + i);
+            V4<float> v = handoff ? ld16_handoff(src_blk + i) : *(const V4<float>*)(src_blk + i);
             if (diag_add != 0.f) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v.v[e] += ((i >> 6) == (i & 63) + e) ? diag_add : 0.f;
@@ -2271,8 +2282,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     }
                     fparts[q] = __uint_as_float((unsigned int)(got >> 32));
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (no acquire fence: every load of the partner's tiles bypasses this CU's L1 -- ld16_handoff -- and the polls
+                //  above have matched before anybody loads, the barrier below in between)
                 if (k == 0 && lr.dsc && lr.fro_self) {
                     // rho = clamp(||Qs||_F / sqrt(n)) (reference :200-203), the same bits in both workgroups
                     float fsum = fparts[0];             // (summed in part order: the same bits in every workgroup)
@@ -2303,7 +2314,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
             // ---- pivot tile -> W, W^T by waves 0..3 | panel tiles -> LDS by waves 4..7 (slot s holds P_i = A_ik, i.e.
             //      block (k, i) transposed when i < k) ----
-            wg_pivot_block_mfma<false, PIVOT>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64, nullptr, 0, diag_add);
+            wg_pivot_block_mfma<false, PIVOT>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64, nullptr, 0, diag_add, true);
             // (lane parts of every LDS / global address of this step, opaque: as loop invariants of the step loop they
             //  would be formed once, held in registers -- one per distinct address -- and spilled with the tiles)
             int li_s = li, lh_s = lh, tid_s = tid;
@@ -2318,7 +2329,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         const float* src = src_l + s0 * LQP_BLK + 32 * hf * 64;
-                        const V4<float> a = *(const V4<float>*)src, b = *(const V4<float>*)(src + 4);
+                        const V4<float> a = ld16_handoff(src), b = ld16_handoff(src + 4);
                         if (s0 >= k) {
                             *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS) = a;
                             *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS + 4) = b;

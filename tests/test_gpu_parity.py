@@ -1060,6 +1060,28 @@ def test_bound_flags_come_from_the_device(dev):
     assert ctl2["rho"] == 0 and err(xa, ref["x"]) < 2e-5 and err(xb, ref0["x"]) < 2e-5
 
 
+@pytest.mark.parametrize("n,B,m", [(500, 8, 1), (500, 16, 0), (448, 5, 2), (512, 3, 0)])
+def test_xcd_local_exchange_is_only_a_transport(dev, monkeypatch, n, B, m):
+    """Workgroups that share a matrix and find themselves on one XCD (B a multiple of 8 under round-robin placement) exchange
+    tiles and granules through that XCD's L2 (workgroup-scope stores); otherwise, and with LQP_XCD_LOCAL=0, through
+    write-through stores.  Only the transport differs: bit-identical outputs, same iteration count."""
+    torch.manual_seed(n + 3 * B)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=5 * n + B, with_eq=False)
+    A = torch.randn(B, m, n) if m else None
+    b = 0.1 * torch.randn(B, m, 1) if m else None
+    ctl = O.make_control(**TOL)
+    sols = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("LQP_XCD_LOCAL", knob)
+        sols[knob], _ = solve(dev, (Q, p, A, b, lb, ub), ctl)
+        assert sols[knob]["_stats"]["factor_launches"] == 3 and sols[knob]["_stats"]["loop_workgroups"] >= 2
+    assert sols["1"]["iter"] == sols["0"]["iter"]
+    for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+        assert torch.equal(sols["1"][k], sols["0"][k]), k
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, ctl)
+    assert sols["1"]["iter"] == ref["iter"] and err(sols["1"]["x"], ref["x"]) < 2e-5 * max(1.0, float(ref["x"].abs().max()))
+
+
 def test_control_struct_cache_follows_the_dict(dev):
     """The resolved control struct of the last call with the same settings is reused (host time in front of the first
     launch); a changed value -- in place or in another dict -- must reach the library, tensors are never cached."""
