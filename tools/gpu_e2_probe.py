@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The layer alone at the minibatch of experiment 2 (B = 32, n = 500, default synchronous calls): forward / backward wall time with
+only p requiring a gradient and with Q too, plus the kernel classes of one step -- what of experiment 2's epoch is the layer."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import lqp_py_amd as L
