@@ -981,8 +981,9 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
     if (it0 >= it1) return;
     if constexpr (TAIL && sizeof(T) == 4 && NT == 1024 && !SYM) {   // f64 / symmetric path keep the separate gated kernels
         if ((persistent & 2) && prev_slot >= 0) {
-            const unsigned int* ctl = P.counters + (size_t)prev_slot * CT_WORDS;
-            if (ctl[CT_WANTS] > 0 && ctl[CT_TRIG] > 0) {                     // uniform over the whole grid
+            unsigned int* ctl = P.counters + (size_t)prev_slot * CT_WORDS;
+            if (__hip_atomic_load(ctl + CT_WANTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+                __hip_atomic_load(ctl + CT_TRIG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {          // uniform over the whole grid
                 constexpr int kPB = sizeof(T) == 4 ? 16 : 8;
                 T* scal_ = P.scal + (size_t)b * SC_WORDS;
                 VecView<T> V_(P.vecs + (size_t)b * P.vstride, n, m);
@@ -1040,8 +1041,9 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
             const int nxt = (seg0 / P.ar_iter + 1) * P.ar_iter;
             if (nxt < P.ar_max && nxt < seg1) seg1 = nxt;
             if (seg0 > 0 && seg0 % P.ar_iter == 0 && seg0 < P.ar_max) {
-                const unsigned int* ctl = P.counters + (size_t)(((seg0 - 1) / P.check_solved) % P.ring) * CT_WORDS;
-                if (ctl[CT_WANTS] > 0 && ctl[CT_TRIG] > 0) {                 // uniform over the whole grid
+                unsigned int* ctl = P.counters + (size_t)(((seg0 - 1) / P.check_solved) % P.ring) * CT_WORDS;
+                if (__hip_atomic_load(ctl + CT_WANTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+                    __hip_atomic_load(ctl + CT_TRIG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {      // uniform over the whole grid
                     T rho_ = scal[SC_RHO];
                     if (scal[SC_WANTS] != T(0)) rho_ = rho_ * scal[SC_RATIO];
                     rho_ = tmin(tmax(rho_, P.rho_min), P.rho_max);
@@ -1212,18 +1214,23 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
                 scal[SC_WANTS] = wants ? T(1) : T(0);
                 scal[SC_PRI] = mv[0];                        // primal / dual error of this check (the NumPy twin returns them)
                 scal[SC_DUA] = mv[1];
-                if (!solved) atomicAdd(ct + CT_NOTOPT, 1u);
-                if (wants) atomicAdd(ct + CT_WANTS, 1u);
-                if (trig) atomicAdd(ct + CT_TRIG, 1u);
+                unsigned int r1 = 0, r2 = 0;
+                if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
+                if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
+                if (persistent & 1) {
+                    // the arrival and this problem's verdict in ONE 64-bit add (NOTOPT and ARRIVE share an aligned word), behind
+                    // the RETURNED adds above: whoever sees the last arrival sees every counter of the check.  Nothing else
+                    // is handed over here -- no release fence (an L2 write-back, microseconds per check)
+                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(r1), "v"(r2) : "memory");
+                    __hip_atomic_fetch_add((unsigned long long*)(ct + CT_NOTOPT), (solved ? 0ull : 1ull) | (1ull << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (!solved) {
+                    atomicAdd(ct + CT_NOTOPT, 1u);
+                }
             }
             ++slot;
             if (persistent & 1) {
                 // all workgroups resident: device-wide "all optimal?" (torch.all at :312)
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(ct + CT_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
                 grid_wait(ct + CT_ARRIVE, gridDim.x, P.status);
                 const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
