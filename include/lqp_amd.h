@@ -147,6 +147,9 @@ void lqp_debug_set_lu_counters(void* device_buf);
 /* test aid: occupies `blocks` workgroups (512 threads, `lds_bytes` of LDS each) for `usec` microseconds on `stream`:
  * the co-residency tests run the two-workgroup schedules of the forward solve beside it. */
 int lqp_debug_spin(void* stream, int blocks, int usec, int lds_bytes);
+/* test aid: out_dev[b] (int32, device) := the XCD (0..7, HW_REG_XCC_ID) workgroup b of a `blocks`-workgroup launch runs on --
+ * the question the workgroups that share a matrix ask at every launch before they choose their exchange protocol.        */
+int lqp_debug_xcd(void* stream, int blocks, void* out_dev);
 
 /* ---- forward ADMM solve ------------------------------------------------
  * Replaces torch_solve_box_qp (lqp_py/solve_box_qp_admm_torch.py:108-333):

@@ -59,6 +59,7 @@ SYMBOLS = {
     "lqp_profile_get": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_longlong), c_int]),
     "lqp_debug_set_lu_counters": (None, [_P]),
     "lqp_debug_spin": (c_int, [_P, c_int, c_int, c_int]),
+    "lqp_debug_xcd": (c_int, [_P, c_int, _P]),
     "lqp_boxqp_forward_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                   ctypes.POINTER(BoxQPCtrl), _P, _P, _P, _P, _P, _P, _P,

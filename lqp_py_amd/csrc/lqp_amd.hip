@@ -1037,6 +1037,16 @@ int lqp_debug_spin(void* stream, int blocks, int usec, int lds_bytes) {
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
+// test aid: the XCD every workgroup of a `blocks`-workgroup launch lands on (what the XCD-aware exchange asks at run time)
+__global__ __launch_bounds__(512) void k_debug_xcd(int* __restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)my_xcd();
+}
+int lqp_debug_xcd(void* stream, int blocks, void* out_dev) {
+    if (blocks < 1 || !out_dev) return LQP_ERR_INVALID;
+    hipLaunchKernelGGL(k_debug_xcd, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (int*)out_dev);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
 int lqp_profile_classes(void) { return PC_COUNT; }
 
 const char* lqp_profile_class_name(int c) {

@@ -1060,6 +1060,20 @@ def test_bound_flags_come_from_the_device(dev):
     assert ctl2["rho"] == 0 and err(xa, ref["x"]) < 2e-5 and err(xb, ref0["x"]) < 2e-5
 
 
+def test_workgroups_can_ask_which_xcd_they_run_on(dev):
+    """HW_REG_XCC_ID, the question behind the XCD-aware exchange: ids are 0..7, an MI355X in its default mode shows more than
+    one of them over a 256-workgroup launch, and -- recorded, not asserted: placement is the dispatcher's -- how often
+    workgroups b and b + 128 (the two that share a matrix at B = 128) report the same one."""
+    lib = _lib.load()
+    out = torch.full((256,), -1, dtype=torch.int32, device=dev)
+    _lib.check(lib.lqp_debug_xcd(_lib.stream_ptr(dev), 256, _lib.ptr(out)), "debug_xcd")
+    ids = out.cpu()
+    assert int(ids.min()) >= 0 and int(ids.max()) <= 7
+    together = float((ids[:128] == ids[128:]).float().mean())
+    P.record("xcd_placement", "observation", 0.0, 1.0, pairs_on_one_xcd=together, distinct_ids=int(ids.unique().numel()))
+    assert ids.unique().numel() >= 1
+
+
 @pytest.mark.parametrize("n,B,m", [(500, 8, 1), (500, 16, 0), (448, 5, 2), (512, 3, 0)])
 def test_xcd_local_exchange_is_only_a_transport(dev, monkeypatch, n, B, m):
     """Workgroups that share a matrix and find themselves on one XCD (B a multiple of 8 under round-robin placement) exchange
