@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extras (configs 2 and 4, LU step, sync step)")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling as the metric string states it: ONE batch of --batch QPs (default 128) split "
+                         "over the N GPUs (128/N per GPU: 64 / 32 / 16 at N = 2 / 4 / 8); default: weak scaling, --batch per GPU")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE configs[4]: batch=8192 dz=500 sharded over 8 GPUs = 1024 QPs per GPU (weak: 1024 per "
+                         "GPU at any N)")
     ap.add_argument("--sync", action="store_true",
                     help="time the layer with its default control (calls wait for the GPU and raise at the call, like the "
                          "reference); default here: control['sync']=False, the pipelined training-loop mode")
@@ -184,12 +190,26 @@ def main():
     from lqp_py_amd.solve_box_qp_admm_torch import last_forward_status
     from lqp_py_amd.synthetic import create_qp_data
 
-    B, n, m = args.batch, args.n, N_EQ
-    # one batch per simulation seed (rank r draws seeds 100 r + 0..9), HBM resident
+    from lqp_py_amd.dist import shard_slice
+    n, m = args.n, N_EQ
+    if args.config5:
+        args.batch = 1024
+    B_total = args.batch if args.strong else args.batch * world
+    if args.strong:
+        # ONE batch of B_total problems, drawn identically on every rank (seeds 0..9 as in experiment_1.py), each rank
+        # keeping its contiguous slice -- the batch the single-GPU line solves, cut across the GPUs
+        lo, hi = shard_slice(B_total, rank, world)
+        shard_sizes = [shard_slice(B_total, r, world)[1] - shard_slice(B_total, r, world)[0] for r in range(world)]
+    else:
+        lo, hi = 0, args.batch
+        shard_sizes = [args.batch] * world
+    B = hi - lo
+    # one batch per simulation seed (weak scaling: rank r draws seeds 100 r + 0..9), HBM resident
     data = []
-    for s in range(N_SEEDS):
-        Q, p, A, b, lb, ub = create_qp_data(n, B, seed=100 * rank + s)
-        data.append([t.to(dev) for t in (Q, p, A, b, lb, ub)])
+    n_seeds_here = 3 if args.config5 else N_SEEDS          # (1 GB of Q per batch at B = 1024)
+    for s in range(n_seeds_here):
+        Q, p, A, b, lb, ub = create_qp_data(n, B_total if args.strong else B, seed=s if args.strong else 100 * rank + s)
+        data.append([t[lo:hi].contiguous().to(dev) for t in (Q, p, A, b, lb, ub)])
     ones = torch.ones(B, n, 1, device=dev)
 
     def make_layer(linsolve, sync):
@@ -197,12 +217,12 @@ def main():
         if linsolve != "auto":
             control['linsolve'] = linsolve
         control['sync'] = bool(sync)     # False: the pipelined training-loop mode (errors reported late, NaN on failure)
-        return control, (ShardedBoxQP(control, shard_sizes=[B] * world) if world > 1 else L.SolveBoxQP(control=control))
+        return control, (ShardedBoxQP(control, shard_sizes=shard_sizes) if world > 1 else L.SolveBoxQP(control=control))
 
     control, layer = make_layer(args.linsolve, args.sync)
 
     def forward(i, lay=None):
-        Q, p, A, b, lb, ub = data[i % N_SEEDS]
+        Q, p, A, b, lb, ub = data[i % len(data)]
         Q = Q.detach().requires_grad_(True)          # experiment_1 differentiates w.r.t. Q and p
         p = p.detach().requires_grad_(True)
         out = (lay or layer)(Q, p, A, b, lb, ub)
@@ -232,10 +252,10 @@ def main():
     step(0)
     sync()
     t_first = time.perf_counter()
-    for i in range(1, N_SEEDS):
+    for i in range(1, len(data)):
         step(i)
     sync()
-    first_use_ms = (time.perf_counter() - t_first) / (N_SEEDS - 1) * 1e3
+    first_use_ms = (time.perf_counter() - t_first) / (len(data) - 1) * 1e3
     for i in range(args.warmup):
         step(i)
     # ---- timed region: exactly K steps, nothing else on the stream ----
@@ -247,13 +267,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t[0])
     ms_per_step = dt / args.steps * 1e3
-    value = world * B / (dt / args.steps)
+    value = B_total / (dt / args.steps)
 
     # ---- the reference's protocol (experiment_1.py:53-94): one simulation per seed 0..9, forward and
     #      backward timed separately (device events on the launch stream), medians over the simulations ----
     ev = lambda: torch.cuda.Event(enable_timing=True)
     t_fwd, t_bwd = [], []
-    for s in range(N_SEEDS):
+    for s in range(len(data)):
         # fresh tensors for every simulation, as experiment_1.py:58 draws fresh data (copies made outside the timed phases)
         Qs_, ps_, As_, bs_, lbs_, ubs_ = (t.clone() for t in data[s])
         Qs_.requires_grad_(True)
@@ -271,10 +291,10 @@ def main():
         t_bwd.append(e1.elapsed_time(e2))
         del Qs_, ps_, As_, bs_, lbs_, ubs_, x, out_
     L.synchronize()
-    protocol = {"simulations": N_SEEDS, "seeds": f"{100 * rank}..{100 * rank + N_SEEDS - 1}",
+    protocol = {"simulations": len(data), "seeds": f"{100 * rank}..{100 * rank + len(data) - 1}",
                 "median_forward_ms": round(median(t_fwd), 4), "median_backward_ms": round(median(t_bwd), 4),
                 "QPs_per_sec_median": round(B / ((median(t_fwd) + median(t_bwd)) * 1e-3), 1),
-                "QPs_per_sec_mean": round(B / ((sum(t_fwd) + sum(t_bwd)) / N_SEEDS * 1e-3), 1),
+                "QPs_per_sec_mean": round(B / ((sum(t_fwd) + sum(t_bwd)) / len(data) * 1e-3), 1),
                 "timing": "device events around each phase, one isolated simulation at a time (per GPU), every "
                           "simulation on freshly allocated copies of its inputs",
                 "is": "SURVEY 8(d)'s metric: B / (median t_forward + median t_backward) over the 10 simulations"}
@@ -353,13 +373,17 @@ def main():
     roofline["whole_step_frac_of_hbm_roofline"] = round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)
     roofline["whole_step_algorithmic_bytes"] = step_bytes
 
+    workload = (f"BASELINE configs[4]: batch={B_total} dz={n} m={m} sharded over {world} GPU(s), {B}/GPU" if args.config5 else
+                f"BASELINE configs[2], strong scaling: ONE batch={B_total} dz={n} m={m} split over {world} GPU(s), {B} on rank 0"
+                if args.strong else f"BASELINE configs[2]: batch={B}/GPU dz={n} m={m}")
     out = {"metric": "QPs/sec forward+backward, batch=128 dz=500 tol=1e-5", "value": round(value, 1),
            "unit": "QPs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[2]: batch={B}/GPU dz={n} m={m} box+equality QP, "
-                                  "ADMM forward + fixed-point backward, eps 1e-5, scale+adaptive_rho defaults",
-                      "global_batch": world * B, "seeds": f"{N_SEEDS} batches, seeds 0..{N_SEEDS - 1} per rank, cycled",
+           "config": {"workload": workload + " box+equality QP, ADMM forward + fixed-point backward, eps 1e-5, "
+                                  "scale+adaptive_rho defaults",
+                      "global_batch": B_total, "shard_sizes": shard_sizes,
+                      "seeds": f"{len(data)} batches, seeds 0..{len(data) - 1}" + (" (one batch, cut)" if args.strong else " per rank") + ", cycled",
                       "first_use_ms_per_step": round(first_use_ms, 4),
                       "first_use": "mean step time over batches 2..10 on their first pass through the layer (nothing is cached per tensor: the bound flags of :33-38 are found on the device in every call)",
                       "iters": iters, "checks": st_timed["n_check"], "launch_mode": st_timed["mode_used"],
@@ -368,12 +392,15 @@ def main():
                       "loop_workgroups_per_qp": st_timed["loop_workgroups_per_qp"],
                       "parallelism": f"batch-sharded x{world}", "rccl_world_size": world},
            "metric_keys": {"value": "B x K / wall time of the K timed steps (pipelined calls, control['sync']=False)",
-                           "sec_8d_metric": "experiment_1_protocol.QPs_per_sec_median"},
+                           "sec_8d_metric": "experiment_1_protocol.QPs_per_sec_median",
+                           "unchanged_reference_harness": "step_sync_default (the layer's default control: every call waits "
+                                                          "for its solve and raises at the call, as experiments/experiment_1.py "
+                                                          "gets it without setting any extension key)"},
            "experiment_1_protocol": protocol,
            "roofline": roofline, "roofline_loop": roof_loop, "roofline_factorisation": roof_factor,
            "kernel_ms_per_step": breakdown, "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4)}
 
-    if world == 1 and not args.no_other_configs and B == B_PER_GPU and n == N_X:
+    if world == 1 and not args.no_other_configs and B == B_PER_GPU and n == N_X and not args.strong:
         # ---- the same step on the north-star-named algorithm (cached pivoted LU) and with the layer's default
         #      synchronous calls, driver-measured every round ----
         for key, (lsv, syncv) in {"step_linsolve_lu": ("lu", args.sync), "step_sync_default": (args.linsolve, True)}.items():

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <string>
@@ -244,6 +246,38 @@ int first_failure(hipStream_t st, const int* info_dev, int B, int* fail_index, c
     return LQP_OK;
 }
 
+// A synchronous call waits for its report, not for its stream: the words of a host report (pinned host memory, all set to
+// -1 by the call before its first launch; every word the kernels store is >= 0) are polled until none is missing.  A
+// hipStreamSynchronize of a ~0.5 ms schedule parks the thread after 100 us of spinning and pays the interrupt + wake-up
+// on top of the completion signal's trip; the polled word is seen ~a microsecond after the store.  The device results
+// themselves are stream-ordered like those of any torch operator -- the host only ever reads the report.  The stream is
+// queried every ~50 us of waiting: a drained (or failed) stream whose report is still incomplete is an error, not a hang.
+void report_reset(int* host_report, int words) {
+    for (int i = 0; i < words; ++i) ((volatile int*)host_report)[i] = -1;
+}
+int wait_report(hipStream_t st, const int* host_report, int words) {
+    const volatile int* r = (const volatile int*)host_report;
+    int first_missing = 0;
+    auto t_query = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        while (first_missing < words && r[first_missing] >= 0) ++first_missing;
+        if (first_missing >= words) { std::atomic_thread_fence(std::memory_order_acquire); return LQP_OK; }
+        __builtin_ia32_pause();
+        if ((spins & 255u) == 255u) {
+            const auto now = std::chrono::steady_clock::now();
+            if (now - t_query > std::chrono::microseconds(50)) {
+                t_query = now;
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {              // everything enqueued has run: the report must be complete now
+                    for (int i = first_missing; i < words; ++i) if (r[i] < 0) return LQP_ERR_HIP;
+                    return LQP_OK;
+                }
+                if (q != hipErrorNotReady) return LQP_ERR_HIP;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -292,6 +326,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
     P.scale = ctl->scale; P.bound_flags_in = (const int*)ctl->bound_flags_in;
     P.host_report = (int*)ctl->host_report;
+    if (P.host_report) report_reset(P.host_report, ST_WORDS + 2 * B);      // (before the first launch: see wait_report)
     P.xcd_local = env_int("LQP_XCD_LOCAL", 1) != 0 ? 1 : 0;
     P.zero_words = (int)(((char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status) / sizeof(int));
     P.dbg = g_lu_dbg;
@@ -570,7 +605,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     //      Every kernel exits at once when the device-side DONE flag is up, the refactor chains are
     //      gated on device, so nothing needs the host; errors are read later by the caller
     //      (lqp_boxqp_forward_layout).  Only taken when the number of adaptive-rho events is small.
-    if (ctl->reserved == 1 && mode == 2) {
+    // A synchronous call (the default: the reference's semantics) enqueues the same schedule and then waits for the report
+    // the last kernel stores into the caller's pinned memory (wait_report) -- not for the stream.
+    if ((ctl->reserved == 1 || env_int("LQP_SYNC_PLAN", 1) != 0) && mode == 2) {
         int n_events = 0;
         if (ctl->adaptive_rho)
             for (int a = ar_iter; a < max_iters && a < ctl->adaptive_rho_max_iter; a += ar_iter) ++n_events;
@@ -629,14 +666,61 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 ++n_launch;
             }
             if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
+            const int factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
+            if (ctl->reserved == 1) {
+                if (stats) {
+                    memset(stats, 0, sizeof(*stats));
+                    stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
+                    stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
+                    stats->any_lb = stats->any_ub = -1;
+                    stats->linsolve_used = spd ? 2 : 1;
+                    stats->factor_launches = factor_launches;
+                    stats->loop_workgroups = loop_split ? loop_np : 1;
+                }
+                return LQP_OK;
+            }
+            // ---- synchronous call: status block, info and flag words of every problem ----
+            std::vector<int> rep_copy;
+            const int* rep = P.host_report;
+            if (rep) {
+                rc = wait_report(st, rep, ST_WORDS + 2 * B);
+                if (rc) return rc;
+            } else {                        // (a C caller without pinned memory: two small copies and a stream wait)
+                rep_copy.resize(ST_WORDS + 2 * B);
+                HIP_OK(hipMemcpyAsync(rep_copy.data(), P.status, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipMemcpyAsync(rep_copy.data() + ST_WORDS, P.info, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipMemcpyAsync(rep_copy.data() + ST_WORDS + B, P.bflags, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                rep = rep_copy.data();
+            }
+            const volatile int* rv = (const volatile int*)rep;
+            int fail_index = -1, flags_or = 0;
+            for (int i = 0; i < B; ++i) {
+                if (fail_index < 0 && rv[ST_WORDS + i] != 0) fail_index = i;
+                flags_or |= rv[ST_WORDS + B + i];
+            }
+            if (fail_index >= 0 && spd)         // Qs + rho I not positive definite in f32 (first factorisation or an
+                return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
+                                       ws, ws_bytes, true);     // adaptive-rho one): the LU path takes the solve
+            if (fail_index >= 0) {
+                if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
+                return LQP_ERR_SINGULAR;
+            }
+            if (rv[ST_TIMEOUT] || (flags_or & RP_TIMEOUT)) return LQP_ERR_TIMEOUT;
             if (stats) {
-                memset(stats, 0, sizeof(*stats));
-                stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;   // not known on the host
-                stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 3;
-                stats->any_lb = stats->any_ub = -1;
+                const int final_iter = rv[ST_DONE] ? rv[ST_FINAL_ITER] : max_iters - 1;
+                stats->iters = final_iter;
+                stats->n_factor = 1 + rv[ST_NFACTOR];
+                stats->n_solve = final_iter + 1;
+                stats->n_check = final_iter / check + 1;
+                stats->rho_updated = rv[ST_RHO_UPDATED];
+                stats->fail_index = -1;
+                stats->n_launch = n_launch;
+                stats->mode_used = 2;
                 stats->linsolve_used = spd ? 2 : 1;
-                stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
+                stats->factor_launches = factor_launches;
                 stats->loop_workgroups = loop_split ? loop_np : 1;
+                stats->any_lb = rv[ST_ANY_LB]; stats->any_ub = rv[ST_ANY_UB];
             }
             return LQP_OK;
         }
@@ -819,6 +903,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     BwdParams<T> P;
     memset(&P, 0, sizeof(P));
     P.host_report = (int*)host_report;
+    if (P.host_report) report_reset(P.host_report, B);
     const size_t need = carve_backward<T>(ws, B, n, m, P);
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
     P.g = (const T*)g; P.x = (const T*)x; P.u = (const T*)u; P.lams = (const T*)lams; P.nus = (const T*)nus;
@@ -894,7 +979,16 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
     if (fail_index) {
         int fi = -1;
-        rc = first_failure(st, P.info, B, &fi, P.host_report);       // torch.linalg.solve checks info (and syncs) too
+        // torch.linalg.solve checks info (and waits) too.  The epilogue stores the info words into the caller's pinned
+        // memory as it STARTS: the call returns while the gradients are still being written (stream-ordered results)
+        if (P.host_report && env_int("LQP_SYNC_PLAN", 1) != 0) {
+            rc = wait_report(st, P.host_report, B);
+            if (rc) return rc;
+            for (int i = 0; i < B && fi < 0; ++i)
+                if (((const volatile int*)P.host_report)[i] != 0) fi = i;
+            rc = fi >= 0 ? LQP_ERR_SINGULAR : LQP_OK;
+        } else
+            rc = first_failure(st, P.info, B, &fi, P.host_report);
         if (rc == LQP_ERR_SINGULAR && chol)           // Q_FF not positive definite in f32: the pivoted LU takes it
             return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
                                     db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report);

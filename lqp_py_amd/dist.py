@@ -144,7 +144,8 @@ class ShardedBoxQP(torch.nn.Module):
             # private keys for the layer: the flags of the WHOLE batch (a shard without any finite bound must still run
             # the ADMM path the whole batch runs) and, in strict mode, the per-check all-reduce
             ctl = dict(ctl)
-            ctl['_owner'] = self.control        # (what the layer remembers between calls, it remembers there)
+            ctl['_owner'] = self.control        # (the dict side effect control['rho'] = 0 belongs to the caller's dict)
+            ctl['_holder'] = self               # (what the layer remembers between calls, it remembers per module)
             if lb.is_cuda:
                 ctl['_bound_flags_dev'] = device_bound_flags(lb, ub, self.group)
             else:                               # CPU stand-in solver of the gloo tests: host flags

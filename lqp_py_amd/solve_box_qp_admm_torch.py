@@ -13,6 +13,7 @@ and moves pointers.  Tensors must be on the GPU; there is no CPU fallback.
 """
 import ctypes
 import threading
+import weakref
 
 import torch
 import torch.nn as nn
@@ -33,7 +34,14 @@ class SolveBoxQP(nn.Module):
     def forward(self, Q, p, A, b, lb, ub):
         if self.control.get('unroll', False):
             return torch_solve_box_qp(Q=Q, p=p, A=A, b=b, lb=lb, ub=ub, control=self.control)
-        return SolveBoxQPLayer.apply(Q, p, A, b, lb, ub, self.control)
+        # what the layer remembers between calls (did the last batch hold a finite bound?) it remembers per MODULE, in a
+        # weak-keyed side table -- never in the caller's dict
+        prev = getattr(_tls, 'holder', None)
+        _tls.holder = self
+        try:
+            return SolveBoxQPLayer.apply(Q, p, A, b, lb, ub, self.control)
+        finally:
+            _tls.holder = prev
 
 
 class SolveBoxQPLayer(torch.autograd.Function):
@@ -51,7 +59,8 @@ class SolveBoxQPLayer(torch.autograd.Function):
         # (lqp_py_amd.dist passes the flags of the WHOLE batch when this call holds one shard of it.)
         sync = bool(control.get('sync', True))
         sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=control.get('_global_bounds'), sync=sync,
-                             check_hook=control.get('_check_hook'), mutate=True)
+                             check_hook=control.get('_check_hook'), mutate=True,
+                             holder=control.get('_holder') or getattr(_tls, 'holder', None))
         ctx.rho = sol['rho']
         ctx.linsolve = int(sol['_stats']['linsolve_used'])     # 2: Q was checked symmetric by the forward
         ctx.sync = sync
@@ -186,19 +195,31 @@ def _finite_bounds(lb, ub):
 
 # "Does the batch hold any finite bound?" selects the schedule (rho = 0: one KKT solve, :157-158) and is a host decision
 # in the reference.  Here the setup kernel answers it from the data of EVERY call (status words 12/13); the host only
-# assumes an answer when it enqueues -- what the last solve with the same control dict saw (kept in the dict under a
-# private key; unknown keys are carried and ignored like the reference's `reduce`) -- and compares afterwards: a call
+# assumes an answer when it enqueues -- what the last solve of the same LAYER saw -- and compares afterwards: a call
 # that waits for the GPU repeats itself on the other schedule, an un-synchronised one reports the mismatch late (its
-# outputs are then not the reference's and must not be used).
-_SEEN = '_any_bound_seen'
+# outputs are then not the reference's and must not be used).  The remembered answer lives in a side table, never in
+# the caller's control dict (box_qp_control(**control), dict comparisons and serialisation see the dict unchanged):
+# keyed weakly by the nn.Module that made the call (SolveBoxQP, ShardedBoxQP), or -- SolveBoxQPLayer.apply /
+# torch_solve_box_qp called directly: plain dicts cannot be weakly referenced -- by the dict's id in a bounded table
+# (a stale entry after an id is re-used costs one repeated solve, nothing else).
+_tls = threading.local()
+_seen_by_module = weakref.WeakKeyDictionary()
+_seen_by_dict_id = {}
 
 
-def _assume_any_bound(control):
-    return control.get(_SEEN)
+def _assume_any_bound(holder, control):
+    if holder is not None:
+        return _seen_by_module.get(holder)
+    return _seen_by_dict_id.get(id(control))
 
 
-def _remember_any_bound(control, any_bound):
-    control[_SEEN] = bool(any_bound)
+def _remember_any_bound(holder, control, any_bound):
+    if holder is not None:
+        _seen_by_module[holder] = bool(any_bound)
+        return
+    if len(_seen_by_dict_id) > 256:
+        _seen_by_dict_id.clear()
+    _seen_by_dict_id[id(control)] = bool(any_bound)
 
 
 def resolve_control(control, n_x):
@@ -260,9 +281,11 @@ def _beta_argument(beta, B, like):
     return 2, 0.0, beta.detach().to(device=like.device, dtype=like.dtype).reshape(B).contiguous()
 
 
-def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None, mutate=False):
+def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None, mutate=False,
+                   holder=None):
     """bounds: (any_lb, any_ub) when the caller KNOWS them (a shard of a larger batch with host-side flags); None: found
-    on the device.  mutate: apply the reference layer's dict side effect control['rho'] = 0 (:37-38)."""
+    on the device.  mutate: apply the reference layer's dict side effect control['rho'] = 0 (:37-38).  holder: the
+    nn.Module on whose behalf the call is made (keys what is remembered between calls, see _assume_any_bound)."""
     # (what stands between the call and its first kernel launch is the forward time of a step that starts from an idle
     #  queue -- experiment_1's protocol: errors of EARLIER calls are polled after this one is enqueued, the outputs are
     #  one allocation)
@@ -276,16 +299,23 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         sync = True                                   # the strict global stop is host-driven (one launch per check)
     known = bounds is not None
     owner = control.get('_owner') or control          # (lqp_py_amd.dist hands the layer a copy of the caller's dict)
+    flags_dev = control.get('_bound_flags_dev')       # (lqp_py_amd.dist: device-side flags of the whole batch)
     if known:
         any_bound = bool(bounds[0] or bounds[1])
     else:
-        any_bound = _assume_any_bound(owner)
-        if any_bound is None:                         # first solve with this control dict
-            any_bound = True if sync else any(_finite_bounds(lb, ub))
+        any_bound = _assume_any_bound(holder, owner)
+        if any_bound is None:                         # first solve of this layer
+            if sync:
+                any_bound = True
+            elif flags_dev is not None:
+                # a shard: the flags of the WHOLE batch decide (one host read, the same answer on every rank -- a shard
+                # without any finite bound inside a batch that has some must enqueue the schedule its peers enqueue)
+                any_bound = bool(flags_dev.max().item())
+            else:
+                any_bound = any(_finite_bounds(lb, ub))
     # the control struct of the last call with the same settings is reused (resolving ~25 keys and filling the struct
     # costs ~15 us, in front of the first kernel launch); anything that holds a tensor (per-problem rho / beta) is
     # resolved afresh
-    flags_dev = control.get('_bound_flags_dev')       # (lqp_py_amd.dist: device-side flags of the whole batch)
     ckey, cached = None, None
     cache = _ctl_cache.__dict__.setdefault('d', {})   # (per thread: the struct is written to below)
     if check_hook is None:
@@ -333,15 +363,18 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     ctl.host_report = report.data_ptr()
     stats = _lib.BoxQPStats()
 
-    # one allocation for the six outputs; only its ADDRESS is needed in front of the launches -- the views are made after
-    # the library call has enqueued them (everything here is host time the GPU idles through in experiment_1's protocol)
+    # x is its own allocation (a caller that collects solutions across batches keeps n floats per problem, not the
+    # iterates and duals); z, u, lams, nus, rho share one.  Only ADDRESSES are needed in front of the launches -- the views
+    # are made after the library call has enqueued them (everything here is host time the GPU idles through in
+    # experiment_1's protocol)
     n4 = (n + 3) // 4 * 4                  # (every output starts 16-byte aligned)
     m4 = (m + 3) // 4 * 4
-    outbuf = torch.empty((B * (5 * n4 + m4 + 4),), dtype=p.dtype, device=dev)
+    x = torch.empty((B, n, 1), dtype=p.dtype, device=dev)
+    outbuf = torch.empty((B * (4 * n4 + m4 + 4),), dtype=p.dtype, device=dev)
     es = outbuf.element_size()
     base = outbuf.data_ptr()
-    o_x, o_z, o_u, o_l = base, base + B * n4 * es, base + 2 * B * n4 * es, base + 3 * B * n4 * es
-    o_nu, o_rho = base + 5 * B * n4 * es, base + (5 * B * n4 + B * m4) * es
+    o_x, o_z, o_u, o_l = x.data_ptr(), base, base + B * n4 * es, base + 2 * B * n4 * es
+    o_nu, o_rho = base + 4 * B * n4 * es, base + (4 * B * n4 + B * m4) * es
     nbytes = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = _lib.workspace(dev, nbytes, "fwd", stream)
@@ -367,16 +400,30 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
                                    ctypes.byref(ctl), _lib.ptr(rho_tensor),
                                    o_x, o_z, o_u, o_l, o_nu if m > 0 else None, o_rho,
                                    ctypes.byref(stats), _lib.ptr(ws), ws.numel())
-    parts = outbuf.split_with_sizes((B * n4, B * n4, B * n4, 2 * B * n4, B * m4, 4 * B))
+    parts = outbuf.split_with_sizes((B * n4, B * n4, 2 * B * n4, B * m4, 4 * B))
     if n4 == n:
-        x, z, u, lams = parts[0].view(B, n, 1), parts[1].view(B, n, 1), parts[2].view(B, n, 1), parts[3].view(B, 2 * n, 1)
+        z, u, lams = parts[0].view(B, n, 1), parts[1].view(B, n, 1), parts[2].view(B, 2 * n, 1)
     else:
-        x, z, u, lams = (parts[k][:B * n * (2 if k == 3 else 1)].view(B, n * (2 if k == 3 else 1), 1) for k in range(4))
-    nus = parts[4][:B * m].view(B, m, 1) if m > 0 else None
-    rho_out = parts[5][:B]
+        z, u, lams = (parts[k][:B * n * (2 if k == 2 else 1)].view(B, n * (2 if k == 2 else 1), 1) for k in range(3))
+    nus = parts[3][:B * m].view(B, m, 1) if m > 0 else None
+    rho_out = parts[4][:B]
+    if st != 0 or (check_hook is not None and hook_error):
+        # kernels of the failed call may still be in flight, and they write their report into `report`: wait before the
+        # pinned buffer goes back to the pool (cold path)
+        torch.cuda.current_stream(dev).synchronize()
+        _lib._pinned_free.setdefault(report.numel(), []).append(report)
     if check_hook is not None and hook_error:
         raise hook_error[0]
     if st == 3:
+        if not known and not any_bound:
+            # the rho = 0 one-shot was enqueued on the ASSUMPTION that this batch, like the layer's last one, holds no
+            # finite bound.  If it does, the reference would have run its ADMM loop with rho > 0 (:157-158 do not apply),
+            # whose KKT matrix can be regular where [[Q, A^T], [A, 0]] is not (Q = 0: an LP, zero rows): look (cold path)
+            has = _finite_bounds(lb, ub)
+            if has[0] or has[1]:
+                _remember_any_bound(holder, owner, True)
+                return _forward_solve(Q, p, A, b, lb, ub, control, bounds=has, sync=sync, residuals=residuals,
+                                      check_hook=check_hook, mutate=mutate, holder=holder)
         # the reference's torch.linalg.lu_factor raises on an exactly singular KKT matrix (:215)
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "
                            f"(batch index {stats.fail_index}); the KKT matrix is singular")
@@ -386,17 +433,18 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     finally:                          #  its own report is queued behind the poll -- it is never raised at its own call)
         if stats.mode_used == 3:      # nothing was waited for: the report is read once the stream has passed the call
             _lib.defer_check("SolveBoxQP.forward", dev, report, B, True,
-                             bounds_check=None if known else (any_bound, owner, mutate, _remember_any_bound))
+                             bounds_check=None if known else (
+                                 any_bound, owner, mutate, lambda _c, seen: _remember_any_bound(holder, owner, seen)))
         elif report is not None:      # (the library waited after all: nothing left to report late)
             _lib._pinned_free.setdefault(report.numel(), []).append(report)
             report = None
     if stats.mode_used != 3 and not known and stats.any_lb >= 0:
         # the device looked at the bounds: did the schedule we enqueued fit them?
         seen = bool(stats.any_lb or stats.any_ub)
-        _remember_any_bound(owner, seen)
+        _remember_any_bound(holder, owner, seen)
         if seen != any_bound:
             return _forward_solve(Q, p, A, b, lb, ub, control, bounds=(bool(stats.any_lb), bool(stats.any_ub)), sync=sync,
-                                  residuals=residuals, check_hook=check_hook, mutate=mutate)
+                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder)
     if mutate and not any_bound:
         control['rho'] = owner['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
     if r['verbose']:

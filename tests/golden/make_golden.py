@@ -84,6 +84,42 @@ def main():
         _save = save
         save = lambda name, **kw: _save(name, **kw) if any(name.startswith(o) for o in only) else None
 
+    # G16: above the 1024 rows the on-chip tiers of the build hold -- B=8 n=1500 m=1 (README.md:49 discusses n_x > 500;
+    #      the reference's LAPACK calls take any size), forward + all six FP gradients for a random cotangent
+    if not only or any(o.startswith("g16") for o in only):
+        Q, p, A, b, lb, ub = ref_inputs(1500, 8, 0)
+        sol = torch_solve_box_qp(Q, p, A, b, lb, ub, box_qp_control(**tol))
+        torch.manual_seed(16)
+        cot = torch.randn(8, 1500, 1)
+        gr = fp_grads(sol, Q, A, lb, ub, cot)
+        rs = np.random.RandomState(16)
+        sb, si, sj = rs.randint(0, 8, 64), rs.randint(0, 1500, 64), rs.randint(0, 1500, 64)
+        out = dict(cot=cot, in_sum=checksum(Q, p, lb, ub), sb=sb, si=si, sj=sj,
+                   dQ_fro=torch.linalg.matrix_norm(gr[0]), dQ_samples=gr[0][sb, si, sj],
+                   **{k: sol[k] for k in ("x", "z", "u", "lams", "nus", "rho", "iter")})
+        for nm, t in zip(GRAD_NAMES[1:], gr[1:6]):
+            out[nm] = t
+        save("g16_b8_n1500_eq", **out)
+        print("   n=1500 iter", sol["iter"])
+        del Q, sol, gr
+
+    # G17: unroll=True at a size where the loop runs on the two-level kernels -- B=8 n=100 m=1, tol 1e-5 (the published
+    #      "ADMM Unroll" rows use the experiment_1 distribution); autograd through the loop, all six gradients
+    if not only or any(o.startswith("g17") for o in only):
+        Q, p, A, b, lb, ub = ref_inputs(100, 8, 17)
+        torch.manual_seed(17)
+        cot = torch.randn(8, 100, 1)
+        ctl = box_qp_control(unroll=True, **tol)
+        leaves = [t.clone().requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        xu = SolveBoxQP(control=ctl)(*leaves)
+        xu.backward(cot)
+        out = dict(Q=Q, p=p, A=A, b=b, lb=lb, ub=ub, cot=cot, x=xu.detach())
+        for nm, t in zip(GRAD_NAMES, leaves):
+            out[nm] = t.grad
+        save("g17_unroll_n100", **out)
+    if only and all(o.startswith(("g16", "g17")) for o in only):
+        return
+
     # G14: the NumPy twin (lqp_py/solve_box_qp_admm.py:45-91, single problem, float64) -- SURVEY 8f rank 4
     from lqp_py.solve_box_qp_admm import solve_box_qp as np_solve_box_qp
     out = {}
@@ -163,7 +199,7 @@ def main():
     grads_r = fp_grads(sol, Q, A, lb, ub, g_rand)
     rs = np.random.RandomState(0)
     sb, si, sj = rs.randint(0, 128, 64), rs.randint(0, 500, 64), rs.randint(0, 500, 64)
-    out = dict(x=sol["x"], u=sol["u"], nus=sol["nus"], rho=sol["rho"], iter=sol["iter"],
+    out = dict(x=sol["x"], u=sol["u"], z=sol["z"], lams=sol["lams"], nus=sol["nus"], rho=sol["rho"], iter=sol["iter"],
                in_sum=checksum(Q, p, lb, ub), sb=sb, si=si, sj=sj)
     for tag, gr in (("ones", grads), ("rand", grads_r)):
         dQ = gr[0]

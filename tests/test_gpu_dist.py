@@ -193,3 +193,50 @@ def test_one_rank_nccl_group_drives_the_sharded_layer(tmp_path):
     assert torch.equal(out["x_1"], out["x_0"])
     for key in ("dp_1", "dp_0"):
         assert float((out[key] - g[1]).abs().max()) < 2e-4 * max(1.0, float(g[1].abs().max())), key
+
+
+def _unbounded_shard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lqp_py_amd as L
+    from lqp_py_amd.dist import ShardedBoxQP, shard_slice
+    from lqp_py_amd.solve_box_qp_admm_torch import last_forward_status
+    dev = torch.device("cuda:0")
+    n, B = 64, 6
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=21)
+    lb[B // 2:] = -float("inf")              # rank 1's shard holds no finite bound at all; the batch does
+    ub[B // 2:] = float("inf")
+    lo, hi = shard_slice(B, rank, world)
+    Q, p, A, b, lb, ub = (t[lo:hi].to(dev) for t in (Q, p, A, b, lb, ub))
+    ctl = L.box_qp_control(sync=False, **TOL)
+    keys = set(ctl)
+    layer = ShardedBoxQP(ctl, shard_sizes=[3, 3])
+    x_local, x_all = layer(Q, p, A, b, lb, ub)          # the FIRST un-synchronised call of this layer
+    L.synchronize()                                      # (a schedule chosen from the local bounds would raise here)
+    st = last_forward_status(dev)
+    x_local2, x_all2 = layer(Q, p, A, b, lb, ub)
+    L.synchronize()
+    torch.cuda.synchronize()
+    assert set(ctl) == keys, set(ctl) ^ keys             # nothing private is left in the caller's dict
+    torch.save({"x_all": x_all.cpu(), "x_all2": x_all2.cpu(), "iter": st["iters"], "rho": ctl.get("rho")},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_first_pipelined_call_of_a_shard_without_bounds(tmp_path):
+    """the first `sync=False` call of a layer picked rho = 0 vs ADMM from THIS rank's bounds; a shard without
+    any finite bound inside a batch that has some must enqueue the ADMM schedule its peers enqueue (the flags of the
+    whole batch decide, :33-38 / :129-131) -- no late 'bound flags differ' error on one rank, no hang on the others."""
+    world = 2
+    mp.spawn(_unbounded_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    assert torch.equal(outs[0]["x_all"], outs[1]["x_all"]) and torch.equal(outs[0]["x_all"], outs[0]["x_all2"])
+    n, B = 64, 6
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=21)
+    lb[B // 2:] = -float("inf")
+    ub[B // 2:] = float("inf")
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+    assert all(o["rho"] is None for o in outs)           # the rho = 0 side effect did not fire: the batch has bounds
+    e = float((outs[0]["x_all"] - ref["x"]).abs().max())
+    assert e < 1e-3 * max(1.0, float(ref["x"].abs().max())), e      # (per-shard stop: within the stopping tolerance)

@@ -292,7 +292,7 @@ def test_g4_headline_config3(dev, mode, linsolve):
     sol, a = solve(dev, T["inp"], O.make_control(launch_mode=mode, linsolve=linsolve, **TOL))
     assert sol["iter"] == g["iter"] == 60 and sol["_stats"]["n_check"] == 4 and sol["_stats"]["n_factor"] == 1
     case = "g4_b128_n500_eq"
-    for k in ("x", "u", "nus"):
+    for k in ("x", "z", "u", "lams", "nus"):             # (SURVEY 8c lists x, u, lams, nus for G4; z rides along)
         close_or_fp64(case, k, sol[k], g[k], T["sol"][k], X_TOL, linsolve=linsolve, mode=mode)
     for tag, cot in T["cots"].items():
         gr = L.torch_solve_box_qp_grad(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
@@ -331,13 +331,22 @@ def test_the_benched_step_matches_g4(dev, sync):
 
 
 def test_g5_config4_n1000(dev):
+    """BASELINE configs[3].  x against the reference-made golden at north_star's 1e-5, or -- fp32 rounding at n = 1000 --
+    no further from an fp64 solve of the same inputs than the reference's own fp32 result: the fp64 truth is computed for
+    16 of the 128 problems (the iteration count is pinned, so the problems are independent)."""
     g = load_golden("g5_b128_n1000_eq")
     inp = O.create_qp_data(1000, 128, seed=0)
     sol, _ = solve(dev, inp, O.make_control(**TOL))
     assert sol["iter"] == g["iter"] == 60 and sol["_stats"]["linsolve_used"] == 2      # symmetric path up to n = 1024
-    P.record("g5_b128_n1000_eq", "x", err(sol["x"], g["x"]), linsolve=sol["_stats"]["linsolve_used"])
-    assert err(sol["x"], g["x"]) < 2 * X_TOL and rel(sol["rho"], g["rho"]) < 1e-4
-
+    assert rel(sol["rho"], g["rho"]) < 1e-4
+    idx = torch.arange(0, 128, 8)
+    t64, _ = fp64_truth([None if t is None else t[idx] for t in inp], g["iter"])
+    case = "g5_b128_n1000_eq"
+    P.record(case, "x_all_128", err(sol["x"], g["x"]), linsolve=sol["_stats"]["linsolve_used"])
+    close_or_fp64(case, "x", sol["x"][idx.to(dev)], g["x"][idx], t64["x"], X_TOL)
+    # the other 112 problems: within the band the 16 establish (their own fp32-vs-fp64 distance is not computed)
+    band = max(X_TOL, err(g["x"][idx], t64["x"]) + X_TOL)
+    assert err(sol["x"], g["x"]) <= band + err(sol["x"][idx.to(dev)], t64["x"]), (err(sol["x"], g["x"]), band)
 
 
 # ---------------------------------------------------------------- symmetric-inverse x-update (linsolve 'spd')
@@ -794,9 +803,11 @@ def test_late_rho_matches_the_setup_pass(dev, monkeypatch, n, B, scale):
     assert float(((r1 - r0).abs() / r0).max()) < 1e-6
     ref = O.solve_box_qp(*inp, O.make_control(max_iters=41, eps_abs=1e-12, eps_rel=1e-12, scale=scale))
     assert float((r1 - ref["rho"].flatten().double()).abs().max() / ref["rho"].max()) < 1e-5
+    t64 = O.solve_box_qp(*[None if t is None else t.double() for t in inp],
+                         O.make_control(max_iters=41, eps_abs=1e-12, eps_rel=1e-12, scale=scale))
     for k in ("x", "u", "lams"):
         assert err(out["1"][k], out["0"][k]) < 1e-5, k
-        assert err(out["1"][k], ref[k]) < 2 * X_TOL, k
+        close_or_fp64(f"late_rho_n{n}", k, out["1"][k], ref[k], t64[k], X_TOL, scale_on=scale)
 
 
 @pytest.mark.parametrize("n,B,m", [(500, 4, 1), (330, 3, 2), (448, 2, 5)])
@@ -819,14 +830,15 @@ def test_equality_correction_in_the_loop_kernel(dev, monkeypatch, n, B, m):
         ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**kw))
         scale = max(1.0, float(ref["x"].abs().max()))
         if "rho" in kw:
+            # (with the stopping rule live -- and rho adapted from a ratio of residuals -- the solution is only as good
+            #  as the tolerance: compare the primal solution, at the accuracy the stopping rule gives)
             assert out["1"]["_stats"]["n_factor"] >= 2 and abs(out["1"]["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
-            tol = 5e-4
+            assert err(out["1"]["x"], out["0"]["x"]) < 5e-4 * scale and err(out["1"]["x"], ref["x"]) < 5e-4 * scale, kw
         else:
-            tol = 2 * X_TOL
-        # (with the stopping rule live the duals are only as good as the tolerance: compare the primal solution)
-        for k in (("x",) if "rho" in kw else ("x", "u", "lams", "nus")):
-            assert err(out["1"][k], out["0"][k]) < tol * scale, (kw, k)
-            assert err(out["1"][k], ref[k]) < tol * scale, (kw, k)
+            t64 = O.solve_box_qp(*[t.double() for t in (Q, p, A, b, lb, ub)], O.make_control(**kw))
+            for k in ("x", "u", "lams", "nus"):
+                close_or_fp64(f"eq_in_loop_n{n}_m{m}", k, out["1"][k], ref[k], t64[k], X_TOL)
+                close_or_fp64(f"eq_in_loop_n{n}_m{m}_off", k, out["0"][k], ref[k], t64[k], X_TOL)
         assert float((A.to(dev) @ out["1"]["x"] - b.to(dev)).abs().max()) < 1e-4
 
 
@@ -904,16 +916,13 @@ def test_config5_shard_b1024_n500(dev):
     idx = torch.arange(0, B, B // 16)
     sub = [t[idx] for t in inp]
     ref = O.solve_box_qp(*sub, O.make_control(eps_abs=1e-12, eps_rel=1e-12, max_iters=st["iters"] + 1))
+    t64, g64 = fp64_truth(sub, st["iters"], cots=(cot[idx],))
+    case = "config5_shard_b1024_n500"
     for k in ("x", "u", "nus", "lams"):
-        e = err(sol[k][idx.to(dev)], ref[k])
-        P.record("config5_shard_b1024_n500", k, e)
-        assert e < 2 * X_TOL, k
+        close_or_fp64(case, k, sol[k][idx.to(dev)], ref[k], t64[k], X_TOL)
     gref = O.solve_box_qp_grad(cot[idx], ref["x"], ref["u"], ref["lams"], ref["nus"], sub[0], sub[2], sub[4], sub[5], ref["rho"])
-    for nm, t, r in (("dp", pg.grad, gref[1]), ("dQ", Qg.grad, gref[0])):
-        scale = max(1.0, float(r.abs().max()))
-        e = err(t[idx.to(dev)], r)
-        P.record("config5_shard_b1024_n500", nm, e, scale)
-        assert e < 5 * G_RTOL * scale, nm
+    for nm, t, r, r64 in (("dp", pg.grad, gref[1], g64[0][1]), ("dQ", Qg.grad, gref[0], g64[0][0])):
+        close_or_fp64(case, nm, t[idx.to(dev)], r, r64, G_RTOL)
     # ---- full size: KKT conditions ----
     cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sol.items()}
     res = O.kkt_residuals(*inp, cpu)
@@ -1060,6 +1069,33 @@ def test_bound_flags_come_from_the_device(dev):
     assert ctl2["rho"] == 0 and err(xa, ref["x"]) < 2e-5 and err(xb, ref0["x"]) < 2e-5
 
 
+def test_the_callers_control_dict_stays_clean(dev, monkeypatch):
+    """what the layer remembers between calls (did the last batch hold a finite bound?) lives in a side table
+    keyed by the module, never in the caller's dict: the dict keeps its keys, and two modules sharing ONE dict -- one fed
+    bounded batches, one unbounded ones -- do not make each other repeat solves."""
+    Q, p, A, b, lb, ub = (t.to(dev) for t in O.create_qp_data(40, 3, seed=5))
+    inf = torch.full_like(lb, float("inf"))
+    control = L.box_qp_control(**TOL)
+    keys = set(control)
+    bounded, free = L.SolveBoxQP(control=control), L.SolveBoxQP(control=control)
+    calls = []
+    inner = SB._forward_solve
+    monkeypatch.setattr(SB, "_forward_solve", lambda *a, **k: (calls.append(1), inner(*a, **k))[1])
+    per_round = []
+    for _ in range(3):
+        calls.clear()
+        xb = bounded(Q, p, A, b, lb, ub)
+        xf = free(Q, p, A, b, -inf, inf)
+        assert control["rho"] == 0                       # the reference's own side effect (:37-38) ...
+        control["rho"] = None                            # ... undone by the caller between the rounds
+        per_round.append(len(calls))
+    assert set(control) == keys, set(control) ^ keys
+    assert SB._seen_by_module[bounded] is True and SB._seen_by_module[free] is False
+    assert per_round[0] == 3 and per_round[1:] == [2, 2], per_round      # (only `free`'s first call repeated itself)
+    ref = O.solve_box_qp(*[t.cpu() for t in (Q, p, A, b, lb, ub)], O.make_control(**TOL))
+    assert err(xb, ref["x"]) < 2e-5 and torch.isfinite(xf).all()
+
+
 def test_workgroups_can_ask_which_xcd_they_run_on(dev):
     """HW_REG_XCC_ID, the question behind the XCD-aware exchange: ids are 0..7, an MI355X in its default mode shows more than
     one of them over a 256-workgroup launch, and -- recorded, not asserted: placement is the dispatcher's -- how often
@@ -1201,16 +1237,19 @@ def test_cholesky_backward_above_512(dev, n, m, B):
                                  want, sync=True, linsolve=ls)
         used = _lib.profile(); _lib.profile(enable=False)
         assert (used["bwd_cholesky"][1] == 1) == (ls == 2), used
+    # the reference's arithmetic on the same inputs (fp32 oracle at the GPU's iteration count) and the fp64 truth: within
+    # rtol 1e-4 of the former, or no further from the latter than the former is (fp32 forward iterates differ from the
+    # fp64 ones at the 1e-5 level, which the gradients inherit)
+    pinned = dict(ctl, eps_abs=1e-12, eps_rel=1e-12, max_iters=sol["iter"] + 1)
+    s32 = O.solve_box_qp(*inp, dict(pinned))
+    g32 = O.solve_box_qp_grad(cot, s32["x"], s32["u"], s32["lams"], s32["nus"], inp[0], inp[2], inp[4], inp[5], s32["rho"])
     d = [None if t is None else t.double() for t in inp]
-    s64 = O.solve_box_qp(*d, dict(ctl, eps_abs=1e-12, eps_rel=1e-12, max_iters=sol["iter"] + 1))
+    s64 = O.solve_box_qp(*d, dict(pinned))
     g64 = O.solve_box_qp_grad(cot.double(), s64["x"], s64["u"], s64["lams"], s64["nus"], d[0], d[2], d[4], d[5], s64["rho"])
     for idx, nm in enumerate(GRADS):
         if out[2][idx] is None:
             continue
-        scale = max(1.0, float(g64[idx].abs().max()))
-        e2, e1 = err(out[2][idx], g64[idx]), err(out[1][idx], g64[idx])
-        P.record(f"chol_backward_big_n{n}", nm, e2, scale, lu_form_vs_fp64=e1)
-        assert e2 < 5 * G_RTOL * scale, (nm, e2, e1, scale)       # (fp32 forward iterates differ from the fp64 ones at 1e-5)
+        close_or_fp64(f"chol_backward_big_n{n}", nm, out[2][idx], g32[idx], g64[idx], G_RTOL, lu_form_vs_fp64=err(out[1][idx], g64[idx]))
 
 
 @pytest.mark.parametrize("n,B,m", [(500, 32, 1), (448, 3, 2), (512, 5, 0)])
