@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 6
+#define LQP_ABI_VERSION 7
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -37,7 +37,9 @@ enum {
     LQP_ERR_SINGULAR = 3,     /* exactly-zero pivot; batch index in stats / info         */
     LQP_ERR_HIP = 4,          /* a HIP runtime call failed                               */
     LQP_ERR_TIMEOUT = 5,      /* in-kernel grid barrier gave up (bounded spin)           */
-    LQP_ERR_UNSUPPORTED = 6   /* size outside what the kernels are built for             */
+    LQP_ERR_UNSUPPORTED = 6,  /* size outside what the kernels are built for             */
+    LQP_ERR_NOT_SPD = 7       /* lqp_boxqp_forward_finish only: the matrix left the symmetric x-update (not symmetric / Qs + rho I not
+                                 positive definite in f32): repeat lqp_boxqp_forward with ctrl.linsolve = 1                     */
 };
 
 /* Resolved solver controls.  Key-name resolution of the reference's control
@@ -66,7 +68,13 @@ typedef struct lqp_boxqp_ctrl {
     int32_t reserved;                /* 1: do not synchronise with the host (needs persistent launches and a
                                         short adaptive-rho schedule, else ignored): the whole schedule is
                                         enqueued speculatively, stats come back as -1, and the caller fetches
-                                        status / info later (lqp_boxqp_forward_layout)                       */
+                                        status / info later (lqp_boxqp_forward_layout)
+                                        2: split synchronous call (needs host_report): the schedule is enqueued
+                                        and the call returns with stats.mode_used = 4; the caller does its own
+                                        host work while the GPU runs and then calls lqp_boxqp_forward_finish,
+                                        which waits and reports like a synchronous call would have.  Where the
+                                        library cannot enqueue the whole schedule (segmented launches, a check
+                                        hook) the call simply waits itself (mode_used 1 / 2)                  */
     int32_t linsolve;                /* x-update linear algebra: 0 auto, 1 pivoted LU of the KKT matrix (the
                                         reference's, :214-215/:267), 2 symmetric inverse of Qs + rho I with a
                                         rank-m equality correction (f32, n <= 1024, m <= 16, rho > 0; anything
@@ -105,8 +113,10 @@ typedef struct lqp_boxqp_ctrl {
                                         [16+B..16+2B) per-problem flag bits {1: a lower bound is finite, 2: an upper
                                         bound is finite, 4: its workgroup saw a barrier timeout, 8: its matrix left the
                                         symmetric x-update}.  Valid once the stream has passed the call (an event):
-                                        ctrl.reserved = 1 callers read it then; a synchronous call reads its status
-                                        and info words from it right after its own wait instead of copying them.   */
+                                        ctrl.reserved = 1 callers read it then.  A synchronous call sets every
+                                        word to -1 before its first launch and POLLS them (all stored words are >= 0)
+                                        instead of synchronising the stream: it returns about a microsecond after the
+                                        last kernel's stores, not after an interrupt-driven stream wait.            */
 } lqp_boxqp_ctrl;
 
 /* Host-side bookkeeping returned by the forward solve. */
@@ -118,7 +128,7 @@ typedef struct lqp_boxqp_stats {
     int32_t rho_updated;    /* 1 if adaptive rho changed rho at least once             */
     int32_t fail_index;     /* batch index of the first singular problem, or -1        */
     int32_t n_launch;       /* kernel launches issued                                  */
-    int32_t mode_used;      /* 1 segmented, 2 persistent, 3 persistent without host sync */
+    int32_t mode_used;      /* 1 segmented, 2 persistent, 3 persistent without host sync, 4 enqueued, lqp_boxqp_forward_finish pending */
     int32_t linsolve_used;  /* 1 pivoted LU, 2 symmetric inverse (what linsolve 0 / a fallback resolved to) */
     int32_t factor_launches; /* kernel launches per (re)factorisation: 1, 2 (LU + pack) or Ks + 2 when a small batch
                               * shares each matrix between two workgroups (one launch per pivot step) */
@@ -175,6 +185,15 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m,
                       void* x, void* z, void* u, void* lams, void* nus, void* rho_out,
                       lqp_boxqp_stats* stats,
                       void* workspace, size_t workspace_bytes);
+
+/* Second half of a split synchronous forward (ctrl.reserved = 2, stats.mode_used == 4 on return): waits until the
+ * forward's last kernel has stored its report into `host_report` -- the pinned words are POLLED, the stream is not
+ * synchronised: the outputs are stream-ordered like those of any asynchronous operator -- and completes `stats`
+ * (the same struct the forward call filled).  max_iters / check_solved: the values of the ctrl struct of that call.
+ * Returns what the synchronous call would have: LQP_OK, LQP_ERR_SINGULAR (stats.fail_index), LQP_ERR_TIMEOUT, or
+ * LQP_ERR_NOT_SPD: repeat the forward with ctrl.linsolve = 1 (a one-call synchronous forward does that by itself). */
+int lqp_boxqp_forward_finish(void* stream, int B, int max_iters, int check_solved, const void* host_report,
+                             lqp_boxqp_stats* stats);
 
 /* Primal / dual error (inf-norms of D r and D s, :287-288) of the LAST convergence check of the forward that
  * used `workspace`, one value per problem -- the two numbers the reference's NumPy solver returns next to the

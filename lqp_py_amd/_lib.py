@@ -16,12 +16,12 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQP_LIB: A/B builds
-SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
+SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_lu_big.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
 
 LQP_F32, LQP_F64 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
-          5: "grid barrier timeout", 6: "unsupported size"}
+          5: "grid barrier timeout", 6: "unsupported size", 7: "matrix outside the symmetric x-update"}
 
 c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
 
@@ -64,6 +64,7 @@ SYMBOLS = {
     "lqp_boxqp_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                   ctypes.POINTER(BoxQPCtrl), _P, _P, _P, _P, _P, _P, _P,
                                   ctypes.POINTER(BoxQPStats), _P, c_size_t]),
+    "lqp_boxqp_forward_finish": (c_int, [_P, c_int, c_int, c_int, _P, ctypes.POINTER(BoxQPStats)]),
     "lqp_boxqp_forward_layout": (c_int, [c_int] * 4 + [ctypes.POINTER(c_size_t)] * 4),
     "lqp_boxqp_last_residuals": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
@@ -88,17 +89,55 @@ _lock = threading.Lock()
 _lib = None
 
 
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               "-mllvm", "-pragma-unroll-threshold=200000",      # the 32-column panel loops must fully unroll
+               "-fno-slp-vectorize"]    # SLP packing of f32 ops (v_pk_*) blows up register pressure in the LU panel
+
+
 def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> csrc/liblqp_amd.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> csrc/liblqp_amd.so (cross-compiles without a GPU).
+
+    Default: the split build -- the host translation unit (csrc/lqp_amd.hip with `extern template` declarations of every
+    kernel instance, csrc/split/lqp_extern.inc) and one translation unit per group of kernel instances
+    (csrc/split/lqp_tu_*.hip), compiled in parallel and linked; same headers and flags, hence the same code per kernel
+    as the single-source build (LQP_UNITY_BUILD=1: one hipcc command, ~3.5 minutes of serial code generation).  The
+    lists are generated from a built library's kernel names by tools/gen_split_build.py."""
+    split_dir = os.path.join(CSRC, "split")
+    tus = sorted(f for f in os.listdir(split_dir) if f.endswith(".hip")) if os.path.isdir(split_dir) else []
+    unity = bool(os.environ.get("LQP_UNITY_BUILD")) or not tus
     srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "lqp_amd.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s)):
-            return LIB_PATH
+    if not unity:
+        srcs += [os.path.join(split_dir, f) for f in tus] + [os.path.join(split_dir, "lqp_extern.inc")]
+    newest = max(os.path.getmtime(s) for s in srcs if os.path.exists(s))
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-mllvm", "-pragma-unroll-threshold=200000",      # the 32-column panel loops must fully unroll
-           "-fno-slp-vectorize",     # SLP packing of f32 ops (v_pk_*) blows up register pressure in the LU panel
-           "-o", LIB_PATH, os.path.join(CSRC, "lqp_amd.hip")]
+    if unity:
+        cmd = [hipcc] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH, os.path.join(CSRC, "lqp_amd.hip")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(os.path.join(CSRC, "lqp_amd.hip"), os.path.join(objdir, "lqp_amd.o"), ["-DLQP_SPLIT_BUILD"])]
+    jobs += [(os.path.join(split_dir, f), os.path.join(objdir, f[:-4] + ".o"), []) for f in tus]
+
+    def compile_one(job):
+        src, obj, extra = job
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+            return obj
+        cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    workers = int(os.environ.get("LQP_BUILD_JOBS", str(min(len(jobs), os.cpu_count() or 1))))
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+        objs = list(pool.map(compile_one, jobs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -197,9 +236,7 @@ RP_LB, RP_UB, RP_TIMEOUT, RP_NOTSPD = 1, 2, 4, 8
 def host_report(words):
     """Pinned int32 buffer the kernels of an un-synchronised call report into (no device-to-host copy: the forward's / the
     backward's last kernel stores the words straight into host memory).  Word 0 starts as -1 = "nothing arrived"."""
-    buf = _pinned(words)
-    buf.numpy()[0] = -1
-    return buf
+    return _pinned(words)        # (the library sets every word to -1 before its first launch)
 
 
 def defer_check(what, device, report, B, forward, bounds_check=None):

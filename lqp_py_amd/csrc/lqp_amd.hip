@@ -2,6 +2,11 @@
 // orchestration, status reporting.  See include/lqp_amd.h for the contract.
 #include "../../include/lqp_amd.h"
 #include "lqp_boxqp.cuh"
+#ifdef LQP_SPLIT_BUILD
+// split build (lqp_py_amd/_lib.py build_library, tools/gen_split_build.py): the kernel instances are compiled in the
+// translation units csrc/split/lqp_tu_*.hip; here they are only declared
+#include "split/lqp_extern.inc"
+#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +24,7 @@ using namespace lqp;
 namespace {
 
 constexpr int kRing = 1024;          // per-check counter slots
-constexpr int kMaxN = 1024;          // one panel row per thread
+constexpr int kMaxN = 2048;          // pivoted LU: one panel row per thread to 1024, two above (k_lu_factor_big)
 constexpr size_t kAlign = 256;
 constexpr int kSplitMaxB = 256;      // two-workgroup loop: batches up to half the CUs of any device we know of
 
@@ -143,8 +148,22 @@ int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, i
 
 // N <= 512: 512 threads (one row per thread, 256-VGPR budget) -> 32-column panel for f32, 16 for f64;
 // larger N: 1024 threads, 16 / 8 columns.  LQP_LU_PB / LQP_LU_MFMA / LQP_LU_NT override for experiments.
+// 1024 < N <= 2048: two panel rows per thread (k_lu_factor_big)
+template <typename T>
+int launch_lu_big(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
+                  const int* gate, const int* nvec) {
+    const int lds = LuLds<T, lu_big_panel<T>()>(round_up(N, 64)).total;
+    auto fn = k_lu_factor_big<T>;
+    const int rc = ensure_lds((const void*)fn, lds);
+    if (rc) return rc;
+    ProfScope ps(st, PC_LU);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
+    if (N > 1024) return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     const int la = env_int("LQP_LU_LA", 0);       // lookahead variants (see lqp_lu.cuh): 1 = 16 columns / 1024
     if (N <= 512 && N > 64 && la != 0) {           // threads, 2 = 32 columns / 768 threads (8 + 4 waves)
         int rc;
@@ -185,6 +204,7 @@ int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, in
 }
 int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
+    if (N > 1024) return launch_lu_big<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     const int nt = lu_threads<double>(N);
     const int pb = lu_panel_width<double>(N);
 #define LQP_LU_CASE(PBV, NTV) return launch_lu_impl<double, PBV, false, NTV>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
@@ -276,6 +296,42 @@ int wait_report(hipStream_t st, const int* host_report, int words) {
             }
         }
     }
+}
+
+// What a synchronous forward does once its whole schedule is enqueued: wait for the report (wait_report, when it sits in
+// the caller's pinned memory), look at the info / flag words of every problem, fill the statistics.  `stats` comes in
+// with n_launch / linsolve_used / factor_launches / loop_workgroups of the enqueue and keeps them.
+// LQP_RETRY_LU (internal): the matrix left the symmetric x-update -- repeat the solve with linsolve = 1.
+constexpr int LQP_RETRY_LU = 100;
+int collect_report(hipStream_t st, const int* rep, const bool polled, const int B, const int max_iters, const int check,
+                   lqp_boxqp_stats* stats) {
+    if (polled) {
+        const int rc = wait_report(st, rep, ST_WORDS + 2 * B);
+        if (rc) return rc;
+    }
+    const volatile int* rv = (const volatile int*)rep;
+    int fail_index = -1, flags_or = 0;
+    for (int i = 0; i < B; ++i) {
+        if (fail_index < 0 && rv[ST_WORDS + i] != 0) fail_index = i;
+        flags_or |= rv[ST_WORDS + B + i];
+    }
+    if (fail_index >= 0 && stats->linsolve_used == 2) return LQP_RETRY_LU;
+    if (fail_index >= 0) {
+        memset(stats, 0, sizeof(*stats));
+        stats->fail_index = fail_index;
+        return LQP_ERR_SINGULAR;
+    }
+    if (rv[ST_TIMEOUT] || (flags_or & RP_TIMEOUT)) return LQP_ERR_TIMEOUT;
+    const int final_iter = rv[ST_DONE] ? rv[ST_FINAL_ITER] : max_iters - 1;
+    stats->iters = final_iter;
+    stats->n_factor = 1 + rv[ST_NFACTOR];
+    stats->n_solve = final_iter + 1;
+    stats->n_check = final_iter / check + 1;
+    stats->rho_updated = rv[ST_RHO_UPDATED];
+    stats->fail_index = -1;
+    stats->mode_used = 2;
+    stats->any_lb = rv[ST_ANY_LB]; stats->any_ub = rv[ST_ANY_UB];
+    return LQP_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -416,10 +472,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     if constexpr (sizeof(T) == 4) {
         if (P.prep_fused) {
             const int lds = (2 * 64 * SPD_LS + 2 * LQP_NW + 64 * P.Ks) * 4;
-            const int r3 = ensure_lds((const void*)k_spd_prep, lds);
+            const int r3 = ensure_lds((const void*)k_spd_prep<>, lds);
             if (r3) return r3;
             ProfScope ps(st, PC_SPD_INV);
-            hipLaunchKernelGGL(k_spd_prep, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P);
+            hipLaunchKernelGGL(k_spd_prep<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P);
             ++n_launch;
         }
     }
@@ -439,32 +495,32 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if constexpr (sizeof(T) == 4) {
             if (spd) {
                 const int lds = spd_factor_lds_bytes(m, P.Ks);
-                const int r2 = ensure_lds((const void*)k_spd_inverse, lds);
+                const int r2 = ensure_lds((const void*)k_spd_inverse<>, lds);
                 if (r2) return r2;
                 ProfScope ps(st, PC_SPD_INV);
                 if (spd_big_split) {
                     // 512 < n <= 1024, few problems: two workgroups per matrix, a launch per phase of a pivot step
-                    int r3 = ensure_lds((const void*)k_spd_begin, lds);
-                    if (!r3) r3 = ensure_lds((const void*)k_spd_big_step, lds);
-                    if (!r3) r3 = ensure_lds((const void*)k_spd_end, lds);
+                    int r3 = ensure_lds((const void*)k_spd_begin<>, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_big_step<>, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_end<>, lds);
                     if (r3) return r3;
-                    hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
+                    hipLaunchKernelGGL(k_spd_begin<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
                     for (int k = 0; k < P.Ks; ++k) {
-                        hipLaunchKernelGGL(k_spd_big_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 1);
-                        hipLaunchKernelGGL(k_spd_big_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 2);
+                        hipLaunchKernelGGL(k_spd_big_step<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 1);
+                        hipLaunchKernelGGL(k_spd_big_step<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 2);
                     }
-                    hipLaunchKernelGGL(k_spd_end, dim3(B), dim3(LQP_NT), lds, st, P, gate);
+                    hipLaunchKernelGGL(k_spd_end<>, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                     n_launch += 2 * P.Ks + 2;
                     return LQP_OK;
                 }
                 if (spd_split) {
                     // few problems: SPD_NP workgroups per matrix, one launch per pivot step (k_spd_begin/step/end)
-                    int r3 = ensure_lds((const void*)k_spd_begin, lds);
-                    if (!r3) r3 = ensure_lds((const void*)k_spd_step, lds);
-                    if (!r3) r3 = ensure_lds((const void*)k_spd_end, lds);
+                    int r3 = ensure_lds((const void*)k_spd_begin<>, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_step<>, lds);
+                    if (!r3) r3 = ensure_lds((const void*)k_spd_end<>, lds);
                     if (r3) return r3;
                     if (!(gate == nullptr && P.prep_fused))      // (the first factorisation's blocks: k_spd_prep built them)
-                        hipLaunchKernelGGL(k_spd_begin, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
+                        hipLaunchKernelGGL(k_spd_begin<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
                     if (spd_resident) {
                         // all pivot steps in one launch, the matrix in the registers of its two workgroups
                         const int rlds = spd_lds_bytes(P.Ks);
@@ -474,14 +530,14 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                         n_launch += 1;
                     } else {
                         for (int k = 0; k < P.Ks; ++k)
-                            hipLaunchKernelGGL(k_spd_step, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
+                            hipLaunchKernelGGL(k_spd_step<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
                         n_launch += P.Ks;
                     }
-                    if (!(gate == nullptr && P.eq_in_loop)) hipLaunchKernelGGL(k_spd_end, dim3(B), dim3(LQP_NT), lds, st, P, gate);
+                    if (!(gate == nullptr && P.eq_in_loop)) hipLaunchKernelGGL(k_spd_end<>, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                     n_launch += 2;
                     return LQP_OK;
                 }
-                hipLaunchKernelGGL(k_spd_inverse, dim3(B), dim3(LQP_NT), lds, st, P, gate);
+                hipLaunchKernelGGL(k_spd_inverse<>, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                 ++n_launch;
                 return LQP_OK;
             }
@@ -509,7 +565,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     auto tail_fn = k_admm_loop<T, false, true, 1024>;        // same code, own name: continuation launches
     // the continuation kernel also runs LU + pack (in-kernel adaptive-rho refactor): LDS = max of the three
     int tail_lds = 0;
-    bool inkernel_refactor = sizeof(T) == 4;
+    // (above 1024 rows the LU kernel is the two-rows-per-thread one, launched on its own: refactorisations go through the
+    //  separate gated kernels, and the continuation kernel's LDS does not have to hold an LU panel)
+    bool inkernel_refactor = sizeof(T) == 4 && P.N <= 1024;
     if constexpr (sizeof(T) == 4) {
         if (resident) { loop_fn = k_admm_loop<T, true, false, 1024>; tail_fn = k_admm_loop<T, true, true, 1024>; }
         if (hot512) loop_fn = k_admm_loop<T, true, false, 512>;
@@ -535,8 +593,11 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     rc = ensure_lds((const void*)loop_fn, loop_lds);
     if (rc) return rc;
     if (!spd) {
-        tail_lds = std::max(loop_lds, LuLds<T, (sizeof(T) == 4 ? 16 : 8)>(round_up(P.N, 64)).total);
-        tail_lds = std::max(tail_lds, (int)pack_lds_bytes<T>());
+        tail_lds = loop_lds;
+        if (P.N <= 1024) {
+            tail_lds = std::max(tail_lds, LuLds<T, (sizeof(T) == 4 ? 16 : 8)>(round_up(P.N, 64)).total);
+            tail_lds = std::max(tail_lds, (int)pack_lds_bytes<T>());
+        }
     }
     rc = ensure_lds((const void*)tail_fn, tail_lds);
     if (rc) return rc;
@@ -607,7 +668,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     //      (lqp_boxqp_forward_layout).  Only taken when the number of adaptive-rho events is small.
     // A synchronous call (the default: the reference's semantics) enqueues the same schedule and then waits for the report
     // the last kernel stores into the caller's pinned memory (wait_report) -- not for the stream.
-    if ((ctl->reserved == 1 || env_int("LQP_SYNC_PLAN", 1) != 0) && mode == 2) {
+    if ((ctl->reserved >= 1 || env_int("LQP_SYNC_PLAN", 1) != 0) && mode == 2) {
         int n_events = 0;
         if (ctl->adaptive_rho)
             for (int a = ar_iter; a < max_iters && a < ctl->adaptive_rho_max_iter; a += ar_iter) ++n_events;
@@ -679,13 +740,24 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 }
                 return LQP_OK;
             }
+            if (ctl->reserved == 2 && P.host_report) {
+                // split call: everything is enqueued; the caller does its own host work (output views, bookkeeping) while
+                // the GPU runs and then collects the report with lqp_boxqp_forward_finish
+                if (stats) {
+                    memset(stats, 0, sizeof(*stats));
+                    stats->iters = stats->n_factor = stats->n_solve = stats->n_check = -1;
+                    stats->fail_index = -1; stats->n_launch = n_launch; stats->mode_used = 4;
+                    stats->any_lb = stats->any_ub = -1;
+                    stats->linsolve_used = spd ? 2 : 1;
+                    stats->factor_launches = factor_launches;
+                    stats->loop_workgroups = loop_split ? loop_np : 1;
+                }
+                return LQP_OK;
+            }
             // ---- synchronous call: status block, info and flag words of every problem ----
             std::vector<int> rep_copy;
             const int* rep = P.host_report;
-            if (rep) {
-                rc = wait_report(st, rep, ST_WORDS + 2 * B);
-                if (rc) return rc;
-            } else {                        // (a C caller without pinned memory: two small copies and a stream wait)
+            if (!rep) {                     // (a C caller without pinned memory: three small copies and a stream wait)
                 rep_copy.resize(ST_WORDS + 2 * B);
                 HIP_OK(hipMemcpyAsync(rep_copy.data(), P.status, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, st));
                 HIP_OK(hipMemcpyAsync(rep_copy.data() + ST_WORDS, P.info, sizeof(int) * B, hipMemcpyDeviceToHost, st));
@@ -693,36 +765,16 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 HIP_OK(hipStreamSynchronize(st));
                 rep = rep_copy.data();
             }
-            const volatile int* rv = (const volatile int*)rep;
-            int fail_index = -1, flags_or = 0;
-            for (int i = 0; i < B; ++i) {
-                if (fail_index < 0 && rv[ST_WORDS + i] != 0) fail_index = i;
-                flags_or |= rv[ST_WORDS + B + i];
-            }
-            if (fail_index >= 0 && spd)         // Qs + rho I not positive definite in f32 (first factorisation or an
+            lqp_boxqp_stats local;
+            lqp_boxqp_stats* so = stats ? stats : &local;
+            memset(so, 0, sizeof(*so));
+            so->n_launch = n_launch; so->linsolve_used = spd ? 2 : 1; so->factor_launches = factor_launches;
+            so->loop_workgroups = loop_split ? loop_np : 1;
+            rc = collect_report(st, rep, rep == P.host_report, B, max_iters, check, so);
+            if (rc == LQP_RETRY_LU)         // Qs + rho I not positive definite in f32 (first factorisation or an
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
                                        ws, ws_bytes, true);     // adaptive-rho one): the LU path takes the solve
-            if (fail_index >= 0) {
-                if (stats) { memset(stats, 0, sizeof(*stats)); stats->fail_index = fail_index; }
-                return LQP_ERR_SINGULAR;
-            }
-            if (rv[ST_TIMEOUT] || (flags_or & RP_TIMEOUT)) return LQP_ERR_TIMEOUT;
-            if (stats) {
-                const int final_iter = rv[ST_DONE] ? rv[ST_FINAL_ITER] : max_iters - 1;
-                stats->iters = final_iter;
-                stats->n_factor = 1 + rv[ST_NFACTOR];
-                stats->n_solve = final_iter + 1;
-                stats->n_check = final_iter / check + 1;
-                stats->rho_updated = rv[ST_RHO_UPDATED];
-                stats->fail_index = -1;
-                stats->n_launch = n_launch;
-                stats->mode_used = 2;
-                stats->linsolve_used = spd ? 2 : 1;
-                stats->factor_launches = factor_launches;
-                stats->loop_workgroups = loop_split ? loop_np : 1;
-                stats->any_lb = rv[ST_ANY_LB]; stats->any_ub = rv[ST_ANY_UB];
-            }
-            return LQP_OK;
+            return rc;
         }
     }
 
@@ -793,7 +845,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             // did the last check of this chunk stop the loop?  (tiny kernel, own name in traces)
             const int prev_slot = ((it - 1) / check) % kRing;
             ProfScope ps(st, PC_MISC);
-            hipLaunchKernelGGL(k_check_done, dim3(1), dim3(64), 0, st, P.status, P.counters, prev_slot, it - 1);
+            hipLaunchKernelGGL(k_check_done<>, dim3(1), dim3(64), 0, st, P.status, P.counters, prev_slot, it - 1);
             ++n_launch;
         }
         // the epilogue only reads state: run it now so that the common case (converged in this chunk)
@@ -904,6 +956,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     memset(&P, 0, sizeof(P));
     P.host_report = (int*)host_report;
     if (P.host_report) report_reset(P.host_report, B);
+    P.early_report = env_int("LQP_BWD_EARLY", 1) != 0 ? 1 : 0;
     const size_t need = carve_backward<T>(ws, B, n, m, P);
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
     P.g = (const T*)g; P.x = (const T*)x; P.u = (const T*)u; P.lams = (const T*)lams; P.nus = (const T*)nus;
@@ -926,17 +979,17 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
                 const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
                 ProfScope ps(st, PC_BWD_BUILD);
                 const int split = B <= 128 ? 2 : 1;
-                hipLaunchKernelGGL(k_bwd_build_chol, dim3(B, split), dim3(LQP_NT), lds, st, P);
+                hipLaunchKernelGGL(k_bwd_build_chol<>, dim3(B, split), dim3(LQP_NT), lds, st, P);
             }
             const int lds = bwd_chol_lds_bytes(n, m);
             {
                 const int Kmax = round_up(n, LQP_NB) / LQP_NB;
                 P.la_maxk = !env_int("LQP_BWD_LOOKAHEAD", 1) ? 0 : (Kmax < SPD_MAXK ? Kmax : SPD_MAXK - 1);
             }
-            int r2 = ensure_lds((const void*)k_bwd_chol_solve, lds);
+            int r2 = ensure_lds((const void*)k_bwd_chol_solve<>, lds);
             if (r2) return r2;
             ProfScope ps(st, PC_BWD_CHOL);
-            hipLaunchKernelGGL(k_bwd_chol_solve, dim3(B), dim3(LQP_NT), lds, st, P);
+            hipLaunchKernelGGL(k_bwd_chol_solve<>, dim3(B), dim3(LQP_NT), lds, st, P);
         }
     }
     if (chol) {
@@ -1173,7 +1226,8 @@ const char* lqp_status_string(int s) {
         case LQP_ERR_SINGULAR: return "singular matrix (exactly zero pivot)";
         case LQP_ERR_HIP: return "HIP runtime error";
         case LQP_ERR_TIMEOUT: return "in-kernel grid barrier timed out";
-        case LQP_ERR_UNSUPPORTED: return "size not supported by this build (n + m <= 1024)";
+        case LQP_ERR_UNSUPPORTED: return "size not supported by this build (n + m <= 2048)";
+        case LQP_ERR_NOT_SPD: return "matrix outside the symmetric x-update: repeat with linsolve = 1";
         default: return "unknown status";
     }
 }
@@ -1214,6 +1268,15 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m, const void* 
     if (dtype == LQP_F32)
         return forward_impl<float>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes);
     return forward_impl<double>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes);
+}
+
+int lqp_boxqp_forward_finish(void* stream, int B, int max_iters, int check_solved, const void* host_report,
+                             lqp_boxqp_stats* stats) {
+    if (!host_report || !stats || B < 1) return LQP_ERR_INVALID;
+    if (stats->mode_used != 4) return LQP_OK;               // (the forward call waited itself)
+    const int rc = collect_report((hipStream_t)stream, (const int*)host_report, true, B, max_iters,
+                                  check_solved < 1 ? 1 : check_solved, stats);
+    return rc == LQP_RETRY_LU ? LQP_ERR_NOT_SPD : rc;
 }
 
 int lqp_boxqp_last_residuals(void* stream, int dtype, int B, int n, int m, const void* workspace, size_t workspace_bytes,
@@ -1277,10 +1340,10 @@ int lqp_spd_inverse_batched(void* stream, int dtype, int B, int n, const void* K
     float* Hs = c.take<float>((size_t)B * sym_blocks(Ks) * LQP_BLK);
     float* Yg = Ks > SPD_MAXK ? c.take<float>((size_t)B * (Ks - 1) * LQP_BLK) : nullptr;
     const int lds = spd_lds_bytes(Ks > SPD_MAXK ? SPD_MAXK : Ks);
-    int rc = ensure_lds((const void*)k_spd_inverse_dense, lds);
+    int rc = ensure_lds((const void*)k_spd_inverse_dense<>, lds);
     if (rc) return rc;
     { ProfScope ps(st, PC_SPD_INV);
-      hipLaunchKernelGGL(k_spd_inverse_dense, dim3(B), dim3(LQP_NT), lds, st, (const float*)K_in, (float*)Kinv_out, Hs,
+      hipLaunchKernelGGL(k_spd_inverse_dense<>, dim3(B), dim3(LQP_NT), lds, st, (const float*)K_in, (float*)Kinv_out, Hs,
                          (int*)info_out, n, Ks, Yg); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }

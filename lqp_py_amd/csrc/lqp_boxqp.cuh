@@ -4,6 +4,7 @@
 #include <type_traits>
 #include "lqp_common.cuh"
 #include "lqp_lu.cuh"
+#include "lqp_lu_big.cuh"
 #include "lqp_trsv.cuh"
 #include "lqp_spd.cuh"
 
@@ -91,8 +92,11 @@ __host__ __device__ inline size_t vec_stride(int n, int m) { return (size_t)roun
 // (lqp_py/solve_box_qp_admm_torch.py:124-131, 160-212, 221-223)
 // LDS: red[NW * n] | d[n] | sel[8] | scratch[NW]
 // ---------------------------------------------------------------------------
+// (n <= 1024: one slab of column maxima per wave; above, the waves merge their maxima into 4 slabs in 4 rounds -- 16
+//  slabs of 2048 doubles would not fit)
+__host__ __device__ inline int setup_slabs(int n) { return n > 1024 ? 4 : LQP_NW; }
 template <typename T> __host__ __device__ inline int setup_lds_bytes(int n) {
-    return (round_up(LQP_NW * n, 8) + round_up(n, 8) + 8 + LQP_NW + 8) * (int)sizeof(T);
+    return (round_up(setup_slabs(n) * n, 8) + round_up(n, 8) + 8 + LQP_NW + 8) * (int)sizeof(T);
 }
 
 // M = [[Qs + rho I, As^T], [As, 0]]  (solve_box_qp_admm_torch.py:206-212, 252).
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     T* red = (T*)smem;
-    T* d = red + (size_t)round_up(LQP_NW * n, 8);
+    T* d = red + (size_t)round_up(setup_slabs(n) * n, 8);
     T* sel = d + round_up(n, 8);
     T* scratch = sel + 8;
     const T* Q = P.Q + (size_t)b * n * n;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     bool q_in_m = false;          // top-left KKT block already written by the scaling pass
     if (P.scale) {
         // ---- column max of |Q| (:163): wave w sweeps rows w, w+16, ...; 16 B per lane per load ----
-        const bool qvec = (n % 4 == 0) && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
+        const bool qvec = (n % 4 == 0) && n <= 1024 && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
         int nred = LQP_NW;
         if (P.prep_fused) {
             // k_spd_prep has been over Q: the maxima of its SPD_NP workgroups' shares, and their symmetry verdicts
@@ -290,21 +294,34 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             // (several workgroups per QP for this pass: no faster -- 128 MB in 38 us either way, the HBM rate)
             setup_colmax<T, 4, 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster)
         } else {
-            T cm[16];
+            // (also the HBM-resident tier, 1024 < n <= 2048: two passes of 1024 columns, the 16 waves merging their maxima
+            //  into setup_slabs(n) = 4 slabs in 4 rounds; up to 1024 columns: one pass, one slab per wave, no round trip)
+            nred = setup_slabs(n);
+            for (int c0 = 0; c0 < n; c0 += 1024) {
+                T cm[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) cm[q] = T(0);
-            for (int i = w; i < n; i += LQP_NW) {
-                const T* qr = Q + (size_t)i * n;
+                for (int q = 0; q < 16; ++q) cm[q] = T(0);
+                for (int i = w; i < n; i += LQP_NW) {
+                    const T* qr = Q + (size_t)i * n + c0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int j = lane + 64 * q;
-                    if (j < n) cm[q] = tmax(cm[q], tabs(qr[j]));
+                    for (int q = 0; q < 16; ++q) {
+                        const int j = lane + 64 * q;
+                        if (c0 + j < n) cm[q] = tmax(cm[q], tabs(qr[j]));
+                    }
                 }
-            }
+                for (int round = 0; round < LQP_NW / nred; ++round) {
+                    if (w / nred == round) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int j = lane + 64 * q;
-                if (j < n) red[(size_t)w * n + j] = cm[q];
+                        for (int q = 0; q < 16; ++q) {
+                            const int j = c0 + lane + 64 * q;
+                            if (j < n) {
+                                T* slot = red + (size_t)(w % nred) * n + j;
+                                *slot = round == 0 ? cm[q] : tmax(*slot, cm[q]);
+                            }
+                        }
+                    }
+                    if (nred < LQP_NW) __syncthreads();
+                }
             }
         }
         __syncthreads();
@@ -528,6 +545,21 @@ __global__ __launch_bounds__(NT) void k_lu_factor(T* __restrict__ Mall, const in
                               dbg ? dbg + (size_t)b * 4 : nullptr);
 }
 
+// 1024 < N <= 2048: two panel rows per thread (lqp_lu_big.cuh)
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_lu_factor_big(T* __restrict__ Mall, const int N, const int ld,
+                                                          const size_t mstride, int* __restrict__ piv,
+                                                          const int pstride, int* __restrict__ info,
+                                                          const int* __restrict__ gate, const int* __restrict__ Nvec) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) info[b] = 0;
+    __syncthreads();
+    wg_lu_factor_big<T, lu_big_panel<T>(), sizeof(T) == 4, 2>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld,
+                                                               piv + (size_t)b * pstride, info + b, smem);
+}
+
 // lookahead LU (f32, N <= 512): panel k+1 on waves 0-7 while waves 8-15 run panel k's trailing update
 template <int PB, int NT>
 __global__ __launch_bounds__(NT) void k_lu_factor_la(float* __restrict__ Mall, const int N, const int ld,
@@ -613,6 +645,7 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
 // symmetric-inverse path (lqp_spd.cuh): factorisation kernels
 // ---------------------------------------------------------------------------
 // standalone SPD inverse (test / utility entry lqp_spd_inverse_batched): dense (B,n,n) in, dense inverse out
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __restrict__ Kin, float* __restrict__ out,
                                                               float* __restrict__ Hs_all, int* __restrict__ info,
                                                               const int n, const int Ks, float* __restrict__ Yg_all) {
@@ -774,6 +807,7 @@ __host__ __device__ inline int spd_factor_lds_bytes(int m, int Ks) {
     const int a = spd_lds_bytes(Ks > SPD_MAXK ? SPD_MAXK : Ks), c = m > 0 ? eqc_lds_bytes(m, Ks) : 0;
     return a > c ? a : c;
 }
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
@@ -789,6 +823,7 @@ constexpr int SPD_NP = 2;
 __device__ __forceinline__ float* spd_half(const FwdParams<float>& P, const int b, const int which) {
     return P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK + (size_t)which * sym_blocks(P.Ks) * LQP_BLK;
 }
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
@@ -810,6 +845,7 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, 
 // scaling starts from come out of the same pass over Q that checks its symmetry and builds the blocks -- unscaled; the
 // resident sweep scales them as it loads them.  One pass over Q per solve instead of two.
 static_assert(SPD_NP == 2, "k_fwd_setup reads the two halves k_spd_prep leaves");
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_prep(const FwdParams<float> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
@@ -818,6 +854,7 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_prep(const FwdParams<float> P) {
                                            part, sc + (size_t)part * P.Ks * LQP_NB);
     if (threadIdx.x == 0) ((int*)(sc + (size_t)SPD_NP * P.Ks * LQP_NB))[part] = asym > 0.f ? 1 : 0;
 }
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, const int* __restrict__ gate, const int k,
                                                       const int pivot_tasks) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -829,6 +866,7 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, c
 }
 // 512 < n <= 1024, few problems: one launch per PHASE of a pivot step (1: pivot block + Y phase, 2: tile updates), two
 // workgroups per matrix, in place in half 0; the panel scratch is the (unused on this path) KKT matrix area.
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_big_step(const FwdParams<float> P, const int* __restrict__ gate, const int k,
                                                           const int phases) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -869,6 +907,7 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
                               (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
 #endif
 }
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_end(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
@@ -1768,6 +1807,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
 }
 
 // all problems optimal at the check held in `slot` (iteration `it_check`)?  -> DONE
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ void k_check_done(int* status, const unsigned int* counters, const int slot, const int it_check) {
     if (threadIdx.x == 0 && status[ST_DONE] == 0 && counters[(size_t)slot * CT_WORDS + CT_NOTOPT] == 0) {
         status[ST_FINAL_ITER] = it_check;
@@ -1847,6 +1887,7 @@ template <typename T> struct BwdParams {
     unsigned long long* dbg;   // optional cycle counters (8 per problem), debug only
     int la_maxk;               // largest block count the look-ahead Cholesky may take (LDS of the launch), 0 = off
     int* host_report;          // optional pinned host memory, B ints: the epilogue leaves every problem's info word there
+    int early_report;          // 1: Cholesky form -- k_bwd_chol_solve reports (the info words are final there), not the epilogue
 };
 
 template <typename T>
@@ -1922,26 +1963,31 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
     T* M = P.M + (size_t)b * Np * Np;
     T* rhs = P.rhs + (size_t)b * Np;
     if (tid == 0 && blockIdx.y == 0) P.info[b] = 0;
-    // ---- ordered compaction of the free set (n <= 1024: one variable per thread) ----
-    bool keep = false;
-    if (tid < n) {
-        const T sxu = x[tid] + u[tid];
-        keep = !(sxu > ub[tid] || sxu < lb[tid]);
-    }
-    const unsigned long long bal = __ballot(keep);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wtot[w] = __popcll(bal);
-    __syncthreads();
-    int base = 0, nf = 0;
+    // ---- ordered compaction of the free set: one variable per thread and pass (n <= 1024: one pass) ----
+    int nf = 0;
+    for (int i0 = 0; i0 < n; i0 += LQP_NT) {
+        const int i = i0 + tid;
+        bool keep = false;
+        if (i < n) {
+            const T sxu = x[i] + u[i];
+            keep = !(sxu > ub[i] || sxu < lb[i]);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (i0 > 0) __syncthreads();                  // (wtot of the previous pass has been read by everybody)
+        if (lane == 0) wtot[w] = __popcll(bal);
+        __syncthreads();
+        int base = nf;
 #pragma unroll
-    for (int ww = 0; ww < LQP_NW; ++ww) {
-        const int c = wtot[ww];
-        if (ww < w) base += c;
-        nf += c;
-    }
-    if (keep) {
-        fl[base + before] = tid;
-        if (blockIdx.y == 0) P.fidx[(size_t)b * n + base + before] = tid;
+        for (int ww = 0; ww < LQP_NW; ++ww) {
+            const int c = wtot[ww];
+            if (ww < w) base += c;
+            nf += c;
+        }
+        if (keep) {
+            fl[base + before] = i;
+            if (blockIdx.y == 0) P.fidx[(size_t)b * n + base + before] = i;
+        }
     }
     if (tid == 0 && blockIdx.y == 0) P.nred[b] = nf + m;
     __syncthreads();
@@ -1974,6 +2020,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
 // Build: ordered compaction of the free set, Kf as packed lower 64x64 blocks (identity padding), -g_F -> rhs,
 // A_F rows -> the (otherwise unused) M buffer.  LDS: fl[n] (int) | wtot[NW]
 // ---------------------------------------------------------------------------
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
@@ -2058,6 +2105,7 @@ __host__ __device__ inline int bwd_chol_lds_bytes(int n, int m) {
     const int c = ((3 + m) * Npm + 2 * 64 + 2 * LQP_NW * 64 + m * m + 2 * m + 8) * 4;
     return a > c ? a : c;
 }
+template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
@@ -2140,6 +2188,15 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     }
     for (int q = tid; q < m; q += LQP_NT) rhs[nf + q] = dn[q];
     if (P.dbg && tid == 0) P.dbg[(size_t)b * 8 + 2] = clock64() - dt0;
+    // The info word of this problem is final here: it goes to the caller's pinned host memory NOW (the epilogue of the
+    // Cholesky form does not report again), so a synchronous caller -- it polls those words -- returns while the epilogue
+    // still writes the gradients (stream-ordered results) and prepares its next call under it.
+    if (P.host_report && P.early_report) {
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(P.host_report + b, __hip_atomic_load(P.info + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // One step of iterative refinement for the LU form of the reduced system: r = rhs - M d with the ORIGINAL entries
@@ -2237,7 +2294,8 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     const T* x = P.x + (size_t)b * n;
     // singular system / Q_FF not positive definite: gradients come out as NaN, never as plausible garbage
     const T poison = P.info[b] != 0 ? T(__builtin_nanf("")) : T(0);
-    if (P.host_report && tid == 0 && blockIdx.y == 0)      // (straight into pinned host memory: no device-to-host copy behind the call)
+    if (P.host_report && !(P.chol && P.early_report) && tid == 0 && blockIdx.y == 0)      // (straight into pinned host memory: no device-to-host copy behind the
+                                                                       //  call; Cholesky form: k_bwd_chol_solve has reported already)
         __hip_atomic_store(P.host_report + b, P.info[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (P.reduced) {
         const int nf = P.nred[b] - m;

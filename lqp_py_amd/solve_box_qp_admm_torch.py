@@ -12,6 +12,7 @@ control dict -- including its key-name traps and the caller-dict side effect --
 and moves pointers.  Tensors must be on the GPU; there is no CPU fallback.
 """
 import ctypes
+import os
 import threading
 import weakref
 
@@ -22,6 +23,7 @@ from . import _lib
 from .utils import get_ncon
 
 _INF = float("inf")
+_SYNC_SPLIT = os.environ.get("LQP_SYNC_SPLIT", "1") != "0"      # (A/B knob: 0 = one-call synchronous forward)
 
 
 class SolveBoxQP(nn.Module):
@@ -344,7 +346,10 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
             adaptive_rho=int(r['adaptive_rho']), adaptive_rho_iter=int(r['adaptive_rho_iter']),
             adaptive_rho_max_iter=int(r['adaptive_rho_max_iter']), scale=int(r['scale']),
             any_lb=int(any_bound), any_ub=int(any_bound), rho_mode=rho_mode,
-            beta_mode=beta_mode, launch_mode=int(r['launch_mode']), reserved=0 if sync else 1,
+            beta_mode=beta_mode, launch_mode=int(r['launch_mode']),
+            # 1: pipelined (nothing waits); 2: split synchronous call -- enqueue, build the output views while the GPU runs,
+            # then lqp_boxqp_forward_finish polls the report (include/lqp_amd.h)
+            reserved=(2 if (check_hook is None and _SYNC_SPLIT) else 0) if sync else 1,
             eps_abs=float(r['eps_abs']), eps_rel=float(r['eps_rel']), rho_value=rho_value,
             rho_min=float(r['rho_min']), rho_max=float(r['rho_max']),
             adaptive_rho_tol=float(r['adaptive_rho_tol']),
@@ -400,6 +405,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
                                    ctypes.byref(ctl), _lib.ptr(rho_tensor),
                                    o_x, o_z, o_u, o_l, o_nu if m > 0 else None, o_rho,
                                    ctypes.byref(stats), _lib.ptr(ws), ws.numel())
+    split_wait = st == 0 and stats.mode_used == 4
     parts = outbuf.split_with_sizes((B * n4, B * n4, 2 * B * n4, B * m4, 4 * B))
     if n4 == n:
         z, u, lams = parts[0].view(B, n, 1), parts[1].view(B, n, 1), parts[2].view(B, 2 * n, 1)
@@ -407,6 +413,16 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         z, u, lams = (parts[k][:B * n * (2 if k == 2 else 1)].view(B, n * (2 if k == 2 else 1), 1) for k in range(3))
     nus = parts[3][:B * m].view(B, m, 1) if m > 0 else None
     rho_out = parts[4][:B]
+    if split_wait:
+        # (the views above were made while the GPU ran; now the report: polled in pinned memory, no stream wait)
+        st = lib.lqp_boxqp_forward_finish(ctypes.c_void_p(stream), B, ctl.max_iters, ctl.check_solved,
+                                          ctypes.c_void_p(report.data_ptr()), ctypes.byref(stats))
+        if st == 7:
+            # the matrix left the symmetric x-update (not symmetric, or Qs + rho I not positive definite in f32): the
+            # reference's algorithm -- the pivoted LU -- takes the solve, as a one-call synchronous forward does by itself
+            _lib._pinned_free.setdefault(report.numel(), []).append(report)
+            return _forward_solve(Q, p, A, b, lb, ub, dict(control, linsolve='lu', _owner=owner), bounds=bounds, sync=sync,
+                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder)
     if st != 0 or (check_hook is not None and hook_error):
         # kernels of the failed call may still be in flight, and they write their report into `report`: wait before the
         # pinned buffer goes back to the pool (cold path)

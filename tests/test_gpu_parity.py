@@ -91,6 +91,35 @@ def test_lu_factor_matches_lapack(dev, N, B, dtype):
     assert rel(lu_layer.lu_solve(LU, P, rhs.to(dev)), xr) < stol                         # HIP factor, HIP solve
 
 
+@pytest.mark.parametrize("N,B,dtype", [(1025, 2, torch.float64), (1100, 2, torch.float32), (1501, 2, torch.float64),
+                                       (2048, 1, torch.float32), (2048, 1, torch.float64)])
+def test_lu_factor_above_1024(dev, N, B, dtype):
+    """1024 < N <= 2048: two panel rows per thread (k_lu_factor_big), the matrix in global memory.  float64: the pivots
+    ARE LAPACK's; float32 (a near-tie may flip under another summation order at this size): P A = L U to rounding,
+    |L| <= 1 (partial pivoting), and the solves."""
+    torch.manual_seed(N)
+    A = torch.randn(B, N, N, dtype=dtype)
+    LUr, Pr = torch.linalg.lu_factor(A)
+    LU, piv = lu_layer.lu_factor(A.to(dev))
+    LUc, Pc = LU.cpu(), piv.cpu()
+    if dtype == torch.float64:
+        assert torch.equal(Pc, Pr)
+        assert rel(LU, LUr) < 1e-9
+    Pm, Lm, Um = torch.lu_unpack(LUc.double(), Pc)
+    recon = float((Pm @ Lm @ Um - A.double()).abs().max()) / float(A.abs().max())
+    assert recon < (1e-4 if dtype == torch.float32 else 1e-12), recon
+    assert float(torch.tril(LUc, -1).abs().max()) <= 1.0 + 1e-6
+    # the solves: residual of A x = rhs no worse than LAPACK's own in the same precision (a random dense matrix of this
+    # size has cond ~ 1e4-1e5: the float32 residual is ~1e-2 for either)
+    rhs = torch.randn(B, N, 2, dtype=dtype)
+    resid = lambda x: float((A.double() @ x.cpu().double() - rhs.double()).abs().max())
+    r_lapack = resid(torch.linalg.lu_solve(LUr, Pr, rhs))
+    r_hip = resid(lu_layer.lu_solve(LU, piv, rhs.to(dev)))                             # HIP factor, HIP solve
+    r_mix = resid(lu_layer.lu_solve(LUr.to(dev), Pr.to(dev), rhs.to(dev)))           # torch factor, HIP solve
+    P.record(f"lu_above_1024_N{N}_{'f32' if dtype == torch.float32 else 'f64'}", "residual", r_hip, lapack=r_lapack, mixed=r_mix)
+    assert r_hip <= 3 * r_lapack + 1e-9 and r_mix <= 3 * r_lapack + 1e-9, (r_hip, r_mix, r_lapack)
+
+
 @pytest.mark.parametrize("mfma", ["0", "1"])
 @pytest.mark.parametrize("n,dtype", [(500, torch.float32), (1000, torch.float32), (500, torch.float64)])
 def test_lu_kkt_sized(dev, n, dtype, mfma, monkeypatch):
@@ -684,9 +713,41 @@ def test_training_loop_matches_cpu_oracle(dev):
 
 
 def test_unsupported_sizes_fail_loudly(dev):
+    n = 2049                                  # (n + m <= 2048 since round 4: the pivoted LU holds two panel rows per thread)
     with pytest.raises(RuntimeError, match="unsupported"):
-        L.torch_solve_box_qp(torch.zeros(1, 1100, 1100, device=dev), torch.zeros(1, 1100, 1, device=dev), None, None,
-                             -torch.ones(1, 1100, 1, device=dev), torch.ones(1, 1100, 1, device=dev), {})
+        L.torch_solve_box_qp(torch.zeros(1, n, n, device=dev), torch.zeros(1, n, 1, device=dev), None, None,
+                             -torch.ones(1, n, 1, device=dev), torch.ones(1, n, 1, device=dev), {})
+
+
+def test_g16_n1500_above_the_on_chip_tiers(dev):
+    """Reference-made golden at n = 1500, m = 1, B = 8 (the reference's LAPACK calls take any size; README.md:49 discusses
+    n_x > 500): forward iterates + all six fixed-point gradients.  n + m > 1024 runs the reference's own algorithm, the
+    pivoted LU of the KKT matrix with cached triangular solves, on the HBM-resident tier."""
+    g = load_golden("g16_b8_n1500_eq")
+    inp = O.create_qp_data(1500, 8, seed=0)
+    assert abs(float(inp[0].double().sum()) - float(g["in_sum"][0])) < 1e-6 * abs(float(g["in_sum"][0]))
+    sol, a = solve(dev, inp, O.make_control(**TOL))
+    assert sol["iter"] == g["iter"] and sol["_stats"]["linsolve_used"] == 1
+    t64, g64 = fp64_truth(inp, int(g["iter"]), cots=(g["cot"],))
+    case = "g16_b8_n1500_eq"
+    for k in ("x", "z", "u", "lams", "nus"):
+        close_or_fp64(case, k, sol[k], g[k], t64[k], X_TOL)
+    assert rel(sol["rho"], g["rho"]) < 1e-5
+    gr = L.torch_solve_box_qp_grad(g["cot"].to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
+    for idx, nm in enumerate(GRADS):
+        if nm == "dQ":
+            continue
+        close_or_fp64(case, nm, gr[idx], g[nm], g64[0][idx], G_RTOL)
+    dQ = gr[0]
+    close_or_fp64(case, "dQ_fro", torch.linalg.matrix_norm(dQ), g["dQ_fro"], torch.linalg.matrix_norm(g64[0][0]), G_RTOL)
+    sb, si, sj = (g[k].long() for k in ("sb", "si", "sj"))
+    close_or_fp64(case, "dQ_samples", dQ[sb.to(dev), si.to(dev), sj.to(dev)], g["dQ_samples"], g64[0][0][sb, si, sj], G_RTOL)
+    # the module path (autograd) at the same size, float64 inputs: the same kernels in double
+    d = [t.double().to(dev) for t in inp]
+    Qg = d[0].clone().requires_grad_(True)
+    x64 = L.SolveBoxQP(control=L.box_qp_control(**TOL))(Qg, *d[1:])
+    x64.backward(g["cot"].double().to(dev))
+    assert err(x64, t64["x"]) < 1e-4 and torch.isfinite(Qg.grad).all()      # (its own stopping point: the tolerance level)
 
 
 # ---------------------------------------------------------------- bench.py contract

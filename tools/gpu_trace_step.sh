@@ -1,9 +1,9 @@
 #!/bin/bash
 # kernel trace of a few bench steps: which launches (ours, torch's, the runtime's copy / fill kernels) one step consists of
-# usage (GPU box, repo root): bash tools/gpu_trace_step.sh  ->  gpurun_out/trace_step.txt
+# usage (GPU box, repo root): bash tools/gpu_trace_step.sh [extra bench.py flags, e.g. --sync]  ->  gpurun_out/trace_step.txt
 root=$(pwd); out=$root/gpurun_out/trace; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/kt -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs > $out/kt.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/kt -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs "$@" > $out/kt.log 2>&1 || exit 1
 cd $root
 python3 - <<'PY'
 import csv, glob

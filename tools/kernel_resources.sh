@@ -5,8 +5,8 @@ so=$(realpath ${LQP_LIB:-lqp_py_amd/csrc/liblqp_amd.so})
 tmp=$(mktemp -d)
 cp $so $tmp/lib.so
 (cd $tmp && /opt/rocm/lib/llvm/bin/llvm-objdump --offloading lib.so > /dev/null 2>&1)
-co=$(ls $tmp/lib.so.*gfx950* 2>/dev/null | head -1)
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $co | python3 -c "
+# (the split build leaves one code object per translation unit)
+for co in $(ls $tmp/lib.so.*gfx950* 2>/dev/null); do /opt/rocm/lib/llvm/bin/llvm-readelf --notes $co; done | python3 -c "
 import sys,re
 txt=sys.stdin.read()
 pat=sys.argv[1] if len(sys.argv)>1 else ''
