@@ -732,7 +732,8 @@ def test_g16_n1500_above_the_on_chip_tiers(dev):
     case = "g16_b8_n1500_eq"
     for k in ("x", "z", "u", "lams", "nus"):
         close_or_fp64(case, k, sol[k], g[k], t64[k], X_TOL)
-    assert rel(sol["rho"], g["rho"]) < 1e-5
+    # (rho = ||Qs||_F / sqrt(n), a float32 sum of 2.25 M squares: within 1e-5, or no further from float64 than the reference's)
+    close_or_fp64(case, "rho", sol["rho"], g["rho"], t64["rho"], 1e-5)
     gr = L.torch_solve_box_qp_grad(g["cot"].to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
     for idx, nm in enumerate(GRADS):
         if nm == "dQ":
