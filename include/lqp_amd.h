@@ -79,7 +79,8 @@ typedef struct lqp_boxqp_ctrl {
                                         reference's, :214-215/:267), 2 symmetric inverse of Qs + rho I with a
                                         rank-m equality correction (f32, n <= 1024, m <= 16, rho > 0; anything
                                         else, or a matrix that is not positive definite, runs on LU)            */
-    int32_t reserved2;
+    int32_t reserved2;               /* bit 0: leave the complete factor (equality correction included) in the workspace for
+                                        lqp_boxqp_unroll_backward                                                    */
     double eps_abs;
     double eps_rel;
     double rho_value;
@@ -194,6 +195,21 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m,
  * LQP_ERR_NOT_SPD: repeat the forward with ctrl.linsolve = 1 (a one-call synchronous forward does that by itself). */
 int lqp_boxqp_forward_finish(void* stream, int B, int max_iters, int check_solved, const void* host_report,
                              lqp_boxqp_stats* stats);
+
+/* ---- unroll=True: backward through the unrolled ADMM loop ------------------------------------------------
+ * The reference's `unroll` mode (lqp_py/solve_box_qp_admm_torch.py:14-15, 216-219, 255-256, 264-265) lets autograd tape
+ * every iteration, each x-update being TorchLULayer (lqp_py/lu_layer.py:25-58: backward dx = lu_solve(LU, P, -g),
+ * dA = dx x^T, db = -dx).  With a constant factor that tape is ONE reverse recurrence: this entry replays the `iters + 1`
+ * x-updates of the float32 forward that used `fwd_workspace` (it must have run the symmetric x-update WITHOUT an
+ * adaptive-rho refactorisation, with ctrl.reserved2 bit 0 set so that its factor is complete in the workspace; nothing
+ * else may have used that workspace since) and walks back through them.  Outputs are the gradients w.r.t. the SCALED
+ * problem the loop ran on -- dQs (B,n,n; NULL = skip), dps (B,n), dAs (B,m,n), dbs (B,m), dlbs, dubs (B,n), drho (B) --
+ * and dD (B,n) = dl_dx * x_scaled (the returned x is D x); the caller chains them through the scaling (:160-203).
+ * dl_dx (B,n): gradient w.r.t. the returned solution.  float32 only.                                            */
+size_t lqp_boxqp_unroll_backward_workspace_bytes(int B, int n, int m, int iters);
+int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                              int iters, const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs,
+                              void* dubs, void* drho, void* dD, void* scratch, size_t scratch_bytes);
 
 /* Primal / dual error (inf-norms of D r and D s, :287-288) of the LAST convergence check of the forward that
  * used `workspace`, one value per problem -- the two numbers the reference's NumPy solver returns next to the

@@ -16,7 +16,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQP_LIB: A/B builds
-SOURCES = ["lqp_amd.hip", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_lu_big.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
+SOURCES = ["lqp_amd.hip", "lqp_unroll.cuh", "lqp_boxqp.cuh", "lqp_lu.cuh", "lqp_lu_big.cuh", "lqp_trsv.cuh", "lqp_spd.cuh", "lqp_common.cuh"]
 
 LQP_F32, LQP_F64 = 0, 1
 ABI_VERSION = 7
@@ -66,6 +66,8 @@ SYMBOLS = {
                                   ctypes.POINTER(BoxQPStats), _P, c_size_t]),
     "lqp_boxqp_forward_finish": (c_int, [_P, c_int, c_int, c_int, _P, ctypes.POINTER(BoxQPStats)]),
     "lqp_boxqp_forward_layout": (c_int, [c_int] * 4 + [ctypes.POINTER(c_size_t)] * 4),
+    "lqp_boxqp_unroll_backward_workspace_bytes": (c_size_t, [c_int] * 4),
+    "lqp_boxqp_unroll_backward": (c_int, [_P, c_int, c_int, c_int, _P, c_size_t, c_int] + [_P] * 10 + [c_size_t]),
     "lqp_boxqp_last_residuals": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +

@@ -2,6 +2,7 @@
 // orchestration, status reporting.  See include/lqp_amd.h for the contract.
 #include "../../include/lqp_amd.h"
 #include "lqp_boxqp.cuh"
+#include "lqp_unroll.cuh"
 #ifdef LQP_SPLIT_BUILD
 // split build (lqp_py_amd/_lib.py build_library, tools/gen_split_build.py): the kernel instances are compiled in the
 // translation units csrc/split/lqp_tu_*.hip; here they are only declared
@@ -90,7 +91,7 @@ template <typename F> bool blocks_per_cu(int* per_cu, F fn, int nt, int lds, int
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream ----
 enum { PC_SETUP = 0, PC_LU, PC_PACK, PC_LOOP, PC_RHO, PC_EPILOGUE, PC_BWD_BUILD, PC_SOLVE, PC_BWD_EPILOGUE,
-       PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_BWD_CHOL, PC_COUNT };
+       PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_BWD_CHOL, PC_UNROLL, PC_COUNT };
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::mutex g_prof_mutex;
 bool g_prof_on = false;
@@ -647,7 +648,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         }
     }
     // the equality correction of the first factorisation moves into that kernel (its blocks are in registers there)
-    if constexpr (sizeof(T) == 4) P.eq_in_loop = (loop_split && spd_resident && m > 0 && env_int("LQP_EQ_IN_LOOP", 1)) ? 1 : 0;
+    // (ctrl.reserved2 bit 0: the caller will read the corrected H from the workspace afterwards -- lqp_boxqp_unroll_backward --
+    //  so the correction must reach global memory: k_spd_end runs)
+    if constexpr (sizeof(T) == 4)
+        P.eq_in_loop = (loop_split && spd_resident && m > 0 && !(ctl->reserved2 & 1) && env_int("LQP_EQ_IN_LOOP", 1)) ? 1 : 0;
     rc = factor_step(nullptr);
     if (rc) return rc;
     // the first launch of the persistent modes
@@ -1199,7 +1203,7 @@ int lqp_profile_classes(void) { return PC_COUNT; }
 const char* lqp_profile_class_name(int c) {
     static const char* names[PC_COUNT] = {"fwd_setup", "lu_factor", "pack", "admm_loop", "rho_update", "fwd_epilogue",
                                           "bwd_build", "packed_solve", "bwd_epilogue", "misc", "admm_loop_tail",
-                                          "spd_inverse", "eq_correct", "bwd_cholesky"};
+                                          "spd_inverse", "eq_correct", "bwd_cholesky", "unroll_backward"};
     return (c >= 0 && c < PC_COUNT) ? names[c] : "?";
 }
 
@@ -1277,6 +1281,60 @@ int lqp_boxqp_forward_finish(void* stream, int B, int max_iters, int check_solve
     const int rc = collect_report((hipStream_t)stream, (const int*)host_report, true, B, max_iters,
                                   check_solved < 1 ? 1 : check_solved, stats);
     return rc == LQP_RETRY_LU ? LQP_ERR_NOT_SPD : rc;
+}
+
+// ---- unroll=True: backward through the unrolled loop (lqp_unroll.cuh) ----
+struct UnrollCarve { UnrollParams U; size_t bytes; };
+static UnrollCarve carve_unroll(void* ws, int B, int n, int m, int T) {
+    UnrollCarve c;
+    memset(&c.U, 0, sizeof(c.U));
+    Carver cv(ws);
+    c.U.X = cv.take<float>((size_t)B * T * n);
+    c.U.W = cv.take<float>((size_t)B * T * n);
+    c.U.DX = cv.take<float>((size_t)B * T * n);
+    c.U.NU = cv.take<float>((size_t)B * T * (m > 0 ? m : 1));
+    c.U.MK = cv.take<signed char>((size_t)B * T * n);
+    c.bytes = cv.off + kAlign;
+    return c;
+}
+
+size_t lqp_boxqp_unroll_backward_workspace_bytes(int B, int n, int m, int iters) {
+    if (B < 1 || n < 1 || m < 0 || iters < 0) return 0;
+    return carve_unroll(nullptr, B, n, m, iters + 1).bytes;
+}
+
+int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                              int iters, const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs,
+                              void* dubs, void* drho, void* dD, void* scratch, size_t scratch_bytes) {
+    if (B < 1 || n < 1 || m < 0 || iters < 0 || !fwd_workspace || !dl_dx || !dps || !dlbs || !dubs || !drho || !dD || !scratch)
+        return LQP_ERR_INVALID;
+    if (m > 0 && (!dAs || !dbs)) return LQP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    FwdLayout<float> L = carve_forward<float>((void*)fwd_workspace, B, n, m);
+    if (fwd_workspace_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+    const FwdParams<float>& P = L.P;
+    if (P.Ks > SPD_BIGK || m > SPD_MAXM) return LQP_ERR_UNSUPPORTED;      // (what the symmetric x-update takes)
+    const int T = iters + 1;
+    UnrollCarve c = carve_unroll(scratch, B, n, m, T);
+    if (scratch_bytes < c.bytes) return LQP_ERR_WORKSPACE;
+    UnrollParams& U = c.U;
+    U.T = T;
+    U.rl = unroll_lds_blocks(m, P.Ks);
+    U.g = (const float*)dl_dx;
+    U.dps = (float*)dps; U.dlbs = (float*)dlbs; U.dubs = (float*)dubs; U.dD = (float*)dD;
+    U.dAs = (float*)dAs; U.dbs = (float*)dbs; U.drho = (float*)drho;
+    const int lds = unroll_lds_bytes(m, P.Ks, U.rl);
+    int rc = ensure_lds((const void*)k_unroll_sweep<>, lds);
+    if (rc) return rc;
+    { ProfScope ps(st, PC_UNROLL);
+      hipLaunchKernelGGL(k_unroll_sweep<>, dim3(B), dim3(LQP_NT), lds, st, P, U); }
+    if (dQs) {
+        ProfScope ps(st, PC_UNROLL);
+        const int tiles = (n + 63) / 64;
+        hipLaunchKernelGGL(k_unroll_outer<>, dim3(tiles, tiles, B), dim3(256), 0, st, (const float*)U.DX, (const float*)U.X,
+                           (float*)dQs, n, T);
+    }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
 int lqp_boxqp_last_residuals(void* stream, int dtype, int B, int n, int m, const void* workspace, size_t workspace_bytes,

@@ -121,7 +121,7 @@ def torch_solve_box_qp(Q, p, A, b, lb, ub, control):
         from .unrolled import unrolled_solve_box_qp
         _lib.require_gpu(Q, p, A, b, lb, ub)
         has_lb, has_ub = _finite_bounds(lb, ub)
-        return unrolled_solve_box_qp(Q, p, A, b, lb, ub, resolve_control(control, p.shape[1]), has_lb, has_ub)
+        return unrolled_solve_box_qp(Q, p, A, b, lb, ub, resolve_control(control, p.shape[1]), has_lb, has_ub, control=control)
     return _forward_solve(Q, p, A, b, lb, ub, control, bounds=None)
 
 
@@ -284,7 +284,7 @@ def _beta_argument(beta, B, like):
 
 
 def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None, mutate=False,
-                   holder=None):
+                   holder=None, private_ws=None, keep_factor=False):
     """bounds: (any_lb, any_ub) when the caller KNOWS them (a shard of a larger batch with host-side flags); None: found
     on the device.  mutate: apply the reference layer's dict side effect control['rho'] = 0 (:37-38).  holder: the
     nn.Module on whose behalf the call is made (keys what is remembered between calls, see _assume_any_bound)."""
@@ -382,7 +382,9 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     o_nu, o_rho = base + 4 * B * n4 * es, base + (4 * B * n4 + B * m4) * es
     nbytes = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    ws = _lib.workspace(dev, nbytes, "fwd", stream)
+    # (private_ws / keep_factor: the unroll mode keeps the solve's workspace -- factor included -- for its backward)
+    ws = private_ws if private_ws is not None else _lib.workspace(dev, nbytes, "fwd", stream)
+    ctl.reserved2 = 1 if keep_factor else 0
     if check_hook is not None:
         # check_hook(counters) all-reduces (SUM) the four uint32 words of a check -- {not optimal, arrivals, wants rho,
         # ratio trigger} -- in place; it gets a tensor VIEW of the workspace at the device address the library names.

@@ -1,15 +1,23 @@
-"""``unroll=True``: the ADMM loop as ordinary differentiable torch ops on the GPU, so that
-autograd tapes every iteration (reference: lqp_py/solve_box_qp_admm_torch.py:14-15 routes the
-module here, :216-219/:255-256/:264-265 swap the plain LU solve for the ``TorchLU`` layer).
+"""``unroll=True``: differentiate THROUGH the ADMM loop (reference: lqp_py/solve_box_qp_admm_torch.py:14-15 routes the
+module here, :216-219/:255-256/:264-265 swap the plain LU solve for the ``TorchLU`` layer so that autograd tapes every
+iteration).
 
-Only the linear algebra leaves torch: every x-update is ``TorchLU`` (lqp_py_amd/lu_layer.py), i.e. the
-HIP batched LU factor + streaming cached solve with the analytic backward of lu_layer.py:41-58.
-The element-wise algebra stays in torch on purpose -- it is what autograd differentiates through.
-This is the slow, memory-hungry mode the reference benchmarks as "ADMM Unroll"; the fast path is the
-fixed-point backward of ``SolveBoxQPLayer``.
+Native path (float32, symmetric x-update, no adaptive-rho refactorisation -- the benchmark case): the forward is the
+ordinary persistent HIP solve; the backward is ONE reverse sweep over the recorded iterations in the HIP library
+(``lqp_boxqp_unroll_backward``, csrc/lqp_unroll.cuh): per iteration one product with the cached inverse instead of a taped
+``TorchLULayer`` node, no per-iteration torch op, no host sync.  The kernel differentiates the loop, i.e. it returns the
+gradients w.r.t. the SCALED problem (Qs, ps, As, bs, lbs, ubs, rho, D); the scaling itself (:160-203: ~25 element-wise /
+reduction ops, once per call) is differentiated by autograd on a small eager graph rebuilt in ``backward``.
+
+Everything else (float64, a matrix outside the symmetric x-update, a solve in which rho was adapted, no finite bound)
+takes the eager path below: the loop as torch ops with ``TorchLU`` (HIP LU factor / cached solves) as the taped solve.
 """
+import ctypes
+import os
+
 import torch
 
+from . import _lib
 from .lu_layer import TorchLU
 from .utils import get_ncon
 
@@ -31,18 +39,15 @@ def _inf_norm(v):
     return torch.linalg.norm(v, ord=_INF, dim=1, keepdim=True)
 
 
-def unrolled_solve_box_qp(Q, p, A, b, lb, ub, r, has_lb, has_ub):
-    """``r`` is the resolved control (solve_box_qp_admm_torch.resolve_control). Returns x only,
-    as the reference does in unroll mode (:328-329)."""
-    dev, dt = p.device, p.dtype
-    B, n = Q.shape[0], p.shape[1]
+def _scaled_problem(Q, p, A, b, lb, ub, r, has_box):
+    """The reference's pre-conditioning (:160-203) as differentiable torch ops -> (Qs, ps, As, bs, lbs, ubs, D, E, rho);
+    D / E are 1.0 without scaling, rho may be a python number."""
+    dev = p.device
+    n = p.shape[1]
     m = get_ncon(A, dim=1)
-    has_box = has_lb or has_ub
-    p_inf = _inf_norm(p)
     rho = r['rho']
     if not has_box:
         rho = 0
-
     D = E = 1.0
     if r['scale']:
         d = torch.sqrt(1 / _floor_nonpositive(torch.linalg.norm(Q, ord=_INF, dim=1)))
@@ -61,9 +66,93 @@ def unrolled_solve_box_qp(Q, p, A, b, lb, ub, r, has_lb, has_ub):
         D = d.unsqueeze(2)
         if has_box:
             lb, ub = lb / D, ub / D
-
     if rho is None:
         rho = torch.clamp(torch.linalg.matrix_norm(Q, keepdim=True) / n ** 0.5, min=r['rho_min'], max=r['rho_max'])
+    return Q, p, A, b, lb, ub, D, E, rho
+
+
+class _UnrolledLoop(torch.autograd.Function):
+    """forward: the persistent HIP solve on a workspace of its own (kept for the backward); backward: the reverse sweep of
+    lqp_boxqp_unroll_backward + the scaling chain by autograd.  Raises _NotNative when the solve did not take the
+    symmetric x-update with a constant factor."""
+
+    @staticmethod
+    def forward(ctx, Q, p, A, b, lb, ub, control, r, bounds):
+        from .solve_box_qp_admm_torch import _forward_solve
+        lib = _lib.load()
+        B, n = Q.shape[0], p.shape[1]
+        m = get_ncon(A, dim=1)
+        ws = torch.empty(int(lib.lqp_boxqp_forward_workspace_bytes(_lib.LQP_F32, B, n, m)), dtype=torch.uint8, device=p.device)
+        sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=bounds, sync=True, private_ws=ws, keep_factor=True)
+        st = sol['_stats']
+        if st['linsolve_used'] != 2 or st['n_factor'] != 1:
+            raise _NotNative()
+        ctx.ws, ctx.iters, ctx.r, ctx.has_box = ws, int(st['iters']), r, bool(bounds[0] or bounds[1])
+        ctx.save_for_backward(Q, p, A, b, lb, ub)
+        return sol['x']
+
+    @staticmethod
+    def backward(ctx, g):
+        Q, p, A, b, lb, ub = ctx.saved_tensors
+        lib = _lib.load()
+        B, n = Q.shape[0], p.shape[1]
+        m = get_ncon(A, dim=1)
+        dev, dt = p.device, p.dtype
+        need = ctx.needs_input_grad
+        mk = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+        dQs = mk(B, n, n) if need[0] else None
+        dps, dlbs, dubs, dD, drho = mk(B, n, 1), mk(B, n, 1), mk(B, n, 1), mk(B, n, 1), mk(B, 1, 1)
+        dAs, dbs = (mk(B, m, n), mk(B, m, 1)) if m > 0 else (None, None)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        nbytes = lib.lqp_boxqp_unroll_backward_workspace_bytes(B, n, m, ctx.iters)
+        scratch = _lib.workspace(dev, nbytes, "unroll", stream)
+        gc = _lib.norm(g, dt)
+        with _lib.on_device(dev):
+            _lib.check(lib.lqp_boxqp_unroll_backward(
+                ctypes.c_void_p(stream), B, n, m, _lib.ptr(ctx.ws), ctx.ws.numel(), ctx.iters, _lib.ptr(gc),
+                _lib.ptr(dQs), _lib.ptr(dps), _lib.ptr(dAs), _lib.ptr(dbs), _lib.ptr(dlbs), _lib.ptr(dubs),
+                _lib.ptr(drho), _lib.ptr(dD), _lib.ptr(scratch), scratch.numel()), "unroll_backward")
+        ctx.ws = None
+        # ---- the scaling (:160-203) by autograd: leaves -> (Qs, ps, As, bs, lbs, ubs, D, rho) ----
+        leaves = [None if t is None else t.detach().requires_grad_(bool(nd)) for t, nd in zip((Q, p, A, b, lb, ub), need[:6])]
+        with torch.enable_grad():
+            Qs, ps, As, bs, lbs, ubs, D, _E, rho = _scaled_problem(*leaves, ctx.r, ctx.has_box)
+        pairs = [(Qs, dQs), (ps, dps), (As, dAs), (bs, dbs), (lbs, dlbs), (ubs, dubs), (D, dD), (rho, drho)]
+        outs = [(o, go) for o, go in pairs if torch.is_tensor(o) and o.requires_grad and go is not None]
+        wanted = [t for t in leaves if t is not None and t.requires_grad]
+        grads = iter(torch.autograd.grad([o for o, _ in outs], wanted, [go for _, go in outs], allow_unused=True) if outs and wanted
+                     else [None] * len(wanted))
+        res = [next(grads) if (t is not None and t.requires_grad) else None for t in leaves]
+        return tuple(res) + (None, None, None)
+
+
+class _NotNative(Exception):
+    pass
+
+
+def unrolled_solve_box_qp(Q, p, A, b, lb, ub, r, has_lb, has_ub, control=None):
+    """``r`` is the resolved control (solve_box_qp_admm_torch.resolve_control). Returns x only,
+    as the reference does in unroll mode (:328-329)."""
+    if (control is not None and p.dtype == torch.float32 and (has_lb or has_ub) and r['linsolve'] != 'lu'
+            and os.environ.get("LQP_UNROLL_NATIVE", "1") != "0"):
+        try:
+            ctl = {k: v for k, v in control.items() if k != 'unroll'}
+            return _UnrolledLoop.apply(Q, p, A, b, lb, ub, ctl, r, (has_lb, has_ub))
+        except _NotNative:
+            pass                   # (LU path / adapted rho: the taped loop below)
+    return _eager_unrolled(Q, p, A, b, lb, ub, r, has_lb, has_ub)
+
+
+def _eager_unrolled(Q, p, A, b, lb, ub, r, has_lb, has_ub, solver_cls=TorchLU):
+    """The loop as ordinary differentiable torch ops; every x-update is ``TorchLU`` (lqp_py_amd/lu_layer.py): HIP batched
+    LU factor + cached solves with the analytic backward of lu_layer.py:41-58.  (solver_cls: tests substitute a CPU
+    float64 stand-in for the HIP layer to obtain a higher-precision truth of the same taped computation.)"""
+    dev, dt = p.device, p.dtype
+    B, n = Q.shape[0], p.shape[1]
+    m = get_ncon(A, dim=1)
+    has_box = has_lb or has_ub
+    p_inf = _inf_norm(p)
+    Q, p, A, b, lb, ub, D, E, rho = _scaled_problem(Q, p, A, b, lb, ub, r, has_box)
 
     eye = torch.eye(n, dtype=dt, device=dev).unsqueeze(0)
 
@@ -75,7 +164,7 @@ def unrolled_solve_box_qp(Q, p, A, b, lb, ub, r, has_lb, has_ub):
         return M
 
     M = kkt(rho)
-    solver = TorchLU(A=M)                         # HIP factorisation, no_grad inside
+    solver = solver_cls(A=M)                      # HIP factorisation, no_grad inside
 
     x = z = u = torch.zeros(B, n, 1, dtype=dt, device=dev)
     tiny = torch.full((1,), _TINY, dtype=dt, device=dev)
@@ -90,7 +179,7 @@ def unrolled_solve_box_qp(Q, p, A, b, lb, ub, r, has_lb, has_ub):
                 rho = rho * torch.logical_not(wants) + (rho * ratio) * wants
                 rho = torch.clamp(rho, min=r['rho_min'], max=r['rho_max'])
                 M = kkt(rho)
-                solver = TorchLU(A=M)
+                solver = solver_cls(A=M)
         rhs = -p + rho * (z - u)
         if m > 0:
             rhs = torch.cat((rhs, b), 1)

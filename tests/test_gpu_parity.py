@@ -672,16 +672,83 @@ def test_g12_kkt_backward_mode(dev):
         assert err(t.grad, g[nm]) < 1e-4 * max(1.0, float(g[nm].abs().max())), nm
 
 
-def test_g13_unroll_mode(dev):
-    """unroll=True: autograd through the loop, HIP LU factor/solve inside TorchLU."""
-    g = load_golden("g13_unroll")
+class _CpuLU(torch.nn.Module):
+    """CPU stand-in for the taped solve of the unrolled loop (lqp_py/lu_layer.py:5-58 restated with torch.linalg): lets
+    lqp_py_amd.unrolled._eager_unrolled run in float64 on the host as the truth of the same taped computation."""
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, A, b, LU, piv):
+            x = O.lu_solve(LU, piv, b)
+            ctx.save_for_backward(LU, piv, x)
+            return x
+
+        @staticmethod
+        def backward(ctx, g):
+            LU, piv, x = ctx.saved_tensors
+            dA, db = O.lu_layer_backward(LU, piv, x, g)
+            return dA, db, None, None
+
+    def __init__(self, A):
+        super().__init__()
+        with torch.no_grad():
+            self.LU, self.piv = O.lu_factor(A)
+
+    def forward(self, A, b):
+        return self._Fn.apply(A, b, self.LU, self.piv)
+
+
+def _unroll_truth64(g, ctl):
+    from lqp_py_amd.unrolled import _eager_unrolled
+    leaves = [g[k].double().requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    x = _eager_unrolled(*leaves, SB.resolve_control(ctl, leaves[1].shape[1]), True, True, solver_cls=_CpuLU)
+    x.backward(g["cot"].double())
+    return x.detach(), [t.grad for t in leaves]
+
+
+@pytest.mark.parametrize("name,tol", [("g13_unroll", 1e-6), ("g17_unroll_n100", 1e-5)])
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_unroll_mode_goldens(dev, monkeypatch, name, tol, native):
+    """unroll=True against the reference-made goldens G13 (n = 20) and G17 (n = 100): the solution at
+    1e-5, all six gradients at rtol 1e-4 -- or no further from a float64 run of the same taped computation than the
+    reference's own float32 gradients.  native 1: the HIP reverse sweep (lqp_boxqp_unroll_backward); 0: the taped loop."""
+    monkeypatch.setenv("LQP_UNROLL_NATIVE", native)
+    g = load_golden(name)
     leaves = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
-    ctl = L.box_qp_control(unroll=True, eps_abs=1e-6, eps_rel=1e-6)
+    ctl = L.box_qp_control(unroll=True, eps_abs=tol, eps_rel=tol)
+    _lib.profile(enable=True, reset=True)
     x = L.SolveBoxQP(control=ctl)(*leaves)
-    assert torch.is_tensor(x) and err(x, g["x"]) < 2e-5
+    assert torch.is_tensor(x)
     x.backward(g["cot"].to(dev))
-    for nm, t in zip(GRADS, leaves):
-        assert err(t.grad, g[nm]) < 2e-4 * max(1.0, float(g[nm].abs().max())), nm
+    used = _lib.profile(); _lib.profile(enable=False)
+    assert (used["unroll_backward"][1] == 2) == (native == "1"), used["unroll_backward"]
+    x64, g64 = _unroll_truth64(g, ctl)
+    close_or_fp64(name, "x", x, g["x"], x64, X_TOL, native=native)
+    for nm, t, t64 in zip(GRADS, leaves, g64):
+        close_or_fp64(name, nm, t.grad, g[nm], t64, G_RTOL, native=native)
+
+
+def test_unroll_native_falls_back(dev):
+    """What the reverse sweep does not cover takes the taped loop by itself: float64, the cached-LU x-update, a solve in
+    which rho was adapted (the factor is no longer constant along the tape)."""
+    g = load_golden("g13_unroll")
+    for kind in ("f64", "lu", "adapted"):
+        cast = (lambda t: t.double()) if kind == "f64" else (lambda t: t)
+        leaves = [cast(g[k]).to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+        ctl = L.box_qp_control(unroll=True, eps_abs=1e-6, eps_rel=1e-6)
+        if kind == "lu":
+            ctl["linsolve"] = "lu"
+        if kind == "adapted":
+            leaves[0] = (g["Q"] * 50).to(dev).requires_grad_(True)
+            ctl.update(rho=100.0, scale=False)
+        _lib.profile(enable=True, reset=True)
+        x = L.SolveBoxQP(control=ctl)(*leaves)
+        x.backward(cast(g["cot"]).to(dev))
+        used = _lib.profile(); _lib.profile(enable=False)
+        assert used["unroll_backward"][1] == 0 and used["lu_factor"][1] >= 1, (kind, used)
+        assert all(torch.isfinite(t.grad).all() for t in leaves), kind
+        if kind != "adapted":
+            assert err(x, cast(g["x"])) < 2e-5, kind
 
 
 def test_training_loop_matches_cpu_oracle(dev):
