@@ -647,6 +647,18 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             loop_split = loop_np > 1;
         }
     }
+    // small problems (n <= 128, e.g. BASELINE configs[1]): 256 threads per QP, the full matrix in registers (k_admm_loop_small)
+    bool loop_small = false;
+    int small_lds = 0;
+    if constexpr (sizeof(T) == 4) {
+        if (spd && mode == 2 && !loop_split && P.Ks <= 2 && env_int("LQP_LOOP_SMALL", 1) != 0) {
+            int dev = 0, cus = 0, per_cu = 0;
+            small_lds = small_loop_lds_bytes(m);
+            if (current_device_cus(&dev, &cus) && blocks_per_cu(&per_cu, k_admm_loop_small<>, 256, small_lds, dev) &&
+                per_cu >= 1 && B <= cus * per_cu)
+                loop_small = true;
+        }
+    }
     // the equality correction of the first factorisation moves into that kernel (its blocks are in registers there)
     // (ctrl.reserved2 bit 0: the caller will read the corrected H from the workspace afterwards -- lqp_boxqp_unroll_backward --
     //  so the correction must reach global memory: k_spd_end runs)
@@ -660,6 +672,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if constexpr (sizeof(T) == 4) {
             if (loop_split && it == 0) {
                 hipLaunchKernelGGL(split_fn, dim3(loop_np * B), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
+                return;
+            }
+            if (loop_small && it == 0) {
+                hipLaunchKernelGGL(k_admm_loop_small<>, dim3(B), dim3(256), small_lds, st, P, it, e, ctr_base);
                 return;
             }
         }
@@ -1324,10 +1340,11 @@ int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd
     U.dps = (float*)dps; U.dlbs = (float*)dlbs; U.dubs = (float*)dubs; U.dD = (float*)dD;
     U.dAs = (float*)dAs; U.dbs = (float*)dbs; U.drho = (float*)drho;
     const int lds = unroll_lds_bytes(m, P.Ks, U.rl);
-    int rc = ensure_lds((const void*)k_unroll_sweep<>, lds);
+    auto sweep_fn = m <= 1 ? k_unroll_sweep<1> : k_unroll_sweep<SPD_MAXM>;
+    int rc = ensure_lds((const void*)sweep_fn, lds);
     if (rc) return rc;
     { ProfScope ps(st, PC_UNROLL);
-      hipLaunchKernelGGL(k_unroll_sweep<>, dim3(B), dim3(LQP_NT), lds, st, P, U); }
+      hipLaunchKernelGGL(sweep_fn, dim3(B), dim3(LQP_NT), lds, st, P, U); }
     if (dQs) {
         ProfScope ps(st, PC_UNROLL);
         const int tiles = (n + 63) / 64;

@@ -1349,6 +1349,172 @@ template <int NT, int NP = 2> __host__ __device__ inline int split_loop_lds_byte
     return (split_loop_lds_floats<NT, NP>(Ks) + 3 * m * Ks * LQP_NB + 2 * m * m + 4 * m + 8) * 4;
 }
 
+// ---------------------------------------------------------------------------
+// The hot loop for SMALL problems (symmetric path, n <= 128: BASELINE configs[1], n = 100): the 1024-thread kernel above
+// spends 8.4 k cycles per iteration there -- a 16-wave static walk with per-block LDS slots and partial-sum slices, sized
+// for 36 blocks, around THREE blocks of work.  Here: 256 threads, the whole (unpacked, full) matrix -H in registers --
+// thread t holds the 64 entries of row t >> 1, columns 64 (t & 1) .. -- the product is 64 FMAs per thread against
+// broadcast reads of w and ONE lane-pair add; element e of every vector lives in thread e's registers (threads 0..127).
+// Same iteration, same check (:285-313, blocking device-wide stop) and same exit state as admm_loop_body; first (hot)
+// launch only, continuation launches (adaptive-rho events, a counter ring turn) run the general kernel.
+// LDS: w[128] | y[128] | nus[m] | red[4 * 8 + 8]
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int small_loop_lds_bytes(int m) { return (128 + 128 + (m > 0 ? m : 1) + 4 * 8 + 8 + 8) * 4; }
+
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(256) void k_admm_loop_small(const FwdParams<float> P, const int it0, const int it1,
+                                                         const int ctr_base) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    typedef float T;
+    constexpr int NT = 256;
+    const int b = blockIdx.x, n = P.n, m = P.m, Ks = P.Ks;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (it0 >= it1) return;
+    T* const wv = (T*)smem;
+    T* const yv = wv + 128;
+    T* const nus_l = yv + 128;
+    T* const red = nus_l + (m > 0 ? m : 1);
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    T* scal = P.scal + (size_t)b * SC_WORDS;
+    const T* packed = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+    const T rho = scal[SC_RHO];
+    const T pnorm = scal[SC_PNORM];
+
+    // ---- the full matrix: row r, columns 64 h .. 64 h + 63 (block (i, j) of the packed lower triangle, or the transpose
+    //      of block (j, i)) ----
+    const int r = tid >> 1, h = tid & 1;
+    const int bi = r >> 6, rr = r & 63;
+    const bool row_live = bi < Ks && h < Ks;
+    T hreg[64];
+    if (row_live) {
+        if (bi >= h) {
+            const T* src = packed + (size_t)sym_idx(bi, h, Ks) * LQP_BLK + rr * 64;
+#pragma unroll
+            for (int c = 0; c < 64; c += 4) {
+                const V4<T> q = *(const V4<T>*)(src + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hreg[c + e] = q.v[e];
+            }
+        } else {
+            const T* src = packed + (size_t)sym_idx(h, bi, Ks) * LQP_BLK + rr;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) hreg[c] = src[c * 64];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) hreg[c] = T(0);
+    }
+    // ---- element e = tid of every vector (threads 0..127) ----
+    const int e = tid;
+    const bool live = e < n;
+    T zi = live ? V.z[e] : T(0), ui = live ? V.u[e] : T(0);
+    const T psi = live ? V.ps[e] : T(0), lbi = live ? V.lbs[e] : T(0), ubi = live ? V.ubs[e] : T(0);
+    const T di = live ? V.D[e] : T(1), cvi = (live && m > 0) ? V.cv[e] : T(0);
+    T xi = T(0);
+    if (tid < 128) { wv[tid] = live ? -psi + rho * (zi - ui) : T(0); }
+    __syncthreads();
+
+    int slot = ctr_base;
+    for (int it = it0; it < it1; ++it) {
+        const bool check = (it % P.check_solved) == 0;
+        // ---- x-update: y = (-H) w, x = c - y ----
+        {
+            const T* wp = wv + 64 * h;
+            T a0 = T(0), a1 = T(0);
+#pragma unroll
+            for (int c = 0; c < 64; c += 8) {
+                const V4<T> q0 = *(const V4<T>*)(wp + c), q1 = *(const V4<T>*)(wp + c + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a0 += hreg[c + k] * q0.v[k]; a1 += hreg[c + 4 + k] * q1.v[k]; }
+            }
+            T acc = a0 + a1;
+            acc += dpp<0xB1>(acc);                               // the two halves of a row sit in adjacent lanes
+            if (h == 0 && r < 128) yv[r] = acc;
+        }
+        if ((check || it + 1 == it1) && m > 0) {                 // nu = T^T w - s0 (one wave per row) while wv still holds w
+            for (int q = w; q < m; q += NT / 64) {
+                T acc = T(0);
+                for (int i = lane; i < n; i += 64) acc += V.Tm[(size_t)q * n + i] * wv[i];
+                acc = wave_sum(acc);
+                if (lane == 0) nus_l[q] = acc - V.s0[q];
+            }
+        }
+        __syncthreads();
+        T mx[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) mx[q] = T(0);
+        if (live) {
+            const T wi = wv[e];
+            xi = cvi - yv[e];
+            const T zp = zi;
+            T zn = xi + ui;
+            zn = tmin(tmax(zn, lbi), ubi);                       // (:273-276; an infinite bound is a no-op)
+            const T rr_ = xi - zn;
+            const T ss = rho * (zn - zp);
+            const T un = ui + rr_;
+            zi = zn;
+            ui = un;
+            if (check) {
+                mx[0] = tabs(di * rr_);
+                mx[1] = tabs(di * ss);
+                mx[2] = tabs(di * xi);
+                mx[3] = tabs(di * zn);
+                mx[4] = tabs((rho * di) * un);
+                T qx = wi - rho * xi;                            // Qs x = w - rho x - As^T nu (see admm_loop_body)
+                for (int q = 0; q < m; ++q) qx -= V.As[(size_t)q * n + e] * nus_l[q];
+                mx[5] = tabs(qx / di);
+            }
+        }
+        __syncthreads();                                         // (everybody has read w and y)
+        if (tid < 128) wv[tid] = live ? -psi + rho * (zi - ui) : T(0);     // next right-hand side
+        if (check) {
+            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], mx[5]};
+            wg_max_n<T, 6, NT / 64>(mv, red);
+            const T tiny = T(1e-16);
+            const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
+            const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
+            const T dua_scale = tmax(tmax(tmax(mv[4], mv[5]), pnorm), tiny);
+            const T tol_d = P.eps_abs + P.eps_rel * dua_scale;
+            const bool solved = (mv[0] < tol_p) && (mv[1] < tol_d);
+            const bool wants = (mv[0] > tmax(tol_p, P.ar_thr)) || (mv[1] > tmax(tol_d, P.ar_thr));
+            const T num = tmax(mv[0] / pri_scale, tiny);
+            const T den = tmax(mv[1] / dua_scale, tiny);
+            const T ratio = tsqrt(num / den);
+            const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
+            unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
+            if (tid == 0) {
+                scal[SC_RATIO] = ratio;
+                scal[SC_WANTS] = wants ? T(1) : T(0);
+                scal[SC_PRI] = mv[0];
+                scal[SC_DUA] = mv[1];
+                unsigned int r1 = 0, r2 = 0;
+                if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
+                if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
+                asm volatile("s_waitcnt vmcnt(0)" :: "v"(r1), "v"(r2) : "memory");
+                __hip_atomic_fetch_add((unsigned long long*)(ct + CT_NOTOPT), (solved ? 0ull : 1ull) | (1ull << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ++slot;
+            grid_wait(ct + CT_ARRIVE, gridDim.x, P.status);      // device-wide "all optimal?" (torch.all at :312)
+            const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (notopt == 0 || tmo) {
+                if (b == 0 && tid == 0) {
+                    P.status[ST_FINAL_ITER] = it;
+                    __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- state for the continuation launch / the epilogue ----
+    if (live) { V.z[e] = zi; V.u[e] = ui; V.x[e] = xi; }
+    __syncthreads();
+    for (int q = tid; q < m; q += NT) V.nu[q] = nus_l[q];
+}
+
 // NP = 4 (batches up to a quarter of the CUs): one column pair per workgroup, every partial product published once and
 // fetched by the three others; the sum runs over the parts in their order on every workgroup (identical iterates).
 template <int KS, int NT, bool DBG = false, int NP = 2>

@@ -44,7 +44,9 @@ __host__ __device__ inline int unroll_lds_blocks(int m, int Ks) {
     return rl;
 }
 
-template <int LQP_ANY = 0>
+// MA: equality rows the per-thread Asbar accumulators are built for (1: the benchmark's single row -- sixteen of them cost
+// the product its registers; SPD_MAXM otherwise)
+template <int MA = SPD_MAXM>
 __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep(const FwdParams<float> P, const UnrollParams U) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     constexpr int NT = LQP_NT;
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep(const FwdParams<float> 
     const float gi = live ? U.g[(size_t)b * n + i] : 0.f;
     const float di = live ? V.D[i] : 0.f;
     float ubar = 0.f, zbar = 0.f, pbar = 0.f, lbbar = 0.f, ubbar = 0.f, rho_part = 0.f, bbar = 0.f;
-    float dA[SPD_MAXM];
+    float dA[MA];
 #pragma unroll
-    for (int q = 0; q < SPD_MAXM; ++q) dA[q] = 0.f;
+    for (int q = 0; q < MA; ++q) dA[q] = 0.f;
     __syncthreads();                                        // (the scratch rows written above: read below by their writers
                                                             //  only, except NU -- written by lane 0 of a wave, read by all)
     for (int k = T - 1; k >= 0; --k) {
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep(const FwdParams<float> 
             zbar = -rho * dxx;
             ubar = unew + rho * dxx;
 #pragma unroll
-            for (int q = 0; q < SPD_MAXM; ++q)
+            for (int q = 0; q < MA; ++q)
                 if (q < m) dA[q] += dnul[q] * xk + nus[q] * dxx;
         }
         if (tid < m) bbar -= dnul[tid];
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep(const FwdParams<float> 
         U.dubs[(size_t)b * n + i] = ubbar;
         U.dD[(size_t)b * n + i] = gi * X[(size_t)(T - 1) * n + i];
 #pragma unroll
-        for (int q = 0; q < SPD_MAXM; ++q)
+        for (int q = 0; q < MA; ++q)
             if (q < m) U.dAs[((size_t)b * m + q) * n + i] = dA[q];
     }
     if (tid < m) U.dbs[(size_t)b * m + tid] = bbar;
