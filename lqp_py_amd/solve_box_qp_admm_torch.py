@@ -24,6 +24,7 @@ from .utils import get_ncon
 
 _INF = float("inf")
 _SYNC_SPLIT = os.environ.get("LQP_SYNC_SPLIT", "1") != "0"      # (A/B knob: 0 = one-call synchronous forward)
+_PREPARE_BWD = os.environ.get("LQP_PREPARE_BWD", "1") != "0"    # (A/B knob: 0 = the backward prepares itself when it is called)
 
 
 class SolveBoxQP(nn.Module):
@@ -60,13 +61,22 @@ class SolveBoxQPLayer(torch.autograd.Function):
         # the CALLER's dict as the reference does (_forward_solve, mutate=True).
         # (lqp_py_amd.dist passes the flags of the WHOLE batch when this call holds one shard of it.)
         sync = bool(control.get('sync', True))
+        ctx.backward_method = control.get('backward', 'fixed_point')
+        ctx.prepared = None
+        while_running = None
+        need = ctx.needs_input_grad
+        if sync and ctx.backward_method != 'kkt' and any(need[:6]) and _PREPARE_BWD:
+            # a synchronous call only waits while its schedule runs: the backward's outputs, workspace and argument list are
+            # made in that window (the cotangent is all that is missing), see _fp_backward_prepare
+            def while_running(parts, linsolve_used):
+                ctx.prepared = _fp_backward_prepare(parts['x'], parts['u'], parts['lams'], parts['nus'], Q, A, lb, ub,
+                                                    parts['rho_out'], _wanted(need, A), sync=True, linsolve=linsolve_used)
         sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=control.get('_global_bounds'), sync=sync,
                              check_hook=control.get('_check_hook'), mutate=True,
-                             holder=control.get('_holder') or getattr(_tls, 'holder', None))
+                             holder=control.get('_holder') or getattr(_tls, 'holder', None), while_running=while_running)
         ctx.rho = sol['rho']
         ctx.linsolve = int(sol['_stats']['linsolve_used'])     # 2: Q was checked symmetric by the forward
         ctx.sync = sync
-        ctx.backward_method = control.get('backward', 'fixed_point')
         ctx.save_for_backward(sol['x'], sol['u'], sol['lams'], sol['nus'], Q, A, lb, ub)
         return sol['x']
 
@@ -75,11 +85,16 @@ class SolveBoxQPLayer(torch.autograd.Function):
         x, u, lams, nus, Q, A, lb, ub = ctx.saved_tensors
         if ctx.backward_method == 'kkt':
             return torch_solve_box_qp_grad_kkt(dl_dz, x=x, lams=lams, nus=nus, Q=Q, A=A, lb=lb, ub=ub)
-        need = ctx.needs_input_grad
-        want = dict(dQ=need[0], dp=need[1], dA=need[2] and A is not None, db=need[3] and A is not None,
-                    dlb=need[4], dub=need[5])
-        grads = _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, ctx.rho, want, sync=ctx.sync, linsolve=ctx.linsolve)
+        prep, ctx.prepared = ctx.prepared, None
+        if prep is not None:
+            return _fp_backward_run(prep, dl_dz)
+        grads = _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, ctx.rho, _wanted(ctx.needs_input_grad, A), sync=ctx.sync,
+                             linsolve=ctx.linsolve)
         return grads
+
+
+def _wanted(need, A):
+    return dict(dQ=need[0], dp=need[1], dA=need[2] and A is not None, db=need[3] and A is not None, dlb=need[4], dub=need[5])
 
 
 class BoxQPTH:
@@ -262,6 +277,7 @@ def _rho_argument(rho, B, like):
 
 
 _LINSOLVE = {'auto': 0, 'lu': 1, 'spd': 2, 0: 0, 1: 1, 2: 2}
+_ws_bytes = {}                      # (dtype, B, n, m) -> lqp_boxqp_forward_workspace_bytes (a library call per solve otherwise)
 _ctl_cache = threading.local()      # .d: (control items, n, any_bound, sync, dtype) -> (resolved dict, rho, lqp_boxqp_ctrl)
 
 
@@ -284,7 +300,7 @@ def _beta_argument(beta, B, like):
 
 
 def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None, mutate=False,
-                   holder=None, private_ws=None, keep_factor=False):
+                   holder=None, private_ws=None, keep_factor=False, while_running=None):
     """bounds: (any_lb, any_ub) when the caller KNOWS them (a shard of a larger batch with host-side flags); None: found
     on the device.  mutate: apply the reference layer's dict side effect control['rho'] = 0 (:37-38).  holder: the
     nn.Module on whose behalf the call is made (keys what is remembered between calls, see _assume_any_bound)."""
@@ -380,7 +396,9 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     base = outbuf.data_ptr()
     o_x, o_z, o_u, o_l = x.data_ptr(), base, base + B * n4 * es, base + 2 * B * n4 * es
     o_nu, o_rho = base + 4 * B * n4 * es, base + (4 * B * n4 + B * m4) * es
-    nbytes = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
+    nbytes = _ws_bytes.get((dt, B, n, m))
+    if nbytes is None:
+        nbytes = _ws_bytes[(dt, B, n, m)] = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
     stream = torch.cuda.current_stream(dev).cuda_stream
     # (private_ws / keep_factor: the unroll mode keeps the solve's workspace -- factor included -- for its backward)
     ws = private_ws if private_ws is not None else _lib.workspace(dev, nbytes, "fwd", stream)
@@ -416,6 +434,8 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     nus = parts[3][:B * m].view(B, m, 1) if m > 0 else None
     rho_out = parts[4][:B]
     if split_wait:
+        if while_running is not None:
+            while_running(dict(x=x, u=u, lams=lams, nus=nus, rho_out=rho_out.view(B, 1, 1)), int(stats.linsolve_used))
         # (the views above were made while the GPU ran; now the report: polled in pinned memory, no stream wait)
         st = lib.lqp_boxqp_forward_finish(ctypes.c_void_p(stream), B, ctl.max_iters, ctl.check_solved,
                                           ctypes.c_void_p(report.data_ptr()), ctypes.byref(stats))
@@ -424,7 +444,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
             # reference's algorithm -- the pivoted LU -- takes the solve, as a one-call synchronous forward does by itself
             _lib._pinned_free.setdefault(report.numel(), []).append(report)
             return _forward_solve(Q, p, A, b, lb, ub, dict(control, linsolve='lu', _owner=owner), bounds=bounds, sync=sync,
-                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder)
+                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder, while_running=while_running)
     if st != 0 or (check_hook is not None and hook_error):
         # kernels of the failed call may still be in flight, and they write their report into `report`: wait before the
         # pinned buffer goes back to the pool (cold path)
@@ -441,7 +461,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
             if has[0] or has[1]:
                 _remember_any_bound(holder, owner, True)
                 return _forward_solve(Q, p, A, b, lb, ub, control, bounds=has, sync=sync, residuals=residuals,
-                                      check_hook=check_hook, mutate=mutate, holder=holder)
+                                      check_hook=check_hook, mutate=mutate, holder=holder, while_running=while_running)
         # the reference's torch.linalg.lu_factor raises on an exactly singular KKT matrix (:215)
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "
                            f"(batch index {stats.fail_index}); the KKT matrix is singular")
@@ -462,7 +482,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         _remember_any_bound(holder, owner, seen)
         if seen != any_bound:
             return _forward_solve(Q, p, A, b, lb, ub, control, bounds=(bool(stats.any_lb), bool(stats.any_ub)), sync=sync,
-                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder)
+                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder, while_running=while_running)
     if mutate and not any_bound:
         control['rho'] = owner['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
     if r['verbose']:
@@ -514,8 +534,11 @@ def last_forward_status(device):
     return st
 
 
-def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1):
-    _lib.require_gpu(dl_dz, x, u, lams, nus, Q, A, lb, ub)
+def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1):
+    """Everything of the fixed-point backward that does not need the cotangent: output tensors, workspace, report buffer,
+    the argument list of lqp_boxqp_backward_fp.  A synchronous layer call runs this WHILE its forward is on the GPU (the host
+    would only wait), so that `backward` is one library call behind the autograd engine's thread hop."""
+    _lib.require_gpu(x, u, lams, nus, Q, A, lb, ub)
     lib = _lib.load()
     B, n = Q.shape[0], Q.shape[1]
     m = get_ncon(A, dim=1)
@@ -524,7 +547,7 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, lin
     if rho is None:
         rho = 1.0                                          # (:356-357)
     rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, x)
-    gc, xc, uc, lc, nc, Qc, Ac, lbc, ubc = (_lib.norm(t, dty) for t in (dl_dz, x, u, lams, nus, Q, A, lb, ub))
+    xc, uc, lc, nc, Qc, Ac, lbc, ubc = (_lib.norm(t, dty) for t in (x, u, lams, nus, Q, A, lb, ub))
     mk = lambda on, shape: torch.empty(shape, dtype=dty, device=dev) if on else None
     dQ = mk(want['dQ'], (B, n, n))
     dp = mk(want['dp'], (B, n, 1))
@@ -537,16 +560,25 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, lin
     ws = _lib.workspace(dev, nbytes, "bwd", stream)
     fail = ctypes.c_int32(-1)
     report = _lib.host_report(B)                        # (the info words go straight into pinned host memory)
+    head = (ctypes.c_void_p(stream), dt, B, n, m)
+    tail = (_lib.ptr(xc), _lib.ptr(uc), _lib.ptr(lc), _lib.ptr(nc), _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
+            rho_mode, rho_value, _lib.ptr(rho_tensor),
+            _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
+            ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel(), int(linsolve),
+            None if report is None else ctypes.c_void_p(report.data_ptr()))
+    keep = (xc, uc, lc, nc, Qc, Ac, lbc, ubc, rho_tensor, ws)          # (the pointers above point into these)
+    return dict(lib=lib, head=head, tail=tail, keep=keep, grads=(dQ, dp, dA, db, dlb, dub, None), fail=fail, report=report,
+                dev=dev, dty=dty, B=B, sync=sync)
+
+
+def _fp_backward_run(prep, dl_dz):
+    _lib.require_gpu(dl_dz)
+    gc = _lib.norm(dl_dz, prep['dty'])
+    dev, report, B, sync = prep['dev'], prep['report'], prep['B'], prep['sync']
     with _lib.on_device(dev):
-        st = lib.lqp_boxqp_backward_fp(ctypes.c_void_p(stream), dt, B, n, m,
-                                       _lib.ptr(gc), _lib.ptr(xc), _lib.ptr(uc), _lib.ptr(lc), _lib.ptr(nc),
-                                       _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
-                                       rho_mode, rho_value, _lib.ptr(rho_tensor),
-                                       _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
-                                       ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel(), int(linsolve),
-                                       None if report is None else ctypes.c_void_p(report.data_ptr()))
+        st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *prep['tail'])
     if st == 3:
-        raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {fail.value})")
+        raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {prep['fail'].value})")
     _lib.check(st, "torch_solve_box_qp_grad")
     try:
         _lib.poll_errors()              # (errors of earlier calls; this call's own report is queued behind the poll)
@@ -555,4 +587,8 @@ def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, lin
             _lib.defer_check("SolveBoxQP.backward", dev, report, B, False)
         else:
             _lib._pinned_free.setdefault(report.numel(), []).append(report)
-    return (dQ, dp, dA, db, dlb, dub, None)
+    return prep['grads']
+
+
+def _fp_backward(dl_dz, x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1):
+    return _fp_backward_run(_fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=sync, linsolve=linsolve), dl_dz)
