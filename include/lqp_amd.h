@@ -243,6 +243,21 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
                                                    per-problem info words there (read instead of a copy when
                                                    fail_index is given, left for the caller when it is NULL)    */
 
+/* ---- KKT-system backward (control['backward'] = 'kkt') -------------------
+ * Replaces torch_solve_box_qp_grad_kkt (solve_box_qp_admm_torch.py:435-584) for a batch with finite lower AND upper
+ * bounds somewhere (any_lb and any_ub, :439-441).  The reference solves the (3n+m) system
+ *     [[Q, G^T diag(lam), A^T], [G, -diag(s), 0], [A, 0, 0]] [dx; dlam; dnu] = [-dl_dz; 0; 0],   G = [-I; I],
+ * s = clamp(h - G x, 1e-8), lam = clamp(lams, 1e-8) (:450-452).  Eliminating dlam = diag(1/s) G dx leaves
+ *     [[Q + diag(w), A^T], [A, 0]] [dx; dnu] = [-dl_dz; 0],   w = lam_lo / s_lo + lam_hi / s_hi,
+ * the same solution on the kernels of the fixed-point backward: every variable free, w in place of its 1e-8
+ * regulariser (linsolve 2: blocked Cholesky when Q is known to be symmetric, else pivoted LU), and an epilogue that
+ * forms dQ, dp, dA, db (:527-562) and dlb = -dl_dh[:n], dub = dl_dh[n:], dl_dh = -lam dlam (:544, :573-575).
+ * Arguments as lqp_boxqp_backward_fp without u / rho.                                                          */
+int lqp_boxqp_backward_kkt(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x,
+                           const void* lams, const void* nus, const void* Q, const void* A, const void* lb, const void* ub,
+                           void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub, int32_t* fail_index,
+                           void* workspace, size_t workspace_bytes, int linsolve, void* host_report);
+
 /* ---- batched LU (partial pivoting) and cached LU solve ------------------
  * Replace torch.linalg.lu_factor / lu_solve as used by lqp_py/lu_layer.py:
  * 10,31,33,52 and solve_box_qp_admm_torch.py:215,254,267.  M (B,N,N) is

@@ -72,6 +72,8 @@ SYMBOLS = {
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
                               [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int, _P]),
+    "lqp_boxqp_backward_kkt": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 8 + [_P] * 6 +
+                               [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int, _P]),
     "lqp_lu_factor_workspace_bytes": (c_size_t, [c_int] * 3),
     "lqp_lu_factor_batched": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t]),
     "lqp_lu_solve_workspace_bytes": (c_size_t, [c_int] * 3),

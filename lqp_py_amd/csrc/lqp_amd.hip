@@ -971,9 +971,10 @@ template <typename T>
 int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void* x, const void* u, const void* lams,
                   const void* nus, const void* Q, const void* A, const void* lb, const void* ub, int rho_mode,
                   double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
-                  int32_t* fail_index, void* ws, size_t ws_bytes, int linsolve, void* host_report) {
+                  int32_t* fail_index, void* ws, size_t ws_bytes, int linsolve, void* host_report, const int kkt = 0) {
     BwdParams<T> P;
     memset(&P, 0, sizeof(P));
+    P.kkt = kkt ? 1 : 0;
     P.host_report = (int*)host_report;
     if (P.host_report) report_reset(P.host_report, B);
     P.early_report = env_int("LQP_BWD_EARLY", 1) != 0 ? 1 : 0;
@@ -985,7 +986,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     P.dQ = (T*)dQ; P.dp = (T*)dp; P.dA = (T*)dA; P.db = (T*)db; P.dlb = (T*)dlb; P.dub = (T*)dub;
     P.dbg = g_lu_dbg;
     // default: solve on the free set only (see k_bwd_build_reduced); LQP_BWD_FULL=1 keeps the full system
-    P.reduced = env_int("LQP_BWD_FULL", 0) ? 0 : 1;
+    P.reduced = (env_int("LQP_BWD_FULL", 0) && !kkt) ? 0 : 1;
     const int* nvec = P.reduced ? P.nred : nullptr;
     // linsolve 2: the caller vouches for a symmetric Q (the forward's symmetric x-update checked it): the
     // reduced system goes through a blocked Cholesky of Q_FF instead of the pivoted LU of the bordered matrix
@@ -996,7 +997,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (chol) {
             P.chol = 1;
             {
-                const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
+                const int lds = (2 * round_up(n, 8) + LQP_NW + 8) * 4;      // (fl | wtot | the KKT form's diagonal weights)
                 ProfScope ps(st, PC_BWD_BUILD);
                 const int split = B <= 128 ? 2 : 1;
                 hipLaunchKernelGGL(k_bwd_build_chol<>, dim3(B, split), dim3(LQP_NT), lds, st, P);
@@ -1030,7 +1031,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (rc) return rc;
         rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);
         if (rc) return rc;
-        if (P.reduced && env_int("LQP_BWD_REFINE", 1)) {
+        if (P.reduced && !kkt && env_int("LQP_BWD_REFINE", 1)) {
             // one refinement step: residual with the original entries (double accumulation), correction solve
             const int lds = (round_up(n, 8) + round_up(m > 0 ? m : 1, 8)) * (int)sizeof(T) + round_up(n, 8) * 4;
             { ProfScope ps(st, PC_BWD_BUILD);
@@ -1064,7 +1065,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             rc = first_failure(st, P.info, B, &fi, P.host_report);
         if (rc == LQP_ERR_SINGULAR && chol)           // Q_FF not positive definite in f32: the pivoted LU takes it
             return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
-                                    db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report);
+                                    db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report, kkt);
         *fail_index = fi;
         if (rc) return rc;
     }
@@ -1393,6 +1394,21 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const vo
     if (dtype == LQP_F32)
         return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, linsolve, host_report);
     return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, 1, host_report);
+}
+
+int lqp_boxqp_backward_kkt(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x,
+                           const void* lams, const void* nus, const void* Q, const void* A, const void* lb, const void* ub,
+                           void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub, int32_t* fail_index, void* workspace,
+                           size_t workspace_bytes, int linsolve, void* host_report) {
+    if (bad_dims(dtype, B, n, m) || !dl_dz || !x || !lams || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
+    if (m > 0 && (!A || !nus)) return LQP_ERR_INVALID;
+    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LQP_F32)
+        return backward_impl<float>(st, B, n, m, dl_dz, x, nullptr, lams, nus, Q, A, lb, ub, 1, 1.0, nullptr, dQ, dp, dA, db, dlb,
+                                    dub, fail_index, workspace, workspace_bytes, linsolve, host_report, 1);
+    return backward_impl<double>(st, B, n, m, dl_dz, x, nullptr, lams, nus, Q, A, lb, ub, 1, 1.0, nullptr, dQ, dp, dA, db, dlb,
+                                 dub, fail_index, workspace, workspace_bytes, 1, host_report, 1);
 }
 
 size_t lqp_spd_inverse_workspace_bytes(int dtype, int B, int n) {

@@ -2054,7 +2054,22 @@ template <typename T> struct BwdParams {
     int la_maxk;               // largest block count the look-ahead Cholesky may take (LDS of the launch), 0 = off
     int* host_report;          // optional pinned host memory, B ints: the epilogue leaves every problem's info word there
     int early_report;          // 1: Cholesky form -- k_bwd_chol_solve reports (the info words are final there), not the epilogue
+    int kkt;                   // 1: the KKT-system backward (backward='kkt', reference :435-584) on the same kernels: the (3n+m)
+                               //    system [[Q, G^T diag(lam), A^T], [G, -diag(s), 0], [A, 0, 0]] with G = [-I; I] reduces exactly
+                               //    (dlam = diag(1/s) G dx) to [[Q + diag(w), A^T], [A, 0]] [dx; dnu] = [-g; 0],
+                               //    w = lam_lo / s_lo + lam_hi / s_hi (both clamped at 1e-8, :450-452): every variable is "free",
+                               //    w takes the place of the 1e-8 regulariser, and the epilogue forms dlb / dub from dlam
 };
+
+// diagonal weight of the KKT-system backward for variable i (see BwdParams::kkt)
+template <typename T>
+__device__ __forceinline__ T kkt_weight(const BwdParams<T>& P, const int b, const int i) {
+    const int n = P.n;
+    const T xi = P.x[(size_t)b * n + i];
+    const T slo = tmax(xi - P.lb[(size_t)b * n + i], T(1e-8)), shi = tmax(P.ub[(size_t)b * n + i] - xi, T(1e-8));
+    const T llo = tmax(P.lams[(size_t)b * 2 * n + i], T(1e-8)), lhi = tmax(P.lams[(size_t)b * 2 * n + n + i], T(1e-8));
+    return llo / slo + lhi / shi;
+}
 
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_bwd_build(const BwdParams<T> P) {
@@ -2135,8 +2150,11 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
         const int i = i0 + tid;
         bool keep = false;
         if (i < n) {
-            const T sxu = x[i] + u[i];
-            keep = !(sxu > ub[i] || sxu < lb[i]);
+            if (P.kkt) keep = true;
+            else {
+                const T sxu = x[i] + u[i];
+                keep = !(sxu > ub[i] || sxu < lb[i]);
+            }
         }
         const unsigned long long bal = __ballot(keep);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -2163,9 +2181,10 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
         const int i = fl[a];
         const T* qr = Q + (size_t)i * n;
         T* mr = M + (size_t)a * Np;
+        const T dg = P.kkt ? kkt_weight(P, b, i) : T(1e-8);
         for (int c = lane; c < nf; c += 64) {
             T val = qr[fl[c]];
-            if (c == a) val = val + T(1e-8);
+            if (c == a) val = val + dg;
             mr[c] = val;
         }
         for (int r = lane; r < m; r += 64) mr[nf + r] = A[(size_t)r * n + i];
@@ -2174,7 +2193,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
     for (int r = w * ny + wy; r < m; r += LQP_NW * ny) {
         T* mr = M + (size_t)(nf + r) * Np;
         for (int c = lane; c < nf; c += 64) mr[c] = A[(size_t)r * n + fl[c]];
-        for (int c = lane; c < m; c += 64) mr[nf + c] = (c == r) ? T(1e-8) : T(0);
+        for (int c = lane; c < m; c += 64) mr[nf + c] = (c == r && !P.kkt) ? T(1e-8) : T(0);
         if (lane == 0) rhs[nf + r] = T(0);
     }
 }
@@ -2205,10 +2224,14 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
     float* AF = P.M + (size_t)b * Np * Np;
     float* rhs = P.rhs + (size_t)b * Np;
     if (tid == 0 && blockIdx.y == 0) P.info[b] = 0;
+    float* wl = (float*)(wtot + LQP_NW + 8);          // KKT-system backward: the diagonal weights (n floats)
     bool keep = false;
     if (tid < n) {
-        const float sxu = x[tid] + u[tid];
-        keep = !(sxu > ub[tid] || sxu < lb[tid]);
+        if (P.kkt) { keep = true; wl[tid] = kkt_weight(P, b, tid); }
+        else {
+            const float sxu = x[tid] + u[tid];
+            keep = !(sxu > ub[tid] || sxu < lb[tid]);
+        }
     }
     const unsigned long long bal = __ballot(keep);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -2250,7 +2273,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
         for (int e = 0; e < 4; ++e) {
             const int c = j * 64 + c4 + e;
             float val = (a == c) ? 1.f : 0.f;
-            if (rok && c < nf) val = q4[e] + (a == c ? 1e-8f : 0.f);
+            if (rok && c < nf) val = q4[e] + (a == c ? (P.kkt ? wl[fl[a]] : 1e-8f) : 0.f);
             v.v[e] = val;
         }
         *(V4<float>*)(Ls + (size_t)t * LQP_BLK + tid * 4) = v;
@@ -2489,7 +2512,17 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     }
     const T* Q = P.Q + (size_t)b * n * n;
     const T* A = P.A ? P.A + (size_t)b * m * n : nullptr;
-    const bool need_kkt = P.dlb || P.dub;
+    if (P.kkt && first) {
+        // dlam = diag(1 / s) G dx (rows -I | I), dl_dh = -lam dlam, dlb = -dl_dh[:n], dub = dl_dh[n:] (:544, :573-575)
+        for (int i = tid; i < n; i += LQP_NT) {
+            const T xi = xs[i];
+            const T slo = tmax(xi - P.lb[(size_t)b * n + i], T(1e-8)), shi = tmax(P.ub[(size_t)b * n + i] - xi, T(1e-8));
+            const T llo = tmax(P.lams[(size_t)b * 2 * n + i], T(1e-8)), lhi = tmax(P.lams[(size_t)b * 2 * n + n + i], T(1e-8));
+            if (P.dlb) P.dlb[(size_t)b * n + i] = llo * (-dv[i] / slo);
+            if (P.dub) P.dub[(size_t)b * n + i] = -lhi * (dv[i] / shi);
+        }
+    }
+    const bool need_kkt = (P.dlb || P.dub) && !P.kkt;
     T* dQ = P.dQ ? P.dQ + (size_t)b * n * n : nullptr;
     // 16-B stores; a lane's columns are the same in every row, so their x_j and dv_j / 2 stay in registers
     const bool vec = (n % 4 == 0) && n <= 1024 && dQ && ((((uintptr_t)dQ) % sizeof(V4<T>)) == 0);

@@ -24,6 +24,7 @@ from .utils import get_ncon
 
 _INF = float("inf")
 _SYNC_SPLIT = os.environ.get("LQP_SYNC_SPLIT", "1") != "0"      # (A/B knob: 0 = one-call synchronous forward)
+_KKT_NATIVE = os.environ.get("LQP_KKT_NATIVE", "1") != "0"      # (A/B knob: 0 = the KKT backward composed from torch ops + lqp_kkt_solve)
 _PREPARE_BWD = os.environ.get("LQP_PREPARE_BWD", "1") != "0"    # (A/B knob: 0 = the backward prepares itself when it is called)
 
 
@@ -75,6 +76,8 @@ class SolveBoxQPLayer(torch.autograd.Function):
                              check_hook=control.get('_check_hook'), mutate=True,
                              holder=control.get('_holder') or getattr(_tls, 'holder', None), while_running=while_running)
         ctx.rho = sol['rho']
+        st_ = sol['_stats']
+        ctx.bound_flags = (bool(st_['any_lb']), bool(st_['any_ub'])) if st_['any_lb'] >= 0 else None     # (pipelined: not known)
         ctx.linsolve = int(sol['_stats']['linsolve_used'])     # 2: Q was checked symmetric by the forward
         ctx.sync = sync
         ctx.save_for_backward(sol['x'], sol['u'], sol['lams'], sol['nus'], Q, A, lb, ub)
@@ -84,7 +87,8 @@ class SolveBoxQPLayer(torch.autograd.Function):
     def backward(ctx, dl_dz):
         x, u, lams, nus, Q, A, lb, ub = ctx.saved_tensors
         if ctx.backward_method == 'kkt':
-            return torch_solve_box_qp_grad_kkt(dl_dz, x=x, lams=lams, nus=nus, Q=Q, A=A, lb=lb, ub=ub)
+            return _kkt_backward(dl_dz, x, lams, nus, Q, A, lb, ub, flags=ctx.bound_flags, linsolve=ctx.linsolve,
+                                 want=_wanted(ctx.needs_input_grad, A), sync=ctx.sync)
         prep, ctx.prepared = ctx.prepared, None
         if prep is not None:
             return _fp_backward_run(prep, dl_dz)
@@ -153,10 +157,51 @@ def torch_solve_box_qp_grad_kkt(dl_dz, x, lams, nus, Q, A, lb, ub):
     with G = [-I; I].  Eliminating dlam = diag(1/slack) G dx exactly turns it into one (n+m) KKT
     solve with Q + diag(lam_lo/slack_lo + lam_hi/slack_hi) -- the same solution, on the HIP KKT
     solve (lqp_kkt_solve).  Clamps (1e-8) and the lb/ub bookkeeping of :565-584 are kept."""
+    return _kkt_backward(dl_dz, x, lams, nus, Q, A, lb, ub)
+
+
+def _kkt_backward(dl_dz, x, lams, nus, Q, A, lb, ub, flags=None, linsolve=1, want=None, sync=True):
+    """flags: (any_lb, any_ub) when the caller knows them (the layer's forward saw them in the device's report).  With both
+    true the whole backward is the library's (lqp_boxqp_backward_kkt: the reduced system on the fixed-point backward's
+    kernels, gradients formed in its epilogue); the one-sided and unbounded cases keep the composition below, including
+    the reference's bookkeeping of which half of dl_dh goes where (:565-584)."""
     from .solve_qp_eqcon_torch import _kkt_solve
     _lib.require_gpu(dl_dz, x, lams, nus, Q, A, lb, ub)
     n = Q.shape[1]
-    any_lb, any_ub = _finite_bounds(lb, ub)
+    any_lb, any_ub = flags if flags is not None else _finite_bounds(lb, ub)
+    if any_lb and any_ub and _KKT_NATIVE:
+        lib = _lib.load()
+        B = Q.shape[0]
+        m = get_ncon(A, dim=1)
+        dt = _lib.dtype_code(x)
+        dev, dty = x.device, x.dtype
+        want = want or dict(dQ=True, dp=True, dA=m > 0, db=m > 0, dlb=True, dub=True)
+        gc, xc, lc, nc, Qc, Ac, lbc, ubc = (_lib.norm(t, dty) for t in (dl_dz, x, lams, nus, Q, A, lb, ub))
+        mk = lambda on, shape: torch.empty(shape, dtype=dty, device=dev) if on else None
+        dQ, dp = mk(want['dQ'], (B, n, n)), mk(want['dp'], (B, n, 1))
+        dA, db = mk(want['dA'] and m > 0, (B, m, n)), mk(want['db'] and m > 0, (B, m, 1))
+        dlb, dub = mk(want['dlb'], (B, n, 1)), mk(want['dub'], (B, n, 1))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = _lib.workspace(dev, lib.lqp_boxqp_backward_fp_workspace_bytes(dt, B, n, m), "bwd", stream)
+        fail = ctypes.c_int32(-1)
+        report = _lib.host_report(B)
+        with _lib.on_device(dev):
+            st = lib.lqp_boxqp_backward_kkt(ctypes.c_void_p(stream), dt, B, n, m, _lib.ptr(gc), _lib.ptr(xc), _lib.ptr(lc),
+                                            _lib.ptr(nc), _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
+                                            _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
+                                            ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel(), int(linsolve),
+                                            ctypes.c_void_p(report.data_ptr()))
+        if st == 3:
+            raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad_kkt: the input matrix is singular (batch index {fail.value})")
+        _lib.check(st, "torch_solve_box_qp_grad_kkt")
+        try:
+            _lib.poll_errors()
+        finally:
+            if not sync:
+                _lib.defer_check("SolveBoxQP.backward", dev, report, B, False)
+            else:
+                _lib._pinned_free.setdefault(report.numel(), []).append(report)
+        return (dQ, dp, dA, db, dlb, dub, None)
     dlam = None
     Qw = Q
     if any_lb or any_ub:

@@ -656,8 +656,13 @@ def test_singular_kkt_raises(dev):
         L.torch_solve_box_qp(Q, p, None, None, lb, ub, {"rho": 0.0, "scale": False})
 
 
-def test_g12_kkt_backward_mode(dev):
-    """backward='kkt' (SURVEY 8f rank 2): reference solves the (3n+m) system, we its exact (n+m) reduction."""
+@pytest.mark.parametrize("native", [True, False])
+def test_g12_kkt_backward_mode(dev, monkeypatch, native):
+    """backward='kkt' (SURVEY 8f rank 2): reference solves the (3n+m) system, we its exact (n+m) reduction -- native: one
+    library call on the fixed-point backward's kernels (lqp_boxqp_backward_kkt: Cholesky form behind the symmetric
+    forward, gradients in the epilogue); otherwise composed from lqp_kkt_solve and torch ops."""
+    monkeypatch.setattr(SB, "_KKT_NATIVE", native)
+    _lib.profile(enable=True, reset=True)
     g = load_golden("g12_kkt_backward")
     leaves = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
     x = L.SolveBoxQP(control=L.box_qp_control(backward='kkt', **TOL))(*leaves)
@@ -670,6 +675,18 @@ def test_g12_kkt_backward_mode(dev):
     x2.backward(g["cot"].to(dev))
     for nm, t in zip(("dQ_box", "dp_box", "dlb_box", "dub_box"), lv):
         assert err(t.grad, g[nm]) < 1e-4 * max(1.0, float(g[nm].abs().max())), nm
+    used = _lib.profile(); _lib.profile(enable=False)
+    assert (used["bwd_cholesky"][1] == 2) == native and (used["lu_factor"][1] == 0) == native, used
+    # the functional entry (pivoted LU of the reduced system, it cannot know that Q is symmetric) and a one-sided batch
+    # (upper bounds only: the reference's bookkeeping of dl_dh, :576-584, stays with the composed path)
+    sol, a = solve(dev, [g[k] for k in ("Q", "p", "A", "b", "lb", "ub")], O.make_control(**TOL))
+    gk = L.torch_solve_box_qp_grad_kkt(g["cot"].to(dev), sol["x"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5])
+    for nm, t in zip(GRADS, gk):
+        assert err(t, g[nm]) < 1e-4 * max(1.0, float(g[nm].abs().max())), nm
+    inf = torch.full_like(a[4], float("inf"))
+    s1 = L.torch_solve_box_qp(a[0], a[1], a[2], a[3], -inf, a[5], O.make_control(**TOL))
+    g1 = L.torch_solve_box_qp_grad_kkt(g["cot"].to(dev), s1["x"], s1["lams"], s1["nus"], a[0], a[2], -inf, a[5])
+    assert g1[4] is None and g1[5] is not None and all(torch.isfinite(t).all() for t in g1 if t is not None)
 
 
 class _CpuLU(torch.nn.Module):
