@@ -116,23 +116,24 @@ def build_library(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("LQP_EXTRA_FLAGS", "").split()       # (A/B builds: LQP_LIB=<other .so> LQP_EXTRA_FLAGS="-D...")
     if unity:
-        cmd = [hipcc] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH, os.path.join(CSRC, "lqp_amd.hip")]
+        cmd = [hipcc] + HIPCC_FLAGS + extra + ["-shared", "-o", LIB_PATH, os.path.join(CSRC, "lqp_amd.hip")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build" if LIB_PATH.endswith("liblqp_amd.so") else "build_" + os.path.basename(LIB_PATH)[:-3])
     os.makedirs(objdir, exist_ok=True)
     jobs = [(os.path.join(CSRC, "lqp_amd.hip"), os.path.join(objdir, "lqp_amd.o"), ["-DLQP_SPLIT_BUILD"])]
     jobs += [(os.path.join(split_dir, f), os.path.join(objdir, f[:-4] + ".o"), []) for f in tus]
 
     def compile_one(job):
-        src, obj, extra = job
+        src, obj, extra_tu = job
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
             return obj
-        cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", src, "-o", obj]
+        cmd = [hipcc] + HIPCC_FLAGS + extra + extra_tu + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)

@@ -443,9 +443,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         // its workgroups per matrix wait for each other inside the launch: every one of them must be resident -- ask the
         // occupancy calculator for THIS kernel (block size, registers, LDS), not just the CU count
         int dev_ = 0, cus_ = 0, per_cu = 0;
-        const int rlds = spd_lds_bytes(P.Ks);
+        const int rlds = rs4_lds_bytes(P.Ks);      // (the look-ahead sweep's counters behind the flags)
         bool ok = false;
-#if LQP_PIV_MFMA && LQP_RS_V2 == 2
+#if LQP_PIV_MFMA && (LQP_RS_V2 == 2 || LQP_RS_V2 == 4)
         if (P.Ks >= 7 && current_device_cus(&dev_, &cus_) && 4 * B <= cus_ && env_int("LQP_SPD_RESIDENT4", 1) != 0) {
             rs_fn = P.Ks == 7 ? k_spd_resident<7, 4> : k_spd_resident<8, 4>;
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) &&
@@ -466,7 +466,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // auto-scaling on: ONE pass over Q for the column maxima, the symmetry verdict and the (unscaled) blocks, in front of
     // the setup kernel (k_spd_prep); the resident sweep scales its tiles as it loads them and sums ||Qs||_F itself
     P.prep_fused = 0;
-#if LQP_PIV_MFMA && LQP_RS_V2 == 2
+#if LQP_PIV_MFMA && (LQP_RS_V2 == 2 || LQP_RS_V2 == 4)
     if constexpr (sizeof(T) == 4)
         P.prep_fused = (spd_resident && P.scale && P.qs_lazy && (ctl->rho_mode != 0 || P.rho_late) && env_int("LQP_PREP_FUSED", 1)) ? 1 : 0;
 #endif
@@ -524,7 +524,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                         hipLaunchKernelGGL(k_spd_begin<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
                     if (spd_resident) {
                         // all pivot steps in one launch, the matrix in the registers of its two workgroups
-                        const int rlds = spd_lds_bytes(P.Ks);
+                        const int rlds = rs4_lds_bytes(P.Ks);      // (the look-ahead sweep's counters behind the flags)
                         r3 = ensure_lds((const void*)rs_fn, rlds);
                         if (r3) return r3;
                         hipLaunchKernelGGL(rs_fn, dim3(B * rs_np), dim3(RS_NT), rlds, st, P, gate);

@@ -897,6 +897,15 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     wg_spd_sweep_resident_v3<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
                                  (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
+#elif LQP_PIV_MFMA && LQP_RS_V2 == 4
+    if constexpr (NP == 2)
+        wg_spd_sweep_resident_v4<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
+                                         P.info + b, P.status + ST_TIMEOUT, smem, lr,
+                                         (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
+    else
+        wg_spd_sweep_resident_v2<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
+                                         P.info + b, P.status + ST_TIMEOUT, smem, lr,
+                                         (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
 #elif LQP_PIV_MFMA && LQP_RS_V2
     wg_spd_sweep_resident_v2<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,

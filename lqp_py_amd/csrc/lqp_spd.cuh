@@ -399,6 +399,20 @@ __device__ __forceinline__ void lds_wait_ge(int* word, const int target) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// the same wait with a way out: after ~0.5 s the timeout word is raised and the wait ends (the results are flagged, the
+// workgroup still reaches its barriers) -- for schedules in which one group of waves waits for ANOTHER group's progress
+__device__ __forceinline__ void lds_wait_ge_bounded(int* word, const int target, int* __restrict__ timeout_word) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();             // 100 MHz
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) {
+        __builtin_amdgcn_s_sleep(LQP_WAIT_SLEEP);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ULL) {
+            __hip_atomic_store(timeout_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // GSYNC = false: called by all waves of the workgroup (waves >= NWP only take part in the barriers).
 // GSYNC = true : called ONLY by waves 0..NWP-1 while the other waves of the workgroup do something else (s_barrier is
 //                not available then): they synchronise among themselves through the LDS counter `gaux`, `gseq` is the
@@ -2410,6 +2424,457 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
     __syncthreads();
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
+
+// ---- resident sweep, fourth form: LOOK-AHEAD without a second W / W^T pair -------------------------------------------
+// In wg_spd_sweep_resident_v2 the matrix pipes idle while waves 0..3 eliminate the pivot block (22.6 k of 84 k cycles per
+// step) and waves 4..7, done with the panel staging after 5.6 k, wait for them.  Here the pivot block of step k+1 and the
+// staging of panel k+1 run INSIDE step k's update phase, in the buffers of step k:
+//   * every wave first updates its tiles of rows / columns k and k+1 -- the only ones that read W_k / W_k^T, and the ones
+//     step k+1 needs (pivot tile, panel) -- and publishes the latter at once; the workgroup's flag of step k+1 is raised by
+//     the wave that sees the last of the eight arrive (an LDS counter), not behind a barrier;
+//   * waves 0..3 (raised priority) finish their other tiles, wait until all eight waves are past the first group -- W_k,
+//     W_k^T are dead then --, take the pivot tile of step k+1 out of the exchange buffer INTO the W area and eliminate it
+//     there (wg_pivot_block_mfma in its group-synchronised form) while waves 4..7 still update;
+//   * waves 4..7 finish their tiles, wait until all eight waves are done with the panel Y_k and stage panel k+1 over it.
+// One workgroup barrier per step closes it (W_{k+1}, W_{k+1}^T and the raw panel k+1 are in place), one more follows the
+// Y phase.  Both workgroups still eliminate every pivot block (nothing but tiles crosses between them, as in v2); same
+// arithmetic per tile in the same order: bit-identical to v2 (tested).  LDS: v2's + 48 bytes of counters (rs4_lds_bytes).
+// MEASURED (round 4, B = 128, n = 500; -DLQP_RS_V2=4, not the default): 0.366 ms against v2's 0.364 -- correct, no spilled
+// vector registers (v2: 20), and no faster.  Stamps of wave 0 / wave 4 per step: Y 14.6 k, wave 0's eight tiles 35 k, waits
+// 8.8 k, pivot block 27.7 k; wave 4's ten tiles 44.7 k, staging 11 k.  Why the overlap does not materialise: ONE wave runs
+// its dependent v_mfma_f32_32x32x2 chains at one instruction per ~135 cycles (8 quadrants in 34 k cycles whether its SIMD
+// partner works, waits or yields -- LQP_RS4_YIELD), half the pipe's rate; the two waves of a SIMD fill the pipe only
+// together, so both finish their tiles at about the same time whatever the priorities, and the pivot block still runs
+// beside idle matrix pipes.  Variants measured slower: the chain waves' pivot block BEFORE their other tiles
+// (LQP_RS4_CHAIN_FIRST: 0.402 ms), the staging waves yielding the pipe (0.372), two accumulator chains per wave interleaved
+// (1134 spilled registers: 0.405), six / twelve tiles per wave (524 spilled).  What it would take: the chain on waves that
+// hold no tiles at all -- 1024 threads per workgroup (four waves per SIMD, 72 quadrant slots over twelve tile waves).
+__host__ __device__ inline int rs4_lds_bytes(int K) { return spd_lds_bytes(K) + 64; }
+// tiles per wave: the chain waves 0..3 take fewer than the others (their pivot block runs behind their updates, and a wave's
+// dependent matrix instructions alternate with its SIMD partner's whatever the priorities: the chain starts the earlier the
+// fewer tiles its waves hold)
+#ifndef LQP_RS4_CHAIN_FIRST
+#define LQP_RS4_CHAIN_FIRST 0
+#endif
+#ifndef LQP_RS4_YIELD
+#define LQP_RS4_YIELD 0
+#endif
+#ifndef LQP_RS4_NA9
+#define LQP_RS4_NA9 3          // ninths of the workgroup's tiles held by waves 0..3 (v2: 4 -> 8 of 18; 3 -> 6 of 18)
+#endif
+template <int K> __host__ __device__ constexpr int rs4_na() { return (rs2_max<K, 2>() * LQP_RS4_NA9) / 9; }
+template <int K> __host__ __device__ constexpr int rs4_nb() { return rs2_max<K, 2>() - rs4_na<K>(); }
+template <int K, int NP = 2>
+__device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, float* Hdst,
+                                                         float* __restrict__ xb, unsigned int* __restrict__ fl,
+                                                         const unsigned int epoch, const int part, int* __restrict__ info,
+                                                         int* __restrict__ status_timeout, char* smem,
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
+                                                         unsigned long long* __restrict__ dbg = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
+    const int nloc = split_count(K, part, NP);
+    float* Y = (float*)smem;
+    float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
+    float* WT = W + 64 * SPD_LS;
+    float* pcol = WT + 64 * SPD_LS;
+    int* flag = (int*)(pcol + PIV_LDS);
+    static_assert(NP == 2, "the look-ahead schedule is written for two workgroups per matrix");
+    // LDS words behind the flags (rs4_lds_bytes): [0] sync of the chain waves | [1] waves done with W_k / W_k^T | [2] waves done
+    // with the panel Y_k | [3] waves whose tiles of step k+1 have left | [4] sync of the staging waves | [5] the partner's tiles
+    // of step k+1 have arrived | [6..7] the pivot block's words
+    int* const sy = flag + 4;
+    if (tid < 16) flag[tid] = 0;
+    // unscaled blocks (k_spd_prep): the scaling vector, 1 on the padding, in LDS while the tiles are loaded (the Y area
+    // is not written before the staging of step 0, two barriers away)
+    float* const Dl = Y;
+    static_assert(64 * K <= RS_NT, "one element of the scaling vector per thread");
+    // (requested first, staged behind the tile loads: its latency then hides under theirs)
+    const float dmine = (lr.dsc && tid < lr.n) ? lr.dsc[tid] : 1.f;
+    // step flags: one 64-bit granule per workgroup {step number, payload} -- at step 0 the payload is the workgroup's
+    // half of ||Qs||_F^2 (fro_self), so the norm costs no hand-off of its own
+    unsigned long long* const fl64 = (unsigned long long*)fl;
+    // Which XCD are the workgroups of this matrix on?  Each announces its id now (write-through store) and reads the others'
+    // after its tile loads.  On ONE XCD its L2 is their point of coherence: tiles and step granules are then stored with
+    // workgroup scope -- they stay in that L2 instead of being written through to memory and fetched back from there
+    // (131 MB per sweep of the batch) -- and read as before behind the acquire.  Never assumed: asked at every launch.
+    const unsigned int xcd_me = (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
+    if (tid == 0) __hip_atomic_store(fl64 + 4 + part, ((unsigned long long)(epoch + 1u) << 8) | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    auto body = [&](auto pivot_tag) {
+        constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
+        constexpr int NS = PIVOT ? rs2_na<K, NP>() : rs2_nb<K, NP>(), FIRST = PIVOT ? 0 : rs2_na<K, NP>();
+        // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
+        f32x16 T[NS];
+        int ti[NS], tj[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int l = FIRST + s;
+            int a, b;
+            rs2_tile_of(l < nloc ? l : 0, K, part, NP, a, b);
+            ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
+            tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
+            if (ti[s] >= 0) {
+                const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
+                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
+                    // upper-right quadrant of a diagonal tile := transpose of its lower-left one (see wg_spd_sweep_resident)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
+                } else {
+                    const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
+                }
+            }
+        }
+        if (lr.dsc) {
+            // unscaled blocks (k_spd_prep): entry (r, c) is taken as (D_r * v) * D_c, what sym_scale4 computes
+            Dl[tid] = dmine;
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] < 0) continue;
+                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {      // (as the lower-left entry it mirrors: row 32 + li, column quad_row)
+                    const float dr = Dl[ti[s] * 64 + 32 + li];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = (dr * T[s][q]) * Dl[tj[s] * 64 + quad_row(q, lh)];
+                } else {
+                    const float dc = Dl[tj[s] * 64 + 32 * qj + li];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = (Dl[ti[s] * 64 + 32 * qi + quad_row(q, lh)] * T[s][q]) * dc;
+                }
+            }
+        }
+        if (lr.dsc && lr.fro_self) {
+            // this wave's share of ||Qs||_F^2: tiles below the diagonal count twice, a diagonal tile's four quadrants once
+            // each (its upper-right one is held as the mirror of the lower-left one); the identity on the padding is left out
+            // (lane-dependent compares against an opaque value, formed where they are used: as invariants of the step loop
+            //  the sixteen diagonal masks would be held in scalar registers -- and spilled -- for the whole kernel)
+            float fs = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] < 0) continue;
+                float t2 = 0.f;
+                if (ti[s] == tj[s] && qi == qj) {
+                    int dqp = (ti[s] * 64 + 32 * qi + li >= lr.n) ? li - 4 * lh : -1;      // register q is a padding-diagonal entry
+                    asm volatile("" : "+v"(dqp));
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) t2 += (dqp == (q & 3) + 8 * (q >> 2)) ? 0.f : T[s][q] * T[s][q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) t2 += T[s][q] * T[s][q];
+                }
+                fs += ti[s] == tj[s] ? t2 : 2.f * t2;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) fs += __shfl_xor(fs, o);
+            if (lane == 0) WT[w] = fs;                     // (summed by thread 0 behind the first barrier of step 0)
+        }
+        if (lr.on) {
+            const float* xw = xb + (size_t)2 * K * LQP_BLK;
+            float rho = sqrtf(xw[0] + xw[1]) / (float)sqrt((double)lr.n);
+            rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
+            if (tid == 0 && lr.rho_out) *lr.rho_out = rho;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (quad_row(q, lh) == li && ti[s] * 64 + 32 * qi + li < lr.n) T[s][q] += rho;
+                }
+            }
+        }
+        // publish the pivot tile and the panel tiles of step kk this wave holds (as soon as ITS quadrants have step kk-1's
+        // update: the store drain then overlaps with the wait for the slowest wave)
+        bool xlocal_p = false;          // (set before the first publish)
+        auto publish = [&](const int kk) {
+            float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i >= 0 && (i == kk || j == kk)) {
+                    const int slot = (i == kk && j == kk) ? K - 1 : (j == kk ? i - 1 : j);      // P_i: i > kk -> i - 1, i < kk -> i
+                    unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
+                    if (xlocal_p) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float tv = T[s][q];
+                            __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float tv = T[s][q];
+                            __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+        };
+        if (tid == 0) {
+            int same = lr.xcd_local;
+            for (int q = 0; q < NP && same; ++q) {
+                if (q == part) continue;
+                unsigned long long g = 0;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (((g = __hip_atomic_load(fl64 + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned long long)(epoch + 1u)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) { g = ~0ull; break; }      // (1 s: the step flags below will flag it)
+                }
+                same = (unsigned int)(g & 0xFFull) == xcd_me;
+            }
+            flag[1] = same;
+        }
+        __syncthreads();
+        const bool xlocal = flag[1] != 0;
+        xlocal_p = xlocal;
+        publish(0);
+        // ---- step 0: as in wg_spd_sweep_resident_v2 -- flags, rho, pivot block by waves 0..3 beside the panel staging ----
+        auto set_flag = [&](const int kk, const float payload) {
+            const unsigned long long gran = (unsigned long long)(epoch + (unsigned int)kk + 1u) | ((unsigned long long)__float_as_uint(payload) << 32);
+            if (xlocal) __hip_atomic_store(fl64 + part, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(fl64 + part, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto wait_partner = [&](const int kk) -> unsigned long long {      // (one lane)
+            unsigned long long got;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while ((unsigned int)(got = __hip_atomic_load(fl64 + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch + (unsigned int)kk + 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
+                    __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            return got;
+        };
+        // panel tiles of step kk: exchange buffer -> LDS (slot s holds P_i = A_i,kk, i.e. block (kk, i) transposed when i < kk);
+        // by the 256 threads of waves 4..7
+        auto stage_panel = [&](const int kk) {
+            int tid_s = tid;
+            asm volatile("" : "+v"(tid_s));
+            const float* const xbk = xb + (size_t)(kk & 1) * K * LQP_BLK;
+            const int tt = tid_s - 256, r0 = tt >> 3, c8 = (tt & 7) * 8;
+            const float* const src_l = xbk + r0 * 64 + c8;
+            float* const yrow_l = Y + r0 * SPD_LS + c8;            // row-major destination
+            float* const ycol_l = Y + c8 * SPD_LS + r0;            // transposed destination
+#pragma unroll 1
+            for (int s0 = 0; s0 < K - 1; ++s0) {           // (not unrolled: these waves hold twelve tiles)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float* src = src_l + s0 * LQP_BLK + 32 * hf * 64;
+                    const V4<float> a = ld16_handoff(src), b = ld16_handoff(src + 4);
+                    if (s0 >= kk) {
+                        *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS) = a;
+                        *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS + 4) = b;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ycol_l[(s0 * 64 + e) * SPD_LS + 32 * hf] = a.v[e];
+                            ycol_l[(s0 * 64 + 4 + e) * SPD_LS + 32 * hf] = b.v[e];
+                        }
+                    }
+                }
+            }
+        };
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                float fmine = 0.f;
+                if (lr.dsc && lr.fro_self)      // this workgroup's half of the norm travels in the step-0 granule
+                    for (int ww = 0; ww < RS_NW; ++ww) fmine += WT[ww];
+                set_flag(0, fmine);
+                const unsigned long long got = wait_partner(0);
+                if (lr.dsc && lr.fro_self) {
+                    // rho = clamp(||Qs||_F / sqrt(n)) (reference :200-203), the same bits in both workgroups (part order)
+                    const float fother = __uint_as_float((unsigned int)(got >> 32));
+                    const float fsum = part == 0 ? fmine + fother : fother + fmine;
+                    float rho = sqrtf(fsum) / (float)sqrt((double)lr.n);
+                    rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
+                    WT[RS_NW] = rho;
+                    if (lr.rho_out) *lr.rho_out = rho;
+                }
+            }
+            __syncthreads();
+            float diag_add = 0.f;
+            if (lr.dsc) {
+                diag_add = lr.fro_self ? WT[RS_NW] : lr.rho_given;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
+                        int dq = (ti[s] * 64 + 32 * qi + li < lr.n) ? li - 4 * lh : -1;      // (opaque: see the norm above)
+                        asm volatile("" : "+v"(dq));
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) T[s][q] += (dq == (q & 3) + 8 * (q >> 2)) ? diag_add : 0.f;
+                    }
+                }
+            }
+            wg_pivot_block_mfma<false, PIVOT>(xb + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, 0, nullptr, 0, diag_add, true);
+            if constexpr (!PIVOT) stage_panel(0);
+            __syncthreads();
+        }
+        int gchain = 0, gstage = 0;                          // running targets of the two group syncs
+        // (debug: cycles of wave 0 -- Y | updates | waits before the chain | chain | closing barrier -- and of wave 4 --
+        //  updates | waits + staging | closing barrier)
+        unsigned long long dbt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt0 = 0;
+        const bool stamp = dbg != nullptr && lane == 0 && (w == 0 || w == 4);
+#define RS4_STAMP(slot) do { if (stamp) { const unsigned long long t_ = clock64(); dbt[slot] += t_ - dt0; dt0 = t_; } } while (0)
+        for (int k = 0; k < K; ++k) {
+            if (stamp) dt0 = clock64();
+            // (lane parts of every LDS address of this step, opaque: as loop invariants of the step loop they would be
+            //  formed once, held in registers -- one per distinct address -- and spilled with the tiles)
+            int li_s = li, lh_s = lh;
+            asm volatile("" : "+v"(li_s), "+v"(lh_s));
+            // ---- Y_i = P_i W_k^T in place: a wave takes whole 32-row blocks (both column halves) ----
+            constexpr int WOFF = (K - 1) * 64 * SPD_LS, WTOFF = WOFF + 64 * SPD_LS;      // W, W^T behind the panel
+            const float* const yF = Y + li_s * SPD_LS + 32 * lh_s;     // operand row li at the lane's k range (full)
+            const float* const yH = Y + li_s * SPD_LS + 16 * lh_s;     // ... (half k range; + 32: the upper half)
+            float* const yC = Y + (4 * lh_s) * SPD_LS + li_s;          // element (quad_row(q, lh), li) at + ((q&3) + 8 (q>>2)) * SPD_LS
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
+                if (rb < 2 * (K - 1)) {
+                    const int xoff = ((rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
+                    const f32x16 a0 = spd_quadrant_lp<1>(yH + xoff, yH + WOFF);
+                    const f32x16 a1 = spd_quadrant_lp<0>(yF + xoff, yF + WOFF + 32 * SPD_LS);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS] = a0[q];
+                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS + 32] = a1[q];
+                    }
+                }
+            }
+            __syncthreads();
+            RS4_STAMP(0);
+            const bool more = k + 1 < K;
+            if constexpr (PIVOT) { if (more) __builtin_amdgcn_s_setprio(2); }      // the chain waves should reach the chain first
+            const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
+            auto update_slot = [&](const int s) {
+                const int i = ti[s], j = tj[s];
+                if (i != k && j != k) {
+                    const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
+                    T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
+                } else if (i == k && j == k) {    // (W^T is upper triangular: rows >= 32 only see k >= 32 -- same halves,
+                                                  //  hence the same summation order and bits, as the multi-launch sweep)
+                    const f32x16 a = (qi | qj) ? spd_quadrant_lp<1>(yH + 32 + WTOFF + oi, yH + 32 + WTOFF + oj)
+                                               : spd_quadrant_lp<0>(yF + WTOFF, yF + WTOFF);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
+                } else if (j == k) {              // tile (i, k), i > k: Y_i W
+                    const int yo = (i - 1) * 64 * SPD_LS + oi;
+                    T[s] = qj == 1 ? spd_quadrant_lp<1>(yH + 32 + yo, yH + 32 + WTOFF + 32 * SPD_LS) : spd_quadrant_lp<0>(yF + yo, yF + WTOFF);
+                } else {                          // tile (k, j), j < k: W^T Y_j^T
+                    const int yo = j * 64 * SPD_LS + oj;
+                    T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
+                }
+            };
+            // ---- first: the tiles of rows / columns k (they read W_k, W_k^T) and k+1 (the next pivot tile and panel) ----
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i < 0) continue;
+                if (i == k || j == k || i == k + 1 || j == k + 1) update_slot(s);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // done with W_k, W_k^T
+            if (more) {
+                publish(k + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    // the wave that sees the last arrival raises this workgroup's flag of step k+1
+                    const int old = __hip_atomic_fetch_add(sy + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (old + 1 == RS_NW * (k + 1)) set_flag(k + 1, 0.f);
+                }
+            }
+            // ---- then every other tile (the panel Y_k only) ----
+            auto rest = [&]() {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int i = ti[s], j = tj[s];
+                    if (i < 0) continue;
+                    if (!(i == k || j == k || i == k + 1 || j == k + 1)) update_slot(s);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(sy + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // done with the panel Y_k
+            };
+            constexpr bool CHAIN_FIRST = LQP_RS4_CHAIN_FIRST != 0;     // the chain waves: pivot block k+1 BEFORE their other tiles
+            if constexpr (!PIVOT && LQP_RS4_YIELD) {
+                // the staging waves leave the matrix pipes to the chain waves' remaining tiles (dependent matrix instructions of
+                // two waves of a SIMD alternate whatever their priorities): the chain then starts sooner and THESE tiles are
+                // updated beside it
+                if (more) lds_wait_ge_bounded(sy + 8, 4 * (k + 1), status_timeout);
+            }
+            if (!(PIVOT && CHAIN_FIRST && more)) rest();
+            if constexpr (PIVOT) {
+                if (lane == 0) __hip_atomic_fetch_add(sy + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            RS4_STAMP(PIVOT ? 1 : 5);
+            if (more) {
+                if constexpr (PIVOT) {
+                    __builtin_amdgcn_s_setprio(0);
+                    // ---- pivot block k+1 beside the other waves' updates: W / W^T are free once all eight waves have passed
+                    //      the first group of tiles; the pivot tile comes out of the exchange buffer ----
+                    if (tid == 0) {
+                        wait_partner(k + 1);
+                        __hip_atomic_store(sy + 5, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    lds_wait_ge_bounded(sy + 5, k + 1, status_timeout);                   // the partner's tiles of step k+1 ...
+                    lds_wait_ge_bounded(sy + 3, RS_NW * (k + 1), status_timeout);         // ... and this workgroup's own have left
+                    lds_wait_ge_bounded(sy + 1, RS_NW * (k + 1), status_timeout);         // W_k, W_k^T are dead
+                    RS4_STAMP(2);
+                    {
+                        int tid_s = tid;
+                        asm volatile("" : "+v"(tid_s));
+                        const float* src = xb + (size_t)((k + 1) & 1) * K * LQP_BLK + (size_t)(K - 1) * LQP_BLK;
+#pragma unroll
+                        for (int v0 = 0; v0 < 4; ++v0) {
+                            const int i4 = (tid_s + 256 * v0) * 4;
+                            const V4<float> v = ld16_handoff(src + i4);
+                            *(V4<float>*)(W + (i4 >> 6) * SPD_LS + (i4 & 63)) = v;
+                        }
+                    }
+                    lds_group_sync<true>(sy + 0, gchain += 4);
+                    wg_pivot_block_mfma<true, true, true>(nullptr, W, WT, pcol, flag, (k + 1) * 64, sy + 6, k);
+                    lds_group_sync<true>(sy + 0, gchain += 4);
+                    RS4_STAMP(3);
+                    if (CHAIN_FIRST) rest();
+                } else {
+                    // ---- panel of step k+1 into the Y area once nobody reads Y_k any more ----
+                    lds_wait_ge_bounded(sy + 5, k + 1, status_timeout);
+                    lds_wait_ge_bounded(sy + 3, RS_NW * (k + 1), status_timeout);
+                    lds_wait_ge_bounded(sy + 2, RS_NW * (k + 1), status_timeout);         // nobody reads the panel Y_k any more
+                    stage_panel(k + 1);
+                    (void)gstage;
+                    RS4_STAMP(6);
+                }
+            }
+            __syncthreads();
+            RS4_STAMP(PIVOT ? 4 : 7);
+        }
+#undef RS4_STAMP
+        if (stamp) {
+            if (w == 0) for (int q = 0; q < 5; ++q) dbg[q] = dbt[q];
+            else for (int q = 5; q < 8; ++q) dbg[q] = dbt[q];
+        }
+        // ---- the finished tiles to their home blocks ----
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (ti[s] >= 0) {
+                float* C = Hdst + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
+            }
+        }
+    };
+    if (w < 4) body(std::true_type());
+    else body(std::false_type());
+    __syncthreads();
+    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
+}
+
 
 // ---- resident sweep, third form: the pivot block of step k+1 runs BESIDE the tile updates of step k ------------------
 // In wg_spd_sweep_resident_v2 the matrix pipes idle while the pivot block is eliminated (24 k of 87 k cycles per step)
