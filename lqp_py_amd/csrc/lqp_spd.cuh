@@ -1860,7 +1860,8 @@ __device__ __forceinline__ float split_combine(const int e, const int Np, const 
 #define LQP_RS_PIV_MFMA 0      // (the first resident sweep with the matrix-core pivot block: spills, see wg_spd_sweep_resident_v2)
 #endif
 #ifndef LQP_RS_V2
-#define LQP_RS_V2 2            // k_spd_resident runs wg_spd_sweep_resident_v2 (2) / _v3 (3: measured slower, see there); 0: the first form
+#define LQP_RS_V2 2            // k_spd_resident runs wg_spd_sweep_resident_v2 (2) / _v3 (3: measured slower, see there) / _v4 for two
+                               // workgroups per matrix and _v2 for four (4: the look-ahead form, measured no faster); 0: the first form
 #endif
 constexpr int RS_NT = 512, RS_NW = RS_NT / 64;
 template <int K> __host__ __device__ constexpr int rs_slots() {
