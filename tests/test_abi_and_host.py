@@ -159,3 +159,53 @@ def test_bench_spawns_its_own_ranks_without_touching_the_gpu(tmp_path, monkeypat
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _kernel_resources():
+    """{demangled kernel name: (vgprs, spilled vgprs, scratch bytes)} from the code-object metadata of the built library
+    (every translation unit of the split build carries its own code object)."""
+    import shutil
+    import subprocess
+    import tempfile
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and shutil.which("c++filt")):
+        pytest.skip("llvm-objdump / llvm-readelf / c++filt not available")
+    _lib.build_library()
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(_lib.LIB_PATH, os.path.join(tmp, "lib.so"))
+        subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([readelf, "--notes", os.path.join(tmp, f)], capture_output=True, text=True, check=True).stdout
+            for blk in notes.split("- .agpr_count")[1:]:
+                g = lambda k: re.search(r"\." + k + r":\s*(\S+)", blk).group(1)
+                name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
+                out[name.split("(")[0].replace("void ", "")] = (int(g("vgpr_count")), int(g("vgpr_spill_count")),
+                                                                int(g("private_segment_fixed_size")))
+    return out
+
+
+def test_register_budgets_of_the_hot_kernels():
+    """What the shipped code object says about the kernels of the benched step (VERDICT r3 asked for this check after
+    DESIGN.md claimed 0 spilled registers for a kernel that had 20).  Exact zeros where they hold; elsewhere the measured
+    numbers as CEILINGS, so that a change that makes the compiler spill more is caught here and not on the GPU:
+      * k_spd_resident<8,2>: 20 spilled VGPRs / 44 B of scratch in the step body (its look-ahead form, -DLQP_RS_V2=4, holds
+        its tiles without spilling and is exactly as fast: DESIGN.md section 8);
+      * k_admm_loop_split<8,512,false,2>: 127 spilled VGPRs, all in the once-per-launch equality prologue."""
+    res = _kernel_resources()
+    assert len(res) >= 80, len(res)
+    exact_zero = ["lqp::k_spd_resident<5, 2>", "lqp::k_spd_resident<6, 2>", "lqp::k_spd_resident<7, 2>", "lqp::k_spd_resident<7, 4>",
+                  "lqp::k_spd_resident<8, 4>", "lqp::k_admm_loop_split<5, 512, false, 2>", "lqp::k_admm_loop_split<6, 512, false, 2>",
+                  "lqp::k_admm_loop_split<7, 512, false, 2>", "lqp::k_admm_loop_split<7, 512, false, 4>",
+                  "lqp::k_admm_loop_split<8, 512, false, 4>", "lqp::k_admm_loop_small<0>", "lqp::k_spd_prep<0>",
+                  "lqp::k_bwd_build_chol<0>", "lqp::k_unroll_outer<0>"]
+    for k in exact_zero:
+        assert res[k][1] == 0 and res[k][2] == 0, (k, res[k])
+    ceilings = {"lqp::k_spd_resident<8, 2>": (20, 44), "lqp::k_admm_loop_split<8, 512, false, 2>": (127, 216),
+                "lqp::k_bwd_chol_solve<0>": (33, 112)}
+    for k, (spill, scratch) in ceilings.items():
+        assert res[k][1] <= spill and res[k][2] <= scratch, (k, res[k])
+    for k, (vg, _, _) in res.items():
+        assert vg <= 256, (k, vg)
