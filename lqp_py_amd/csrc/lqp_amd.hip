@@ -1,8 +1,8 @@
 // C ABI of the MI355X box-QP ADMM layer: workspace carving, launch
 // orchestration, status reporting.  See include/lqp_amd.h for the contract.
 #include "../../include/lqp_amd.h"
-#include "lqp_boxqp.cuh"
-#include "lqp_unroll.cuh"
+#include "lqp_boxqp.hpp"
+#include "lqp_unroll.hpp"
 #ifdef LQP_SPLIT_BUILD
 // split build (lqp_py_amd/_lib.py build_library, tools/gen_split_build.py): the kernel instances are compiled in the
 // translation units csrc/split/lqp_tu_*.hip; here they are only declared
@@ -165,7 +165,7 @@ int launch_lu_big(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, in
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr) {
     if (N > 1024) return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
-    const int la = env_int("LQP_LU_LA", 0);       // lookahead variants (see lqp_lu.cuh): 1 = 16 columns / 1024
+    const int la = env_int("LQP_LU_LA", 0);       // lookahead variants (see lqp_lu.hpp): 1 = 16 columns / 1024
     if (N <= 512 && N > 64 && la != 0) {           // threads, 2 = 32 columns / 768 threads (8 + 4 waves)
         int rc;
         if (la == 2) {
@@ -402,7 +402,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     const int ar_iter = ctl->adaptive_rho_iter < 1 ? 1 : ctl->adaptive_rho_iter;
     int n_launch = 0;
 
-    // ---- x-update linear algebra: pivoted LU of the KKT matrix, or the symmetric inverse (lqp_spd.cuh) ----
+    // ---- x-update linear algebra: pivoted LU of the KKT matrix, or the symmetric inverse (lqp_spd.hpp) ----
     bool spd = false;
     if constexpr (sizeof(T) == 4) {
         int want = ctl->linsolve;
@@ -1300,7 +1300,7 @@ int lqp_boxqp_forward_finish(void* stream, int B, int max_iters, int check_solve
     return rc == LQP_RETRY_LU ? LQP_ERR_NOT_SPD : rc;
 }
 
-// ---- unroll=True: backward through the unrolled loop (lqp_unroll.cuh) ----
+// ---- unroll=True: backward through the unrolled loop (lqp_unroll.hpp) ----
 struct UnrollCarve { UnrollParams U; size_t bytes; };
 static UnrollCarve carve_unroll(void* ws, int B, int n, int m, int T) {
     UnrollCarve c;

@@ -2,11 +2,11 @@
 // rho, fixed-point backward, KKT solve).  One 1024-thread workgroup per QP.
 #pragma once
 #include <type_traits>
-#include "lqp_common.cuh"
-#include "lqp_lu.cuh"
-#include "lqp_lu_big.cuh"
-#include "lqp_trsv.cuh"
-#include "lqp_spd.cuh"
+#include "lqp_common.hpp"
+#include "lqp_lu.hpp"
+#include "lqp_lu_big.hpp"
+#include "lqp_trsv.hpp"
+#include "lqp_spd.hpp"
 
 namespace lqp {
 
@@ -76,7 +76,7 @@ template <typename T> struct FwdParams {
 };
 
 // vector block of problem b: [ps | lbs | ubs | D | z | u | x | As (m*n) | bs | E | nu | cv | Tm (m*n) | s0]
-// (cv, Tm, s0: constant term c, T = G S^-1 and S^-1 b of the symmetric-inverse path, lqp_spd.cuh)
+// (cv, Tm, s0: constant term c, T = G S^-1 and S^-1 b of the symmetric-inverse path, lqp_spd.hpp)
 template <typename T> struct VecView {
     T *ps, *lbs, *ubs, *D, *z, *u, *x, *As, *bs, *E, *nu, *cv, *Tm, *s0;
     __device__ VecView(T* base, int n, int m) {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(NT) void k_lu_factor(T* __restrict__ Mall, const in
                               dbg ? dbg + (size_t)b * 4 : nullptr);
 }
 
-// 1024 < N <= 2048: two panel rows per thread (lqp_lu_big.cuh)
+// 1024 < N <= 2048: two panel rows per thread (lqp_lu_big.hpp)
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_lu_factor_big(T* __restrict__ Mall, const int N, const int ld,
                                                           const size_t mstride, int* __restrict__ piv,
@@ -642,7 +642,7 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
 }
 
 // ---------------------------------------------------------------------------
-// symmetric-inverse path (lqp_spd.cuh): factorisation kernels
+// symmetric-inverse path (lqp_spd.hpp): factorisation kernels
 // ---------------------------------------------------------------------------
 // standalone SPD inverse (test / utility entry lqp_spd_inverse_batched): dense (B,n,n) in, dense inverse out
 template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_big_step(const FwdParams<float> 
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
     wg_spd_sweep_big<SPD_NP>(spd_half(P, b, 0), P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np, k, k + 1, phases, part);
 }
-// all pivot steps in ONE launch, the matrix resident in the registers of its two workgroups (lqp_spd.cuh).  Reads the
+// all pivot steps in ONE launch, the matrix resident in the registers of its two workgroups (lqp_spd.hpp).  Reads the
 // blocks k_spd_begin built (half Ks & 1 of the packed area), leaves -(Qs + rho I)^-1 in half 0, where the loop reads it.
 // Exchange buffer: the (unused on this path) KKT-matrix area; step flags: behind the loop's exchange granules.
 template <int KS, int NP = 2>
@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const in
 
 // ---------------------------------------------------------------------------
 // The same loop with TWO workgroups per QP (symmetric x-update, f32, 2 B <= #CUs, Ks >= SPLIT_MINK): workgroups b
-// and b + B hold one half of the blocks of H each, ALL of them on chip for the whole launch (lqp_spd.cuh,
+// and b + B hold one half of the blocks of H each, ALL of them on chip for the whole launch (lqp_spd.hpp,
 // wg_sym_gemv_split), and exchange their partial products every iteration:
 //   thread e < Nps combines its element of this workgroup's partial, publishes it as ONE 8-byte granule
 //   {tag, value} (agent-scope relaxed atomic store = sc1 write-through store), polls the partner's granule of the

@@ -16,7 +16,7 @@
 //               32x32x2 f32 tiles (C tile prefetched one tile ahead and used
 //               as the accumulator: D = C - L21 U12), or 8x4 VALU tiles.
 #pragma once
-#include "lqp_common.cuh"
+#include "lqp_common.hpp"
 
 namespace lqp {
 

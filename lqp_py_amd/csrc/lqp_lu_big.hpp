@@ -1,12 +1,12 @@
 // Batched LU with partial pivoting for matrices ABOVE the one-row-per-thread tier (1024 < N <= 2048): the same
-// right-looking algorithm, LAPACK layout and pivot rule as wg_lu_factor (lqp_lu.cuh; replaces torch.linalg.lu_factor at
+// right-looking algorithm, LAPACK layout and pivot rule as wg_lu_factor (lqp_lu.hpp; replaces torch.linalg.lu_factor at
 // lqp_py/solve_box_qp_admm_torch.py:215,254 and lqp_py/lu_layer.py:10,31 -- the reference's LAPACK calls take any size),
 // with R = 2 panel rows per thread: thread t keeps the rows k0 + t and k0 + t + 1024 of the panel in registers.  The
 // matrix stays in global memory (16 MB per matrix at N = 2048: L2 / Infinity Cache resident for small batches, HBM
 // otherwise); L21^T and U12 of a panel are staged in LDS (2 * PB * Mpad elements: PB = 8 in f32, 4 in f64).  Kept apart
 // from the tuned kernel on purpose: that one's register budget and barrier count are what the LU tier's speed rests on.
 #pragma once
-#include "lqp_lu.cuh"
+#include "lqp_lu.hpp"
 
 namespace lqp {
 

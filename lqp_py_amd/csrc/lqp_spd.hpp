@@ -20,9 +20,9 @@
 // A non-positive pivot (K not positive definite in f32) is reported through info; the host then repeats
 // the solve on the LU path.
 #pragma once
-#include "lqp_common.cuh"
-#include "lqp_lu.cuh"
-#include "lqp_trsv.cuh"
+#include "lqp_common.hpp"
+#include "lqp_lu.hpp"
+#include "lqp_trsv.hpp"
 
 namespace lqp {
 

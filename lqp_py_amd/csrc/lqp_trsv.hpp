@@ -16,7 +16,7 @@
 // 16-lane DPP reduction per block row.  Loads run LQP_PF blocks ahead of
 // their use through a register ring (independent of the data dependence).
 #pragma once
-#include "lqp_common.cuh"
+#include "lqp_common.hpp"
 
 namespace lqp {
 

@@ -16,7 +16,7 @@
 //   Asbar = sum_k dnu_k x_k^T + nu_k dxx_k^T,   bsbar = -sum_k dnu_k,   lbsbar / ubsbar: what the clamps kept.
 // A clamp that sits EXACTLY on its bound (x_k + u_k == lb: torch.maximum splits the gradient in two) is treated as free.
 #pragma once
-#include "lqp_boxqp.cuh"
+#include "lqp_boxqp.hpp"
 
 namespace lqp {
 

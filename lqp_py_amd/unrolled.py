@@ -4,7 +4,7 @@ iteration).
 
 Native path (float32, symmetric x-update, no adaptive-rho refactorisation -- the benchmark case): the forward is the
 ordinary persistent HIP solve; the backward is ONE reverse sweep over the recorded iterations in the HIP library
-(``lqp_boxqp_unroll_backward``, csrc/lqp_unroll.cuh): per iteration one product with the cached inverse instead of a taped
+(``lqp_boxqp_unroll_backward``, csrc/lqp_unroll.hpp): per iteration one product with the cached inverse instead of a taped
 ``TorchLULayer`` node, no per-iteration torch op, no host sync.  The kernel differentiates the loop, i.e. it returns the
 gradients w.r.t. the SCALED problem (Qs, ps, As, bs, lbs, ubs, rho, D); the scaling itself (:160-203: ~25 element-wise /
 reduction ops, once per call) is differentiated by autograd on a small eager graph rebuilt in ``backward``.

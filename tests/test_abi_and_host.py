@@ -77,7 +77,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(REPO, "lqp_py_amd")
     for root, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("the oracle", ""), f"{f} mentions the oracle"
 

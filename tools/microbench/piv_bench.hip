@@ -3,7 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -pragma-unroll-threshold=200000 -fno-slp-vectorize \
 //         -DNWPT=16 -DNT=1024 -o piv_bench tools/microbench/piv_bench.hip && ./piv_bench
 // Prints us per block for both and the largest difference of W / W^T against a double-precision Cholesky inverse.
-#include "../../lqp_py_amd/csrc/lqp_boxqp.cuh"
+#include "../../lqp_py_amd/csrc/lqp_boxqp.hpp"
 #include <cstdio>
 #include <vector>
 #include <cmath>

@@ -1,7 +1,7 @@
 // debug aid for wg_pivot_block_mfma: one workgroup, one block; dumps the scales and the coefficient queue next to a
 // float emulation of the same elimination (first rows only).  Build with -DLQP_PIV_DEBUG_STOP (the function then returns
 // before its final stores, so the queue survives in the W^T area).
-#include "../../lqp_py_amd/csrc/lqp_boxqp.cuh"
+#include "../../lqp_py_amd/csrc/lqp_boxqp.hpp"
 #include <cstdio>
 #include <vector>
 #include <cmath>
