@@ -1446,3 +1446,106 @@ def test_four_workgroups_per_qp_sweep(dev, monkeypatch, n, B, m, scale):
         P.record("sweep_np4", k, err(sols["1"][k], ref[k]), 1.0, n=n, B=B, m=m)
         assert err(sols["1"][k], sols["0"][k]) < 1e-5 * max(1.0, float(ref[k].abs().max())), k
         assert err(sols["1"][k], ref[k]) < 2e-5 * max(1.0, float(ref[k].abs().max())), k
+
+
+# ---------------------------------------------------------------- round 4: hardening of the new tiers
+@pytest.mark.parametrize("n,B,m", [(30, 5, 0), (64, 4, 2), (100, 16, 1), (128, 3, 3)])
+def test_small_loop_kernel_against_the_general_one(dev, monkeypatch, n, B, m):
+    """k_admm_loop_small (n <= 128: the whole matrix in the registers of 256 threads) against the 1024-thread loop kernel
+    it stands in for (LQP_LOOP_SMALL=0) and against the oracle.  At a pinned iteration count: iterates within rounding of
+    each other and within the bar of the oracle; with the stopping rule live: the same stop up to one check interval (the
+    check is a floating-point threshold: a borderline problem may stop one check later on one side)."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
+    pinned = dict(eps_abs=1e-12, eps_rel=1e-12, max_iters=41)
+    out, live = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_LOOP_SMALL", flag)
+        out[flag], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve="spd", **pinned))
+        live[flag], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve="spd", **TOL))
+        assert out[flag]["_stats"]["linsolve_used"] == 2 and out[flag]["_stats"]["mode_used"] == 2 and out[flag]["iter"] == 40
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**pinned))
+    t64 = O.solve_box_qp(*[None if t is None else t.double() for t in (Q, p, A, b, lb, ub)], O.make_control(**pinned))
+    for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+        assert err(out["1"][k], out["0"][k]) < 5e-6, k
+        close_or_fp64(f"small_loop_n{n}_m{m}", k, out["1"][k], ref[k], t64[k], X_TOL)
+    ref_live = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+    interval = O.resolve_control(O.make_control(**TOL), n).check_solved
+    assert abs(live["1"]["iter"] - live["0"]["iter"]) <= interval and abs(live["1"]["iter"] - ref_live["iter"]) <= interval
+    assert err(live["1"]["x"], ref_live["x"]) < 1e-3 * max(1.0, float(ref_live["x"].abs().max()))
+
+
+@pytest.mark.parametrize("n,B,m", [(60, 3, 0), (96, 4, 3), (200, 2, 1)])
+def test_unroll_native_against_the_taped_loop(dev, monkeypatch, n, B, m):
+    """The reverse sweep (lqp_boxqp_unroll_backward) against the taped loop it replaces, box-only and with several equality
+    rows: the same solution, all gradients within rtol 1e-4 of scale, and the float64 tape as arbiter."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + 7 * m, with_eq=False)
+    gen = torch.Generator().manual_seed(n + m)
+    A = torch.randn(B, m, n, generator=gen) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=gen) if m else None
+    cot = torch.randn(B, n, 1, generator=gen)
+    names = ("Q", "p", "A", "b", "lb", "ub")
+    data = dict(zip(names, (Q, p, A, b, lb, ub)))
+    grads = {}
+    for native in ("1", "0"):
+        monkeypatch.setenv("LQP_UNROLL_NATIVE", native)
+        leaves = [None if data[k] is None else data[k].to(dev).requires_grad_(True) for k in names]
+        x = L.SolveBoxQP(control=L.box_qp_control(unroll=True, **TOL))(*leaves)
+        x.backward(cot.to(dev))
+        grads[native] = (x.detach(), [None if t is None else t.grad for t in leaves])
+    from lqp_py_amd.unrolled import _eager_unrolled
+    l64 = [None if data[k] is None else data[k].double().requires_grad_(True) for k in names]
+    x64 = _eager_unrolled(*l64, SB.resolve_control(L.box_qp_control(unroll=True, **TOL), n), True, True, solver_cls=_CpuLU)
+    x64.backward(cot.double())
+    close_or_fp64(f"unroll_vs_tape_n{n}_m{m}", "x", grads["1"][0], grads["0"][0], x64.detach(), X_TOL)
+    for nm, g1, g0, t64 in zip(GRADS, grads["1"][1], grads["0"][1], l64):
+        if g1 is None:
+            assert g0 is None
+            continue
+        close_or_fp64(f"unroll_vs_tape_n{n}_m{m}", nm, g1, g0, t64.grad, G_RTOL)
+
+
+@pytest.mark.parametrize("n,B,m,dtype", [(1100, 2, 0, torch.float32), (1030, 2, 20, torch.float32), (1200, 1, 2, torch.float64)])
+def test_lu_tier_above_1024_rows(dev, n, B, m, dtype):
+    """n + m > 1024 with no / many equality rows and in float64: forward against the oracle (iteration count, iterates), the
+    fixed-point gradients against the oracle's for the same solution."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n, with_eq=False, dtype=dtype)
+    gen = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=gen, dtype=dtype) if m else None
+    b = (0.1 * torch.randn(B, m, 1, generator=gen, dtype=dtype)) if m else None
+    inp = (Q, p, A, b, lb, ub)
+    sol, a = solve(dev, inp, O.make_control(**TOL))
+    ref = O.solve_box_qp(*inp, O.make_control(**TOL))
+    assert sol["_stats"]["linsolve_used"] == 1 and sol["iter"] == ref["iter"]
+    t64 = ref if dtype == torch.float64 else O.solve_box_qp(*[None if t is None else t.double() for t in inp],
+                                                          O.make_control(eps_abs=1e-12, eps_rel=1e-12, max_iters=ref["iter"] + 1))
+    tol = X_TOL if dtype == torch.float32 else 1e-9
+    for k in ("x", "u", "lams") + (("nus",) if m else ()):
+        close_or_fp64(f"lu_tier_n{n}_m{m}", k, sol[k], ref[k], t64[k], tol)
+    cot = torch.randn(B, n, 1, generator=gen, dtype=dtype)
+    gr = L.torch_solve_box_qp_grad(cot.to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
+    gref = O.solve_box_qp_grad(cot, ref["x"], ref["u"], ref["lams"], ref["nus"], Q, A, lb, ub, ref["rho"])
+    d = [None if t is None else t.double() for t in inp]
+    g64 = O.solve_box_qp_grad(cot.double(), t64["x"], t64["u"], t64["lams"], t64["nus"], d[0], d[2], d[4], d[5], t64["rho"])
+    for idx, nm in enumerate(GRADS):
+        if gr[idx] is None:
+            continue
+        close_or_fp64(f"lu_tier_n{n}_m{m}", nm, gr[idx], gref[idx], g64[idx], G_RTOL if dtype == torch.float32 else 1e-8)
+
+
+def test_kkt_backward_native_in_float64(dev, monkeypatch):
+    """backward='kkt' in float64 (the reference itself fails there, SURVEY 8c: a dtype bug at :447): native (LU form of the
+    reduced system: float64 has no Cholesky form) against the composed path."""
+    g = load_golden("g12_kkt_backward")
+    out = {}
+    for native in (True, False):
+        monkeypatch.setattr(SB, "_KKT_NATIVE", native)
+        leaves = [g[k].double().to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+        x = L.SolveBoxQP(control=L.box_qp_control(backward='kkt', **TOL))(*leaves)
+        x.backward(g["cot"].double().to(dev))
+        out[native] = [t.grad for t in leaves]
+    for nm, a_, b_ in zip(GRADS, out[True], out[False]):
+        assert err(a_, b_) < 1e-8 * max(1.0, float(b_.abs().max())), nm
+        assert err(a_, g[nm]) < 1e-4 * max(1.0, float(g[nm].abs().max())), nm
