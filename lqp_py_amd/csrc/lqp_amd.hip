@@ -467,8 +467,15 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // the setup kernel (k_spd_prep); the resident sweep scales its tiles as it loads them and sums ||Qs||_F itself
     P.prep_fused = 0;
 #if LQP_PIV_MFMA && (LQP_RS_V2 == 2 || LQP_RS_V2 == 4)
-    if constexpr (sizeof(T) == 4)
+    if constexpr (sizeof(T) == 4) {
         P.prep_fused = (spd_resident && P.scale && P.qs_lazy && (ctl->rho_mode != 0 || P.rho_late) && env_int("LQP_PREP_FUSED", 1)) ? 1 : 0;
+        // ... and the one-workgroup tier (more problems than half the CUs, n <= 512): k_spd_inverse scales the prepared
+        // blocks, sums ||Qs||_F and adds rho itself (wg_spd_factor)
+        if (!P.prep_fused && spd && !spd_split && !spd_big_split && P.Ks <= SPD_MAXK && P.scale && P.qs_lazy &&
+            ctl->rho_mode != 2 && (size_t)n * P.ldq >= (size_t)SPD_NP * P.Ks * LQP_NB + 8 &&      // (k_spd_prep's scratch per
+            env_int("LQP_PREP_ONE", 1))                                                             //  problem lives in its Qs area)
+            P.prep_fused = 2;
+    }
 #endif
     if constexpr (sizeof(T) == 4) {
         if (P.prep_fused) {

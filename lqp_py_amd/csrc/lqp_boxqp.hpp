@@ -44,7 +44,7 @@ template <typename T> struct FwdParams {
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
     int rho_late;                        // 1: rho = ||Qs||_F / sqrt(n) from the sums k_spd_begin leaves, added by k_spd_resident
-    int prep_fused;                      // 1: k_spd_prep ran BEFORE the setup kernel -- one pass over Q for the column maxima, the
+    int prep_fused;                      // 1 / 2: k_spd_prep ran BEFORE the setup kernel (2: one-workgroup tier, k_spd_inverse finishes the blocks) -- one pass over Q for the column maxima, the
                                          //    symmetry verdict and the UNSCALED blocks; the resident sweep scales them as it loads
                                          //    them and takes ||Qs||_F (-> rho) from its own tiles
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         // (symmetric path: the scaled matrix is not stored, its readers scale Q as they load it)
         T* Qw = P.qs_lazy ? nullptr : P.Qs + (size_t)b * n * ldq;
         T* Mw = P.M + (size_t)b * Np * Np;
-        if (P.qs_lazy && P.spd && (P.rho_late || (P.prep_fused && P.rho_mode != 0))) {
+        if (P.qs_lazy && P.spd && (P.rho_late || (P.prep_fused && P.rho_mode != 0) || P.prep_fused == 2)) {
             // nothing to store here and the norm (when rho is derived from it) is taken by k_spd_begin / the resident
             // sweep: no second pass over Q
         } else if (qvec) {
@@ -787,6 +787,55 @@ __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const i
     const float* Qs = (P.scale && !lazy) ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
     const int ldq = (P.scale && !lazy) ? P.ldq : P.n;
     const float* dsc = lazy ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
+    if (check_sym && P.prep_fused && P.Ks <= SPD_MAXK) {
+        // First factorisation behind k_spd_prep (the one-workgroup tier: more problems than half the CUs).  The UNSCALED
+        // lower blocks are in the packed area already and the symmetry verdict went to the setup kernel: what is left is
+        // element-wise -- (D_r v) D_c (the operations of sym_scale4: the same bits as the scaled copy), ||Qs||_F^2 on the way
+        // (-> rho = clamp(||Qs||_F / sqrt(n)), :200-203, when rho is not given), rho on the diagonal.  Three passes over Q
+        // less per solve (norm, symmetry check, block build: 0.6 of 7.9 ms at B = 1024, n = 500).
+        const int n = P.n, Ks = P.Ks, tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
+        float* Dl = (float*)smem;                                    // [64 Ks] scaling vector, 1 on the padding
+        float* red = Dl + 64 * Ks;
+        for (int i = tid; i < 64 * Ks; i += LQP_NT) Dl[i] = i < n ? dsc[i] : 1.f;
+        __syncthreads();
+        const float* src = Hs + (size_t)(Ks & 1) * sym_blocks(Ks) * LQP_BLK;     // (where k_spd_prep leaves them: spd_half(P, b, Ks & 1))
+        float fs = 0.f;
+        for (int j = 0; j < Ks; ++j)
+            for (int i = j; i < Ks; ++i) {
+                const size_t off = (size_t)sym_idx(i, j, Ks) * LQP_BLK + tid * 4;
+                V4<float> v = *(const V4<float>*)(src + off);
+                const int gr = i * 64 + r, gc = j * 64 + c4;
+                const float dr = Dl[gr];
+                float t2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v.v[e] = (dr * v.v[e]) * Dl[gc + e];
+                    t2 += (gr < n && gc + e < n) ? v.v[e] * v.v[e] : 0.f;      // (the identity on the padding is left out)
+                }
+                fs += i == j ? t2 : 2.f * t2;
+                *(V4<float>*)(Hs + off) = v;
+            }
+        float rho_here = rho;
+        if (P.rho_mode == 0) {
+            const float fro = sqrtf(wg_sum(fs, red));
+            rho_here = fro / (float)sqrt((double)n);
+            rho_here = tmin(tmax(rho_here, P.rho_min), P.rho_max);
+            if (tid == 0) P.scal[(size_t)b * SC_WORDS + SC_RHO] = rho_here;
+        }
+        __syncthreads();
+        for (int i = 0; i < Ks; ++i) {                               // rho on the diagonal (own elements: written above by this thread)
+            const int gr = i * 64 + r;
+            if (gr < n && r >= c4 && r < c4 + 4) Hs[(size_t)sym_idx(i, i, Ks) * LQP_BLK + tid * 4 + (r - c4)] += rho_here;
+        }
+        __syncthreads();
+        wg_spd_sweep(Hs, Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
+        if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
+        if (P.m > 0) {
+            __syncthreads();
+            wg_eq_correct(P, b, smem);
+        }
+        return;
+    }
     if (check_sym) {
         float* red = (float*)smem;
         const float asym = wg_sym_asymmetry(Qs, ldq, P.n, P.Ks, red, dsc);

@@ -915,6 +915,8 @@ def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeyp
     # (... and applies the equality correction inside the loop kernel, with the summation order of its own products:
     #  test_equality_correction_in_the_loop_kernel)
     monkeypatch.setenv("LQP_EQ_IN_LOOP", "0")
+    # (... and the one-workgroup sweep behind k_spd_prep sums ||Qs||_F from the prepared blocks: the same last-bit matter)
+    monkeypatch.setenv("LQP_PREP_ONE", "0")
     for split in ("1", "0"):
         monkeypatch.setenv("LQP_SPD_SPLIT", split)
         for rho in (None, 100.0):
