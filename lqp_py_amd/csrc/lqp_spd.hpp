@@ -2718,13 +2718,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
             __syncthreads();
         }
         int gchain = 0, gstage = 0;                          // running targets of the two group syncs
-        // (debug: cycles of wave 0 -- Y | updates | waits before the chain | chain | closing barrier -- and of wave 4 --
-        //  updates | waits + staging | closing barrier)
-        unsigned long long dbt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt0 = 0;
-        const bool stamp = dbg != nullptr && lane == 0 && (w == 0 || w == 4);
-#define RS4_STAMP(slot) do { if (stamp) { const unsigned long long t_ = clock64(); dbt[slot] += t_ - dt0; dt0 = t_; } } while (0)
         for (int k = 0; k < K; ++k) {
-            if (stamp) dt0 = clock64();
             // (lane parts of every LDS address of this step, opaque: as loop invariants of the step loop they would be
             //  formed once, held in registers -- one per distinct address -- and spilled with the tiles)
             int li_s = li, lh_s = lh;
@@ -2749,7 +2743,6 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                 }
             }
             __syncthreads();
-            RS4_STAMP(0);
             const bool more = k + 1 < K;
             if constexpr (PIVOT) { if (more) __builtin_amdgcn_s_setprio(2); }      // the chain waves should reach the chain first
             const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
@@ -2812,7 +2805,6 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
             if constexpr (PIVOT) {
                 if (lane == 0) __hip_atomic_fetch_add(sy + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            RS4_STAMP(PIVOT ? 1 : 5);
             if (more) {
                 if constexpr (PIVOT) {
                     __builtin_amdgcn_s_setprio(0);
@@ -2825,7 +2817,6 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                     lds_wait_ge_bounded(sy + 5, k + 1, status_timeout);                   // the partner's tiles of step k+1 ...
                     lds_wait_ge_bounded(sy + 3, RS_NW * (k + 1), status_timeout);         // ... and this workgroup's own have left
                     lds_wait_ge_bounded(sy + 1, RS_NW * (k + 1), status_timeout);         // W_k, W_k^T are dead
-                    RS4_STAMP(2);
                     {
                         int tid_s = tid;
                         asm volatile("" : "+v"(tid_s));
@@ -2840,7 +2831,6 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                     lds_group_sync<true>(sy + 0, gchain += 4);
                     wg_pivot_block_mfma<true, true, true>(nullptr, W, WT, pcol, flag, (k + 1) * 64, sy + 6, k);
                     lds_group_sync<true>(sy + 0, gchain += 4);
-                    RS4_STAMP(3);
                     if (CHAIN_FIRST) rest();
                 } else {
                     // ---- panel of step k+1 into the Y area once nobody reads Y_k any more ----
@@ -2849,17 +2839,11 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                     lds_wait_ge_bounded(sy + 2, RS_NW * (k + 1), status_timeout);         // nobody reads the panel Y_k any more
                     stage_panel(k + 1);
                     (void)gstage;
-                    RS4_STAMP(6);
                 }
             }
             __syncthreads();
-            RS4_STAMP(PIVOT ? 4 : 7);
         }
-#undef RS4_STAMP
-        if (stamp) {
-            if (w == 0) for (int q = 0; q < 5; ++q) dbg[q] = dbt[q];
-            else for (int q = 5; q < 8; ++q) dbg[q] = dbt[q];
-        }
+        (void)dbg;
         // ---- the finished tiles to their home blocks ----
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
