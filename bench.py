@@ -249,8 +249,9 @@ def main():
     #      step; the other nine are what a step on never-seen tensors costs (config.first_use_ms_per_step).  Nothing about
     #      a tensor is remembered between calls: whether any bound is finite (reference :33-38, a host decision there) is
     #      found by the setup kernel from the data of every call. ----
-    step(0)
-    sync()
+    for _ in range(5):                    # (batch 0 alone: clocks, allocator and the pinned report pool of a fresh process --
+        step(0)                           #  tools/gpu_first_use.py: with ONE such step the nine first-use steps below are 6 %
+    sync()                                #  slower than the steady state, with five they equal it)
     t_first = time.perf_counter()
     for i in range(1, len(data)):
         step(i)
@@ -385,7 +386,7 @@ def main():
                       "global_batch": B_total, "shard_sizes": shard_sizes,
                       "seeds": f"{len(data)} batches, seeds 0..{len(data) - 1}" + (" (one batch, cut)" if args.strong else " per rank") + ", cycled",
                       "first_use_ms_per_step": round(first_use_ms, 4),
-                      "first_use": "mean step time over batches 2..10 on their first pass through the layer (nothing is cached per tensor: the bound flags of :33-38 are found on the device in every call)",
+                      "first_use": "mean step time over batches 2..10 on their FIRST pass through the layer, after five warm-up steps on batch 1 alone (nothing is cached per tensor: the bound flags of :33-38 are found on the device in every call)",
                       "iters": iters, "checks": st_timed["n_check"], "launch_mode": st_timed["mode_used"],
                       "stats_source": "device status block of the last timed forward",
                       "sync": bool(args.sync), "linsolve": {1: "lu", 2: "spd"}[ls],
