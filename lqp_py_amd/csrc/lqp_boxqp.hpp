@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
     const T rho = scal[SC_RHO];
     const T pnorm = scal[SC_PNORM];
     const int S = SYM ? sym_blocks(P.Ks) : K * (K + 1);
-    const bool cyclic = (S % LQP_PF) == 0;
+    const bool cyclic = true;                 // (wg_packed_solve pads the stream to a multiple of the ring depth)
 
     BlockStream<T, NT> st;
     ResidentRegs<T, NT> rr;
@@ -2511,7 +2511,7 @@ __global__ __launch_bounds__(LQP_NT) void k_packed_solve(const T* __restrict__ p
     int* dest = (int*)(tmp + 64);
     const T* packed = packed_all + (size_t)b * packed_blocks(Kmax) * LQP_BLK;
     const int S = K * (K + 1);
-    const bool cyclic = (S % LQP_PF) == 0;
+    const bool cyclic = true;                 // (wg_packed_solve pads the stream to a multiple of the ring depth)
     BlockStream<T, LQP_NT> st;
     stream_prime(st, packed, S);
     for (int i = tid; i < Np; i += LQP_NT) dest[i] = dest_all[(size_t)b * Npmax + i];

@@ -23,6 +23,10 @@ namespace lqp {
 #ifndef LQP_PF
 #define LQP_PF 8   // blocks in flight per thread (f32: 128 KB per workgroup)
 #endif
+#ifndef LQP_PF64
+#define LQP_PF64 6 // ... of the float64 stream (8 x 8 registers next to the solve's own spilled 39 of the loop kernel's 128)
+#endif
+template <typename T> __host__ __device__ constexpr int ring_pf() { return sizeof(T) == 8 ? LQP_PF64 : LQP_PF; }
 
 __host__ __device__ inline size_t packed_blocks(int K) { return (size_t)K * (K + 1); }
 
@@ -167,7 +171,7 @@ template <typename T, int NT> struct Frag {
     V4<T> q[NV];
 };
 template <typename T, int NT> struct BlockStream {
-    Frag<T, NT> buf[LQP_PF];
+    Frag<T, NT> buf[ring_pf<T>()];
 };
 
 // (uniform block base + 32-bit per-thread byte offset: the load takes its base from SGPRs)
@@ -215,7 +219,7 @@ template <int NT, typename T> __device__ __forceinline__ T rowgroup_sum(T v) {
 template <typename T, int NT = LQP_NT>
 __device__ __forceinline__ void stream_prime(BlockStream<T, NT>& st, const T* __restrict__ packed, const int S) {
 #pragma unroll
-    for (int i = 0; i < LQP_PF; ++i)                 // (slots past the end get block 0 again: never used)
+    for (int i = 0; i < ring_pf<T>(); ++i)                 // (slots past the end get block 0 again: never used)
         st.buf[i] = frag_load<T, NT>(packed + (size_t)(i < S ? i : 0) * LQP_BLK);
 }
 
@@ -334,16 +338,21 @@ template <typename T, int NT = LQP_NT>
 __device__ __forceinline__ void wg_packed_solve(BlockStream<T, NT>& st, const T* __restrict__ packed, const int K,
                                                 T* __restrict__ v, T* __restrict__ tmp, const bool cyclic) {
     const int S = K * (K + 1);
+    // virtual stream length: a multiple of the ring depth, so that ANY factor can be walked cyclically (round 4: the ring used
+    // to wrap only when S % LQP_PF == 0 -- K = 8 -- and was drained and re-primed before every solve otherwise, e.g. K = 5:
+    // the float64 hard distribution); padding steps re-load block 0 and drop it
+    constexpr int PF = ring_pf<T>();
+    const int Sv = round_up(S, PF);
     SolveWalk<T> wk;
     wk.phase = 0; wk.k = 0; wk.j = 0; wk.acc = T(0);
-    for (int s0 = 0; s0 < S; s0 += LQP_PF) {
+    for (int s0 = 0; s0 < Sv; s0 += PF) {
 #pragma unroll
-        for (int i = 0; i < LQP_PF; ++i) {
+        for (int i = 0; i < PF; ++i) {
             const int s = s0 + i;
             // one unconditional refill per step (exact vmcnt, see above); past the end it re-loads block 0
             const Frag<T, NT> blk = st.buf[i];
-            int nx = s + LQP_PF;
-            if (nx >= S && cyclic) nx -= S;
+            int nx = s + PF;
+            if (nx >= Sv && cyclic) nx -= Sv;
             st.buf[i] = frag_load<T, NT>(packed + (size_t)(nx < S ? nx : 0) * LQP_BLK);
             if (s < S) solve_block<T, NT>(wk, blk, K, v, tmp);
         }
