@@ -198,7 +198,7 @@ int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, in
         if (pb == 16) { if (mfma) LQP_LU_CASE(16, true, 512); LQP_LU_CASE(16, false, 512); }
         LQP_LU_CASE(8, false, 512);
     }
-    if (pb == 32) { if (mfma) LQP_LU_CASE(32, true, 1024); LQP_LU_CASE(32, false, 1024); }
+    if (pb == 32) LQP_LU_CASE(32, true, 1024);        // (no scalar-update flavour: 1829 spilled registers)
     if (pb == 16) { if (mfma) LQP_LU_CASE(16, true, 1024); LQP_LU_CASE(16, false, 1024); }
     LQP_LU_CASE(8, false, 1024);
 #undef LQP_LU_CASE

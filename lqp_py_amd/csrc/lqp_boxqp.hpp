@@ -292,7 +292,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             nred = 1;
         } else if (qvec) {
             // (several workgroups per QP for this pass: no faster -- 128 MB in 38 us either way, the HBM rate)
-            setup_colmax<T, 4, 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster)
+            setup_colmax<T, 4, sizeof(T) == 8 ? 1 : 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster; float64: 4 rows in flight = 128 VGPRs of loads, 315 spilled registers)
         } else {
             // (also the HBM-resident tier, 1024 < n <= 2048: two passes of 1024 columns, the 16 waves merging their maxima
             //  into setup_slabs(n) = 4 slabs in 4 rounds; up to 1024 columns: one pass, one slab per wave, no round trip)
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             // nothing to store here and the norm (when rho is derived from it) is taken by k_spd_begin / the resident
             // sweep: no second pass over Q
         } else if (qvec) {
-            fro2 += setup_scale<T, 4, 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
+            fro2 += setup_scale<T, 4, sizeof(T) == 8 ? 1 : 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
         } else {
             for (int i = w; i < n; i += LQP_NW) {
                 const T* qr = Q + (size_t)i * n;
