@@ -443,7 +443,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         // its workgroups per matrix wait for each other inside the launch: every one of them must be resident -- ask the
         // occupancy calculator for THIS kernel (block size, registers, LDS), not just the CU count
         int dev_ = 0, cus_ = 0, per_cu = 0;
-        const int rlds = rs4_lds_bytes(P.Ks);      // (the look-ahead sweep's counters behind the flags)
+        const int rlds = rs_q_lds_bytes(P.Ks);     // (the look-ahead sweep's counters behind the flags, the scaling vector behind them)
         bool ok = false;
 #if LQP_PIV_MFMA && (LQP_RS_V2 == 2 || LQP_RS_V2 == 4)
         if (P.Ks >= 7 && current_device_cus(&dev_, &cus_) && 4 * B <= cus_ && env_int("LQP_SPD_RESIDENT4", 1) != 0) {
@@ -477,8 +477,12 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             P.prep_fused = 2;
     }
 #endif
+#if LQP_PIV_MFMA && LQP_RS_V2 == 2
+    // ... or no pass in front at all: the resident sweep reads Q itself, straight into the registers that keep it
+    if (P.prep_fused == 1 && (size_t)n * P.ldq >= (size_t)rs_np * (64 * P.Ks + 2) && env_int("LQP_QPASS", 1)) P.prep_fused = 3;
+#endif
     if constexpr (sizeof(T) == 4) {
-        if (P.prep_fused) {
+        if (P.prep_fused == 1 || P.prep_fused == 2) {
             const int lds = (2 * 64 * SPD_LS + 2 * LQP_NW + 64 * P.Ks) * 4;
             const int r3 = ensure_lds((const void*)k_spd_prep<>, lds);
             if (r3) return r3;
@@ -531,7 +535,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                         hipLaunchKernelGGL(k_spd_begin<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
                     if (spd_resident) {
                         // all pivot steps in one launch, the matrix in the registers of its two workgroups
-                        const int rlds = rs4_lds_bytes(P.Ks);      // (the look-ahead sweep's counters behind the flags)
+                        const int rlds = rs_q_lds_bytes(P.Ks);
                         r3 = ensure_lds((const void*)rs_fn, rlds);
                         if (r3) return r3;
                         hipLaunchKernelGGL(rs_fn, dim3(B * rs_np), dim3(RS_NT), rlds, st, P, gate);

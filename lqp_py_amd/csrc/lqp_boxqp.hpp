@@ -44,7 +44,7 @@ template <typename T> struct FwdParams {
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
     int rho_late;                        // 1: rho = ||Qs||_F / sqrt(n) from the sums k_spd_begin leaves, added by k_spd_resident
-    int prep_fused;                      // 1 / 2: k_spd_prep ran BEFORE the setup kernel (2: one-workgroup tier, k_spd_inverse finishes the blocks) -- one pass over Q for the column maxima, the
+    int prep_fused;                      // 3: no k_spd_prep at all -- the resident sweep reads Q itself (maxima, verdict, tiles; k_fwd_setup defers what needs D to it); 1 / 2: k_spd_prep ran BEFORE the setup kernel (2: one-workgroup tier, k_spd_inverse finishes the blocks) -- one pass over Q for the column maxima, the
                                          //    symmetry verdict and the UNSCALED blocks; the resident sweep scales them as it loads
                                          //    them and takes ||Qs||_F (-> rho) from its own tiles
     int ar_iter, ar_max, ring;           // adaptive-rho schedule and counter-ring length, for the in-kernel events
@@ -242,6 +242,97 @@ __device__ __forceinline__ T setup_scale(const T* __restrict__ Q, const int n, c
 template <typename T>
 __device__ __forceinline__ T* prep_scratch(const FwdParams<T>& P, const int b) { return P.Qs + (size_t)b * P.n * P.ldq; }
 
+// The auto-scaling vector (reference :163-175) from the column maxima of |Q|: red[ww * n + j], ww < nred (LDS; reused as the
+// sort buffer) -> d[0..n) (LDS).  Zero guard, D = sqrt(1 / max), beta from the 10 % / 90 % quantiles of D, the blend with the
+// mean.  A workgroup of NT threads (k_fwd_setup: 1024; the resident sweep, which takes the maxima from its own pass over Q:
+// 512 -- for n <= 512 every thread holds the same element in both and the sums are taken in the same order: the same bits).
+// sel: 8 elements, scratch: >= NT / 64 (LDS).
+template <typename T, int NT>
+__device__ __forceinline__ void wg_scaling_vector(const FwdParams<T>& P, const int b, T* __restrict__ red, const int nred,
+                                                  T* __restrict__ d, T* __restrict__ sel, T* __restrict__ scratch) {
+    const int tid = threadIdx.x, n = P.n;
+    T part = T(0);
+    for (int j = tid; j < n; j += NT) {
+        T v = red[j];
+        for (int ww = 1; ww < nred; ++ww) v = tmax(v, red[(size_t)ww * n + j]);
+        d[j] = v;
+        part += v;
+    }
+    // ---- zero guard (:164-168) ----
+    const T mean_norm = wg_sum_nw<NT / 64>(part, scratch) / T(n);
+    const T floor_v = tmax(mean_norm, T(1e-6));
+    part = T(0);
+    for (int j = tid; j < n; j += NT) {
+        T v = d[j];
+        if (v <= T(0)) v = tmax(v, floor_v);
+        v = tsqrt(T(1) / v);          // D = sqrt(1 / Q_norm) (:170)
+        d[j] = v;
+        part += v;
+    }
+    const T dmean = wg_sum_nw<NT / 64>(part, scratch) / T(n);     // also makes d[] visible
+    // ---- beta = 1 - q10(D) / q90(D), linear-interpolated quantiles (:171-174) ----
+    T beta = P.beta_mode == 2 ? P.beta_in[b] : P.beta_value;
+    if (P.beta_mode == 0) {
+        const T pos0 = T(0.10) * T(n - 1), pos1 = T(0.90) * T(n - 1);
+        const int lo0 = (int)tfloor(pos0), hi0 = (int)tceil(pos0);
+        const int lo1 = (int)tfloor(pos1), hi1 = (int)tceil(pos1);
+        // the four order statistics behind the two quantiles: bitonic sort of D, padded with +inf to a power of two.
+        // One element per thread while that fits: partners closer than 64 are reached by a wave shuffle, only the
+        // far ones (6 of the 45 rounds at n = 500) go through LDS and a barrier.  (Counting every element's rank
+        // costs n^2 comparisons: 10 us at n = 500 even over all 1024 threads; every round through LDS: 12 us.)
+        T* sb = red;                                      // the column maxima are no longer needed
+        int N2 = 1;
+        while (N2 < n) N2 <<= 1;
+        __syncthreads();
+        if (N2 <= NT) {
+            T v = tid < n ? d[tid] : T(INFINITY);
+            for (int k = 2; k <= N2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    T other;
+                    if (j >= 64) {
+                        if (tid < N2) sb[tid] = v;
+                        __syncthreads();
+                        other = tid < N2 ? sb[tid ^ j] : v;
+                        __syncthreads();
+                    } else {
+                        other = __shfl_xor(v, j);
+                    }
+                    const bool keep_min = ((tid & j) == 0) == ((tid & k) == 0);
+                    v = keep_min ? tmin(v, other) : tmax(v, other);
+                }
+            }
+            if (tid < N2) sb[tid] = v;
+            __syncthreads();
+        } else {
+            for (int i = tid; i < N2; i += NT) sb[i] = i < n ? d[i] : T(INFINITY);
+            __syncthreads();
+            for (int k = 2; k <= N2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (N2 >> 1); t += NT) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                        const T x0 = sb[i], x1 = sb[l];
+                        if ((x0 > x1) == ((i & k) == 0)) { sb[i] = x1; sb[l] = x0; }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (tid == 0) { sel[0] = sb[lo0]; sel[1] = sb[hi0]; sel[2] = sb[lo1]; sel[3] = sb[hi1]; }
+        __syncthreads();
+        const T w0 = pos0 - tfloor(pos0), w1 = pos1 - tfloor(pos1);
+        // torch lerp: w < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
+        const T q10 = (w0 < T(0.5)) ? sel[0] + w0 * (sel[1] - sel[0]) : sel[1] - (sel[1] - sel[0]) * (T(1) - w0);
+        const T q90 = (w1 < T(0.5)) ? sel[2] + w1 * (sel[3] - sel[2]) : sel[3] - (sel[3] - sel[2]) * (T(1) - w1);
+        beta = T(1) - q10 / q90;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += NT) {
+        const T v = (T(1) - beta) * d[j] + beta * dmean;     // (:175)
+        d[j] = v;
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -279,7 +370,12 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     int ldq = n;
     T fro2 = T(0);
     bool q_in_m = false;          // top-left KKT block already written by the scaling pass
-    if (P.scale) {
+    // prep_fused == 3: the resident sweep makes the pass over Q itself (column maxima, symmetry verdict, tiles straight into
+    // its registers) and with it everything that needs D: the vector, ps, As / E / bs, lbs / ubs (wg_deferred_*).  What is
+    // left here: the zeroes, ||p||_inf, a given rho, the bound flags.
+    const bool defer = P.prep_fused == 3;
+    if (defer) {
+    } else if (P.scale) {
         // ---- column max of |Q| (:163): wave w sweeps rows w, w+16, ...; 16 B per lane per load ----
         const bool qvec = (n % 4 == 0) && n <= 1024 && ((((uintptr_t)Q) % sizeof(V4<T>)) == 0);
         int nred = LQP_NW;
@@ -326,88 +422,9 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         }
         __syncthreads();
         SETUP_STAMP(1);
-        T part = T(0);
-        for (int j = tid; j < n; j += LQP_NT) {
-            T v = red[j];
-            for (int ww = 1; ww < nred; ++ww) v = tmax(v, red[(size_t)ww * n + j]);
-            d[j] = v;
-            part += v;
-        }
-        // ---- zero guard (:164-168) ----
-        const T mean_norm = wg_sum(part, scratch) / T(n);
-        const T floor_v = tmax(mean_norm, T(1e-6));
-        part = T(0);
-        for (int j = tid; j < n; j += LQP_NT) {
-            T v = d[j];
-            if (v <= T(0)) v = tmax(v, floor_v);
-            v = tsqrt(T(1) / v);          // D = sqrt(1 / Q_norm) (:170)
-            d[j] = v;
-            part += v;
-        }
-        const T dmean = wg_sum(part, scratch) / T(n);     // also makes d[] visible
+        wg_scaling_vector<T, LQP_NT>(P, b, red, nred, d, sel, scratch);
         SETUP_STAMP(2);
-        // ---- beta = 1 - q10(D) / q90(D), linear-interpolated quantiles (:171-174) ----
-        T beta = P.beta_mode == 2 ? P.beta_in[b] : P.beta_value;
-        if (P.beta_mode == 0) {
-            const T pos0 = T(0.10) * T(n - 1), pos1 = T(0.90) * T(n - 1);
-            const int lo0 = (int)tfloor(pos0), hi0 = (int)tceil(pos0);
-            const int lo1 = (int)tfloor(pos1), hi1 = (int)tceil(pos1);
-            // the four order statistics behind the two quantiles: bitonic sort of D, padded with +inf to a power of two.
-            // One element per thread while that fits: partners closer than 64 are reached by a wave shuffle, only the
-            // far ones (6 of the 45 rounds at n = 500) go through LDS and a barrier.  (Counting every element's rank
-            // costs n^2 comparisons: 10 us at n = 500 even over all 1024 threads; every round through LDS: 12 us.)
-            T* sb = red;                                      // the column maxima are no longer needed
-            int N2 = 1;
-            while (N2 < n) N2 <<= 1;
-            __syncthreads();
-            if (N2 <= LQP_NT) {
-                T v = tid < n ? d[tid] : T(INFINITY);
-                for (int k = 2; k <= N2; k <<= 1) {
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        T other;
-                        if (j >= 64) {
-                            if (tid < N2) sb[tid] = v;
-                            __syncthreads();
-                            other = tid < N2 ? sb[tid ^ j] : v;
-                            __syncthreads();
-                        } else {
-                            other = __shfl_xor(v, j);
-                        }
-                        const bool keep_min = ((tid & j) == 0) == ((tid & k) == 0);
-                        v = keep_min ? tmin(v, other) : tmax(v, other);
-                    }
-                }
-                if (tid < N2) sb[tid] = v;
-                __syncthreads();
-            } else {
-                for (int i = tid; i < N2; i += LQP_NT) sb[i] = i < n ? d[i] : T(INFINITY);
-                __syncthreads();
-                for (int k = 2; k <= N2; k <<= 1) {
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        for (int t = tid; t < (N2 >> 1); t += LQP_NT) {
-                            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                            const T x0 = sb[i], x1 = sb[l];
-                            if ((x0 > x1) == ((i & k) == 0)) { sb[i] = x1; sb[l] = x0; }
-                        }
-                        __syncthreads();
-                    }
-                }
-            }
-            if (tid == 0) { sel[0] = sb[lo0]; sel[1] = sb[hi0]; sel[2] = sb[lo1]; sel[3] = sb[hi1]; }
-            __syncthreads();
-            const T w0 = pos0 - tfloor(pos0), w1 = pos1 - tfloor(pos1);
-            // torch lerp: w < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
-            const T q10 = (w0 < T(0.5)) ? sel[0] + w0 * (sel[1] - sel[0]) : sel[1] - (sel[1] - sel[0]) * (T(1) - w0);
-            const T q90 = (w1 < T(0.5)) ? sel[2] + w1 * (sel[3] - sel[2]) : sel[3] - (sel[3] - sel[2]) * (T(1) - w1);
-            beta = T(1) - q10 / q90;
-        }
-        __syncthreads();
-        for (int j = tid; j < n; j += LQP_NT) {
-            const T v = (T(1) - beta) * d[j] + beta * dmean;     // (:175)
-            d[j] = v;
-            V.D[j] = v;
-        }
-        __syncthreads();
+        for (int j = tid; j < n; j += LQP_NT) V.D[j] = d[j];
         SETUP_STAMP(3);
         // ---- Qs = (D_i Q_ij) D_j, its Frobenius norm (:176, :201), and the top-left KKT block ----
         ldq = P.ldq;
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     if (tid == 0) { scal[SC_RHO] = rho; scal[SC_RATIO] = T(1); scal[SC_WANTS] = T(0); }
 
     // ---- equality block: A D, row normalisation E (:179-190) ----
-    if (m > 0) {
+    if (m > 0 && !defer) {
         const T* A = P.A + (size_t)b * m * n;
         const T* bb = P.b + (size_t)b * m;
         if (P.scale) {
@@ -514,9 +531,11 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         if (tid == 0) P.bflags[b] = (wg_lb ? RP_LB : 0) | (wg_ub ? RP_UB : 0);
     }
     for (int i = tid; i < n; i += LQP_NT) {
-        const T di = P.scale ? V.D[i] : T(1);                // (:192-194; +-inf / D stays +-inf)
-        V.lbs[i] = (i == tid ? lb0 : lb[i]) / di;
-        V.ubs[i] = (i == tid ? ub0 : ub[i]) / di;
+        if (!defer) {
+            const T di = P.scale ? V.D[i] : T(1);                // (:192-194; +-inf / D stays +-inf)
+            V.lbs[i] = (i == tid ? lb0 : lb[i]) / di;
+            V.ubs[i] = (i == tid ? ub0 : ub[i]) / di;
+        }
         V.z[i] = T(0); V.u[i] = T(0); V.x[i] = T(0);
     }
     for (int r = tid; r < m; r += LQP_NT) V.nu[r] = T(0);
@@ -923,6 +942,76 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_big_step(const FwdParams<float> 
     const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
     wg_spd_sweep_big<SPD_NP>(spd_half(P, b, 0), P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np, k, k + 1, phases, part);
 }
+// ---- what k_fwd_setup leaves to the resident sweep under prep_fused == 3 (the same operations on the same values as
+//      there: the same bits).  d: the scaling vector in LDS. ----
+// One wave each (they run beside the pivot block of the sweep's first step).
+__device__ __forceinline__ void wave_deferred_vectors(const FwdParams<float>& P, const int b, const float* __restrict__ d) {
+    const int n = P.n, lane = threadIdx.x & 63;
+    VecView<float> V(P.vecs + (size_t)b * P.vstride, n, P.m);
+    const float* p = P.p + (size_t)b * n;
+    const float* lb = P.lb + (size_t)b * n;
+    const float* ub = P.ub + (size_t)b * n;
+    for (int i0 = 0; i0 < n; i0 += 256) {               // (twelve requests in flight)
+        float pv[4], lv[4], uv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane, ic = i < n ? i : n - 1;
+            pv[u] = p[ic]; lv[u] = lb[ic]; uv[u] = ub[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane;
+            if (i < n) {
+                const float di = d[i];
+                V.D[i] = di;
+                V.ps[i] = di * pv[u];                // (:177)
+                V.lbs[i] = lv[u] / di;               // (:192-194; +-inf / D stays +-inf)
+                V.ubs[i] = uv[u] / di;
+            }
+        }
+    }
+}
+// equality block: A D, row normalisation E (:179-190)
+__device__ __forceinline__ void wave_deferred_eq_rows(const FwdParams<float>& P, const int b, const float* __restrict__ d) {
+    const int n = P.n, m = P.m, lane = threadIdx.x & 63;
+    if (m <= 0) return;
+    VecView<float> V(P.vecs + (size_t)b * P.vstride, n, m);
+    const float* A = P.A + (size_t)b * m * n;
+    const float* bb = P.b + (size_t)b * m;
+    float esum = 0.f, mine = 0.f;                           // lane r keeps the norm of row r (m <= SPD_MAXM <= 64)
+    for (int r = 0; r < m; ++r) {
+        float am = 0.f;
+        for (int j = lane; j < n; j += 64) {
+            const float v = A[(size_t)r * n + j] * d[j];
+            V.As[(size_t)r * n + j] = v;
+            am = tmax(am, tabs(v));
+        }
+        am = wave_max(am);
+        if (lane == r) mine = am;
+        esum += am;
+    }
+    const float floor_a = tmax(esum / (float)m, 1e-6f);
+    for (int r = 0; r < m; ++r) {
+        float an = __shfl(mine, r);
+        if (an <= 0.f) an = tmax(an, floor_a);
+        const float e = 1.f / an;
+        for (int j = lane; j < n; j += 64) V.As[(size_t)r * n + j] = e * V.As[(size_t)r * n + j];      // (this lane's own stores)
+        if (lane == 0) { V.E[r] = e; V.bs[r] = e * bb[r]; }
+    }
+}
+// the hooks of wg_spd_sweep_resident_v2 (RsNoScaling)
+struct RsSetupHooks {
+    const FwdParams<float>& P;
+    int b, part, np;
+    __device__ __forceinline__ void scaling(float* red, float* d, float* work) const {
+        wg_scaling_vector<float, RS_NT>(P, b, red, 1, d, work, work + 8);
+    }
+    __device__ __forceinline__ void deferred(const float* d) const {
+        if (part == 0) wave_deferred_vectors(P, b, d);
+        if (part == np - 1) wave_deferred_eq_rows(P, b, d);
+    }
+};
+
 // all pivot steps in ONE launch, the matrix resident in the registers of its two workgroups (lqp_spd.hpp).  Reads the
 // blocks k_spd_begin built (half Ks & 1 of the packed area), leaves -(Qs + rho I)^-1 in half 0, where the loop reads it.
 // Exchange buffer: the (unused on this path) KKT-matrix area; step flags: behind the loop's exchange granules.
@@ -935,13 +1024,17 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
     RsLateRho lr;
     const bool fused = gate == nullptr && P.prep_fused;     // unscaled blocks from k_spd_prep (first factorisation only)
+    const bool qpass = fused && P.prep_fused == 3;          // ... or no blocks at all: the sweep reads Q itself
     lr.on = (gate == nullptr && P.rho_late && !fused) ? 1 : 0;
     lr.n = P.n; lr.rho_min = P.rho_min; lr.rho_max = P.rho_max;
     lr.rho_out = part == 0 ? P.scal + (size_t)b * SC_WORDS + SC_RHO : nullptr;
-    lr.dsc = fused ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
+    lr.dsc = (fused && !qpass) ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
+    lr.q = qpass ? P.Q + (size_t)b * P.n * P.n : nullptr;
+    lr.cmx = qpass ? prep_scratch(P, b) : nullptr;
     lr.fro_self = (fused && P.rho_mode == 0) ? 1 : 0;
     lr.rho_given = (fused && P.rho_mode != 0) ? P.scal[(size_t)b * SC_WORDS + SC_RHO] : 0.f;
     lr.xcd_local = P.xcd_local;
+    const RsSetupHooks hooks{P, b, part, NP};
 #if LQP_PIV_MFMA && LQP_RS_V2 == 3
     wg_spd_sweep_resident_v3<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
@@ -958,7 +1051,7 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
 #elif LQP_PIV_MFMA && LQP_RS_V2
     wg_spd_sweep_resident_v2<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
-                                 (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
+                                 (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr, hooks);
 #else
     wg_spd_sweep_resident<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                               P.info + b, P.status + ST_TIMEOUT, smem, lr, -1,

@@ -88,6 +88,30 @@ template <typename T> __device__ __forceinline__ T wg_sum(T v, T* scratch) {
     for (int i = 0; i < LQP_NW; ++i) r += scratch[i];
     return r;
 }
+// the same for a workgroup of NW waves (scratch >= NW elements).  The partial sums are added in wave order, as wg_sum adds
+// them: when the waves beyond NW of a 1024-thread workgroup hold zeros, both give the same bits.
+template <int NW, typename T> __device__ __forceinline__ T wg_sum_nw(T v, T* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T r = T(0);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += scratch[i];
+    return r;
+}
+template <int NW, typename T> __device__ __forceinline__ T wg_max_nw(T v, T* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = tmax(r, scratch[i]);
+    return r;
+}
 template <typename T> __device__ __forceinline__ T wg_max(T v, T* scratch) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     v = wave_max(v);

@@ -344,12 +344,36 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
 }
 // the same product with the lane parts of the operand addresses made by the caller: xa = X + (l&31) * SPD_LS + kb,
 // zb = Z + (l&31) * SPD_LS + kb, kb = 32 (l>>5) for the full k range, 16 (l>>5) [+ 32: upper half] with HALF
+// The operands of group t + 1 are requested BEFORE the four matrix instructions of group t (LQP_QUAD_PF, 8 more registers):
+// as the compiler emits the plain loop -- four instructions, two LDS reads into the same registers, wait, four instructions --
+// a wave that is alone on its SIMD stands through one LDS latency per group (measured: one matrix instruction per ~135
+// cycles instead of 64; two waves per SIMD hide it for each other).  Same products in the same order.
+#ifndef LQP_QUAD_PF
+#define LQP_QUAD_PF 1
+#endif
 template <int HALF = 0>
 __device__ __forceinline__ f32x16 spd_quadrant_lp(const float* __restrict__ xa, const float* __restrict__ zb) {
     constexpr int KL = HALF ? 16 : 32;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#if LQP_QUAD_PF
+    V4<float> a = *(const V4<float>*)xa, b = *(const V4<float>*)zb;
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int t = 0; t < KL / 4; ++t) {
+        V4<float> an = a, bn = b;
+        if (t + 1 < KL / 4) {
+            an = *(const V4<float>*)(xa + 4 * (t + 1));
+            bn = *(const V4<float>*)(zb + 4 * (t + 1));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two LDS reads first ...
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[e], b.v[e], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);          // ... then this group's four matrix instructions
+        a = an; b = bn;
+    }
+#else
 #pragma unroll
     for (int t = 0; t < KL / 4; ++t) {
         const V4<float> a = *(const V4<float>*)(xa + 4 * t);
@@ -357,6 +381,7 @@ __device__ __forceinline__ f32x16 spd_quadrant_lp(const float* __restrict__ xa, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[e], b.v[e], acc, 0, 0, 0);
     }
+#endif
     return acc;
 }
 // accumulator register q of lane l is element (row = (q&3) + 8 (q>>2) + 4 (l>>5), col = l&31) of the quadrant
@@ -1893,6 +1918,16 @@ struct RsLateRho {
                               //    workgroups swap their halves with the step-0 flags); 0 (with dsc): rho_given is added
     float rho_given;
     int xcd_local;            // 1: workgroups that find themselves on ONE XCD exchange through its L2 (workgroup-scope stores)
+    // wg_spd_sweep_resident_v2 only -- the sweep makes the pass over the UNSCALED matrix itself (FwdParams::prep_fused == 3):
+    const float* q;           // Q of this problem (n x n, row-major); nullptr: off
+    float* cmx;               // global scratch of this problem: [NP][64 K + 2] words (column maxima | asymmetry | magnitude)
+};
+// (the scaling vector from the column maxima: supplied by the kernel, which knows the problem's parameters)
+//  scaling(red, d, work): every thread of the workgroup; red: n column maxima, d: n values out, work: 8 + RS_NW floats (LDS)
+//  deferred(d): ONE wave, while the pivot block of step 0 is eliminated -- what the setup kernel left undone for want of d
+struct RsNoScaling {
+    __device__ __forceinline__ void scaling(float*, float*, float*) const {}
+    __device__ __forceinline__ void deferred(const float*) const {}
 };
 template <int K>
 // (Hsrc and Hdst may be the same buffer -- even K: the blocks are all loaded before the first store, barriers in between)
@@ -2105,13 +2140,14 @@ __device__ __forceinline__ void rs2_tile_of(int l, const int K, const int part, 
 // NP = 4 (batches up to a quarter of the CUs, K >= 7): four workgroups share a matrix, one column pair each (9 tiles at
 // K = 8: 4 + 5 per wave pair); every one of them still eliminates the pivot block and computes Y for itself -- what is
 // divided is the tile updates.  Step flags: one 64-bit granule per workgroup, a workgroup waits for all the others.
-template <int K, int NP = 2>
+template <int K, int NP = 2, class DFn = RsNoScaling>
 __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, float* Hdst,
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
                                                          int* __restrict__ status_timeout, char* smem,
                                                          const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
-                                                         unsigned long long* __restrict__ dbg = nullptr) {
+                                                         unsigned long long* __restrict__ dbg = nullptr,
+                                                         const DFn hooks = DFn{}) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
@@ -2121,7 +2157,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
     float* WT = W + 64 * SPD_LS;
     float* pcol = WT + 64 * SPD_LS;
     int* flag = (int*)(pcol + PIV_LDS);
-    if (tid == 0) flag[0] = 0;
+    float* const dkeep = (float*)(flag + 20);               // [64 K] the scaling vector of the sweep's own pass over Q (rs_q_lds_bytes)
+    if (tid == 0) { flag[0] = 0; flag[2] = 0; }
     // unscaled blocks (k_spd_prep): the scaling vector, 1 on the padding, in LDS while the tiles are loaded (the Y area
     // is not written before the staging of step 0, two barriers away)
     float* const Dl = Y;
@@ -2136,7 +2173,27 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
     // workgroup scope -- they stay in that L2 instead of being written through to memory and fetched back from there
     // (131 MB per sweep of the batch) -- and read as before behind the acquire.  Never assumed: asked at every launch.
     const unsigned int xcd_me = (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
-    if (tid == 0) __hip_atomic_store(fl64 + 4 + part, ((unsigned long long)(epoch + 1u) << 8) | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (with the pass over Q inside: announced BEHIND the column maxima, whose arrival it then signals as well)
+    if (tid == 0 && !lr.q) __hip_atomic_store(fl64 + 4 + part, ((unsigned long long)(epoch + 1u) << 8) | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // thread 0: wait for the announcements of the other workgroups of this matrix -> are all of them on this XCD?
+    auto partners_on_my_xcd = [&](const bool wait_for_all) -> int {
+        int same = 1;
+        for (int q = 0; q < NP && (same || wait_for_all); ++q) {
+            if (q == part) continue;
+            unsigned long long g = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (((g = __hip_atomic_load(fl64 + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned long long)(epoch + 1u)) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // (1 s: give up, results are flagged)
+                    g = ~0ull;
+                    if (wait_for_all) __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            same = same && (unsigned int)(g & 0xFFull) == xcd_me;
+        }
+        return same;
+    };
 
     auto body = [&](auto pivot_tag) {
         constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
@@ -2151,7 +2208,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             rs2_tile_of(l < nloc ? l : 0, K, part, NP, a, b);
             ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
             tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
-            if (ti[s] >= 0) {
+            if (ti[s] >= 0 && !lr.q) {
                 const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
                 if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
                     // upper-right quadrant of a diagonal tile := transpose of its lower-left one (see wg_spd_sweep_resident)
@@ -2164,9 +2221,151 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 }
             }
         }
-        if (lr.dsc) {
+        if (lr.q) {
+            // ---- the pass over Q inside the sweep: this wave's quadrants straight into their registers, and with them the
+            //      mirror quadrants (Q is read once per solve, by the workgroups that keep it) for the column maxima of |Q|
+            //      (what the auto-scaling starts from, reference :163) and the symmetry verdict of wg_sym_prep.  The
+            //      workgroups of the matrix swap their maxima through global scratch; every one of them then forms the
+            //      scaling vector for itself (make_d: the same bits as k_fwd_setup).  LDS: the Y area, free until step 0. ----
+            const int n = lr.n;
+            const float* __restrict__ Qm = lr.q;
+            const unsigned long long qt0 = dbg ? clock64() : 0ull;
+            unsigned int* cm = (unsigned int*)(Y + 64 * K);       // [64 K] column maxima as bit patterns (non-negative floats order like integers)
+            float* redm = Y + 2 * 64 * K;                          // [512] the combined maxima, then the sort buffer of make_d (n padded to a power of two)
+            float* redw = redm + 512;                              // [2 RS_NW] asymmetry / magnitude per wave
+            float* work = redw + 2 * RS_NW;                        // [8 + RS_NW] make_d
+            float* trw = work + 8 + RS_NW + 8 + w * (32 * 33);     // this wave's 32 x 33 transposition tile
+            for (int i = tid; i < 64 * K; i += RS_NT) cm[i] = 0u;
+            // Quadrant (a, b) of tile (i, j) in the accumulator layout.  Requests only: the addresses are clamped to the matrix
+            // and what lies outside is zeroed where the values are first used (mask_quadrant) -- a select behind every load
+            // made the compiler wait for each quadrant before it asked for the next: 20 memory latencies, 112 us.
+            auto load_quadrant = [&](f32x16& dst, const int i, const int j, const int a, const int b) {
+                const int r0 = i * 64 + 32 * a, col = j * 64 + 32 * b + li;
+                const float* __restrict__ base = Qm + (col < n ? col : n - 1);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = r0 + quad_row(q, lh);
+                    dst[q] = base[(row < n ? row : n - 1) * n];
+                }
+            };
+            auto mask_quadrant = [&](f32x16& dst, const int i, const int j, const int a, const int b) {
+                if (i * 64 + 32 * a + 32 <= n && j * 64 + 32 * b + 32 <= n) return;       // (uniform: inside)
+                const int r0 = i * 64 + 32 * a, col = j * 64 + 32 * b + li;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dst[q] = (r0 + quad_row(q, lh) < n && col < n) ? dst[q] : 0.f;
+            };
+            constexpr int MD = 3;                                   // mirrors requested ahead
+            f32x16 M[MD];
+#pragma unroll
+            for (int s = 0; s < MD && s < NS; ++s)
+                if (ti[s] >= 0) load_quadrant(M[s], tj[s], ti[s], qj, qi);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                // (the upper-right quadrant of a diagonal tile > 0 is held as the transpose of its lower-left one: it comes out
+                //  of the mirror below)
+                if (ti[s] >= 0 && !(ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1)) load_quadrant(T[s], ti[s], tj[s], qi, qj);
+            }
+            wg_barrier_lds();                                       // (cm is zero; the requests stay in flight)
+            float dmax = 0.f, vmax = 0.f;
+            auto col_max = [&](const f32x16& v, const int col0) {
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a = tmax(a, tabs(v[q]));
+                a = tmax(a, __shfl_xor(a, 32));
+                if (lh == 0) atomicMax(cm + col0 + li, __float_as_uint(a));
+            };
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ti[s] < 0) continue;
+                const bool held_as_mirror = ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1;
+                f32x16 Mc = M[s % MD];
+                if (s + MD < NS && ti[s + MD] >= 0) load_quadrant(M[s % MD], tj[s + MD], ti[s + MD], qj, qi);
+                mask_quadrant(Mc, tj[s], ti[s], qj, qi);
+                col_max(Mc, ti[s] * 64 + 32 * qi);
+                // transpose the mirror through LDS: Mt[q] = mirror(li, quad_row(q, lh))
+                f32x16 Mt;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) trw[quad_row(q, lh) * 33 + li] = Mc[q];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 16; ++q) Mt[q] = trw[li * 33 + quad_row(q, lh)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (held_as_mirror) {
+                    T[s] = Mt;
+                } else {
+                    mask_quadrant(T[s], ti[s], tj[s], qi, qj);
+                    col_max(T[s], tj[s] * 64 + 32 * qj);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        dmax = tmax(dmax, tabs(T[s][q] - Mt[q]));
+                        vmax = tmax(vmax, tmax(tabs(T[s][q]), tabs(Mt[q])));
+                    }
+                }
+                // identity on the padding
+                if (ti[s] == tj[s] && qi == qj) {
+                    int dqp = (ti[s] * 64 + 32 * qi + li >= n) ? li - 4 * lh : -1;
+                    asm volatile("" : "+v"(dqp));
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = (dqp == (q & 3) + 8 * (q >> 2)) ? 1.f : T[s][q];
+                }
+            }
+            if (dbg && tid == 0) dbg[7] = clock64() - qt0;         // (tiles + mirrors)
+            dmax = wave_max(dmax);
+            vmax = wave_max(vmax);
+            if (lane == 0) { redw[w] = dmax; redw[RS_NW + w] = vmax; }
+            __syncthreads();                                        // (cm, redw complete)
+            unsigned int* out = (unsigned int*)lr.cmx + (size_t)part * (64 * K + 2);
+            for (int i = tid; i < 64 * K; i += RS_NT) __hip_atomic_store(out + i, cm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                float a = 0.f, v = 0.f;
+                for (int ww = 0; ww < RS_NW; ++ww) { a = tmax(a, redw[ww]); v = tmax(v, redw[RS_NW + ww]); }
+                redw[0] = a; redw[RS_NW] = v;
+                __hip_atomic_store(out + 64 * K, __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(out + 64 * K + 1, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                        // (every store of this workgroup has been acknowledged)
+            if (tid == 0) {
+                __hip_atomic_store(fl64 + 4 + part, ((unsigned long long)(epoch + 1u) << 8) | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int same = partners_on_my_xcd(true);
+                flag[1] = same && lr.xcd_local;
+            }
+            __syncthreads();
+            // (the partners' words: agent-scope loads, past this CU's L1)
+            for (int i = tid; i < 64 * K; i += RS_NT) {
+                unsigned int v = cm[i];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (q == part) continue;
+                    const unsigned int o = __hip_atomic_load((const unsigned int*)lr.cmx + (size_t)q * (64 * K + 2) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = o > v ? o : v;
+                }
+                redm[i] = __uint_as_float(v);
+            }
+            if (tid == 0) {
+                float a = redw[0], v = redw[RS_NW];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (q == part) continue;
+                    const unsigned int* o = (const unsigned int*)lr.cmx + (size_t)q * (64 * K + 2) + 64 * K;
+                    a = tmax(a, __uint_as_float(__hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                    v = tmax(v, __uint_as_float(__hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                }
+                flag[2] = a > 1e-5f * v ? 1 : 0;                   // not symmetric (the rule of wg_sym_prep, over the whole matrix)
+            }
+            __syncthreads();
+            hooks.scaling(redm, Dl, work);                          // Dl[0 .. n): the scaling vector (every thread returns behind a barrier)
+            for (int i = n + tid; i < 64 * K; i += RS_NT) Dl[i] = 1.f;
+            for (int i = tid; i < n; i += RS_NT) dkeep[i] = Dl[i];  // (the Y area goes to the panel of step 0)
+            if (dbg && tid == 0) dbg[6] = clock64() - qt0;         // (... + exchange + scaling vector + deferred vectors)
+            if (flag[2]) {
+                if (tid == 0 && part == 0) *info = K * 64 + 2;      // the LU path takes it (status word: k_spd_end / the loop kernel)
+                return;
+            }
+        }
+        if (lr.dsc || lr.q) {
             // unscaled blocks (k_spd_prep): entry (r, c) is taken as (D_r * v) * D_c, what sym_scale4 computes
-            Dl[tid] = dmine;
+            if (lr.dsc) Dl[tid] = dmine;
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -2182,7 +2381,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 }
             }
         }
-        if (lr.dsc && lr.fro_self) {
+        if ((lr.dsc || lr.q) && lr.fro_self) {
             // this wave's share of ||Qs||_F^2: tiles below the diagonal count twice, a diagonal tile's four quadrants once
             // each (its upper-right one is held as the mirror of the lower-left one); the identity on the padding is left out
             // (lane-dependent compares against an opaque value, formed where they are used: as invariants of the step loop
@@ -2251,20 +2450,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 }
             }
         };
-        if (tid == 0) {
-            int same = lr.xcd_local;
-            for (int q = 0; q < NP && same; ++q) {
-                if (q == part) continue;
-                unsigned long long g = 0;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (((g = __hip_atomic_load(fl64 + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned long long)(epoch + 1u)) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) { g = ~0ull; break; }      // (1 s: the step flags below will flag it)
-                }
-                same = (unsigned int)(g & 0xFFull) == xcd_me;
-            }
-            flag[1] = same;
-        }
+        if (tid == 0 && !lr.q) flag[1] = lr.xcd_local ? partners_on_my_xcd(false) : 0;
         __syncthreads();
         const bool xlocal = flag[1] != 0;
         xlocal_p = xlocal;
@@ -2276,7 +2462,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             __syncthreads();                       // (also closes step k-1: every wave is done with the LDS panel)
             if (tid == 0) {
                 float fmine = 0.f;
-                if (k == 0 && lr.dsc && lr.fro_self)      // this workgroup's half of the norm travels in the step-0 granule
+                if (k == 0 && (lr.dsc || lr.q) && lr.fro_self)      // this workgroup's half of the norm travels in the step-0 granule
                     for (int ww = 0; ww < RS_NW; ++ww) fmine += WT[ww];
                 const unsigned long long gran = (unsigned long long)(epoch + (unsigned int)k + 1u) | ((unsigned long long)__float_as_uint(fmine) << 32);
                 if (xlocal) __hip_atomic_store(fl64 + part, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2299,7 +2485,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 }
                 // (no acquire fence: every load of the partner's tiles bypasses this CU's L1 -- ld16_handoff -- and the polls
                 //  above have matched before anybody loads, the barrier below in between)
-                if (k == 0 && lr.dsc && lr.fro_self) {
+                if (k == 0 && (lr.dsc || lr.q) && lr.fro_self) {
                     // rho = clamp(||Qs||_F / sqrt(n)) (reference :200-203), the same bits in both workgroups
                     float fsum = fparts[0];             // (summed in part order: the same bits in every workgroup)
 #pragma unroll
@@ -2312,7 +2498,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             }
             __syncthreads();
             float diag_add = 0.f;
-            if (k == 0 && lr.dsc) {
+            if (k == 0 && (lr.dsc || lr.q)) {
                 // rho on the diagonal: of the tiles in registers, and (diag_add) of the pivot tile as it is staged -- tile
                 // (0, 0) was published without it
                 diag_add = lr.fro_self ? WT[RS_NW] : lr.rho_given;
@@ -2357,6 +2543,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                         }
                     }
                 }
+                // (these waves now wait ~20 k cycles for the pivot block: room for the vectors the setup kernel left)
+                if (k == 0 && lr.q && w == RS_NW - 1) hooks.deferred(dkeep);
             }
             __syncthreads();
             if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
@@ -2451,6 +2639,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 // (1134 spilled registers: 0.405), six / twelve tiles per wave (524 spilled).  What it would take: the chain on waves that
 // hold no tiles at all -- 1024 threads per workgroup (four waves per SIMD, 72 quadrant slots over twelve tile waves).
 __host__ __device__ inline int rs4_lds_bytes(int K) { return spd_lds_bytes(K) + 64; }
+// ... + the scaling vector kept across step 0 when the sweep makes the pass over Q itself (wg_spd_sweep_resident_v2, RsLateRho::q)
+__host__ __device__ inline int rs_q_lds_bytes(int K) { return rs4_lds_bytes(K) + 64 * K * 4; }
 // tiles per wave: the chain waves 0..3 take fewer than the others (their pivot block runs behind their updates, and a wave's
 // dependent matrix instructions alternate with its SIMD partner's whatever the priorities: the chain starts the earlier the
 // fewer tiles its waves hold)
@@ -2463,8 +2653,17 @@ __host__ __device__ inline int rs4_lds_bytes(int K) { return spd_lds_bytes(K) + 
 #ifndef LQP_RS4_NA9
 #define LQP_RS4_NA9 3          // ninths of the workgroup's tiles held by waves 0..3 (v2: 4 -> 8 of 18; 3 -> 6 of 18)
 #endif
+#ifdef LQP_RS4_NA            // (... or their number itself, for K = 8)
+template <int K> __host__ __device__ constexpr int rs4_na() { return K == 8 ? LQP_RS4_NA : (rs2_max<K, 2>() * LQP_RS4_NA9) / 9; }
+#else
 template <int K> __host__ __device__ constexpr int rs4_na() { return (rs2_max<K, 2>() * LQP_RS4_NA9) / 9; }
+#endif
 template <int K> __host__ __device__ constexpr int rs4_nb() { return rs2_max<K, 2>() - rs4_na<K>(); }
+// -DLQP_RS4_STAMPS=1 (wave 0) / 2 (wave 4): cycles per phase, summed over the steps, into dbg[0..5] (tools/gpu_resident_phases.py)
+#ifndef LQP_RS4_STAMPS
+#define LQP_RS4_STAMPS 0
+#endif
+#define RS4_STAMP(i) do { if (LQP_RS4_STAMPS && dbg && tid == 64 * (4 * (LQP_RS4_STAMPS - 1))) { const unsigned long long t_ = clock64(); dbt4[i] += t_ - dt4; dt4 = t_; } } while (0)
 template <int K, int NP = 2>
 __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, float* Hdst,
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
@@ -2505,7 +2704,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
 
     auto body = [&](auto pivot_tag) {
         constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
-        constexpr int NS = PIVOT ? rs2_na<K, NP>() : rs2_nb<K, NP>(), FIRST = PIVOT ? 0 : rs2_na<K, NP>();
+        constexpr int NS = PIVOT ? rs4_na<K>() : rs4_nb<K>(), FIRST = PIVOT ? 0 : rs4_na<K>();      // (-DLQP_RS4_NA9=4: the 8 / 10 split of v2)
         // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
         f32x16 T[NS];
         int ti[NS], tj[NS];
@@ -2718,6 +2917,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
             __syncthreads();
         }
         int gchain = 0, gstage = 0;                          // running targets of the two group syncs
+        unsigned long long dbt4[6] = {0, 0, 0, 0, 0, 0}, dt4 = LQP_RS4_STAMPS ? clock64() : 0ull;
         for (int k = 0; k < K; ++k) {
             // (lane parts of every LDS address of this step, opaque: as loop invariants of the step loop they would be
             //  formed once, held in registers -- one per distinct address -- and spilled with the tiles)
@@ -2733,16 +2933,21 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                 const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
                 if (rb < 2 * (K - 1)) {
                     const int xoff = ((rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
-                    const f32x16 a0 = spd_quadrant_lp<1>(yH + xoff, yH + WOFF);
-                    const f32x16 a1 = spd_quadrant_lp<0>(yF + xoff, yF + WOFF + 32 * SPD_LS);
+                    // (one accumulator at a time: the tile waves hold up to twelve tiles; the two products read the same
+                    //  panel rows, which nobody overwrites before the barrier below: the first may be stored at once)
+                    {
+                        const f32x16 a0 = spd_quadrant_lp<1>(yH + xoff, yH + WOFF);
+                        const f32x16 a1 = spd_quadrant_lp<0>(yF + xoff, yF + WOFF + 32 * SPD_LS);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS] = a0[q];
-                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS + 32] = a1[q];
+                        for (int q = 0; q < 16; ++q) {
+                            yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS] = a0[q];
+                            yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS + 32] = a1[q];
+                        }
                     }
                 }
             }
             __syncthreads();
+            RS4_STAMP(0);                                      // Y phase + barrier
             const bool more = k + 1 < K;
             if constexpr (PIVOT) { if (more) __builtin_amdgcn_s_setprio(2); }      // the chain waves should reach the chain first
             const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
@@ -2783,6 +2988,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                     if (old + 1 == RS_NW * (k + 1)) set_flag(k + 1, 0.f);
                 }
             }
+            RS4_STAMP(1);                                      // tiles of rows / columns k, k+1 + publish
             // ---- then every other tile (the panel Y_k only) ----
             auto rest = [&]() {
 #pragma unroll
@@ -2802,6 +3008,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                 if (more) lds_wait_ge_bounded(sy + 8, 4 * (k + 1), status_timeout);
             }
             if (!(PIVOT && CHAIN_FIRST && more)) rest();
+            RS4_STAMP(2);                                      // the other tiles
             if constexpr (PIVOT) {
                 if (lane == 0) __hip_atomic_fetch_add(sy + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -2817,6 +3024,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                     lds_wait_ge_bounded(sy + 5, k + 1, status_timeout);                   // the partner's tiles of step k+1 ...
                     lds_wait_ge_bounded(sy + 3, RS_NW * (k + 1), status_timeout);         // ... and this workgroup's own have left
                     lds_wait_ge_bounded(sy + 1, RS_NW * (k + 1), status_timeout);         // W_k, W_k^T are dead
+                    RS4_STAMP(3);                              // waits
                     {
                         int tid_s = tid;
                         asm volatile("" : "+v"(tid_s));
@@ -2837,13 +3045,17 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, floa
                     lds_wait_ge_bounded(sy + 5, k + 1, status_timeout);
                     lds_wait_ge_bounded(sy + 3, RS_NW * (k + 1), status_timeout);
                     lds_wait_ge_bounded(sy + 2, RS_NW * (k + 1), status_timeout);         // nobody reads the panel Y_k any more
+                    RS4_STAMP(3);                              // waits
                     stage_panel(k + 1);
                     (void)gstage;
                 }
             }
+            RS4_STAMP(4);                                      // pivot block k+1 / staging of panel k+1
             __syncthreads();
+            RS4_STAMP(5);                                      // closing barrier
         }
-        (void)dbg;
+        if (LQP_RS4_STAMPS && dbg && tid == 64 * (4 * (LQP_RS4_STAMPS - 1)))
+            for (int q = 0; q < 6; ++q) dbg[q] = dbt4[q];
         // ---- the finished tiles to their home blocks ----
 #pragma unroll
         for (int s = 0; s < NS; ++s) {

@@ -935,6 +935,50 @@ def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeyp
     assert sols["1", 100.0]["_stats"]["n_factor"] >= 2
 
 
+@pytest.mark.parametrize("n,B,m", [(500, 4, 1), (333, 3, 2), (448, 2, 0), (449, 70, 1), (300, 5, 3), (512, 2, 16)])
+@pytest.mark.parametrize("rho", [None, 0.7])
+def test_pass_over_q_inside_the_resident_sweep(dev, monkeypatch, n, B, m, rho):
+    """FwdParams::prep_fused == 3: no k_spd_prep launch -- the workgroups that keep the matrix in their registers read Q
+    themselves (tiles, mirrors for the column maxima and the symmetry verdict), swap the maxima, form the scaling vector
+    with the setup kernel's code and do what that kernel deferred (D, ps, As / E / bs, lbs / ubs).  The same operations on
+    the same values as behind k_spd_prep: identical bits, one launch less."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
+    lb[0, : n // 3] = -float("inf")
+    ub[B - 1, n // 2:] = float("inf")
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_QPASS", flag)
+        ctl = O.make_control(rho=rho, linsolve="spd", **TOL)
+        out[flag], _ = solve(dev, (Q, p, A, b, lb, ub), ctl)
+        assert out[flag]["_stats"]["linsolve_used"] == 2
+    s1, s0 = out["1"], out["0"]
+    assert s1["_stats"]["n_launch"] == s0["_stats"]["n_launch"] - 1
+    assert s1["iter"] == s0["iter"] and s1["_stats"]["n_factor"] == s0["_stats"]["n_factor"]
+    for k in ("x", "z", "u", "lams") + (("rho",) if rho is None else ()) + (("nus",) if m else ()):
+        assert torch.equal(s1[k], s0[k]), k
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(rho=rho, **TOL))
+    assert abs(s1["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
+    assert err(s1["x"], ref["x"]) < 5e-4 * max(1.0, float(ref["x"].abs().max()))
+
+
+def test_pass_over_q_inside_the_resident_sweep_sees_an_unsymmetric_matrix(dev):
+    """... and its verdict on symmetry is the one of k_spd_prep: a Q that is not symmetric goes to the pivoted LU."""
+    n, B = 500, 4
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=5)
+    Q = Q.clone()
+    Q[2, 400, 17] += 0.05                      # one entry of one matrix, far from the diagonal, in the last block row
+    ctl = O.make_control(**TOL)
+    sol, _ = solve(dev, (Q, p, A, b, lb, ub), ctl)
+    assert sol["_stats"]["linsolve_used"] == 1
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+    assert abs(sol["iter"] - ref["iter"]) <= O.resolve_control(ctl, n).check_solved
+    if sol["iter"] == ref["iter"]:
+        assert err(sol["x"], ref["x"]) < 5e-5
+
+
 @pytest.mark.parametrize("n,B,scale", [(500, 4, True), (330, 3, True), (448, 2, False)])
 def test_late_rho_matches_the_setup_pass(dev, monkeypatch, n, B, scale):
     """rho = ||Qs||_F / sqrt(n) (reference :200-203): with the resident sweep the squares are summed by k_spd_begin

@@ -22,15 +22,17 @@ torch.cuda.synchronize()
 lib.lqp_debug_set_lu_counters(None)
 c = dbg.view(B, 8).double()
 if os.environ.get("LQP_RS_FORM", "2") == "4":
-    # the look-ahead sweep (wg_spd_sweep_resident_v4): wave 0 (a chain wave) and wave 4 (a staging wave)
-    names = ["w0 Y = P W^T", "w0 tile updates", "w0 waits before the chain", "w0 pivot block k+1", "w0 closing barrier",
-             "w4 tile updates", "w4 waits + panel staging", "w4 closing barrier"]
+    # the look-ahead sweep (wg_spd_sweep_resident_v4) built with -DLQP_RS4_STAMPS=1 (wave 0, a chain wave) or 2 (wave 4, a staging wave)
+    names = ["Y = P W^T + barrier", "tiles of rows/columns k, k+1 + publish", "the other tiles", "waits", "pivot block k+1 / staging of panel k+1",
+             "closing barrier"]
+    tot = c[:, :6].sum(1).mean()
     for i, nm in enumerate(names):
-        print("%-32s %9.0f cycles" % (nm, c[:, i].mean()))
-    print("wave 0 total of the 8 steps %.0f cycles, wave 4 (without Y) %.0f" % (c[:, :5].sum(1).mean(), c[:, 5:8].sum(1).mean()))
+        print("%-40s %9.0f cycles (%.0f per step)" % (nm, c[:, i].mean(), c[:, i].mean() / 8))
+    print("total of the 8 steps %.0f cycles" % tot)
 else:
     names = ["publish + wait for the partner", "pivot block", "panel tiles -> LDS", "Y = P W^T", "tile updates", "closing barrier"]
     tot = c[:, :6].sum(1).mean()
     for i, nm in enumerate(names):
         print("%-32s %9.0f cycles  (%4.1f %%)" % (nm, c[:, i].mean(), 100 * c[:, i].mean() / tot))
     print("total of the 8 steps %.0f cycles" % tot)
+    print("pass over Q inside the sweep: tiles + mirrors %.0f cycles, up to the scaling vector %.0f" % (c[:, 7].mean(), c[:, 6].mean()))
