@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 7
+#define LQP_ABI_VERSION 8
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -230,6 +230,18 @@ int lqp_boxqp_last_residuals(void* stream, int dtype, int B, int n, int m,
  * Q_FF + the Schur complement of the equality rows (f32, n <= 512, m <= 16;
  * otherwise, or when Q_FF is not positive definite, LU).                     */
 size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m);
+/* The part of the Cholesky form that does not need the cotangent -- the free set (:360-365), Q_FF and its factorisation --
+ * enqueued ahead of it, e.g. right behind the forward whose x, u it reads (stream order): a caller that waits for its
+ * forward (the reference's semantics) then has the factorisation running while its host code travels from `forward` to
+ * `backward`.  lqp_boxqp_backward_fp called afterwards on the SAME workspace (nothing else may have used it in between)
+ * with linsolve = 2 | LQP_BWD_PREFACTORED only gathers dl_dz, solves and writes the gradients; a factorisation that
+ * failed still ends in that call's pivoted-LU retry.  LQP_ERR_UNSUPPORTED: no Cholesky form for these sizes / dtype
+ * (float32, linsolve 2 only) -- nothing was enqueued, call lqp_boxqp_backward_fp without the flag.                     */
+#define LQP_BWD_PREFACTORED 0x100
+int lqp_boxqp_backward_fp_prefactor(void* stream, int dtype, int B, int n, int m,
+                                    const void* x, const void* u,
+                                    const void* Q, const void* A, const void* lb, const void* ub,
+                                    void* workspace, size_t workspace_bytes, int linsolve);
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
                           const void* dl_dz, const void* x, const void* u,
                           const void* lams, const void* nus,

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQ
 SOURCES = ["lqp_amd.hip", "lqp_unroll.hpp", "lqp_boxqp.hpp", "lqp_lu.hpp", "lqp_lu_big.hpp", "lqp_trsv.hpp", "lqp_spd.hpp", "lqp_common.hpp"]
 
 LQP_F32, LQP_F64 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
           5: "grid barrier timeout", 6: "unsupported size", 7: "matrix outside the symmetric x-update"}
 
@@ -70,6 +70,7 @@ SYMBOLS = {
     "lqp_boxqp_unroll_backward": (c_int, [_P, c_int, c_int, c_int, _P, c_size_t, c_int] + [_P] * 10 + [c_size_t]),
     "lqp_boxqp_last_residuals": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
+    "lqp_boxqp_backward_fp_prefactor": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 6 + [_P, c_size_t, c_int]),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
                               [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int, _P]),
     "lqp_boxqp_backward_kkt": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 8 + [_P] * 6 +
@@ -319,6 +320,7 @@ def poll_errors(block=False):
 
 
 _ws_cache = {}
+_ws_uses = {}
 _ws_lock = threading.Lock()
 
 
@@ -348,7 +350,15 @@ def workspace(device, nbytes, tag, stream=None):
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             _ws_cache[key] = buf
+        _ws_uses[key] = _ws_uses.get(key, 0) + 1
         return buf
+
+
+def workspace_uses(device, tag, stream):
+    """How often `workspace` has handed out the buffer of (device, stream, tag): somebody who left state in it (the
+    backward's factorisation made ahead of the cotangent) compares the count to know whether it is still his."""
+    with _ws_lock:
+        return _ws_uses.get((device.index, stream, tag), 0)
 
 
 def release_workspaces(device=None):

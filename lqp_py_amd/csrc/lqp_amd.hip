@@ -982,10 +982,12 @@ template <typename T>
 int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void* x, const void* u, const void* lams,
                   const void* nus, const void* Q, const void* A, const void* lb, const void* ub, int rho_mode,
                   double rho_value, const void* rho_in, void* dQ, void* dp, void* dA, void* db, void* dlb, void* dub,
-                  int32_t* fail_index, void* ws, size_t ws_bytes, int linsolve, void* host_report, const int kkt = 0) {
+                  int32_t* fail_index, void* ws, size_t ws_bytes, int linsolve, void* host_report, const int kkt = 0,
+                  int phase = 0) {
     BwdParams<T> P;
     memset(&P, 0, sizeof(P));
     P.kkt = kkt ? 1 : 0;
+    if (linsolve & LQP_BWD_PREFACTORED) { linsolve &= ~LQP_BWD_PREFACTORED; if (phase == 0 && !kkt) phase = 2; }
     P.host_report = (int*)host_report;
     if (P.host_report) report_reset(P.host_report, B);
     P.early_report = env_int("LQP_BWD_EARLY", 1) != 0 ? 1 : 0;
@@ -1005,9 +1007,12 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     if constexpr (sizeof(T) == 4) {
         chol = P.reduced && linsolve == 2 && env_int("LQP_BWD_CHOL", 1) && round_up(n, LQP_NB) / LQP_NB <= SPD_BIGK &&
                m <= SPD_MAXM && bwd_chol_lds_bytes(n, m) <= 160 * 1024;
+        if (!chol && phase == 1) return LQP_ERR_UNSUPPORTED;      // (nothing to run ahead of the cotangent on the LU form)
+        if (!chol) phase = 0;
+        P.phase = phase;
         if (chol) {
             P.chol = 1;
-            {
+            if (phase != 2) {
                 const int lds = (2 * round_up(n, 8) + LQP_NW + 8) * 4;      // (fl | wtot | the KKT form's diagonal weights)
                 ProfScope ps(st, PC_BWD_BUILD);
                 const int split = B <= 128 ? 2 : 1;
@@ -1022,8 +1027,9 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             if (r2) return r2;
             ProfScope ps(st, PC_BWD_CHOL);
             hipLaunchKernelGGL(k_bwd_chol_solve<>, dim3(B), dim3(LQP_NT), lds, st, P);
+            if (phase == 1) return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
         }
-    }
+    } else if (phase == 1) return LQP_ERR_UNSUPPORTED;
     if (chol) {
     } else if (P.reduced) {
         const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
@@ -1076,7 +1082,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             rc = first_failure(st, P.info, B, &fi, P.host_report);
         if (rc == LQP_ERR_SINGULAR && chol)           // Q_FF not positive definite in f32: the pivoted LU takes it
             return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
-                                    db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report, kkt);
+                                    db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report, kkt, 0);
         *fail_index = fi;
         if (rc) return rc;
     }
@@ -1389,6 +1395,17 @@ size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m) {
     if (bad_dims(dtype, B, n, m)) return 0;
     if (dtype == LQP_F32) { BwdParams<float> P; return carve_backward<float>(nullptr, B, n, m, P); }
     BwdParams<double> P; return carve_backward<double>(nullptr, B, n, m, P);
+}
+
+int lqp_boxqp_backward_fp_prefactor(void* stream, int dtype, int B, int n, int m, const void* x, const void* u, const void* Q,
+                                    const void* A, const void* lb, const void* ub, void* workspace, size_t workspace_bytes,
+                                    int linsolve) {
+    if (bad_dims(dtype, B, n, m) || !x || !u || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
+    if (m > 0 && !A) return LQP_ERR_INVALID;
+    if (dtype != LQP_F32 || linsolve != 2 || n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    return backward_impl<float>((hipStream_t)stream, B, n, m, nullptr, x, u, nullptr, nullptr, Q, A, lb, ub, 1, 1.0, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, 2,
+                                nullptr, 0, 1);
 }
 
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x, const void* u,

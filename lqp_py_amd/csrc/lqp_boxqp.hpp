@@ -2205,6 +2205,8 @@ template <typename T> struct BwdParams {
     int la_maxk;               // largest block count the look-ahead Cholesky may take (LDS of the launch), 0 = off
     int* host_report;          // optional pinned host memory, B ints: the epilogue leaves every problem's info word there
     int early_report;          // 1: Cholesky form -- k_bwd_chol_solve reports (the info words are final there), not the epilogue
+    int phase;                 // Cholesky form in two calls: 1 = free set + Q_FF + its factorisation only (no cotangent needed:
+                               // enqueued right behind the forward), 2 = the solves + epilogue on that factor; 0 = everything
     int kkt;                   // 1: the KKT-system backward (backward='kkt', reference :435-584) on the same kernels: the (3n+m)
                                //    system [[Q, G^T diag(lam), A^T], [G, -diag(s), 0], [A, 0, 0]] with G = [-I; I] reduces exactly
                                //    (dlam = diag(1/s) G dx) to [[Q + diag(w), A^T], [A, 0]] [dx; dnu] = [-g; 0],
@@ -2430,7 +2432,8 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
         *(V4<float>*)(Ls + (size_t)t * LQP_BLK + tid * 4) = v;
     }
     if (blockIdx.y == 0) {
-        for (int a = tid; a < Npm; a += LQP_NT) rhs[a] = a < nf ? -g[fl[a]] : 0.f;
+        if (P.phase != 1)          // (phase 1: no cotangent yet -- k_bwd_chol_solve gathers it in phase 2)
+            for (int a = tid; a < Npm; a += LQP_NT) rhs[a] = a < nf ? -g[fl[a]] : 0.f;
         for (int q = 0; q < m; ++q)
             for (int a = tid; a < Npm; a += LQP_NT) AF[(size_t)q * Npm + a] = a < nf ? A[(size_t)q * n + fl[a]] : 0.f;
     }
@@ -2457,11 +2460,12 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     const float* AF = P.M + (size_t)b * Np * Np;
     float* rhs = P.rhs + (size_t)b * Np;
     unsigned long long dt0 = P.dbg ? clock64() : 0;
-    if (Kb > 0) {
+    if (Kb > 0 && P.phase != 2) {
         if (Kb <= P.la_maxk) wg_chol_factor_la(Ls, Kb, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
         else if (Kb <= SPD_MAXK) wg_chol_factor(Ls, Kb, P.info + b, smem);
         else wg_chol_factor_big(Ls, Kb, P.info + b, smem);
     }
+    if (P.phase == 1) return;              // (the factor is in the workspace: lqp_boxqp_backward_fp_prefactor)
     __syncthreads();
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 0] = t - dt0; dt0 = t; P.dbg[(size_t)b * 8 + 3] = Kb; }
     // right-hand sides [rhs | A_F^T] as rows of X (u0 = X[0], G = X[1 ..]), solved two at a time
@@ -2474,7 +2478,13 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     float* S = part + NR * LQP_NW * 64;
     float* wv = S + m * m;
     float* dn = wv + m;
-    for (int e = tid; e < Nb; e += LQP_NT) u0[e] = rhs[e];
+    if (P.phase == 2) {                    // the cotangent arrives only now: gathered over the free set of phase 1
+        const float* g = P.g + (size_t)b * n;
+        const int* fidx = P.fidx + (size_t)b * n;
+        for (int e = tid; e < Nb; e += LQP_NT) u0[e] = e < nf ? -g[fidx[e]] : 0.f;
+    } else {
+        for (int e = tid; e < Nb; e += LQP_NT) u0[e] = rhs[e];
+    }
     for (int q = 0; q < m; ++q)
         for (int e = tid; e < Nb; e += LQP_NT) G[(size_t)q * Npm + e] = AF[(size_t)q * Npm + e];
     __syncthreads();

@@ -26,6 +26,8 @@ _INF = float("inf")
 _SYNC_SPLIT = os.environ.get("LQP_SYNC_SPLIT", "1") != "0"      # (A/B knob: 0 = one-call synchronous forward)
 _KKT_NATIVE = os.environ.get("LQP_KKT_NATIVE", "1") != "0"      # (A/B knob: 0 = the KKT backward composed from torch ops + lqp_kkt_solve)
 _PREPARE_BWD = os.environ.get("LQP_PREPARE_BWD", "1") != "0"    # (A/B knob: 0 = the backward prepares itself when it is called)
+_PREFACTOR_BWD = os.environ.get("LQP_PREFACTOR_BWD", "1") != "0"   # (A/B knob: 0 = nothing of the backward runs ahead of the cotangent)
+_BWD_PREFACTORED = 0x100                                         # include/lqp_amd.h: LQP_BWD_PREFACTORED
 
 
 class SolveBoxQP(nn.Module):
@@ -70,8 +72,12 @@ class SolveBoxQPLayer(torch.autograd.Function):
             # a synchronous call only waits while its schedule runs: the backward's outputs, workspace and argument list are
             # made in that window (the cotangent is all that is missing), see _fp_backward_prepare
             def while_running(parts, linsolve_used):
+                # ... and the part of the backward that does not need the cotangent (free set, Q_FF, its Cholesky
+                # factorisation) is enqueued right behind the forward: it runs while this call returns, the caller forms its
+                # loss and autograd finds its way to `backward`, which then only solves
                 ctx.prepared = _fp_backward_prepare(parts['x'], parts['u'], parts['lams'], parts['nus'], Q, A, lb, ub,
-                                                    parts['rho_out'], _wanted(need, A), sync=True, linsolve=linsolve_used)
+                                                    parts['rho_out'], _wanted(need, A), sync=True, linsolve=linsolve_used,
+                                                    prefactor=_PREFACTOR_BWD)
         sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=control.get('_global_bounds'), sync=sync,
                              check_hook=control.get('_check_hook'), mutate=True,
                              holder=control.get('_holder') or getattr(_tls, 'holder', None), while_running=while_running)
@@ -579,7 +585,7 @@ def last_forward_status(device):
     return st
 
 
-def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1):
+def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1, prefactor=False):
     """Everything of the fixed-point backward that does not need the cotangent: output tensors, workspace, report buffer,
     the argument list of lqp_boxqp_backward_fp.  A synchronous layer call runs this WHILE its forward is on the GPU (the host
     would only wait), so that `backward` is one library call behind the autograd engine's thread hop."""
@@ -609,19 +615,33 @@ def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, li
     tail = (_lib.ptr(xc), _lib.ptr(uc), _lib.ptr(lc), _lib.ptr(nc), _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc), _lib.ptr(ubc),
             rho_mode, rho_value, _lib.ptr(rho_tensor),
             _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dA), _lib.ptr(db), _lib.ptr(dlb), _lib.ptr(dub),
-            ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel(), int(linsolve),
-            None if report is None else ctypes.c_void_p(report.data_ptr()))
+            ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel())
+    rep = None if report is None else ctypes.c_void_p(report.data_ptr())
     keep = (xc, uc, lc, nc, Qc, Ac, lbc, ubc, rho_tensor, ws)          # (the pointers above point into these)
+    pref = None
+    if prefactor and int(linsolve) == 2 and dt == _lib.LQP_F32:
+        # (reads x, u behind the forward's kernels in stream order; LQP_ERR_UNSUPPORTED = no Cholesky form at this size:
+        #  nothing was enqueued)
+        with _lib.on_device(dev):
+            st = lib.lqp_boxqp_backward_fp_prefactor(*head, _lib.ptr(xc), _lib.ptr(uc), _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc),
+                                                     _lib.ptr(ubc), _lib.ptr(ws), ws.numel(), 2)
+        if st == 0:
+            pref = _lib.workspace_uses(dev, "bwd", stream)      # (still ours at `backward` if nobody asked for the buffer since)
+        elif st != 6:
+            _lib.check(st, "torch_solve_box_qp_grad (prefactor)")
     return dict(lib=lib, head=head, tail=tail, keep=keep, grads=(dQ, dp, dA, db, dlb, dub, None), fail=fail, report=report,
-                dev=dev, dty=dty, B=B, sync=sync)
+                dev=dev, dty=dty, B=B, sync=sync, linsolve=int(linsolve), rep=rep, pref=pref, stream=stream)
 
 
 def _fp_backward_run(prep, dl_dz):
     _lib.require_gpu(dl_dz)
     gc = _lib.norm(dl_dz, prep['dty'])
     dev, report, B, sync = prep['dev'], prep['report'], prep['B'], prep['sync']
+    linsolve = prep['linsolve']
+    if prep['pref'] is not None and prep['pref'] == _lib.workspace_uses(dev, "bwd", prep['stream']):
+        linsolve |= _BWD_PREFACTORED                       # the factorisation made behind the forward is still in the workspace
     with _lib.on_device(dev):
-        st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *prep['tail'])
+        st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *prep['tail'], linsolve, prep['rep'])
     if st == 3:
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {prep['fail'].value})")
     _lib.check(st, "torch_solve_box_qp_grad")

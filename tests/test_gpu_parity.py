@@ -515,6 +515,65 @@ def test_cholesky_backward_falls_back(dev):
         assert torch.equal(t1, t2)
 
 
+@pytest.mark.parametrize("n,B,m", [(500, 16, 1), (200, 5, 3), (60, 4, 0)])
+def test_backward_factorisation_ahead_of_the_cotangent(dev, monkeypatch, n, B, m):
+    """lqp_boxqp_backward_fp_prefactor: a synchronous layer call enqueues the free set, Q_FF and its Cholesky factorisation
+    right behind its forward; `backward` then only gathers the cotangent, solves and writes the gradients.  The same kernels
+    on the same values as the one-call backward: identical bits.  Also: a workspace somebody else has used in between is not
+    trusted (the backward runs in full), and a Q_FF that is not positive definite still ends in the pivoted-LU answer."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
+    cot = torch.randn(B, n, 1, generator=g).to(dev)
+
+    def run(prefactor, disturb=False):
+        monkeypatch.setattr(SB, "_PREFACTOR_BWD", prefactor)
+        leaves = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        prof = _lib.profile(enable=True, reset=True)
+        x = L.SolveBoxQP(control=L.box_qp_control(**TOL))(*leaves)
+        if disturb:      # another backward on the same stream takes the workspace before ours runs
+            other = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+            L.SolveBoxQP(control=L.box_qp_control(**TOL))(*other).sum().backward()
+        x.backward(cot)
+        used = _lib.profile(); _lib.profile(enable=False)
+        return x.detach(), [None if t is None else t.grad for t in leaves], used
+
+    x0, g0, u0 = run(False)
+    x1, g1, u1 = run(True)
+    x2, g2, u2 = run(True, disturb=True)
+    assert u0["bwd_cholesky"][1] == 1 and u0["bwd_build"][1] == 1
+    assert u1["bwd_cholesky"][1] == 2 and u1["bwd_build"][1] == 1 and u1["lu_factor"][1] == 0      # factor | solve, one build
+    assert u2["bwd_build"][1] == 3 and u2["bwd_cholesky"][1] == 4     # ours ahead | the other call's ahead, then its solve | ours again in full
+    assert torch.equal(x0, x1) and torch.equal(x0, x2)
+    for a0, a1, a2 in zip(g0, g1, g2):
+        if a0 is not None:
+            assert torch.equal(a0, a1) and torch.equal(a0, a2)
+
+
+def test_backward_factorisation_ahead_of_the_cotangent_falls_back(dev):
+    """... and on the C ABI: prefactor + solve-only call == one call; a factorisation that failed ends in the LU retry."""
+    lib = _lib.load()
+    Q, p, A, b, lb, ub = O.create_qp_data(40, 3, seed=9)
+    want = dict(dQ=True, dp=True, dA=True, db=True, dlb=True, dub=True)
+    for shift in (0.0, -0.5):          # (-0.5: Q_FF not positive definite)
+        a = [t.to(dev) for t in (Q + shift * torch.eye(40), p, A, b, lb, ub)]
+        x = torch.zeros(3, 40, 1, device=dev); u = torch.zeros_like(x)
+        lams = torch.zeros(3, 80, 1, device=dev); nus = torch.zeros(3, 1, 1, device=dev)
+        cot = torch.randn(3, 40, 1, device=dev)
+        g1 = SB._fp_backward(cot, x, u, lams, nus, a[0], a[2], a[4], a[5], 1.0, want, sync=True, linsolve=2)
+        prep = SB._fp_backward_prepare(x, u, lams, nus, a[0], a[2], a[4], a[5], 1.0, want, sync=True, linsolve=2, prefactor=True)
+        assert prep["pref"] is not None
+        g2 = SB._fp_backward_run(prep, cot)
+        for t1, t2 in zip(g1[:6], g2[:6]):
+            assert torch.equal(t1, t2)
+    # float64 / the LU form: nothing to run ahead
+    ws = torch.empty(int(lib.lqp_boxqp_backward_fp_workspace_bytes(_lib.LQP_F64, 3, 40, 1)), dtype=torch.uint8, device=dev)
+    st = lib.lqp_boxqp_backward_fp_prefactor(_lib.stream_ptr(dev), _lib.LQP_F64, 3, 40, 1, _lib.ptr(x), _lib.ptr(u), _lib.ptr(a[0]),
+                                             _lib.ptr(a[2]), _lib.ptr(a[4]), _lib.ptr(a[5]), _lib.ptr(ws), ws.numel(), 2)
+    assert st == 6
+
+
 # ---------------------------------------------------------------- SURVEY 8f rank 4: NumPy twin, OptNet (equality only)
 _G14_CTL = {"a": dict(scale=False, adaptive_rho=False), "b": dict(), "c": dict(rho=5.0, adaptive_rho_iter=20)}
 
