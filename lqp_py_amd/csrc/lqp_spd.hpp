@@ -1695,6 +1695,20 @@ template <int NT, int NP = 2> __host__ __device__ constexpr int split_lds_blocks
     return c > 0 ? c : 0;
 }
 
+// a := [a rows 0, b rows 0, a rows 2, b rows 2], b := [a rows 1, b rows 1, a rows 3, b rows 3] (rows of 16 lanes): afterwards
+// a + b holds a's lane ^ 16 sum in the even rows and b's in the odd ones.  (Inline assembly like piv_pair; the s_nops
+// cover the swap's wait states behind a VALU write of its operands and before its results are read.)
+#ifndef LQP_SPLIT_SWAP
+#define LQP_SPLIT_SWAP 1
+#endif
+__device__ __forceinline__ void lane_swap16(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// a := [a lanes 0-31, b lanes 0-31], b := [a lanes 32-63, b lanes 32-63]: a + b = a's lane ^ 32 sum below lane 32, b's above
+__device__ __forceinline__ void lane_swap32(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
 template <int NT> struct SplitResident {
     Frag<float, NT> r[split_rr<NT>()];
 };
@@ -1832,6 +1846,29 @@ __device__ __forceinline__ void wg_sym_gemv_split(const SplitResident<NT>& rr, c
                 }
             }
         }
+#if LQP_SPLIT_SWAP
+        // The fold over the rows a wave holds (lane bits 3 | 4 | 5, in this order: the same sums as ever) WITHOUT the LDS:
+        // lane ^ 8 by DPP; lane ^ 16 and lane ^ 32 by v_permlane16_swap / v_permlane32_swap on PAIRS of elements -- the swap
+        // hands each half of the lanes the partner's value of ONE of the two, so one add folds both and the number of
+        // live values halves with every step (8 -> 4 -> 2): 8 + 4 + 2 adds and 6 swaps where 16 ds_bpermute round trips
+        // (and their 24 adds) stood in the product's dependency chains.  Afterwards lane L holds, in t[k], element
+        // 4 k + 2 (L >> 5) + ((L >> 4) & 1) of its column group (EPT = 8; EPT = 4: one value, element 2 (L >> 5) + ((L >> 4) & 1)).
+        float a1[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            a1[e] = a2[e >> 1][e & 1];
+            if constexpr (LPR == 8) a1[e] += dpp<0x128>(a1[e]);          // row_ror:8 = lane ^ 8 inside a 16-lane DPP row
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; e += 2) { lane_swap16(a1[e], a1[e + 1]); a1[e >> 1] = a1[e] + a1[e + 1]; }
+#pragma unroll
+        for (int e = 0; e < EPT / 2; e += 2) { lane_swap32(a1[e], a1[e + 1]); a1[e >> 1] = a1[e] + a1[e + 1]; }
+        if (LPR == 16 || (lane & 8) == 0) {
+            float* dst = part + (size_t)w * Np + j * 64 + cq * EPT + 2 * (lane >> 5) + ((lane >> 4) & 1);
+#pragma unroll
+            for (int k = 0; k < EPT / 4; ++k) dst[4 * k] = a1[k];
+        }
+#else
         float a1[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -1850,6 +1887,7 @@ __device__ __forceinline__ void wg_sym_gemv_split(const SplitResident<NT>& rr, c
                 *(V4<float>*)(part + (size_t)w * Np + j * 64 + cq * EPT + 4 * q) = o;
             }
         }
+#endif
     }
     constexpr int first_row = M::col_of(0);            // the lowest owned column: rows above it get nothing
 #pragma unroll
