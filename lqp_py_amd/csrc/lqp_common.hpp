@@ -50,10 +50,61 @@ template <typename T> __device__ __forceinline__ T row16_sum(T v) {
     v += dpp<0x128>(v);   // row_ror:8
     return v;
 }
+// ---- lanes l and l ^ 16 / l ^ 32 WITHOUT the LDS crossbar (gfx950: v_permlane16_swap / v_permlane32_swap) ----
+// lane_swap16: a := [a rows 0, b rows 0, a rows 2, b rows 2], b := [a rows 1, b rows 1, a rows 3, b rows 3] (rows of 16 lanes):
+//              afterwards a + b holds a's lane ^ 16 sum in the even rows and b's in the odd ones;
+// lane_swap32: a := [a lanes 0-31, b lanes 0-31], b := [a lanes 32-63, b lanes 32-63]: a + b = a's lane ^ 32 sum below lane 32,
+//              b's above.
+// With a == b every lane gets the fold of the one value (fold16 / fold32: what v + __shfl_xor(v, 16) computes -- the same two
+// summands, hence the same bits -- as two VALU instructions instead of a ds_bpermute round trip); with two different values one
+// add folds both and the number of live values halves (col_fold).  Inline assembly: the builtin of hipcc 7.2 mixed up its two
+// results (lqp_spd.hpp, piv_pair); the s_nops cover the swap's wait states behind a VALU write of its operands and before its
+// results are read.
+#ifndef LQP_LANE_SWAP
+#define LQP_LANE_SWAP 1
+#endif
+__device__ __forceinline__ void lane_swap16(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap32(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <typename T> __device__ __forceinline__ T xor16(T v) { return (T)__shfl_xor(v, 16); }
+template <typename T> __device__ __forceinline__ T xor32(T v) { return (T)__shfl_xor(v, 32); }
+#if LQP_LANE_SWAP
+// the value of lane l ^ 16 / l ^ 32
+template <> __device__ __forceinline__ float xor16<float>(float v) {
+    float a = v, b = v;
+    lane_swap16(a, b);                  // a = [r0 r0 r2 r2], b = [r1 r1 r3 r3]
+    return (threadIdx.x & 16) ? a : b;
+}
+template <> __device__ __forceinline__ float xor32<float>(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b);                  // a = [lo lo], b = [hi hi]
+    return (threadIdx.x & 32) ? a : b;
+}
+#endif
+// Column sums over the rows a wave holds: lane l carries EPT partial sums of the columns EPT (l % LPR) .. of row l / LPR
+// (LPR = 64 / EPT lanes per row); the fold runs over lane bits log2(LPR) .. 5 in ascending order (the sums
+// ((a + a^8) + a^16) + a^32 of the plain shuffle fold: the same bits).  Afterwards lane l holds in a[k], k < EPT / 4, the
+// total of element 4 k + col_fold_elem(l) of its column group.
+template <int EPT> __device__ __forceinline__ void col_fold(float (&a)[EPT]) {
+    static_assert(EPT == 4 || EPT == 8, "1024 or 512 threads per 64x64 block");
+    if constexpr (EPT == 8) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) a[e] += dpp<0x128>(a[e]);          // row_ror:8 = lane ^ 8 inside a 16-lane DPP row
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e += 2) { lane_swap16(a[e], a[e + 1]); a[e >> 1] = a[e] + a[e + 1]; }
+#pragma unroll
+    for (int e = 0; e < EPT / 2; e += 2) { lane_swap32(a[e], a[e + 1]); a[e >> 1] = a[e] + a[e + 1]; }
+}
+__device__ __forceinline__ int col_fold_elem(const int lane) { return 2 * (lane >> 5) + ((lane >> 4) & 1); }
+
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     v = row16_sum(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    v += xor16(v);
+    v += xor32(v);
     return v;
 }
 template <typename T> __device__ __forceinline__ T wave_max(T v) {
@@ -61,8 +112,8 @@ template <typename T> __device__ __forceinline__ T wave_max(T v) {
     v = tmax(v, dpp<0x4E>(v));
     v = tmax(v, dpp<0x124>(v));
     v = tmax(v, dpp<0x128>(v));
-    v = tmax(v, (T)__shfl_xor(v, 16));
-    v = tmax(v, (T)__shfl_xor(v, 32));
+    v = tmax(v, xor16(v));
+    v = tmax(v, xor32(v));
     return v;
 }
 

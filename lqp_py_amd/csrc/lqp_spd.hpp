@@ -261,8 +261,8 @@ __device__ __forceinline__ float wg_sym_prep(float* __restrict__ Hs, const float
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = tabs(v.v[e]);
-            a = tmax(a, __shfl_xor(a, 16));
-            a = tmax(a, __shfl_xor(a, 32));
+            a = tmax(a, xor16(a));
+            a = tmax(a, xor32(a));
             if (lane < 16) atomicMax(cm + col0 + c4 + e, __float_as_uint(a));
         }
     };
@@ -1555,6 +1555,15 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
     wk.i = __builtin_amdgcn_readfirstlane(wk.i + 1);
     if (wk.i == K) {
         // end of block column j: fold the rows this wave holds, publish its 64 column sums
+#if LQP_LANE_SWAP
+        // (lanes l, l ^ LPR, ... hold the same columns of other rows: folded by lane swaps on pairs of elements, no LDS)
+        col_fold<EPT>(wk.acc2);
+        if (LPR == 16 || (lane & 8) == 0) {
+            float* dst = part + (size_t)w * Np + wk.j * 64 + cq * EPT + col_fold_elem(lane);
+#pragma unroll
+            for (int k = 0; k < EPT / 4; ++k) dst[4 * k] = wk.acc2[k];
+        }
+#else
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             float a = wk.acc2[e];
@@ -1573,6 +1582,7 @@ __device__ __forceinline__ void sym_block(SymWalk<NT>& wk, const Frag<float, NT>
                 *(V4<float>*)(dst + 4 * q) = o;
             }
         }
+#endif
 #pragma unroll
         for (int e = 0; e < EPT; ++e) wk.acc2[e] = 0.f;
         wk.j = __builtin_amdgcn_readfirstlane(wk.j + 1);
@@ -1695,20 +1705,9 @@ template <int NT, int NP = 2> __host__ __device__ constexpr int split_lds_blocks
     return c > 0 ? c : 0;
 }
 
-// a := [a rows 0, b rows 0, a rows 2, b rows 2], b := [a rows 1, b rows 1, a rows 3, b rows 3] (rows of 16 lanes): afterwards
-// a + b holds a's lane ^ 16 sum in the even rows and b's in the odd ones.  (Inline assembly like piv_pair; the s_nops
-// cover the swap's wait states behind a VALU write of its operands and before its results are read.)
 #ifndef LQP_SPLIT_SWAP
 #define LQP_SPLIT_SWAP 1
 #endif
-__device__ __forceinline__ void lane_swap16(float& a, float& b) {
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-// a := [a lanes 0-31, b lanes 0-31], b := [a lanes 32-63, b lanes 32-63]: a + b = a's lane ^ 32 sum below lane 32, b's above
-__device__ __forceinline__ void lane_swap32(float& a, float& b) {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-
 template <int NT> struct SplitResident {
     Frag<float, NT> r[split_rr<NT>()];
 };
@@ -1855,16 +1854,10 @@ __device__ __forceinline__ void wg_sym_gemv_split(const SplitResident<NT>& rr, c
         // 4 k + 2 (L >> 5) + ((L >> 4) & 1) of its column group (EPT = 8; EPT = 4: one value, element 2 (L >> 5) + ((L >> 4) & 1)).
         float a1[EPT];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            a1[e] = a2[e >> 1][e & 1];
-            if constexpr (LPR == 8) a1[e] += dpp<0x128>(a1[e]);          // row_ror:8 = lane ^ 8 inside a 16-lane DPP row
-        }
-#pragma unroll
-        for (int e = 0; e < EPT; e += 2) { lane_swap16(a1[e], a1[e + 1]); a1[e >> 1] = a1[e] + a1[e + 1]; }
-#pragma unroll
-        for (int e = 0; e < EPT / 2; e += 2) { lane_swap32(a1[e], a1[e + 1]); a1[e >> 1] = a1[e] + a1[e + 1]; }
+        for (int e = 0; e < EPT; ++e) a1[e] = a2[e >> 1][e & 1];
+        col_fold<EPT>(a1);
         if (LPR == 16 || (lane & 8) == 0) {
-            float* dst = part + (size_t)w * Np + j * 64 + cq * EPT + 2 * (lane >> 5) + ((lane >> 4) & 1);
+            float* dst = part + (size_t)w * Np + j * 64 + cq * EPT + col_fold_elem(lane);
 #pragma unroll
             for (int k = 0; k < EPT / 4; ++k) dst[4 * k] = a1[k];
         }
@@ -2309,7 +2302,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 float a = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) a = tmax(a, tabs(v[q]));
-                a = tmax(a, __shfl_xor(a, 32));
+                a = tmax(a, xor32(a));
                 if (lh == 0) atomicMax(cm + col0 + li, __float_as_uint(a));
             };
 #pragma unroll
@@ -3874,15 +3867,8 @@ __device__ __forceinline__ void wg_chol_solve_n(const float* __restrict__ Ls, co
     }
     // ---- L^T x = y, from the last block column up ----
     auto fold = [&](float (&a2)[4], const int c) {           // column sums of this wave's 4 rows -> part[c][w][64]
-        V4<float> o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float a = a2[e];
-            a += __shfl_xor(a, 16);
-            a += __shfl_xor(a, 32);
-            o.v[e] = a;
-        }
-        if (lane < 16) *(V4<float>*)(part + ((size_t)c * LQP_NW + w) * 64 + cq * 4) = o;
+        col_fold<4>(a2);                                      // (lane swaps on pairs of elements, no LDS round trips)
+        part[((size_t)c * LQP_NW + w) * 64 + cq * 4 + col_fold_elem(lane)] = a2[0];
     };
     if (dbg && threadIdx.x == 0) { const unsigned long long c1 = clock64(); dbg[4] += c1 - c0; c0 = c1; }
     bd = blk4(K - 1, K - 1);
