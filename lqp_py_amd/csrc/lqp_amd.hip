@@ -27,7 +27,7 @@ namespace {
 constexpr int kRing = 1024;          // per-check counter slots
 constexpr int kMaxN = 2048;          // pivoted LU: one panel row per thread to 1024, two above (k_lu_factor_big)
 constexpr size_t kAlign = 256;
-constexpr int kSplitMaxB = 256;      // two-workgroup loop: batches up to half the CUs of any device we know of
+constexpr int kSplitMaxB = 8192;     // two-workgroup loop: exchange granules (32 KB per problem) are carved for batches up to this
 
 struct Carver {
     char* base;
@@ -658,6 +658,25 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             loop_split = loop_np > 1;
         }
     }
+    // ... and for batches LARGER than half the CUs (BASELINE configs[4]: 1024 per GPU), where the loop runs one launch per
+    // check segment anyway: the same kernel, its pairs taking turns on the chip (FwdParams::split_seg) -- a pair holds its
+    // whole matrix in registers for the 15 iterations of a segment where the one-workgroup kernel streams two thirds of it
+    // per iteration (B = 1024, n = 500: loop 3.35 -> 8 turns x 4 segments)
+    bool loop_split_seg = false;
+    if constexpr (sizeof(T) == 4) {
+        if (spd && mode == 1 && !loop_split && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 &&
+            env_int("LQP_LOOP_SPLIT", 1) != 0 && env_int("LQP_LOOP_SPLIT_SEG", 1) != 0) {
+            int dev = 0, cus = 0, per_cu = 0;
+            split_nt = 512;
+            split_lds = split_loop_lds_bytes<512>(P.Ks, m);
+            split_fn = P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
+                     : P.Ks == 7 ? k_admm_loop_split<7, 512> : k_admm_loop_split<8, 512>;
+            if (current_device_cus(&dev, &cus) && 2 * B > cus && split_lds <= 160 * 1024 &&
+                ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
+                blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1)
+                loop_split_seg = true;
+        }
+    }
     // small problems (n <= 128, e.g. BASELINE configs[1]): 256 threads per QP, the full matrix in registers (k_admm_loop_small)
     bool loop_small = false;
     int small_lds = 0;
@@ -855,6 +874,14 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             { const bool first = (mode == 2 && it == 0) || mode == 1;
               if (first && mode == 2) {
                   launch_hot(it, e, ctr_base, prev_slot, 1);
+              } else if (loop_split_seg) {
+                  if constexpr (sizeof(T) == 4) {
+                      FwdParams<float> Ps = P;
+                      Ps.split_seg = 1;
+                      Ps.seg_prev_slot = prev_slot;
+                      ProfScope ps(st, PC_LOOP);
+                      hipLaunchKernelGGL(split_fn, dim3(2 * B), dim3(split_nt), split_lds, st, Ps, it, e, ctr_base);
+                  }
               } else {
                   ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);
                   hipLaunchKernelGGL(first ? loop_fn : tail_fn, dim3(B), dim3(first ? loop_nt : LQP_NT), first ? loop_lds : tail_lds, st, P, it, e,
@@ -952,7 +979,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->mode_used = mode;
         stats->linsolve_used = spd ? 2 : 1;
         stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
-        stats->loop_workgroups = (loop_split && mode == 2) ? loop_np : 1;
+        stats->loop_workgroups = (loop_split && mode == 2) ? loop_np : loop_split_seg ? 2 : 1;
         stats->any_lb = h_status[ST_ANY_LB]; stats->any_ub = h_status[ST_ANY_UB];
     }
     return LQP_OK;

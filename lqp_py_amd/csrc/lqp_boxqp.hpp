@@ -43,6 +43,10 @@ template <typename T> struct FwdParams {
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
+    int split_seg;                       // 1: k_admm_loop_split launched once per check segment for a batch LARGER than half the CUs (the
+                                         //    pairs take their turns on the chip): workgroups 16 g + x and 16 g + 8 + x share problem 8 g + x
+                                         //    (same XCD, neighbours in its dispatch queue), no verdict inside the kernel
+    int seg_prev_slot;                   // ... counter slot of the last check before it0 (-1: none)
     int rho_late;                        // 1: rho = ||Qs||_F / sqrt(n) from the sums k_spd_begin leaves, added by k_spd_resident
     int prep_fused;                      // 3: no k_spd_prep at all -- the resident sweep reads Q itself (maxima, verdict, tiles; k_fwd_setup defers what needs D to it); 1 / 2: k_spd_prep ran BEFORE the setup kernel (2: one-workgroup tier, k_spd_inverse finishes the blocks) -- one pass over Q for the column maxima, the
                                          //    symmetry verdict and the UNSCALED blocks; the resident sweep scales them as it loads
@@ -1675,10 +1679,23 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     typedef float T;
     constexpr int NWV = NT / 64, Ks = KS, Nps = KS * LQP_NB, rl = split_lds_blocks<NT, NP>(KS);
     constexpr int XPART = SPD_MAXK * LQP_NB, XPAR = NP * XPART;      // granules of one part / of one parity of the exchange
-    const int b = blockIdx.x % P.B, part_id = blockIdx.x / P.B;
+    // (split_seg: NP == 2, B a multiple of 8 -- the host's condition)
+    const int b = P.split_seg ? 8 * ((int)blockIdx.x >> 4) + ((int)blockIdx.x & 7) : (int)blockIdx.x % P.B;
+    const int part_id = P.split_seg ? ((int)blockIdx.x >> 3) & 1 : (int)blockIdx.x / P.B;
     const int n = P.n, m = P.m;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (P.split_seg && P.seg_prev_slot >= 0) {
+        // every problem was optimal at the last check (a launch enqueued ahead of that knowledge): as admm_loop_body
+        if (__hip_atomic_load(P.counters + (size_t)P.seg_prev_slot * CT_WORDS + CT_NOTOPT, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            if (blockIdx.x == 0 && tid == 0) {
+                P.status[ST_FINAL_ITER] = it0 - 1;
+                __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
     if (it0 >= it1) return;
     T* const lds_res = (T*)smem;
     T* const v = lds_res + (size_t)rl * LQP_BLK;
@@ -1743,7 +1760,10 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     // read as before (sc1 loads bypass the reader's L1 only).  Placement is the dispatcher's: never assumed, always asked.
     unsigned long long* const xcw = P.xchg + (size_t)P.B * XCHG_WORDS + (size_t)XCHG_TAIL * b + 8;
     const unsigned int xcd_me = my_xcd();
-    if (tid == 0) __hip_atomic_store(xcw + part_id, 0x100ull | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (tagged with the launch's first iteration: a problem sees one launch of this kernel per check segment when the batch takes
+    //  turns on the chip, and the dispatcher is free to place every one of them differently)
+    const unsigned long long ann = (unsigned long long)(it0 + 1) << 16;
+    if (tid == 0) __hip_atomic_store(xcw + part_id, ann | 0x100ull | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (tid == 0) {
         int same = P.xcd_local;
@@ -1751,7 +1771,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             if (pp == part_id) continue;
             unsigned long long g = 0;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (((g = __hip_atomic_load(xcw + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x100ull) == 0) {
+            while (((g = __hip_atomic_load(xcw + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~0xFFFFull) != ann) {
                 __builtin_amdgcn_s_sleep(2);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ULL) { g = ~0ull; break; }      // (0.5 s: the exchange below will flag it)
             }
@@ -2069,7 +2089,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
                 }
                 pend_word = (const unsigned long long*)(P.counters + (size_t)slot * CT_WORDS);
                 pend_it = it;
-                pending = true;
+                pending = !P.split_seg;        // (one launch per check segment: the verdict is the next launch's / k_check_done's)
                 ++slot;
             }
         }

@@ -1147,7 +1147,8 @@ def test_symmetric_path_above_512(dev, monkeypatch, n, B, m, split):
 # ---------------------------------------------------------------- config 5: the per-GPU shard of B=8192 over 8 GPUs
 def test_config5_shard_b1024_n500(dev):
     """BASELINE configs[4]: batch 8192 dz 500 sharded over 8 GPUs = 1024 QPs per GPU, forward + backward through the
-    module.  B > 256 CUs: one launch per check segment, one workgroup per QP.  Checked against the CPU oracle on 16
+    module.  B > 256 CUs: one launch per check segment; since round 4 the loop's launches are those of the two-workgroup kernel,
+    its pairs taking turns on the chip (FwdParams::split_seg).  Checked against the CPU oracle on 16
     problems (its iteration count pinned to the GPU's: the stop is decided by ALL 1024 problems) and, at full size,
     through the KKT conditions."""
     B, n = 1024, 500
@@ -1156,7 +1157,7 @@ def test_config5_shard_b1024_n500(dev):
     Qg, pg = Q.clone().requires_grad_(True), p.clone().requires_grad_(True)
     x = L.SolveBoxQP(control=L.box_qp_control(**TOL))(Qg, pg, A, b, lb, ub)
     st = SB.last_forward_status(dev)
-    assert st["mode_used"] == 1 and st["linsolve_used"] == 2 and st["loop_workgroups_per_qp"] == 1
+    assert st["mode_used"] == 1 and st["linsolve_used"] == 2 and st["loop_workgroups_per_qp"] == 2
     assert 40 <= st["iters"] <= 100 and st["iters"] % 20 == 0
     torch.manual_seed(3)
     cot = torch.randn(B, n, 1)
@@ -1180,6 +1181,39 @@ def test_config5_shard_b1024_n500(dev):
     assert float(res["stationarity"].max()) < 2e-3 and float(res["equality"].max()) < 2e-4
     assert float(res["box"].max()) < 1e-6 and float(res["x_minus_z"].max()) < 2e-4
     assert float((cpu["lams"] < 0).sum()) == 0 and torch.isfinite(Qg.grad).all()
+
+
+@pytest.mark.parametrize("B,n,m,rho", [(264, 500, 1, None), (272, 330, 2, 100.0), (520, 448, 0, None)])
+def test_large_batch_loop_on_pairs_taking_turns(dev, monkeypatch, B, n, m, rho):
+    """More problems than half the CUs: the loop is launched once per check segment, and since round 4 those launches are
+    the two-workgroup kernel's (a pair holds its whole matrix in registers for the segment), the pairs taking their turns on
+    the chip.  Against the one-workgroup launches (LQP_LOOP_SPLIT_SEG=0): the same iteration count (the stop is decided by
+    all problems), iterates within the tolerance of two summation orders; rho = 100 forces refactorisations between the
+    segments; the CPU oracle on a few problems at the same iteration count."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=B + m, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_LOOP_SPLIT_SEG", flag)
+        out[flag], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(rho=rho, linsolve="spd", **TOL))
+        st = out[flag]["_stats"]
+        assert st["mode_used"] == 1 and st["linsolve_used"] == 2 and st["loop_workgroups"] == (2 if flag == "1" else 1)
+    s1, s0 = out["1"], out["0"]
+    assert s1["iter"] == s0["iter"] and s1["_stats"]["n_factor"] == s0["_stats"]["n_factor"]
+    if rho is not None:
+        assert s1["_stats"]["n_factor"] >= 2
+    # (rho = 100 is a hundred times too large: at the checks the adaptation reads, the primal residual is at rounding level, the
+    #  ratio sqrt(r / s) it multiplies rho with moves by 0.5 % between two summation orders -- 0.06 ... 0.7 % between the CPU
+    #  oracle and either of them -- and u = lam / rho with it: only what does not depend on rho is compared there)
+    for k in (("x", "z") if rho is not None else ("x", "z", "u", "lams") + (("nus",) if m else ())):
+        assert err(s1[k], s0[k]) < 2e-5 * max(1.0, float(s0[k].abs().max())), k
+    idx = torch.arange(0, B, B // 4)
+    sub = [None if t is None else t[idx] for t in (Q, p, A, b, lb, ub)]
+    if rho is None:      # (with refactorisations the oracle's rho history depends on the whole batch)
+        ref = O.solve_box_qp(*sub, O.make_control(eps_abs=1e-12, eps_rel=1e-12, max_iters=s1["iter"] + 1))
+        assert err(s1["x"][idx.to(dev)], ref["x"]) < 5e-5
 
 
 # ---------------------------------------------------------------- the reference's "hard" distribution in float32
