@@ -625,6 +625,16 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             return LQP_ERR_HIP;
         per_cu = std::min(per_cu, per_cu_tail);
         if (per_cu < 1 || B > cus * per_cu) mode = 1;     // not every workgroup resident: no grid barrier
+        // More problems than half the CUs but all resident (128 < B <= 256 here): the persistent one-workgroup kernel streams
+        // two thirds of its matrix per iteration, while pairs of the two-workgroup kernel, taking turns, hold theirs in
+        // registers (split_seg below) -- one launch per check segment then beats the persistent launch (B = 256, n = 500: loop
+        // 0.82 -> 0.42 ms, step 1.87 -> 1.60 ms; B = 192: 1.63 -> 1.51).  Only when the caller left the mode to the library.
+        if constexpr (sizeof(T) == 4) {
+            if (mode == 2 && ctl->launch_mode == 0 && env_int("LQP_LAUNCH_MODE", 2) == 2 && spd && P.xchg && 2 * B > cus &&
+                P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 && env_int("LQP_LOOP_SPLIT", 1) != 0 &&
+                env_int("LQP_LOOP_SPLIT_SEG", 1) != 0 && !ctl->check_hook)
+                mode = 1;
+        }
     }
     const int max_checks_per_launch = kRing / 4;
     // two workgroups per QP for the first (hot) launch: symmetric path, persistent mode, 2 B workgroups resident
