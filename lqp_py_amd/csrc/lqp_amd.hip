@@ -435,7 +435,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd_big_split = env_int("LQP_SPD_SPLIT", spd_big_split ? 1 : 0) != 0;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
-    bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK && (size_t)P.Np * P.Np >= rs3_xb_floats(P.Ks) &&
+    bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK &&
+                        (size_t)P.Np * P.Np >= ((LQP_RS_V2 == 2 || LQP_RS_V2 == 4) ? rs2_xb_floats(P.Ks) : rs3_xb_floats(P.Ks)) &&
                         env_int("LQP_SPD_RESIDENT", 1) != 0;
     int rs_np = SPD_NP;                 // workgroups per matrix of the resident sweep: 2, or 4 for batches up to a quarter of the CUs
     void (*rs_fn)(const FwdParams<float>, const int*) = nullptr;
@@ -454,7 +455,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         }
 #endif
         if (!ok) {
-            rs_fn = P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6> : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
+            rs_fn = P.Ks == 3 ? k_spd_resident<3> : P.Ks == 4 ? k_spd_resident<4> : P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6>
+                  : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
                  blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
         }
@@ -659,7 +661,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             }
             if (loop_np != 4) {
                 split_lds = split_loop_lds_bytes<512>(P.Ks, m);
-                split_fn = P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
+                split_fn = P.Ks == 3 ? k_admm_loop_split<3, 512> : P.Ks == 4 ? k_admm_loop_split<4, 512> : P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
                          : P.Ks == 7 ? k_admm_loop_split<7, 512> : (g_lu_dbg ? k_admm_loop_split<8, 512, true> : k_admm_loop_split<8, 512>);
                 if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
                     blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1 && 2 * B <= cus * per_cu)
@@ -679,7 +681,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             int dev = 0, cus = 0, per_cu = 0;
             split_nt = 512;
             split_lds = split_loop_lds_bytes<512>(P.Ks, m);
-            split_fn = P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
+            split_fn = P.Ks == 3 ? k_admm_loop_split<3, 512> : P.Ks == 4 ? k_admm_loop_split<4, 512> : P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
                      : P.Ks == 7 ? k_admm_loop_split<7, 512> : k_admm_loop_split<8, 512>;
             if (current_device_cus(&dev, &cus) && 2 * B > cus && split_lds <= 160 * 1024 &&
                 ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&

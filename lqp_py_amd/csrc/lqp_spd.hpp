@@ -1690,7 +1690,7 @@ __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, NT>& st, const Re
 // register-resident blocks per workgroup: 1024 threads (128 VGPRs each, 4 per block) keep 12 and the rest in LDS;
 // 512 threads (256 VGPRs each, 8 per block) keep all 18
 template <int NT> __host__ __device__ constexpr int split_rr() { return NT == 512 ? 18 : 12; }
-constexpr int SPLIT_MINK = 5;       // below that one workgroup holds the whole matrix in registers anyway
+constexpr int SPLIT_MINK = 3;       // (below that -- n <= 128 -- k_admm_loop_small holds the whole matrix in the registers of 256 threads)
 // NP workgroups per matrix (2, or 4 when 4 B <= #CUs: batches up to 64): column pair p = min(j, K-1-j) belongs to workgroup p % NP
 __host__ __device__ constexpr int split_owner(int j, int K, int NP = 2) { return (j < K - 1 - j ? j : K - 1 - j) & (NP - 1); }
 __host__ __device__ constexpr int split_count(int K, int part, int NP = 2) {
@@ -3141,6 +3141,8 @@ __device__ __forceinline__ void rs3_tile_of(int l, const int K, const int part, 
     }
 }
 constexpr int RS3_XW = 1024;        // floats between the panel slots (+ the late-rho words) and the W slots of the exchange buffer
+// (wg_spd_sweep_resident_v2 / _v4: two parities of K tiles + the words behind them)
+__host__ __device__ constexpr size_t rs2_xb_floats(int K) { return (size_t)2 * K * LQP_BLK + 64; }
 __host__ __device__ constexpr size_t rs3_xb_floats(int K) { return (size_t)2 * K * LQP_BLK + RS3_XW + (size_t)2 * 2 * LQP_BLK; }
 
 // xb: [2][K][4096] panel slots by step parity | 2 words of ||Qs||_F^2 (rho_late) | ... | [2][2][4096] W, W^T by pivot parity

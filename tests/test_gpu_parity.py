@@ -994,7 +994,7 @@ def test_split_factorisation_is_bit_identical_and_tracks_the_oracle(dev, monkeyp
     assert sols["1", 100.0]["_stats"]["n_factor"] >= 2
 
 
-@pytest.mark.parametrize("n,B,m", [(500, 4, 1), (333, 3, 2), (448, 2, 0), (449, 70, 1), (300, 5, 3), (512, 2, 16)])
+@pytest.mark.parametrize("n,B,m", [(500, 4, 1), (333, 3, 2), (448, 2, 0), (449, 70, 1), (300, 5, 3), (512, 2, 16), (250, 5, 2), (150, 6, 1), (129, 3, 0)])
 @pytest.mark.parametrize("rho", [None, 0.7])
 def test_pass_over_q_inside_the_resident_sweep(dev, monkeypatch, n, B, m, rho):
     """FwdParams::prep_fused == 3: no k_spd_prep launch -- the workgroups that keep the matrix in their registers read Q

@@ -23,8 +23,10 @@ OUT = os.path.join(CSRC, "split")
 
 # group -> predicate on the demangled name; first match wins.  Balanced by measured compile time (seconds at -O3).
 GROUPS = [
+    ("resident_c", lambda n: re.search(r"k_spd_resident<(3|4), 2>", n)),
     ("resident_a", lambda n: re.search(r"k_spd_resident<(5|6|7), 2>", n)),
     ("resident_b", lambda n: re.search(r"k_spd_resident<8, 2>|k_spd_resident<\d, 4>", n)),
+    ("split_c", lambda n: re.search(r"k_admm_loop_split<(3|4), 512, false, 2>", n)),
     ("split_a", lambda n: re.search(r"k_admm_loop_split<(5|6|7), 512, false, 2>", n)),
     ("split_b", lambda n: "k_admm_loop_split<" in n),
     ("loop_tail", lambda n: re.search(r"k_admm_loop<\w+, \w+, true,", n)),
@@ -45,6 +47,10 @@ EXTRA = [
     "void lqp::k_unroll_sweep<16>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_unroll_outer<0>(float const*, float const*, float*, int, int)",
     "void lqp::k_admm_loop_small<0>(lqp::FwdParams<float>, int, int, int)",
+    "void lqp::k_spd_resident<3, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<4, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_admm_loop_split<3, 512, false, 2>(lqp::FwdParams<float>, int, int, int)",
+    "void lqp::k_admm_loop_split<4, 512, false, 2>(lqp::FwdParams<float>, int, int, int)",
 ]
 
 
