@@ -348,6 +348,12 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
 // as the compiler emits the plain loop -- four instructions, two LDS reads into the same registers, wait, four instructions --
 // a wave that is alone on its SIMD stands through one LDS latency per group (measured: one matrix instruction per ~135
 // cycles instead of 64; two waves per SIMD hide it for each other).  Same products in the same order.
+// wg_spd_sweep_resident_v2: the tiles of row / column k+1 updated and published FIRST in step k (their write-through stores
+// would drain under the other tiles' updates).  Measured (round 4): correct, bit-identical, 113 instead of 64 spilled registers
+// (two passes over the slots) and 0.372 against 0.365 ms -- not the default.
+#ifndef LQP_RS2_EARLY_PUBLISH
+#define LQP_RS2_EARLY_PUBLISH 0
+#endif
 #ifndef LQP_QUAD_PF
 #define LQP_QUAD_PF 1
 #endif
@@ -2602,10 +2608,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
             // ---- every resident quadrant by its kind ----
             const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            auto update_slot = [&](const int s) {
                 const int i = ti[s], j = tj[s];
-                if (i < 0) continue;
                 if (i != k && j != k) {
                     const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
                     T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
@@ -2622,9 +2626,25 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     const int yo = j * 64 * SPD_LS + oj;
                     T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
                 }
-            }
+            };
+#if LQP_RS2_EARLY_PUBLISH
+            // first the tiles the partner waits for -- row / column k+1: the next pivot tile and panel -- and their stores at once:
+            // the write-through drains under the other tiles' updates instead of in front of the step's closing barrier
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (ti[s] >= 0 && (ti[s] == k + 1 || tj[s] == k + 1)) update_slot(s);
+            if (k + 1 < K) publish(k + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (ti[s] >= 0 && !(ti[s] == k + 1 || tj[s] == k + 1)) update_slot(s);
+            if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
+#else
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (ti[s] >= 0) update_slot(s);
             if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
             if (k + 1 < K) publish(k + 1);
+#endif
             if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
         }
         if (dbg && tid == 0)
