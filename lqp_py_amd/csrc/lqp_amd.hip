@@ -435,22 +435,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd_big_split = env_int("LQP_SPD_SPLIT", spd_big_split ? 1 : 0) != 0;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
-    // More matrices than half the CUs: the register-resident sweep with its pairs taking turns on the chip (one launch, 2 B
-    // workgroups; FwdParams::rs_turns).  Built, tested (LQP_SPD_TURNS=1) and NOT the default: the one-workgroup sweep streams
-    // every tile through L2 / HBM in every pivot step (B = 1024, n = 500: 9.7 GB per factorisation) and still is as fast --
-    // 2.91 ms against 8 turns x 0.36 = 2.9 ms + the equality correction in a launch of its own (0.2 ms): 3.13 ms (B = 256: 0.73
-    // against 0.80)
-    bool spd_turns = false;
-    if constexpr (sizeof(T) == 4) {
-        int dev_ = 0, cus_ = 0;
-        if (spd && !spd_split && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && P.xchg && B % 8 == 0 && current_device_cus(&dev_, &cus_) &&
-            B * SPD_NP > cus_ && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS && env_int("LQP_SPD_SPLIT", 1) != 0 &&
-            env_int("LQP_SPD_TURNS", 0) != 0) {
-            spd_turns = true;
-            spd_split = true;
-        }
-    }
-    P.rs_turns = spd_turns ? 1 : 0;
+    // (More matrices than half the CUs: the register-resident sweep with its pairs taking turns on the chip, as the loop does it
+    //  -- FwdParams::split_seg -- was built and measured in round 4: the one-workgroup sweep streams every tile through L2 / HBM
+    //  in every pivot step, 9.7 GB per factorisation at B = 1024, n = 500, and still is as fast: 2.91 ms against 8 turns x 0.36
+    //  ms + the equality correction in a launch of its own = 3.13 ms; B = 256: 0.73 against 0.80.  Not kept.)
     bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK &&
                         (size_t)P.Np * P.Np >= ((LQP_RS_V2 == 2 || LQP_RS_V2 == 4) ? rs2_xb_floats(P.Ks) : rs3_xb_floats(P.Ks)) &&
                         env_int("LQP_SPD_RESIDENT", 1) != 0;
@@ -474,7 +462,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             rs_fn = P.Ks == 3 ? k_spd_resident<3> : P.Ks == 4 ? k_spd_resident<4> : P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6>
                   : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
-                 blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && (spd_turns || B * SPD_NP <= cus_ * per_cu);
+                 blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
         }
         spd_resident = ok;
     }

@@ -43,7 +43,6 @@ template <typename T> struct FwdParams {
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
-    int rs_turns;                        // 1: k_spd_resident for a batch larger than half the CUs: its pairs take turns on the chip, mapped like split_seg
     int split_seg;                       // 1: k_admm_loop_split launched once per check segment for a batch LARGER than half the CUs (the
                                          //    pairs take their turns on the chip): workgroups 16 g + x and 16 g + 8 + x share problem 8 g + x
                                          //    (same XCD, neighbours in its dispatch queue), no verdict inside the kernel
@@ -1024,10 +1023,7 @@ template <int KS, int NP = 2>
 __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
-    // b and b + B: same XCD; with more pairs than fit the chip (rs_turns, NP == 2, B a multiple of 8): workgroups 16 g + x and
-    // 16 g + 8 + x share problem 8 g + x -- same XCD, neighbours in its dispatch queue (FwdParams::split_seg)
-    const int b = P.rs_turns ? 8 * ((int)blockIdx.x >> 4) + ((int)blockIdx.x & 7) : (int)blockIdx.x % P.B;
-    const int part = P.rs_turns ? ((int)blockIdx.x >> 3) & 1 : (int)blockIdx.x / P.B;
+    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD
     unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS + (size_t)XCHG_TAIL * b);
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
     RsLateRho lr;

@@ -2608,6 +2608,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
             // ---- every resident quadrant by its kind ----
             const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
+#if LQP_RS2_EARLY_PUBLISH
             auto update_slot = [&](const int s) {
                 const int i = ti[s], j = tj[s];
                 if (i != k && j != k) {
@@ -2627,7 +2628,6 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
                 }
             };
-#if LQP_RS2_EARLY_PUBLISH
             // first the tiles the partner waits for -- row / column k+1: the next pivot tile and panel -- and their stores at once:
             // the write-through drains under the other tiles' updates instead of in front of the step's closing barrier
 #pragma unroll
@@ -2640,8 +2640,26 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
 #else
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if (ti[s] >= 0) update_slot(s);
+            for (int s = 0; s < NS; ++s) {
+                const int i = ti[s], j = tj[s];
+                if (i < 0) continue;
+                if (i != k && j != k) {
+                    const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
+                    T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
+                } else if (i == k && j == k) {    // (W^T is upper triangular: rows >= 32 only see k >= 32 -- same halves,
+                                                  //  hence the same summation order and bits, as the multi-launch sweep)
+                    const f32x16 a = (qi | qj) ? spd_quadrant_lp<1>(yH + 32 + WTOFF + oi, yH + 32 + WTOFF + oj)
+                                               : spd_quadrant_lp<0>(yF + WTOFF, yF + WTOFF);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
+                } else if (j == k) {              // tile (i, k), i > k: Y_i W
+                    const int yo = (i - 1) * 64 * SPD_LS + oi;
+                    T[s] = qj == 1 ? spd_quadrant_lp<1>(yH + 32 + yo, yH + 32 + WTOFF + 32 * SPD_LS) : spd_quadrant_lp<0>(yF + yo, yF + WTOFF);
+                } else {                          // tile (k, j), j < k: W^T Y_j^T
+                    const int yo = j * 64 * SPD_LS + oj;
+                    T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
+                }
+            }
             if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
             if (k + 1 < K) publish(k + 1);
 #endif
