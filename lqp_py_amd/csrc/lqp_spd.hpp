@@ -351,6 +351,9 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
 // wg_spd_sweep_resident_v2: the tiles of row / column k+1 updated and published FIRST in step k (their write-through stores
 // would drain under the other tiles' updates).  Measured (round 4): correct, bit-identical, 113 instead of 64 spilled registers
 // (two passes over the slots) and 0.372 against 0.365 ms -- not the default.
+#ifndef LQP_QPASS_MD
+#define LQP_QPASS_MD 2
+#endif
 #ifndef LQP_RS2_EARLY_PUBLISH
 #define LQP_RS2_EARLY_PUBLISH 0
 #endif
@@ -2291,7 +2294,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 #pragma unroll
                 for (int q = 0; q < 16; ++q) dst[q] = (r0 + quad_row(q, lh) < n && col < n) ? dst[q] : 0.f;
             };
-            constexpr int MD = 3;                                   // mirrors requested ahead
+            constexpr int MD = LQP_QPASS_MD;                        // mirrors requested ahead (measured, group ms / spilled registers: 2: 0.358 / 31, 3: 0.360 / 63, 4: 0.378 / 125)
             f32x16 M[MD];
 #pragma unroll
             for (int s = 0; s < MD && s < NS; ++s)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lqp_py_amd as L
 from lqp_py_amd.synthetic import create_qp_data
 dev = torch.device("cuda:0")
-B, n = 128, 500
+B, n = int(os.environ.get("B", 128)), int(os.environ.get("N", 500))
 inp = [t.to(dev) for t in create_qp_data(n, B, seed=0)]
 ones = torch.ones(B, n, 1, device=dev)
 layer = L.SolveBoxQP(control=dict(L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5), sync=False))
