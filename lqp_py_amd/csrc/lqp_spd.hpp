@@ -358,7 +358,7 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
 #define LQP_RS2_EARLY_PUBLISH 0
 #endif
 #ifndef LQP_QUAD_PF
-#define LQP_QUAD_PF 1
+#define LQP_QUAD_PF (LQP_RS_V2 == 4)      // (the default sweep runs two waves per SIMD: pipe-bound either way, and 8 registers matter there)
 #endif
 template <int HALF = 0>
 __device__ __forceinline__ f32x16 spd_quadrant_lp(const float* __restrict__ xa, const float* __restrict__ zb) {
