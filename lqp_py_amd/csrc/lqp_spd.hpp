@@ -2644,7 +2644,10 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 #else
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const int i = ti[s], j = tj[s];
+                // (opaque per step: what the compiler can derive from a slot's tile indices alone -- lane addresses of its panel
+                //  rows -- it forms once before the step loop, one register per slot, and spills them with the tiles)
+                int i = ti[s], j = tj[s];
+                asm volatile("" : "+s"(i), "+s"(j));
                 if (i < 0) continue;
                 if (i != k && j != k) {
                     const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
