@@ -513,7 +513,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if constexpr (sizeof(T) == 4) {
             if (spd) {
                 const int lds = spd_factor_lds_bytes(m, P.Ks);
-                const int r2 = ensure_lds((const void*)k_spd_inverse<>, lds);
+                auto inv_fn = P.Ks > SPD_MAXK ? k_spd_inverse<2> : k_spd_inverse<1>;
+                const int r2 = ensure_lds((const void*)inv_fn, lds);
                 if (r2) return r2;
                 ProfScope ps(st, PC_SPD_INV);
                 if (spd_big_split) {
@@ -555,7 +556,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     n_launch += 2;
                     return LQP_OK;
                 }
-                hipLaunchKernelGGL(k_spd_inverse<>, dim3(B), dim3(LQP_NT), lds, st, P, gate);
+                hipLaunchKernelGGL(inv_fn, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                 ++n_launch;
                 return LQP_OK;
             }

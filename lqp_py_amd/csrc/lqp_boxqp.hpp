@@ -803,6 +803,9 @@ __device__ __forceinline__ void wg_eq_correct(const FwdParams<float>& P, const i
 // (re)factorisation of the symmetric path for problem b: Hs = -(Qs + rho I)^-1, then the equality correction.
 // check_sym: also verify that Qs is symmetric to rounding (the sweep only ever reads its lower triangle); a
 // matrix that is not goes to the LU path like one that is not positive definite.
+// SEL: 0 = any size (the continuation kernel's in-kernel refactorisation), 1 = n <= 512 only, 2 = above only: one sweep per
+// instance of k_spd_inverse -- with both inlined the register allocator spilled 236 registers
+template <int SEL = 0>
 __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const int b, const float rho, char* smem,
                                               const bool check_sym) {
     float* Hs = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
@@ -867,7 +870,7 @@ __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const i
     }
     wg_sym_init(Hs, Qs, ldq, P.n, P.Ks, rho, dsc);
     __syncthreads();
-    if (P.Ks > SPD_MAXK) wg_spd_sweep_big(Hs, P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np);   // (M: unused on this path)
+    if (SEL == 2 || (SEL == 0 && P.Ks > SPD_MAXK)) wg_spd_sweep_big(Hs, P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np);   // (M: unused on this path)
     else wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
     if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
     if (P.m > 0) {
@@ -879,12 +882,12 @@ __host__ __device__ inline int spd_factor_lds_bytes(int m, int Ks) {
     const int a = spd_lds_bytes(Ks > SPD_MAXK ? SPD_MAXK : Ks), c = m > 0 ? eqc_lds_bytes(m, Ks) : 0;
     return a > c ? a : c;
 }
-template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
+template <int SEL = 1>          // 1: n <= 512 (wg_spd_sweep), 2: 512 < n <= 1024 (wg_spd_sweep_big)
 __global__ __launch_bounds__(LQP_NT) void k_spd_inverse(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = blockIdx.x;
-    wg_spd_factor(P, b, P.scal[(size_t)b * SC_WORDS + SC_RHO], smem, gate == nullptr);
+    wg_spd_factor<SEL>(P, b, P.scal[(size_t)b * SC_WORDS + SC_RHO], smem, gate == nullptr);
 }
 
 // ---- the same factorisation spread over launches: with fewer problems than half the CUs, SPD_NP workgroups share

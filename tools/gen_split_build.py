@@ -51,6 +51,8 @@ EXTRA = [
     "void lqp::k_spd_resident<4, 2>(lqp::FwdParams<float>, int const*)",
     "void lqp::k_admm_loop_split<3, 512, false, 2>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_admm_loop_split<4, 512, false, 2>(lqp::FwdParams<float>, int, int, int)",
+    "void lqp::k_spd_inverse<1>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_inverse<2>(lqp::FwdParams<float>, int const*)",
 ]
 
 
@@ -58,6 +60,7 @@ EXTRA = [
 DROP = [
     "void lqp::k_unroll_sweep<0>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_lu_factor<float, 32, false, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, unsigned long long*, int const*)",
+    "void lqp::k_spd_inverse<0>(lqp::FwdParams<float>, int const*)",
 ]
 
 
