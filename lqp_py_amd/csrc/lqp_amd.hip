@@ -1503,10 +1503,11 @@ int lqp_spd_inverse_batched(void* stream, int dtype, int B, int n, const void* K
     float* Hs = c.take<float>((size_t)B * sym_blocks(Ks) * LQP_BLK);
     float* Yg = Ks > SPD_MAXK ? c.take<float>((size_t)B * (Ks - 1) * LQP_BLK) : nullptr;
     const int lds = spd_lds_bytes(Ks > SPD_MAXK ? SPD_MAXK : Ks);
-    int rc = ensure_lds((const void*)k_spd_inverse_dense<>, lds);
+    auto dense_fn = Ks > SPD_MAXK ? k_spd_inverse_dense<2> : k_spd_inverse_dense<1>;
+    int rc = ensure_lds((const void*)dense_fn, lds);
     if (rc) return rc;
     { ProfScope ps(st, PC_SPD_INV);
-      hipLaunchKernelGGL(k_spd_inverse_dense<>, dim3(B), dim3(LQP_NT), lds, st, (const float*)K_in, (float*)Kinv_out, Hs,
+      hipLaunchKernelGGL(dense_fn, dim3(B), dim3(LQP_NT), lds, st, (const float*)K_in, (float*)Kinv_out, Hs,
                          (int*)info_out, n, Ks, Yg); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }

@@ -668,7 +668,7 @@ __device__ __forceinline__ bool grid_wait(unsigned int* ctr, const unsigned int 
 // symmetric-inverse path (lqp_spd.hpp): factorisation kernels
 // ---------------------------------------------------------------------------
 // standalone SPD inverse (test / utility entry lqp_spd_inverse_batched): dense (B,n,n) in, dense inverse out
-template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
+template <int SEL = 1>          // 1: n <= 512 (wg_spd_sweep), 2: above (wg_spd_sweep_big): one sweep per instance, as k_spd_inverse
 __global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __restrict__ Kin, float* __restrict__ out,
                                                               float* __restrict__ Hs_all, int* __restrict__ info,
                                                               const int n, const int Ks, float* __restrict__ Yg_all) {
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __res
     if (tid == 0) info[b] = 0;
     wg_sym_init(Hs, Kin + (size_t)b * n * n, n, n, Ks, 0.f);
     __syncthreads();
-    if (Ks > SPD_MAXK) wg_spd_sweep_big(Hs, Ks, info + b, smem, Yg_all + (size_t)b * (Ks - 1) * LQP_BLK);
+    if constexpr (SEL == 2) wg_spd_sweep_big(Hs, Ks, info + b, smem, Yg_all + (size_t)b * (Ks - 1) * LQP_BLK);
     else wg_spd_sweep(Hs, Ks, info + b, smem);
     __syncthreads();
     float* o = out + (size_t)b * n * n;
@@ -854,22 +854,17 @@ __device__ __forceinline__ void wg_spd_factor(const FwdParams<float>& P, const i
             if (gr < n && r >= c4 && r < c4 + 4) Hs[(size_t)sym_idx(i, i, Ks) * LQP_BLK + tid * 4 + (r - c4)] += rho_here;
         }
         __syncthreads();
-        wg_spd_sweep(Hs, Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
-        if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;
-        if (P.m > 0) {
+    } else {
+        if (check_sym) {
+            float* red = (float*)smem;
+            const float asym = wg_sym_asymmetry(Qs, ldq, P.n, P.Ks, red, dsc);
+            if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
             __syncthreads();
-            wg_eq_correct(P, b, smem);
         }
-        return;
-    }
-    if (check_sym) {
-        float* red = (float*)smem;
-        const float asym = wg_sym_asymmetry(Qs, ldq, P.n, P.Ks, red, dsc);
-        if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
+        wg_sym_init(Hs, Qs, ldq, P.n, P.Ks, rho, dsc);
         __syncthreads();
     }
-    wg_sym_init(Hs, Qs, ldq, P.n, P.Ks, rho, dsc);
-    __syncthreads();
+    // (one sweep for both ways in: the blocks are in place either way)
     if (SEL == 2 || (SEL == 0 && P.Ks > SPD_MAXK)) wg_spd_sweep_big(Hs, P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np);   // (M: unused on this path)
     else wg_spd_sweep(Hs, P.Ks, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
     if (threadIdx.x == 0 && P.info[b] != 0) P.status[ST_NOTSPD] = 1;

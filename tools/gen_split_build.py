@@ -53,6 +53,8 @@ EXTRA = [
     "void lqp::k_admm_loop_split<4, 512, false, 2>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_spd_inverse<1>(lqp::FwdParams<float>, int const*)",
     "void lqp::k_spd_inverse<2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_inverse_dense<1>(float const*, float*, float*, int*, int, int, float*)",
+    "void lqp::k_spd_inverse_dense<2>(float const*, float*, float*, int*, int, int, float*)",
 ]
 
 
@@ -61,6 +63,7 @@ DROP = [
     "void lqp::k_unroll_sweep<0>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_lu_factor<float, 32, false, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, unsigned long long*, int const*)",
     "void lqp::k_spd_inverse<0>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_inverse_dense<0>(float const*, float*, float*, int*, int, int, float*)",
 ]
 
 
