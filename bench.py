@@ -34,7 +34,7 @@ N_SEEDS = 10                  # experiment_1.py: n_sims = 10, seed = simulation 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 INFINITY_CACHE_BYTES = 256 * 2 ** 20
-TRAFFIC_FILE = "profiles/r04_d_traffic.json"
+TRAFFIC_FILE = "profiles/r04_e_traffic.json"
 
 
 def parse():
