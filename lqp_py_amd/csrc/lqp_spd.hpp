@@ -350,7 +350,8 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
 // cycles instead of 64; two waves per SIMD hide it for each other).  Same products in the same order.
 // wg_spd_sweep_resident_v2: the tiles of row / column k+1 updated and published FIRST in step k (their write-through stores
 // would drain under the other tiles' updates).  Measured (round 4): correct, bit-identical, 113 instead of 64 spilled registers
-// (two passes over the slots) and 0.372 against 0.365 ms -- not the default.
+// (two passes over the slots) and 0.372 against 0.365 ms; with the tile indices opaque per step (one spilled register either
+// way) still 0.365 against 0.357 -- not the default.
 #ifndef LQP_QPASS_MD
 #define LQP_QPASS_MD 2
 #endif
@@ -2613,7 +2614,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
 #if LQP_RS2_EARLY_PUBLISH
             auto update_slot = [&](const int s) {
-                const int i = ti[s], j = tj[s];
+                int i = ti[s], j = tj[s];
+                asm volatile("" : "+s"(i), "+s"(j));        // (opaque per step: see the plain loop below)
                 if (i != k && j != k) {
                     const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
                     T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
