@@ -385,6 +385,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.host_report = (int*)ctl->host_report;
     if (P.host_report) report_reset(P.host_report, ST_WORDS + 2 * B);      // (before the first launch: see wait_report)
     P.xcd_local = env_int("LQP_XCD_LOCAL", 1) != 0 ? 1 : 0;
+    P.dbg_qpass = env_int("LQP_DBG_QPASS", 0) != 0 ? 1 : 0;
     P.zero_words = (int)(((char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status) / sizeof(int));
     P.dbg = g_lu_dbg;
     P.dbg_setup = nullptr;

@@ -39,6 +39,7 @@ template <typename T> struct FwdParams {
     int Ks, sym_rl, sym_rl_hot;          // symmetric-inverse path: 64-blocks of n, LDS-resident blocks of the loop
                                          // (continuation kernel / 512-thread first launch)
     unsigned long long* dbg;             // optional cycle counters (8 per problem), debug only
+    int dbg_qpass;                       // LQP_DBG_QPASS=1: the caller's debug buffer has a second half of B x 8 words for the stamps of the sweep's pass over Q
     unsigned long long* dbg_setup;       // the same words for k_fwd_setup's stamps (LQP_DBG_SETUP=1: then only those)
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
@@ -1033,6 +1034,7 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     lr.dsc = (fused && !qpass) ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
     lr.q = qpass ? P.Q + (size_t)b * P.n * P.n : nullptr;
     lr.cmx = qpass ? prep_scratch(P, b) : nullptr;
+    lr.qdbg = (qpass && P.dbg && P.dbg_qpass && part == 0) ? P.dbg + (size_t)(P.B + b) * 8 : nullptr;      // (LQP_DBG_QPASS=1: the debug buffer holds 2 B x 8 words)
     lr.fro_self = (fused && P.rho_mode == 0) ? 1 : 0;
     lr.rho_given = (fused && P.rho_mode != 0) ? P.scal[(size_t)b * SC_WORDS + SC_RHO] : 0.f;
     lr.xcd_local = P.xcd_local;

@@ -1962,6 +1962,7 @@ struct RsLateRho {
     // wg_spd_sweep_resident_v2 only -- the sweep makes the pass over the UNSCALED matrix itself (FwdParams::prep_fused == 3):
     const float* q;           // Q of this problem (n x n, row-major); nullptr: off
     float* cmx;               // global scratch of this problem: [NP][64 K + 2] words (column maxima | asymmetry | magnitude)
+    unsigned long long* qdbg; // optional: 8 cycle stamps of the pass (tools/gpu_resident_phases.py), workgroup 0 of the matrix
 };
 // (the scaling vector from the column maxima: supplied by the kernel, which knows the problem's parameters)
 //  scaling(red, d, work): every thread of the workgroup; red: n column maxima, d: n values out, work: 8 + RS_NW floats (LDS)
@@ -2270,7 +2271,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             //      scaling vector for itself (make_d: the same bits as k_fwd_setup).  LDS: the Y area, free until step 0. ----
             const int n = lr.n;
             const float* __restrict__ Qm = lr.q;
-            const unsigned long long qt0 = dbg ? clock64() : 0ull;
+            const unsigned long long qt0 = (dbg || lr.qdbg) ? clock64() : 0ull;
             unsigned int* cm = (unsigned int*)(Y + 64 * K);       // [64 K] column maxima as bit patterns (non-negative floats order like integers)
             float* redm = Y + 2 * 64 * K;                          // [512] the combined maxima, then the sort buffer of make_d (n padded to a power of two)
             float* redw = redm + 512;                              // [2 RS_NW] asymmetry / magnitude per wave
@@ -2351,6 +2352,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 }
             }
             if (dbg && tid == 0) dbg[7] = clock64() - qt0;         // (tiles + mirrors)
+            if (lr.qdbg && tid == 0) lr.qdbg[0] = clock64() - qt0;
             dmax = wave_max(dmax);
             vmax = wave_max(vmax);
             if (lane == 0) { redw[w] = dmax; redw[RS_NW + w] = vmax; }
@@ -2366,12 +2368,14 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                        // (every store of this workgroup has been acknowledged)
+            if (lr.qdbg && tid == 0) lr.qdbg[1] = clock64() - qt0;
             if (tid == 0) {
                 __hip_atomic_store(fl64 + 4 + part, ((unsigned long long)(epoch + 1u) << 8) | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int same = partners_on_my_xcd(true);
                 flag[1] = same && lr.xcd_local;
             }
             __syncthreads();
+            if (lr.qdbg && tid == 0) lr.qdbg[2] = clock64() - qt0;
             // (the partners' words: agent-scope loads, past this CU's L1)
             for (int i = tid; i < 64 * K; i += RS_NT) {
                 unsigned int v = cm[i];
@@ -2395,7 +2399,9 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 flag[2] = a > 1e-5f * v ? 1 : 0;                   // not symmetric (the rule of wg_sym_prep, over the whole matrix)
             }
             __syncthreads();
+            if (lr.qdbg && tid == 0) lr.qdbg[3] = clock64() - qt0;
             hooks.scaling(redm, Dl, work);                          // Dl[0 .. n): the scaling vector (every thread returns behind a barrier)
+            if (lr.qdbg && tid == 0) lr.qdbg[4] = clock64() - qt0;
             for (int i = n + tid; i < 64 * K; i += RS_NT) Dl[i] = 1.f;
             for (int i = tid; i < n; i += RS_NT) dkeep[i] = Dl[i];  // (the Y area goes to the panel of step 0)
             if (dbg && tid == 0) dbg[6] = clock64() - qt0;         // (... + exchange + scaling vector + deferred vectors)
