@@ -249,14 +249,25 @@ def main():
     #      step; the other nine are what a step on never-seen tensors costs (config.first_use_ms_per_step).  Nothing about
     #      a tensor is remembered between calls: whether any bound is finite (reference :33-38, a host decision there) is
     #      found by the setup kernel from the data of every call. ----
-    for _ in range(5):                    # (batch 0 alone: clocks, allocator and the pinned report pool of a fresh process --
-        step(0)                           #  tools/gpu_first_use.py: with ONE such step the nine first-use steps below are 6 %
-    sync()                                #  slower than the steady state, with five they equal it)
-    t_first = time.perf_counter()
-    for i in range(1, len(data)):
-        step(i)
-    sync()
-    first_use_ms = (time.perf_counter() - t_first) / (len(data) - 1) * 1e3
+    for _ in range(30):                   # (batch 0 alone: clocks, allocator and the pinned report pool of a fresh process --
+        step(0)                           #  tools/gpu_first_use.py: with ONE such step the nine first-use steps below are 6-8 %
+    sync()                                #  slower than the steady state, with thirty they equal it)
+    # nine steps are 6.6 ms: one hiccup of the box is 5 % of that.  Three rounds, each on FRESHLY ALLOCATED copies of batches
+    # 2..10 (never seen by the layer; the copies are made outside the clock), the median round is reported.
+    rounds = []
+    n_fresh = len(data) - 1
+    for _r in range(1 if args.config5 else 3):
+        fresh = [[t.clone() for t in data[i]] for i in range(1, len(data))]
+        sync()
+        t_first = time.perf_counter()
+        for d_ in fresh:
+            Q_, p_ = d_[0].requires_grad_(True), d_[1].requires_grad_(True)
+            out_ = layer(Q_, p_, *d_[2:])
+            (out_[0] if world > 1 else out_).backward(ones)
+        sync()
+        rounds.append((time.perf_counter() - t_first) / n_fresh * 1e3)
+        del fresh, d_, Q_, p_, out_
+    first_use_ms = sorted(rounds)[len(rounds) // 2]
     for i in range(args.warmup):
         step(i)
     # ---- timed region: exactly K steps, nothing else on the stream ----
@@ -389,7 +400,7 @@ def main():
                       "global_batch": B_total, "shard_sizes": shard_sizes,
                       "seeds": f"{len(data)} batches, seeds 0..{len(data) - 1}" + (" (one batch, cut)" if args.strong else " per rank") + ", cycled",
                       "first_use_ms_per_step": round(first_use_ms, 4),
-                      "first_use": "mean step time over batches 2..10 on their FIRST pass through the layer, after five warm-up steps on batch 1 alone (nothing is cached per tensor: the bound flags of :33-38 are found on the device in every call)",
+                      "first_use": "step time over freshly allocated copies of batches 2..10 on their FIRST pass through the layer (median of three such rounds of nine steps, after thirty warm-up steps on batch 1 alone; nothing is cached per tensor: the bound flags of :33-38 are found on the device in every call)",
                       "iters": iters, "checks": st_timed["n_check"], "launch_mode": st_timed["mode_used"],
                       "stats_source": "device status block of the last timed forward",
                       "sync": bool(args.sync), "linsolve": {1: "lu", 2: "spd"}[ls],

@@ -5,7 +5,7 @@ import os, sys, time, subprocess
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) < 2:
-    for k in (1, 5, 30):
+    for k in (1, 5, 30, 100):
         subprocess.run([sys.executable, os.path.abspath(__file__), str(k)])
     sys.exit(0)
 k = int(sys.argv[1])
