@@ -361,6 +361,14 @@ def workspace_uses(device, tag, stream):
         return _ws_uses.get((device.index, stream, tag), 0)
 
 
+def workspace_touch(device, tag, stream):
+    """Count a WRITE to the buffer of (device, stream, tag) that did not go through `workspace`: whoever left state there
+    before (see workspace_uses) must find the count changed."""
+    with _ws_lock:
+        key = (device.index, stream, tag)
+        _ws_uses[key] = _ws_uses.get(key, 0) + 1
+
+
 def release_workspaces(device=None):
     """Drop the cached scratch buffers (all devices, or one).  A long-lived process that used many streams holds one
     forward and one backward workspace per (device, stream); nothing else ever frees them.  Only call this when no

@@ -275,10 +275,13 @@ _seen_by_module = weakref.WeakKeyDictionary()
 _seen_by_dict_id = {}
 
 
-def _assume_any_bound(holder, control):
+def _assume_any_bound(holder, control, sync=True):
     if holder is not None:
         return _seen_by_module.get(holder)
-    return _seen_by_dict_id.get(id(control))
+    # CPython hands the address of a short-lived dict (box_qp_control(...) built per call) to the next one: an entry of the
+    # id table may belong to an unrelated dict.  A call that waits can afford that (it repeats itself on the other
+    # schedule); a pipelined one cannot (wrong schedule, invalid outputs, a late error): it looks at the bounds.
+    return _seen_by_dict_id.get(id(control)) if sync else None
 
 
 def _remember_any_bound(holder, control, any_bound):
@@ -372,7 +375,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     if known:
         any_bound = bool(bounds[0] or bounds[1])
     else:
-        any_bound = _assume_any_bound(holder, owner)
+        any_bound = _assume_any_bound(holder, owner, sync)
         if any_bound is None:                         # first solve of this layer
             if sync:
                 any_bound = True
@@ -640,6 +643,10 @@ def _fp_backward_run(prep, dl_dz):
     linsolve = prep['linsolve']
     if prep['pref'] is not None and prep['pref'] == _lib.workspace_uses(dev, "bwd", prep['stream']):
         linsolve |= _BWD_PREFACTORED                       # the factorisation made behind the forward is still in the workspace
+    # Every run writes the (shared, cached) backward workspace: a full run rebuilds free set, factor and info words in it, the
+    # solve phase its right-hand sides.  Whoever prefactored into the same buffer earlier (forward A, forward B, backward A,
+    # backward B: B's factor is overwritten by A's full run) must see the count move and run in full too.
+    _lib.workspace_touch(dev, "bwd", prep['stream'])
     with _lib.on_device(dev):
         st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *prep['tail'], linsolve, prep['rep'])
     if st == 3:

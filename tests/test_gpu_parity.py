@@ -551,6 +551,37 @@ def test_backward_factorisation_ahead_of_the_cotangent(dev, monkeypatch, n, B, m
             assert torch.equal(a0, a1) and torch.equal(a0, a2)
 
 
+def test_prefactored_backwards_in_forward_order(dev, monkeypatch):
+    """forward A, forward B, backward A, backward B on DIFFERENT data of one shape and one stream: A's backward
+    finds the shared workspace taken by B's prefactor and runs in full -- which overwrites B's free set and factor.  B's
+    backward must notice (the count of writes moved) and run in full too, never solve with A's factor."""
+    n, B = 96, 8
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(5)).to(dev)
+    data = [O.create_qp_data(n, B, seed=s) for s in (11, 12)]
+
+    def leaves_of(d):
+        return [t.clone().to(dev).requires_grad_(True) for t in d]
+
+    def alone(d):
+        monkeypatch.setattr(SB, "_PREFACTOR_BWD", False)
+        lv = leaves_of(d)
+        L.SolveBoxQP(control=L.box_qp_control(**TOL))(*lv).backward(cot)
+        return [t.grad for t in lv]
+
+    ref = [alone(d) for d in data]
+    monkeypatch.setattr(SB, "_PREFACTOR_BWD", True)
+    la, lb_ = leaves_of(data[0]), leaves_of(data[1])
+    layer = L.SolveBoxQP(control=L.box_qp_control(**TOL))
+    xa = layer(*la)
+    xb = layer(*lb_)
+    xa.backward(cot)
+    xb.backward(cot)
+    torch.cuda.synchronize()
+    for got, want in ((la, ref[0]), (lb_, ref[1])):
+        for t, w in zip(got, want):
+            assert torch.equal(t.grad, w)
+
+
 def test_backward_factorisation_ahead_of_the_cotangent_falls_back(dev):
     """... and on the C ABI: prefactor + solve-only call == one call; a factorisation that failed ends in the LU retry."""
     lib = _lib.load()
