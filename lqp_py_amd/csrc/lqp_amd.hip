@@ -162,9 +162,33 @@ int launch_lu_big(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, in
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
+// Two workgroups per matrix (lqp_lu2.hpp) when the batch leaves half the chip idle: N <= 512, at least three column blocks, 2 B
+// workgroups resident (they wait for each other inside the launch), and the caller has 8 * LU2_SCR_WORDS bytes of scratch per
+// problem (`scr`, problem b at scr + b * scr_stride words).  Returns -1: not applicable, take the one-workgroup kernel.
+std::atomic<unsigned int> g_lu2_epoch{(unsigned int)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
+template <typename T>
+int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
+               const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
+    constexpr int PB = lu2_panel_width<T>();
+    if (!scr || scr_stride < (size_t)LU2_SCR_WORDS || N > 512 || N < 3 * PB || env_int("LQP_LU2", 1) == 0) return -1;
+    int dev = 0, cus = 0, per_cu = 0;
+    auto fn = k_lu_factor2<T, PB>;
+    const int lds = Lu2Lds<T, PB>(round_up(N, 64)).total;
+    if (!current_device_cus(&dev, &cus) || ensure_lds((const void*)fn, lds) != LQP_OK ||
+        !blocks_per_cu(&per_cu, fn, LU2_NT, lds, dev) || per_cu < 1 || 2 * B > cus * per_cu)
+        return -1;
+    const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
+    { ProfScope ps(st, PC_LU);
+      hipLaunchKernelGGL(fn, dim3(2 * B), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
+                         scr_stride, epoch, g_lu_dbg, B); }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
-              const int* gate, const int* nvec = nullptr) {
+              const int* gate, const int* nvec = nullptr, unsigned long long* scr = nullptr, size_t scr_stride = 0) {
     if (N > 1024) return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
+    { const int r2 = launch_lu2<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
+      if (r2 >= 0) return r2; }
     const int la = env_int("LQP_LU_LA", 0);       // lookahead variants (see lqp_lu.hpp): 1 = 16 columns / 1024
     if (N <= 512 && N > 64 && la != 0) {           // threads, 2 = 32 columns / 768 threads (8 + 4 waves)
         int rc;
@@ -204,8 +228,10 @@ int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, in
 #undef LQP_LU_CASE
 }
 int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
-              const int* gate, const int* nvec = nullptr) {
+              const int* gate, const int* nvec = nullptr, unsigned long long* scr = nullptr, size_t scr_stride = 0) {
     if (N > 1024) return launch_lu_big<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
+    { const int r2 = launch_lu2<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
+      if (r2 >= 0) return r2; }
     const int nt = lu_threads<double>(N);
     const int pb = lu_panel_width<double>(N);
 #define LQP_LU_CASE(PBV, NTV) return launch_lu_impl<double, PBV, false, NTV>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
@@ -562,7 +588,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 return LQP_OK;
             }
         }
-        int r2 = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, gate);
+        // (scratch of the two-workgroup LU: the head of each problem's packed area -- the pack kernel fills it afterwards)
+        const size_t pk_words = packed_blocks(P.K) * LQP_BLK * sizeof(T) / 8;
+        int r2 = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, gate, nullptr,
+                           (unsigned long long*)P.packed, pk_words);
         if (r2) return r2;
         r2 = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, gate);
         n_launch += 2;
@@ -1087,7 +1116,8 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     }
     int rc = LQP_OK;
     if (!chol) {
-        rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec);
+        rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec,
+                       (unsigned long long*)P.packed, packed_blocks(P.K) * LQP_BLK * sizeof(T) / 8);
         if (rc) return rc;
         rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr, nvec);
         if (rc) return rc;
@@ -1138,22 +1168,23 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
 // LU / solve / KKT entry points
 // ---------------------------------------------------------------------------
 template <typename T>
-size_t carve_lu(void* ws, int B, int N, T*& M, int*& piv) {
+size_t carve_lu(void* ws, int B, int N, T*& M, int*& piv, unsigned long long*& scr) {
     const int Np = round_up(N, LQP_NB);
     Carver c(ws);
     piv = c.take<int>((size_t)B * Np);
     M = c.take<T>((size_t)B * Np * Np);
+    scr = c.take<unsigned long long>((size_t)B * LU2_SCR_WORDS);      // (hand-off words of the two-workgroup LU)
     return c.off + kAlign;
 }
 
 template <typename T>
 int lu_factor_impl(hipStream_t st, int B, int N, void* Mio, int32_t* piv_out, int32_t* info_out, void* ws, size_t ws_bytes) {
-    T* M; int* piv;
-    const size_t need = carve_lu<T>(ws, B, N, M, piv);
+    T* M; int* piv; unsigned long long* scr;
+    const size_t need = carve_lu<T>(ws, B, N, M, piv, scr);
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
     const int Np = round_up(N, LQP_NB);
     hipLaunchKernelGGL(k_copy_matrix<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)Mio, N, (size_t)N * N, M, Np, (size_t)Np * Np, N);
-    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info_out, nullptr);
+    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info_out, nullptr, nullptr, scr, LU2_SCR_WORDS);
     if (rc) return rc;
     hipLaunchKernelGGL(k_copy_matrix<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)M, Np, (size_t)Np * Np, (T*)Mio, N, (size_t)N * N, N);
     hipLaunchKernelGGL(k_copy_ints<int>, dim3(B), dim3(256), 0, st, (const int*)piv, Np, (int*)piv_out, N, N);
@@ -1209,7 +1240,8 @@ int kkt_solve_impl(hipStream_t st, int B, int n, int m, const void* Q, const voi
     const int N = n + m, Np = round_up(N, LQP_NB);
     hipLaunchKernelGGL(k_kkt_build<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)Q, (const T*)p, (const T*)A, (const T*)b,
                        n, m, Np, M, rhs, info);
-    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info, nullptr);
+    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info, nullptr, nullptr, (unsigned long long*)packed,
+                       packed_blocks(Np / LQP_NB) * LQP_BLK * sizeof(T) / 8);
     if (rc) return rc;
     rc = launch_pack<T>(st, B, M, N, Np, (size_t)Np * Np, piv, Np, packed, dest, nullptr);
     if (rc) return rc;
@@ -1515,9 +1547,9 @@ int lqp_spd_inverse_batched(void* stream, int dtype, int B, int n, const void* K
 
 size_t lqp_lu_factor_workspace_bytes(int dtype, int B, int N) {
     if (bad_dims(dtype, B, N, 0)) return 0;
-    int* piv;
-    if (dtype == LQP_F32) { float* M; return carve_lu<float>(nullptr, B, N, M, piv); }
-    double* M; return carve_lu<double>(nullptr, B, N, M, piv);
+    int* piv; unsigned long long* scr;
+    if (dtype == LQP_F32) { float* M; return carve_lu<float>(nullptr, B, N, M, piv, scr); }
+    double* M; return carve_lu<double>(nullptr, B, N, M, piv, scr);
 }
 
 int lqp_lu_factor_batched(void* stream, int dtype, int B, int N, void* M_inout, int32_t* piv_out, int32_t* info_out,

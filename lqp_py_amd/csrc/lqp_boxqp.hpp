@@ -5,6 +5,7 @@
 #include "lqp_common.hpp"
 #include "lqp_lu.hpp"
 #include "lqp_lu_big.hpp"
+#include "lqp_lu2.hpp"
 #include "lqp_trsv.hpp"
 #include "lqp_spd.hpp"
 
@@ -567,6 +568,24 @@ __global__ __launch_bounds__(NT) void k_lu_factor(T* __restrict__ Mall, const in
     const int Nb = Nvec ? Nvec[b] : N;            // per-problem size (reduced backward systems)
     wg_lu_factor<T, PB, MFMA, NT>(Mall + (size_t)b * mstride, Nb, ld, piv + (size_t)b * pstride, info + b, smem,
                               dbg ? dbg + (size_t)b * 4 : nullptr);
+}
+
+// two workgroups per matrix (lqp_lu2.hpp; N <= 512, 2 B workgroups resident): workgroups b and b + B share matrix b
+template <typename T, int PB>
+__global__ __launch_bounds__(LU2_NT) void k_lu_factor2(T* __restrict__ Mall, const int N, const int ld, const size_t mstride,
+                                                       int* __restrict__ piv, const int pstride, int* __restrict__ info,
+                                                       const int* __restrict__ gate, const int* __restrict__ Nvec,
+                                                       unsigned long long* __restrict__ scr, const size_t scr_stride,
+                                                       const unsigned int epoch, unsigned long long* __restrict__ dbg,
+                                                       const int B) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    if (gate && *gate == 0) return;
+    const int b = (int)blockIdx.x % B, me = (int)blockIdx.x / B;
+    const int Nb = Nvec ? Nvec[b] : N;
+    if (threadIdx.x == 0 && me == 0) info[b] = 0;
+    __syncthreads();
+    wg_lu_factor2<T, PB>(Mall + (size_t)b * mstride, Nb, ld, piv + (size_t)b * pstride, info + b, smem, me,
+                         scr + (size_t)b * scr_stride, epoch, (dbg && me == 0) ? dbg + (size_t)b * 8 : nullptr);
 }
 
 // 1024 < N <= 2048: two panel rows per thread (lqp_lu_big.hpp)

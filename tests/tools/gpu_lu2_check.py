@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Two-workgroup LU (csrc/lqp_lu2.hpp) against the one-workgroup kernel (bit for bit) and LAPACK (pivots), timing and
+in-kernel phase counters.  Usage: gpu_lu2_check.py [f32|f64] [N ...]"""
+import os, sys
+os.environ.setdefault("LQP_ENV_NOCACHE", "1")
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from lqp_py_amd import _lib, lu_layer
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+dt = torch.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else torch.float32
+sizes = [int(a) for a in sys.argv[2:]] or [501, 317, 266, 130, 512, 97, 200]
+B = int(os.environ.get("LU_B", "128"))
+PH = ["wait", "recv", "next-cols", "panel", "publish", "swaps+U12", "trailing", "total"]
+
+
+def kkt_like(N, gen):
+    n = N - max(1, N // 20)
+    G = torch.randn(B, n, n, generator=gen, dtype=torch.float64)
+    Q = G.transpose(1, 2) @ G / n + 0.5 * torch.eye(n, dtype=torch.float64)
+    A = torch.randn(B, N - n, n, generator=gen, dtype=torch.float64)
+    M = torch.zeros(B, N, N, dtype=torch.float64)
+    M[:, :n, :n] = Q; M[:, n:, :n] = A; M[:, :n, n:] = A.transpose(1, 2)
+    return M.to(dt).to(dev)
+
+
+def timed(M, reps=5):
+    lu_layer.lu_factor(M); torch.cuda.synchronize()
+    _lib.profile(enable=True, reset=True)
+    for _ in range(reps):
+        LU, P = lu_layer.lu_factor(M)
+    torch.cuda.synchronize()
+    pr = _lib.profile(); _lib.profile(enable=False)
+    return LU, P, pr["lu_factor"][0] / pr["lu_factor"][1] * 1e3
+
+
+ok = True
+for N in sizes:
+    gen = torch.Generator().manual_seed(N)
+    M = kkt_like(N, gen)
+    os.environ["LQP_LU2"] = "0"
+    LU1, P1, us1 = timed(M)
+    os.environ["LQP_LU2"] = "1"
+    LU2, P2, us2 = timed(M)
+    dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
+    lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
+    lu_layer.lu_factor(M); torch.cuda.synchronize()
+    lib.lqp_debug_set_lu_counters(None)
+    c = dbg.view(B, 8).double().mean(0).tolist()
+    LUr, Pr = torch.linalg.lu_factor(M.cpu())
+    same_p = bool(torch.equal(P1.cpu(), P2.cpu())); lap_p = bool(torch.equal(P2.cpu().int(), Pr.int()))
+    diff = float((LU1 - LU2).abs().max())
+    Pm, Lm, Um = torch.lu_unpack(LU2.cpu(), P2.cpu())
+    rec = float((Pm @ Lm @ Um - M.cpu()).abs().max())
+    Pm1, Lm1, Um1 = torch.lu_unpack(LU1.cpu(), P1.cpu())
+    rec1 = float((Pm1 @ Lm1 @ Um1 - M.cpu()).abs().max())
+    # (the block right of a panel is updated in registers -- one FMA per term -- where the one-workgroup kernel subtracts a matrix-core
+    #  sum: same factorisation to rounding, not the same bits; float32 pivots may then differ on near ties)
+    good = rec <= 2 * rec1 + 1e-12 and (lap_p or dt == torch.float32)
+    ok = ok and good
+    print(f"{dt} N={N}: one-wg {us1:7.1f} us  two-wg {us2:7.1f} us | pivots == one-wg {same_p}, == LAPACK {lap_p}; max|LU1-LU2| {diff:.1e}; "
+          f"|PLU-M| {rec:.1e} (one-wg {rec1:.1e}) | " + " ".join(f"{k} {v/1e3:.0f}k" for k, v in zip(PH, c)), flush=True)
+# a singular matrix: info as the one-workgroup kernel reports it
+N = 200
+M = kkt_like(N, torch.Generator().manual_seed(1)); M[:, :, 70] = 0
+for flag in ("0", "1"):
+    os.environ["LQP_LU2"] = flag
+    try:
+        lu_layer.lu_factor(M); print("LU2=" + flag, "no error?!"); ok = False
+    except RuntimeError as e:
+        print("LU2=" + flag, "->", str(e)[:100])
+print("ALL OK" if ok else "MISMATCH")
+if os.environ.get("LU2_DIAG"):
+    import ctypes
+    def raw(M):
+        Bq, N = M.shape[0], M.shape[1]
+        LU = M.clone().contiguous(); piv = torch.zeros((Bq, N), dtype=torch.int32, device=dev); info = torch.zeros((Bq,), dtype=torch.int32, device=dev)
+        dtc = _lib.dtype_code(M)
+        ws = torch.empty(int(lib.lqp_lu_factor_workspace_bytes(dtc, Bq, N)), dtype=torch.uint8, device=dev)
+        st = lib.lqp_lu_factor_batched(_lib.stream_ptr(dev), dtc, Bq, N, _lib.ptr(LU), _lib.ptr(piv), _lib.ptr(info), _lib.ptr(ws), ws.numel())
+        torch.cuda.synchronize()
+        return LU, piv, info, st
+    for N in [int(a) for a in os.environ["LU2_DIAG"].split(",")]:
+        M = kkt_like(N, torch.Generator().manual_seed(N))
+        os.environ["LQP_LU2"] = "0"; LU1, P1, i1, s1 = raw(M)
+        os.environ["LQP_LU2"] = "1"; LU2, P2, i2, s2 = raw(M)
+        PBd = 32 if dt == torch.float32 else 16
+        nb = (N + PBd - 1) // PBd
+        bad = [b for b in range(B) if not torch.equal(LU1[b], LU2[b])]
+        print(f"N={N}: status {s1} {s2}; info1 nonzero {int((i1 != 0).sum())}, info2 nonzero {int((i2 != 0).sum())} first {i2[:8].tolist()}; problems that differ: {len(bad)} of {B}: {bad[:10]}")
+        b0 = bad[0] if bad else 0
+        d = (LU1 - LU2).abs()[b0].cpu()
+        print(" problem", b0, "pivots equal per block:", [bool(torch.equal(P1[b0, i*PBd:(i+1)*PBd], P2[b0, i*PBd:(i+1)*PBd])) for i in range(nb)])
+        for i in range(nb):
+            print("  " + " ".join(f"{float(torch.nan_to_num(d[i*PBd:(i+1)*PBd, j*PBd:(j+1)*PBd], nan=9e9).max()):8.1e}" for j in range(nb)))
+        if N == 97:
+            torch.set_printoptions(precision=4, linewidth=200)
+            print("rows of block (0,0) that differ:", [i for i in range(32) if float(d[i, :32].max()) > 0])
+            print("cols of block (0,0) that differ:", [j for j in range(32) if float(d[:32, j].max()) > 0])
+            print("LU1\n", LU1[b0, :6, :6].cpu(), "\nLU2\n", LU2[b0, :6, :6].cpu(), "\nP1", P1[b0, :32].tolist())
+            r = 0
+            for i in range(N):
+                for i2 in range(N):
+                    if float((LU2[b0, i, :32] - LU1[b0, i2, :32]).abs().max()) == 0 and i != i2:
+                        r += 1
+                        if r < 12: print(f"  LU2 row {i} (cols 0..31) == LU1 row {i2}")

@@ -31,6 +31,7 @@ GROUPS = [
     ("split_b", lambda n: "k_admm_loop_split<" in n),
     ("loop_tail", lambda n: re.search(r"k_admm_loop<\w+, \w+, true,", n)),
     ("loop_hot", lambda n: "k_admm_loop<" in n),
+    ("lu2", lambda n: "k_lu_factor2<" in n),
     ("lu_a", lambda n: re.search(r"k_lu_factor<float, (32|16), true|k_lu_factor_la|k_lu_factor_big", n)),
     ("lu_b", lambda n: "k_lu_factor<" in n),
     ("spd", lambda n: re.search(r"k_spd_|k_bwd_chol_solve|k_bwd_build_chol", n)),
@@ -41,6 +42,8 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
+    "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
+    "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
     "void lqp::k_lu_factor_big<float>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_lu_factor_big<double>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_unroll_sweep<1>(lqp::FwdParams<float>, lqp::UnrollParams)",
