@@ -180,7 +180,7 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
     const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
     { ProfScope ps(st, PC_LU);
       hipLaunchKernelGGL(fn, dim3(2 * B), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
-                         scr_stride, epoch, g_lu_dbg, B); }
+                         scr_stride, epoch, g_lu_dbg, B, env_int("LQP_XCD_LOCAL", 1) != 0 ? 1 : 0); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(LU2_NT) void k_lu_factor2(T* __restrict__ Mall, con
                                                        const int* __restrict__ gate, const int* __restrict__ Nvec,
                                                        unsigned long long* __restrict__ scr, const size_t scr_stride,
                                                        const unsigned int epoch, unsigned long long* __restrict__ dbg,
-                                                       const int B) {
+                                                       const int B, const int xlocal_ok) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
     const int b = (int)blockIdx.x % B, me = (int)blockIdx.x / B;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(LU2_NT) void k_lu_factor2(T* __restrict__ Mall, con
     if (threadIdx.x == 0 && me == 0) info[b] = 0;
     __syncthreads();
     wg_lu_factor2<T, PB>(Mall + (size_t)b * mstride, Nb, ld, piv + (size_t)b * pstride, info + b, smem, me,
-                         scr + (size_t)b * scr_stride, epoch, (dbg && me == 0) ? dbg + (size_t)b * 8 : nullptr);
+                         scr + (size_t)b * scr_stride, epoch, xlocal_ok != 0, (dbg && me == 0) ? dbg + (size_t)b * 16 : nullptr);
 }
 
 // 1024 < N <= 2048: two panel rows per thread (lqp_lu_big.hpp)

@@ -29,16 +29,17 @@ constexpr int LU2_NW = LU2_NT / 64;
 constexpr int LU2_PW = 4;                    // waves that hold panel rows
 constexpr int LU2_MSG = 128;                 // ints per message: [0] ne, [1] first zero pivot (1-based; 0: none), [2, 2+PB) src of the new
                                              // top rows, [34, 34+PB) xdst, [66, 66+PB) xsrc  (PB <= 32)
-constexpr int LU2_SCR_WORDS = 8 + LU2_MSG;   // 64-bit words per problem: [0], [1] panels published by workgroup 0 / 1
+constexpr int LU2_SCR_WORDS = 8 + LU2_MSG;   // 64-bit words per problem: [0], [1] panels published by workgroup 0 / 1; [2], [3] their XCDs
                                              // {launch epoch : 32 | count : 32}; [8..): two messages of LU2_MSG ints
 
 template <typename T, int PB> struct Lu2Lds {
-    int lt, up, l11, rowp, wval, wrcp, widx, wtid, pidx, src, xdst, xsrc, pxdst, pxsrc, cnt, total;
+    int lt, up, l11, lit, rowp, wval, wrcp, widx, wtid, pidx, src, xdst, xsrc, pxdst, pxsrc, cnt, total;
     __host__ __device__ explicit Lu2Lds(int Mpad) {
         int o = 0;
         lt = o;   o += PB * Mpad * (int)sizeof(T);
         up = o;   o += PB * Mpad * (int)sizeof(T);
-        l11 = o;  o += round_up(PB * (PB + 1) * (int)sizeof(T), 32);
+        l11 = o;
+        lit = o;  o += PB * PB * (int)sizeof(T);       // (L11^-1)^T: [k * PB + i] = Linv[i][k], the A operand of the U12 products
         rowp = o; o += 2 * LU2_PW * PB * (int)sizeof(T);
         wval = o; o += round_up(2 * LU2_PW * (int)sizeof(T), 32);
         wrcp = o; o += round_up(2 * LU2_PW * (int)sizeof(T), 32);
@@ -102,6 +103,38 @@ __device__ __forceinline__ V4<double> ld_vec_sc1(const double* p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v.v[e] = ld_sc1(p + e);
     return v;
+}
+
+// one 128-byte row another workgroup has published: eight 16-byte sc1 loads (past this CU's L1) in flight at once.  Issued
+// from inline assembly (the compiler has no 16-byte agent-scope load), so the wait is explicit and carries the registers.
+__device__ __forceinline__ void ld_row128_sc1(const void* p, u32x4 (&v)[8]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:96 sc1\n\t"
+                 "global_load_dwordx4 %7, %8, off offset:112 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p) : "memory");
+}
+template <typename T, int PB> __device__ __forceinline__ void row128_unpack(const u32x4 (&v)[8], T (&r)[PB]) {
+    static_assert(PB * sizeof(T) == 128, "a panel row is 128 bytes");
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const unsigned int u = v[c >> 2][c & 3];      // (a bit_cast straight from the vector element yields element 0: hipcc 7.2)
+            r[c] = __uint_as_float(u);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const unsigned int lo = v[c >> 1][2 * (c & 1)], hi = v[c >> 1][2 * (c & 1) + 1];
+            r[c] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+        }
+    }
 }
 
 // f64 trailing update on the matrix cores: v_mfma_f64_16x16x4_f64, D = C - L21 U12 over one 16x16 tile.
@@ -191,39 +224,140 @@ __device__ __forceinline__ void lu2_trailing(T* __restrict__ A22, const int ld, 
     }
 }
 
-// the interchanges of a panel applied to column `col` (rows k0 ..), and -- `right` -- U12 = L11^-1 (P A)12 of that column
-// into UP[j * Mpad + ucol] and back to the matrix (what wg_lu_factor does per thread; same operations in the same order)
+// (L11^-1)^T by the wave whose lanes 0 .. PB-1 hold the rows of the panel's top block (lane i, register j: L[i][j]): lane c
+// carries column c of the inverse of the unit lower triangle; L[i][j] reaches every lane as a scalar (v_readlane), so the
+// substitution is 2 instructions per term with no memory operand (through LDS broadcast reads the 496 terms of a 32-wide
+// panel waited ~240 times for the LDS: 23 k cycles per panel).  The U12 of every column then is a plain product, and those
+// run on the matrix cores.
 template <typename T, int PB>
-__device__ __forceinline__ void lu2_swap_u12_column(T* __restrict__ A, const int ld, const int k0, const int pb, const int col,
-                                                    const bool right, const int ucol, const int ne, const int* __restrict__ src,
-                                                    const int* __restrict__ xdst, const int* __restrict__ xsrc,
-                                                    const T* __restrict__ L11, T* __restrict__ UP, const int Mpad) {
+__device__ __forceinline__ void lu2_invert_l11(const T (&r)[PB], T* __restrict__ LIT) {
+    const int c = threadIdx.x & 63;
+    T x[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) x[i] = (i == c) ? T(1) : T(0);
+#pragma unroll
+    for (int j = 0; j < PB - 1; ++j) {
+        const T xj = x[j];
+#pragma unroll
+        for (int i = j + 1; i < PB; ++i) x[i] -= readlane_t(r[j], i) * xj;
+    }
+    if (c < PB) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) LIT[c * PB + i] = x[i];
+    }
+}
+
+// One tile = the PB columns of one block.  Lane l: column l % PB, k-group l / PB (G = 64 / PB groups = the k-depth of one
+// matrix instruction: f32 32x32x2, f64 16x16x4).
+template <typename T, int PB> struct Lu2Tile {
+    static constexpr int G = 64 / PB;
+    T b[PB / G];             // rows lu2_tile_row(kk, group) of (P A)12, this lane's column
+    int cb;                  // block (-1: none)
+    bool right;
+};
+// f64: the B operand of v_mfma_f64_16x16x4 (row 4 kk + group); f32: the ACCUMULATOR layout of v_mfma_f32_32x32x2 (register kk of
+// lane group g: row (kk & 3) + 8 (kk >> 2) + 4 g) -- the f32 tile is solved in place, see lu2_tile_finish
+template <typename T, int PB> __device__ __forceinline__ constexpr int lu2_tile_row(const int kk, const int lg) {
+    return sizeof(T) == 4 ? (kk & 3) + 8 * (kk >> 2) + 4 * lg : (64 / PB) * kk + lg;
+}
+
+// interchanges of panel k on the tile's columns: the new top rows into registers (gather map `src`), the displaced top rows
+// down to their new places.  Only this wave touches these columns.
+template <typename T, int PB>
+__device__ __forceinline__ void lu2_tile_load(Lu2Tile<T, PB>& t, T* __restrict__ A, const int ld, const int N, const int k0,
+                                              const int pb, const int ne, const int* __restrict__ src,
+                                              const int* __restrict__ xdst, const int* __restrict__ xsrc) {
+    constexpr int G = 64 / PB;
+    if (t.cb < 0) return;
+    const int lane = threadIdx.x & 63, li = lane % PB, lg = lane / PB;
+    const int col = t.cb * PB + li;
+    const bool colok = col < N;
     T* Ac = A + (size_t)k0 * ld + col;
-    T top[PB];
 #pragma unroll
-    for (int j = 0; j < PB; ++j)
-        top[j] = (j < pb) ? Ac[(size_t)__builtin_amdgcn_readfirstlane(src[j]) * ld] : T(0);
-    for (int q0 = 0; q0 < ne; q0 += 8) {
-        T ext[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            ext[q] = (q0 + q < ne) ? Ac[(size_t)__builtin_amdgcn_readfirstlane(xsrc[q0 + q]) * ld] : T(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (q0 + q < ne) Ac[(size_t)__builtin_amdgcn_readfirstlane(xdst[q0 + q]) * ld] = ext[q];
+    for (int kk = 0; kk < PB / G; ++kk) {
+        const int kr = lu2_tile_row<T, PB>(kk, lg);
+        t.b[kk] = (kr < pb && colok) ? Ac[(size_t)src[kr] * ld] : T(0);
     }
-    if (right) {
+    // (all old rows first -- at most PB / G per lane --, ONE wait, then the stores: a wait per chunk cost a memory round trip each)
+    T ext[PB / G];
 #pragma unroll
-        for (int j = 0; j < PB; ++j) {
+    for (int q = 0; q < PB / G; ++q) {
+        const int e = G * q + lg;
+        ext[q] = (e < ne && colok) ? Ac[(size_t)xsrc[e] * ld] : T(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (every load of the old rows before the first store)
 #pragma unroll
-            for (int i = j + 1; i < PB; ++i) top[i] -= L11[i * (PB + 1) + j] * top[j];
+    for (int q = 0; q < PB / G; ++q) {
+        const int e = G * q + lg;
+        if (e < ne && colok) Ac[(size_t)xdst[e] * ld] = ext[q];
+    }
+}
+
+// right of the panel: U12 = L11^-1 (P A)12 on the matrix cores, to the matrix and to UP (row i at i * Mpad, column relative
+// to k1); left of it: the new top rows go back as they are
+template <typename T, int PB>
+__device__ __forceinline__ void lu2_tile_finish(const Lu2Tile<T, PB>& t, T* __restrict__ A, const int ld, const int N, const int k0,
+                                                const int pb, const int* __restrict__ src, const T* __restrict__ LIT,
+                                                T* __restrict__ UP, const int Mpad) {
+    constexpr int G = 64 / PB;
+    if (t.cb < 0) return;
+    const int lane = threadIdx.x & 63, li = lane % PB, lg = lane / PB;
+    const int col = t.cb * PB + li;
+    const bool colok = col < N;
+    T* Ac = A + (size_t)k0 * ld + col;
+    if (t.right) {
+        const int ucol = col - (k0 + pb);
+        if constexpr (sizeof(T) == 4) {
+            // Forward substitution IN the accumulators, two rows per matrix instruction: rows 2p, 2p+1 of a column sit in
+            // registers q0, q0 + 1 of one lane (group (p >> 1) & 1); row 2p+1 takes its one term on the vector unit, ONE
+            // v_permlane32_swap turns the two finished rows into the B operand (row 2p in lanes 0-31, row 2p+1 in lanes 32-63)
+            // and a single v_mfma_f32_32x32x2 subtracts L[:, 2p : 2p+2] times them from every row below.  LIT here holds L11
+            // itself ([k * PB + i] = L[i][k]): no inverse (one wave inverting a 32 x 32 triangle, whether against LDS broadcast
+            // reads or v_readlane scalars, took 23-25 k cycles per panel: ~5 instructions per term, 496 terms).
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = t.b[q];
+#pragma unroll
+            for (int p = 0; p < PB / 2; ++p) {
+                constexpr int dummy = 0; (void)dummy;
+                const int lgp = (p >> 1) & 1, q0 = ((2 * p) & 3) + 4 * (p >> 2);
+                const float lp = LIT[(2 * p) * PB + 2 * p + 1];
+                const float leff = (lg == lgp) ? lp : 0.f;
+                acc[q0 + 1] = __builtin_fmaf(-leff, acc[q0], acc[q0 + 1]);
+                if (p < PB / 2 - 1) {
+                    float a0 = acc[q0], a1 = acc[q0 + 1];
+                    lane_swap32(a0, a1);                          // a0 = [a0 lanes 0-31 | a1 lanes 0-31], a1 = [a0 lanes 32-63 | a1 lanes 32-63]
+                    const float bop = lgp == 0 ? a0 : a1;
+                    const float lraw = LIT[(2 * p + lg) * PB + li];
+                    const float aop = (li > 2 * p + 1) ? -lraw : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * lg;
+                UP[i * Mpad + ucol] = acc[q];
+                if (colok) Ac[(size_t)i * ld] = acc[q];
+            }
+        } else {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < PB / G; ++kk)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(LIT[(G * kk + lg) * PB + li], t.b[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 4 * lg + q;
+                UP[i * Mpad + ucol] = acc[q];
+                if (colok) Ac[(size_t)i * ld] = acc[q];
+            }
         }
+    } else {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) UP[j * Mpad + ucol] = top[j];
+        for (int kk = 0; kk < PB / G; ++kk) {
+            const int kr = lu2_tile_row<T, PB>(kk, lg);
+            if (kr < pb && colok && src[kr] != kr) Ac[(size_t)kr * ld] = t.b[kk];
+        }
     }
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-        if (j < pb && (right || __builtin_amdgcn_readfirstlane(src[j]) != j)) Ac[(size_t)j * ld] = top[j];
 }
 
 template <typename T> struct Panel2Lds {
@@ -370,9 +504,14 @@ __device__ __forceinline__ void lu2_load_rows(const T* __restrict__ A, const int
 template <typename T, int PB>
 __device__ __forceinline__ void lu2_put_row(T* __restrict__ A, const int ld, const V4<T> (&row)[PB / 4], const int pos, const int rel,
                                             const int k0, const int pb, int* __restrict__ msg, int* __restrict__ cnt,
-                                            int* __restrict__ xdst, int* __restrict__ xsrc) {
+                                            int* __restrict__ xdst, int* __restrict__ xsrc, const bool xlocal) {
     T* dst = A + (size_t)(k0 + pos) * ld + k0;
-    if (pb == PB) {
+    if (pb == PB && xlocal) {
+        // both workgroups on ONE XCD: its L2 is their point of coherence -- plain stores (the lines stay in that L2, the reader's
+        // sc1 loads find them there; a write-through store drops the line and the reader goes to memory)
+#pragma unroll
+        for (int q = 0; q < PB / 4; ++q) *(V4<T>*)(dst + 4 * q) = row[q];
+    } else if (pb == PB) {
 #pragma unroll
         for (int q = 0; q < PB / 4; ++q) st_vec_sc1(dst + 4 * q, row[q]);
     } else {
@@ -396,12 +535,12 @@ __device__ __forceinline__ void lu2_publish(T* __restrict__ A, const int ld, int
                                             const V4<T> (&rb)[PB / 4], const int posa, const int posb, const int kk, const int k0,
                                             const int pb, const int M, int* __restrict__ msg_base, int* __restrict__ cnt,
                                             const int* __restrict__ pidx, int* __restrict__ xdst, int* __restrict__ xsrc,
-                                            unsigned long long* __restrict__ flag, const unsigned int epoch) {
+                                            unsigned long long* __restrict__ flag, const unsigned int epoch, const bool xlocal) {
     const int tid = threadIdx.x;
     int* msg = msg_base + (kk & 1) * LU2_MSG;
     if (tid < 256) {
-        if (tid < M) lu2_put_row<T, PB>(A, ld, ra, posa, tid, k0, pb, msg, cnt, xdst, xsrc);
-        if (tid + 256 < M) lu2_put_row<T, PB>(A, ld, rb, posb, tid + 256, k0, pb, msg, cnt, xdst, xsrc);
+        if (tid < M) lu2_put_row<T, PB>(A, ld, ra, posa, tid, k0, pb, msg, cnt, xdst, xsrc, xlocal);
+        if (tid + 256 < M) lu2_put_row<T, PB>(A, ld, rb, posb, tid + 256, k0, pb, msg, cnt, xdst, xsrc, xlocal);
     }
     __syncthreads();
     if (tid < pb) ipiv[k0 + tid] = k0 + pidx[tid] + 1;
@@ -414,25 +553,26 @@ __device__ __forceinline__ void lu2_publish(T* __restrict__ A, const int ld, int
         cnt[0] = 0;
         __hip_atomic_store(flag, ((unsigned long long)epoch << 32) | (unsigned long long)(kk + 1), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        if (!xlocal) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    if (!xlocal) __syncthreads();
 }
 
 // dbg (optional, workgroup 0 of the matrix): cycles of wave 0 -- [0] waiting for the partner, [1] receive (message, L panel),
 // [2] the next panel's columns (interchanges, U12, update in registers), [3] panel factorisation, [4] publish,
-// [5] interchanges + U12 of the other columns, [6] trailing update, [7] total
+// [5] interchanges + U12 (after the inverse / loads / barrier: [8] inverse of L11, [9] tile loads, [10] barrier), [6] trailing
+// update, [7] total, [11] both workgroups on one XCD
 template <typename T, int PB>
 __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, const int ld, int* __restrict__ ipiv,
                                               int* __restrict__ info, char* __restrict__ smem, const int me,
                                               unsigned long long* __restrict__ scr, const unsigned int epoch,
-                                              unsigned long long* __restrict__ dbg) {
+                                              const bool xlocal_ok, unsigned long long* __restrict__ dbg) {
     typedef V4<T> vec;
     const int Mpad = round_up(N, 64);
     const Lu2Lds<T, PB> L(Mpad);
     T* LT = (T*)(smem + L.lt);
     T* UP = (T*)(smem + L.up);
-    T* L11 = (T*)(smem + L.l11);
+    T* LIT = (T*)(smem + L.lit);
     int* pidx = (int*)(smem + L.pidx);
     int* src = (int*)(smem + L.src);
     int* xdst = (int*)(smem + L.xdst);
@@ -445,14 +585,28 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
     const int tid = threadIdx.x;
     const int nblk = (N + PB - 1) / PB;
     int* const msg_base = (int*)(scr + 8);
-    unsigned long long dbt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt0 = 0, dt_all = 0;
+    unsigned long long dbt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dt0 = 0, dt_all = 0;
     const bool dbg_on = dbg != nullptr;
     if (dbg_on) dt_all = clock64();
 #define LU2_STAMP(i) do { if (dbg_on) { const unsigned long long t_ = clock64(); dbt[i] += t_ - dt0; dt0 = t_; } } while (0)
 
-    if (tid < 4) cnt[tid] = 0;
+    if (tid < 8) cnt[tid] = 0;
     if (tid < 2 * LU2_PW) S.wval[tid] = T(-2);
+    // Which XCD is the partner on?  Each workgroup announces its own (one write-through word) and reads the other's.
+    if (tid == 0) {
+        const unsigned int xme = (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;       // HW_REG_XCC_ID
+        const unsigned long long ann = ((unsigned long long)epoch << 8) | 0x80ull;
+        __hip_atomic_store(scr + 2 + me, ann | xme, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long g = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (((g = __hip_atomic_load(scr + 2 + (1 - me), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~0xFull) != ann) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) { cnt[2] = 1; g = ~0ull; break; }
+        }
+        cnt[4] = (xlocal_ok && (unsigned int)(g & 0xFull) == xme) ? 1 : 0;
+    }
     __syncthreads();
+    const bool xlocal = cnt[4] != 0;
 
     // ---- prologue: workgroup 0 factors panel 0 ----
     if (me == 0) {
@@ -464,7 +618,7 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
         bool donea = !(tid < 256 && tid < N), doneb = !(tid < 256 && tid + 256 < N);
         lu2_panel_columns<T, PB>(ra, rb, posa, posb, donea, doneb, pb, 0, S);
         LU2_STAMP(3);
-        lu2_publish<T, PB>(A, ld, ipiv, ra, rb, posa, posb, 0, 0, pb, N, msg_base, cnt, pidx, pxdst, pxsrc, scr + me, epoch);
+        lu2_publish<T, PB>(A, ld, ipiv, ra, rb, posa, posb, 0, 0, pb, N, msg_base, cnt, pidx, pxdst, pxsrc, scr + me, epoch, xlocal);
         LU2_STAMP(4);
     }
 
@@ -494,20 +648,34 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
             if (tid == 0) { cnt[3] = ld_sc1(msg); if (!mine && cnt[1] == 0) cnt[1] = ld_sc1(msg + 1); }
             if (tid < M) {
                 const T* rowp = A + (size_t)(k0 + tid) * ld + k0;
-                vec v[PB / 4];
-                if (pb == PB) {
+                T r[PB];
+                if (pb == PB && mine && xlocal) {      // (my own plain stores: this CU's L1 / the XCD's L2 have them)
 #pragma unroll
-                    for (int q = 0; q < PB / 4; ++q) v[q] = ld_vec_sc1(rowp + 4 * q);
+                    for (int q = 0; q < PB / 4; ++q) {
+                        const vec v4 = *(const vec*)(rowp + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[4 * q + e] = v4.v[e];
+                    }
+                } else if (pb == PB) {
+                    u32x4 raw[8];
+                    ld_row128_sc1(rowp, raw);
+                    row128_unpack<T, PB>(raw, r);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < PB; ++c) v[c >> 2].v[c & 3] = (c < pb) ? ld_sc1(rowp + c) : T(0);
+                    for (int c = 0; c < PB; ++c) r[c] = (c < pb) ? ld_sc1(rowp + c) : T(0);
                 }
-                if (tid < pb) {
+                if (tid >= pb) {
 #pragma unroll
-                    for (int c = 0; c < PB; ++c) L11[tid * (PB + 1) + c] = v[c >> 2].v[c & 3];
+                    for (int c = 0; c < PB; ++c) LT[c * Mpad + (tid - pb)] = r[c];
+                }
+                // (wave 0: its lanes 0 .. pb-1 hold the rows of the top block)
+                if constexpr (sizeof(T) == 4) {
+                    if (tid < pb && pb == PB) {
+#pragma unroll
+                        for (int c = 0; c < PB; ++c) LIT[c * PB + tid] = r[c];       // L11 itself, [k * PB + i] = L[i][k]
+                    }
                 } else {
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) LT[c * Mpad + (tid - pb)] = v[c >> 2].v[c & 3];
+                    if (tid < 64 && pb == PB && k0 + pb < N) lu2_invert_l11<T, PB>(r, LIT);
                 }
             }
         }
@@ -521,13 +689,42 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
 
         const int k1 = k0 + pb;
         const bool next_mine = (k + 1 < nblk) && (((k + 1) & 1) == me);
+        // ---- interchanges + U12 on ALL my columns, one tile (block) per wave and round; the inverse of L11 by wave 0 beside the
+        //      other waves' loads ----
+        {
+            const int w = tid >> 6;
+            // the idx-th of my blocks that panel k touches: right of it, or left of it when anything was interchanged
+            auto nth_block = [&](int idx) -> int {
+                for (int cb = me; cb < nblk; cb += 2) {
+                    if (cb == k || (cb < k && !anyswap)) continue;
+                    if (idx-- == 0) return cb;
+                }
+                return -1;
+            };
+            Lu2Tile<T, PB> tl;
+            int idx = LU2_NW - 1 - w;
+            tl.cb = __builtin_amdgcn_readfirstlane(nth_block(idx));
+            tl.right = tl.cb > k;
+            LU2_STAMP(8);
+            lu2_tile_load<T, PB>(tl, A, ld, N, k0, pb, ne, src, xdst, xsrc);
+            LU2_STAMP(9);
+            __syncthreads();
+            LU2_STAMP(10);
+            lu2_tile_finish<T, PB>(tl, A, ld, N, k0, pb, src, LIT, UP, Mpad);
+            while (tl.cb >= 0) {
+                idx += LU2_NW;
+                tl.cb = __builtin_amdgcn_readfirstlane(nth_block(idx));
+                tl.right = tl.cb > k;
+                lu2_tile_load<T, PB>(tl, A, ld, N, k0, pb, ne, src, xdst, xsrc);
+                lu2_tile_finish<T, PB>(tl, A, ld, N, k0, pb, src, LIT, UP, Mpad);
+            }
+        }
+        __syncthreads();
+        LU2_STAMP(5);
         if (next_mine) {
-            // ---- the columns of block k+1 first: interchanges + U12, update in registers, factor, publish ----
+            // ---- block k+1: update in registers, factor, publish ----
             const int pb1 = (N - k1 < PB) ? (N - k1) : PB;
             const int M1 = N - k1;
-            if (tid < pb1)
-                lu2_swap_u12_column<T, PB>(A, ld, k0, pb, k1 + tid, true, tid, ne, src, xdst, xsrc, L11, UP, Mpad);
-            __syncthreads();
             vec ra[PB / 4], rb[PB / 4];
             lu2_load_rows<T, PB>(A, ld, ra, rb, k1, pb1, M1);
             if (tid < 256) {
@@ -546,7 +743,7 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
                         }
                     }
                 }
-                if (pb1 < PB) {       // (columns beyond the panel: U12 was not computed for them)
+                if (pb1 < PB) {       // (columns beyond the matrix: their U12 entries are whatever the padding lanes produced)
 #pragma unroll
                     for (int c = 0; c < PB; ++c)
                         if (c >= pb1) { ra[c >> 2].v[c & 3] = T(0); rb[c >> 2].v[c & 3] = T(0); }
@@ -557,23 +754,9 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
             bool donea = !(tid < 256 && tid < M1), doneb = !(tid < 256 && tid + 256 < M1);
             lu2_panel_columns<T, PB>(ra, rb, posa, posb, donea, doneb, pb1, k1, S);
             LU2_STAMP(3);
-            lu2_publish<T, PB>(A, ld, ipiv, ra, rb, posa, posb, k + 1, k1, pb1, M1, msg_base, cnt, pidx, pxdst, pxsrc, scr + me, epoch);
+            lu2_publish<T, PB>(A, ld, ipiv, ra, rb, posa, posb, k + 1, k1, pb1, M1, msg_base, cnt, pidx, pxdst, pxsrc, scr + me, epoch, xlocal);
             LU2_STAMP(4);
         }
-        // ---- my other columns: interchanges (left and right of the panel) + U12 ----
-        {
-            const int nmine = ((nblk - me + 1) >> 1) * PB;        // index space over my blocks me, me + 2, ...
-            for (int idx = tid; idx < nmine; idx += LU2_NT) {
-                const int cb = 2 * (idx / PB) + me;
-                const int col = cb * PB + (idx % PB);
-                if (cb == k || (next_mine && cb == k + 1) || col >= N) continue;
-                const bool right = cb > k;
-                if (right || anyswap)
-                    lu2_swap_u12_column<T, PB>(A, ld, k0, pb, col, right, col - k1, ne, src, xdst, xsrc, L11, UP, Mpad);
-            }
-        }
-        __syncthreads();
-        LU2_STAMP(5);
         // ---- trailing update of my tile columns: tile column tj = block k + 1 + tj ----
         if (M2 > 0)
             lu2_trailing<T, PB>(A + (size_t)k1 * ld + k1, ld, M2, LT, UP, Mpad, /*tj_par=*/(k + 1 + me) & 1,
@@ -588,7 +771,8 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
     if (tid == 0 && me == 1 && cnt[2]) *info = -7;
     if (dbg_on && tid == 0 && me == 0) {
         dbt[7] = clock64() - dt_all;
-        for (int q = 0; q < 8; ++q) dbg[q] = dbt[q];
+        dbt[11] = xlocal ? 1 : 0;
+        for (int q = 0; q < 16; ++q) dbg[q] = dbt[q];
     }
 #undef LU2_STAMP
 }

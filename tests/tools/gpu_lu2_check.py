@@ -13,7 +13,7 @@ lib = _lib.load()
 dt = torch.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else torch.float32
 sizes = [int(a) for a in sys.argv[2:]] or [501, 317, 266, 130, 512, 97, 200]
 B = int(os.environ.get("LU_B", "128"))
-PH = ["wait", "recv", "next-cols", "panel", "publish", "swaps+U12", "trailing", "total"]
+PH = ["wait", "recv", "next-cols", "panel", "publish", "S-finish", "trailing", "total", "S-inv", "S-load", "S-barrier", "xlocal"]
 
 
 def kkt_like(N, gen):
@@ -44,11 +44,11 @@ for N in sizes:
     LU1, P1, us1 = timed(M)
     os.environ["LQP_LU2"] = "1"
     LU2, P2, us2 = timed(M)
-    dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(B * 16, dtype=torch.int64, device=dev)
     lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
     lu_layer.lu_factor(M); torch.cuda.synchronize()
     lib.lqp_debug_set_lu_counters(None)
-    c = dbg.view(B, 8).double().mean(0).tolist()
+    c = dbg.view(B, 16).double().mean(0).tolist()
     LUr, Pr = torch.linalg.lu_factor(M.cpu())
     same_p = bool(torch.equal(P1.cpu(), P2.cpu())); lap_p = bool(torch.equal(P2.cpu().int(), Pr.int()))
     diff = float((LU1 - LU2).abs().max())
@@ -61,7 +61,7 @@ for N in sizes:
     good = rec <= 2 * rec1 + 1e-12 and (lap_p or dt == torch.float32)
     ok = ok and good
     print(f"{dt} N={N}: one-wg {us1:7.1f} us  two-wg {us2:7.1f} us | pivots == one-wg {same_p}, == LAPACK {lap_p}; max|LU1-LU2| {diff:.1e}; "
-          f"|PLU-M| {rec:.1e} (one-wg {rec1:.1e}) | " + " ".join(f"{k} {v/1e3:.0f}k" for k, v in zip(PH, c)), flush=True)
+          f"|PLU-M| {rec:.1e} (one-wg {rec1:.1e}) | " + " ".join(f"{k} {v/1e3:.1f}k" for k, v in zip(PH, c)), flush=True)
 # a singular matrix: info as the one-workgroup kernel reports it
 N = 200
 M = kkt_like(N, torch.Generator().manual_seed(1)); M[:, :, 70] = 0

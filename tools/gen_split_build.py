@@ -42,8 +42,8 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
-    "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
-    "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
+    "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
+    "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
     "void lqp::k_lu_factor_big<float>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_lu_factor_big<double>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_unroll_sweep<1>(lqp::FwdParams<float>, lqp::UnrollParams)",
@@ -63,6 +63,8 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
+    "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
     "void lqp::k_unroll_sweep<0>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_lu_factor<float, 32, false, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, unsigned long long*, int const*)",
     "void lqp::k_spd_inverse<0>(lqp::FwdParams<float>, int const*)",
