@@ -140,7 +140,7 @@ template <typename T, int PB> __device__ __forceinline__ void row128_unpack(cons
 // f64 trailing update on the matrix cores: v_mfma_f64_16x16x4_f64, D = C - L21 U12 over one 16x16 tile.
 //   A operand (16x4 slice of L21): lane l holds L21[i = l & 15][k = l >> 4]
 //   B operand (4x16 slice of U12): lane l holds U12[k = l >> 4][j = l & 15]
-//   C/D: lane l holds rows 4 (l >> 4) + q, q = 0..3, of column l & 15
+//   C/D: lane l holds rows 4 q + (l >> 4), q = 0..3, of column l & 15 (measured: tools/microbench/mfma_f64_layout.hip)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // Trailing update of the tile columns this workgroup owns.  A22: the M2 x M2 trailing matrix (row stride ld); LT / UP:
@@ -148,7 +148,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // f32: 32x32 tiles (PB == 32 columns = one block per tile column); f64: 16x16 tiles (PB == 16).
 template <typename T, int PB>
 __device__ __forceinline__ void lu2_trailing(T* __restrict__ A22, const int ld, const int M2, const T* __restrict__ LT,
-                                             const T* __restrict__ UP, const int Mpad, const int tj_par, const int tj_first) {
+                                             const T* __restrict__ UP, const int Mpad, const int tj_par, const int tj_first,
+                                             const int only_tj = -1) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if constexpr (sizeof(T) == 4) {
         static_assert(sizeof(T) == 8 || PB == 32, "one 32-column tile per block");
@@ -157,7 +158,8 @@ __device__ __forceinline__ void lu2_trailing(T* __restrict__ A22, const int ld, 
         // my tile columns: tj = tj0, tj0 + 2, ...
         int tj0 = tj_par & 1;                 // smallest tj with (tj + tj_par) even
         while (tj0 < tj_first) tj0 += 2;
-        const int ncol = tj0 < nt ? (nt - tj0 + 1) >> 1 : 0;
+        int ncol = tj0 < nt ? (nt - tj0 + 1) >> 1 : 0;
+        if (only_tj >= 0) { tj0 = only_tj; ncol = 1; }
         const int ntiles = nt * ncol;
         const int voff = 4 * lh * ld + li;
         for (int t = __builtin_amdgcn_readfirstlane(w); t < ntiles; t += LU2_NW) {
@@ -196,17 +198,18 @@ __device__ __forceinline__ void lu2_trailing(T* __restrict__ A22, const int ld, 
         const int nt = (M2 + 15) >> 4;
         int tj0 = tj_par & 1;
         while (tj0 < tj_first) tj0 += 2;
-        const int ncol = tj0 < nt ? (nt - tj0 + 1) >> 1 : 0;
+        int ncol = tj0 < nt ? (nt - tj0 + 1) >> 1 : 0;
+        if (only_tj >= 0) { tj0 = only_tj; ncol = 1; }
         const int ntiles = nt * ncol;
         for (int t = __builtin_amdgcn_readfirstlane(w); t < ntiles; t += LU2_NW) {
             const int ti = t / ncol, tj = tj0 + 2 * (t - ti * ncol);
             const int i0 = ti << 4, j0 = tj << 4;
-            double* base = (double*)A22 + (size_t)(i0 + 4 * lh) * ld + j0 + li;
+            double* base = (double*)A22 + (size_t)(i0 + lh) * ld + j0 + li;
             const bool colok = j0 + li < M2;
-            const int rlim = M2 - i0 - 4 * lh;
+            const int rlim = M2 - i0 - lh;            // register q holds row 4 q + lh (measured: tools/microbench/mfma_f64_layout.hip)
             f64x4 cur;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = (colok && q < rlim) ? base[(size_t)q * ld] : 0.0;
+            for (int q = 0; q < 4; ++q) cur[q] = (colok && 4 * q < rlim) ? base[(size_t)(4 * q) * ld] : 0.0;
             const double* lt = (const double*)LT + i0 + li + lh * Mpad;
             const double* up = (const double*)UP + j0 + li + lh * Mpad;
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -219,7 +222,7 @@ __device__ __forceinline__ void lu2_trailing(T* __restrict__ A22, const int ld, 
             cur -= acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (colok && q < rlim) base[(size_t)q * ld] = cur[q];
+                if (colok && 4 * q < rlim) base[(size_t)(4 * q) * ld] = cur[q];
         }
     }
 }
@@ -317,20 +320,25 @@ __device__ __forceinline__ void lu2_tile_finish(const Lu2Tile<T, PB>& t, T* __re
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = t.b[q];
+            // (every operand that comes from LDS first: inside the chain each read would be a round trip of its own)
+            float leff[PB / 2], aop[PB / 2];
 #pragma unroll
             for (int p = 0; p < PB / 2; ++p) {
-                constexpr int dummy = 0; (void)dummy;
-                const int lgp = (p >> 1) & 1, q0 = ((2 * p) & 3) + 4 * (p >> 2);
+                const int lgp = (p >> 1) & 1;
                 const float lp = LIT[(2 * p) * PB + 2 * p + 1];
-                const float leff = (lg == lgp) ? lp : 0.f;
-                acc[q0 + 1] = __builtin_fmaf(-leff, acc[q0], acc[q0 + 1]);
+                leff[p] = (lg == lgp) ? -lp : 0.f;
+                const float lraw = LIT[(2 * p + lg) * PB + li];
+                aop[p] = (li > 2 * p + 1) ? -lraw : 0.f;
+            }
+#pragma unroll
+            for (int p = 0; p < PB / 2; ++p) {
+                const int lgp = (p >> 1) & 1, q0 = ((2 * p) & 3) + 4 * (p >> 2);
+                acc[q0 + 1] = __builtin_fmaf(leff[p], acc[q0], acc[q0 + 1]);
                 if (p < PB / 2 - 1) {
                     float a0 = acc[q0], a1 = acc[q0 + 1];
                     lane_swap32(a0, a1);                          // a0 = [a0 lanes 0-31 | a1 lanes 0-31], a1 = [a0 lanes 32-63 | a1 lanes 32-63]
                     const float bop = lgp == 0 ? a0 : a1;
-                    const float lraw = LIT[(2 * p + lg) * PB + li];
-                    const float aop = (li > 2 * p + 1) ? -lraw : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[p], bop, acc, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -346,7 +354,7 @@ __device__ __forceinline__ void lu2_tile_finish(const Lu2Tile<T, PB>& t, T* __re
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(LIT[(G * kk + lg) * PB + li], t.b[kk], acc, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = 4 * lg + q;
+                const int i = 4 * q + lg;
                 UP[i * Mpad + ucol] = acc[q];
                 if (colok) Ac[(size_t)i * ld] = acc[q];
             }
@@ -364,10 +372,12 @@ template <typename T> struct Panel2Lds {
     T* rowP; T* wval; T* wrcp; int* widx; int* wtid; int* pidx; int* cnt;
 };
 
-// The PB columns of one panel on LU2_PW waves, two rows per thread: row a = relative row t, row b = t + 256.
-// Same per-element arithmetic and the same pivot rule as lu_panel_columns (max |.|, ties to the smallest position).
+// The PB columns of one panel on LU2_PW waves: row a = relative row t and -- TWO: panels of more than 256 rows -- row b =
+// t + 256.  Same per-element arithmetic and the same pivot rule as lu_panel_columns (max |.|, ties to the smallest position).
 // Every wave of the workgroup calls it (the barrier per column is the workgroup's); waves >= LU2_PW only synchronise.
-template <typename T, int PB>
+// The bookkeeping of positions is branch-free (selects); the pivot index / first zero pivot are noted by thread 0 (every lane
+// knows them).
+template <typename T, int PB, bool TWO>
 __device__ __forceinline__ void lu2_panel_columns(V4<T> (&ra)[PB / 4], V4<T> (&rb)[PB / 4], int& posa, int& posb, bool& donea,
                                                   bool& doneb, const int pb, const int k0, const Panel2Lds<T>& S) {
     typedef V4<T> vec;
@@ -383,12 +393,20 @@ __device__ __forceinline__ void lu2_panel_columns(V4<T> (&ra)[PB / 4], V4<T> (&r
             int* wt = S.wtid + par * LU2_PW;
             T* wr = S.wrcp + par * LU2_PW;
             if (pw) {
-                const T aa = ra[j >> 2].v[j & 3], ab = rb[j >> 2].v[j & 3];
-                const T ka = donea ? T(-1) : tabs(aa), kb = doneb ? T(-1) : tabs(ab);
-                const bool pickb = kb > ka || (kb == ka && posb < posa);
-                const T key = pickb ? kb : ka;
-                const int cpos = pickb ? posb : posa;
-                T myrcp = T(1) / (pickb ? ab : aa);
+                const T aa = ra[j >> 2].v[j & 3];
+                const T ka = donea ? T(-1) : tabs(aa);
+                bool pickb = false;
+                T key = ka, apick = aa;
+                int cpos = posa;
+                if constexpr (TWO) {
+                    const T ab = rb[j >> 2].v[j & 3];
+                    const T kb = doneb ? T(-1) : tabs(ab);
+                    pickb = kb > ka || (kb == ka && posb < posa);
+                    key = pickb ? kb : ka;
+                    cpos = pickb ? posb : posa;
+                    apick = pickb ? ab : aa;
+                }
+                T myrcp = T(1) / apick;
                 asm volatile("" : "+v"(myrcp));
                 T bw; int lb;
                 wave_argmax(key, bw, lb);
@@ -412,10 +430,12 @@ __device__ __forceinline__ void lu2_panel_columns(V4<T> (&ra)[PB / 4], V4<T> (&r
 #pragma unroll
                     for (int q = 0; q < PB / 4; ++q) *(vec*)(cand + w * PB + 4 * q) = ra[q];
                 }
-                asm volatile("" ::: "memory");
-                if (lane == lb && pickb) {
+                if constexpr (TWO) {
+                    asm volatile("" ::: "memory");
+                    if (lane == lb && pickb) {
 #pragma unroll
-                    for (int q = 0; q < PB / 4; ++q) *(vec*)(cand + w * PB + 4 * q) = rb[q];
+                        for (int q = 0; q < PB / 4; ++q) *(vec*)(cand + w * PB + 4 * q) = rb[q];
+                    }
                 }
             }
             __syncthreads();
@@ -441,22 +461,14 @@ __device__ __forceinline__ void lu2_panel_columns(V4<T> (&ra)[PB / 4], V4<T> (&r
                 for (int q = j >> 2; q < PB / 4; ++q) pr[q] = *(const vec*)(rowPc + 4 * q);
                 const T rinv = wr[ww];
                 const bool nz = best > T(0);
-                // row a
-                if (tid == bi) {
+                if (tid == 0) {
                     S.pidx[j] = pivpos;
                     if (!nz && S.cnt[1] == 0) S.cnt[1] = k0 + j + 1;
-                    posa = j; donea = true;
-                } else if (posa == j) {
-                    posa = pivpos;
-                }
-                if (tid + 256 == bi) {
-                    S.pidx[j] = pivpos;
-                    if (!nz && S.cnt[1] == 0) S.cnt[1] = k0 + j + 1;
-                    posb = j; doneb = true;
-                } else if (posb == j) {
-                    posb = pivpos;
                 }
                 {
+                    const bool isp = tid == bi;
+                    posa = isp ? j : (posa == j ? pivpos : posa);
+                    donea = donea || isp;
                     const bool upd = !donea && nz;
                     const T aj = ra[j >> 2].v[j & 3];
                     const T l = upd ? aj * rinv : T(0);
@@ -464,7 +476,10 @@ __device__ __forceinline__ void lu2_panel_columns(V4<T> (&ra)[PB / 4], V4<T> (&r
 #pragma unroll
                     for (int c = j + 1; c < PB; ++c) ra[c >> 2].v[c & 3] -= l * pr[c >> 2].v[c & 3];
                 }
-                {
+                if constexpr (TWO) {
+                    const bool isp = tid + 256 == bi;
+                    posb = isp ? j : (posb == j ? pivpos : posb);
+                    doneb = doneb || isp;
                     const bool upd = !doneb && nz;
                     const T aj = rb[j >> 2].v[j & 3];
                     const T l = upd ? aj * rinv : T(0);
@@ -616,7 +631,8 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
         lu2_load_rows<T, PB>(A, ld, ra, rb, 0, pb, N);
         int posa = tid, posb = tid + 256;
         bool donea = !(tid < 256 && tid < N), doneb = !(tid < 256 && tid + 256 < N);
-        lu2_panel_columns<T, PB>(ra, rb, posa, posb, donea, doneb, pb, 0, S);
+        if (N > 256) lu2_panel_columns<T, PB, true>(ra, rb, posa, posb, donea, doneb, pb, 0, S);
+        else lu2_panel_columns<T, PB, false>(ra, rb, posa, posb, donea, doneb, pb, 0, S);
         LU2_STAMP(3);
         lu2_publish<T, PB>(A, ld, ipiv, ra, rb, posa, posb, 0, 0, pb, N, msg_base, cnt, pidx, pxdst, pxsrc, scr + me, epoch, xlocal);
         LU2_STAMP(4);
@@ -681,10 +697,9 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
         }
         __syncthreads();
         const int ne = __builtin_amdgcn_readfirstlane(cnt[3]);
-        bool anyswap = ne > 0;
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-            if (j < pb && __builtin_amdgcn_readfirstlane(src[j]) != j) anyswap = true;
+        // (any row interchanged at all?  lane j looks at src[j]: one LDS read and a ballot per wave, the same answer in every wave)
+        const int lane_ = tid & 63;
+        const bool anyswap = ne > 0 || __ballot(lane_ < pb && src[lane_ < pb ? lane_ : 0] != lane_) != 0ull;
         LU2_STAMP(1);
 
         const int k1 = k0 + pb;
@@ -725,34 +740,18 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
             // ---- block k+1: update in registers, factor, publish ----
             const int pb1 = (N - k1 < PB) ? (N - k1) : PB;
             const int M1 = N - k1;
+            // panel k's update of block k+1 alone (tile column 0 of the trailing matrix, all eight waves on the matrix cores:
+            // in registers -- 2 x 32 x 32 terms per thread on the four panel waves -- it cost 22 k cycles of the chain), then the
+            // block's rows into the panel waves' registers
+            lu2_trailing<T, PB>(A + (size_t)k1 * ld + k1, ld, M2, LT, UP, Mpad, 0, 0, /*only_tj=*/0);
+            __syncthreads();
             vec ra[PB / 4], rb[PB / 4];
             lu2_load_rows<T, PB>(A, ld, ra, rb, k1, pb1, M1);
-            if (tid < 256) {
-                const bool acta = tid < M1, actb = tid + 256 < M1;
-#pragma unroll 4
-                for (int kk = 0; kk < PB; ++kk) {
-                    const T la = acta ? LT[kk * Mpad + tid] : T(0);
-                    const T lb = actb ? LT[kk * Mpad + tid + 256] : T(0);
-#pragma unroll
-                    for (int q = 0; q < PB / 4; ++q) {
-                        const vec uq = *(const vec*)(UP + kk * Mpad + 4 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            ra[q].v[e] -= la * uq.v[e];
-                            rb[q].v[e] -= lb * uq.v[e];
-                        }
-                    }
-                }
-                if (pb1 < PB) {       // (columns beyond the matrix: their U12 entries are whatever the padding lanes produced)
-#pragma unroll
-                    for (int c = 0; c < PB; ++c)
-                        if (c >= pb1) { ra[c >> 2].v[c & 3] = T(0); rb[c >> 2].v[c & 3] = T(0); }
-                }
-            }
             LU2_STAMP(2);
             int posa = tid, posb = tid + 256;
             bool donea = !(tid < 256 && tid < M1), doneb = !(tid < 256 && tid + 256 < M1);
-            lu2_panel_columns<T, PB>(ra, rb, posa, posb, donea, doneb, pb1, k1, S);
+            if (M1 > 256) lu2_panel_columns<T, PB, true>(ra, rb, posa, posb, donea, doneb, pb1, k1, S);
+            else lu2_panel_columns<T, PB, false>(ra, rb, posa, posb, donea, doneb, pb1, k1, S);
             LU2_STAMP(3);
             lu2_publish<T, PB>(A, ld, ipiv, ra, rb, posa, posb, k + 1, k1, pb1, M1, msg_base, cnt, pidx, pxdst, pxsrc, scr + me, epoch, xlocal);
             LU2_STAMP(4);

@@ -61,7 +61,7 @@ for N in sizes:
     good = rec <= 2 * rec1 + 1e-12 and (lap_p or dt == torch.float32)
     ok = ok and good
     print(f"{dt} N={N}: one-wg {us1:7.1f} us  two-wg {us2:7.1f} us | pivots == one-wg {same_p}, == LAPACK {lap_p}; max|LU1-LU2| {diff:.1e}; "
-          f"|PLU-M| {rec:.1e} (one-wg {rec1:.1e}) | " + " ".join(f"{k} {v/1e3:.1f}k" for k, v in zip(PH, c)), flush=True)
+          f"|PLU-M| {rec:.1e} (one-wg {rec1:.1e}) | " + " ".join(f"{k} {v/1e3:.1f}k" for k, v in zip(PH[:11], c)) + f" xlocal {c[11]:.2f}", flush=True)
 # a singular matrix: info as the one-workgroup kernel reports it
 N = 200
 M = kkt_like(N, torch.Generator().manual_seed(1)); M[:, :, 70] = 0
