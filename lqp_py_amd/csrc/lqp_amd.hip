@@ -132,6 +132,99 @@ int env_int(const char* name, int dflt) {
     return it->second.first ? it->second.second : dflt;
 }
 
+// Every LQP_* environment switch that steers a schedule, read ONCE per process (tests that flip one run in a fresh process
+// or set LQP_ENV_NOCACHE=1, which re-reads them at every use).  -1: not set, the library decides.
+struct Knobs {
+    int bwd_chol;              // LQP_BWD_CHOL
+    int bwd_early;             // LQP_BWD_EARLY
+    int bwd_full;              // LQP_BWD_FULL
+    int bwd_lookahead;         // LQP_BWD_LOOKAHEAD
+    int bwd_refine;            // LQP_BWD_REFINE
+    int dbg_qpass;             // LQP_DBG_QPASS
+    int dbg_setup;             // LQP_DBG_SETUP
+    int epi_slabs;             // LQP_EPI_SLABS
+    int eq_in_loop;            // LQP_EQ_IN_LOOP
+    int launch_mode;           // LQP_LAUNCH_MODE
+    int linsolve;              // LQP_LINSOLVE
+    int loop512;               // LQP_LOOP512
+    int loop_small;            // LQP_LOOP_SMALL
+    int loop_split;            // LQP_LOOP_SPLIT
+    int loop_split4;           // LQP_LOOP_SPLIT4
+    int loop_split_seg;        // LQP_LOOP_SPLIT_SEG
+    int lu2;                   // LQP_LU2
+    int lu_mfma;               // LQP_LU_MFMA
+    int lu_nt;                 // LQP_LU_NT
+    int lu_pb;                 // LQP_LU_PB
+    int nosync_max_events;     // LQP_NOSYNC_MAX_EVENTS
+    int prep_fused;            // LQP_PREP_FUSED
+    int prep_one;              // LQP_PREP_ONE
+    int qpass;                 // LQP_QPASS
+    int qs_lazy;               // LQP_QS_LAZY
+    int resident;              // LQP_RESIDENT
+    int rho_late;              // LQP_RHO_LATE
+    int spd_big;               // LQP_SPD_BIG
+    int spd_ptasks;            // LQP_SPD_PTASKS
+    int spd_resident;          // LQP_SPD_RESIDENT
+    int spd_resident4;         // LQP_SPD_RESIDENT4
+    int spd_split;             // LQP_SPD_SPLIT
+    int spec_launches;         // LQP_SPEC_LAUNCHES
+    int split2;                // LQP_SPLIT2
+    int sym512;                // LQP_SYM512
+    int sync_plan;             // LQP_SYNC_PLAN
+    int tail_epilogue;         // LQP_TAIL_EPILOGUE
+    int xcd_local;             // LQP_XCD_LOCAL
+};
+Knobs read_knobs() {
+    Knobs k;
+    k.bwd_chol = env_int("LQP_BWD_CHOL", 1);
+    k.bwd_early = env_int("LQP_BWD_EARLY", 1);
+    k.bwd_full = env_int("LQP_BWD_FULL", 0);
+    k.bwd_lookahead = env_int("LQP_BWD_LOOKAHEAD", 1);
+    k.bwd_refine = env_int("LQP_BWD_REFINE", 1);
+    k.dbg_qpass = env_int("LQP_DBG_QPASS", 0);
+    k.dbg_setup = env_int("LQP_DBG_SETUP", 0);
+    k.epi_slabs = env_int("LQP_EPI_SLABS", -1);
+    k.eq_in_loop = env_int("LQP_EQ_IN_LOOP", 1);
+    k.launch_mode = env_int("LQP_LAUNCH_MODE", 2);
+    k.linsolve = env_int("LQP_LINSOLVE", 0);
+    k.loop512 = env_int("LQP_LOOP512", 0);
+    k.loop_small = env_int("LQP_LOOP_SMALL", 1);
+    k.loop_split = env_int("LQP_LOOP_SPLIT", 1);
+    k.loop_split4 = env_int("LQP_LOOP_SPLIT4", 1);
+    k.loop_split_seg = env_int("LQP_LOOP_SPLIT_SEG", 1);
+    k.lu2 = env_int("LQP_LU2", 1);
+    k.lu_mfma = env_int("LQP_LU_MFMA", 1);
+    k.lu_nt = env_int("LQP_LU_NT", 0);
+    k.lu_pb = env_int("LQP_LU_PB", 0);
+    k.nosync_max_events = env_int("LQP_NOSYNC_MAX_EVENTS", 12);
+    k.prep_fused = env_int("LQP_PREP_FUSED", 1);
+    k.prep_one = env_int("LQP_PREP_ONE", 1);
+    k.qpass = env_int("LQP_QPASS", 1);
+    k.qs_lazy = env_int("LQP_QS_LAZY", 1);
+    k.resident = env_int("LQP_RESIDENT", 1);
+    k.rho_late = env_int("LQP_RHO_LATE", 1);
+    k.spd_big = env_int("LQP_SPD_BIG", 1);
+    k.spd_ptasks = env_int("LQP_SPD_PTASKS", 48);
+    k.spd_resident = env_int("LQP_SPD_RESIDENT", 1);
+    k.spd_resident4 = env_int("LQP_SPD_RESIDENT4", 1);
+    k.spd_split = env_int("LQP_SPD_SPLIT", -1);
+    k.spec_launches = env_int("LQP_SPEC_LAUNCHES", 6);
+    k.split2 = env_int("LQP_SPLIT2", 1);
+    k.sym512 = env_int("LQP_SYM512", 0);
+    k.sync_plan = env_int("LQP_SYNC_PLAN", 1);
+    k.tail_epilogue = env_int("LQP_TAIL_EPILOGUE", 1);
+    k.xcd_local = env_int("LQP_XCD_LOCAL", 1);
+    return k;
+}
+const Knobs& knobs() {
+    static const bool nocache = getenv("LQP_ENV_NOCACHE") != nullptr;
+    static const Knobs cached = read_knobs();
+    if (!nocache) return cached;
+    static thread_local Knobs fresh;
+    fresh = read_knobs();
+    return fresh;
+}
+
 unsigned long long* g_lu_dbg = nullptr;     // optional device buffer (4 counters per problem), debug only
 
 // ---- LU launch: pick panel width / trailing-update flavour --------------------
@@ -170,7 +263,7 @@ template <typename T>
 int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
     constexpr int PB = lu2_panel_width<T>();
-    if (!scr || scr_stride < (size_t)LU2_SCR_WORDS || N > 512 || N < 3 * PB || env_int("LQP_LU2", 1) == 0) return -1;
+    if (!scr || scr_stride < (size_t)LU2_SCR_WORDS || N > 512 || N < 3 * PB || knobs().lu2 == 0) return -1;
     int dev = 0, cus = 0, per_cu = 0;
     auto fn = k_lu_factor2<T, PB>;
     const int lds = Lu2Lds<T, PB>(round_up(N, 64)).total;
@@ -180,7 +273,7 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
     const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
     { ProfScope ps(st, PC_LU);
       hipLaunchKernelGGL(fn, dim3(2 * B), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
-                         scr_stride, epoch, g_lu_dbg, B, env_int("LQP_XCD_LOCAL", 1) != 0 ? 1 : 0); }
+                         scr_stride, epoch, g_lu_dbg, B, knobs().xcd_local != 0 ? 1 : 0); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
@@ -189,40 +282,19 @@ int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, in
     if (N > 1024) return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     { const int r2 = launch_lu2<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
       if (r2 >= 0) return r2; }
-    const int la = env_int("LQP_LU_LA", 0);       // lookahead variants (see lqp_lu.hpp): 1 = 16 columns / 1024
-    if (N <= 512 && N > 64 && la != 0) {           // threads, 2 = 32 columns / 768 threads (8 + 4 waves)
-        int rc;
-        if (la == 2) {
-            const int lds = LuLds<float, 32>(round_up(N, 64)).total;
-            auto fn = k_lu_factor_la<32, 768>;
-            rc = ensure_lds((const void*)fn, lds);
-            if (rc) return rc;
-            ProfScope ps(st, PC_LU);
-            hipLaunchKernelGGL(fn, dim3(B), dim3(768), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, g_lu_dbg);
-        } else {
-            const int lds = LuLds<float, 16>(round_up(N, 64)).total;
-            auto fn = k_lu_factor_la<16, 1024>;
-            rc = ensure_lds((const void*)fn, lds);
-            if (rc) return rc;
-            ProfScope ps(st, PC_LU);
-            hipLaunchKernelGGL(fn, dim3(B), dim3(1024), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, g_lu_dbg);
-        }
-        return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
-    }
     int nt = lu_threads<float>(N);
     int pb = lu_panel_width<float>(N);
-    const int want_nt = env_int("LQP_LU_NT", 0);
+    const int want_nt = knobs().lu_nt;
     if (want_nt == 1024) { nt = 1024; pb = std::min(pb, 16); }
-    const int want = env_int("LQP_LU_PB", 0);
-    if ((want == 8 || want == 16 || want == 32) && 2 * want * round_up(N, 64) * 4 <= 128 * 1024) pb = want;
-    const bool mfma = env_int("LQP_LU_MFMA", 1) != 0;
+    const int want = knobs().lu_pb;
+    if ((want == 8 || want == 16 || (want == 32 && nt == 512)) && 2 * want * round_up(N, 64) * 4 <= 128 * 1024) pb = want;
+    const bool mfma = knobs().lu_mfma != 0;
 #define LQP_LU_CASE(PBV, MF, NTV) return launch_lu_impl<float, PBV, MF, NTV>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
     if (nt == 512) {
         if (pb == 32) { if (mfma) LQP_LU_CASE(32, true, 512); LQP_LU_CASE(32, false, 512); }
         if (pb == 16) { if (mfma) LQP_LU_CASE(16, true, 512); LQP_LU_CASE(16, false, 512); }
         LQP_LU_CASE(8, false, 512);
     }
-    if (pb == 32) LQP_LU_CASE(32, true, 1024);        // (no scalar-update flavour: 1829 spilled registers)
     if (pb == 16) { if (mfma) LQP_LU_CASE(16, true, 1024); LQP_LU_CASE(16, false, 1024); }
     LQP_LU_CASE(8, false, 1024);
 #undef LQP_LU_CASE
@@ -254,7 +326,7 @@ int launch_pack(hipStream_t st, int B, const T* LU, int N, int ld, size_t mstrid
     if (rc) return rc;
     const bool vec_ok = (ld % 4 == 0) && (mstride % 4 == 0) && (((uintptr_t)LU) % (4 * sizeof(T)) == 0);
     ProfScope ps(st, PC_PACK);
-    const int split = (B <= 128 && env_int("LQP_SPLIT2", 1)) ? 2 : 1;      // use the idle half of the chip
+    const int split = (B <= 128 && knobs().split2) ? 2 : 1;      // use the idle half of the chip
     hipLaunchKernelGGL(fn, dim3(B, split), dim3(LQP_NT), lds, st, LU, N, ld, mstride, piv, pstride, packed,
                        packed_blocks(K) * LQP_BLK, dest, K * LQP_NB, vec_ok ? 1 : 0, gate, nvec);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
@@ -410,12 +482,12 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.scale = ctl->scale; P.bound_flags_in = (const int*)ctl->bound_flags_in;
     P.host_report = (int*)ctl->host_report;
     if (P.host_report) report_reset(P.host_report, ST_WORDS + 2 * B);      // (before the first launch: see wait_report)
-    P.xcd_local = env_int("LQP_XCD_LOCAL", 1) != 0 ? 1 : 0;
-    P.dbg_qpass = env_int("LQP_DBG_QPASS", 0) != 0 ? 1 : 0;
+    P.xcd_local = knobs().xcd_local != 0 ? 1 : 0;
+    P.dbg_qpass = knobs().dbg_qpass != 0 ? 1 : 0;
     P.zero_words = (int)(((char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status) / sizeof(int));
     P.dbg = g_lu_dbg;
     P.dbg_setup = nullptr;
-    if (g_lu_dbg && env_int("LQP_DBG_SETUP", 0)) { P.dbg_setup = g_lu_dbg; P.dbg = nullptr; }
+    if (g_lu_dbg && knobs().dbg_setup) { P.dbg_setup = g_lu_dbg; P.dbg = nullptr; }
     P.rho_mode = ctl->rho_mode; P.beta_mode = ctl->beta_mode;
     P.check_solved = ctl->check_solved < 1 ? 1 : ctl->check_solved;
     P.adaptive_rho = ctl->adaptive_rho;
@@ -433,33 +505,33 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     bool spd = false;
     if constexpr (sizeof(T) == 4) {
         int want = ctl->linsolve;
-        if (want == 0) want = env_int("LQP_LINSOLVE", 0);
+        if (want == 0) want = knobs().linsolve;
         const bool rho_pos = !(ctl->rho_mode == 1 && !(ctl->rho_value > 0.0));
         // (512 < n <= 1024: the sweep parks its panel in the M area, see wg_spd_sweep_big)
         spd = !force_lu && want != 1 && rho_pos && P.Ks <= SPD_BIGK && m <= SPD_MAXM &&
-              (P.Ks <= SPD_MAXK || ((size_t)P.Np * P.Np >= (size_t)P.Ks * LQP_BLK && env_int("LQP_SPD_BIG", 1)));
+              (P.Ks <= SPD_MAXK || ((size_t)P.Np * P.Np >= (size_t)P.Ks * LQP_BLK && knobs().spd_big));
         // the equality correction (G, T: 2 m rows of 64 Ks floats next to the product's scratch) and the loop's vectors must
         // fit the 160 KB of LDS: large n with many equality rows (n > 960 at m >= 8, ...) stays on the LU path
         spd = spd && spd_factor_lds_bytes(m, P.Ks) <= 160 * 1024 && sym_loop_lds_bytes(n, m, P.Ks, 0) <= 160 * 1024;
     }
     P.spd = spd ? 1 : 0;
-    P.qs_lazy = (spd && env_int("LQP_QS_LAZY", 1)) ? 1 : 0;
+    P.qs_lazy = (spd && knobs().qs_lazy) ? 1 : 0;
     P.ar_iter = ar_iter; P.ar_max = ctl->adaptive_rho_max_iter; P.ring = kRing;
 
     // symmetric path with fewer problems than half the CUs: share each matrix between SPD_NP workgroups
     bool spd_split = false;
-    const int spd_pivot_tasks = env_int("LQP_SPD_PTASKS", 48);
+    const int spd_pivot_tasks = knobs().spd_ptasks;
     if (spd && P.Ks >= 3 && P.Ks <= SPD_MAXK) {
         int dev_ = 0, cus_ = 0;
         if (current_device_cus(&dev_, &cus_)) spd_split = B * SPD_NP <= cus_;
-        spd_split = env_int("LQP_SPD_SPLIT", spd_split ? 1 : 0) != 0;
+        spd_split = (knobs().spd_split < 0 ? (spd_split ? 1 : 0) : knobs().spd_split) != 0;
         spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
     }
     bool spd_big_split = false;
     if (spd && P.Ks > SPD_MAXK) {
         int dev_ = 0, cus_ = 0;
         if (current_device_cus(&dev_, &cus_)) spd_big_split = B * SPD_NP <= cus_;
-        spd_big_split = env_int("LQP_SPD_SPLIT", spd_big_split ? 1 : 0) != 0;
+        spd_big_split = (knobs().spd_split < 0 ? (spd_big_split ? 1 : 0) : knobs().spd_split) != 0;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
     // (More matrices than half the CUs: the register-resident sweep with its pairs taking turns on the chip, as the loop does it
@@ -467,8 +539,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     //  in every pivot step, 9.7 GB per factorisation at B = 1024, n = 500, and still is as fast: 2.91 ms against 8 turns x 0.36
     //  ms + the equality correction in a launch of its own = 3.13 ms; B = 256: 0.73 against 0.80.  Not kept.)
     bool spd_resident = spd_split && P.xchg && P.Ks >= SPLIT_MINK &&
-                        (size_t)P.Np * P.Np >= ((LQP_RS_V2 == 2 || LQP_RS_V2 == 4) ? rs2_xb_floats(P.Ks) : rs3_xb_floats(P.Ks)) &&
-                        env_int("LQP_SPD_RESIDENT", 1) != 0;
+                        (size_t)P.Np * P.Np >= rs2_xb_floats(P.Ks) &&
+                        knobs().spd_resident != 0;
     int rs_np = SPD_NP;                 // workgroups per matrix of the resident sweep: 2, or 4 for batches up to a quarter of the CUs
     void (*rs_fn)(const FwdParams<float>, const int*) = nullptr;
     if (spd_resident) {
@@ -477,8 +549,8 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         int dev_ = 0, cus_ = 0, per_cu = 0;
         const int rlds = rs_q_lds_bytes(P.Ks);     // (the look-ahead sweep's counters behind the flags, the scaling vector behind them)
         bool ok = false;
-#if LQP_PIV_MFMA && (LQP_RS_V2 == 2 || LQP_RS_V2 == 4)
-        if (P.Ks >= 7 && current_device_cus(&dev_, &cus_) && 4 * B <= cus_ && env_int("LQP_SPD_RESIDENT4", 1) != 0) {
+#if LQP_PIV_MFMA
+        if (P.Ks >= 7 && current_device_cus(&dev_, &cus_) && 4 * B <= cus_ && knobs().spd_resident4 != 0) {
             rs_fn = P.Ks == 7 ? k_spd_resident<7, 4> : k_spd_resident<8, 4>;
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) &&
                  per_cu >= 1 && 4 * B <= cus_ * per_cu;
@@ -495,24 +567,24 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     }
     // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
-    P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && env_int("LQP_RHO_LATE", 1)) ? 1 : 0;
+    P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && knobs().rho_late) ? 1 : 0;
     // auto-scaling on: ONE pass over Q for the column maxima, the symmetry verdict and the (unscaled) blocks, in front of
     // the setup kernel (k_spd_prep); the resident sweep scales its tiles as it loads them and sums ||Qs||_F itself
     P.prep_fused = 0;
-#if LQP_PIV_MFMA && (LQP_RS_V2 == 2 || LQP_RS_V2 == 4)
+#if LQP_PIV_MFMA
     if constexpr (sizeof(T) == 4) {
-        P.prep_fused = (spd_resident && P.scale && P.qs_lazy && (ctl->rho_mode != 0 || P.rho_late) && env_int("LQP_PREP_FUSED", 1)) ? 1 : 0;
+        P.prep_fused = (spd_resident && P.scale && P.qs_lazy && (ctl->rho_mode != 0 || P.rho_late) && knobs().prep_fused) ? 1 : 0;
         // ... and the one-workgroup tier (more problems than half the CUs, n <= 512): k_spd_inverse scales the prepared
         // blocks, sums ||Qs||_F and adds rho itself (wg_spd_factor)
         if (!P.prep_fused && spd && !spd_split && !spd_big_split && P.Ks <= SPD_MAXK && P.scale && P.qs_lazy &&
             ctl->rho_mode != 2 && (size_t)n * P.ldq >= (size_t)SPD_NP * P.Ks * LQP_NB + 8 &&      // (k_spd_prep's scratch per
-            env_int("LQP_PREP_ONE", 1))                                                             //  problem lives in its Qs area)
+            knobs().prep_one)                                                             //  problem lives in its Qs area)
             P.prep_fused = 2;
     }
 #endif
-#if LQP_PIV_MFMA && LQP_RS_V2 == 2
+#if LQP_PIV_MFMA
     // ... or no pass in front at all: the resident sweep reads Q itself, straight into the registers that keep it
-    if (P.prep_fused == 1 && (size_t)n * P.ldq >= (size_t)rs_np * (64 * P.Ks + 2) && env_int("LQP_QPASS", 1)) P.prep_fused = 3;
+    if (P.prep_fused == 1 && (size_t)n * P.ldq >= (size_t)rs_np * (64 * P.Ks + 2) && knobs().qpass) P.prep_fused = 3;
 #endif
     if constexpr (sizeof(T) == 4) {
         if (P.prep_fused == 1 || P.prep_fused == 2) {
@@ -604,10 +676,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // of 8).  Measured SLOWER at B=128 n=500 (2.03 ms vs 1.54 ms; 1.76 ms with a 6-deep ring and 4 spills):
     // 8 waves hide the per-block dependent chain worse than 16, which costs more than the 8 extra resident
     // blocks save.  Kept selectable (LQP_LOOP512=1) for re-measurement; continuation launches always use 1024.
-    const bool res_env = env_int("LQP_RESIDENT", 1) != 0;
+    const bool res_env = knobs().resident != 0;
     const bool resident = loop_resident_ok<1024>(P.K, sizeof(T)) && res_env &&
                           loop_lds_bytes<T>(n, m, P.Np, true) <= 160 * 1024;
-    const bool hot512 = resident && loop_resident_ok<512>(P.K, sizeof(T)) && env_int("LQP_LOOP512", 0) != 0;
+    const bool hot512 = resident && loop_resident_ok<512>(P.K, sizeof(T)) && knobs().loop512 != 0;
     int loop_lds = loop_lds_bytes<T>(n, m, P.Np, resident);
     int loop_nt = hot512 ? 512 : 1024;
     auto loop_fn = k_admm_loop<T, false, false, 1024>;
@@ -631,7 +703,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             // B=128 n=500: 0.96-0.99 ms with an 8-deep ring (26 spilled VGPRs), 0.87 ms with a 6-deep one, against
             // 0.885 ms for the 1024-thread kernel: neither the halved instruction count nor the fewer streamed
             // blocks show, the product is bound by the un-overlapped sum of its resident and streamed phases.
-            if (env_int("LQP_SYM512", 0)) {
+            if (knobs().sym512) {
                 P.sym_rl_hot = sym_resident_lds_blocks(n, m, P.Ks, resident_regs<512>(), 8);
                 loop_lds = sym_loop_lds_bytes(n, m, P.Ks, P.sym_rl_hot, 8);
                 loop_nt = 512;
@@ -651,7 +723,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     rc = ensure_lds((const void*)tail_fn, tail_lds);
     if (rc) return rc;
     int mode = ctl->launch_mode;
-    if (mode == 0) mode = env_int("LQP_LAUNCH_MODE", 2);     // auto: persistent when every workgroup is resident
+    if (mode == 0) mode = knobs().launch_mode;     // auto: persistent when every workgroup is resident
     if (ctl->check_hook) mode = 1;                           // the hook sits between the check segments
     if (mode == 2) {
         // the grid barrier needs EVERY workgroup resident -- of the hot kernel and of the continuation kernel
@@ -667,9 +739,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         // registers (split_seg below) -- one launch per check segment then beats the persistent launch (B = 256, n = 500: loop
         // 0.82 -> 0.42 ms, step 1.87 -> 1.60 ms; B = 192: 1.63 -> 1.51).  Only when the caller left the mode to the library.
         if constexpr (sizeof(T) == 4) {
-            if (mode == 2 && ctl->launch_mode == 0 && env_int("LQP_LAUNCH_MODE", 2) == 2 && spd && P.xchg && 2 * B > cus &&
-                P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 && env_int("LQP_LOOP_SPLIT", 1) != 0 &&
-                env_int("LQP_LOOP_SPLIT_SEG", 1) != 0 && !ctl->check_hook)
+            if (mode == 2 && ctl->launch_mode == 0 && knobs().launch_mode == 2 && spd && P.xchg && 2 * B > cus &&
+                P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 && knobs().loop_split != 0 &&
+                knobs().loop_split_seg != 0 && !ctl->check_hook)
                 mode = 1;
         }
     }
@@ -679,7 +751,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     int split_lds = 0, split_nt = 512, loop_np = 1;
     void (*split_fn)(const FwdParams<float>, const int, const int, const int) = nullptr;
     if constexpr (sizeof(T) == 4) {
-        if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && env_int("LQP_LOOP_SPLIT", 1) != 0) {
+        if (spd && mode == 2 && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && knobs().loop_split != 0) {
             // 512 threads x 256 VGPRs: every block of the workgroup's half lives in registers.  (The 1024-thread
             // build -- 12 blocks in 128 VGPRs, 6 in LDS, 16 waves -- spills ~60 VGPRs into the hot loop and measured
             // 0.38 ms against 0.28 ms at B = 128, n = 500; the template still takes NT = 1024.)
@@ -687,7 +759,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             int dev = 0, cus = 0, per_cu = 0;
             if (!current_device_cus(&dev, &cus)) return LQP_ERR_HIP;
             // four workgroups per QP (one column pair each) when the batch leaves room for them: B <= #CUs / 4
-            if (P.Ks >= 7 && 4 * B <= cus && env_int("LQP_LOOP_SPLIT4", 1) != 0) {
+            if (P.Ks >= 7 && 4 * B <= cus && knobs().loop_split4 != 0) {
                 split_lds = split_loop_lds_bytes<512, 4>(P.Ks, m);
                 split_fn = P.Ks == 7 ? k_admm_loop_split<7, 512, false, 4> : k_admm_loop_split<8, 512, false, 4>;
                 if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
@@ -712,7 +784,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     bool loop_split_seg = false;
     if constexpr (sizeof(T) == 4) {
         if (spd && mode == 1 && !loop_split && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 &&
-            env_int("LQP_LOOP_SPLIT", 1) != 0 && env_int("LQP_LOOP_SPLIT_SEG", 1) != 0) {
+            knobs().loop_split != 0 && knobs().loop_split_seg != 0) {
             int dev = 0, cus = 0, per_cu = 0;
             split_nt = 512;
             split_lds = split_loop_lds_bytes<512>(P.Ks, m);
@@ -728,7 +800,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     bool loop_small = false;
     int small_lds = 0;
     if constexpr (sizeof(T) == 4) {
-        if (spd && mode == 2 && !loop_split && P.Ks <= 2 && env_int("LQP_LOOP_SMALL", 1) != 0) {
+        if (spd && mode == 2 && !loop_split && P.Ks <= 2 && knobs().loop_small != 0) {
             int dev = 0, cus = 0, per_cu = 0;
             small_lds = small_loop_lds_bytes(m);
             if (current_device_cus(&dev, &cus) && blocks_per_cu(&per_cu, k_admm_loop_small<>, 256, small_lds, dev) &&
@@ -740,7 +812,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // (ctrl.reserved2 bit 0: the caller will read the corrected H from the workspace afterwards -- lqp_boxqp_unroll_backward --
     //  so the correction must reach global memory: k_spd_end runs)
     if constexpr (sizeof(T) == 4)
-        P.eq_in_loop = (loop_split && spd_resident && m > 0 && !(ctl->reserved2 & 1) && env_int("LQP_EQ_IN_LOOP", 1)) ? 1 : 0;
+        P.eq_in_loop = (loop_split && spd_resident && m > 0 && !(ctl->reserved2 & 1) && knobs().eq_in_loop) ? 1 : 0;
     rc = factor_step(nullptr);
     if (rc) return rc;
     // the first launch of the persistent modes
@@ -765,13 +837,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     //      (lqp_boxqp_forward_layout).  Only taken when the number of adaptive-rho events is small.
     // A synchronous call (the default: the reference's semantics) enqueues the same schedule and then waits for the report
     // the last kernel stores into the caller's pinned memory (wait_report) -- not for the stream.
-    if ((ctl->reserved >= 1 || env_int("LQP_SYNC_PLAN", 1) != 0) && mode == 2) {
+    if ((ctl->reserved >= 1 || knobs().sync_plan != 0) && mode == 2) {
         int n_events = 0;
         if (ctl->adaptive_rho)
             for (int a = ar_iter; a < max_iters && a < ctl->adaptive_rho_max_iter; a += ar_iter) ++n_events;
-        if (n_events <= env_int("LQP_NOSYNC_MAX_EVENTS", 12)) {
+        if (n_events <= knobs().nosync_max_events) {
             int it = 0;
-            const bool tail_epilogue = env_int("LQP_TAIL_EPILOGUE", 1) != 0;
+            const bool tail_epilogue = knobs().tail_epilogue != 0;
             bool epilogue_done = false;
             while (it < max_iters) {
                 // the adaptive-rho step of iteration `it` runs as the prologue of the continuation kernel
@@ -882,7 +954,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     long long zeroed_upto = kRing;     // check indices [0, zeroed_upto) have clean slots
     bool done = false, singular_checked = false;
     int nfactor_seen = 0;
-    int chunk_cap = env_int("LQP_SPEC_LAUNCHES", 6);
+    int chunk_cap = knobs().spec_launches;
     int fail_index = -1;
     while (it < max_iters && !done) {
         int in_chunk = 0;
@@ -1064,7 +1136,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     if (linsolve & LQP_BWD_PREFACTORED) { linsolve &= ~LQP_BWD_PREFACTORED; if (phase == 0 && !kkt) phase = 2; }
     P.host_report = (int*)host_report;
     if (P.host_report) report_reset(P.host_report, B);
-    P.early_report = env_int("LQP_BWD_EARLY", 1) != 0 ? 1 : 0;
+    P.early_report = knobs().bwd_early != 0 ? 1 : 0;
     const size_t need = carve_backward<T>(ws, B, n, m, P);
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
     P.g = (const T*)g; P.x = (const T*)x; P.u = (const T*)u; P.lams = (const T*)lams; P.nus = (const T*)nus;
@@ -1073,13 +1145,13 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     P.dQ = (T*)dQ; P.dp = (T*)dp; P.dA = (T*)dA; P.db = (T*)db; P.dlb = (T*)dlb; P.dub = (T*)dub;
     P.dbg = g_lu_dbg;
     // default: solve on the free set only (see k_bwd_build_reduced); LQP_BWD_FULL=1 keeps the full system
-    P.reduced = (env_int("LQP_BWD_FULL", 0) && !kkt) ? 0 : 1;
+    P.reduced = (knobs().bwd_full && !kkt) ? 0 : 1;
     const int* nvec = P.reduced ? P.nred : nullptr;
     // linsolve 2: the caller vouches for a symmetric Q (the forward's symmetric x-update checked it): the
     // reduced system goes through a blocked Cholesky of Q_FF instead of the pivoted LU of the bordered matrix
     bool chol = false;
     if constexpr (sizeof(T) == 4) {
-        chol = P.reduced && linsolve == 2 && env_int("LQP_BWD_CHOL", 1) && round_up(n, LQP_NB) / LQP_NB <= SPD_BIGK &&
+        chol = P.reduced && linsolve == 2 && knobs().bwd_chol && round_up(n, LQP_NB) / LQP_NB <= SPD_BIGK &&
                m <= SPD_MAXM && bwd_chol_lds_bytes(n, m) <= 160 * 1024;
         if (!chol && phase == 1) return LQP_ERR_UNSUPPORTED;      // (nothing to run ahead of the cotangent on the LU form)
         if (!chol) phase = 0;
@@ -1095,7 +1167,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             const int lds = bwd_chol_lds_bytes(n, m);
             {
                 const int Kmax = round_up(n, LQP_NB) / LQP_NB;
-                P.la_maxk = !env_int("LQP_BWD_LOOKAHEAD", 1) ? 0 : (Kmax < SPD_MAXK ? Kmax : SPD_MAXK - 1);
+                P.la_maxk = !knobs().bwd_lookahead ? 0 : (Kmax < SPD_MAXK ? Kmax : SPD_MAXK - 1);
             }
             int r2 = ensure_lds((const void*)k_bwd_chol_solve<>, lds);
             if (r2) return r2;
@@ -1108,7 +1180,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     } else if (P.reduced) {
         const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
         ProfScope ps(st, PC_BWD_BUILD);
-        const int split = (B <= 128 && env_int("LQP_SPLIT2", 1)) ? 2 : 1;
+        const int split = (B <= 128 && knobs().split2) ? 2 : 1;
         hipLaunchKernelGGL(k_bwd_build_reduced<T>, dim3(B, split), dim3(LQP_NT), lds, st, P);
     } else {
         ProfScope ps(st, PC_BWD_BUILD);
@@ -1123,7 +1195,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (rc) return rc;
         rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);
         if (rc) return rc;
-        if (P.reduced && !kkt && env_int("LQP_BWD_REFINE", 1)) {
+        if (P.reduced && !kkt && knobs().bwd_refine) {
             // one refinement step: residual with the original entries (double accumulation), correction solve
             const int lds = (round_up(n, 8) + round_up(m > 0 ? m : 1, 8)) * (int)sizeof(T) + round_up(n, 8) * 4;
             { ProfScope ps(st, PC_BWD_BUILD);
@@ -1139,7 +1211,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         rc = ensure_lds((const void*)fn, lds);
         if (rc) return rc;
         ProfScope ps(st, PC_BWD_EPILOGUE);
-        const int slabs = env_int("LQP_EPI_SLABS", B <= 128 ? 2 : 1);      // row slabs per problem: fill the chip when the batch is small
+        const int slabs = (knobs().epi_slabs < 0 ? (B <= 128 ? 2 : 1) : knobs().epi_slabs);      // row slabs per problem: fill the chip when the batch is small
         hipLaunchKernelGGL(fn, dim3(B, slabs), dim3(LQP_NT), lds, st, P);
     }
     if (hipGetLastError() != hipSuccess) return LQP_ERR_HIP;
@@ -1147,7 +1219,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         int fi = -1;
         // torch.linalg.solve checks info (and waits) too.  The epilogue stores the info words into the caller's pinned
         // memory as it STARTS: the call returns while the gradients are still being written (stream-ordered results)
-        if (P.host_report && env_int("LQP_SYNC_PLAN", 1) != 0) {
+        if (P.host_report && knobs().sync_plan != 0) {
             rc = wait_report(st, P.host_report, B);
             if (rc) return rc;
             for (int i = 0; i < B && fi < 0; ++i)

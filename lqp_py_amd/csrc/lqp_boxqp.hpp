@@ -603,21 +603,6 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_big(T* __restrict__ Mall, 
                                                                piv + (size_t)b * pstride, info + b, smem);
 }
 
-// lookahead LU (f32, N <= 512): panel k+1 on waves 0-7 while waves 8-15 run panel k's trailing update
-template <int PB, int NT>
-__global__ __launch_bounds__(NT) void k_lu_factor_la(float* __restrict__ Mall, const int N, const int ld,
-                                                         const size_t mstride, int* __restrict__ piv, const int pstride,
-                                                         int* __restrict__ info, const int* __restrict__ gate,
-                                                         const int* __restrict__ Nvec, unsigned long long* __restrict__ dbg) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
-    if (gate && *gate == 0) return;
-    const int b = blockIdx.x;
-    if (threadIdx.x == 0) info[b] = 0;
-    __syncthreads();
-    wg_lu_factor_la_f32<PB, NT>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld, piv + (size_t)b * pstride, info + b, smem,
-                            dbg ? dbg + (size_t)b * 4 : nullptr);
-}
-
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_pack(const T* __restrict__ LUall, const int N, const int ld,
                                                  const size_t mstride, const int* __restrict__ piv,
@@ -1058,28 +1043,9 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     lr.rho_given = (fused && P.rho_mode != 0) ? P.scal[(size_t)b * SC_WORDS + SC_RHO] : 0.f;
     lr.xcd_local = P.xcd_local;
     const RsSetupHooks hooks{P, b, part, NP};
-#if LQP_PIV_MFMA && LQP_RS_V2 == 3
-    wg_spd_sweep_resident_v3<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
-                                 P.info + b, P.status + ST_TIMEOUT, smem, lr,
-                                 (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
-#elif LQP_PIV_MFMA && LQP_RS_V2 == 4
-    if constexpr (NP == 2)
-        wg_spd_sweep_resident_v4<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
-                                         P.info + b, P.status + ST_TIMEOUT, smem, lr,
-                                         (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
-    else
-        wg_spd_sweep_resident_v2<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
-                                         P.info + b, P.status + ST_TIMEOUT, smem, lr,
-                                         (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
-#elif LQP_PIV_MFMA && LQP_RS_V2
     wg_spd_sweep_resident_v2<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
                                  (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr, hooks);
-#else
-    wg_spd_sweep_resident<KS>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
-                              P.info + b, P.status + ST_TIMEOUT, smem, lr, -1,
-                              (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr);
-#endif
 }
 template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_end(const FwdParams<float> P, const int* __restrict__ gate) {

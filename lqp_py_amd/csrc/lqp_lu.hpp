@@ -433,259 +433,8 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Lookahead variant (f32, 1024 threads, N <= 512).  The panel factorisation is a dependent-latency
-// chain (~2k cycles per column) and the trailing update is bound by the per-CU memory path; run back
-// to back they add up, so they are overlapped: after the swaps / U12 of panel k,
-//   * waves 0-7 ("panel group") load the next panel's rows, apply panel k's update to just those PB
-//     columns in registers (L21 from LDS, U12 from LDS) and factor panel k+1, synchronising among
-//     themselves through an LDS counter (the hardware barrier would also wait for the other group);
-//   * waves 8-15 ("update group") run the MFMA trailing update of panel k on the remaining columns.
-// Both groups meet at a workgroup barrier; panel k+1 then stays in registers until its write-back.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void group_barrier(int* bar, int& epoch, const int nwaves) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS traffic has landed
-    ++epoch;
-    if ((threadIdx.x & 63) == 0) atomicAdd(bar, 1);
-    const int target = epoch * nwaves;
-    // bounded: a wave that never arrives must not hang the GPU (bar goes negative -> everybody falls through)
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();             // 100 MHz
-    while (true) {
-        const int seen = __builtin_amdgcn_readfirstlane(*(volatile int*)bar);
-        if (seen >= target || seen < 0) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) { *(volatile int*)bar = -1000000000; break; }
-    }
-    asm volatile("" ::: "memory");
-}
-
-// trailing update by the waves [wave0, wave0 + nwaves); columns < col_skip of A22 are left alone
-template <int PB>
-__device__ __forceinline__ void lu_trailing_mfma_f32_part(float* __restrict__ A22, const int ld, const int M2,
-                                                           const float* __restrict__ LT, const float* __restrict__ UP,
-                                                           const int Mpad, const int wave0, const int nwaves,
-                                                           const int col_skip) {
-    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) - wave0;
-    const int li = lane & 31, lh = lane >> 5;
-    const int nt = (M2 + 31) >> 5;
-    const int ntiles = nt * nt;
-    const int voff = 4 * lh * ld + li;
-    for (int t = __builtin_amdgcn_readfirstlane(w); t < ntiles; t += nwaves) {
-        const int ti = t / nt, tj = t - ti * nt;
-        const int i0 = ti << 5, j0 = tj << 5;
-        float* base = A22 + (size_t)i0 * ld + j0;
-        const bool colok = (j0 + li < M2) && (j0 + li >= col_skip);
-        const int rlim = M2 - i0 - 4 * lh;
-        f32x16 cur;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int qrow = (q & 3) + 8 * (q >> 2);
-            cur[q] = (colok && qrow < rlim) ? base[(size_t)qrow * ld + voff] : 0.f;
-        }
-        const float* lt = LT + i0 + li + lh * Mpad;
-        const float* up = UP + j0 + li + lh * Mpad;
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < PB; kk += 2) {
-            const float a = lt[kk * Mpad];
-            const float b = up[kk * Mpad];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        cur -= acc;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int qrow = (q & 3) + 8 * (q >> 2);
-            if (colok && qrow < rlim) base[(size_t)qrow * ld + voff] = cur[q];
-        }
-    }
-}
-
-template <int PB, int NT>
-__device__ __forceinline__ void wg_lu_factor_la_f32(float* __restrict__ A, const int N, const int ld,
-                                                    int* __restrict__ ipiv, int* __restrict__ info,
-                                                    char* __restrict__ smem, unsigned long long* __restrict__ dbg) {
-    typedef float T;
-    typedef V4<T> vec;
-    unsigned long long t_p = 0, t_u = 0, t_ser = 0, t_all = dbg ? clock64() : 0, tq = 0;
-    constexpr int NPW = 8;                          // waves in the panel group (rows 0..511)
-    const int Mpad = round_up(N, 64);
-    const LuLds<T, PB> L(Mpad);
-    T* LT = (T*)(smem + L.lt);
-    T* UP = (T*)(smem + L.up);
-    T* L11 = (T*)(smem + L.l11);
-    T* rowP = (T*)(smem + L.rowp);
-    T* wval = (T*)(smem + L.wval);
-    T* wrcp = (T*)(smem + L.wrcp);
-    int* widx = (int*)(smem + L.widx);
-    int* wtid = (int*)(smem + L.wtid);
-    int* pidx = (int*)(smem + L.pidx);
-    int* src = (int*)(smem + L.src);
-    int* xdst = (int*)(smem + L.xdst);
-    int* xsrc = (int*)(smem + L.xsrc);
-    int* cnt = (int*)(smem + L.cnt);              // [0] displaced-row counter, [1] info, [2] group barrier
-    const PanelLds<T> S{rowP, wval, wrcp, widx, wtid, pidx, cnt};
-
-    const int tid = threadIdx.x;
-    const bool isP = tid < NPW * 64;
-    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
-    const int r = tid;
-    int epoch = 0;
-    if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = 0; }
-    if (tid < 2 * LQP_NW) wval[tid] = T(-2);      // slots of the update group's waves never win
-    __syncthreads();
-
-    // this thread's row of the CURRENT panel (panel group only)
-    vec row4[PB / 4];
-    int curpos = r;
-    bool done = true;
-
-    // ---- prologue: factor panel 0 (the update group waits at the first workgroup barrier) ----
-    if (isP) {
-        const int pb = N < PB ? N : PB;
-        const bool act = r < N;
-        if (pb == PB) {
-#pragma unroll
-            for (int q = 0; q < PB / 4; ++q) {
-                if (act) row4[q] = *(const vec*)(A + (size_t)r * ld + 4 * q);
-                else { row4[q].v[0] = row4[q].v[1] = row4[q].v[2] = row4[q].v[3] = T(0); }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < PB; ++c) row4[c >> 2].v[c & 3] = (act && c < pb) ? A[(size_t)r * ld + c] : T(0);
-        }
-        done = !act;
-        lu_panel_columns<T, PB>(row4, curpos, done, wbase < N, pb, 0, r, S, [&] { group_barrier(cnt + 2, epoch, NPW); });
-    }
-
-    for (int k0 = 0; k0 < N; k0 += PB) {
-        const int pb = (N - k0 < PB) ? (N - k0) : PB;
-        const int M = N - k0;
-        const int M2 = M - pb;
-        const bool act = isP && r < M;
-        __syncthreads();                      // panel k0 complete in the panel group's registers; cnt[0] == 0
-        if (dbg) tq = clock64();
-
-        // ---- (1) write the factored panel back at its final position; stage L11 and L21^T in LDS ----
-        if (act) {
-            if (pb == PB) {
-#pragma unroll
-                for (int q = 0; q < PB / 4; ++q) *(vec*)(A + (size_t)(k0 + curpos) * ld + k0 + 4 * q) = row4[q];
-            } else {
-#pragma unroll
-                for (int c = 0; c < PB; ++c)
-                    if (c < pb) A[(size_t)(k0 + curpos) * ld + k0 + c] = row4[c >> 2].v[c & 3];
-            }
-            if (curpos < pb) {
-#pragma unroll
-                for (int c = 0; c < PB; ++c) L11[curpos * (PB + 1) + c] = row4[c >> 2].v[c & 3];
-            } else {
-#pragma unroll
-                for (int c = 0; c < PB; ++c) LT[c * Mpad + (curpos - pb)] = row4[c >> 2].v[c & 3];
-            }
-            src[curpos] = r;
-            if (curpos >= pb && curpos != r) {
-                const int q = atomicAdd(cnt, 1);
-                xdst[q] = curpos;
-                xsrc[q] = r;
-            }
-        }
-        __syncthreads();
-        if (tid < pb) ipiv[k0 + tid] = k0 + pidx[tid] + 1;
-        const int ne = __builtin_amdgcn_readfirstlane(*cnt);
-        bool anyswap = ne > 0;
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-            if (j < pb && __builtin_amdgcn_readfirstlane(src[j]) != j) anyswap = true;
-
-        // ---- (2) interchanges left and right of the panel; U12 = L11^-1 (PA)12 ----
-        if (tid < N - pb) {
-            const bool right = tid >= k0;
-            const int col = right ? tid + pb : tid;
-            if (right || anyswap) {
-                T* Ac = A + (size_t)k0 * ld + col;
-                T top[PB];
-#pragma unroll
-                for (int j = 0; j < PB; ++j)
-                    top[j] = (j < pb) ? Ac[(size_t)__builtin_amdgcn_readfirstlane(src[j]) * ld] : T(0);
-                for (int q0 = 0; q0 < ne; q0 += 8) {
-                    T ext[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        ext[q] = (q0 + q < ne) ? Ac[(size_t)__builtin_amdgcn_readfirstlane(xsrc[q0 + q]) * ld] : T(0);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (q0 + q < ne) Ac[(size_t)__builtin_amdgcn_readfirstlane(xdst[q0 + q]) * ld] = ext[q];
-                }
-                if (right) {
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-#pragma unroll
-                        for (int i = j + 1; i < PB; ++i) top[i] -= L11[i * (PB + 1) + j] * top[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) UP[j * Mpad + (col - k0 - pb)] = top[j];
-                }
-#pragma unroll
-                for (int j = 0; j < PB; ++j)
-                    if (j < pb && (right || __builtin_amdgcn_readfirstlane(src[j]) != j)) Ac[(size_t)j * ld] = top[j];
-            }
-        }
-        __syncthreads();
-        if (tid == 0) *cnt = 0;               // for the next panel's displaced-row list (read after 2 barriers)
-        if (dbg) { const unsigned long long t1 = clock64(); t_ser += t1 - tq; tq = t1; }
-
-        // ---- (3) panel group: next panel; update group: trailing update of this panel ----
-        const int k1 = k0 + pb;
-        const int pb1 = (N - k1 < PB) ? (N - k1) : PB;      // width of the next panel (<= 0: none)
-        if (isP) {
-            if (k1 < N) {
-                const int M1 = N - k1;
-                const bool act1 = r < M1;
-                // rows of the next panel: position k1 + r, columns k1 .. k1 + pb1 (swaps of panel k0 applied)
-                if (pb1 == PB) {
-#pragma unroll
-                    for (int q = 0; q < PB / 4; ++q) {
-                        if (act1) row4[q] = *(const vec*)(A + (size_t)(k1 + r) * ld + k1 + 4 * q);
-                        else { row4[q].v[0] = row4[q].v[1] = row4[q].v[2] = row4[q].v[3] = T(0); }
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < PB; ++c)
-                        row4[c >> 2].v[c & 3] = (act1 && c < pb1) ? A[(size_t)(k1 + r) * ld + k1 + c] : T(0);
-                }
-                // panel k0's update restricted to these PB columns:  row -= L21[r, :] * U12[:, 0:PB]
-                if (act1) {
-#pragma unroll 4
-                    for (int kk = 0; kk < PB; ++kk) {
-                        const T l = LT[kk * Mpad + r];
-#pragma unroll
-                        for (int q = 0; q < PB / 4; ++q) {
-                            const vec uq = *(const vec*)(UP + kk * Mpad + 4 * q);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) row4[q].v[e] -= l * uq.v[e];
-                        }
-                    }
-                }
-                curpos = r;
-                done = !act1;
-                lu_panel_columns<T, PB>(row4, curpos, done, wbase < M1, pb1, k1, r, S,
-                                        [&] { group_barrier(cnt + 2, epoch, NPW); });
-            }
-        } else if (M2 > 0) {
-            lu_trailing_mfma_f32_part<PB>(A + (size_t)k1 * ld + k1, ld, M2, LT, UP, Mpad, NPW, NT / 64 - NPW,
-                                          pb1 > 0 ? pb1 : 0);
-        }
-        if (dbg) { const unsigned long long t1 = clock64(); if (isP) t_p += t1 - tq; else t_u += t1 - tq; }
-    }
-    __syncthreads();
-    if (dbg && tid == 0) { dbg[0] = t_p; dbg[1] = t_ser; dbg[3] = clock64() - t_all; }
-    if (dbg && tid == 512) dbg[2] = t_u;
-    if (tid == 0 && cnt[1] != 0) *info = cnt[1];
-    if (tid == 0 && cnt[2] < 0) *info = -7;        // panel-group barrier timed out (should never happen)
-}
-
+// (A look-ahead variant inside ONE workgroup -- waves 0-7 factoring panel k+1 while waves 8-15 ran panel k's trailing update -- was
+//  measured no faster in rounds 1-2 and is gone from the sources; the look-ahead that pays runs on two CUs: lqp_lu2.hpp.)
 // Panel width: L21^T and U12 (2 * PB * Mpad elements) must fit in LDS, and the panel row plus the
 // broadcast pivot row (2 * PB elements per thread) must fit the register budget without spilling:
 // 128 VGPRs in a 1024-thread workgroup (f32: 16 columns, f64: 8), 256 VGPRs in a 512-thread one

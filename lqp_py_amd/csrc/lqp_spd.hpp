@@ -344,46 +344,12 @@ __device__ __forceinline__ f32x16 spd_quadrant(const float* __restrict__ X, cons
 }
 // the same product with the lane parts of the operand addresses made by the caller: xa = X + (l&31) * SPD_LS + kb,
 // zb = Z + (l&31) * SPD_LS + kb, kb = 32 (l>>5) for the full k range, 16 (l>>5) [+ 32: upper half] with HALF
-// The operands of group t + 1 are requested BEFORE the four matrix instructions of group t (LQP_QUAD_PF, 8 more registers):
-// as the compiler emits the plain loop -- four instructions, two LDS reads into the same registers, wait, four instructions --
-// a wave that is alone on its SIMD stands through one LDS latency per group (measured: one matrix instruction per ~135
-// cycles instead of 64; two waves per SIMD hide it for each other).  Same products in the same order.
-// wg_spd_sweep_resident_v2: the tiles of row / column k+1 updated and published FIRST in step k (their write-through stores
-// would drain under the other tiles' updates).  Measured (round 4): correct, bit-identical, 113 instead of 64 spilled registers
-// (two passes over the slots) and 0.372 against 0.365 ms; with the tile indices opaque per step (one spilled register either
-// way) still 0.365 against 0.357 -- not the default.
-#ifndef LQP_QPASS_MD
-#define LQP_QPASS_MD 2
-#endif
-#ifndef LQP_RS2_EARLY_PUBLISH
-#define LQP_RS2_EARLY_PUBLISH 0
-#endif
-#ifndef LQP_QUAD_PF
-#define LQP_QUAD_PF (LQP_RS_V2 == 4)      // (the default sweep runs two waves per SIMD: pipe-bound either way, and 8 registers matter there)
-#endif
 template <int HALF = 0>
 __device__ __forceinline__ f32x16 spd_quadrant_lp(const float* __restrict__ xa, const float* __restrict__ zb) {
     constexpr int KL = HALF ? 16 : 32;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#if LQP_QUAD_PF
-    V4<float> a = *(const V4<float>*)xa, b = *(const V4<float>*)zb;
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-    for (int t = 0; t < KL / 4; ++t) {
-        V4<float> an = a, bn = b;
-        if (t + 1 < KL / 4) {
-            an = *(const V4<float>*)(xa + 4 * (t + 1));
-            bn = *(const V4<float>*)(zb + 4 * (t + 1));
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two LDS reads first ...
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[e], b.v[e], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);          // ... then this group's four matrix instructions
-        a = an; b = bn;
-    }
-#else
 #pragma unroll
     for (int t = 0; t < KL / 4; ++t) {
         const V4<float> a = *(const V4<float>*)(xa + 4 * t);
@@ -391,7 +357,6 @@ __device__ __forceinline__ f32x16 spd_quadrant_lp(const float* __restrict__ xa, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[e], b.v[e], acc, 0, 0, 0);
     }
-#endif
     return acc;
 }
 // accumulator register q of lane l is element (row = (q&3) + 8 (q>>2) + 4 (l>>5), col = l&31) of the quadrant
@@ -1922,28 +1887,7 @@ __device__ __forceinline__ float split_combine(const int e, const int Np, const 
 // The multi-launch form (k_spd_begin/step/end) moved all 36 tiles through L2/HBM in every step (1.24 GB per batch of
 // 128 at n = 500, 13x the minimum); this one reads the matrix once and writes it once.
 // ---------------------------------------------------------------------------
-#ifndef LQP_RS_PIV_MFMA
-#define LQP_RS_PIV_MFMA 0      // (the first resident sweep with the matrix-core pivot block: spills, see wg_spd_sweep_resident_v2)
-#endif
-#ifndef LQP_RS_V2
-#define LQP_RS_V2 2            // k_spd_resident runs wg_spd_sweep_resident_v2 (2) / _v3 (3: measured slower, see there) / _v4 for two
-                               // workgroups per matrix and _v2 for four (4: the look-ahead form, measured no faster); 0: the first form
-#endif
 constexpr int RS_NT = 512, RS_NW = RS_NT / 64;
-template <int K> __host__ __device__ constexpr int rs_slots() {
-    const int a = split_count(K, 0), b = split_count(K, 1);
-    return (4 * (a > b ? a : b) + RS_NW - 1) / RS_NW;
-}
-// (i, j) of local tile l of workgroup `part` (columns ascending, as SplitMap)
-__device__ __forceinline__ void rs_tile_of(int l, const int K, const int part, int& ti, int& tj) {
-    ti = 0; tj = 0;
-    for (int j = 0; j < K; ++j) {
-        if (split_owner(j, K) != part) continue;
-        if (l < K - j) { ti = j + l; tj = j; return; }
-        l -= K - j;
-    }
-}
-
 // xb: exchange buffer of this matrix, [2][K][4096] floats; fl: step flags of the two workgroups; epoch: added to the
 // step numbers (a refactorisation in the same forward must not match the flags of the first one)
 // rho not known when the blocks were built (FwdParams::rho_late): the two halves of ||Qs||_F^2 wait behind the exchange
@@ -1953,13 +1897,13 @@ struct RsLateRho {
     int on, n;
     float rho_min, rho_max;
     float* rho_out;           // workgroup 0 only
-    // wg_spd_sweep_resident_v2 only -- the blocks are UNSCALED (k_spd_prep built them before the scaling was known):
+    // the blocks are UNSCALED (k_spd_prep built them before the scaling was known):
     const float* dsc;         // the scaling D (n values): a tile entry is taken as (D_row * v) * D_col, like sym_scale4
     int fro_self;             // 1: rho = clamp(||Qs||_F / sqrt(n)) with the norm summed from the tiles themselves (the two
                               //    workgroups swap their halves with the step-0 flags); 0 (with dsc): rho_given is added
     float rho_given;
     int xcd_local;            // 1: workgroups that find themselves on ONE XCD exchange through its L2 (workgroup-scope stores)
-    // wg_spd_sweep_resident_v2 only -- the sweep makes the pass over the UNSCALED matrix itself (FwdParams::prep_fused == 3):
+    // the sweep makes the pass over the UNSCALED matrix itself (FwdParams::prep_fused == 3):
     const float* q;           // Q of this problem (n x n, row-major); nullptr: off
     float* cmx;               // global scratch of this problem: [NP][64 K + 2] words (column maxima | asymmetry | magnitude)
     unsigned long long* qdbg; // optional: 8 cycle stamps of the pass (tools/gpu_resident_phases.py), workgroup 0 of the matrix
@@ -1971,190 +1915,6 @@ struct RsNoScaling {
     __device__ __forceinline__ void scaling(float*, float*, float*) const {}
     __device__ __forceinline__ void deferred(const float*) const {}
 };
-template <int K>
-// (Hsrc and Hdst may be the same buffer -- even K: the blocks are all loaded before the first store, barriers in between)
-__device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* Hdst,
-                                                      float* __restrict__ xb, unsigned int* __restrict__ fl,
-                                                      const unsigned int epoch, const int part, int* __restrict__ info,
-                                                      int* __restrict__ status_timeout, char* smem,
-                                                      const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
-                                                      const int dbg_stop = -1,
-                                                      unsigned long long* __restrict__ dbg = nullptr) {
-    constexpr int NS = rs_slots<K>();
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
-    const int nloc = split_count(K, part);
-    float* Y = (float*)smem;
-    float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
-    float* WT = W + 64 * SPD_LS;
-    float* pcol = WT + 64 * SPD_LS;
-    int* flag = (int*)(pcol + PIV_LDS);
-    if (tid == 0) flag[0] = 0;
-
-    // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
-    f32x16 T[NS];
-    int ti[NS], tj[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int l = 2 * s + (w >> 2);
-        int a, b;
-        rs_tile_of(l < nloc ? l : 0, K, part, a, b);
-        ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
-        tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
-        if (ti[s] >= 0) {
-            const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
-            if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
-                // upper-right quadrant of a diagonal tile := transpose of its lower-left one.  (Q is symmetric only to
-                // rounding; the multi-launch sweep mirrors these quadrants after every step, so this keeps the two
-                // schedules bit-identical.  Tile (0,0) is the first pivot: both use it as given.)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
-            } else {
-                const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
-            }
-        }
-    }
-
-    if (lr.on) {
-        const float* xw = xb + (size_t)2 * K * LQP_BLK;
-        float rho = sqrtf(xw[0] + xw[1]) / (float)sqrt((double)lr.n);
-        rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
-        if (tid == 0 && lr.rho_out) *lr.rho_out = rho;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (quad_row(q, lh) == li && ti[s] * 64 + 32 * qi + li < lr.n) T[s][q] += rho;
-            }
-        }
-    }
-
-    unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
-    // publish the pivot tile and the panel tiles of step kk this workgroup holds.  A wave does so as soon as ITS quadrants
-    // have step kk-1's update (end of the step body): the store drain then overlaps with the wait for the slowest wave.
-    auto publish = [&](const int kk) {
-        float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int i = ti[s], j = tj[s];
-            if (i >= 0 && (i == kk || j == kk)) {
-                const int slot = (i == kk && j == kk) ? K - 1 : (j == kk ? i - 1 : j);      // P_i: i > kk -> i - 1, i < kk -> i
-                unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float tv = T[s][q];      // (bit_cast straight from the vector element stores element 0 sixteen times)
-                    __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    };
-    publish(0);
-    for (int k = 0; k < K; ++k) {
-        if (dbg) dt0 = clock64();
-        float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // (also closes step k-1: every wave is done with the LDS panel)
-        if (tid == 0) {
-            __hip_atomic_store(fl + part, epoch + (unsigned int)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load(fl + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + (unsigned int)k + 1u) {
-                __builtin_amdgcn_s_sleep(2);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
-                    __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (k == dbg_stop) return;
-        if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
-        // ---- pivot tile -> W, W^T; panel tiles -> LDS (slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k) ----
-        // (the matrix-core pivot block needs 32 accumulator registers next to the 144 this kernel keeps its tiles in: the
-        //  compiler then spills 245 registers and the sweep takes 0.55 ms instead of 0.36 -- see LQP_RS_PARK)
-        wg_pivot<LQP_PIV_WAVES_RS, (LQP_PIV_MFMA != 0 && LQP_RS_PIV_MFMA != 0)>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64);
-        if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
-        {
-            const int r = tid >> 3, c8 = (tid & 7) * 8;
-#pragma unroll
-            for (int s0 = 0; s0 < K - 1; ++s0) {
-                const float* src = xbk + (size_t)s0 * LQP_BLK + tid * 8;
-                const V4<float> a = *(const V4<float>*)src, b = *(const V4<float>*)(src + 4);
-                float* Ys = Y + (size_t)s0 * 64 * SPD_LS;
-                if (s0 >= k) {
-                    *(V4<float>*)(Ys + r * SPD_LS + c8) = a;
-                    *(V4<float>*)(Ys + r * SPD_LS + c8 + 4) = b;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { Ys[(c8 + e) * SPD_LS + r] = a.v[e]; Ys[(c8 + 4 + e) * SPD_LS + r] = b.v[e]; }
-                }
-            }
-        }
-        __syncthreads();
-        if (dbg) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
-        // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves), so nobody else reads
-        //      the rows it overwrites ----
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
-            if (rb < 2 * (K - 1)) {
-                float* Xp = Y + ((size_t)(rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
-                const f32x16 a0 = spd_quadrant<1, false>(Xp, W);
-                const f32x16 a1 = spd_quadrant(Xp, W + 32 * SPD_LS);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    Xp[quad_row(q, lh) * SPD_LS + li] = a0[q];
-                    Xp[quad_row(q, lh) * SPD_LS + 32 + li] = a1[q];
-                }
-            }
-        }
-        __syncthreads();
-        if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
-        // ---- every resident quadrant by its kind ----
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int i = ti[s], j = tj[s];
-            if (i < 0) continue;
-            if (i != k && j != k) {
-                const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
-                T[s] -= spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS, Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
-            } else if (i == k && j == k) {    // (W^T is upper triangular: rows >= 32 only see k >= 32 -- same halves,
-                                              //  hence the same summation order and bits, as the multi-launch sweep)
-                const f32x16 a = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
-                                           : spd_quadrant(WT, WT);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
-            } else if (j == k) {              // tile (i, k), i > k: Y_i W
-                const float* Yi = Y + ((size_t)(i - 1) * 64 + 32 * qi) * SPD_LS;
-                T[s] = qj == 1 ? spd_quadrant<1, true>(Yi, WT + 32 * SPD_LS) : spd_quadrant(Yi, WT);
-            } else {                          // tile (k, j), j < k: W^T Y_j^T
-                const float* Yj = Y + ((size_t)j * 64 + 32 * qj) * SPD_LS;
-                T[s] = qi == 1 ? spd_quadrant<1, true>(WT + 32 * SPD_LS, Yj) : spd_quadrant(WT, Yj);
-            }
-        }
-        if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
-        if (k + 1 < K) publish(k + 1);
-        if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
-    }
-    if (dbg && tid == 0)
-        for (int q = 0; q < 6; ++q) dbg[q] = dbt[q];
-    // ---- the finished tiles to their home blocks ----
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (ti[s] >= 0) {
-            float* C = Hdst + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
-        }
-    }
-    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
-}
 
 // ---- the same resident sweep with the pivot block on the matrix cores --------------------------------------------
 // wg_pivot_block_mfma keeps 32 accumulator registers per working wave next to the tiles; with 9 x 16 tile registers in
@@ -2162,7 +1922,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident(const float* Hsrc, float* 
 // working waves) hold NA tiles each, waves 4..7 NB = nloc - NA (8 and 10 of 18 at K = 8).  Wave w and wave w + 4 share a
 // SIMD, so every SIMD still carries 18 quadrant updates per step: the update phase stays MFMA-bound.  While waves 0..3 run
 // the pivot block, waves 4..7 stage the panel (it used to be staged by everybody afterwards).  Same exchange protocol,
-// same arithmetic per tile as wg_spd_sweep_resident; results differ from it only through the pivot block's rounding.
+// same arithmetic per tile as the first resident sweep (round 2; its code is in the repository's history).
 template <int K, int NP = 2> __host__ __device__ constexpr int rs2_max() {
     int mx = 0;
     for (int q = 0; q < NP; ++q) { const int a = split_count(K, q, NP); mx = a > mx ? a : mx; }
@@ -2253,7 +2013,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (ti[s] >= 0 && !lr.q) {
                 const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
                 if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
-                    // upper-right quadrant of a diagonal tile := transpose of its lower-left one (see wg_spd_sweep_resident)
+                    // upper-right quadrant of a diagonal tile := transpose of its lower-left one (as in the block sweep)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
                 } else {
@@ -2296,7 +2056,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 #pragma unroll
                 for (int q = 0; q < 16; ++q) dst[q] = (r0 + quad_row(q, lh) < n && col < n) ? dst[q] : 0.f;
             };
-            constexpr int MD = LQP_QPASS_MD;                        // mirrors requested ahead (measured, group ms / spilled registers: 2: 0.358 / 31, 3: 0.360 / 63, 4: 0.378 / 125)
+            constexpr int MD = 2;                        // mirrors requested ahead (measured, group ms / spilled registers: 2: 0.358 / 31, 3: 0.360 / 63, 4: 0.378 / 125)
             f32x16 M[MD];
 #pragma unroll
             for (int s = 0; s < MD && s < NS; ++s)
@@ -2618,38 +2378,6 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
             // ---- every resident quadrant by its kind ----
             const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
-#if LQP_RS2_EARLY_PUBLISH
-            auto update_slot = [&](const int s) {
-                int i = ti[s], j = tj[s];
-                asm volatile("" : "+s"(i), "+s"(j));        // (opaque per step: see the plain loop below)
-                if (i != k && j != k) {
-                    const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
-                    T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
-                } else if (i == k && j == k) {    // (W^T is upper triangular: rows >= 32 only see k >= 32 -- same halves,
-                                                  //  hence the same summation order and bits, as the multi-launch sweep)
-                    const f32x16 a = (qi | qj) ? spd_quadrant_lp<1>(yH + 32 + WTOFF + oi, yH + 32 + WTOFF + oj)
-                                               : spd_quadrant_lp<0>(yF + WTOFF, yF + WTOFF);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
-                } else if (j == k) {              // tile (i, k), i > k: Y_i W
-                    const int yo = (i - 1) * 64 * SPD_LS + oi;
-                    T[s] = qj == 1 ? spd_quadrant_lp<1>(yH + 32 + yo, yH + 32 + WTOFF + 32 * SPD_LS) : spd_quadrant_lp<0>(yF + yo, yF + WTOFF);
-                } else {                          // tile (k, j), j < k: W^T Y_j^T
-                    const int yo = j * 64 * SPD_LS + oj;
-                    T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
-                }
-            };
-            // first the tiles the partner waits for -- row / column k+1: the next pivot tile and panel -- and their stores at once:
-            // the write-through drains under the other tiles' updates instead of in front of the step's closing barrier
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if (ti[s] >= 0 && (ti[s] == k + 1 || tj[s] == k + 1)) update_slot(s);
-            if (k + 1 < K) publish(k + 1);
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if (ti[s] >= 0 && !(ti[s] == k + 1 || tj[s] == k + 1)) update_slot(s);
-            if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
-#else
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 // (opaque per step: what the compiler can derive from a slot's tile indices alone -- lane addresses of its panel
@@ -2676,7 +2404,6 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             }
             if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
             if (k + 1 < K) publish(k + 1);
-#endif
             if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
         }
         if (dbg && tid == 0)
@@ -2697,782 +2424,12 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
 }
 
-// ---- resident sweep, fourth form: LOOK-AHEAD without a second W / W^T pair -------------------------------------------
-// In wg_spd_sweep_resident_v2 the matrix pipes idle while waves 0..3 eliminate the pivot block (22.6 k of 84 k cycles per
-// step) and waves 4..7, done with the panel staging after 5.6 k, wait for them.  Here the pivot block of step k+1 and the
-// staging of panel k+1 run INSIDE step k's update phase, in the buffers of step k:
-//   * every wave first updates its tiles of rows / columns k and k+1 -- the only ones that read W_k / W_k^T, and the ones
-//     step k+1 needs (pivot tile, panel) -- and publishes the latter at once; the workgroup's flag of step k+1 is raised by
-//     the wave that sees the last of the eight arrive (an LDS counter), not behind a barrier;
-//   * waves 0..3 (raised priority) finish their other tiles, wait until all eight waves are past the first group -- W_k,
-//     W_k^T are dead then --, take the pivot tile of step k+1 out of the exchange buffer INTO the W area and eliminate it
-//     there (wg_pivot_block_mfma in its group-synchronised form) while waves 4..7 still update;
-//   * waves 4..7 finish their tiles, wait until all eight waves are done with the panel Y_k and stage panel k+1 over it.
-// One workgroup barrier per step closes it (W_{k+1}, W_{k+1}^T and the raw panel k+1 are in place), one more follows the
-// Y phase.  Both workgroups still eliminate every pivot block (nothing but tiles crosses between them, as in v2); same
-// arithmetic per tile in the same order: bit-identical to v2 (tested).  LDS: v2's + 48 bytes of counters (rs4_lds_bytes).
-// MEASURED (round 4, B = 128, n = 500; -DLQP_RS_V2=4, not the default): 0.366 ms against v2's 0.364 -- correct, no spilled
-// vector registers (v2: 20), and no faster.  Stamps of wave 0 / wave 4 per step: Y 14.6 k, wave 0's eight tiles 35 k, waits
-// 8.8 k, pivot block 27.7 k; wave 4's ten tiles 44.7 k, staging 11 k.  Why the overlap does not materialise: ONE wave runs
-// its dependent v_mfma_f32_32x32x2 chains at one instruction per ~135 cycles (8 quadrants in 34 k cycles whether its SIMD
-// partner works, waits or yields -- LQP_RS4_YIELD), half the pipe's rate; the two waves of a SIMD fill the pipe only
-// together, so both finish their tiles at about the same time whatever the priorities, and the pivot block still runs
-// beside idle matrix pipes.  Variants measured slower: the chain waves' pivot block BEFORE their other tiles
-// (LQP_RS4_CHAIN_FIRST: 0.402 ms), the staging waves yielding the pipe (0.372), two accumulator chains per wave interleaved
-// (1134 spilled registers: 0.405), six / twelve tiles per wave (524 spilled).  What it would take: the chain on waves that
-// hold no tiles at all -- 1024 threads per workgroup (four waves per SIMD, 72 quadrant slots over twelve tile waves).
-__host__ __device__ inline int rs4_lds_bytes(int K) { return spd_lds_bytes(K) + 64; }
-// ... + the scaling vector kept across step 0 when the sweep makes the pass over Q itself (wg_spd_sweep_resident_v2, RsLateRho::q)
-__host__ __device__ inline int rs_q_lds_bytes(int K) { return rs4_lds_bytes(K) + 64 * K * 4; }
-// tiles per wave: the chain waves 0..3 take fewer than the others (their pivot block runs behind their updates, and a wave's
-// dependent matrix instructions alternate with its SIMD partner's whatever the priorities: the chain starts the earlier the
-// fewer tiles its waves hold)
-#ifndef LQP_RS4_CHAIN_FIRST
-#define LQP_RS4_CHAIN_FIRST 0
-#endif
-#ifndef LQP_RS4_YIELD
-#define LQP_RS4_YIELD 0
-#endif
-#ifndef LQP_RS4_NA9
-#define LQP_RS4_NA9 3          // ninths of the workgroup's tiles held by waves 0..3 (v2: 4 -> 8 of 18; 3 -> 6 of 18)
-#endif
-#ifdef LQP_RS4_NA            // (... or their number itself, for K = 8)
-template <int K> __host__ __device__ constexpr int rs4_na() { return K == 8 ? LQP_RS4_NA : (rs2_max<K, 2>() * LQP_RS4_NA9) / 9; }
-#else
-template <int K> __host__ __device__ constexpr int rs4_na() { return (rs2_max<K, 2>() * LQP_RS4_NA9) / 9; }
-#endif
-template <int K> __host__ __device__ constexpr int rs4_nb() { return rs2_max<K, 2>() - rs4_na<K>(); }
-// -DLQP_RS4_STAMPS=1 (wave 0) / 2 (wave 4): cycles per phase, summed over the steps, into dbg[0..5] (tools/gpu_resident_phases.py)
-#ifndef LQP_RS4_STAMPS
-#define LQP_RS4_STAMPS 0
-#endif
-#define RS4_STAMP(i) do { if (LQP_RS4_STAMPS && dbg && tid == 64 * (4 * (LQP_RS4_STAMPS - 1))) { const unsigned long long t_ = clock64(); dbt4[i] += t_ - dt4; dt4 = t_; } } while (0)
-template <int K, int NP = 2>
-__device__ __forceinline__ void wg_spd_sweep_resident_v4(const float* Hsrc, float* Hdst,
-                                                         float* __restrict__ xb, unsigned int* __restrict__ fl,
-                                                         const unsigned int epoch, const int part, int* __restrict__ info,
-                                                         int* __restrict__ status_timeout, char* smem,
-                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
-                                                         unsigned long long* __restrict__ dbg = nullptr) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
-    const int nloc = split_count(K, part, NP);
-    float* Y = (float*)smem;
-    float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
-    float* WT = W + 64 * SPD_LS;
-    float* pcol = WT + 64 * SPD_LS;
-    int* flag = (int*)(pcol + PIV_LDS);
-    static_assert(NP == 2, "the look-ahead schedule is written for two workgroups per matrix");
-    // LDS words behind the flags (rs4_lds_bytes): [0] sync of the chain waves | [1] waves done with W_k / W_k^T | [2] waves done
-    // with the panel Y_k | [3] waves whose tiles of step k+1 have left | [4] sync of the staging waves | [5] the partner's tiles
-    // of step k+1 have arrived | [6..7] the pivot block's words
-    int* const sy = flag + 4;
-    if (tid < 16) flag[tid] = 0;
-    // unscaled blocks (k_spd_prep): the scaling vector, 1 on the padding, in LDS while the tiles are loaded (the Y area
-    // is not written before the staging of step 0, two barriers away)
-    float* const Dl = Y;
-    static_assert(64 * K <= RS_NT, "one element of the scaling vector per thread");
-    // (requested first, staged behind the tile loads: its latency then hides under theirs)
-    const float dmine = (lr.dsc && tid < lr.n) ? lr.dsc[tid] : 1.f;
-    // step flags: one 64-bit granule per workgroup {step number, payload} -- at step 0 the payload is the workgroup's
-    // half of ||Qs||_F^2 (fro_self), so the norm costs no hand-off of its own
-    unsigned long long* const fl64 = (unsigned long long*)fl;
-    // Which XCD are the workgroups of this matrix on?  Each announces its id now (write-through store) and reads the others'
-    // after its tile loads.  On ONE XCD its L2 is their point of coherence: tiles and step granules are then stored with
-    // workgroup scope -- they stay in that L2 instead of being written through to memory and fetched back from there
-    // (131 MB per sweep of the batch) -- and read as before behind the acquire.  Never assumed: asked at every launch.
-    const unsigned int xcd_me = (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
-    if (tid == 0) __hip_atomic_store(fl64 + 4 + part, ((unsigned long long)(epoch + 1u) << 8) | xcd_me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    auto body = [&](auto pivot_tag) {
-        constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
-        constexpr int NS = PIVOT ? rs4_na<K>() : rs4_nb<K>(), FIRST = PIVOT ? 0 : rs4_na<K>();      // (-DLQP_RS4_NA9=4: the 8 / 10 split of v2)
-        // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
-        f32x16 T[NS];
-        int ti[NS], tj[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int l = FIRST + s;
-            int a, b;
-            rs2_tile_of(l < nloc ? l : 0, K, part, NP, a, b);
-            ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
-            tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
-            if (ti[s] >= 0) {
-                const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
-                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
-                    // upper-right quadrant of a diagonal tile := transpose of its lower-left one (see wg_spd_sweep_resident)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
-                } else {
-                    const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
-                }
-            }
-        }
-        if (lr.dsc) {
-            // unscaled blocks (k_spd_prep): entry (r, c) is taken as (D_r * v) * D_c, what sym_scale4 computes
-            Dl[tid] = dmine;
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (ti[s] < 0) continue;
-                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {      // (as the lower-left entry it mirrors: row 32 + li, column quad_row)
-                    const float dr = Dl[ti[s] * 64 + 32 + li];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = (dr * T[s][q]) * Dl[tj[s] * 64 + quad_row(q, lh)];
-                } else {
-                    const float dc = Dl[tj[s] * 64 + 32 * qj + li];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = (Dl[ti[s] * 64 + 32 * qi + quad_row(q, lh)] * T[s][q]) * dc;
-                }
-            }
-        }
-        if (lr.dsc && lr.fro_self) {
-            // this wave's share of ||Qs||_F^2: tiles below the diagonal count twice, a diagonal tile's four quadrants once
-            // each (its upper-right one is held as the mirror of the lower-left one); the identity on the padding is left out
-            // (lane-dependent compares against an opaque value, formed where they are used: as invariants of the step loop
-            //  the sixteen diagonal masks would be held in scalar registers -- and spilled -- for the whole kernel)
-            float fs = 0.f;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (ti[s] < 0) continue;
-                float t2 = 0.f;
-                if (ti[s] == tj[s] && qi == qj) {
-                    int dqp = (ti[s] * 64 + 32 * qi + li >= lr.n) ? li - 4 * lh : -1;      // register q is a padding-diagonal entry
-                    asm volatile("" : "+v"(dqp));
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) t2 += (dqp == (q & 3) + 8 * (q >> 2)) ? 0.f : T[s][q] * T[s][q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) t2 += T[s][q] * T[s][q];
-                }
-                fs += ti[s] == tj[s] ? t2 : 2.f * t2;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) fs += __shfl_xor(fs, o);
-            if (lane == 0) WT[w] = fs;                     // (summed by thread 0 behind the first barrier of step 0)
-        }
-        if (lr.on) {
-            const float* xw = xb + (size_t)2 * K * LQP_BLK;
-            float rho = sqrtf(xw[0] + xw[1]) / (float)sqrt((double)lr.n);
-            rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
-            if (tid == 0 && lr.rho_out) *lr.rho_out = rho;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (quad_row(q, lh) == li && ti[s] * 64 + 32 * qi + li < lr.n) T[s][q] += rho;
-                }
-            }
-        }
-        // publish the pivot tile and the panel tiles of step kk this wave holds (as soon as ITS quadrants have step kk-1's
-        // update: the store drain then overlaps with the wait for the slowest wave)
-        bool xlocal_p = false;          // (set before the first publish)
-        auto publish = [&](const int kk) {
-            float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int i = ti[s], j = tj[s];
-                if (i >= 0 && (i == kk || j == kk)) {
-                    const int slot = (i == kk && j == kk) ? K - 1 : (j == kk ? i - 1 : j);      // P_i: i > kk -> i - 1, i < kk -> i
-                    unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
-                    if (xlocal_p) {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float tv = T[s][q];
-                            __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float tv = T[s][q];
-                            __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-            }
-        };
-        if (tid == 0) {
-            int same = lr.xcd_local;
-            for (int q = 0; q < NP && same; ++q) {
-                if (q == part) continue;
-                unsigned long long g = 0;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (((g = __hip_atomic_load(fl64 + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned long long)(epoch + 1u)) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) { g = ~0ull; break; }      // (1 s: the step flags below will flag it)
-                }
-                same = (unsigned int)(g & 0xFFull) == xcd_me;
-            }
-            flag[1] = same;
-        }
-        __syncthreads();
-        const bool xlocal = flag[1] != 0;
-        xlocal_p = xlocal;
-        publish(0);
-        // ---- step 0: as in wg_spd_sweep_resident_v2 -- flags, rho, pivot block by waves 0..3 beside the panel staging ----
-        auto set_flag = [&](const int kk, const float payload) {
-            const unsigned long long gran = (unsigned long long)(epoch + (unsigned int)kk + 1u) | ((unsigned long long)__float_as_uint(payload) << 32);
-            if (xlocal) __hip_atomic_store(fl64 + part, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(fl64 + part, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        auto wait_partner = [&](const int kk) -> unsigned long long {      // (one lane)
-            unsigned long long got;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while ((unsigned int)(got = __hip_atomic_load(fl64 + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch + (unsigned int)kk + 1u) {
-                __builtin_amdgcn_s_sleep(2);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
-                    __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-            return got;
-        };
-        // panel tiles of step kk: exchange buffer -> LDS (slot s holds P_i = A_i,kk, i.e. block (kk, i) transposed when i < kk);
-        // by the 256 threads of waves 4..7
-        auto stage_panel = [&](const int kk) {
-            int tid_s = tid;
-            asm volatile("" : "+v"(tid_s));
-            const float* const xbk = xb + (size_t)(kk & 1) * K * LQP_BLK;
-            const int tt = tid_s - 256, r0 = tt >> 3, c8 = (tt & 7) * 8;
-            const float* const src_l = xbk + r0 * 64 + c8;
-            float* const yrow_l = Y + r0 * SPD_LS + c8;            // row-major destination
-            float* const ycol_l = Y + c8 * SPD_LS + r0;            // transposed destination
-#pragma unroll 1
-            for (int s0 = 0; s0 < K - 1; ++s0) {           // (not unrolled: these waves hold twelve tiles)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const float* src = src_l + s0 * LQP_BLK + 32 * hf * 64;
-                    const V4<float> a = ld16_handoff(src), b = ld16_handoff(src + 4);
-                    if (s0 >= kk) {
-                        *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS) = a;
-                        *(V4<float>*)(yrow_l + (s0 * 64 + 32 * hf) * SPD_LS + 4) = b;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            ycol_l[(s0 * 64 + e) * SPD_LS + 32 * hf] = a.v[e];
-                            ycol_l[(s0 * 64 + 4 + e) * SPD_LS + 32 * hf] = b.v[e];
-                        }
-                    }
-                }
-            }
-        };
-        {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                float fmine = 0.f;
-                if (lr.dsc && lr.fro_self)      // this workgroup's half of the norm travels in the step-0 granule
-                    for (int ww = 0; ww < RS_NW; ++ww) fmine += WT[ww];
-                set_flag(0, fmine);
-                const unsigned long long got = wait_partner(0);
-                if (lr.dsc && lr.fro_self) {
-                    // rho = clamp(||Qs||_F / sqrt(n)) (reference :200-203), the same bits in both workgroups (part order)
-                    const float fother = __uint_as_float((unsigned int)(got >> 32));
-                    const float fsum = part == 0 ? fmine + fother : fother + fmine;
-                    float rho = sqrtf(fsum) / (float)sqrt((double)lr.n);
-                    rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
-                    WT[RS_NW] = rho;
-                    if (lr.rho_out) *lr.rho_out = rho;
-                }
-            }
-            __syncthreads();
-            float diag_add = 0.f;
-            if (lr.dsc) {
-                diag_add = lr.fro_self ? WT[RS_NW] : lr.rho_given;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
-                        int dq = (ti[s] * 64 + 32 * qi + li < lr.n) ? li - 4 * lh : -1;      // (opaque: see the norm above)
-                        asm volatile("" : "+v"(dq));
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) T[s][q] += (dq == (q & 3) + 8 * (q >> 2)) ? diag_add : 0.f;
-                    }
-                }
-            }
-            wg_pivot_block_mfma<false, PIVOT>(xb + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, 0, nullptr, 0, diag_add, true);
-            if constexpr (!PIVOT) stage_panel(0);
-            __syncthreads();
-        }
-        int gchain = 0, gstage = 0;                          // running targets of the two group syncs
-        unsigned long long dbt4[6] = {0, 0, 0, 0, 0, 0}, dt4 = LQP_RS4_STAMPS ? clock64() : 0ull;
-        for (int k = 0; k < K; ++k) {
-            // (lane parts of every LDS address of this step, opaque: as loop invariants of the step loop they would be
-            //  formed once, held in registers -- one per distinct address -- and spilled with the tiles)
-            int li_s = li, lh_s = lh;
-            asm volatile("" : "+v"(li_s), "+v"(lh_s));
-            // ---- Y_i = P_i W_k^T in place: a wave takes whole 32-row blocks (both column halves) ----
-            constexpr int WOFF = (K - 1) * 64 * SPD_LS, WTOFF = WOFF + 64 * SPD_LS;      // W, W^T behind the panel
-            const float* const yF = Y + li_s * SPD_LS + 32 * lh_s;     // operand row li at the lane's k range (full)
-            const float* const yH = Y + li_s * SPD_LS + 16 * lh_s;     // ... (half k range; + 32: the upper half)
-            float* const yC = Y + (4 * lh_s) * SPD_LS + li_s;          // element (quad_row(q, lh), li) at + ((q&3) + 8 (q>>2)) * SPD_LS
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
-                if (rb < 2 * (K - 1)) {
-                    const int xoff = ((rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
-                    // (one accumulator at a time: the tile waves hold up to twelve tiles; the two products read the same
-                    //  panel rows, which nobody overwrites before the barrier below: the first may be stored at once)
-                    {
-                        const f32x16 a0 = spd_quadrant_lp<1>(yH + xoff, yH + WOFF);
-                        const f32x16 a1 = spd_quadrant_lp<0>(yF + xoff, yF + WOFF + 32 * SPD_LS);
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS] = a0[q];
-                            yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS + 32] = a1[q];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            RS4_STAMP(0);                                      // Y phase + barrier
-            const bool more = k + 1 < K;
-            if constexpr (PIVOT) { if (more) __builtin_amdgcn_s_setprio(2); }      // the chain waves should reach the chain first
-            const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
-            auto update_slot = [&](const int s) {
-                const int i = ti[s], j = tj[s];
-                if (i != k && j != k) {
-                    const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
-                    T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
-                } else if (i == k && j == k) {    // (W^T is upper triangular: rows >= 32 only see k >= 32 -- same halves,
-                                                  //  hence the same summation order and bits, as the multi-launch sweep)
-                    const f32x16 a = (qi | qj) ? spd_quadrant_lp<1>(yH + 32 + WTOFF + oi, yH + 32 + WTOFF + oj)
-                                               : spd_quadrant_lp<0>(yF + WTOFF, yF + WTOFF);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
-                } else if (j == k) {              // tile (i, k), i > k: Y_i W
-                    const int yo = (i - 1) * 64 * SPD_LS + oi;
-                    T[s] = qj == 1 ? spd_quadrant_lp<1>(yH + 32 + yo, yH + 32 + WTOFF + 32 * SPD_LS) : spd_quadrant_lp<0>(yF + yo, yF + WTOFF);
-                } else {                          // tile (k, j), j < k: W^T Y_j^T
-                    const int yo = j * 64 * SPD_LS + oj;
-                    T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
-                }
-            };
-            // ---- first: the tiles of rows / columns k (they read W_k, W_k^T) and k+1 (the next pivot tile and panel) ----
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int i = ti[s], j = tj[s];
-                if (i < 0) continue;
-                if (i == k || j == k || i == k + 1 || j == k + 1) update_slot(s);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // done with W_k, W_k^T
-            if (more) {
-                publish(k + 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) {
-                    // the wave that sees the last arrival raises this workgroup's flag of step k+1
-                    const int old = __hip_atomic_fetch_add(sy + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (old + 1 == RS_NW * (k + 1)) set_flag(k + 1, 0.f);
-                }
-            }
-            RS4_STAMP(1);                                      // tiles of rows / columns k, k+1 + publish
-            // ---- then every other tile (the panel Y_k only) ----
-            auto rest = [&]() {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int i = ti[s], j = tj[s];
-                    if (i < 0) continue;
-                    if (!(i == k || j == k || i == k + 1 || j == k + 1)) update_slot(s);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(sy + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // done with the panel Y_k
-            };
-            constexpr bool CHAIN_FIRST = LQP_RS4_CHAIN_FIRST != 0;     // the chain waves: pivot block k+1 BEFORE their other tiles
-            if constexpr (!PIVOT && LQP_RS4_YIELD) {
-                // the staging waves leave the matrix pipes to the chain waves' remaining tiles (dependent matrix instructions of
-                // two waves of a SIMD alternate whatever their priorities): the chain then starts sooner and THESE tiles are
-                // updated beside it
-                if (more) lds_wait_ge_bounded(sy + 8, 4 * (k + 1), status_timeout);
-            }
-            if (!(PIVOT && CHAIN_FIRST && more)) rest();
-            RS4_STAMP(2);                                      // the other tiles
-            if constexpr (PIVOT) {
-                if (lane == 0) __hip_atomic_fetch_add(sy + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (more) {
-                if constexpr (PIVOT) {
-                    __builtin_amdgcn_s_setprio(0);
-                    // ---- pivot block k+1 beside the other waves' updates: W / W^T are free once all eight waves have passed
-                    //      the first group of tiles; the pivot tile comes out of the exchange buffer ----
-                    if (tid == 0) {
-                        wait_partner(k + 1);
-                        __hip_atomic_store(sy + 5, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    lds_wait_ge_bounded(sy + 5, k + 1, status_timeout);                   // the partner's tiles of step k+1 ...
-                    lds_wait_ge_bounded(sy + 3, RS_NW * (k + 1), status_timeout);         // ... and this workgroup's own have left
-                    lds_wait_ge_bounded(sy + 1, RS_NW * (k + 1), status_timeout);         // W_k, W_k^T are dead
-                    RS4_STAMP(3);                              // waits
-                    {
-                        int tid_s = tid;
-                        asm volatile("" : "+v"(tid_s));
-                        const float* src = xb + (size_t)((k + 1) & 1) * K * LQP_BLK + (size_t)(K - 1) * LQP_BLK;
-#pragma unroll
-                        for (int v0 = 0; v0 < 4; ++v0) {
-                            const int i4 = (tid_s + 256 * v0) * 4;
-                            const V4<float> v = ld16_handoff(src + i4);
-                            *(V4<float>*)(W + (i4 >> 6) * SPD_LS + (i4 & 63)) = v;
-                        }
-                    }
-                    lds_group_sync<true>(sy + 0, gchain += 4);
-                    wg_pivot_block_mfma<true, true, true>(nullptr, W, WT, pcol, flag, (k + 1) * 64, sy + 6, k);
-                    lds_group_sync<true>(sy + 0, gchain += 4);
-                    if (CHAIN_FIRST) rest();
-                } else {
-                    // ---- panel of step k+1 into the Y area once nobody reads Y_k any more ----
-                    lds_wait_ge_bounded(sy + 5, k + 1, status_timeout);
-                    lds_wait_ge_bounded(sy + 3, RS_NW * (k + 1), status_timeout);
-                    lds_wait_ge_bounded(sy + 2, RS_NW * (k + 1), status_timeout);         // nobody reads the panel Y_k any more
-                    RS4_STAMP(3);                              // waits
-                    stage_panel(k + 1);
-                    (void)gstage;
-                }
-            }
-            RS4_STAMP(4);                                      // pivot block k+1 / staging of panel k+1
-            __syncthreads();
-            RS4_STAMP(5);                                      // closing barrier
-        }
-        if (LQP_RS4_STAMPS && dbg && tid == 64 * (4 * (LQP_RS4_STAMPS - 1)))
-            for (int q = 0; q < 6; ++q) dbg[q] = dbt4[q];
-        // ---- the finished tiles to their home blocks ----
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (ti[s] >= 0) {
-                float* C = Hdst + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
-            }
-        }
-    };
-    if (w < 4) body(std::true_type());
-    else body(std::false_type());
-    __syncthreads();
-    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
-}
+// (LDS of the resident sweep: the block sweep's + 64 bytes of flags / counters; with the pass over Q inside the sweep also the
+//  scaling vector)
+__host__ __device__ inline int rs_q_lds_bytes(int K) { return spd_lds_bytes(K) + 64 + 64 * K * 4; }
 
 
-// ---- resident sweep, third form: the pivot block of step k+1 runs BESIDE the tile updates of step k ------------------
-// In wg_spd_sweep_resident_v2 the matrix pipes idle while the pivot block is eliminated (24 k of 87 k cycles per step)
-// and both workgroups eliminate every pivot block.  Here
-//   * pivot block k is eliminated by ONE workgroup, the one that holds tile (k, k) (its four quadrants sit in waves 0..3:
-//     the diagonal tiles come first in a workgroup's tile list), and W, W^T travel to the partner through the exchange
-//     buffer (32 KB, write-through stores + flag) -- the pivot tile itself no longer travels;
-//   * inside step k the tiles that need W_k (row / column k) and the tiles of the NEXT panel (row / column k+1, tile
-//     (k+1, k+1) among them) are updated first; the next panel is published at once; then waves 0..3 of the owner of
-//     pivot block k+1 eliminate it while everybody else -- waves 4..7 there, all eight waves of the partner -- goes on
-//     with the remaining rank-64 updates: the elimination's latency chain runs beside matrix instructions instead of in
-//     front of them.  The pivot waves take their own remaining tiles afterwards.
-// Same tile arithmetic as v2 (bit-identical results); only the order of independent updates and who computes W differ.
-// MEASURED (B = 128, n = 500): 0.47 ms against 0.36 ms for v2 -- kept for the record, not built in by default
-// (LQP_RS_V2 = 3).  Per step (cycles of wave 0): waiting for the partner 21 k (v2: 7.6 k), staging 12 k (v2: hidden behind
-// the pivot block), Y 18 k, W_k tiles 12.6 k, pivot block + the rest 44 k.  The pivot block cannot start before every
-// tile that reads W_k / W_k^T is done (it eliminates IN the W / W^T areas: there is no LDS for a second pair), so the
-// chain W_k -> Y -> W_k tiles -> pivot block k+1 -> 32 KB to the partner -> its staging is still serial, and what the
-// overlap hides (the partner's updates beside the owner's elimination) is less than what the hand-over adds.  What would
-// pay: the pivot block in ONE scratch area (ring queues instead of 16-panel queues) and the W_k tiles reading W
-// transposed, so that W^T's area is free and block k+1 starts right behind tile (k+1, k+1).
-template <int K> __host__ __device__ constexpr int rs3_na() { return rs2_na<K>(); }
-template <int K> __host__ __device__ constexpr int rs3_nb() { return rs2_nb<K>(); }
-// (i, j) of local tile l of workgroup `part`: its diagonal tiles first (columns ascending), then the others
-__device__ __forceinline__ void rs3_tile_of(int l, const int K, const int part, int& ti, int& tj) {
-    ti = 0; tj = 0;
-    for (int j = 0; j < K; ++j) {
-        if (split_owner(j, K) != part) continue;
-        if (l == 0) { ti = j; tj = j; return; }
-        --l;
-    }
-    for (int j = 0; j < K; ++j) {
-        if (split_owner(j, K) != part) continue;
-        if (l < K - 1 - j) { ti = j + 1 + l; tj = j; return; }
-        l -= K - 1 - j;
-    }
-}
-constexpr int RS3_XW = 1024;        // floats between the panel slots (+ the late-rho words) and the W slots of the exchange buffer
-// (wg_spd_sweep_resident_v2 / _v4: two parities of K tiles + the words behind them)
 __host__ __device__ constexpr size_t rs2_xb_floats(int K) { return (size_t)2 * K * LQP_BLK + 64; }
-__host__ __device__ constexpr size_t rs3_xb_floats(int K) { return (size_t)2 * K * LQP_BLK + RS3_XW + (size_t)2 * 2 * LQP_BLK; }
-
-// xb: [2][K][4096] panel slots by step parity | 2 words of ||Qs||_F^2 (rho_late) | ... | [2][2][4096] W, W^T by pivot parity
-// fl: four words of this matrix: [part] panel flag, [2 + part] W flag of the workgroups
-template <int K>
-__device__ __forceinline__ void wg_spd_sweep_resident_v3(const float* Hsrc, float* Hdst,
-                                                         float* __restrict__ xb, unsigned int* __restrict__ fl,
-                                                         const unsigned int epoch, const int part, int* __restrict__ info,
-                                                         int* __restrict__ status_timeout, char* smem,
-                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
-                                                         unsigned long long* __restrict__ dbg = nullptr) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qi = (w >> 1) & 1, qj = w & 1;                  // quadrant of the tile this wave holds in every slot
-    const int nloc = split_count(K, part);
-    float* Y = (float*)smem;
-    float* W = Y + (size_t)(K - 1) * 64 * SPD_LS;
-    float* WT = W + 64 * SPD_LS;
-    float* pcol = WT + 64 * SPD_LS;
-    int* flag = (int*)(pcol + PIV_LDS);
-    int* gw = (int*)(pcol + 66);                              // [0..1] the pivot block's words, [2] sync of waves 0..3
-    float* xw = xb + (size_t)2 * K * LQP_BLK + RS3_XW;        // W, W^T slots
-    if (tid == 0) { flag[0] = 0; gw[0] = 0; gw[1] = 0; gw[2] = 0; }
-    __syncthreads();
-
-    auto body = [&](auto pivot_tag) {
-        constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
-        constexpr int NS = PIVOT ? rs3_na<K>() : rs3_nb<K>(), FIRST = PIVOT ? 0 : rs3_na<K>();
-        f32x16 T[NS];
-        int ti[NS], tj[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int l = FIRST + s;
-            int a, b;
-            rs3_tile_of(l < nloc ? l : 0, K, part, a, b);
-            ti[s] = __builtin_amdgcn_readfirstlane(l < nloc ? a : -1);
-            tj[s] = __builtin_amdgcn_readfirstlane(l < nloc ? b : -1);
-            if (ti[s] >= 0) {
-                const float* blk = Hsrc + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK;
-                if (ti[s] == tj[s] && ti[s] > 0 && qi == 0 && qj == 1) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = blk[(32 + li) * 64 + quad_row(q, lh)];
-                } else {
-                    const float* C = blk + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) T[s][q] = C[quad_row(q, lh) * 64];
-                }
-            }
-        }
-        if (lr.on) {
-            const float* xr = xb + (size_t)2 * K * LQP_BLK;
-            float rho = sqrtf(xr[0] + xr[1]) / (float)sqrt((double)lr.n);
-            rho = tmin(tmax(rho, lr.rho_min), lr.rho_max);
-            if (tid == 0 && lr.rho_out) *lr.rho_out = rho;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (ti[s] >= 0 && ti[s] == tj[s] && qi == qj) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (quad_row(q, lh) == li && ti[s] * 64 + 32 * qi + li < lr.n) T[s][q] += rho;
-                }
-            }
-        }
-        unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
-        int gsync = 0, pcall = 0;                              // running targets of the 4-wave sync / calls of the pivot block
-        // the panel tiles of step kk this wave holds -> exchange buffer (not the pivot tile)
-        auto publish = [&](const int kk) {
-            float* xbp = xb + (size_t)(kk & 1) * K * LQP_BLK;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int i = ti[s], j = tj[s];
-                if (i >= 0 && (i == kk || j == kk) && i != j) {
-                    const int slot = j == kk ? i - 1 : j;      // P_i: i > kk -> i - 1, i < kk -> i
-                    unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float tv = T[s][q];
-                        __hip_atomic_store(dst + quad_row(q, lh) * 64, __builtin_bit_cast(unsigned int, tv),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-        };
-        // pivot block kk by this workgroup's waves 0..3 (it holds tile (kk, kk): slot of that tile = its rank among the
-        // workgroup's diagonal tiles); W, W^T stay in LDS and go to the partner
-        auto eliminate = [&](const int kk) {
-            if constexpr (PIVOT) {
-                int sd = 0;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) if (ti[s] == kk && tj[s] == kk) sd = s;
-                // this wave's quadrant of the tile into the W area (row stride SPD_LS)
-                {
-                    int li_s = li, lh_s = lh;
-                    asm volatile("" : "+v"(li_s), "+v"(lh_s));
-                    float* dst = W + (32 * qi + 4 * lh_s) * SPD_LS + 32 * qj + li_s;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        if (s == sd) {
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * SPD_LS] = T[s][q];
-                        }
-                    }
-                }
-                lds_group_sync<true>(gw + 2, gsync += 4);
-                wg_pivot_block_mfma<true, true, true>(nullptr, W, WT, pcol, flag, kk * 64, gw, pcall);
-                ++pcall;
-                lds_group_sync<true>(gw + 2, gsync += 4);          // W, W^T complete
-                // -> the partner: 2 x 4096 floats by 256 threads, write-through
-                {
-                    unsigned int* dstg = (unsigned int*)(xw + (size_t)(kk & 1) * 2 * LQP_BLK);
-                    for (int v = tid; v < 2 * 1024; v += 256) {
-                        const int m = v >> 10, e = v & 1023, rr = e >> 4, cc = (e & 15) * 4;
-                        const V4<float> val = *(const V4<float>*)((m ? WT : W) + rr * SPD_LS + cc);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            __hip_atomic_store(dstg + m * LQP_BLK + e * 4 + q, __builtin_bit_cast(unsigned int, val.v[q]),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    lds_group_sync<true>(gw + 2, gsync += 4);
-                    if (tid == 0) __hip_atomic_store(fl + 2 + part, epoch + (unsigned int)kk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        };
-        // one lane waits for a flag of the partner, then ONE agent-scope acquire for the workgroup (bounded spin)
-        auto wait_flag = [&](unsigned int* word, const unsigned int target) {
-            if (tid == 0) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ULL) {      // 1 s: give up, results are flagged
-                        __hip_atomic_store(status_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        };
-        auto update_slot = [&](const int s, const int k, const float* yF, const float* yH) {
-            constexpr int WOFF = (K - 1) * 64 * SPD_LS, WTOFF = WOFF + 64 * SPD_LS;
-            const int oi = 32 * qi * SPD_LS, oj = 32 * qj * SPD_LS;
-            const int i = ti[s], j = tj[s];
-            if (i != k && j != k) {
-                const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
-                T[s] -= spd_quadrant_lp<0>(yF + si * 64 * SPD_LS + oi, yF + sj * 64 * SPD_LS + oj);
-            } else if (i == k && j == k) {
-                const f32x16 a = (qi | qj) ? spd_quadrant_lp<1>(yH + 32 + WTOFF + oi, yH + 32 + WTOFF + oj)
-                                           : spd_quadrant_lp<0>(yF + WTOFF, yF + WTOFF);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) T[s][q] = -a[q];
-            } else if (j == k) {              // tile (i, k), i > k: Y_i W
-                const int yo = (i - 1) * 64 * SPD_LS + oi;
-                T[s] = qj == 1 ? spd_quadrant_lp<1>(yH + 32 + yo, yH + 32 + WTOFF + 32 * SPD_LS) : spd_quadrant_lp<0>(yF + yo, yF + WTOFF);
-            } else {                          // tile (k, j), j < k: W^T Y_j^T
-                const int yo = j * 64 * SPD_LS + oj;
-                T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
-            }
-        };
-
-        // ---- prologue: panel of step 0 out, pivot block 0 by its owner ----
-        publish(0);
-        if (split_owner(0, K) == part) eliminate(0);
-        for (int k = 0; k < K; ++k) {
-            if (dbg) dt0 = clock64();
-            const bool own_k = split_owner(k, K) == part;
-            const bool own_next = k + 1 < K && split_owner(k + 1, K) == part;
-            float* xbk = xb + (size_t)(k & 1) * K * LQP_BLK;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                       // (closes step k-1: every wave is done with the LDS panel; this wave's
-                                                   //  panel tiles of step k have left)
-            if (tid == 0) __hip_atomic_store(fl + part, epoch + (unsigned int)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            wait_flag(fl + (1 - part), epoch + (unsigned int)k + 1u);
-            if (!own_k) wait_flag(fl + 2 + (1 - part), epoch + (unsigned int)k + 1u);
-            __syncthreads();
-            if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
-            int li_s = li, lh_s = lh, tid_s = tid;
-            asm volatile("" : "+v"(li_s), "+v"(lh_s), "+v"(tid_s));
-            // ---- panel tiles -> LDS (slot s holds P_i = A_ik, i.e. block (k, i) transposed when i < k); W, W^T of the
-            //      partner's pivot block -> LDS ----
-            {
-                const int r0 = tid_s >> 3, c8 = (tid_s & 7) * 8;
-                const float* const src_l = xbk + r0 * 64 + c8;
-                float* const yrow_l = Y + r0 * SPD_LS + c8;            // row-major destination
-                float* const ycol_l = Y + c8 * SPD_LS + r0;            // transposed destination
-#pragma unroll
-                for (int s0 = 0; s0 < K - 1; ++s0) {
-                    const float* src = src_l + s0 * LQP_BLK;
-                    const V4<float> a = *(const V4<float>*)src, b = *(const V4<float>*)(src + 4);
-                    if (s0 >= k) {
-                        *(V4<float>*)(yrow_l + (s0 * 64) * SPD_LS) = a;
-                        *(V4<float>*)(yrow_l + (s0 * 64) * SPD_LS + 4) = b;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            ycol_l[(s0 * 64 + e) * SPD_LS] = a.v[e];
-                            ycol_l[(s0 * 64 + 4 + e) * SPD_LS] = b.v[e];
-                        }
-                    }
-                }
-                if (!own_k) {
-                    const float* wsrc = xw + (size_t)(k & 1) * 2 * LQP_BLK + r0 * 64 + c8;
-                    constexpr int WOFF = (K - 1) * 64 * SPD_LS;
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const V4<float> a = *(const V4<float>*)(wsrc + m * LQP_BLK), b = *(const V4<float>*)(wsrc + m * LQP_BLK + 4);
-                        *(V4<float>*)(yrow_l + WOFF + m * 64 * SPD_LS) = a;
-                        *(V4<float>*)(yrow_l + WOFF + m * 64 * SPD_LS + 4) = b;
-                    }
-                }
-            }
-            __syncthreads();
-            if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
-            // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves) ----
-            constexpr int WOFF = (K - 1) * 64 * SPD_LS;
-            const float* const yF = Y + li_s * SPD_LS + 32 * lh_s;     // operand row li at the lane's k range (full)
-            const float* const yH = Y + li_s * SPD_LS + 16 * lh_s;     // ... (half k range; + 32: the upper half)
-            float* const yC = Y + (4 * lh_s) * SPD_LS + li_s;          // element (quad_row(q, lh), li) at + ((q&3) + 8 (q>>2)) * SPD_LS
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int rb = __builtin_amdgcn_readfirstlane(w + RS_NW * u);
-                if (rb < 2 * (K - 1)) {
-                    const int xoff = ((rb >> 1) * 64 + 32 * (rb & 1)) * SPD_LS;
-                    const f32x16 a0 = spd_quadrant_lp<1>(yH + xoff, yH + WOFF);
-                    const f32x16 a1 = spd_quadrant_lp<0>(yF + xoff, yF + WOFF + 32 * SPD_LS);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS] = a0[q];
-                        yC[xoff + ((q & 3) + 8 * (q >> 2)) * SPD_LS + 32] = a1[q];
-                    }
-                }
-            }
-            __syncthreads();
-            if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
-            // ---- first: the tiles that need W_k (row / column k); tile (k+1, k+1) with them ----
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int i = ti[s], j = tj[s];
-                if (i < 0) continue;
-                if (i == k || j == k || (i == k + 1 && j == k + 1)) update_slot(s, k, yF, yH);
-            }
-            __syncthreads();                       // W, W^T of step k are free
-            if (dbg) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
-            // ---- pivot block k+1 (its owner's waves 0..3) beside the remaining rank-64 updates: the next panel first (it
-            //      leaves for the partner at once), then the rest ----
-            if (own_next) eliminate(k + 1);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int i = ti[s], j = tj[s];
-                if (i < 0) continue;
-                if (!(i == k || j == k) && (i == k + 1 || j == k + 1) && i != j) update_slot(s, k, yF, yH);
-            }
-            if (k + 1 < K) publish(k + 1);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int i = ti[s], j = tj[s];
-                if (i < 0) continue;
-                if (!(i == k || j == k || i == k + 1 || j == k + 1)) update_slot(s, k, yF, yH);
-            }
-            if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
-        }
-        if (dbg && tid == 0)
-            for (int q = 0; q < 6; ++q) dbg[q] = dbt[q];
-        // ---- the finished tiles to their home blocks ----
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (ti[s] >= 0) {
-                float* C = Hdst + (size_t)sym_idx(ti[s], tj[s], K) * LQP_BLK + (32 * qi) * 64 + 32 * qj + li;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = T[s][q];
-            }
-        }
-    };
-    if (w < 4) body(std::true_type());
-    else body(std::false_type());
-    __syncthreads();
-    if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];
-}
 
 // ---------------------------------------------------------------------------
 // Blocked Cholesky of an SPD matrix held as packed lower blocks, in place (the symmetric backward system):

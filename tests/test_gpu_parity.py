@@ -91,6 +91,45 @@ def test_lu_factor_matches_lapack(dev, N, B, dtype):
     assert rel(lu_layer.lu_solve(LU, P, rhs.to(dev)), xr) < stol                         # HIP factor, HIP solve
 
 
+@pytest.mark.parametrize("N,B,dtype", [(97, 8, torch.float32), (130, 5, torch.float32), (317, 8, torch.float32), (501, 16, torch.float32),
+                                       (512, 3, torch.float32), (100, 8, torch.float64), (266, 16, torch.float64), (501, 4, torch.float64)])
+def test_two_workgroup_lu(dev, monkeypatch, N, B, dtype):
+    """csrc/lqp_lu2.hpp (N <= 512, 2 B workgroups resident): column blocks dealt out to two workgroups, panels handed over
+    inside the launch.  Same pivots as the one-workgroup kernel and, in float32, the SAME BITS (every element sees the same
+    operations in the same order); float64 pivots are LAPACK's; a zero column is reported at the same index; on and off one XCD."""
+    torch.manual_seed(N + B)
+    G = torch.randn(B, N, N, dtype=torch.float64)
+    A = (G.transpose(1, 2) @ G / N + 0.3 * torch.eye(N, dtype=torch.float64))
+    A[:, N - 5:, N - 5:] = 0                       # a KKT-like zero block: pivoting is needed
+    A[:, N - 5:, :N - 5] = G[:, :5, :N - 5]; A[:, :N - 5, N - 5:] = G[:, :5, :N - 5].transpose(1, 2)
+    A = A.to(dtype)
+    monkeypatch.setenv("LQP_LU2", "0")
+    LU1, P1 = lu_layer.lu_factor(A.to(dev))
+    monkeypatch.setenv("LQP_LU2", "1")
+    prof = _lib.profile(enable=True, reset=True)
+    LU2, P2 = lu_layer.lu_factor(A.to(dev))
+    _lib.profile(enable=False)
+    # float32: the same bits (matrix-core trailing update and substitution in the same order in both kernels); float64: the
+    # one-workgroup kernel's trailing update runs on the vector unit and its U12 by substitution, this one's on
+    # v_mfma_f64_16x16x4 with the inverse of L11 -- the same factorisation to rounding
+    same = (lambda X, Y: torch.equal(X, Y)) if dtype == torch.float32 else (lambda X, Y: rel(X, Y) < 1e-12)
+    assert torch.equal(P1, P2) and same(LU1, LU2)
+    monkeypatch.setenv("LQP_XCD_LOCAL", "0")       # write-through publication (workgroups on different XCDs take this path)
+    LU3, P3 = lu_layer.lu_factor(A.to(dev))
+    assert torch.equal(P2, P3) and torch.equal(LU2, LU3)
+    LUr, Pr = torch.linalg.lu_factor(A)
+    if dtype == torch.float64:
+        assert torch.equal(P2.cpu(), Pr) and rel(LU2, LUr) < 1e-9
+    Pm, Lm, Um = torch.lu_unpack(LU2.cpu().double(), P2.cpu())
+    recon = float((Pm @ Lm @ Um - A.double()).abs().max()) / float(A.abs().max())
+    assert recon < (1e-4 if dtype == torch.float32 else 1e-12), recon
+    Z = A.clone(); Z[:, :, N // 2] = 0
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LQP_LU2", flag)
+        with pytest.raises(RuntimeError, match=rf"U\[{N // 2 + 1},{N // 2 + 1}\] is zero"):
+            lu_layer.lu_factor(Z.to(dev))
+
+
 @pytest.mark.parametrize("N,B,dtype", [(1025, 2, torch.float64), (1100, 2, torch.float32), (1501, 2, torch.float64),
                                        (2048, 1, torch.float32), (2048, 1, torch.float64)])
 def test_lu_factor_above_1024(dev, N, B, dtype):
@@ -1161,18 +1200,21 @@ def test_symmetric_path_above_512(dev, monkeypatch, n, B, m, split):
         assert sol["_stats"]["factor_launches"] == (2 * ((n + 63) // 64) + 2 if split == "1" else 1)
         lu, _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve="lu", **kw))
         ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**kw))
-        scale = max(1.0, float(ref["x"].abs().max()))
+        dbl = [None if t is None else t.double() for t in (Q, p, A, b, lb, ub)]
+        t64 = O.solve_box_qp(*dbl, O.make_control(**kw))          # the same solve in float64 (same control, same stop rule)
+        case = f"symmetric_above_512_n{n}_split{split}" + ("_adaptive" if "rho" in kw else "")
         if "rho" in kw:
-            assert sol["_stats"]["n_factor"] >= 2 and abs(sol["iter"] - ref["iter"]) <= ref["iter"] // 4 + 20
-            assert err(sol["x"], ref["x"]) < 5e-4 * scale
+            # rho after a refactorisation is the ratio of two 1e-6-level residuals: float32 implementations legitimately take
+            # different numbers of checks -- no further from the reference's count than the float64 solve is (+ one check)
+            chk = max(round((n ** 0.5) / 10) * 10, 1)
+            assert sol["_stats"]["n_factor"] >= 2
+            assert abs(sol["iter"] - ref["iter"]) <= abs(t64["iter"] - ref["iter"]) + chk, (sol["iter"], ref["iter"], t64["iter"])
+            close_or_fp64(case, "x", sol["x"], ref["x"], t64["x"], X_TOL)
         else:
-            # (41 iterations from a cold start at n = 1000: fp32 rounding of either factorisation shows in the scaled
-            #  dual u at the 5e-5 level -- the LU path is as far from the fp32 oracle as this one)
+            # 41 iterations from a cold start: north-star tolerance, or no further from float64 than the reference's own float32
             for k in ("x", "u", "lams") + (("nus",) if m else ()):
-                tol = (2 if k == "x" else 8) * X_TOL * scale
-                P.record(f"symmetric_above_512_n{n}_split{split}", k, err(sol[k], ref[k]), lu_path=err(lu[k], ref[k]))
-                assert err(sol[k], ref[k]) < tol, k
-                assert err(sol[k], lu[k]) < tol, k
+                close_or_fp64(case, k, sol[k], ref[k], t64[k], X_TOL, lu_path=err(lu[k], ref[k]))
+                close_or_fp64(case + "_lu", k, lu[k], ref[k], t64[k], X_TOL)
 
 
 # ---------------------------------------------------------------- config 5: the per-GPU shard of B=8192 over 8 GPUs

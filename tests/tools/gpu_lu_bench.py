@@ -17,7 +17,7 @@ N = M.shape[1]
 dbg = torch.zeros(B * 4, dtype=torch.int64, device=dev)
 for (nt, pb, mfma, la) in ((512, 32, 1, 0), (512, 16, 1, 0), (1024, 16, 1, 0)):
     if True:
-        os.environ["LQP_LU_LA"] = str(la)
+        os.environ["LQP_LU2"] = "0"            # (the one-workgroup kernel; csrc/lqp_lu2.hpp has its own tool: gpu_lu2_check.py)
         os.environ["LQP_LU_NT"] = str(nt)
         os.environ["LQP_LU_PB"] = str(pb)
         os.environ["LQP_LU_MFMA"] = str(mfma)

@@ -32,7 +32,7 @@ GROUPS = [
     ("loop_tail", lambda n: re.search(r"k_admm_loop<\w+, \w+, true,", n)),
     ("loop_hot", lambda n: "k_admm_loop<" in n),
     ("lu2", lambda n: "k_lu_factor2<" in n),
-    ("lu_a", lambda n: re.search(r"k_lu_factor<float, (32|16), true|k_lu_factor_la|k_lu_factor_big", n)),
+    ("lu_a", lambda n: re.search(r"k_lu_factor<float, (32|16), true|k_lu_factor_big", n)),
     ("lu_b", lambda n: "k_lu_factor<" in n),
     ("spd", lambda n: re.search(r"k_spd_|k_bwd_chol_solve|k_bwd_build_chol", n)),
     ("unroll", lambda n: "k_unroll_" in n or "k_admm_loop_small" in n),
@@ -63,6 +63,9 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_lu_factor<float, 32, true, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, unsigned long long*, int const*)",
+    "void lqp::k_lu_factor_la<16, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*)",
+    "void lqp::k_lu_factor_la<32, 768>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*)",
     "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
     "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int)",
     "void lqp::k_unroll_sweep<0>(lqp::FwdParams<float>, lqp::UnrollParams)",
