@@ -688,7 +688,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     int tail_lds = 0;
     // (above 1024 rows the LU kernel is the two-rows-per-thread one, launched on its own: refactorisations go through the
     //  separate gated kernels, and the continuation kernel's LDS does not have to hold an LU panel)
-    bool inkernel_refactor = sizeof(T) == 4 && P.N <= 1024;
+    // (float64 too since round 5: the pipelined schedule enqueues every possible event up front -- nine at the defaults -- and with
+    //  separate gated kernels each one cost four launches that do nothing when the solve is over: rho update, LU, pack, tail)
+    bool inkernel_refactor = P.N <= 1024;
     if constexpr (sizeof(T) == 4) {
         if (resident) { loop_fn = k_admm_loop<T, true, false, 1024>; tail_fn = k_admm_loop<T, true, true, 1024>; }
         if (hot512) loop_fn = k_admm_loop<T, true, false, 512>;

@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
         }
     }
     if (it0 >= it1) return;
-    if constexpr (TAIL && sizeof(T) == 4 && NT == 1024 && !SYM) {   // f64 / symmetric path keep the separate gated kernels
+    if constexpr (TAIL && NT == 1024 && !SYM) {   // (the symmetric path's tail walks through its events further down)
         if ((persistent & 2) && prev_slot >= 0) {
             unsigned int* ctl = P.counters + (size_t)prev_slot * CT_WORDS;
             if (__hip_atomic_load(ctl + CT_WANTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&

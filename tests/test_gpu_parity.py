@@ -243,6 +243,26 @@ def test_g8_fp64(dev):
         assert rel(t, g[f"{nm}_rand"]) < 1e-7, nm
 
 
+@pytest.mark.parametrize("sync", [True, False])
+@pytest.mark.parametrize("tag", ["noscale", "scale"])
+def test_adaptive_rho_refactorises_in_float64(dev, tag, sync):
+    """The G6 inputs in float64 (pivoted-LU path): rho = 100 forces a refactorisation at iteration 100.  Since round 5 the
+    continuation kernel refactorises in-kernel for float64 as well (no separate rho-update / LU / pack launches per possible
+    event).  Against the float64 oracle: same iteration count, one refactorisation, iterates to 1e-9."""
+    g = load_golden(f"g6_adaptive_{tag}")
+    d = [g[k].double() for k in ("Q", "p", "A", "b", "lb", "ub")]
+    kw = dict(rho=100.0, scale=(tag == "scale"), **TOL)
+    ref = O.solve_box_qp(*d, O.make_control(**kw))
+    sol = L.torch_solve_box_qp(*[t.to(dev) for t in d], dict(O.make_control(**kw), sync=sync))
+    L.synchronize()
+    assert sol["x"].dtype == torch.float64
+    if sync:
+        assert sol["iter"] == ref["iter"] and sol["_stats"]["n_factor"] == 2 and sol["_stats"]["linsolve_used"] == 1
+    for k in ("x", "z", "u", "lams", "nus"):
+        assert err(sol[k], ref[k]) < 1e-9 * max(1.0, float(ref[k].abs().max())), k
+    assert err(sol["rho"], ref["rho"]) < 1e-9 * float(ref["rho"].abs().max())
+
+
 @pytest.mark.parametrize("linsolve,mode", [("lu", 2), ("spd", 2), ("spd", 1)])
 @pytest.mark.parametrize("tag", ["noscale", "scale"])
 def test_g6_adaptive_rho_refactorises(dev, tag, linsolve, mode):
