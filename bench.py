@@ -33,8 +33,10 @@ TOL = 1e-5
 N_SEEDS = 10                  # experiment_1.py: n_sims = 10, seed = simulation index
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X: fp64 matrix = fp64 vector peak (v_mfma_f64_16x16x4_f64, 64 cycles per SIMD)
 INFINITY_CACHE_BYTES = 256 * 2 ** 20
-TRAFFIC_FILE = "profiles/r04_e_traffic.json"
+TRAFFIC_FILE = "profiles/r05_b_headline_traffic.json"
+PROFILE_TAG = "r05_b"          # profiles/<tag>_<workload>_{run.json,kernel_stats.csv,traffic.json,pmc_sq_raw.json}: tools/profile_workload.sh
 
 
 def parse():
@@ -116,6 +118,44 @@ def measured_traffic(kernel, B, n):
     except Exception:
         pass
     return None, None
+
+
+def profile_twin(workload):
+    """What the committed rocprofv3 set of a workload (tools/profile_workload.{py,sh}: the same inputs and control as the row
+    of this benchmark it stands beside) says about it: the dominant kernel with its average duration, the counter traffic of
+    the whole step (sum over kernels of bytes per launch x launches per step; FETCH_SIZE doubled per the gfx950 note), and --
+    where matrix instructions ran -- their rate against the dense peak.  None when the set is not in the tree."""
+    import csv
+    base = os.path.join(REPO, "profiles", f"{PROFILE_TAG}_{workload}_")
+    try:
+        run = json.load(open(base + "run.json"))
+        tr = json.load(open(base + "traffic.json"))["kernels"]
+        sq = json.load(open(base + "pmc_sq_raw.json"))
+        rows = [r for r in csv.DictReader(open(base + "kernel_stats.csv")) if r["Name"].replace("void ", "").startswith("lqp::")]
+    except Exception:
+        return None
+    passes = run["steps"] + run["warmup"]
+    step_bytes = sum(rec["hbm_bytes_per_launch_corrected"] * rec["launches"] for rec in tr.values()) / passes
+    step_ns = sum(float(r["TotalDurationNs"]) for r in rows) / passes
+    dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    name = dom["Name"].replace("void ", "").split("(")[0]
+    out = {"source": f"profiles/{PROFILE_TAG}_{workload}_* (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes)",
+           "profiled_ms_per_step": run["ms_per_step"], "kernel_ms_per_step": round(step_ns / 1e6, 4),
+           "traffic_bytes_per_step": int(step_bytes),
+           "traffic_frac_of_hbm_peak": round(step_bytes / (step_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
+           "dominant_kernel": name, "dominant_kernel_avg_us": round(float(dom["AverageNs"]) / 1e3, 1),
+           "dominant_kernel_share": round(float(dom["TotalDurationNs"]) / (step_ns * passes), 3),
+           "dominant_kernel_traffic_bytes_per_launch": tr.get(name, {}).get("hbm_bytes_per_launch_corrected")}
+    cnt = sq.get(name) or sq.get("void " + name) or {}
+    g = lambda k: cnt.get(k, {}).get("mean")
+    for key, peak, unit in (("SQ_INSTS_VALU_MFMA_MOPS_F32", MFMA_F32_PEAK_TFLOPS, "f32"), ("SQ_INSTS_VALU_MFMA_MOPS_F64", MFMA_F64_PEAK_TFLOPS, "f64")):
+        if g(key):
+            tfl = g(key) * 512 / (float(dom["AverageNs"]) * 1e-9) / 1e12          # one MOP = 512 flop (a 32x32x2 f32 instruction: 8 MOPs, 4096 flop)
+            out[f"dominant_kernel_mfma_{unit}_TFLOPs_issued"] = round(tfl, 2)
+            out[f"dominant_kernel_mfma_{unit}_frac_of_peak"] = round(tfl / peak, 4)
+    if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES"):
+        out["dominant_kernel_wave_cycles_parked"] = round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 3)
+    return out
 
 
 def cpu_baseline_worker(args):
@@ -428,6 +468,27 @@ def main():
             dtx = timed(k, lay)
             L.synchronize()
             out[key] = {"value": round(B / (dtx / k), 1), "unit": "QPs/sec", "ms_per_step": round(dtx / k * 1e3, 4), "steps": k}
+            if key == "step_linsolve_lu":
+                # the north-star-named algorithm: its kernel classes (HIP events on the launch stream) and the committed profile
+                _lib.profile(enable=True, reset=True)
+                timed(k, lay)
+                pr = _lib.profile()
+                _lib.profile(enable=False)
+                out[key]["kernel_ms_per_step"] = {c: round(v[0] / k, 4) for c, v in pr.items() if v[1]}
+                N_f, N_b = n + m, int(0.63 * n) + m
+                lu_ms = pr.get("lu_factor", (0.0, 0))[0] / k
+                out[key]["lu_factorisations"] = {
+                    "kernel": "lqp::k_lu_factor2 (two workgroups per matrix, csrc/lqp_lu2.hpp)",
+                    "algorithmic_flops_per_step": round(B * 2.0 / 3.0 * (N_f ** 3 + N_b ** 3)), "ms_per_step": round(lu_ms, 4),
+                    "algorithmic_TFLOPs": round(B * 2.0 / 3.0 * (N_f ** 3 + N_b ** 3) / (lu_ms * 1e-3) / 1e12, 2) if lu_ms > 0 else None,
+                    "note": "forward KKT matrix (n + m rows) + the backward's reduced system (~0.63 n + m rows); the panel chain of "
+                            "partial pivoting is serial: the matrix-core share (trailing update, U12) is the profile's MFMA figure"}
+                loop_lu_ms = pr.get("admm_loop", (0.0, 0))[0] / k
+                lb = es * (iters + 1) * (n + m) ** 2 * B
+                out[key]["loop"] = {"kernel": "lqp::k_admm_loop (cached triangular solves)", "ms_per_step": round(loop_lu_ms, 4),
+                                    "algorithmic_bytes": lb, "achieved_GBs": round(lb / (loop_lu_ms * 1e-3) / 1e9, 1) if loop_lu_ms > 0 else None,
+                                    "frac_of_hbm_peak": round(lb / (loop_lu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if loop_lu_ms > 0 else None}
+                out[key]["profile"] = profile_twin("lu")
         # ---- forward-only for configs 2 and 4 (B=128, n=100 box-only / n=1000 with the equality row),
         #      inputs drawn on the device, roofline terms from the run itself ----
         extras = {}
@@ -462,7 +523,8 @@ def main():
                             "forward_frac_of_hbm_roofline": round(fb * B / dtx / 1e9 / HBM_PEAK_GBS, 4),
                             "forward_frac_of_hbm_roofline_reference_algorithm_bytes": round(fb_ref * B / dtx / 1e9 / HBM_PEAK_GBS, 4),
                             "note": ("whole factor resident on chip (registers / LDS) for the loop: counter bytes << algorithmic"
-                                     if nn <= 128 else "")}
+                                     if nn <= 128 else ""),
+                            "profile": profile_twin("config2" if nn == 100 else "config4")}
             del Qx
         L.synchronize()
         out["other_configs_forward_only"] = extras
@@ -501,8 +563,15 @@ def main():
 
         more = {}
         piped = lambda **kw: L.SolveBoxQP(control=dict(L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, **kw), sync=False))
-        more["b32_n500_fwd_bwd"] = fwd_bwd_rate(piped(), device_batch(32, n, 77), 20, warm=5)
-        more["b1024_n500_fwd_bwd_config5_shard"] = fwd_bwd_rate(piped(), device_batch(1024, n, 78), 3, warm=1)
+        # the per-GPU shards of the metric string's own split ("batch=128 ... at 1/2/4/8 GPUs": 64 / 32 / 16 QPs per GPU)
+        more["b64_n500_fwd_bwd"] = dict(fwd_bwd_rate(piped(), device_batch(64, n, 75), 20, warm=5), is_shard_of="batch=128 at 2 GPUs",
+                                        profile=profile_twin("b64"))
+        more["b32_n500_fwd_bwd"] = dict(fwd_bwd_rate(piped(), device_batch(32, n, 77), 20, warm=5), is_shard_of="batch=128 at 4 GPUs",
+                                        profile=profile_twin("b32"))
+        more["b16_n500_fwd_bwd"] = dict(fwd_bwd_rate(piped(), device_batch(16, n, 76), 20, warm=5), is_shard_of="batch=128 at 8 GPUs",
+                                        profile=profile_twin("b16"))
+        more["b1024_n500_fwd_bwd_config5_shard"] = dict(fwd_bwd_rate(piped(), device_batch(1024, n, 78), 3, warm=1),
+                                                        profile=profile_twin("config5shard"))
         b128 = device_batch(B, n, 79)
         more["b128_n500_backward_kkt"] = fwd_bwd_rate(piped(backward='kkt'), b128, 3, warm=1)
         more["b128_n500_unroll"] = fwd_bwd_rate(L.SolveBoxQP(control=L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, unroll=True)),
@@ -512,7 +581,8 @@ def main():
         more["b8_n1500_fwd_bwd_lu_tier"] = fwd_bwd_rate(piped(), device_batch(8, 1500, 80), 2, warm=1)
         from lqp_py_amd.synthetic import create_hard_qp_data
         hard = create_hard_qp_data(250, 0.85, range(B), dtype=torch.float64, device=dev)      # prob 0.85 (experiment_1_hard.py:15), m = round(sqrt(250)) = 16
-        more["b128_n250_m16_hard_fp64"] = dict(fwd_bwd_rate(piped(), hard, 3, warm=1), dtype="f64", linsolve="lu (pivoted LU: f64)")
+        more["b128_n250_m16_hard_fp64"] = dict(fwd_bwd_rate(piped(), hard, 3, warm=1), dtype="f64", linsolve="lu (pivoted LU: f64)",
+                                               profile=profile_twin("hard64"))
         del hard
         out["other_workloads_fwd_bwd"] = more
         # ---- the reference's training experiment (experiments/experiment_2.py:12-20,57-99): Linear(5 -> 500) -> layer -> QP

@@ -63,6 +63,8 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_admm_loop_lu2<float>(lqp::FwdParams<float>, int, int, int)",
+    "void lqp::k_admm_loop_lu2<double>(lqp::FwdParams<double>, int, int, int)",
     "void lqp::k_lu_factor<float, 32, true, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, unsigned long long*, int const*)",
     "void lqp::k_lu_factor_la<16, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*)",
     "void lqp::k_lu_factor_la<32, 768>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*)",
