@@ -161,6 +161,9 @@ int lqp_debug_spin(void* stream, int blocks, int usec, int lds_bytes);
 /* test aid: out_dev[b] (int32, device) := the XCD (0..7, HW_REG_XCC_ID) workgroup b of a `blocks`-workgroup launch runs on --
  * the question the workgroups that share a matrix ask at every launch before they choose their exchange protocol.        */
 int lqp_debug_xcd(void* stream, int blocks, void* out_dev);
+/* test access to the dense tier's first kernel (csrc/lqp_dense.hpp): X (B, N, N) = M^-1 from a packed factor
+ * (`packed`: the buffer lqp_lu_pack filled).  N <= 1024 (float32: 512).  No reference counterpart. */
+int lqp_debug_lu_inverse(void* stream, int dtype, int B, int N, const void* packed, void* X_out);
 
 /* ---- forward ADMM solve ------------------------------------------------
  * Replaces torch_solve_box_qp (lqp_py/solve_box_qp_admm_torch.py:108-333):

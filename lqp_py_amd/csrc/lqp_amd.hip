@@ -1332,6 +1332,24 @@ int kkt_solve_impl(hipStream_t st, int B, int n, int m, const void* Q, const voi
     return LQP_OK;
 }
 
+// X = M^-1 from the packed factor (lqp_dense.hpp): G workgroups per matrix, each takes column tiles g, g + G, ...
+template <typename T>
+int launch_lu_inverse(hipStream_t st, int B, int N, const T* packed, size_t pkstride, const int* dest, int dstride, T* X,
+                      size_t xstride, int ldx, const int* gate) {
+    const int Np = round_up(N, LQP_NB);
+    const int lds = lu_inverse_lds_bytes<T>(Np);
+    auto fn = k_lu_inverse<T>;
+    const int rc = ensure_lds((const void*)fn, lds);
+    if (rc) return rc;
+    int dev = 0, cus = 256;
+    (void)current_device_cus(&dev, &cus);
+    const int ntiles = (N + InvCfg<T>::TWG - 1) / InvCfg<T>::TWG;
+    int G = std::max(1, std::min(ntiles, (2 * cus) / std::max(B, 1)));
+    ProfScope ps(st, PC_PACK);
+    hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, Np / LQP_NB, dest, dstride, X, xstride, ldx, gate);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
 bool bad_dims(int dtype, int B, int n, int m) {
     return (dtype != LQP_F32 && dtype != LQP_F64) || B < 1 || n < 1 || m < 0;
 }
@@ -1381,6 +1399,21 @@ int lqp_debug_xcd(void* stream, int blocks, void* out_dev) {
     if (blocks < 1 || !out_dev) return LQP_ERR_INVALID;
     hipLaunchKernelGGL(k_debug_xcd, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (int*)out_dev);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+int lqp_debug_lu_inverse(void* stream, int dtype, int B, int N, const void* packed_buf, void* X_out) {
+    if (bad_dims(dtype, B, N, 0) || !packed_buf || !X_out || N > (dtype == LQP_F32 ? 512 : 1024)) return LQP_ERR_INVALID;
+    const int K = round_up(N, LQP_NB) / LQP_NB;
+    if (dtype == LQP_F32) {
+        int* dest; float* packed;
+        carve_packed<float>((void*)packed_buf, B, N, dest, packed);
+        return launch_lu_inverse<float>((hipStream_t)stream, B, N, packed, packed_blocks(K) * LQP_BLK, dest, K * LQP_NB,
+                                        (float*)X_out, (size_t)N * N, N, nullptr);
+    }
+    int* dest; double* packed;
+    carve_packed<double>((void*)packed_buf, B, N, dest, packed);
+    return launch_lu_inverse<double>((hipStream_t)stream, B, N, packed, packed_blocks(K) * LQP_BLK, dest, K * LQP_NB,
+                                     (double*)X_out, (size_t)N * N, N, nullptr);
 }
 
 int lqp_profile_classes(void) { return PC_COUNT; }

@@ -17,6 +17,7 @@
 // A clamp that sits EXACTLY on its bound (x_k + u_k == lb: torch.maximum splits the gradient in two) is treated as free.
 #pragma once
 #include "lqp_boxqp.hpp"
+#include "lqp_dense.hpp"
 
 namespace lqp {
 

@@ -130,6 +130,33 @@ def test_two_workgroup_lu(dev, monkeypatch, N, B, dtype):
             lu_layer.lu_factor(Z.to(dev))
 
 
+@pytest.mark.parametrize("N,B,dtype", [(70, 3, torch.float32), (266, 8, torch.float32), (317, 4, torch.float32), (512, 2, torch.float32),
+                                       (64, 2, torch.float64), (266, 8, torch.float64), (300, 3, torch.float64), (501, 2, torch.float64)])
+def test_inverse_from_the_packed_factor(dev, N, B, dtype):
+    """csrc/lqp_dense.hpp, k_lu_inverse: X = M^-1 from the packed factor (blocked triangular solves with N right-hand sides on
+    the matrix cores) against torch.linalg.inv of a KKT-like matrix (zero lower-right block: the pivoting matters)."""
+    torch.manual_seed(N)
+    m = max(1, N // 16)
+    n = N - m
+    G = torch.randn(B, n, n, dtype=torch.float64)
+    A = torch.zeros(B, N, N, dtype=torch.float64)
+    A[:, :n, :n] = G.transpose(1, 2) @ G / n + torch.eye(n, dtype=torch.float64)
+    Aeq = torch.randn(B, m, n, dtype=torch.float64)
+    A[:, n:, :n] = Aeq; A[:, :n, n:] = Aeq.transpose(1, 2)
+    Ad = A.to(dtype).to(dev)
+    LU, P = lu_layer.lu_factor(Ad)
+    buf = lu_layer._PackedFactor(LU, P).buffer()
+    X = torch.empty_like(Ad)
+    lib = _lib.load()
+    _lib.check(lib.lqp_debug_lu_inverse(_lib.stream_ptr(dev), _lib.dtype_code(Ad), B, N, _lib.ptr(buf), _lib.ptr(X)), "lu_inverse")
+    torch.cuda.synchronize()
+    ref = torch.linalg.inv(A)
+    tol = 2e-4 if dtype == torch.float32 else 1e-10
+    assert rel(X, ref.to(dtype)) < tol
+    eye = torch.eye(N, dtype=torch.float64)
+    assert float((A @ X.cpu().double() - eye).abs().max()) < (5e-4 if dtype == torch.float32 else 1e-10)
+
+
 @pytest.mark.parametrize("N,B,dtype", [(1025, 2, torch.float64), (1100, 2, torch.float32), (1501, 2, torch.float64),
                                        (2048, 1, torch.float32), (2048, 1, torch.float64)])
 def test_lu_factor_above_1024(dev, N, B, dtype):

@@ -31,6 +31,7 @@ GROUPS = [
     ("split_b", lambda n: "k_admm_loop_split<" in n),
     ("loop_tail", lambda n: re.search(r"k_admm_loop<\w+, \w+, true,", n)),
     ("loop_hot", lambda n: "k_admm_loop<" in n),
+    ("dense", lambda n: "k_lu_inverse<" in n or "k_admm_loop_dense<" in n),
     ("lu2", lambda n: "k_lu_factor2<" in n),
     ("lu_a", lambda n: re.search(r"k_lu_factor<float, (32|16), true|k_lu_factor_big", n)),
     ("lu_b", lambda n: "k_lu_factor<" in n),
@@ -42,6 +43,8 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
+    "void lqp::k_lu_inverse<float>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
+    "void lqp::k_lu_inverse<double>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
     "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
     "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
     "void lqp::k_lu_factor_big<float>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
