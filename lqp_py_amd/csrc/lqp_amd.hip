@@ -147,6 +147,7 @@ struct Knobs {
     int launch_mode;           // LQP_LAUNCH_MODE
     int linsolve;              // LQP_LINSOLVE
     int loop512;               // LQP_LOOP512
+    int loop_dense;            // LQP_LOOP_DENSE
     int loop_small;            // LQP_LOOP_SMALL
     int loop_split;            // LQP_LOOP_SPLIT
     int loop_split4;           // LQP_LOOP_SPLIT4
@@ -188,6 +189,7 @@ Knobs read_knobs() {
     k.launch_mode = env_int("LQP_LAUNCH_MODE", 2);
     k.linsolve = env_int("LQP_LINSOLVE", 0);
     k.loop512 = env_int("LQP_LOOP512", 0);
+    k.loop_dense = env_int("LQP_LOOP_DENSE", 1);
     k.loop_small = env_int("LQP_LOOP_SMALL", 1);
     k.loop_split = env_int("LQP_LOOP_SPLIT", 1);
     k.loop_split4 = env_int("LQP_LOOP_SPLIT4", 1);
@@ -345,6 +347,24 @@ int launch_solve(hipStream_t st, int B, const T* packed, int N, const int* dest,
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
+// X = M^-1 from the packed factor (lqp_dense.hpp): G workgroups per matrix, each takes column tiles g, g + G, ...
+template <typename T>
+int launch_lu_inverse(hipStream_t st, int B, int N, const T* packed, size_t pkstride, const int* dest, int dstride, T* X,
+                      size_t xstride, int ldx, const int* gate) {
+    const int Np = round_up(N, LQP_NB);
+    const int lds = lu_inverse_lds_bytes<T>(Np);
+    auto fn = k_lu_inverse<T>;
+    const int rc = ensure_lds((const void*)fn, lds);
+    if (rc) return rc;
+    int dev = 0, cus = 256;
+    (void)current_device_cus(&dev, &cus);
+    const int ntiles = (N + InvCfg<T>::TWG - 1) / InvCfg<T>::TWG;
+    int G = std::max(1, std::min(ntiles, (2 * cus) / std::max(B, 1)));
+    ProfScope ps(st, PC_PACK);
+    hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, Np / LQP_NB, dest, dstride, X, xstride, ldx, gate);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
 // first failing batch index from the per-problem info array (host side, after a sync)
 // host_info: the same words in pinned host memory, stored there by the last kernel the stream has run (host_report): the
 // stream is waited for, nothing is copied
@@ -463,7 +483,11 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
     // granules of the two-workgroup loop (only ever used when 2 B workgroups fit the chip)
-    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB) ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + XCHG_TAIL)) : nullptr;
+    // (only where a two-workgroup kernel can run at all: 32 KB per problem -- a batch of 8192 small problems used to carry 256 MB of it)
+    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK)
+                 ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + XCHG_TAIL)) : nullptr;
+    // granules of the dense LU-tier loop (lqp_dense.hpp): batches that can leave half a chip idle, n <= 256
+    P.dnx = (B <= 256 && n <= DENSE_NMAX && P.N <= 1024) ? c.take<unsigned long long>((size_t)B * DNX_WORDS) : nullptr;
     L.bytes = c.off + kAlign;
     return L;
 }
@@ -798,6 +822,19 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 loop_split_seg = true;
         }
     }
+    // LU tier, persistent mode, n <= 256, 2 B workgroups resident: the explicit inverse of the KKT matrix in the registers of two
+    // workgroups per problem (lqp_dense.hpp) -- float64, many equality rows, non-symmetric Q, control['linsolve'] = 'lu'
+    bool loop_dense = false;
+    int dense_lds = 0;
+    if (!spd && mode == 2 && P.dnx && knobs().loop_dense != 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        dense_lds = dense_loop_lds_bytes<T>(m);
+        auto fnd = k_admm_loop_dense<T>;
+        if (dense_lds <= 160 * 1024 && lu_inverse_lds_bytes<T>(P.Np) <= 160 * 1024 && current_device_cus(&dev, &cus) &&
+            ensure_lds((const void*)fnd, dense_lds) == LQP_OK && blocks_per_cu(&per_cu, fnd, DENSE_NT, dense_lds, dev) &&
+            per_cu >= 1 && 2 * B <= cus * per_cu)
+            loop_dense = true;
+    }
     // small problems (n <= 128, e.g. BASELINE configs[1]): 256 threads per QP, the full matrix in registers (k_admm_loop_small)
     bool loop_small = false;
     int small_lds = 0;
@@ -817,6 +854,12 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         P.eq_in_loop = (loop_split && spd_resident && m > 0 && !(ctl->reserved2 & 1) && knobs().eq_in_loop) ? 1 : 0;
     rc = factor_step(nullptr);
     if (rc) return rc;
+    if (loop_dense) {
+        // X = M^-1 over the LAPACK copy of the factor (the pack kernel has read it; a refactorisation re-assembles M anyway)
+        rc = launch_lu_inverse<T>(st, B, P.N, P.packed, packed_blocks(P.K) * LQP_BLK, P.dest, P.Np, P.M, (size_t)P.Np * P.Np, P.Np, nullptr);
+        if (rc) return rc;
+        ++n_launch;
+    }
     // the first launch of the persistent modes
     auto launch_hot = [&](const int it, const int e, const int ctr_base, const int prev_slot, const int flags) {
         ProfScope ps(st, PC_LOOP);
@@ -829,6 +872,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 hipLaunchKernelGGL(k_admm_loop_small<>, dim3(B), dim3(256), small_lds, st, P, it, e, ctr_base);
                 return;
             }
+        }
+        if (loop_dense && it == 0) {
+            hipLaunchKernelGGL(k_admm_loop_dense<T>, dim3(2 * B), dim3(DENSE_NT), dense_lds, st, P, it, e, ctr_base);
+            return;
         }
         hipLaunchKernelGGL(loop_fn, dim3(B), dim3(loop_nt), loop_lds, st, P, it, e, ctr_base, prev_slot, flags);
     };
@@ -907,7 +954,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     stats->any_lb = stats->any_ub = -1;
                     stats->linsolve_used = spd ? 2 : 1;
                     stats->factor_launches = factor_launches;
-                    stats->loop_workgroups = loop_split ? loop_np : 1;
+                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : 1);
                 }
                 return LQP_OK;
             }
@@ -921,7 +968,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     stats->any_lb = stats->any_ub = -1;
                     stats->linsolve_used = spd ? 2 : 1;
                     stats->factor_launches = factor_launches;
-                    stats->loop_workgroups = loop_split ? loop_np : 1;
+                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : 1);
                 }
                 return LQP_OK;
             }
@@ -940,7 +987,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             lqp_boxqp_stats* so = stats ? stats : &local;
             memset(so, 0, sizeof(*so));
             so->n_launch = n_launch; so->linsolve_used = spd ? 2 : 1; so->factor_launches = factor_launches;
-            so->loop_workgroups = loop_split ? loop_np : 1;
+            so->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : 1);
             rc = collect_report(st, rep, rep == P.host_report, B, max_iters, check, so);
             if (rc == LQP_RETRY_LU)         // Qs + rho I not positive definite in f32 (first factorisation or an
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
@@ -1330,24 +1377,6 @@ int kkt_solve_impl(hipStream_t st, int B, int n, int m, const void* Q, const voi
         if (rc) return rc;
     }
     return LQP_OK;
-}
-
-// X = M^-1 from the packed factor (lqp_dense.hpp): G workgroups per matrix, each takes column tiles g, g + G, ...
-template <typename T>
-int launch_lu_inverse(hipStream_t st, int B, int N, const T* packed, size_t pkstride, const int* dest, int dstride, T* X,
-                      size_t xstride, int ldx, const int* gate) {
-    const int Np = round_up(N, LQP_NB);
-    const int lds = lu_inverse_lds_bytes<T>(Np);
-    auto fn = k_lu_inverse<T>;
-    const int rc = ensure_lds((const void*)fn, lds);
-    if (rc) return rc;
-    int dev = 0, cus = 256;
-    (void)current_device_cus(&dev, &cus);
-    const int ntiles = (N + InvCfg<T>::TWG - 1) / InvCfg<T>::TWG;
-    int G = std::max(1, std::min(ntiles, (2 * cus) / std::max(B, 1)));
-    ProfScope ps(st, PC_PACK);
-    hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, Np / LQP_NB, dest, dstride, X, xstride, ldx, gate);
-    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
 bool bad_dims(int dtype, int B, int n, int m) {

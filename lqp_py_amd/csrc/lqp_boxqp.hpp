@@ -32,6 +32,7 @@ constexpr int XCHG_WORDS = 2 * XCHG_NPMAX * SPD_MAXK * LQP_NB;      // exchange 
 // behind the granules of all QPs, per QP: [0..4) step granules of the resident sweep's workgroups | [4..8) the XCD ids its
 // workgroups announce | [8..12) the same for the shared loop (XCHG_TAIL words; zeroed by the setup kernel)
 constexpr int XCHG_TAIL = 12;
+constexpr int DNX_WORDS = 2 * 256 * 2;   // dense LU-tier loop (lqp_dense.hpp): [parity][row <= 256][one (f32) or two (f64) words]
 // the XCD this workgroup runs on (0..7)
 __device__ __forceinline__ unsigned int my_xcd() { return (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu; }
 
@@ -75,6 +76,7 @@ template <typename T> struct FwdParams {
     int* status;      // ST_WORDS
     unsigned int* counters;   // ring of CT_WORDS per check
     unsigned long long* xchg; // B * XCHG_WORDS granules: partial-product exchange of the two-workgroup loop (or null)
+    unsigned long long* dnx;  // B * DNX_WORDS granules: x-halves of the dense LU-tier loop, lqp_dense.hpp (or null)
     size_t vstride;
     // controls
     int scale, rho_mode, beta_mode, check_solved, adaptive_rho;
@@ -359,6 +361,10 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
         for (int i = tid; i < P.zero_words; i += LQP_NT) P.status[i] = 0;
     unsigned long long tst = clock64();
 #define SETUP_STAMP(i) do { if (P.dbg_setup && tid == 0) { const unsigned long long t_ = clock64(); P.dbg_setup[(size_t)b * 8 + (i)] = t_ - tst; tst = t_; } } while (0)
+    if (P.dnx) {                           // granules of the dense LU-tier loop (lqp_dense.hpp): tags start from zero
+        unsigned long long* dq = P.dnx + (size_t)b * DNX_WORDS;
+        for (int i = tid; i < DNX_WORDS; i += LQP_NT) dq[i] = 0ull;
+    }
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * XCHG_WORDS;
         for (int i = tid; i < XCHG_WORDS; i += LQP_NT) xq[i] = 0ull;

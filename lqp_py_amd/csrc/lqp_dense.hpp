@@ -153,4 +153,231 @@ __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The ADMM loop with the explicit inverse: [x; nu] = X [w; b], w = -p + rho (z - u)  (reference :258-268), n <= 256
+// ---------------------------------------------------------------------------------------------------------------------
+// Two workgroups of 512 threads per problem; workgroup `part` owns rows [h0, h1) of X[0:n, 0:n] -- four threads per row, 64
+// columns each, IN REGISTERS for the whole launch (n = 250, float64: 126 VGPRs per thread).  Per iteration: the product with w
+// (LDS, broadcast reads; one quad reduction per row), the constant term c = X[0:n, n:N] b, the own half of x published as
+// tagged granules and the partner's fetched (two buffers by iteration parity), then BOTH workgroups run the element-wise update
+// of all n variables redundantly (identical bits: no second exchange, and both know the verdict of a check).  nu = X[n:N, :] [w; b]
+// is formed from global memory where it is needed (checks, last iteration).
+constexpr int DENSE_NT = 512, DENSE_CPT = 64, DENSE_TPR = 4, DENSE_NMAX = DENSE_CPT * DENSE_TPR;
+template <typename T> __host__ __device__ constexpr int dense_ws() { return DENSE_CPT + (sizeof(T) == 4 ? 4 : 2); }   // chunk stride of w in LDS
+// granules per problem: [parity][row], one (float32) or two (float64) 8-byte words per element
+template <typename T> __host__ __device__ constexpr size_t dense_xchg_words() { return (size_t)2 * DENSE_NMAX * (sizeof(T) / 4); }
+// LDS: wl[4 WS] xs z u ps lb ub D [7 x 256] cvl[128] | bs nul [2 m] | red[8 * 8 + 8] | flags[8]
+template <typename T> __host__ __device__ inline int dense_loop_lds_bytes(int m) {
+    return (DENSE_TPR * dense_ws<T>() + 7 * DENSE_NMAX + DENSE_NMAX / 2 + 2 * m + (DENSE_NT / 64) * 8 + 8 + 8) * (int)sizeof(T) + 64;
+}
+
+template <typename T>
+__global__ __launch_bounds__(DENSE_NT) void k_admm_loop_dense(const FwdParams<T> P, const int it0, const int it1, const int ctr_base) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    constexpr int NT = DENSE_NT, NWV = NT / 64, CPT = DENSE_CPT, WS = dense_ws<T>(), GW = sizeof(T) / 4, NM = DENSE_NMAX;
+    const int b = (int)blockIdx.x % P.B, part = (int)blockIdx.x / P.B;
+    const int n = P.n, m = P.m, Np = P.Np;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (it0 >= it1) return;
+    T* wl = (T*)smem;
+    T* xs = wl + DENSE_TPR * WS;
+    T* z = xs + NM;
+    T* u = z + NM;
+    T* ps = u + NM;
+    T* lb = ps + NM;
+    T* ub = lb + NM;
+    T* D = ub + NM;
+    T* cvl = D + NM;
+    T* bs = cvl + NM / 2;
+    T* nul = bs + m;
+    T* red = nul + m;
+    int* flags = (int*)(red + NWV * 8 + 8);                   // [0] exchange timed out (sticky)
+    const int nh = (n + 1) / 2;
+    const int h0 = part ? nh : 0, h1 = part ? n : nh;
+    const int r = tid >> 2, q = tid & 3, row = h0 + r;
+    const bool rowok = row < h1;
+    const T* X = P.M + (size_t)b * Np * Np;                   // the inverse, written over the factor's LAPACK copy by k_lu_inverse
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    T* scal = P.scal + (size_t)b * SC_WORDS;
+    const T rho = scal[SC_RHO];
+    const T pnorm = scal[SC_PNORM];
+    static_assert(dense_xchg_words<T>() <= (size_t)DNX_WORDS, "granule area");
+    unsigned long long* const xq = P.dnx + (size_t)b * DNX_WORDS;
+
+    // ---- my rows of X[0:n, 0:n] into registers ----
+    T H[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = q * CPT + j;
+        H[j] = (rowok && c < n) ? X[(size_t)row * Np + c] : T(0);
+    }
+    for (int i = tid; i < NM; i += NT) {
+        const bool in = i < n;
+        z[i] = in ? V.z[i] : T(0); u[i] = in ? V.u[i] : T(0); ps[i] = in ? V.ps[i] : T(0);
+        lb[i] = in ? V.lbs[i] : T(0); ub[i] = in ? V.ubs[i] : T(0); D[i] = in ? V.D[i] : T(1);
+        xs[i] = T(0);
+    }
+    for (int k = tid; k < m; k += NT) { bs[k] = V.bs[k]; nul[k] = T(0); }
+    if (tid < 8) flags[tid] = 0;
+    __syncthreads();
+    if (q == 0 && r < NM / 2) {                                  // c = X[0:n, n:N] b, my rows
+        T acc = T(0);
+        if (rowok)
+            for (int k = 0; k < m; ++k) acc += X[(size_t)row * Np + n + k] * bs[k];
+        cvl[r] = acc;
+    }
+    for (int i = tid; i < NM; i += NT) wl[(i >> 6) * WS + (i & 63)] = (i < n) ? -ps[i] + rho * (z[i] - u[i]) : T(0);
+    __syncthreads();
+
+    int slot = ctr_base;
+    for (int it = it0; it < it1; ++it) {
+        const bool check = (it % P.check_solved) == 0;
+        // ---- x (my rows) = X w + c ----
+        T acc = T(0);
+        const T* wq = wl + q * WS;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc += H[j] * wq[j];
+        acc += dpp<0xB1>(acc);
+        acc += dpp<0x4E>(acc);
+        const unsigned int tag = (unsigned int)(it + 1);
+        unsigned long long* const xb = xq + (size_t)(it & 1) * NM * GW;
+        if (q == 0 && rowok) {
+            const T xi = acc + cvl[r];
+            xs[row] = xi;
+            if constexpr (GW == 1) {
+                __hip_atomic_store(xb + row, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, xi),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const unsigned long long bits = __builtin_bit_cast(unsigned long long, xi);
+                __hip_atomic_store(xb + 2 * row, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xb + 2 * row + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- the partner's rows ----
+        {
+            const int p0 = part ? 0 : nh, p1 = part ? nh : n;
+            const int prow = p0 + tid;
+            if (prow < p1) {
+                unsigned long long g[GW];
+                bool bad = false;
+#pragma unroll
+                for (int e = 0; e < GW; ++e) {
+                    unsigned int spins = 0;
+                    unsigned long long t0 = 0;
+                    for (;;) {
+                        g[e] = __hip_atomic_load(xb + GW * prow + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned int)(g[e] >> 32) == tag || flags[0]) break;
+                        if ((++spins & 255u) == 0) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();         // 100 MHz
+                            if (t0 == 0) t0 = now;
+                            else if (now - t0 > 50000000ULL) {                                       // 0.5 s: give up, flagged
+                                __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                flags[0] = 1;
+                                bad = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (!bad) {
+                    if constexpr (GW == 1) xs[prow] = __builtin_bit_cast(float, (unsigned int)g[0]);
+                    else xs[prow] = __builtin_bit_cast(double, (g[GW - 1] << 32) | (g[0] & 0xFFFFFFFFull));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- nu = X[n:N, :] [w; b] where a check or the end of the launch needs it (w is still this iteration's) ----
+        if ((check || it + 1 == it1) && m > 0) {
+            for (int k = w; k < m; k += NWV) {
+                const T* xr = X + (size_t)(n + k) * Np;
+                T a = T(0);
+                for (int i = lane; i < n; i += 64) a += xr[i] * wl[(i >> 6) * WS + (i & 63)];
+                for (int j = lane; j < m; j += 64) a += xr[n + j] * bs[j];
+                a = wave_sum(a);
+                if (lane == 0) nul[k] = a;
+            }
+            __syncthreads();
+        }
+        // ---- z-update, residuals, dual (:271-282), all n variables on both workgroups ----
+        T mx[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) mx[e] = T(0);
+        if (tid < NM) {
+            const int i = tid;
+            const bool in = i < n;
+            const T xi = xs[i];
+            const T zp = z[i];
+            const T ui = u[i];
+            T zn = xi + ui;
+            zn = tmin(tmax(zn, lb[i]), ub[i]);
+            const T rr = xi - zn;
+            const T ss = rho * (zn - zp);
+            const T un = ui + rr;
+            if (in) { z[i] = zn; u[i] = un; }
+            if (check && in) {
+                const T di = D[i];
+                mx[0] = tabs(di * rr);
+                mx[1] = tabs(di * ss);
+                mx[2] = tabs(di * xi);
+                mx[3] = tabs(di * zn);
+                mx[4] = tabs((rho * di) * un);
+                T qx = -ps[i] + rho * (zp - ui) - rho * xi;
+                for (int k = 0; k < m; ++k) qx -= V.As[(size_t)k * n + i] * nul[k];
+                mx[5] = tabs(qx / di);
+            }
+            wl[(i >> 6) * WS + (i & 63)] = in ? -ps[i] + rho * (zn - un) : T(0);
+        }
+        if (check) {
+            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], mx[5]};
+            wg_max_n<T, 6, NWV>(mv, red);
+            const T tiny = T(1e-16);
+            const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
+            const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
+            const T dua_scale = tmax(tmax(tmax(mv[4], mv[5]), pnorm), tiny);
+            const T tol_d = P.eps_abs + P.eps_rel * dua_scale;
+            const bool solved = (mv[0] < tol_p) && (mv[1] < tol_d);
+            const bool wants = (mv[0] > tmax(tol_p, P.ar_thr)) || (mv[1] > tmax(tol_d, P.ar_thr));
+            const T num = tmax(mv[0] / pri_scale, tiny);
+            const T den = tmax(mv[1] / dua_scale, tiny);
+            const T ratio = tsqrt(num / den);
+            const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
+            unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
+            if (tid == 0) {
+                unsigned int r1 = 0, r2 = 0;
+                if (part == 0) {
+                    scal[SC_RATIO] = ratio;
+                    scal[SC_WANTS] = wants ? T(1) : T(0);
+                    scal[SC_PRI] = mv[0];
+                    scal[SC_DUA] = mv[1];
+                    if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
+                    if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" :: "v"(r1), "v"(r2) : "memory");
+                // both workgroups arrive (they computed the same numbers); the verdict is counted once, by part 0
+                __hip_atomic_fetch_add((unsigned long long*)(ct + CT_NOTOPT), ((part == 0 && !solved) ? 1ull : 0ull) | (1ull << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ++slot;
+            grid_wait(ct + CT_ARRIVE, 2u * (unsigned int)P.B, P.status);      // device-wide "all optimal?" (torch.all at :312)
+            const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (notopt == 0 || tmo) {
+                if (blockIdx.x == 0 && tid == 0) {
+                    P.status[ST_FINAL_ITER] = it;
+                    __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                break;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- state for the continuation launch / the epilogue ----
+    if (part == 0) {
+        for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }
+        for (int k = tid; k < m; k += NT) V.nu[k] = nul[k];
+    }
+}
+
 }  // namespace lqp

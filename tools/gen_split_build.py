@@ -43,6 +43,8 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
+    "void lqp::k_admm_loop_dense<float>(lqp::FwdParams<float>, int, int, int)",
+    "void lqp::k_admm_loop_dense<double>(lqp::FwdParams<double>, int, int, int)",
     "void lqp::k_lu_inverse<float>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
     "void lqp::k_lu_inverse<double>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
     "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
