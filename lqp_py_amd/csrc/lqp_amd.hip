@@ -359,7 +359,9 @@ int launch_lu_inverse(hipStream_t st, int B, int N, const T* packed, size_t pkst
     int dev = 0, cus = 256;
     (void)current_device_cus(&dev, &cus);
     const int ntiles = (N + InvCfg<T>::TWG - 1) / InvCfg<T>::TWG;
-    int G = std::max(1, std::min(ntiles, (2 * cus) / std::max(B, 1)));
+    // (column tiles are independent: every tile its own workgroup while the grid stays within a few waves of workgroups per CU --
+    //  several 256-thread workgroups per CU hide each other's barriers and operand loads)
+    int G = std::max(1, std::min(ntiles, (12 * cus) / std::max(B, 1)));
     ProfScope ps(st, PC_PACK);
     hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, Np / LQP_NB, dest, dstride, X, xstride, ldx, gate);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;

@@ -30,7 +30,8 @@ template <typename T> struct InvCfg {
     static constexpr int RT = 64 / TR;                        // row tiles per 64-row block: 2 | 4
     static constexpr int CT = 4 / RT;                         // column tiles per workgroup: 2 | 1
     static constexpr int TWG = CT * TC;                       // columns of X per workgroup tile: 64 | 16
-    static constexpr int YS = TWG + (sizeof(T) == 4 ? 4 : 2); // row stride of Y in LDS (padded against bank conflicts)
+    static constexpr int YS = TWG + 1;                        // row stride of Y in LDS: odd, so that the lane groups' rows (16 / 32 apart)
+                                                              // start 128 B apart in the banks (an even stride put all of them on the same ones)
 };
 template <typename T> __host__ __device__ inline int lu_inverse_lds_bytes(int Np) { return Np * InvCfg<T>::YS * (int)sizeof(T); }
 
@@ -39,6 +40,7 @@ template <typename T> __host__ __device__ inline int lu_inverse_lds_bytes(int Np
 template <typename T>
 struct InvAcc;
 template <> struct InvAcc<float> {
+    static constexpr int NA = 32;                                  // A operands of one 64-deep block product
     f32x16 a;
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -46,26 +48,41 @@ template <> struct InvAcc<float> {
     }
     // element (row, col) of register q in lane (li, lg)
     __device__ static __forceinline__ int row(int q, int lg) { return (q & 3) + 8 * (q >> 2) + 4 * lg; }
-    __device__ __forceinline__ void mac(const float* __restrict__ blk, const int r0, const float* __restrict__ Y, const int YS,
-                                        const int li, const int lg, const float sign) {
-        const float* ap = blk + (size_t)(r0 + li) * 64 + lg;
-        const float* bp = Y + (size_t)lg * YS + li;
+    __device__ static __forceinline__ void load(float (&op)[NA], const float* __restrict__ blk, const int r0, const int li, const int lg) {
+        // (lane group lg takes k = 32 lg + t -- any split of the 64 terms over the instruction's k-slots sums the same product --,
+        //  so a lane's operands are 128 contiguous bytes of its row: whole cache lines, four times fewer line fetches than k = 2 t + lg)
+        const float* ap = blk + (size_t)(r0 + li) * 64 + 32 * lg;
 #pragma unroll
-        for (int kk = 0; kk < 64; kk += 2)
-            a = __builtin_amdgcn_mfma_f32_32x32x2f32(sign * ap[kk], bp[(size_t)kk * YS], a, 0, 0, 0);
+        for (int v = 0; v < NA / 4; ++v) {
+            const V4<float> x = *(const V4<float>*)(ap + 4 * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) op[4 * v + e] = x.v[e];
+        }
+    }
+    __device__ __forceinline__ void mac(const float (&op)[NA], const float* __restrict__ Y, const int YS, const int li, const int lg) {
+        const float* bp = Y + (size_t)(32 * lg) * YS + li;
+#pragma unroll
+        for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f32_32x32x2f32(op[t], bp[(size_t)t * YS], a, 0, 0, 0);
     }
 };
 template <> struct InvAcc<double> {
+    static constexpr int NA = 16;
     f64x4 a;
     __device__ __forceinline__ void zero() { a = f64x4{0.0, 0.0, 0.0, 0.0}; }
     __device__ static __forceinline__ int row(int q, int lg) { return 4 * q + lg; }
-    __device__ __forceinline__ void mac(const double* __restrict__ blk, const int r0, const double* __restrict__ Y, const int YS,
-                                        const int li, const int lg, const double sign) {
-        const double* ap = blk + (size_t)(r0 + li) * 64 + lg;
-        const double* bp = Y + (size_t)lg * YS + li;
+    __device__ static __forceinline__ void load(double (&op)[NA], const double* __restrict__ blk, const int r0, const int li, const int lg) {
+        const double* ap = blk + (size_t)(r0 + li) * 64 + 16 * lg;       // (k = 16 lg + t: see the float32 form)
 #pragma unroll
-        for (int kk = 0; kk < 64; kk += 4)
-            a = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * ap[kk], bp[(size_t)kk * YS], a, 0, 0, 0);
+        for (int v = 0; v < NA / 4; ++v) {
+            const V4<double> x = *(const V4<double>*)(ap + 4 * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) op[4 * v + e] = x.v[e];
+        }
+    }
+    __device__ __forceinline__ void mac(const double (&op)[NA], const double* __restrict__ Y, const int YS, const int li, const int lg) {
+        const double* bp = Y + (size_t)(16 * lg) * YS + li;
+#pragma unroll
+        for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f64_16x16x4f64(op[t], bp[(size_t)t * YS], a, 0, 0, 0);
     }
 };
 
@@ -101,48 +118,41 @@ __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed
         __syncthreads();
         InvAcc<T> acc;
         const int ycol = ct * C::TC;
-        // ---- L phase: Y_k <- inv(L_kk) (Y_k - sum_{j<k} L_kj Y_j), k ascending ----
-        for (int k = 0; k < K; ++k) {
-            const T* rowblk = Lpk + (size_t)(k * (k + 1) / 2) * LQP_BLK;       // L(k,0) .. L(k,k-1), inv(L(k,k))
+        // One block row of a phase: acc = sum_j B_j Y_(col j) over the off-diagonal blocks (A operands of the NEXT block are
+        // requested before the current block's matrix instructions: the loads' latency stands behind 1024 cycles of them),
+        // Y_k -= acc, barrier, Y_k <- Dinv Y_k with the pre-inverted diagonal block (loaded ahead of the barrier).
+        auto block_row = [&](const T* rowblk, const int noff, const int k, auto col_of) {
             T* Yk = Y + (size_t)(64 * k) * C::YS + ycol;
-            acc.zero();
-            for (int j = 0; j < k; ++j)
-                acc.mac(rowblk + (size_t)j * LQP_BLK, C::TR * rt, Y + (size_t)(64 * j) * C::YS + ycol, C::YS, li, lg, T(-1));
+            T opA[InvAcc<T>::NA], opB[InvAcc<T>::NA];
             constexpr int NQ = sizeof(T) == 4 ? 16 : 4;
+            acc.zero();
+            InvAcc<T>::load(opA, rowblk, C::TR * rt, li, lg);                 // block 0 (the diagonal one when noff == 0)
+            for (int j = 0; j < noff; ++j) {
+                InvAcc<T>::load(opB, rowblk + (size_t)(j + 1) * LQP_BLK, C::TR * rt, li, lg);
+                acc.mac(opA, Y + (size_t)(64 * col_of(j)) * C::YS + ycol, C::YS, li, lg);
+#pragma unroll
+                for (int t = 0; t < InvAcc<T>::NA; ++t) opA[t] = opB[t];
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 T* p = Yk + (size_t)(C::TR * rt + InvAcc<T>::row(q, lg)) * C::YS + li;
-                *p = *p + acc.a[q];
+                *p = *p - acc.a[q];
             }
             __syncthreads();
             acc.zero();
-            acc.mac(rowblk + (size_t)k * LQP_BLK, C::TR * rt, Yk, C::YS, li, lg, T(1));
-            __syncthreads();                                   // (every wave has read the old Y_k)
+            acc.mac(opA, Yk, C::YS, li, lg);                             // (opA holds the diagonal block's operands by now)
+            __syncthreads();                                                   // (every wave has read the old Y_k)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) Yk[(size_t)(C::TR * rt + InvAcc<T>::row(q, lg)) * C::YS + li] = acc.a[q];
             __syncthreads();
-        }
-        // ---- U phase: Y_k <- inv(U_kk) (Y_k - sum_{j>k} U_kj Y_j), k descending ----
+        };
+        // ---- L phase: Y_k <- inv(L_kk) (Y_k - sum_{j<k} L_kj Y_j), k ascending: L(k,0) .. L(k,k-1), inv(L(k,k)) ----
+        for (int k = 0; k < K; ++k)
+            block_row(Lpk + (size_t)(k * (k + 1) / 2) * LQP_BLK, k, k, [](int j) { return j; });
+        // ---- U phase: Y_k <- inv(U_kk) (Y_k - sum_{j>k} U_kj Y_j), k descending: U(k,K-1) .. U(k,k+1), inv(U(k,k)) ----
         for (int k = K - 1; k >= 0; --k) {
             const int kr = K - 1 - k;                           // block rows the U phase has visited
-            const T* rowblk = Upk + (size_t)(kr * (kr + 1) / 2) * LQP_BLK;     // U(k,K-1) .. U(k,k+1), inv(U(k,k))
-            T* Yk = Y + (size_t)(64 * k) * C::YS + ycol;
-            acc.zero();
-            for (int j = K - 1; j > k; --j)
-                acc.mac(rowblk + (size_t)(K - 1 - j) * LQP_BLK, C::TR * rt, Y + (size_t)(64 * j) * C::YS + ycol, C::YS, li, lg, T(-1));
-            constexpr int NQ = sizeof(T) == 4 ? 16 : 4;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                T* p = Yk + (size_t)(C::TR * rt + InvAcc<T>::row(q, lg)) * C::YS + li;
-                *p = *p + acc.a[q];
-            }
-            __syncthreads();
-            acc.zero();
-            acc.mac(rowblk + (size_t)kr * LQP_BLK, C::TR * rt, Yk, C::YS, li, lg, T(1));
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) Yk[(size_t)(C::TR * rt + InvAcc<T>::row(q, lg)) * C::YS + li] = acc.a[q];
-            __syncthreads();
+            block_row(Upk + (size_t)(kr * (kr + 1) / 2) * LQP_BLK, kr, k, [K](int j) { return K - 1 - j; });
         }
         // ---- X[:, c0 ..] = Y ----
         for (int i = tid; i < N * C::TWG; i += 256) {
