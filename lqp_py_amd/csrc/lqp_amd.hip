@@ -909,7 +909,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     event = false;
                 }
                 int e = max_iters;
-                if (ctl->adaptive_rho && !(spd && it > 0)) {      // (the symmetric tail walks through its events itself)
+                if (ctl->adaptive_rho && !((spd || inkernel_refactor) && it > 0)) {      // (the continuation kernel walks through its events itself)
                     const int a = (it / ar_iter + 1) * ar_iter;
                     if (a < ctl->adaptive_rho_max_iter) e = std::min(e, a);
                 }
@@ -935,7 +935,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     last_tail = e >= max_iters && tail_epilogue;
                     ProfScope ps(st, PC_LOOP_TAIL);
                     hipLaunchKernelGGL(tail_fn, dim3(B), dim3(LQP_NT), tail_lds, st,
-                                       P, it, e, (int)(c_first % kRing), prev_slot, ((event || spd) ? 3 : 1) | (last_tail ? 4 : 0));
+                                       P, it, e, (int)(c_first % kRing), prev_slot, ((event || spd || inkernel_refactor) ? 3 : 1) | (last_tail ? 4 : 0));
                 }
                 ++n_launch;
                 it = e;

@@ -1164,32 +1164,6 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
         }
     }
     if (it0 >= it1) return;
-    if constexpr (TAIL && NT == 1024 && !SYM) {   // (the symmetric path's tail walks through its events further down)
-        if ((persistent & 2) && prev_slot >= 0) {
-            unsigned int* ctl = P.counters + (size_t)prev_slot * CT_WORDS;
-            if (__hip_atomic_load(ctl + CT_WANTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
-                __hip_atomic_load(ctl + CT_TRIG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {          // uniform over the whole grid
-                constexpr int kPB = sizeof(T) == 4 ? 16 : 8;
-                T* scal_ = P.scal + (size_t)b * SC_WORDS;
-                VecView<T> V_(P.vecs + (size_t)b * P.vstride, n, m);
-                T rho_ = scal_[SC_RHO];
-                if (scal_[SC_WANTS] != T(0)) rho_ = rho_ * scal_[SC_RATIO];
-                rho_ = tmin(tmax(rho_, P.rho_min), P.rho_max);
-                __syncthreads();
-                if (tid == 0) scal_[SC_RHO] = rho_;
-                if (b == 0 && tid == 0) { P.status[ST_NFACTOR] += 1; P.status[ST_RHO_UPDATED] = 1; }
-                const T* Qs_ = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
-                assemble_kkt_rows(P, b, Qs_, P.scale ? P.ldq : n, V_, rho_, true);
-                __syncthreads();
-                wg_lu_factor<T, kPB, sizeof(T) == 4, NT>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
-                                                            P.info + b, smem, nullptr);
-                __syncthreads();
-                wg_pack_factor<T>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
-                                  P.packed + (size_t)b * packed_blocks(K) * LQP_BLK, P.dest + (size_t)b * Np, smem, true);
-                __syncthreads();
-            }
-        }
-    }
     // LDS carve.  LU path:  [resident blocks] v tmp | z u ps lb ub D bs red | dest
     //            SYM path: [resident blocks] v xs ylds cvl part[NW][Nps] | z u ps lb ub D bs red
     const int Nps = SYM ? P.Ks * LQP_NB : Np;                // padded length of the solve vector
@@ -1241,6 +1215,38 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
             }
         }
     }
+    if constexpr (TAIL && !SYM && NT == 1024) {
+        // The LU path's continuation launch walks through the adaptive-rho events (:237-256) the same way (round 5: one launch
+        // per possible event before -- nine at the defaults, each ~5 us of nothing when the solve was over): the decision from the
+        // counters of the last check (complete: every check of a persistent launch ends in a device-wide wait), the masked rho
+        // update, KKT re-assembly, pivoted LU and pack in-kernel.
+        if (P.adaptive_rho && (persistent & 2)) {
+            const int nxt = (seg0 / P.ar_iter + 1) * P.ar_iter;
+            if (nxt < P.ar_max && nxt < seg1) seg1 = nxt;
+            if (seg0 > 0 && seg0 % P.ar_iter == 0 && seg0 < P.ar_max) {
+                unsigned int* ctl = P.counters + (size_t)(((seg0 - 1) / P.check_solved) % P.ring) * CT_WORDS;
+                if (__hip_atomic_load(ctl + CT_WANTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+                    __hip_atomic_load(ctl + CT_TRIG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {          // uniform over the whole grid
+                    constexpr int kPB = sizeof(T) == 4 ? 16 : 8;
+                    T rho_ = scal[SC_RHO];
+                    if (scal[SC_WANTS] != T(0)) rho_ = rho_ * scal[SC_RATIO];
+                    rho_ = tmin(tmax(rho_, P.rho_min), P.rho_max);
+                    __syncthreads();
+                    if (tid == 0) scal[SC_RHO] = rho_;
+                    if (b == 0 && tid == 0) { P.status[ST_NFACTOR] += 1; P.status[ST_RHO_UPDATED] = 1; }
+                    const T* Qs_ = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
+                    assemble_kkt_rows(P, b, Qs_, P.scale ? P.ldq : n, V, rho_, true);
+                    __syncthreads();
+                    wg_lu_factor<T, kPB, sizeof(T) == 4, NT>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
+                                                                P.info + b, smem, nullptr);
+                    __syncthreads();
+                    wg_pack_factor<T>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
+                                      P.packed + (size_t)b * packed_blocks(K) * LQP_BLK, P.dest + (size_t)b * Np, smem, true);
+                    __syncthreads();
+                }
+            }
+        }
+    }
     const int it0 = seg0, it1 = seg1;                        // (shadow the launch bounds inside the segment)
     const T rho = scal[SC_RHO];
     const T pnorm = scal[SC_PNORM];
@@ -1276,7 +1282,7 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
 
     unsigned long long dbt[4] = {0, 0, 0, 0}, dt0 = 0;      // debug: cycles in rhs / product / combine / update+check
     const bool dbg_on = SYM && P.dbg != nullptr;
-    int slot = (TAIL && SYM) ? ((it0 + P.check_solved - 1) / P.check_solved) % P.ring : ctr_base;
+    int slot = TAIL ? ((it0 + P.check_solved - 1) / P.check_solved) % P.ring : ctr_base;
     for (int it = it0; it < it1; ++it) {
         if (dbg_on) dt0 = clock64();
         const bool check = (it % P.check_solved) == 0;
@@ -1444,7 +1450,7 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
     // ---- save state for the next launch / the epilogue ----
     for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
     loop_store_nu<T, NT, SYM>(V, v, bs + m, n, m);
-    if (!(TAIL && SYM) || seg1 >= it_end) break;
+    if (!TAIL || seg1 >= it_end) break;
     seg0 = seg1;
     __syncthreads();
   }
