@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 8
+#define LQP_ABI_VERSION 9
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 

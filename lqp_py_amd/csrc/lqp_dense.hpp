@@ -61,8 +61,11 @@ template <> struct InvAcc<float> {
     }
     __device__ __forceinline__ void mac(const float (&op)[NA], const float* __restrict__ Y, const int YS, const int li, const int lg) {
         const float* bp = Y + (size_t)(32 * lg) * YS + li;
+        float bq[NA];                                              // (all B operands requested first: read one by one, each matrix
+#pragma unroll                                                     //  instruction stood behind an LDS round trip of its own)
+        for (int t = 0; t < NA; ++t) bq[t] = bp[(size_t)t * YS];
 #pragma unroll
-        for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f32_32x32x2f32(op[t], bp[(size_t)t * YS], a, 0, 0, 0);
+        for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f32_32x32x2f32(op[t], bq[t], a, 0, 0, 0);
     }
 };
 template <> struct InvAcc<double> {
@@ -81,8 +84,11 @@ template <> struct InvAcc<double> {
     }
     __device__ __forceinline__ void mac(const double (&op)[NA], const double* __restrict__ Y, const int YS, const int li, const int lg) {
         const double* bp = Y + (size_t)(16 * lg) * YS + li;
+        double bq[NA];
 #pragma unroll
-        for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f64_16x16x4f64(op[t], bp[(size_t)t * YS], a, 0, 0, 0);
+        for (int t = 0; t < NA; ++t) bq[t] = bp[(size_t)t * YS];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f64_16x16x4f64(op[t], bq[t], a, 0, 0, 0);
     }
 };
 
@@ -244,10 +250,13 @@ __global__ __launch_bounds__(DENSE_NT) void k_admm_loop_dense(const FwdParams<T>
     for (int it = it0; it < it1; ++it) {
         const bool check = (it % P.check_solved) == 0;
         // ---- x (my rows) = X w + c ----
-        T acc = T(0);
         const T* wq = wl + q * WS;
+        T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);          // (four chains: one chain of 64 dependent FMAs is latency, not work)
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) acc += H[j] * wq[j];
+        for (int j = 0; j < CPT; j += 4) {
+            a0 += H[j] * wq[j]; a1 += H[j + 1] * wq[j + 1]; a2 += H[j + 2] * wq[j + 2]; a3 += H[j + 3] * wq[j + 3];
+        }
+        T acc = (a0 + a1) + (a2 + a3);
         acc += dpp<0xB1>(acc);
         acc += dpp<0x4E>(acc);
         const unsigned int tag = (unsigned int)(it + 1);
