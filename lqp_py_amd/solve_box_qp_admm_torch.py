@@ -169,13 +169,14 @@ def torch_solve_box_qp_grad_kkt(dl_dz, x, lams, nus, Q, A, lb, ub):
 def _kkt_backward(dl_dz, x, lams, nus, Q, A, lb, ub, flags=None, linsolve=1, want=None, sync=True):
     """flags: (any_lb, any_ub) when the caller knows them (the layer's forward saw them in the device's report).  With both
     true the whole backward is the library's (lqp_boxqp_backward_kkt: the reduced system on the fixed-point backward's
-    kernels, gradients formed in its epilogue); the one-sided and unbounded cases keep the composition below, including
-    the reference's bookkeeping of which half of dl_dh goes where (:565-584)."""
+    kernels, gradients formed in its epilogue); since round 5 the one-sided and unbounded cases too, with the reference's
+    bookkeeping of which half of dl_dh goes where (:565-584) applied to the kernel's outputs.  _KKT_NATIVE = False keeps
+    the composition below."""
     from .solve_qp_eqcon_torch import _kkt_solve
     _lib.require_gpu(dl_dz, x, lams, nus, Q, A, lb, ub)
     n = Q.shape[1]
     any_lb, any_ub = flags if flags is not None else _finite_bounds(lb, ub)
-    if any_lb and any_ub and _KKT_NATIVE:
+    if _KKT_NATIVE:
         lib = _lib.load()
         B = Q.shape[0]
         m = get_ncon(A, dim=1)
@@ -186,7 +187,13 @@ def _kkt_backward(dl_dz, x, lams, nus, Q, A, lb, ub, flags=None, linsolve=1, wan
         mk = lambda on, shape: torch.empty(shape, dtype=dty, device=dev) if on else None
         dQ, dp = mk(want['dQ'], (B, n, n)), mk(want['dp'], (B, n, 1))
         dA, db = mk(want['dA'] and m > 0, (B, m, n)), mk(want['db'] and m > 0, (B, m, 1))
-        dlb, dub = mk(want['dlb'], (B, n, 1)), mk(want['dub'], (B, n, 1))
+        # One-sided and unbounded batches run the same kernels (round 5): the reference keeps BOTH halves of G = [-I; I] whenever any
+        # bound is finite (:446-452), an infinite bound has an infinite slack, and lam / inf = 0 takes its rows out of the reduced
+        # system exactly.  Only the reference's bookkeeping of dl_dh differs (:573-584): lower bounds only -> dlb; upper bounds only
+        # -> dub = dl_dh[:n], the LOWER half (all zeros: its quirk, kept); no bounds -> neither.
+        only_lb, only_ub = any_lb and not any_ub, any_ub and not any_lb
+        dlb = mk((want['dlb'] and any_lb) or (want['dub'] and only_ub), (B, n, 1))
+        dub = mk(want['dub'] and any_lb and any_ub, (B, n, 1))
         stream = torch.cuda.current_stream(dev).cuda_stream
         ws = _lib.workspace(dev, lib.lqp_boxqp_backward_fp_workspace_bytes(dt, B, n, m), "bwd", stream)
         fail = ctypes.c_int32(-1)
@@ -207,6 +214,14 @@ def _kkt_backward(dl_dz, x, lams, nus, Q, A, lb, ub, flags=None, linsolve=1, wan
                 _lib.defer_check("SolveBoxQP.backward", dev, report, B, False)
             else:
                 _lib._pinned_free.setdefault(report.numel(), []).append(report)
+        if only_ub:
+            dlb, dub = None, (-dlb if want['dub'] else None)
+        elif only_lb:
+            dub = None
+            if not want['dlb']:
+                dlb = None
+        elif not any_lb:
+            dlb = dub = None
         return (dQ, dp, dA, db, dlb, dub, None)
     dlam = None
     Qw = Q

@@ -865,6 +865,39 @@ def test_g12_kkt_backward_mode(dev, monkeypatch, native):
     assert g1[4] is None and g1[5] is not None and all(torch.isfinite(t).all() for t in g1 if t is not None)
 
 
+@pytest.mark.parametrize("sides", ["ub", "lb", "none"])
+def test_kkt_backward_one_sided_native(dev, monkeypatch, sides):
+    """backward='kkt' with upper bounds only / lower bounds only / no bounds on the library's kernels (round 5; the reference keeps
+    both halves of G whenever a bound is finite, an infinite slack takes its rows out: lam / inf = 0) against the composition of
+    lqp_kkt_solve and torch ops that restates the reference (:435-584), including its bookkeeping quirk in the ub-only case."""
+    g = load_golden("g12_kkt_backward")
+    a = [g[k].to(dev) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    inf = torch.full_like(a[4], float("inf"))
+    lb = a[4] if sides == "lb" else -inf
+    ub = a[5] if sides == "ub" else inf
+    sol = L.torch_solve_box_qp(a[0], a[1], a[2], a[3], lb, ub, O.make_control(**TOL))
+    cot = g["cot"].to(dev)
+    out = {}
+    for native in (False, True):
+        monkeypatch.setattr(SB, "_KKT_NATIVE", native)
+        _lib.profile(enable=True, reset=True)
+        out[native] = L.torch_solve_box_qp_grad_kkt(cot, sol["x"], sol["lams"], sol["nus"], a[0], a[2], lb, ub)
+        used = _lib.profile(); _lib.profile(enable=False)
+        assert (used["bwd_epilogue"][1] == 1) == native, used
+    for i, (t0, t1) in enumerate(zip(out[False], out[True])):
+        assert (t0 is None) == (t1 is None), i
+        if t0 is not None:
+            assert err(t1, t0) < 1e-4 * max(1.0, float(t0.abs().max())), i
+    # ... and through the module (Cholesky form of the reduced system behind the symmetric forward)
+    monkeypatch.setattr(SB, "_KKT_NATIVE", True)
+    lv = [t.clone().requires_grad_(True) for t in (a[0], a[1], a[2], a[3])]
+    lbg, ubg = lb.clone().requires_grad_(sides == "lb"), ub.clone().requires_grad_(sides == "ub")
+    x = L.SolveBoxQP(control=L.box_qp_control(backward='kkt', **TOL))(lv[0], lv[1], lv[2], lv[3], lbg, ubg)
+    x.backward(cot)
+    for t, r in zip(lv, out[False][:4]):
+        assert err(t.grad, r) < 2e-4 * max(1.0, float(r.abs().max()))
+
+
 class _CpuLU(torch.nn.Module):
     """CPU stand-in for the taped solve of the unrolled loop (lqp_py/lu_layer.py:5-58 restated with torch.linalg): lets
     lqp_py_amd.unrolled._eager_unrolled run in float64 on the host as the truth of the same taped computation."""
