@@ -238,7 +238,7 @@ int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, i
     int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
     { ProfScope ps(st, PC_LU);
-      hipLaunchKernelGGL(fn, dim3(B), dim3(NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, g_lu_dbg, nvec); }
+      hipLaunchKernelGGL(fn, dim3(B), dim3(NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, knobs().dbg_setup ? nullptr : g_lu_dbg, nvec); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
@@ -275,7 +275,7 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
     const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
     { ProfScope ps(st, PC_LU);
       hipLaunchKernelGGL(fn, dim3(2 * B), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
-                         scr_stride, epoch, g_lu_dbg, B, knobs().xcd_local != 0 ? 1 : 0); }
+                         scr_stride, epoch, knobs().dbg_setup ? nullptr : g_lu_dbg, B, knobs().xcd_local != 0 ? 1 : 0); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
@@ -1250,7 +1250,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             // one refinement step: residual with the original entries (double accumulation), correction solve
             const int lds = (round_up(n, 8) + round_up(m > 0 ? m : 1, 8)) * (int)sizeof(T) + round_up(n, 8) * 4;
             { ProfScope ps(st, PC_BWD_BUILD);
-              hipLaunchKernelGGL(k_bwd_residual<T>, dim3(B), dim3(LQP_NT), lds, st, P); }
+              hipLaunchKernelGGL(k_bwd_residual<T>, dim3(B, (B <= 128 && knobs().split2) ? 2 : 1), dim3(LQP_NT), lds, st, P); }
             rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs2, 1, (size_t)P.Np, 1, 0, nvec);
             if (rc) return rc;
             P.refine = 1;

@@ -245,6 +245,78 @@ __device__ __forceinline__ T setup_scale(const T* __restrict__ Q, const int n, c
     return fro2;
 }
 
+// The same two passes for rows that are not 16-B pieces (n % 4 != 0, e.g. the hard distribution's n = 250): NC column groups
+// of 64 per lane, one element each, RIF rows in flight; unconditional loads at clamped columns as above.  (The plain loop
+// with a per-lane `if (j < n)` had one 512-B load in flight per wave: 64 MB in 33 us at n = 250 in float64.)
+template <typename T, int NC, int RIF>
+__device__ __forceinline__ void setup_colmax_s(const T* __restrict__ Q, const int n, T* __restrict__ red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nq = (n + 63) / 64;
+    T cm[NC];
+    int jq[NC]; bool okq[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { const int j = lane + 64 * q; okq[q] = j < n; jq[q] = okq[q] ? j : 0; cm[q] = T(0); }
+    for (int i0 = w; i0 < n; i0 += RIF * LQP_NW) {
+        T v[RIF][NC];
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr) {
+            const int i = i0 + rr * LQP_NW;
+            const T* qr = Q + (size_t)(i < n ? i : i0) * n;
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (q < nq) v[rr][q] = qr[jq[q]];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr)
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (q < nq) cm[q] = tmax(cm[q], okq[q] ? tabs(v[rr][q]) : T(0));
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+        if (okq[q]) red[(size_t)w * n + lane + 64 * q] = cm[q];
+}
+template <typename T, int NC, int RIF>
+__device__ __forceinline__ T setup_scale_s(const T* __restrict__ Q, const int n, const T* __restrict__ d, T* __restrict__ Qw,
+                                           const int ldq, T* __restrict__ Mw, const int Np, const bool with_m) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nq = (n + 63) / 64;
+    int jq[NC]; bool okq[NC]; T dj[NC];
+    T fro2 = T(0);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { const int j = lane + 64 * q; okq[q] = j < n; jq[q] = okq[q] ? j : 0; dj[q] = d[jq[q]]; }
+    for (int i0 = w; i0 < n; i0 += RIF * LQP_NW) {
+        T v[RIF][NC];
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr) {
+            const int i = i0 + rr * LQP_NW;
+            const T* qr = Q + (size_t)(i < n ? i : i0) * n;
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (q < nq) v[rr][q] = qr[jq[q]];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RIF; ++rr) {
+            const int i = i0 + rr * LQP_NW;
+            if (i < n) {
+                T* qo = Qw + (size_t)i * ldq;
+                T* mo = Mw + (size_t)i * Np;
+                const T di = d[i];
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    if (q < nq && okq[q]) {
+                        const T o = (di * v[rr][q]) * dj[q];
+                        fro2 += o * o;
+                        if (Qw) qo[jq[q]] = o;
+                        if (with_m) mo[jq[q]] = o;
+                    }
+                }
+            }
+        }
+    }
+    return fro2;
+}
+
 // scratch of k_spd_prep for problem b (the Qs area: unused while the scaled matrix is not stored):
 // [SPD_NP][64 Ks] column maxima | [SPD_NP] ints: symmetry verdicts
 template <typename T>
@@ -400,7 +472,14 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             nred = 1;
         } else if (qvec) {
             // (several workgroups per QP for this pass: no faster -- 128 MB in 38 us either way, the HBM rate)
-            setup_colmax<T, 4, sizeof(T) == 8 ? 1 : 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster; float64: 4 rows in flight = 128 VGPRs of loads, 315 spilled registers)
+            // (up to 256 columns: one 16-B piece per lane and row -- more rows in flight instead; float64 at n = 250 had ONE 2-KB row in
+            //  flight per wave: 64 MB in 33 us)
+            if (n <= 256) setup_colmax<T, 1, sizeof(T) == 8 ? 4 : 8>(Q, n, red);
+            else setup_colmax<T, 4, sizeof(T) == 8 ? 1 : 4>(Q, n, red);        // (8 rows in flight with 2 column quads: no faster; float64: 4 rows in flight = 128 VGPRs of loads, 315 spilled registers)
+        } else if (n <= 256) {
+            setup_colmax_s<T, 4, 4>(Q, n, red);
+        } else if (n <= 512) {
+            setup_colmax_s<T, 8, 2>(Q, n, red);
         } else {
             // (also the HBM-resident tier, 1024 < n <= 2048: two passes of 1024 columns, the 16 waves merging their maxima
             //  into setup_slabs(n) = 4 slabs in 4 rounds; up to 1024 columns: one pass, one slab per wave, no round trip)
@@ -447,7 +526,13 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
             // nothing to store here and the norm (when rho is derived from it) is taken by k_spd_begin / the resident
             // sweep: no second pass over Q
         } else if (qvec) {
-            fro2 += setup_scale<T, 4, sizeof(T) == 8 ? 1 : 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
+            // (every thread meets its elements in the same order whatever the shape of the pass: the norm keeps its bits)
+            if (n <= 256) fro2 += setup_scale<T, 1, sizeof(T) == 8 ? 4 : 8>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
+            else fro2 += setup_scale<T, 4, sizeof(T) == 8 ? 1 : 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
+        } else if (n <= 256) {
+            fro2 += setup_scale_s<T, 4, 4>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
+        } else if (n <= 512) {
+            fro2 += setup_scale_s<T, 8, 2>(Q, n, d, Qw, ldq, Mw, Np, !P.spd);
         } else {
             for (int i = w; i < n; i += LQP_NW) {
                 const T* qr = Q + (size_t)i * n;
@@ -499,7 +584,36 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     if (m > 0 && !defer) {
         const T* A = P.A + (size_t)b * m * n;
         const T* bb = P.b + (size_t)b * m;
-        if (P.scale) {
+        if (P.scale && m >= 4 && m <= 64 && setup_slabs(n) * n >= 64) {
+            // a row per wave (rows w, w + 16, ...), its norm a wave maximum, ONE barrier for the mean of the norms (a row per
+            // round of the whole workgroup was three barriers a row: 42 us at m = 16; kept below four rows, where a row on one wave is slower).  The maxima are exact and the mean adds
+            // them in row order as it always did: same bits.
+            T* rn = red;                                   // (the column maxima are done with)
+            for (int r = w; r < m; r += LQP_NW) {
+                T am = T(0);
+                for (int j = lane; j < n; j += 64) {
+                    const T v = ((r == 0 && j == tid) ? a0 : A[(size_t)r * n + j]) * d[j];
+                    am = tmax(am, tabs(v));
+                }
+                am = wave_max(am);
+                if (lane == 0) rn[r] = am;
+            }
+            __syncthreads();
+            T esum = T(0);
+            for (int r = 0; r < m; ++r) esum += rn[r];
+            const T floor_a = tmax(esum / T(m), T(1e-6));
+            for (int r = w; r < m; r += LQP_NW) {
+                T an = rn[r];
+                if (an <= T(0)) an = tmax(an, floor_a);
+                const T e = T(1) / an;
+                for (int j = lane; j < n; j += 64) {
+                    const T v = ((r == 0 && j == tid) ? a0 : A[(size_t)r * n + j]) * d[j];
+                    V.As[(size_t)r * n + j] = e * v;
+                }
+                if (lane == 0) { V.E[r] = e; V.bs[r] = e * bb[r]; }
+            }
+            __syncthreads();
+        } else if (P.scale) {
             T esum = T(0);
             for (int r = 0; r < m; ++r) {
                 T am = T(0);
@@ -2591,25 +2705,48 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_residual(const BwdParams<T> P) {
     __syncthreads();
     for (int a = tid; a < nf; a += LQP_NT) dvf[fl[a]] = d[a];
     __syncthreads();
-    for (int a = w; a < nf + m; a += LQP_NW) {
-        const bool eq = a >= nf;
-        const T* row = eq ? A + (size_t)(a - nf) * n : Q + (size_t)fl[a] * n;
-        double acc = 0.0;
-        for (int j = lane; j < n; j += 64) acc += (double)row[j] * (double)dvf[j];
-        acc = wave_sum(acc);
-        if (lane == 0) {
+    // gridDim.y == 2: two workgroups per problem, alternate groups of rows (at B <= 128 half the CUs are idle).  Four rows per
+    // wave at a time, their loads issued together (a row at a time was one memory round trip + reduction per row: 31 in sequence
+    // at n = 500); each row's terms are added in the order they always were.
+    constexpr int RG = 4;
+    const int ny = (int)gridDim.y, me = (int)blockIdx.y;
+    for (int a0 = (w * ny + me) * RG; a0 < nf + m; a0 += LQP_NW * ny * RG) {
+        const T* row[RG];
+        double acc[RG];
+#pragma unroll
+        for (int u = 0; u < RG; ++u) {
+            const int a = min(a0 + u, nf + m - 1);
+            row[u] = a >= nf ? A + (size_t)(a - nf) * n : Q + (size_t)fl[a] * n;
+            acc[u] = 0.0;
+        }
+        for (int j = lane; j < n; j += 64) {
+            const double dj = (double)dvf[j];
+            T v[RG];
+#pragma unroll
+            for (int u = 0; u < RG; ++u) v[u] = row[u][j];
+#pragma unroll
+            for (int u = 0; u < RG; ++u) acc[u] += (double)v[u] * dj;
+        }
+#pragma unroll
+        for (int u = 0; u < RG; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane < RG && a0 + lane < nf + m) {
+            const int a = a0 + lane;
+            double mine = readlane_t(acc[0], 0);          // (lane 0's sums: the bits the one-row form produced)
+#pragma unroll
+            for (int u = 1; u < RG; ++u) { const double t = readlane_t(acc[u], 0); mine = lane == u ? t : mine; }
             double res;
-            if (!eq) {
+            if (a < nf) {
                 const int i = fl[a];
-                res = -(double)g[i] - acc - 1e-8 * (double)d[a];
+                res = -(double)g[i] - mine - 1e-8 * (double)d[a];
                 for (int q = 0; q < m; ++q) res -= (double)A[(size_t)q * n + i] * (double)dn[q];
             } else {
-                res = -acc - 1e-8 * (double)dn[a - nf];
+                res = -mine - 1e-8 * (double)dn[a - nf];
             }
             r[a] = (T)res;
         }
     }
-    for (int a = nf + m + tid; a < Np; a += LQP_NT) r[a] = T(0);
+    if (me == 0)
+        for (int a = nf + m + tid; a < Np; a += LQP_NT) r[a] = T(0);
 }
 
 // solve with the packed factor (one rhs per problem, in global memory, in place)

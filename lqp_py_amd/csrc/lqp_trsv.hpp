@@ -74,17 +74,46 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
 
     // ---- off-diagonal blocks: straight copies with zero padding ----
     {
-        size_t s = 0;
-        for (int k = 0; doL && k < K; ++k) {
-            for (int j = 0; j < k; ++j, ++s)
-                *(vec*)(Lpk + s * LQP_BLK + tid * 4) = load_padded4(LU, N, ld, k * LQP_NB + row, j * LQP_NB + cq * 4, vec_ok);
-            ++s;   // diagonal slot, filled below
+        // (four blocks' loads before their stores, across block rows: one load in flight per thread left the copy at a block
+        //  per memory round trip)
+        if (doL) {
+            int k = 1, j = 0;
+            while (k < K) {
+                vec t[4];
+                long sl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sl[u] = -1;
+                    if (k < K) {
+                        t[u] = load_padded4(LU, N, ld, k * LQP_NB + row, j * LQP_NB + cq * 4, vec_ok);
+                        sl[u] = (long)k * (k + 1) / 2 + j;
+                        if (++j == k) { ++k; j = 0; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (sl[u] >= 0) *(vec*)(Lpk + (size_t)sl[u] * LQP_BLK + tid * 4) = t[u];
+            }
         }
-        s = 0;
-        for (int k = K - 1; doU && k >= 0; --k) {
-            for (int j = K - 1; j > k; --j, ++s)
-                *(vec*)(Upk + s * LQP_BLK + tid * 4) = load_padded4(LU, N, ld, k * LQP_NB + row, j * LQP_NB + cq * 4, vec_ok);
-            ++s;
+        if (doU) {
+            int k = K - 2, j = K - 1;
+            while (k >= 0) {
+                vec t[4];
+                long sl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sl[u] = -1;
+                    if (k >= 0) {
+                        const int kr = K - 1 - k;
+                        t[u] = load_padded4(LU, N, ld, k * LQP_NB + row, j * LQP_NB + cq * 4, vec_ok);
+                        sl[u] = (long)kr * (kr + 1) / 2 + (K - 1 - j);
+                        if (--j == k) { --k; j = K - 1; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (sl[u] >= 0) *(vec*)(Upk + (size_t)sl[u] * LQP_BLK + tid * 4) = t[u];
+            }
         }
     }
 
@@ -115,19 +144,26 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
             const T* Tk = Tb + g * LQP_BLK;
             const int c = lane;
             // Lane c carries column c of the inverse.  The substitution runs in chunks of 16 rows: the chunk's 16 entries
-            // live in registers, the entries of earlier chunks are read back from the destination block (this lane's own
-            // stores; L1 / L2).  (All 64 entries in registers -- 128 VGPRs in float64 -- spilled 435 registers in k_pack<double>:
-            // 0.2 ms per call at N = 266.)  
+            // live in registers; the entries of earlier chunks are read back from the destination block (this lane's own stores;
+            // L1 / L2: every term a memory round trip, 96 in sequence per block) -- or, when this workgroup packs ONE half of the
+            // factor (part != 0: the other triangle of the staged block is nobody's), from the staged block itself: row i of the
+            // factor is read for row i of the inverse only, so a finished chunk's rows are free and take the inverse's rows.
+            // (Stores under a per-lane condition, to keep the other triangle for a second wave: 339 / 944 spilled registers.  All
+            // 64 entries in registers -- 128 VGPRs in float64 -- spilled 435 registers in k_pack<double>: 0.2 ms per call at
+            // N = 266.)
+            const bool inplace = part != 0;
             constexpr int CH = 16;
             T* dst;
+            T* Tw = Tb + g * LQP_BLK;
             if (lower) {
                 dst = Lpk + ((size_t)kb * (kb + 1) / 2 + kb) * LQP_BLK;
                 for (int i0 = 0; i0 < LQP_NB; i0 += CH) {
                     T acc[CH];
 #pragma unroll
                     for (int r = 0; r < CH; ++r) acc[r] = (i0 + r == c) ? T(1) : T(0);
+#pragma unroll 2
                     for (int j = 0; j < i0; ++j) {
-                        const T xj = dst[j * LQP_NB + c];
+                        const T xj = inplace ? Tk[j * LQP_NB + c] : dst[j * LQP_NB + c];
 #pragma unroll
                         for (int r = 0; r < CH; ++r) acc[r] -= Tk[(i0 + r) * LQP_NB + j] * xj;
                     }
@@ -138,6 +174,10 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
                     }
 #pragma unroll
                     for (int r = 0; r < CH; ++r) dst[(i0 + r) * LQP_NB + c] = acc[r];
+                    if (inplace) {
+#pragma unroll
+                        for (int r = 0; r < CH; ++r) Tw[(i0 + r) * LQP_NB + c] = acc[r];
+                    }
                 }
             } else {
                 const int kr = K - 1 - kb;   // block rows the U phase visits before this one
@@ -146,8 +186,9 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
                     T acc[CH];
 #pragma unroll
                     for (int r = 0; r < CH; ++r) acc[r] = (i0 + r == c) ? T(1) : T(0);
+#pragma unroll 2
                     for (int j = LQP_NB - 1; j >= i0 + CH; --j) {
-                        const T xj = dst[j * LQP_NB + c];
+                        const T xj = inplace ? Tk[j * LQP_NB + c] : dst[j * LQP_NB + c];
 #pragma unroll
                         for (int r = 0; r < CH; ++r) acc[r] -= Tk[(i0 + r) * LQP_NB + j] * xj;
                     }
@@ -159,23 +200,33 @@ __device__ __forceinline__ void wg_pack_factor(const T* __restrict__ LU, const i
                     }
 #pragma unroll
                     for (int r = 0; r < CH; ++r) dst[(i0 + r) * LQP_NB + c] = acc[r];
+                    if (inplace) {
+#pragma unroll
+                        for (int r = 0; r < CH; ++r) Tw[(i0 + r) * LQP_NB + c] = acc[r];
+                    }
                 }
             }
         }
     }
 
     // ---- destination of each rhs row under the LAPACK interchanges ----
+    // (the interchanges through LDS: read from global memory one by one, N scalar loads in sequence were 40 us at N = 501)
     const int Np = K * LQP_NB;
-    for (int r = tid; doL && r < Np; r += LQP_NT) {
-        int pos = r;
-        if (r < N) {
-            for (int i = 0; i < N; ++i) {
-                const int pi = ipiv[i] - 1;
-                if (pos == i) pos = pi;
-                else if (pos == pi) pos = i;
+    if (doL) {
+        int* pv = (int*)smem;
+        __syncthreads();                               // (the staged diagonal blocks are done with)
+        for (int i = tid; i < N; i += LQP_NT) pv[i] = ipiv[i] - 1;
+        __syncthreads();
+        for (int r = tid; r < Np; r += LQP_NT) {
+            int pos = r;
+            if (r < N) {
+                for (int i = 0; i < N; ++i) {
+                    const int pi = pv[i];
+                    pos = pos == i ? pi : (pos == pi ? i : pos);
+                }
             }
+            dest[r] = pos;
         }
-        dest[r] = pos;
     }
 }
 

@@ -1,26 +1,28 @@
 #!/usr/bin/env python3
-"""In-kernel cycle breakdown of k_fwd_setup (debug counters of thread 0)."""
+"""Cycles of k_fwd_setup's phases (LQP_DBG_SETUP=1: stamps of thread 0 per problem): [lu|hard64]"""
 import os, sys
-os.environ.setdefault("LQP_ENV_NOCACHE", "1")      # (this tool flips library knobs between solves)
+os.environ["LQP_DBG_SETUP"] = "1"
+os.environ.setdefault("LQP_ENV_NOCACHE", "1")
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lqp_py_amd as L
 from lqp_py_amd import _lib
-from lqp_py_amd.synthetic import create_qp_data
+from lqp_py_amd.synthetic import create_hard_qp_data
+from tools.profile_workload import device_batch
 dev = torch.device("cuda:0")
-os.environ["LQP_DBG_SETUP"] = "1"          # only the setup kernel writes the debug words
+which = sys.argv[1] if len(sys.argv) > 1 else "lu"
+if which == "hard64":
+    data = create_hard_qp_data(250, 0.85, range(128), dtype=torch.float64, device=dev); extra = {}
+else:
+    data = device_batch(dev, 128, 500, 0); extra = {"linsolve": "lu"}
+B = data[0].shape[0]
+layer = L.SolveBoxQP(control=dict(L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5), **extra))
 lib = _lib.load()
-B, n = 128, 500
-inp = [t.to(dev) for t in create_qp_data(n, B, seed=0)]
-ctl = L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5, max_iters=1)
-dbg = torch.zeros(B * 8, dtype=torch.int64, device=dev)
-L.torch_solve_box_qp(*inp, dict(ctl))
+layer(*data); torch.cuda.synchronize()
+dbg = torch.zeros(B * 16, dtype=torch.int64, device=dev)
 lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
-L.torch_solve_box_qp(*inp, dict(ctl))
-torch.cuda.synchronize()
+layer(*data); torch.cuda.synchronize()
 lib.lqp_debug_set_lu_counters(None)
-c = dbg.view(B, 8).double().mean(0)
-names = ["zero xchg, |p|", "column maxima (reads Q)", "D", "quantiles / beta", "scaling pass", "rho, eq block", "bounds, state"]
-for nm, v in zip(names, c.tolist()):
-    print("%-28s %9.0f cycles" % (nm, v))
+c = dbg[:B * 8].view(B, 8).double()
+names = ["zeroes+small loads", "column maxima", "scaling vector", "store D", "scale pass (Qs, M)", "equality block", "bounds/state", "-"]
+print(which, " ".join(f"[{n}] {v/1e3:.1f}k" for n, v in zip(names, c.mean(0).tolist())), f"| sum {c[:, :7].sum(1).mean()/1e3:.1f}k cycles")
