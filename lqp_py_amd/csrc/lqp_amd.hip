@@ -541,7 +541,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd = spd && spd_factor_lds_bytes(m, P.Ks) <= 160 * 1024 && sym_loop_lds_bytes(n, m, P.Ks, 0) <= 160 * 1024;
     }
     P.spd = spd ? 1 : 0;
-    P.qs_lazy = (spd && knobs().qs_lazy) ? 1 : 0;
+    // (the LU path too: its refactorisations form (D Q) D again from Q and the scaling vector -- assemble_kkt_rows -- instead of
+    //  reading a stored copy the setup kernel would have to write: 128 MB per batch at n = 500)
+    P.qs_lazy = knobs().qs_lazy ? 1 : 0;
     P.ar_iter = ar_iter; P.ar_max = ctl->adaptive_rho_max_iter; P.ring = kRing;
 
     // symmetric path with fewer problems than half the CUs: share each matrix between SPD_NP workgroups

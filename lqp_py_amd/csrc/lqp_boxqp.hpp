@@ -112,29 +112,39 @@ template <typename T> __host__ __device__ inline int setup_lds_bytes(int n) {
 // rho is added on the diagonal.
 template <typename T>
 __device__ __forceinline__ void assemble_kkt_rows(const FwdParams<T>& P, const int b, const T* __restrict__ Qs, const int ldq,
-                                                  const VecView<T>& V, const T rho, const bool copy_q) {
+                                                  const VecView<T>& V, const T rho, const bool copy_q,
+                                                  const T* __restrict__ dsc = nullptr) {
+    // dsc != nullptr: `Qs` is the UNSCALED matrix and dsc the scaling vector (FwdParams::qs_lazy on the LU path: the scaled matrix
+    // is not kept for the refactorisations, they form (D_i Q_ij) D_j again -- the expression of the setup pass, the same bits)
     const int n = P.n, m = P.m, Np = P.Np;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     T* M = P.M + (size_t)b * Np * Np;
     typedef V4<T> vec;
-    const bool vec_ok = (ldq % 4 == 0) && ((((uintptr_t)Qs) % sizeof(vec)) == 0);
+    const bool vec_ok = (ldq % 4 == 0) && ((((uintptr_t)Qs) % sizeof(vec)) == 0) && (n % 4 == 0 || dsc == nullptr);
     if (copy_q) {
         for (int i = w; i < n; i += LQP_NW) {
             const T* q = Qs + (size_t)i * ldq;
             T* mr = M + (size_t)i * Np;
+            const T di = dsc ? dsc[i] : T(1);
             if (vec_ok) {
                 for (int j = lane * 4; j < n; j += 256) {
                     if (j + 3 < n) {
                         vec v = *(const vec*)(q + j);
+                        if (dsc) {
+                            const vec dj = *(const vec*)(dsc + j);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v.v[e] = (di * v.v[e]) * dj.v[e];
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) if (j + e == i) v.v[e] += rho;
                         *(vec*)(mr + j) = v;
                     } else {
-                        for (int e = 0; e < 4 && j + e < n; ++e) mr[j + e] = q[j + e] + (i == j + e ? rho : T(0));
+                        for (int e = 0; e < 4 && j + e < n; ++e)
+                            mr[j + e] = (dsc ? (di * q[j + e]) * dsc[j + e] : q[j + e]) + (i == j + e ? rho : T(0));
                     }
                 }
             } else {
-                for (int j = lane; j < n; j += 64) mr[j] = q[j] + (i == j ? rho : T(0));
+                for (int j = lane; j < n; j += 64) mr[j] = (dsc ? (di * q[j]) * dsc[j] : q[j]) + (i == j ? rho : T(0));
             }
         }
     } else {
@@ -1348,8 +1358,9 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
                     __syncthreads();
                     if (tid == 0) scal[SC_RHO] = rho_;
                     if (b == 0 && tid == 0) { P.status[ST_NFACTOR] += 1; P.status[ST_RHO_UPDATED] = 1; }
-                    const T* Qs_ = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
-                    assemble_kkt_rows(P, b, Qs_, P.scale ? P.ldq : n, V, rho_, true);
+                    const bool lazy_ = P.scale && P.qs_lazy;
+                    const T* Qs_ = (P.scale && !lazy_) ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
+                    assemble_kkt_rows(P, b, Qs_, (P.scale && !lazy_) ? P.ldq : n, V, rho_, true, lazy_ ? V.D : nullptr);
                     __syncthreads();
                     wg_lu_factor<T, kPB, sizeof(T) == 4, NT>(P.M + (size_t)b * Np * Np, N, Np, P.piv + (size_t)b * Np,
                                                                 P.info + b, smem, nullptr);
@@ -2291,8 +2302,9 @@ __global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, con
     __syncthreads();
     if (threadIdx.x == 0) scal[SC_RHO] = rho;
     if (P.spd) return;
-    const T* Qs = P.scale ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
-    assemble_kkt_rows(P, b, Qs, P.scale ? P.ldq : n, V, rho, true);
+    const bool lazy = P.scale && P.qs_lazy;
+    const T* Qs = (P.scale && !lazy) ? (P.Qs + (size_t)b * n * P.ldq) : (P.Q + (size_t)b * n * n);
+    assemble_kkt_rows(P, b, Qs, (P.scale && !lazy) ? P.ldq : n, V, rho, true, lazy ? V.D : nullptr);
 }
 
 // primal / dual error of the last convergence check, per problem (lqp_boxqp_last_residuals)
@@ -2461,18 +2473,38 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
     __syncthreads();
     // ---- reduced matrix and right-hand side (rows interleaved over the gridDim.y workgroups) ----
     const int wy = blockIdx.y, ny = gridDim.y;
-    for (int a = w * ny + wy; a < nf; a += LQP_NW * ny) {
-        const int i = fl[a];
-        const T* qr = Q + (size_t)i * n;
-        T* mr = M + (size_t)a * Np;
-        const T dg = P.kkt ? kkt_weight(P, b, i) : T(1e-8);
-        for (int c = lane; c < nf; c += 64) {
-            T val = qr[fl[c]];
-            if (c == a) val = val + dg;
-            mr[c] = val;
+    // (two rows per wave at a time, eight gathers of each in flight before the first store -- clamped indices, no guarded load:
+    //  one gather, its wait and its store per trip were ~5 memory round trips per row, 56 us at n = 500)
+    constexpr int GQ = 8;
+    for (int a0 = (w * ny + wy) * 2; a0 < nf; a0 += LQP_NW * ny * 2) {
+        const int a1 = a0 + 1 < nf ? a0 + 1 : a0;
+        const int i0 = fl[a0], i1 = fl[a1];
+        const T* q0 = Q + (size_t)i0 * n;
+        const T* q1 = Q + (size_t)i1 * n;
+        const T dg0 = P.kkt ? kkt_weight(P, b, i0) : T(1e-8), dg1 = P.kkt ? kkt_weight(P, b, i1) : T(1e-8);
+        for (int c0 = 0; c0 < nf; c0 += 64 * GQ) {
+            T v0[GQ], v1[GQ];
+#pragma unroll
+            for (int q = 0; q < GQ; ++q) {
+                const int c = c0 + lane + 64 * q;
+                const int col = fl[c < nf ? c : nf - 1];
+                v0[q] = q0[col];
+                v1[q] = q1[col];
+            }
+#pragma unroll
+            for (int q = 0; q < GQ; ++q) {
+                const int c = c0 + lane + 64 * q;
+                if (c < nf) {
+                    M[(size_t)a0 * Np + c] = c == a0 ? v0[q] + dg0 : v0[q];
+                    if (a1 != a0) M[(size_t)a1 * Np + c] = c == a1 ? v1[q] + dg1 : v1[q];
+                }
+            }
         }
-        for (int r = lane; r < m; r += 64) mr[nf + r] = A[(size_t)r * n + i];
-        if (lane == 0) rhs[a] = -g[i];
+        for (int r = lane; r < m; r += 64) {
+            M[(size_t)a0 * Np + nf + r] = A[(size_t)r * n + i0];
+            if (a1 != a0) M[(size_t)a1 * Np + nf + r] = A[(size_t)r * n + i1];
+        }
+        if (lane == 0) { rhs[a0] = -g[i0]; if (a1 != a0) rhs[a1] = -g[i1]; }
     }
     for (int r = w * ny + wy; r < m; r += LQP_NW * ny) {
         T* mr = M + (size_t)(nf + r) * Np;
