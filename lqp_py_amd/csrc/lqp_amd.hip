@@ -498,7 +498,10 @@ template <typename T>
 int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void* p, const void* A, const void* b,
                  const void* lb, const void* ub, const lqp_boxqp_ctrl* ctl, const void* rho_in, void* x, void* z,
                  void* u, void* lams, void* nus, void* rho_out, lqp_boxqp_stats* stats, void* ws, size_t ws_bytes,
-                 const bool force_lu = false) {
+                 const int retry = 0) {
+    // retry: bit 0 -- the symmetric x-update gave the solve up (not symmetric / not positive definite in f32): pivoted LU;
+    //        bit 1 -- a pair of the turn-taking two-workgroup loop (split_seg) waited for its partner in vain: the one-workgroup loop
+    const bool force_lu = (retry & 1) != 0;
     FwdLayout<T> L = carve_forward<T>(ws, B, n, m);
     if (ws_bytes < L.bytes) return LQP_ERR_WORKSPACE;
     FwdParams<T>& P = L.P;
@@ -814,7 +817,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     bool loop_split_seg = false;
     if constexpr (sizeof(T) == 4) {
         if (spd && mode == 1 && !loop_split && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 &&
-            knobs().loop_split != 0 && knobs().loop_split_seg != 0) {
+            knobs().loop_split != 0 && knobs().loop_split_seg != 0 && !(retry & 2)) {
             int dev = 0, cus = 0, per_cu = 0;
             split_nt = 512;
             split_lds = split_loop_lds_bytes<512>(P.Ks, m);
@@ -995,7 +998,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             rc = collect_report(st, rep, rep == P.host_report, B, max_iters, check, so);
             if (rc == LQP_RETRY_LU)         // Qs + rho I not positive definite in f32 (first factorisation or an
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
-                                       ws, ws_bytes, true);     // adaptive-rho one): the LU path takes the solve
+                                       ws, ws_bytes, retry | 1);     // adaptive-rho one): the LU path takes the solve
             return rc;
         }
     }
@@ -1120,7 +1123,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             rc = after_factorisation();
             if (rc == -1)       // Qs + rho I not positive definite in f32 (on some rank): the LU path takes it
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
-                                       ws, ws_bytes, true);
+                                       ws, ws_bytes, retry | 1);
             if (rc) return rc;
         } else {
             { const int r4 = fetch_status(); if (r4) return r4; }
@@ -1128,12 +1131,21 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 rc = after_factorisation();
                 if (rc == -1)
                     return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
-                                           ws, ws_bytes, true);
+                                           ws, ws_bytes, retry | 1);
                 if (rc) return rc;
             }
         }
         nfactor_seen = h_status[ST_NFACTOR];
-        if (h_status[ST_TIMEOUT]) return LQP_ERR_TIMEOUT;
+        if (h_status[ST_TIMEOUT]) {
+            // The pairs of the turn-taking loop become resident together only while the dispatcher hands workgroups out in
+            // blockIdx order onto an otherwise idle chip; when something else holds CUs (another stream, RCCL kernels) a pair can
+            // wait for a partner that is not resident.  Its spin is bounded (0.5 s), the kernels drain, and the solve is run again
+            // from its setup on the loop that needs nobody (degrade, do not fail).
+            if (loop_split_seg && !(retry & 2))
+                return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes,
+                                       retry | 2);
+            return LQP_ERR_TIMEOUT;
+        }
         done = h_status[ST_DONE] != 0;
         chunk_cap = std::min(chunk_cap * 2, 64);
     }

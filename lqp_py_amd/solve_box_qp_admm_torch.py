@@ -603,6 +603,26 @@ def last_forward_status(device):
     return st
 
 
+class _Prepared(dict):
+    """What _fp_backward_prepare hands to _fp_backward_run.  A forward that is never followed by its backward (validation with
+    grad enabled, an exception, a retry on the other schedule) drops it: the pinned report buffer then goes back to the pool
+    instead of leaking one buffer per call.  Nothing writes that buffer before the run (the prefactor phase reports
+    nothing: include/lqp_amd.h, lqp_boxqp_backward_fp_prefactor)."""
+
+    def __del__(self):
+        try:
+            rep = self.get('report')
+            if rep is not None and not self.get('ran'):
+                _lib._pinned_free.setdefault(rep.numel(), []).append(rep)
+        except Exception:
+            pass
+
+
+# dQ of a prepared backward is allocated up front (in the window where the host only waits for the forward) up to this many
+# bytes; above, at `backward` itself: a forward without a backward would hold it for nothing -- 1 GB at B = 1024, n = 500
+_PREPARE_DQ_MAX_BYTES = 256 << 20
+
+
 def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, linsolve=1, prefactor=False):
     """Everything of the fixed-point backward that does not need the cotangent: output tensors, workspace, report buffer,
     the argument list of lqp_boxqp_backward_fp.  A synchronous layer call runs this WHILE its forward is on the GPU (the host
@@ -618,7 +638,8 @@ def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, li
     rho_mode, rho_value, rho_tensor = _rho_argument(rho, B, x)
     xc, uc, lc, nc, Qc, Ac, lbc, ubc = (_lib.norm(t, dty) for t in (x, u, lams, nus, Q, A, lb, ub))
     mk = lambda on, shape: torch.empty(shape, dtype=dty, device=dev) if on else None
-    dQ = mk(want['dQ'], (B, n, n))
+    late_dQ = bool(want['dQ']) and prefactor and B * n * n * x.element_size() > _PREPARE_DQ_MAX_BYTES
+    dQ = None if late_dQ else mk(want['dQ'], (B, n, n))
     dp = mk(want['dp'], (B, n, 1))
     dA = mk(want['dA'] and m > 0, (B, m, n))
     db = mk(want['db'] and m > 0, (B, m, 1))
@@ -647,8 +668,9 @@ def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, li
             pref = _lib.workspace_uses(dev, "bwd", stream)      # (still ours at `backward` if nobody asked for the buffer since)
         elif st != 6:
             _lib.check(st, "torch_solve_box_qp_grad (prefactor)")
-    return dict(lib=lib, head=head, tail=tail, keep=keep, grads=(dQ, dp, dA, db, dlb, dub, None), fail=fail, report=report,
-                dev=dev, dty=dty, B=B, sync=sync, linsolve=int(linsolve), rep=rep, pref=pref, stream=stream)
+    return _Prepared(lib=lib, head=head, tail=tail, keep=keep, grads=(dQ, dp, dA, db, dlb, dub, None), fail=fail, report=report,
+                     dev=dev, dty=dty, B=B, sync=sync, linsolve=int(linsolve), rep=rep, pref=pref, stream=stream,
+                     late_dQ=(B, n) if late_dQ else None)
 
 
 def _fp_backward_run(prep, dl_dz):
@@ -662,8 +684,15 @@ def _fp_backward_run(prep, dl_dz):
     # solve phase its right-hand sides.  Whoever prefactored into the same buffer earlier (forward A, forward B, backward A,
     # backward B: B's factor is overwritten by A's full run) must see the count move and run in full too.
     _lib.workspace_touch(dev, "bwd", prep['stream'])
+    tail = prep['tail']
+    if prep.get('late_dQ'):
+        Bq, nq = prep['late_dQ']
+        dQ = torch.empty((Bq, nq, nq), dtype=prep['dty'], device=dev)
+        prep['grads'] = (dQ,) + tuple(prep['grads'][1:])
+        tail = tail[:11] + (_lib.ptr(dQ),) + tail[12:]                 # (the slot of dQ in lqp_boxqp_backward_fp's argument list)
+    prep['ran'] = True                                                 # (the report buffer is this run's to hand back from here on)
     with _lib.on_device(dev):
-        st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *prep['tail'], linsolve, prep['rep'])
+        st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *tail, linsolve, prep['rep'])
     if st == 3:
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {prep['fail'].value})")
     _lib.check(st, "torch_solve_box_qp_grad")

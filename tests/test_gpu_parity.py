@@ -668,6 +668,37 @@ def test_prefactored_backwards_in_forward_order(dev, monkeypatch):
             assert torch.equal(t.grad, w)
 
 
+def test_prepared_backward_that_never_runs_and_late_gradient(dev, monkeypatch):
+    """A forward with grad enabled prepares its backward (outputs, pinned report buffer, factorisation).  Dropped without a
+    backward, the report buffer goes back to the pool (one leaked pinned buffer per such call); and above
+    _PREPARE_DQ_MAX_BYTES the large gradient is allocated by `backward` itself -- same numbers either way."""
+    import gc
+    n, B = 96, 8
+    d = O.create_qp_data(n, B, seed=21)
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(6)).to(dev)
+    layer = L.SolveBoxQP(control=L.box_qp_control(**TOL))
+
+    def grads(limit):
+        monkeypatch.setattr(SB, "_PREPARE_DQ_MAX_BYTES", limit)
+        lv = [t.clone().to(dev).requires_grad_(True) for t in d]
+        layer(*lv).backward(cot)
+        torch.cuda.synchronize()
+        return [t.grad for t in lv]
+
+    early, late = grads(1 << 40), grads(0)
+    for a, b_ in zip(early, late):
+        assert torch.equal(a, b_)
+    monkeypatch.setattr(SB, "_PREPARE_DQ_MAX_BYTES", 1 << 40)
+    pool = lambda: sum(len(v) for k, v in _lib._pinned_free.items() if k == B)
+    lv = [t.clone().to(dev).requires_grad_(True) for t in d]
+    x = layer(*lv)
+    torch.cuda.synchronize()
+    before = pool()
+    del x, lv
+    gc.collect()
+    assert pool() == before + 1, (before, pool())
+
+
 def test_backward_factorisation_ahead_of_the_cotangent_falls_back(dev):
     """... and on the C ABI: prefactor + solve-only call == one call; a factorisation that failed ends in the LU retry."""
     lib = _lib.load()
