@@ -290,6 +290,61 @@ def test_adaptive_rho_refactorises_in_float64(dev, tag, sync):
     assert err(sol["rho"], ref["rho"]) < 1e-9 * float(ref["rho"].abs().max())
 
 
+def _dense_case(name):
+    """inputs (CPU), control extras, dtype of the dense-tier A/B cases"""
+    from lqp_py_amd.synthetic import create_hard_qp_data
+    if name == "hard_f64":                     # experiments/experiment_1_hard.py's distribution, a small batch of it
+        return create_hard_qp_data(250, 0.85, range(6), dtype=torch.float64), {}
+    if name == "box_only_f64":
+        Q, p, A, b, lb, ub = O.create_qp_data(100, 5, seed=31)
+        return tuple(t.double() for t in (Q, p)) + (None, None) + tuple(t.double() for t in (lb, ub)), {}
+    if name == "largest_f64":                  # n = 256: every register column of the loop in use
+        Q, p, A, b, lb, ub = O.create_qp_data(256, 3, seed=32)
+        A8 = torch.randn(3, 8, 256, generator=torch.Generator().manual_seed(33))
+        x0 = 0.5 * (lb + ub)
+        return tuple(t.double() for t in (Q, p, A8, A8 @ x0, lb, ub)), {}
+    if name == "lu_f32_ragged":                # control['linsolve'] = 'lu' in float32, n % 4 != 0, three equality rows
+        Q, p, A, b, lb, ub = O.create_qp_data(37, 7, seed=34)
+        A3 = torch.randn(7, 3, 37, generator=torch.Generator().manual_seed(35))
+        x0 = 0.5 * (lb + ub)
+        return (Q, p, A3, A3 @ x0, lb, ub), {"linsolve": "lu"}
+    if name == "nonsymmetric_f64":             # what only the pivoted LU takes: Q + a skew part (x^T S x = 0: the same QP value)
+        Q, p, A, b, lb, ub = O.create_qp_data(64, 4, seed=36)
+        S = torch.randn(4, 64, 64, generator=torch.Generator().manual_seed(37))
+        return tuple(t.double() for t in (Q + 0.05 * (S - S.transpose(1, 2)), p, A, b, lb, ub)), {}
+    if name == "one_sided_f64":
+        Q, p, A, b, lb, ub = O.create_qp_data(90, 4, seed=38)
+        return tuple(t.double() for t in (Q, p, A, b, torch.full_like(lb, -float("inf")), ub)), {}
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["hard_f64", "box_only_f64", "largest_f64", "lu_f32_ragged", "nonsymmetric_f64", "one_sided_f64"])
+def test_dense_loop_matches_cached_lu_loop(dev, monkeypatch, name):
+    """csrc/lqp_dense.hpp: the LU path's loop with the explicit inverse in the registers of two workgroups (n <= 256) against the
+    same solve on the cached triangular solves (LQP_LOOP_DENSE=0) and against the CPU oracle: the same iteration count, iterates
+    to rounding.  The dense form is the one that ran (two loop workgroups per problem in the device's report)."""
+    inp, extra = _dense_case(name)
+    f64 = inp[0].dtype == torch.float64
+    ctl = dict(O.make_control(**TOL), **extra)
+    ref = O.solve_box_qp(*inp, O.make_control(**TOL))
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_LOOP_DENSE", flag)
+        sol, _ = solve(dev, inp, ctl)
+        st = sol["_stats"]
+        assert st["linsolve_used"] == 1 and st["loop_workgroups"] == (2 if flag == "1" else 1), (flag, st)
+        out[flag] = sol
+    a, b_ = out["1"], out["0"]
+    assert a["iter"] == b_["iter"] == ref["iter"], (a["iter"], b_["iter"], ref["iter"])
+    tol = 1e-9 if f64 else 2e-5
+    for k in ("x", "z", "u", "lams", "nus"):
+        if ref[k] is None:
+            continue
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert err(a[k], b_[k]) < tol * scale, (k, err(a[k], b_[k]))
+        assert err(a[k], ref[k]) < tol * scale, (k, err(a[k], ref[k]))
+
+
 @pytest.mark.parametrize("linsolve,mode", [("lu", 2), ("spd", 2), ("spd", 1)])
 @pytest.mark.parametrize("tag", ["noscale", "scale"])
 def test_g6_adaptive_rho_refactorises(dev, tag, linsolve, mode):
