@@ -570,10 +570,10 @@ def main():
                                         profile=profile_twin("b32"))
         more["b16_n500_fwd_bwd"] = dict(fwd_bwd_rate(piped(), device_batch(16, n, 76), 20, warm=5), is_shard_of="batch=128 at 8 GPUs",
                                         profile=profile_twin("b16"))
-        more["b1024_n500_fwd_bwd_config5_shard"] = dict(fwd_bwd_rate(piped(), device_batch(1024, n, 78), 3, warm=1),
+        more["b1024_n500_fwd_bwd_config5_shard"] = dict(fwd_bwd_rate(piped(), device_batch(1024, n, 78), 5, warm=2),
                                                         profile=profile_twin("config5shard"))
         b128 = device_batch(B, n, 79)
-        more["b128_n500_backward_kkt"] = fwd_bwd_rate(piped(backward='kkt'), b128, 3, warm=1)
+        more["b128_n500_backward_kkt"] = fwd_bwd_rate(piped(backward='kkt'), b128, 10, warm=3)
         more["b128_n500_unroll"] = fwd_bwd_rate(L.SolveBoxQP(control=L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, unroll=True)),
                                                 b128, 2, warm=1)
         del b128
@@ -581,7 +581,7 @@ def main():
         more["b8_n1500_fwd_bwd_lu_tier"] = fwd_bwd_rate(piped(), device_batch(8, 1500, 80), 2, warm=1)
         from lqp_py_amd.synthetic import create_hard_qp_data
         hard = create_hard_qp_data(250, 0.85, range(B), dtype=torch.float64, device=dev)      # prob 0.85 (experiment_1_hard.py:15), m = round(sqrt(250)) = 16
-        more["b128_n250_m16_hard_fp64"] = dict(fwd_bwd_rate(piped(), hard, 3, warm=1), dtype="f64", linsolve="lu (pivoted LU: f64)",
+        more["b128_n250_m16_hard_fp64"] = dict(fwd_bwd_rate(piped(), hard, 20, warm=5), dtype="f64", linsolve="lu (pivoted LU: f64)",
                                                profile=profile_twin("hard64"))
         del hard
         out["other_workloads_fwd_bwd"] = more
