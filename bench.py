@@ -575,7 +575,7 @@ def main():
         b128 = device_batch(B, n, 79)
         more["b128_n500_backward_kkt"] = fwd_bwd_rate(piped(backward='kkt'), b128, 10, warm=3)
         more["b128_n500_unroll"] = fwd_bwd_rate(L.SolveBoxQP(control=L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, unroll=True)),
-                                                b128, 2, warm=1)
+                                                b128, 10, warm=3)
         del b128
         # above the on-chip tiers (n + m > 1024: pivoted LU with two panel rows per thread, factor streamed from HBM / L2)
         more["b8_n1500_fwd_bwd_lu_tier"] = fwd_bwd_rate(piped(), device_batch(8, 1500, 80), 2, warm=1)

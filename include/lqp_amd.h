@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 9
+#define LQP_ABI_VERSION 10
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -213,6 +213,36 @@ size_t lqp_boxqp_unroll_backward_workspace_bytes(int B, int n, int m, int iters)
 int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
                               int iters, const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs,
                               void* dubs, void* drho, void* dD, void* scratch, size_t scratch_bytes);
+
+/* The scaling (solve_box_qp_admm_torch.py:160-203) behind the unrolled loop (ABI 10): what of its derivative walks over the
+ * (B,n,n) tensors, one pass each; the reference lets autograd tape these as torch ops (:163 column maxima of |Q| --
+ * torch.linalg.norm(ord=inf, dim=1) --, :176 Qs = D Q D, :201 ||Qs||_F and their backward nodes: ~25 passes over Q-sized
+ * tensors), and the n-sized rest of the chain (quantiles / beta :169-175, equality rows :179-190, bounds :192-194) in one
+ * kernel.  float32; Q (B,n,n) row-major; d (B,n) the scaling vector or NULL (scale = False).
+ *   colmax   colmax_j = max_i |Q_ij| (B,n) float, argmax (B,n) int32 = the first row attaining it, count (B,n) int32 = how many do
+ *   grad     G (B,n,n) in: dL/dQs (lqp_boxqp_unroll_backward's dQs); out: D (G + s D Q D) D with s (B) = dL/d||Qs||_F / ||Qs||_F
+ *            (||Qs||_F = rho sqrt(n) of the forward where :201-203 did not clamp, else the term is zero) or NULL = 0;
+ *            parts (B, 1 + slabs, n): [0] r_i = sum_j T_ij Q_ij d_j, [1 + y] the share of row slab y in c_j = sum_i T_ij d_i Q_ij,
+ *            T = G + s D Q D: dL/dd through Qs is parts.sum(1); slabs = lqp_unroll_scale_grad_slabs(B, n)
+ *   scatter  G_ij += g_colmax_j sign(Q_ij) / count_j wherever |Q_ij| = colmax_j (amax shares its gradient between ties)   */
+int lqp_unroll_scale_colmax(void* stream, int B, int n, const void* Q, void* colmax, void* argmax, void* count);
+int lqp_unroll_scale_grad_slabs(int B, int n);
+int lqp_unroll_scale_grad(void* stream, int B, int n, const void* Q, const void* d, const void* s, void* G, void* parts, int slabs);
+/*   vectors  the n-sized rest of the chain for scale = True, one workgroup per problem.  phase 0: d_out (B,n) = the scaling vector from
+ *            colmax (floor :164-168, d0 = colmax^-1/2, beta = 1 - q10(d0) / q90(d0) with torch.quantile's interpolation unless
+ *            beta_given, d = (1 - beta) d0 + beta mean(d0), :169-175).  phase 1: its backward and that of ps = d p, As = E (A d),
+ *            bs = E b (E = 1 / row maxima of |A d|, floored, :179-190), lbs = lb / d, ubs = ub / d (has_box, :192-194): from the
+ *            upstream gradients g_ps (B,n), g_As (B,m,n), g_bs (B,m), g_lbs, g_ubs, g_D (B,n) (any may be NULL = 0) and `parts`
+ *            (B,nparts,n; summed over nparts: dL/dd through Qs, from `grad`) to dp, dA, db, dlb, dub (NULL = skip) and g_colmax (B,n),
+ *            node by node as autograd takes it (amax shares its gradient between ties, the quantile passes it to its two
+ *            neighbours); an infinite bound contributes nothing (0 * inf taken as 0).  n <= ~8000 (LDS), float32.            */
+int lqp_unroll_scale_vectors(void* stream, int B, int n, int m, int phase, int has_box, int beta_given, double beta_value,
+                             const void* colmax, const void* p, const void* A, const void* b, const void* lb, const void* ub,
+                             const void* g_ps, const void* g_As, const void* g_bs, const void* g_lbs, const void* g_ubs, const void* g_D,
+                             const void* parts, int nparts, void* d_out, void* dp, void* dA, void* db, void* dlb, void* dub,
+                             void* g_colmax);
+int lqp_unroll_scale_scatter(void* stream, int B, int n, const void* Q, const void* colmax, const void* argmax, const void* count,
+                             const void* g_colmax, void* G);
 
 /* Primal / dual error (inf-norms of D r and D s, :287-288) of the LAST convergence check of the forward that
  * used `workspace`, one value per problem -- the two numbers the reference's NumPy solver returns next to the

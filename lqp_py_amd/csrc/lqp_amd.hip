@@ -91,7 +91,7 @@ template <typename F> bool blocks_per_cu(int* per_cu, F fn, int nt, int lds, int
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream ----
 enum { PC_SETUP = 0, PC_LU, PC_PACK, PC_LOOP, PC_RHO, PC_EPILOGUE, PC_BWD_BUILD, PC_SOLVE, PC_BWD_EPILOGUE,
-       PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_BWD_CHOL, PC_UNROLL, PC_COUNT };
+       PC_MISC, PC_LOOP_TAIL, PC_SPD_INV, PC_EQ_CORR, PC_BWD_CHOL, PC_UNROLL, PC_UNROLL_SCALE, PC_COUNT };
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::mutex g_prof_mutex;
 bool g_prof_on = false;
@@ -1466,7 +1466,7 @@ int lqp_profile_classes(void) { return PC_COUNT; }
 const char* lqp_profile_class_name(int c) {
     static const char* names[PC_COUNT] = {"fwd_setup", "lu_factor", "pack", "admm_loop", "rho_update", "fwd_epilogue",
                                           "bwd_build", "packed_solve", "bwd_epilogue", "misc", "admm_loop_tail",
-                                          "spd_inverse", "eq_correct", "bwd_cholesky", "unroll_backward"};
+                                          "spd_inverse", "eq_correct", "bwd_cholesky", "unroll_backward", "unroll_scaling"};
     return (c >= 0 && c < PC_COUNT) ? names[c] : "?";
 }
 
@@ -1598,6 +1598,77 @@ int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd
         hipLaunchKernelGGL(k_unroll_outer<>, dim3(tiles, tiles, B), dim3(256), 0, st, (const float*)U.DX, (const float*)U.X,
                            (float*)dQs, n, T);
     }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+int lqp_unroll_scale_colmax(void* stream, int B, int n, const void* Q, void* colmax, void* argmax, void* count) {
+    if (B < 0 || n < 1 || !Q || !colmax || !argmax || !count) return LQP_ERR_INVALID;
+    if (B == 0) return LQP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, PC_UNROLL_SCALE);
+    int dev = 0, cus = 0;
+    const int slabs = (current_device_cus(&dev, &cus) && 2 * B <= cus && n >= 128) ? 2 : 1;      // column halves when half the chip is idle
+    hipLaunchKernelGGL(k_unroll_scale_colmax<>, dim3(B, slabs), dim3(LQP_NT), 0, st, (const float*)Q, n, (float*)colmax, (int*)argmax, (int*)count);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+int lqp_unroll_scale_grad_slabs(int B, int n) {
+    (void)n;
+    int dev = 0, cus = 0;
+    if (B < 1 || !current_device_cus(&dev, &cus)) return 1;
+    int s = (8 * cus) / B;                       // 256-thread workgroups: eight per CU fill it
+    return s < 1 ? 1 : (s > 32 ? 32 : s);
+}
+
+int lqp_unroll_scale_grad(void* stream, int B, int n, const void* Q, const void* d, const void* s, void* G, void* parts, int slabs) {
+    if (B < 0 || n < 1 || !Q || !G || !parts || slabs < 1 || slabs > 64) return LQP_ERR_INVALID;
+    if (B == 0) return LQP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int lds = 4 * n * (int)sizeof(float);
+    if (lds > 64 * 1024) return LQP_ERR_UNSUPPORTED;
+    int rc = ensure_lds((const void*)k_unroll_scale_grad<>, lds);
+    if (rc) return rc;
+    ProfScope ps(st, PC_UNROLL_SCALE);
+    hipLaunchKernelGGL(k_unroll_scale_grad<>, dim3(B, slabs), dim3(256), lds, st, (const float*)Q, (const float*)d, (const float*)s,
+                       (float*)G, n, (float*)parts);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+int lqp_unroll_scale_vectors(void* stream, int B, int n, int m, int phase, int has_box, int beta_given, double beta_value,
+                             const void* colmax, const void* p, const void* A, const void* b, const void* lb, const void* ub,
+                             const void* g_ps, const void* g_As, const void* g_bs, const void* g_lbs, const void* g_ubs, const void* g_D,
+                             const void* parts, int nparts, void* d_out, void* dp, void* dA, void* db, void* dlb, void* dub,
+                             void* g_colmax) {
+    if (B < 0 || n < 1 || m < 0 || !colmax || (phase != 0 && phase != 1)) return LQP_ERR_INVALID;
+    if (phase == 0 && !d_out) return LQP_ERR_INVALID;
+    if (phase == 1 && (!p || !g_colmax || (m > 0 && (!A || !b || !g_As)) || (has_box && (!lb || !ub)) || (nparts > 0 && !parts)))
+        return LQP_ERR_INVALID;
+    if (B == 0) return LQP_OK;
+    const int lds = unroll_scale_vectors_lds_bytes(n, m);
+    if (lds > 160 * 1024) return LQP_ERR_UNSUPPORTED;
+    int rc = ensure_lds((const void*)k_unroll_scale_vectors<>, lds);
+    if (rc) return rc;
+    ScaleVecParams P;
+    memset(&P, 0, sizeof(P));
+    P.n = n; P.m = m; P.phase = phase; P.has_box = has_box; P.beta_given = beta_given; P.nparts = nparts; P.beta_value = (float)beta_value;
+    P.cn = (const float*)colmax; P.p = (const float*)p; P.A = (const float*)A; P.b = (const float*)b; P.lb = (const float*)lb; P.ub = (const float*)ub;
+    P.gps = (const float*)g_ps; P.gAs = (const float*)g_As; P.gbs = (const float*)g_bs; P.glbs = (const float*)g_lbs; P.gubs = (const float*)g_ubs;
+    P.gD = (const float*)g_D; P.parts = (const float*)parts;
+    P.d_out = (float*)d_out; P.dp = (float*)dp; P.dA = (float*)dA; P.db = (float*)db; P.dlb = (float*)dlb; P.dub = (float*)dub; P.gcn = (float*)g_colmax;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, PC_UNROLL_SCALE);
+    hipLaunchKernelGGL(k_unroll_scale_vectors<>, dim3(B), dim3(LQP_NT), lds, st, P);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+int lqp_unroll_scale_scatter(void* stream, int B, int n, const void* Q, const void* colmax, const void* argmax, const void* count,
+                             const void* g_colmax, void* G) {
+    if (B < 0 || n < 1 || !Q || !colmax || !argmax || !count || !g_colmax || !G) return LQP_ERR_INVALID;
+    if (B == 0) return LQP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(st, PC_UNROLL_SCALE);
+    hipLaunchKernelGGL(k_unroll_scale_scatter<>, dim3(B), dim3(LQP_NT), 0, st, (const float*)Q, (const float*)colmax, (const int*)argmax,
+                       (const int*)count, (const float*)g_colmax, (float*)G, n);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 

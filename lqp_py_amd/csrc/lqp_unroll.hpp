@@ -219,4 +219,375 @@ __global__ __launch_bounds__(256) void k_unroll_outer(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The scaling (:160-203) behind the unrolled loop: what of its derivative touches the B x n x n tensors.
+//
+// The reference lets autograd tape the pre-conditioning too; of its ~25 operations four walk over Q-sized tensors
+// (:163 the column maxima of |Q|, :176 Qs = D Q D, :201 ||Qs||_F, and their backward nodes; ||Qs||_F itself is rho sqrt(n) of the forward), which as eager torch ops are
+// ~25 passes over 128 MB at the headline size -- 2.0 of the 4.2 ms of an unroll step.  Here each is ONE pass:
+//   k_unroll_scale_colmax   cn_j = max_i |Q_ij|, the first row that attains it, how many rows do (amax's backward shares
+//                           the gradient evenly between ties)
+//   k_unroll_scale_grad     G := D (G + s D Q D) D in place (G = dL/dQs from the sweep, s = dL/d||Qs||_F / ||Qs||_F) and the two
+//                           reductions the gradient of D needs: r_i = sum_j T_ij Q_ij d_j, c_j = sum_i T_ij d_i Q_ij (T = G + s Qs)
+//   k_unroll_scale_scatter  G_ij += gcn_j sign(Q_ij) / count_j where |Q_ij| = cn_j  (the backward of :163)
+//   k_unroll_scale_vectors  the n-sized rest of the chain (quantiles, beta, the equality rows, the bounds), forward and backward
+// float32, any n (one column per thread and pass); D may be null (scale = False).
+// ---------------------------------------------------------------------------------------------------------------------
+// gridDim.y column slabs per problem; inside a workgroup G = 1024 / (padded slab width) groups of threads share the rows of a
+// column (rows g, g + G, ...: eight loads in flight per thread) and merge through LDS -- first row of the maximum, tie count.
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(LQP_NT) void k_unroll_scale_colmax(const float* __restrict__ Qall, const int n, float* __restrict__ cn,
+                                                                int* __restrict__ arg, int* __restrict__ cnt) {
+    __shared__ float sbest[LQP_NT];
+    __shared__ int sidx[LQP_NT], scnt[LQP_NT];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* Q = Qall + (size_t)b * n * n;
+    const int wcols = (n + (int)gridDim.y - 1) / (int)gridDim.y;           // columns of this slab
+    const int c0 = (int)blockIdx.y * wcols, c1 = c0 + wcols < n ? c0 + wcols : n;
+    constexpr int RIF = 8;
+    for (int cb = c0; cb < c1; cb += LQP_NT) {                               // (slabs wider than 1024 columns: several passes)
+        const int wc = c1 - cb < LQP_NT ? c1 - cb : LQP_NT;
+        int wp = 64;
+        while (wp < wc) wp <<= 1;                                           // padded width: a power of two
+        const int G = LQP_NT / wp, g = tid / wp, j = cb + (tid & (wp - 1));
+        const bool live = j < c1;
+        float best = -1.f;
+        int bi = 0, bc = 0;
+        if (live) {
+            for (int i0 = g; i0 < n; i0 += RIF * G) {
+                float v[RIF];
+#pragma unroll
+                for (int r = 0; r < RIF; ++r) { const int i = i0 + r * G; v[r] = Q[(size_t)(i < n ? i : i0) * n + j]; }
+#pragma unroll
+                for (int r = 0; r < RIF; ++r) {
+                    const int i = i0 + r * G;
+                    if (i < n) {
+                        const float a = fabsf(v[r]);
+                        if (a > best) { best = a; bi = i; bc = 1; }
+                        else if (a == best) ++bc;
+                    }
+                }
+            }
+        }
+        sbest[tid] = best; sidx[tid] = bi; scnt[tid] = bc;
+        __syncthreads();
+        if (g == 0 && live) {
+            for (int q = 1; q < G; ++q) {
+                const float ob = sbest[tid + q * wp];
+                const int oi = sidx[tid + q * wp], oc = scnt[tid + q * wp];
+                if (ob > best) { best = ob; bi = oi; bc = oc; }
+                else if (ob == best) { bc += oc; bi = oi < bi ? oi : bi; }
+            }
+            cn[(size_t)b * n + j] = best;
+            arg[(size_t)b * n + j] = bi;
+            cnt[(size_t)b * n + j] = bc;
+        }
+        __syncthreads();
+    }
+}
+
+// parts: (B, 1 + gridDim.y, n): slot 0 the row sums r_i (written by the slab that owns row i), slot 1 + y the column sums of slab y.
+// 256 threads: wave w takes rows r0 + w, r0 + w + 4, ... of its slab TWO at a time, a lane the columns lane, lane + 64, ...
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(256) void k_unroll_scale_grad(const float* __restrict__ Qall, const float* __restrict__ dall,
+                                                           const float* __restrict__ sall, float* __restrict__ Gall, const int n,
+                                                           float* __restrict__ parts) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    float* cred = (float*)smem;                         // [4][n] column sums of the waves
+    constexpr int NWV = 4, CPL = 8, RIF = 2;
+    const int b = blockIdx.x, y = blockIdx.y, ny = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* Q = Qall + (size_t)b * n * n;
+    float* G = Gall + (size_t)b * n * n;
+    const float* d = dall ? dall + (size_t)b * n : nullptr;
+    const float s = sall ? sall[b] : 0.f;
+    float* P0 = parts + (size_t)b * (1 + ny) * n;
+    float* Py = P0 + (size_t)(1 + y) * n;
+    const int rows = (n + ny - 1) / ny, r0 = y * rows, r1 = (r0 + rows < n) ? r0 + rows : n;
+    for (int c0 = 0; c0 < n; c0 += 64 * CPL) {          // (n <= 512: one pass)
+        float dj[CPL], cacc[CPL];
+        int jc[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int j = c0 + lane + 64 * q;
+            jc[q] = j < n ? j : n - 1;
+            dj[q] = (j < n) ? (d ? d[j] : 1.f) : 0.f;
+            cacc[q] = 0.f;
+        }
+        for (int i0 = r0 + w; i0 < r1; i0 += RIF * NWV) {
+            float qv[RIF][CPL], gv[RIF][CPL], di[RIF];
+#pragma unroll
+            for (int r = 0; r < RIF; ++r) {
+                const int i = (i0 + r * NWV < r1) ? i0 + r * NWV : i0;
+                di[r] = d ? d[i] : 1.f;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) { const size_t o = (size_t)i * n + jc[q]; qv[r][q] = Q[o]; gv[r][q] = G[o]; }
+            }
+#pragma unroll
+            for (int r = 0; r < RIF; ++r) {
+                const int i = i0 + r * NWV;
+                if (i < r1) {
+                    float racc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        if (c0 + lane + 64 * q < n) {
+                            const float dq = di[r] * qv[r][q];                 // d_i Q_ij
+                            const float t = gv[r][q] + s * (dq * dj[q]);         // T_ij
+                            G[(size_t)i * n + jc[q]] = (di[r] * t) * dj[q];
+                            racc += t * (qv[r][q] * dj[q]);
+                            cacc[q] += t * dq;
+                        }
+                    }
+                    racc = wave_sum(racc);
+                    if (lane == 0) { if (c0 == 0) P0[i] = racc; else P0[i] += racc; }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { const int j = c0 + lane + 64 * q; if (j < n) cred[(size_t)w * n + j] = cacc[q]; }
+        __syncthreads();
+        for (int j = c0 + tid; j < n && j < c0 + 64 * CPL; j += 256) {
+            float a = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NWV; ++ww) a += cred[(size_t)ww * n + j];
+            Py[j] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// The n-sized part of the chain, forward (phase 0: the scaling vector only) and backward (phase 1), one workgroup per problem
+// (scale = True; n <= 1024 + m <= 16: what the native unroll takes).  Forward as the setup kernel forms it (wg_scaling_vector,
+// :163-175): c = column maxima (non-positive ones floored, :164-168), d0 = c^-1/2, beta = 1 - q10(d0) / q90(d0) (torch.quantile's
+// linear interpolation) unless given, d = (1 - beta) d0 + beta mean(d0); ps = d p; A1 = A d, E = 1 / rowmax |A1| (floored), As = E A1,
+// bs = E b (:179-190); lbs = lb / d, ubs = ub / d (:192-194).  Backward: the derivative of exactly that, node by node as autograd
+// would take it (amax shares its gradient between ties, clamp passes it inside its range, the quantile to its two neighbours).
+struct ScaleVecParams {
+    int n, m, phase, has_box, beta_given, nparts;
+    float beta_value;
+    const float *cn, *p, *A, *b, *lb, *ub;                       // (B,n) (B,n) (B,m,n) (B,m) (B,n) (B,n)
+    const float *gps, *gAs, *gbs, *glbs, *gubs, *gD, *parts;     // upstream: dL/d(ps, As, bs, lbs, ubs, D) and (B, nparts, n) dL/dd through Qs
+    float *d_out;                                                // phase 0: (B,n)
+    float *dp, *dA, *db, *dlb, *dub, *gcn;                       // phase 1
+};
+
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(LQP_NT) void k_unroll_scale_vectors(const ScaleVecParams P) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    constexpr int NT = LQP_NT;
+    const int b = blockIdx.x, n = P.n, m = P.m, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int N2 = 1;
+    while (N2 < n) N2 <<= 1;
+    float* c = (float*)smem;              // floored column maxima
+    float* d0 = c + n;
+    float* dd = d0 + n;
+    float* gd = dd + n;
+    float* sb = gd + n;                   // [N2] sort buffer
+    float* red = sb + N2;                 // [NW + 8]
+    float* rn = red + LQP_NW + 8;         // [m] row maxima of |A d| (floored)
+    float* Er = rn + (m > 0 ? m : 1);     // [m]
+    float* grn = Er + (m > 0 ? m : 1);    // [m]
+    int* kr = (int*)(grn + (m > 0 ? m : 1));   // [m] tie counts
+    int* sel_i = kr + (m > 0 ? m : 1);    // [4] original indices of the four order statistics
+    float* sel = (float*)(sel_i + 4);     // [4] their values | [4..8) scalars
+    const float* cn = P.cn + (size_t)b * n;
+
+    // ---- forward ----
+    float part = 0.f;
+    int anybad = 0;
+    for (int j = tid; j < n; j += NT) { const float v = cn[j]; part += v; anybad |= (v <= 0.f) ? 1 : 0; }
+    const float meanc = wg_sum(part, red) / (float)n;
+    anybad = __syncthreads_or(anybad);
+    const float floor_c = tmax(meanc, 1e-6f);
+    part = 0.f;
+    for (int j = tid; j < n; j += NT) {
+        float v = cn[j];
+        if (v <= 0.f) v = tmax(v, floor_c);
+        c[j] = v;
+        v = sqrtf(1.f / v);
+        d0[j] = v;
+        part += v;
+    }
+    const float mean0 = wg_sum(part, red) / (float)n;
+    float beta = P.beta_value, q10 = 0.f, q90 = 1.f, w0 = 0.f, w1 = 0.f;
+    if (!P.beta_given) {
+        const float pos0 = 0.10f * (float)(n - 1), pos1 = 0.90f * (float)(n - 1);
+        const int lo0 = (int)floorf(pos0), hi0 = (int)ceilf(pos0), lo1 = (int)floorf(pos1), hi1 = (int)ceilf(pos1);
+        for (int i = tid; i < N2; i += NT) sb[i] = i < n ? d0[i] : INFINITY;
+        __syncthreads();
+        for (int k = 2; k <= N2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (N2 >> 1); t += NT) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const float x0 = sb[i], x1 = sb[l];
+                    if ((x0 > x1) == ((i & k) == 0)) { sb[i] = x1; sb[l] = x0; }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) { sel[0] = sb[lo0]; sel[1] = sb[hi0]; sel[2] = sb[lo1]; sel[3] = sb[hi1]; }
+        if (tid < 4) sel_i[tid] = 0;
+        __syncthreads();
+        w0 = pos0 - floorf(pos0); w1 = pos1 - floorf(pos1);
+        q10 = (w0 < 0.5f) ? sel[0] + w0 * (sel[1] - sel[0]) : sel[1] - (sel[1] - sel[0]) * (1.f - w0);
+        q90 = (w1 < 0.5f) ? sel[2] + w1 * (sel[3] - sel[2]) : sel[3] - (sel[3] - sel[2]) * (1.f - w1);
+        beta = 1.f - q10 / q90;
+        if (P.phase == 1) {
+            // who holds the four order statistics: the element of (stable) rank lo / hi -- only a value equal to one of them can
+            for (int j = tid; j < n; j += NT) {
+                const float v = d0[j];
+                if (v == sel[0] || v == sel[1] || v == sel[2] || v == sel[3]) {
+                    int rank = 0;
+                    for (int i = 0; i < n; ++i) { const float o = d0[i]; rank += (o < v || (o == v && i < j)) ? 1 : 0; }
+                    if (rank == lo0) sel_i[0] = j;
+                    if (rank == hi0) sel_i[1] = j;
+                    if (rank == lo1) sel_i[2] = j;
+                    if (rank == hi1) sel_i[3] = j;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += NT) dd[j] = (1.f - beta) * d0[j] + beta * mean0;
+    __syncthreads();
+    if (P.phase == 0) {
+        for (int j = tid; j < n; j += NT) P.d_out[(size_t)b * n + j] = dd[j];
+        return;
+    }
+
+    // ---- backward ----
+    const float* p = P.p + (size_t)b * n;
+    for (int j = tid; j < n; j += NT) {
+        const size_t o = (size_t)b * n + j;
+        const float dj = dd[j], gp = P.gps ? P.gps[o] : 0.f;
+        float g = (P.gD ? P.gD[o] : 0.f) + gp * p[j];
+        for (int y = 0; y < P.nparts; ++y) g += P.parts[((size_t)b * P.nparts + y) * n + j];
+        if (P.dp) P.dp[o] = dj * gp;
+        if (P.has_box) {
+            const float glb = P.glbs ? P.glbs[o] : 0.f, gub = P.gubs ? P.gubs[o] : 0.f;
+            const float lbj = P.lb[o], ubj = P.ub[o];
+            // (an infinite bound never binds: its gradient is zero and 0 * inf is taken as 0 here)
+            if (lbj > -INFINITY && lbj < INFINITY) g -= glb * lbj / (dj * dj);
+            if (ubj > -INFINITY && ubj < INFINITY) g -= gub * ubj / (dj * dj);
+            if (P.dlb) P.dlb[o] = glb / dj;
+            if (P.dub) P.dub[o] = gub / dj;
+        }
+        gd[j] = g;
+    }
+    __syncthreads();
+    if (m > 0) {
+        const float* A = P.A + (size_t)b * m * n;
+        const float* gA = P.gAs + (size_t)b * m * n;
+        // row maxima of |A d| and their tie counts: a row per wave
+        for (int r = w; r < m; r += LQP_NW) {
+            float mx = 0.f;
+            for (int j = lane; j < n; j += 64) mx = tmax(mx, fabsf(A[(size_t)r * n + j] * dd[j]));
+            mx = wave_max(mx);
+            int k = 0;
+            for (int j = lane; j < n; j += 64) k += (fabsf(A[(size_t)r * n + j] * dd[j]) == mx) ? 1 : 0;
+            k = (int)wave_sum((float)k);                     // (small integers: exact in float)
+            if (lane == 0) { rn[r] = mx; kr[r] = k; }
+        }
+        __syncthreads();
+        float meanr = 0.f;
+        int badr = 0;
+        for (int r = 0; r < m; ++r) { meanr += rn[r]; badr |= rn[r] <= 0.f ? 1 : 0; }
+        meanr /= (float)m;
+        const float floor_r = tmax(meanr, 1e-6f);
+        // E, dL/dE = sum_j gAs_rj A1_rj + gbs_r b_r, dL/d(row maximum): a row per wave
+        for (int r = w; r < m; r += LQP_NW) {
+            const float rv = rn[r] <= 0.f ? tmax(rn[r], floor_r) : rn[r];
+            float acc = 0.f;
+            for (int j = lane; j < n; j += 64) acc += gA[(size_t)r * n + j] * (A[(size_t)r * n + j] * dd[j]);
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                const float e = 1.f / rv;
+                const float gbs = P.gbs ? P.gbs[(size_t)b * m + r] : 0.f;
+                const float gE = acc + gbs * P.b[(size_t)b * m + r];                // (As = E A1, bs = E b)
+                Er[r] = e;
+                grn[r] = -gE / (rv * rv);
+                if (P.db) P.db[(size_t)b * m + r] = e * gbs;
+            }
+        }
+        __syncthreads();
+        if (badr) {                                    // the floor (:182-186): floored rows pass their gradient to the mean
+            float gfl = 0.f;
+            for (int r = 0; r < m; ++r) gfl += rn[r] <= 0.f ? grn[r] : 0.f;
+            __syncthreads();
+            if (tid < m) grn[tid] = (rn[tid] <= 0.f ? 0.f : grn[tid]) + (meanr >= 1e-6f ? gfl / (float)m : 0.f);
+            __syncthreads();
+        }
+        // dA and the share of the equality rows in dL/dd: a column per thread, rows in order
+        for (int j = tid; j < n; j += NT) {
+            const float dj = dd[j];
+            float g = gd[j];
+            for (int r = 0; r < m; ++r) {
+                const float a = A[(size_t)r * n + j], a1 = a * dj;
+                float ga1 = Er[r] * gA[(size_t)r * n + j];
+                if (rn[r] > 0.f && fabsf(a1) == rn[r]) ga1 += (a1 > 0.f ? grn[r] : -grn[r]) / (float)kr[r];
+                if (P.dA) P.dA[((size_t)b * m + r) * n + j] = ga1 * dj;
+                g += ga1 * a;
+            }
+            gd[j] = g;
+        }
+        __syncthreads();
+    }
+    // d = (1 - beta) d0 + beta mean(d0)
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = tid; j < n; j += NT) { s1 += gd[j]; s2 += gd[j] * d0[j]; }
+    s1 = wg_sum(s1, red);
+    s2 = wg_sum(s2, red);
+    const float gbeta = s1 * mean0 - s2;
+    for (int j = tid; j < n; j += NT) gd[j] = (1.f - beta) * gd[j] + beta * s1 / (float)n;      // now dL/dd0
+    __syncthreads();
+    if (!P.beta_given && tid == 0) {
+        const float gq10 = -gbeta / q90, gq90 = gbeta * q10 / (q90 * q90);
+        gd[sel_i[0]] += (1.f - w0) * gq10; gd[sel_i[1]] += w0 * gq10;
+        gd[sel_i[2]] += (1.f - w1) * gq90; gd[sel_i[3]] += w1 * gq90;
+    }
+    __syncthreads();
+    // d0 = c^-1/2, the floor (:164-168)
+    float gfl = 0.f;
+    for (int j = tid; j < n; j += NT) {
+        const float gc = -0.5f * gd[j] * d0[j] / c[j];
+        const bool bad = cn[j] <= 0.f;
+        gfl += bad ? gc : 0.f;
+        gd[j] = bad ? 0.f : gc;
+    }
+    if (anybad) gfl = wg_sum(gfl, red);
+    for (int j = tid; j < n; j += NT) P.gcn[(size_t)b * n + j] = gd[j] + ((anybad && meanc >= 1e-6f) ? gfl / (float)n : 0.f);
+}
+__host__ __device__ inline int unroll_scale_vectors_lds_bytes(int n, int m) {
+    int N2 = 1;
+    while (N2 < n) N2 <<= 1;
+    const int mm = m > 0 ? m : 1;
+    return (4 * n + N2 + LQP_NW + 8 + 3 * mm) * 4 + (mm + 4) * 4 + 8 * 4 + 64;
+}
+
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(LQP_NT) void k_unroll_scale_scatter(const float* __restrict__ Qall, const float* __restrict__ cn,
+                                                                 const int* __restrict__ arg, const int* __restrict__ cnt,
+                                                                 const float* __restrict__ gcn, float* __restrict__ Gall, const int n) {
+    const int b = blockIdx.x;
+    const float* Q = Qall + (size_t)b * n * n;
+    float* G = Gall + (size_t)b * n * n;
+    for (int j = threadIdx.x; j < n; j += LQP_NT) {
+        const size_t o = (size_t)b * n + j;
+        const float g = gcn[o], c = cn[o];
+        const int k = cnt[o];
+        if (g == 0.f || !(c > 0.f)) continue;              // (sign(0) = 0: a zero column passes nothing on)
+        if (k == 1) {
+            const size_t e = (size_t)arg[o] * n + j;
+            G[e] += Q[e] > 0.f ? g : -g;
+        } else {
+            const float gk = g / (float)k;
+            for (int i = 0; i < n; ++i) {
+                const size_t e = (size_t)i * n + j;
+                const float q = Q[e];
+                if (fabsf(q) == c) G[e] += q > 0.f ? gk : -gk;
+            }
+        }
+    }
+}
+
 }  // namespace lqp

@@ -1040,6 +1040,52 @@ def test_unroll_mode_goldens(dev, monkeypatch, name, tol, native):
         close_or_fp64(name, nm, t.grad, g[nm], t64, G_RTOL, native=native)
 
 
+@pytest.mark.parametrize("case", ["default", "ties", "no_scale", "rho_given", "beta_given", "box_only", "ragged", "many_rows"])
+def test_unroll_scaling_chain_native_vs_autograd(dev, monkeypatch, case):
+    """unroll=True: the scaling (:160-203) behind the reverse sweep with its Q-sized nodes on the library's one-pass kernels
+    (lqp_unroll_scale_*; the n-sized rest by autograd) against the whole chain as eager torch ops (LQP_UNROLL_SCALE_NATIVE=0):
+    the same sweep output goes through both, so the gradients agree to float32 summation order.  `ties`: two rows attain a
+    column's maximum of |Q| -- amax shares that column's gradient between them, signs included."""
+    n, B = (61, 3) if case == "ragged" else (96, 4)
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=41)
+    ctl = L.box_qp_control(unroll=True, **TOL)
+    if case == "ties":
+        Q = Q.clone()
+        big = float(Q.abs().max()) * 1.5
+        Q[:, 3, 7] = big; Q[:, 7, 3] = big; Q[:, 11, 7] = -big; Q[:, 7, 11] = -big      # (symmetric; rows 3 and 11 tie in column 7)
+        Q[:, 7, 7] += 4 * big; Q[:, 3, 3] += 4 * big; Q[:, 11, 11] += 4 * big            # (still positive definite)
+    if case == "no_scale":
+        ctl["scale"] = False
+    if case == "rho_given":
+        ctl["rho"] = 0.7
+    if case == "beta_given":
+        ctl["beta"] = 0.3
+    if case == "box_only":
+        A = b = None
+    if case == "many_rows":                                # five equality rows through a feasible point
+        A = torch.randn(B, 5, n, generator=torch.Generator().manual_seed(43))
+        b = A @ (0.5 * (lb + ub))
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(42)).to(dev)
+    got = {}
+    for flag in ("1", "2", "0"):         # 1: five kernels, no autograd; 2: the Q-sized nodes native, the n-sized ones by autograd; 0: all eager
+        monkeypatch.setenv("LQP_UNROLL_SCALE_NATIVE", flag)
+        leaves = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        _lib.profile(enable=True, reset=True)
+        x = L.SolveBoxQP(control=dict(ctl))(*leaves)
+        x.backward(cot)
+        used = _lib.profile(); _lib.profile(enable=False)
+        assert used["unroll_backward"][1] == 2, used
+        assert (used["unroll_scaling"][1] > 0) == (flag != "0"), used["unroll_scaling"]
+        got[flag] = [None if t is None else t.grad for t in leaves]
+    for flag in ("1", "2"):
+        for nm, a, e in zip(GRADS, got[flag], got["0"]):
+            if e is None:
+                assert a is None, (flag, nm)
+                continue
+            scale = max(1e-3, float(e.abs().max()))
+            assert err(a, e) <= 2e-5 * scale, (case, flag, nm, err(a, e), scale)
+
+
 def test_unroll_native_falls_back(dev):
     """What the reverse sweep does not cover takes the taped loop by itself: float64, the cached-LU x-update, a solve in
     which rho was adapted (the factor is no longer constant along the tape)."""

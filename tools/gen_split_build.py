@@ -54,6 +54,10 @@ EXTRA = [
     "void lqp::k_unroll_sweep<1>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_unroll_sweep<16>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_unroll_outer<0>(float const*, float const*, float*, int, int)",
+    "void lqp::k_unroll_scale_colmax<0>(float const*, int, float*, int*, int*)",
+    "void lqp::k_unroll_scale_grad<0>(float const*, float const*, float const*, float*, int, float*)",
+    "void lqp::k_unroll_scale_vectors<0>(lqp::ScaleVecParams)",
+    "void lqp::k_unroll_scale_scatter<0>(float const*, float const*, int const*, int const*, float const*, float*, int)",
     "void lqp::k_admm_loop_small<0>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_spd_resident<3, 2>(lqp::FwdParams<float>, int const*)",
     "void lqp::k_spd_resident<4, 2>(lqp::FwdParams<float>, int const*)",
@@ -68,6 +72,7 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_unroll_scale_fro<0>(float const*, float const*, int, float*)",
     "void lqp::k_admm_loop_lu2<float>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_admm_loop_lu2<double>(lqp::FwdParams<double>, int, int, int)",
     "void lqp::k_lu_factor<float, 32, true, 1024>(float*, int, int, unsigned long, int*, int, int*, int const*, unsigned long long*, int const*)",
