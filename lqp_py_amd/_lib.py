@@ -16,7 +16,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQP_LIB: A/B builds
-SOURCES = ["lqp_amd.hip", "lqp_unroll.hpp", "lqp_boxqp.hpp", "lqp_lu.hpp", "lqp_lu_big.hpp", "lqp_lu2.hpp", "lqp_dense.hpp", "lqp_trsv.hpp", "lqp_spd.hpp", "lqp_common.hpp"]
+SOURCES = ["lqp_amd.hip", "lqp_unroll.hpp", "lqp_boxqp.hpp", "lqp_lu.hpp", "lqp_lu_big.hpp", "lqp_lu2.hpp", "lqp_lu_wide.hpp", "lqp_dense.hpp", "lqp_trsv.hpp", "lqp_spd.hpp", "lqp_common.hpp"]
 
 LQP_F32, LQP_F64 = 0, 1
 ABI_VERSION = 10

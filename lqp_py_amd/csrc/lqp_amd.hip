@@ -153,6 +153,7 @@ struct Knobs {
     int loop_split4;           // LQP_LOOP_SPLIT4
     int loop_split_seg;        // LQP_LOOP_SPLIT_SEG
     int lu2;                   // LQP_LU2
+    int lu_wide;               // LQP_LU_WIDE
     int lu_mfma;               // LQP_LU_MFMA
     int lu_nt;                 // LQP_LU_NT
     int lu_pb;                 // LQP_LU_PB
@@ -195,6 +196,7 @@ Knobs read_knobs() {
     k.loop_split4 = env_int("LQP_LOOP_SPLIT4", 1);
     k.loop_split_seg = env_int("LQP_LOOP_SPLIT_SEG", 1);
     k.lu2 = env_int("LQP_LU2", 1);
+    k.lu_wide = env_int("LQP_LU_WIDE", 1);
     k.lu_mfma = env_int("LQP_LU_MFMA", 1);
     k.lu_nt = env_int("LQP_LU_NT", 0);
     k.lu_pb = env_int("LQP_LU_PB", 0);
@@ -279,9 +281,39 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
+// Several workgroups per matrix above 1024 rows (lqp_lu_wide.hpp, float32) when the batch leaves most of the chip idle: W = what
+// fits resident / B workgroups (>= 2) own the 32-column tiles cyclically.  `scr`: 4 * luw_scratch_words(N) bytes per problem.
+// Returns -1: not applicable, take the one-workgroup kernel.
+int launch_lu_wide(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
+                   const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
+    if (!scr || 2 * scr_stride < luw_scratch_words(N) || N <= 1024 || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
+        (((uintptr_t)M) % 128) != 0)
+        return -1;
+    int dev = 0, cus = 0, per_cu = 0;
+    auto fn = k_lu_factor_wide<>;
+    const int lds = LuLds<float, LUW_PB>(round_up(N, 64)).total;
+    if (!current_device_cus(&dev, &cus) || ensure_lds((const void*)fn, lds) != LQP_OK ||
+        !blocks_per_cu(&per_cu, fn, LQP_NT, lds, dev) || per_cu < 1)
+        return -1;
+    int W = (cus * per_cu) / B;
+    const int ntile = (N + 31) / 32;
+    if (W > ntile) W = ntile;
+    if (W > LUW_HDR - 2) W = LUW_HDR - 2;
+    if (W < 2) return -1;
+    const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
+    { ProfScope ps(st, PC_LU);
+      hipLaunchKernelGGL(fn, dim3(W * B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, (int*)scr,
+                         2 * scr_stride, epoch, B); }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr, unsigned long long* scr = nullptr, size_t scr_stride = 0) {
-    if (N > 1024) return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
+    if (N > 1024) {
+        const int rw = launch_lu_wide(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
+        if (rw >= 0) return rw;
+        return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
+    }
     { const int r2 = launch_lu2<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
       if (r2 >= 0) return r2; }
     int nt = lu_threads<float>(N);
@@ -1304,13 +1336,14 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
 // ---------------------------------------------------------------------------
 // LU / solve / KKT entry points
 // ---------------------------------------------------------------------------
+inline size_t lu_scratch_u64(int N) { return N > 1024 ? (luw_scratch_words(N) + 1) / 2 : (size_t)LU2_SCR_WORDS; }
 template <typename T>
 size_t carve_lu(void* ws, int B, int N, T*& M, int*& piv, unsigned long long*& scr) {
     const int Np = round_up(N, LQP_NB);
     Carver c(ws);
     piv = c.take<int>((size_t)B * Np);
     M = c.take<T>((size_t)B * Np * Np);
-    scr = c.take<unsigned long long>((size_t)B * LU2_SCR_WORDS);      // (hand-off words of the two-workgroup LU)
+    scr = c.take<unsigned long long>((size_t)B * lu_scratch_u64(N));      // (hand-off words of the two-workgroup LU / messages of the wide one)
     return c.off + kAlign;
 }
 
@@ -1321,7 +1354,7 @@ int lu_factor_impl(hipStream_t st, int B, int N, void* Mio, int32_t* piv_out, in
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
     const int Np = round_up(N, LQP_NB);
     hipLaunchKernelGGL(k_copy_matrix<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)Mio, N, (size_t)N * N, M, Np, (size_t)Np * Np, N);
-    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info_out, nullptr, nullptr, scr, LU2_SCR_WORDS);
+    int rc = launch_lu(st, M, B, N, Np, (size_t)Np * Np, piv, Np, info_out, nullptr, nullptr, scr, lu_scratch_u64(N));
     if (rc) return rc;
     hipLaunchKernelGGL(k_copy_matrix<T>, dim3(B), dim3(LQP_NT), 0, st, (const T*)M, Np, (size_t)Np * Np, (T*)Mio, N, (size_t)N * N, N);
     hipLaunchKernelGGL(k_copy_ints<int>, dim3(B), dim3(256), 0, st, (const int*)piv, Np, (int*)piv_out, N, N);

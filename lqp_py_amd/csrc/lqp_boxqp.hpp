@@ -6,6 +6,7 @@
 #include "lqp_lu.hpp"
 #include "lqp_lu_big.hpp"
 #include "lqp_lu2.hpp"
+#include "lqp_lu_wide.hpp"
 #include "lqp_trsv.hpp"
 #include "lqp_spd.hpp"
 

@@ -1,0 +1,284 @@
+// Pivoted LU above the one-row-per-thread tier (1024 < N <= 2048) on SEVERAL workgroups per matrix, for batches that leave the
+// chip idle (B = 8, n = 1500: the one-workgroup kernel of lqp_lu_big.hpp streams the trailing matrix through ONE CU 188 times --
+// 25 ms per factorisation, 34 of the 47 ms of a forward + backward step).  Same right-looking algorithm, LAPACK layout and pivot
+// rule (replaces torch.linalg.lu_factor at lqp_py/solve_box_qp_admm_torch.py:215,254, lqp_py/lu_layer.py:10,31), float32.
+//
+// Columns are dealt out in tiles of 32 (one 128-B line per row): tile g belongs to workgroup g % W for the whole factorisation,
+// and NOBODY else ever reads or writes those columns of the matrix -- the owner brings them up to date, factors the panels that
+// lie in them (PB = 8 columns, two rows per thread, the code of the one-workgroup kernel), applies the interchanges to them when
+// they are left of the panel.  What crosses between workgroups is the factored panel alone: L21^T (PB x M2), L11, the gather map
+// of the interchanges -- a message in a two-slot ring in global memory, written through (sc1 stores), one tagged `go` word per
+// slot, read with sc1 loads (MI355X_MICROARCH R1: the form of lqp_lu2.hpp).  No barrier between the workgroups: a consumer
+// waits for the message of panel k, the publisher of panel k waits until every workgroup has taken message k - 2 out of the slot
+// it is about to overwrite (one progress word per workgroup).  All W B workgroups must be resident (the host checks).
+#pragma once
+#include "lqp_lu2.hpp"
+#include "lqp_lu_big.hpp"
+
+namespace lqp {
+
+constexpr int LUW_PB = 8;                     // panel width (float32: the one-workgroup kernel's)
+constexpr int LUW_HDR = 64;                   // progress words (W <= 64)
+constexpr int LUW_MSG = 128;                  // words of a message head: go | ne | zero pivot | fail | src[8] | xdst[8] | xsrc[8] | L11[72]
+__host__ __device__ inline size_t luw_slot_words(int Mpad) { return (size_t)LUW_MSG + (size_t)LUW_PB * Mpad; }
+__host__ __device__ inline size_t luw_scratch_words(int N) { return (size_t)LUW_HDR + 2 * luw_slot_words(round_up(N, 64)); }
+
+__device__ __forceinline__ unsigned int luw_tag(const unsigned int epoch, const int k) { return (epoch << 12) | (unsigned int)(k + 1); }
+
+// bounded wait for *p == want (thread 0 of the workgroup; the others stand at the barrier behind it)
+__device__ __forceinline__ bool luw_wait_eq(const int* p, const unsigned int want, const int* fail, const unsigned int fail_tag) {
+    unsigned int spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+        if ((unsigned int)ld_sc1(p) == want) return true;
+        if ((++spins & 255u) == 0) {
+            if ((unsigned int)ld_sc1(fail) == fail_tag) return false;
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();         // 100 MHz
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 100000000ULL) return false;                          // 1 s
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ Mall, const int Nuni, const int ld, const size_t mstride,
+                                                           int* __restrict__ piv, const int pstride, int* __restrict__ info_all,
+                                                           const int* __restrict__ gate, const int* __restrict__ Nvec,
+                                                           int* __restrict__ scr_all, const size_t scr_stride, const unsigned int epoch,
+                                                           const int B) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    typedef float T;
+    constexpr int PB = LUW_PB, R = 2, NT = LQP_NT;
+    if (gate && *gate == 0) return;
+    const int b = (int)blockIdx.x % B, y = (int)blockIdx.x / B, W = (int)gridDim.x / B;
+    const int N = Nvec ? Nvec[b] : Nuni;
+    T* A = Mall + (size_t)b * mstride;
+    int* ipiv = piv + (size_t)b * pstride;
+    int* scr = scr_all + (size_t)b * scr_stride;
+    const int Mpad = round_up(Nuni, 64);                  // (the message layout follows the launch's size, not the problem's)
+    const LuLds<T, PB> L(Mpad);
+    T* LT = (T*)(smem + L.lt);
+    T* UPt = (T*)(smem + L.up);                           // [own tile slot][PB][32]
+    T* L11 = (T*)(smem + L.l11);
+    T* rowP = (T*)(smem + L.rowp);
+    T* wval = (T*)(smem + L.wval);
+    T* wrcp = (T*)(smem + L.wrcp);
+    int* widx = (int*)(smem + L.widx);
+    int* wtid = (int*)(smem + L.wtid);
+    int* pidx = (int*)(smem + L.pidx);
+    int* src = (int*)(smem + L.src);
+    int* xdst = (int*)(smem + L.xdst);
+    int* xsrc = (int*)(smem + L.xsrc);
+    int* cnt = (int*)(smem + L.cnt);                      // [0] interchange count | [1] first zero pivot | [2] failed | [3] ne of the message
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    typedef V4<T> vec;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    int* progress = scr;                                  // [W]
+    int* failw = scr + LUW_HDR - 1;                       // sticky: somebody gave up waiting (tagged with the epoch)
+    const size_t SL = luw_slot_words(Mpad);
+    if (tid == 0) { cnt[1] = 0; cnt[2] = 0; }
+    if (tid < 2 * LQP_NW) wval[tid] = T(-2);
+    if (tid == 0 && y == 0) info_all[b] = 0;
+    __syncthreads();
+    const unsigned int fail_tag = ((epoch & 0xFFFFFu) << 12) | 0xFFFu;
+    int first_zero = 0;
+    bool dead = false;
+
+    const int npanels = (N + PB - 1) / PB;
+    for (int k = 0; k < npanels; ++k) {
+        const int k0 = k * PB;
+        const int pb = (N - k0 < PB) ? (N - k0) : PB;
+        const int M = N - k0, M2 = M - pb;
+        const int gk = k0 >> 5, owner = gk % W;
+        int* slot = scr + LUW_HDR + (size_t)(k & 1) * SL;
+        T* LTg = (T*)(slot + LUW_MSG);
+        int ne = 0;
+        if (y == owner) {
+            // ---- the panel: my own columns, two rows per thread (the one-workgroup kernel's code) ----
+            {
+                vec row4[R][PB / 4];
+                int curpos[R];
+                bool done[R];
+                const bool wact = wbase < M;
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const int r = tid + q * NT;
+                    const bool act = r < M;
+                    curpos[q] = r;
+                    done[q] = !act;
+#pragma unroll
+                    for (int c = 0; c < PB; ++c)
+                        row4[q][c >> 2].v[c & 3] = (act && c < pb) ? A[(size_t)(k0 + r) * ld + k0 + c] : T(0);
+                }
+                if (tid == 0) *cnt = 0;
+                {
+                    const PanelLds<T> S{rowP, wval, wrcp, widx, wtid, pidx, cnt};
+                    lu_panel_columns_r<T, PB, R, NT>(row4, curpos, done, wact, pb, k0, S);
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const int r = tid + q * NT;
+                    if (r < M) {
+                        const int cp = curpos[q];
+#pragma unroll
+                        for (int c = 0; c < PB; ++c)
+                            if (c < pb) A[(size_t)(k0 + cp) * ld + k0 + c] = row4[q][c >> 2].v[c & 3];
+                        if (cp < pb) {
+#pragma unroll
+                            for (int c = 0; c < PB; ++c) L11[cp * (PB + 1) + c] = row4[q][c >> 2].v[c & 3];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < PB; ++c) LT[c * Mpad + (cp - pb)] = row4[q][c >> 2].v[c & 3];
+                        }
+                        src[cp] = r;
+                        if (cp >= pb && cp != r) {
+                            const int e = atomicAdd(cnt, 1);
+                            xdst[e] = cp;
+                            xsrc[e] = r;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < pb) ipiv[k0 + tid] = k0 + pidx[tid] + 1;
+            ne = __builtin_amdgcn_readfirstlane(*cnt);
+            if (W > 1) {
+                // ---- publish: nobody may still be reading message k - 2 out of this slot ----
+                if (k >= 2 && tid == 0) {
+                    for (int z = 0; z < W && cnt[2] == 0; ++z) {
+                        unsigned int spins = 0;
+                        unsigned long long t0 = 0;
+                        for (;;) {
+                            const unsigned int v = (unsigned int)ld_sc1(progress + z);
+                            if ((v >> 12) == (epoch & 0xFFFFFu) && (int)(v & 0xFFFu) >= k - 1) break;
+                            if ((++spins & 255u) == 0) {
+                                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                                if ((unsigned int)ld_sc1(failw) == fail_tag) { cnt[2] = 1; break; }
+                                if (t0 == 0) t0 = now;
+                                else if (now - t0 > 100000000ULL) { cnt[2] = 1; break; }
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (cnt[2]) { dead = true; break; }
+                for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; st_sc1(LTg + (size_t)c * Mpad + i, LT[c * Mpad + i]); }
+                if (tid < PB * (PB + 1)) st_sc1((T*)(slot + 4 + 3 * PB) + tid, L11[tid]);
+                if (tid < PB) { st_sc1(slot + 4 + tid, src[tid]); st_sc1(slot + 4 + PB + tid, tid < ne ? xdst[tid] : 0); st_sc1(slot + 4 + 2 * PB + tid, tid < ne ? xsrc[tid] : 0); }
+                if (tid == 0) { st_sc1(slot + 1, ne); st_sc1(slot + 2, cnt[1]); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) { st_sc1(slot, (int)luw_tag(epoch & 0xFFFFFu, k)); st_sc1(progress + y, (int)luw_tag(epoch & 0xFFFFFu, k)); }
+            }
+            if (first_zero == 0 && cnt[1] != 0) first_zero = cnt[1];
+        } else {
+            // ---- take the message of panel k ----
+            if (tid == 0) {
+                if (!luw_wait_eq(slot, luw_tag(epoch & 0xFFFFFu, k), failw, fail_tag)) cnt[2] = 1;
+            }
+            __syncthreads();
+            if (cnt[2]) { dead = true; break; }
+            for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; LT[c * Mpad + i] = ld_sc1(LTg + (size_t)c * Mpad + i); }
+            if (tid < PB * (PB + 1)) L11[tid] = ld_sc1((const T*)(slot + 4 + 3 * PB) + tid);
+            if (tid < PB) { src[tid] = ld_sc1(slot + 4 + tid); xdst[tid] = ld_sc1(slot + 4 + PB + tid); xsrc[tid] = ld_sc1(slot + 4 + 2 * PB + tid); }
+            if (tid == 0) { cnt[3] = ld_sc1(slot + 1); const int z = ld_sc1(slot + 2); if (z != 0 && cnt[1] == 0) cnt[1] = z; }
+            __syncthreads();
+            ne = __builtin_amdgcn_readfirstlane(cnt[3]);
+            if (first_zero == 0 && cnt[1] != 0) first_zero = cnt[1];
+            if (tid == 0) st_sc1(progress + y, (int)luw_tag(epoch & 0xFFFFFu, k));
+        }
+        __syncthreads();
+        bool anyswap = ne > 0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if (j < pb && __builtin_amdgcn_readfirstlane(src[j]) != j) anyswap = true;
+
+        // ---- my tiles: interchanges left and right of the panel, U12 = L11^-1 (P A)12 (a column per thread, 32 tiles at a time) ----
+        const int ntile = (N + 31) >> 5;
+        for (int q = tid >> 5; y + q * W < ntile; q += NT / 32) {
+            const int g = y + q * W, col = (g << 5) + (tid & 31);
+            if (col >= N || (col >= k0 && col < k0 + pb)) continue;
+            const bool right = col >= k0 + pb;
+            if (!right && !anyswap) continue;
+            T* Ac = A + (size_t)k0 * ld + col;
+            T top[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) top[j] = (j < pb) ? Ac[(size_t)src[j] * ld] : T(0);
+            {
+                T ext[PB];
+#pragma unroll
+                for (int e = 0; e < PB; ++e) ext[e] = (e < ne) ? Ac[(size_t)xsrc[e] * ld] : T(0);
+#pragma unroll
+                for (int e = 0; e < PB; ++e)
+                    if (e < ne) Ac[(size_t)xdst[e] * ld] = ext[e];
+            }
+            if (right) {
+#pragma unroll
+                for (int j = 0; j < PB; ++j) {
+#pragma unroll
+                    for (int i = j + 1; i < PB; ++i) top[i] -= L11[i * (PB + 1) + j] * top[j];
+                }
+#pragma unroll
+                for (int j = 0; j < PB; ++j) UPt[(q * PB + j) * 32 + (tid & 31)] = top[j];
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+                if (j < pb && (right || src[j] != j)) Ac[(size_t)j * ld] = top[j];
+        }
+        __syncthreads();
+
+        // ---- trailing update of my tiles: A22[:, tile] -= L21 U12[:, tile] (32 x 32 tiles on the matrix cores, a tile per wave) ----
+        if (M2 > 0) {
+            const int c_lo = k0 + pb;
+            const int q0 = (gk >= y) ? (gk - y + W - 1) / W : 0;          // my first tile at or right of the panel's
+            const int nti = (M2 + 31) >> 5;
+            const int li = lane & 31, lh = lane >> 5;
+            int nq = 0;
+            for (int q = q0; y + q * W < ntile; ++q) ++nq;
+            for (int t = __builtin_amdgcn_readfirstlane(w); t < nq * nti; t += NT / 64) {
+                const int qq = q0 + t / nti, ti = t % nti;
+                const int g = y + qq * W, c0 = g << 5;
+                if (c0 + 31 < c_lo) continue;                              // (the panel's own tile may have nothing right of it)
+                const int i0 = ti << 5;
+                const int col = c0 + li;
+                const bool colok = col >= c_lo && col < N;
+                const int rlim = M2 - i0 - 4 * lh;
+                T* base = A + (size_t)(c_lo + i0) * ld + c0;
+                const int voff = 4 * lh * ld + li;
+                f32x16 cur;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int qrow = (q & 3) + 8 * (q >> 2);
+                    cur[q] = (colok && qrow < rlim) ? base[(size_t)qrow * ld + voff] : 0.f;
+                }
+                const float* lt = LT + i0 + li + lh * Mpad;
+                const float* up = UPt + (qq * PB + lh) * 32 + li;
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < PB; kk += 2) {
+                    const float a = (i0 + li < M2) ? lt[kk * Mpad] : 0.f;
+                    const float bq = colok ? up[kk * 32] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+                }
+                cur -= acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int qrow = (q & 3) + 8 * (q >> 2);
+                    if (colok && qrow < rlim) base[(size_t)qrow * ld + voff] = cur[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (dead) {
+        if (tid == 0) { st_sc1(failw, (int)fail_tag); info_all[b] = -7; }
+        return;
+    }
+    if (tid == 0 && y == 0 && first_zero != 0) info_all[b] = first_zero;
+}
+
+}  // namespace lqp

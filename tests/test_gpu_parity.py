@@ -157,6 +157,33 @@ def test_inverse_from_the_packed_factor(dev, N, B, dtype):
     assert float((A @ X.cpu().double() - eye).abs().max()) < (5e-4 if dtype == torch.float32 else 1e-10)
 
 
+@pytest.mark.parametrize("N,B", [(1100, 3), (1500, 8), (2048, 2), (1030, 5)])
+def test_lu_wide_matches_one_workgroup(dev, monkeypatch, N, B):
+    """csrc/lqp_lu_wide.hpp: above 1024 rows, float32, the batch leaving the chip idle: the pivoted LU on W = #CUs / B workgroups per
+    matrix (32-column tiles owned cyclically, the factored panel handed round as a message) against the one-workgroup kernel
+    (LQP_LU_WIDE=0): the same pivots and, the arithmetic per element being the same, the same factor bit for bit; P A = L U.
+    A singular matrix reports the same first zero pivot."""
+    torch.manual_seed(N)
+    A = torch.randn(B, N, N)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_LU_WIDE", flag)
+        LU, piv = lu_layer.lu_factor(A.to(dev))
+        out[flag] = (LU.cpu(), piv.cpu())
+    assert torch.equal(out["1"][1], out["0"][1])
+    assert torch.equal(out["1"][0], out["0"][0])
+    Pm, Lm, Um = torch.lu_unpack(out["1"][0].double(), out["1"][1])
+    assert float((Pm @ Lm @ Um - A.double()).abs().max()) / float(A.abs().max()) < 1e-4
+    A[:, :, 700] = 0.0
+    msgs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_LU_WIDE", flag)
+        with pytest.raises(RuntimeError) as e:
+            lu_layer.lu_factor(A.to(dev))
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and "701" in msgs[0], msgs
+
+
 @pytest.mark.parametrize("N,B,dtype", [(1025, 2, torch.float64), (1100, 2, torch.float32), (1501, 2, torch.float64),
                                        (2048, 1, torch.float32), (2048, 1, torch.float64)])
 def test_lu_factor_above_1024(dev, N, B, dtype):

@@ -33,7 +33,7 @@ GROUPS = [
     ("loop_hot", lambda n: "k_admm_loop<" in n),
     ("dense", lambda n: "k_lu_inverse<" in n or "k_admm_loop_dense<" in n),
     ("lu2", lambda n: "k_lu_factor2<" in n),
-    ("lu_a", lambda n: re.search(r"k_lu_factor<float, (32|16), true|k_lu_factor_big", n)),
+    ("lu_a", lambda n: re.search(r"k_lu_factor<float, (32|16), true|k_lu_factor_big|k_lu_factor_wide", n)),
     ("lu_b", lambda n: "k_lu_factor<" in n),
     ("spd", lambda n: re.search(r"k_spd_|k_bwd_chol_solve|k_bwd_build_chol", n)),
     ("unroll", lambda n: "k_unroll_" in n or "k_admm_loop_small" in n),
@@ -49,6 +49,7 @@ EXTRA = [
     "void lqp::k_lu_inverse<double>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
     "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
     "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
+    "void lqp::k_lu_factor_wide<0>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int)",
     "void lqp::k_lu_factor_big<float>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_lu_factor_big<double>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_unroll_sweep<1>(lqp::FwdParams<float>, lqp::UnrollParams)",
