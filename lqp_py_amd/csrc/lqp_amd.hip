@@ -303,7 +303,7 @@ int launch_lu_wide(hipStream_t st, float* M, int B, int N, int ld, size_t mstrid
     const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
     { ProfScope ps(st, PC_LU);
       hipLaunchKernelGGL(fn, dim3(W * B), dim3(LQP_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, (int*)scr,
-                         2 * scr_stride, epoch, B); }
+                         2 * scr_stride, epoch, B, knobs().dbg_setup ? nullptr : g_lu_dbg); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 

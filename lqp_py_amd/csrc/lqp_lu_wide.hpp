@@ -46,10 +46,12 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                                                            int* __restrict__ piv, const int pstride, int* __restrict__ info_all,
                                                            const int* __restrict__ gate, const int* __restrict__ Nvec,
                                                            int* __restrict__ scr_all, const size_t scr_stride, const unsigned int epoch,
-                                                           const int B) {
+                                                           const int B, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     typedef float T;
-    constexpr int PB = LUW_PB, R = 2, NT = LQP_NT;
+    constexpr int PB = LUW_PB, NT = LQP_NT;
+    constexpr int R = 8, NTP = 256;           // the panel: waves 0..3, eight rows per thread (sixteen waves with two rows each share four SIMDs:
+                                              // 7 k cycles per column; four waves alone on theirs: see DESIGN.md)
     if (gate && *gate == 0) return;
     const int b = (int)blockIdx.x % B, y = (int)blockIdx.x / B, W = (int)gridDim.x / B;
     const int N = Nvec ? Nvec[b] : Nuni;
@@ -84,6 +86,12 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
     const unsigned int fail_tag = ((epoch & 0xFFFFFu) << 12) | 0xFFFu;
     int first_zero = 0;
     bool dead = false;
+    // debug (lqp_debug_set_lu_counters): cycles of workgroup 1's thread 0 in [0] panel [1] slot wait [2] publish [3] message wait
+    // [4] message copy [5] interchanges + U12 [6] trailing update [7] total
+    unsigned long long dbt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dts = 0;
+    const bool dbg_on = dbg != nullptr && y == (W > 1 ? 1 : 0) && tid == 0;
+    const unsigned long long dt_all = dbg_on ? clock64() : 0;
+#define LUW_STAMP(i) do { if (dbg_on) { const unsigned long long t_ = clock64(); dbt[i] += t_ - dts; dts = t_; } } while (0)
 
     const int npanels = (N + PB - 1) / PB;
     for (int k = 0; k < npanels; ++k) {
@@ -94,36 +102,51 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
         int* slot = scr + LUW_HDR + (size_t)(k & 1) * SL;
         T* LTg = (T*)(slot + LUW_MSG);
         int ne = 0;
+        if (dbg_on) dts = clock64();
         if (y == owner) {
             // ---- the panel: my own columns, two rows per thread (the one-workgroup kernel's code) ----
             {
                 vec row4[R][PB / 4];
                 int curpos[R];
                 bool done[R];
-                const bool wact = wbase < M;
+                const bool wact = wbase < M && tid < NTP;
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
-                    const int r = tid + q * NT;
-                    const bool act = r < M;
+                    const int r = tid + q * NTP;
+                    const bool act = r < M && tid < NTP;
                     curpos[q] = r;
                     done[q] = !act;
+                    // (a full panel is two 16-B pieces of a row, 32-B aligned: element by element every lane asked for its line
+                    //  eight times -- 2 MB of requests per panel through one CU, 30 k of the panel's 70 k cycles)
+                    if (pb == PB) {
+                        const vec* rp = (const vec*)(A + (size_t)(k0 + (act ? r : 0)) * ld + k0);
+                        const vec a0 = rp[0], a1 = rp[1];
 #pragma unroll
-                    for (int c = 0; c < PB; ++c)
-                        row4[q][c >> 2].v[c & 3] = (act && c < pb) ? A[(size_t)(k0 + r) * ld + k0 + c] : T(0);
+                        for (int e = 0; e < 4; ++e) { row4[q][0].v[e] = act ? a0.v[e] : T(0); row4[q][1].v[e] = act ? a1.v[e] : T(0); }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < PB; ++c)
+                            row4[q][c >> 2].v[c & 3] = (act && c < pb) ? A[(size_t)(k0 + r) * ld + k0 + c] : T(0);
+                    }
                 }
                 if (tid == 0) *cnt = 0;
                 {
                     const PanelLds<T> S{rowP, wval, wrcp, widx, wtid, pidx, cnt};
-                    lu_panel_columns_r<T, PB, R, NT>(row4, curpos, done, wact, pb, k0, S);
+                    lu_panel_columns_r<T, PB, R, NTP>(row4, curpos, done, wact, pb, k0, S);
                 }
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
-                    const int r = tid + q * NT;
-                    if (r < M) {
+                    const int r = tid + q * NTP;
+                    if (r < M && tid < NTP) {
                         const int cp = curpos[q];
+                        if (pb == PB) {
+                            vec* wp = (vec*)(A + (size_t)(k0 + cp) * ld + k0);
+                            wp[0] = row4[q][0]; wp[1] = row4[q][1];
+                        } else {
 #pragma unroll
-                        for (int c = 0; c < PB; ++c)
-                            if (c < pb) A[(size_t)(k0 + cp) * ld + k0 + c] = row4[q][c >> 2].v[c & 3];
+                            for (int c = 0; c < PB; ++c)
+                                if (c < pb) A[(size_t)(k0 + cp) * ld + k0 + c] = row4[q][c >> 2].v[c & 3];
+                        }
                         if (cp < pb) {
 #pragma unroll
                             for (int c = 0; c < PB; ++c) L11[cp * (PB + 1) + c] = row4[q][c >> 2].v[c & 3];
@@ -143,26 +166,26 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
             __syncthreads();
             if (tid < pb) ipiv[k0 + tid] = k0 + pidx[tid] + 1;
             ne = __builtin_amdgcn_readfirstlane(*cnt);
+            LUW_STAMP(0);
             if (W > 1) {
                 // ---- publish: nobody may still be reading message k - 2 out of this slot ----
-                if (k >= 2 && tid == 0) {
-                    for (int z = 0; z < W && cnt[2] == 0; ++z) {
-                        unsigned int spins = 0;
-                        unsigned long long t0 = 0;
-                        for (;;) {
-                            const unsigned int v = (unsigned int)ld_sc1(progress + z);
-                            if ((v >> 12) == (epoch & 0xFFFFFu) && (int)(v & 0xFFFu) >= k - 1) break;
-                            if ((++spins & 255u) == 0) {
-                                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                                if ((unsigned int)ld_sc1(failw) == fail_tag) { cnt[2] = 1; break; }
-                                if (t0 == 0) t0 = now;
-                                else if (now - t0 > 100000000ULL) { cnt[2] = 1; break; }
-                            }
-                            __builtin_amdgcn_s_sleep(1);
+                if (k >= 2 && tid < W) {                   // (a lane per workgroup: one after the other the W polls were 30 us a panel)
+                    unsigned int spins = 0;
+                    unsigned long long t0 = 0;
+                    for (;;) {
+                        const unsigned int v = (unsigned int)ld_sc1(progress + tid);
+                        if ((v >> 12) == (epoch & 0xFFFFFu) && (int)(v & 0xFFFu) >= k - 1) break;
+                        if ((++spins & 255u) == 0) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                            if ((unsigned int)ld_sc1(failw) == fail_tag) { cnt[2] = 1; break; }
+                            if (t0 == 0) t0 = now;
+                            else if (now - t0 > 100000000ULL) { cnt[2] = 1; break; }
                         }
+                        __builtin_amdgcn_s_sleep(1);
                     }
                 }
                 __syncthreads();
+                LUW_STAMP(1);
                 if (cnt[2]) { dead = true; break; }
                 for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; st_sc1(LTg + (size_t)c * Mpad + i, LT[c * Mpad + i]); }
                 if (tid < PB * (PB + 1)) st_sc1((T*)(slot + 4 + 3 * PB) + tid, L11[tid]);
@@ -171,6 +194,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) { st_sc1(slot, (int)luw_tag(epoch & 0xFFFFFu, k)); st_sc1(progress + y, (int)luw_tag(epoch & 0xFFFFFu, k)); }
+                LUW_STAMP(2);
             }
             if (first_zero == 0 && cnt[1] != 0) first_zero = cnt[1];
         } else {
@@ -179,6 +203,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                 if (!luw_wait_eq(slot, luw_tag(epoch & 0xFFFFFu, k), failw, fail_tag)) cnt[2] = 1;
             }
             __syncthreads();
+            LUW_STAMP(3);
             if (cnt[2]) { dead = true; break; }
             for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; LT[c * Mpad + i] = ld_sc1(LTg + (size_t)c * Mpad + i); }
             if (tid < PB * (PB + 1)) L11[tid] = ld_sc1((const T*)(slot + 4 + 3 * PB) + tid);
@@ -188,6 +213,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
             ne = __builtin_amdgcn_readfirstlane(cnt[3]);
             if (first_zero == 0 && cnt[1] != 0) first_zero = cnt[1];
             if (tid == 0) st_sc1(progress + y, (int)luw_tag(epoch & 0xFFFFFu, k));
+            LUW_STAMP(4);
         }
         __syncthreads();
         bool anyswap = ne > 0;
@@ -228,6 +254,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                 if (j < pb && (right || src[j] != j)) Ac[(size_t)j * ld] = top[j];
         }
         __syncthreads();
+        LUW_STAMP(5);
 
         // ---- trailing update of my tiles: A22[:, tile] -= L21 U12[:, tile] (32 x 32 tiles on the matrix cores, a tile per wave) ----
         if (M2 > 0) {
@@ -273,7 +300,13 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
             }
         }
         __syncthreads();
+        LUW_STAMP(6);
     }
+    if (dbg_on) {
+        dbt[7] = clock64() - dt_all;
+        for (int q = 0; q < 8; ++q) dbg[(size_t)b * 16 + q] = dbt[q];
+    }
+#undef LUW_STAMP
     if (dead) {
         if (tid == 0) { st_sc1(failw, (int)fail_tag); info_all[b] = -7; }
         return;

@@ -22,6 +22,14 @@ for N in sizes:
     M = torch.randn(B, N, N).to(dev)
     os.environ["LQP_LU_WIDE"] = "0"; LU0, P0, ms0 = timed(M)
     os.environ["LQP_LU_WIDE"] = "1"; LU1, P1, ms1 = timed(M)
+    lib = _lib.load()
+    dbg = torch.zeros(B * 16, dtype=torch.int64, device=dev)
+    lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
+    lu_layer.lu_factor(M); torch.cuda.synchronize()
+    lib.lqp_debug_set_lu_counters(None)
+    c = dbg.view(B, 16)[:, :8].double().mean(0).tolist()
+    names = ["panel", "slot-wait", "publish", "msg-wait", "msg-copy", "swap+U12", "trailing", "total"]
+    print("   workgroup 1, k cycles: " + "  ".join(f"{n} {v/1e3:.0f}" for n, v in zip(names, c)))
     same_p = bool(torch.equal(P0, P1)); d = float((LU0 - LU1).abs().max())
     nbad = int((LU0 != LU1).sum())
     print(f"N={N} B={B}: one-wg {ms0:.2f} ms  wide {ms1:.2f} ms | pivots equal {same_p}  max|diff| {d:.2e}  differing entries {nbad}", flush=True)
