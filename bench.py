@@ -576,9 +576,10 @@ def main():
         more["b128_n500_backward_kkt"] = fwd_bwd_rate(piped(backward='kkt'), b128, 10, warm=3)
         more["b128_n500_unroll"] = fwd_bwd_rate(L.SolveBoxQP(control=L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False, unroll=True)),
                                                 b128, 10, warm=3)
+        more["b128_n500_unroll"]["profile"] = profile_twin("unroll")
         del b128
         # above the on-chip tiers (n + m > 1024: pivoted LU with two panel rows per thread, factor streamed from HBM / L2)
-        more["b8_n1500_fwd_bwd_lu_tier"] = fwd_bwd_rate(piped(), device_batch(8, 1500, 80), 2, warm=1)
+        more["b8_n1500_fwd_bwd_lu_tier"] = dict(fwd_bwd_rate(piped(), device_batch(8, 1500, 80), 3, warm=1), profile=profile_twin("n1500"))
         from lqp_py_amd.synthetic import create_hard_qp_data
         hard = create_hard_qp_data(250, 0.85, range(B), dtype=torch.float64, device=dev)      # prob 0.85 (experiment_1_hard.py:15), m = round(sqrt(250)) = 16
         more["b128_n250_m16_hard_fp64"] = dict(fwd_bwd_rate(piped(), hard, 20, warm=5), dtype="f64", linsolve="lu (pivoted LU: f64)",

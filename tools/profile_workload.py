@@ -11,6 +11,8 @@ workloads (BASELINE.json configs and the rows of bench.py's `other_*` tables; in
   config5shard  batch=1024 dz=500 m=1, forward + backward                (the per-GPU shard of configs[4])
   b16 / b32 / b64  the per-GPU shard of batch=128 at 8 / 4 / 2 GPUs, forward + backward
   hard64        experiments/experiment_1_hard.py: n=250, m=16, float64, forward + backward
+  unroll        batch=128 dz=500 m=1 with control['unroll']=True (the reverse sweep + the native scaling chain), forward + backward
+  n1500         batch=8 dz=1500 m=1: the LU tier above 1024 rows (several workgroups per matrix in the factorisation)
 """
 import argparse, os, sys, time
 import torch
@@ -44,6 +46,8 @@ WORKLOADS = {   # name: (B, n, with_eq, backward, control extras, dtype)
     "b32": (32, 500, True, True, {}, "f32"),
     "b64": (64, 500, True, True, {}, "f32"),
     "hard64": (128, 250, True, True, {}, "f64"),
+    "unroll": (128, 500, True, True, {"unroll": True, "sync": True}, "f32"),
+    "n1500": (8, 1500, True, True, {}, "f32"),
 }
 
 
@@ -59,7 +63,7 @@ def main():
         batch = create_hard_qp_data(n, 0.85, range(B), dtype=torch.float64, device=dev)
     else:
         batch = device_batch(dev, B, n, 4242 + n + B, with_eq)
-    ctl = dict(L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False), sync=False, **extra)
+    ctl = dict(dict(L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False), sync=False), **extra)
     layer = L.SolveBoxQP(control=ctl)
     cot = torch.ones_like(batch[1])
 
