@@ -281,22 +281,23 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
-// Several workgroups per matrix above 1024 rows (lqp_lu_wide.hpp, float32) when the batch leaves most of the chip idle: W = what
-// fits resident / B workgroups (>= 2) own the 32-column tiles cyclically.  `scr`: 4 * luw_scratch_words(N) bytes per problem.
+// Several workgroups per matrix above 1024 rows (lqp_lu_wide.hpp) when the batch leaves most of the chip idle: W = what fits
+// resident / B workgroups (>= 2) own the 128-byte column tiles cyclically.  `scr`: 4 * luw_scratch_words<T>(N) bytes per problem.
 // Returns -1: not applicable, take the one-workgroup kernel.
-int launch_lu_wide(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
+template <typename T>
+int launch_lu_wide(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                    const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
-    if (!scr || 2 * scr_stride < luw_scratch_words(N) || N <= 1024 || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
+    if (!scr || 2 * scr_stride < luw_scratch_words<T>(N) || N <= 1024 || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
         (((uintptr_t)M) % 128) != 0)
         return -1;
     int dev = 0, cus = 0, per_cu = 0;
-    auto fn = k_lu_factor_wide<>;
-    const int lds = LuLds<float, LUW_PB>(round_up(N, 64)).total;
+    auto fn = k_lu_factor_wide<T>;
+    const int lds = LuLds<T, luw_pb<T>()>(round_up(N, 64)).total;
     if (!current_device_cus(&dev, &cus) || ensure_lds((const void*)fn, lds) != LQP_OK ||
         !blocks_per_cu(&per_cu, fn, LQP_NT, lds, dev) || per_cu < 1)
         return -1;
     int W = (cus * per_cu) / B;
-    const int ntile = (N + 31) / 32;
+    const int ntile = (N + luw_tw<T>() - 1) / luw_tw<T>();
     if (W > ntile) W = ntile;
     if (W > LUW_HDR - 2) W = LUW_HDR - 2;
     if (W < 2) return -1;
@@ -310,7 +311,7 @@ int launch_lu_wide(hipStream_t st, float* M, int B, int N, int ld, size_t mstrid
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr, unsigned long long* scr = nullptr, size_t scr_stride = 0) {
     if (N > 1024) {
-        const int rw = launch_lu_wide(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
+        const int rw = launch_lu_wide<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
         if (rw >= 0) return rw;
         return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     }
@@ -335,7 +336,11 @@ int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, in
 }
 int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr, unsigned long long* scr = nullptr, size_t scr_stride = 0) {
-    if (N > 1024) return launch_lu_big<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
+    if (N > 1024) {
+        const int rw = launch_lu_wide<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
+        if (rw >= 0) return rw;
+        return launch_lu_big<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
+    }
     { const int r2 = launch_lu2<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
       if (r2 >= 0) return r2; }
     const int nt = lu_threads<double>(N);
@@ -1336,7 +1341,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
 // ---------------------------------------------------------------------------
 // LU / solve / KKT entry points
 // ---------------------------------------------------------------------------
-inline size_t lu_scratch_u64(int N) { return N > 1024 ? (luw_scratch_words(N) + 1) / 2 : (size_t)LU2_SCR_WORDS; }
+inline size_t lu_scratch_u64(int N) { return N > 1024 ? (luw_scratch_words<double>(N) + 1) / 2 : (size_t)LU2_SCR_WORDS; }
 template <typename T>
 size_t carve_lu(void* ws, int B, int N, T*& M, int*& piv, unsigned long long*& scr) {
     const int Np = round_up(N, LQP_NB);

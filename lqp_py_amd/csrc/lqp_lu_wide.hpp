@@ -17,11 +17,13 @@
 
 namespace lqp {
 
-constexpr int LUW_PB = 8;                     // panel width (float32: the one-workgroup kernel's)
+template <typename T> __host__ __device__ constexpr int luw_pb() { return lu_big_panel<T>(); }     // panel width: the one-workgroup kernel's (8 | 4)
+template <typename T> __host__ __device__ constexpr int luw_tw() { return 128 / (int)sizeof(T); }   // columns of a tile: one 128-B line per row (32 | 16)
 constexpr int LUW_HDR = 64;                   // progress words (W <= 64)
-constexpr int LUW_MSG = 128;                  // words of a message head: go | ne | zero pivot | fail | src[8] | xdst[8] | xsrc[8] | L11[72]
-__host__ __device__ inline size_t luw_slot_words(int Mpad) { return (size_t)LUW_MSG + (size_t)LUW_PB * Mpad; }
-__host__ __device__ inline size_t luw_scratch_words(int N) { return (size_t)LUW_HDR + 2 * luw_slot_words(round_up(N, 64)); }
+constexpr int LUW_MSG = 128;                  // 4-byte words of a message head: go | ne | zero pivot | - | src[PB] | xdst[PB] | xsrc[PB] | ... | [32 ..) L11[PB (PB + 1)]
+constexpr int LUW_L11 = 32;
+template <typename T> __host__ __device__ inline size_t luw_slot_words(int Mpad) { return (size_t)LUW_MSG + (size_t)luw_pb<T>() * Mpad * (sizeof(T) / 4); }
+template <typename T> __host__ __device__ inline size_t luw_scratch_words(int N) { return (size_t)LUW_HDR + 2 * luw_slot_words<T>(round_up(N, 64)); }
 
 __device__ __forceinline__ unsigned int luw_tag(const unsigned int epoch, const int k) { return (epoch << 12) | (unsigned int)(k + 1); }
 
@@ -41,15 +43,14 @@ __device__ __forceinline__ bool luw_wait_eq(const int* p, const unsigned int wan
     }
 }
 
-template <int LQP_ANY = 0>
-__global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ Mall, const int Nuni, const int ld, const size_t mstride,
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(T* __restrict__ Mall, const int Nuni, const int ld, const size_t mstride,
                                                            int* __restrict__ piv, const int pstride, int* __restrict__ info_all,
                                                            const int* __restrict__ gate, const int* __restrict__ Nvec,
                                                            int* __restrict__ scr_all, const size_t scr_stride, const unsigned int epoch,
                                                            const int B, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
-    typedef float T;
-    constexpr int PB = LUW_PB, NT = LQP_NT;
+    constexpr int PB = luw_pb<T>(), NT = LQP_NT, TW = luw_tw<T>(), NV = PB / 4;
     constexpr int R = 8, NTP = 256;           // the panel: waves 0..3, eight rows per thread (sixteen waves with two rows each share four SIMDs:
                                               // 7 k cycles per column; four waves alone on theirs: see DESIGN.md)
     if (gate && *gate == 0) return;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
     int* progress = scr;                                  // [W]
     int* failw = scr + LUW_HDR - 1;                       // sticky: somebody gave up waiting (tagged with the epoch)
-    const size_t SL = luw_slot_words(Mpad);
+    const size_t SL = luw_slot_words<T>(Mpad);
     if (tid == 0) { cnt[1] = 0; cnt[2] = 0; }
     if (tid < 2 * LQP_NW) wval[tid] = T(-2);
     if (tid == 0 && y == 0) info_all[b] = 0;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
         const int k0 = k * PB;
         const int pb = (N - k0 < PB) ? (N - k0) : PB;
         const int M = N - k0, M2 = M - pb;
-        const int gk = k0 >> 5, owner = gk % W;
+        const int gk = k0 / TW, owner = gk % W;
         int* slot = scr + LUW_HDR + (size_t)(k & 1) * SL;
         T* LTg = (T*)(slot + LUW_MSG);
         int ne = 0;
@@ -120,9 +121,12 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                     //  eight times -- 2 MB of requests per panel through one CU, 30 k of the panel's 70 k cycles)
                     if (pb == PB) {
                         const vec* rp = (const vec*)(A + (size_t)(k0 + (act ? r : 0)) * ld + k0);
-                        const vec a0 = rp[0], a1 = rp[1];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { row4[q][0].v[e] = act ? a0.v[e] : T(0); row4[q][1].v[e] = act ? a1.v[e] : T(0); }
+                        for (int v = 0; v < NV; ++v) {
+                            const vec a = rp[v];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) row4[q][v].v[e] = act ? a.v[e] : T(0);
+                        }
                     } else {
 #pragma unroll
                         for (int c = 0; c < PB; ++c)
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                         const int cp = curpos[q];
                         if (pb == PB) {
                             vec* wp = (vec*)(A + (size_t)(k0 + cp) * ld + k0);
-                            wp[0] = row4[q][0]; wp[1] = row4[q][1];
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) wp[v] = row4[q][v];
                         } else {
 #pragma unroll
                             for (int c = 0; c < PB; ++c)
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                 LUW_STAMP(1);
                 if (cnt[2]) { dead = true; break; }
                 for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; st_sc1(LTg + (size_t)c * Mpad + i, LT[c * Mpad + i]); }
-                if (tid < PB * (PB + 1)) st_sc1((T*)(slot + 4 + 3 * PB) + tid, L11[tid]);
+                if (tid < PB * (PB + 1)) st_sc1((T*)(slot + LUW_L11) + tid, L11[tid]);
                 if (tid < PB) { st_sc1(slot + 4 + tid, src[tid]); st_sc1(slot + 4 + PB + tid, tid < ne ? xdst[tid] : 0); st_sc1(slot + 4 + 2 * PB + tid, tid < ne ? xsrc[tid] : 0); }
                 if (tid == 0) { st_sc1(slot + 1, ne); st_sc1(slot + 2, cnt[1]); }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
             LUW_STAMP(3);
             if (cnt[2]) { dead = true; break; }
             for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; LT[c * Mpad + i] = ld_sc1(LTg + (size_t)c * Mpad + i); }
-            if (tid < PB * (PB + 1)) L11[tid] = ld_sc1((const T*)(slot + 4 + 3 * PB) + tid);
+            if (tid < PB * (PB + 1)) L11[tid] = ld_sc1((const T*)(slot + LUW_L11) + tid);
             if (tid < PB) { src[tid] = ld_sc1(slot + 4 + tid); xdst[tid] = ld_sc1(slot + 4 + PB + tid); xsrc[tid] = ld_sc1(slot + 4 + 2 * PB + tid); }
             if (tid == 0) { cnt[3] = ld_sc1(slot + 1); const int z = ld_sc1(slot + 2); if (z != 0 && cnt[1] == 0) cnt[1] = z; }
             __syncthreads();
@@ -222,9 +227,9 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
             if (j < pb && __builtin_amdgcn_readfirstlane(src[j]) != j) anyswap = true;
 
         // ---- my tiles: interchanges left and right of the panel, U12 = L11^-1 (P A)12 (a column per thread, 32 tiles at a time) ----
-        const int ntile = (N + 31) >> 5;
-        for (int q = tid >> 5; y + q * W < ntile; q += NT / 32) {
-            const int g = y + q * W, col = (g << 5) + (tid & 31);
+        const int ntile = (N + TW - 1) / TW;
+        for (int q = tid / TW; y + q * W < ntile; q += NT / TW) {
+            const int g = y + q * W, col = g * TW + (tid % TW);
             if (col >= N || (col >= k0 && col < k0 + pb)) continue;
             const bool right = col >= k0 + pb;
             if (!right && !anyswap) continue;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
                     for (int i = j + 1; i < PB; ++i) top[i] -= L11[i * (PB + 1) + j] * top[j];
                 }
 #pragma unroll
-                for (int j = 0; j < PB; ++j) UPt[(q * PB + j) * 32 + (tid & 31)] = top[j];
+                for (int j = 0; j < PB; ++j) UPt[(q * PB + j) * TW + (tid % TW)] = top[j];
             }
 #pragma unroll
             for (int j = 0; j < PB; ++j)
@@ -256,46 +261,80 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(float* __restrict__ M
         __syncthreads();
         LUW_STAMP(5);
 
-        // ---- trailing update of my tiles: A22[:, tile] -= L21 U12[:, tile] (32 x 32 tiles on the matrix cores, a tile per wave) ----
+        // ---- trailing update of my tiles: A22[:, tile] -= L21 U12[:, tile] on the matrix cores, a tile per wave (float32: 32 x 32
+        //      v_mfma_f32_32x32x2; float64: 16 x 16, ONE v_mfma_f64_16x16x4 per tile -- its depth is the panel's width) ----
         if (M2 > 0) {
             const int c_lo = k0 + pb;
             const int q0 = (gk >= y) ? (gk - y + W - 1) / W : 0;          // my first tile at or right of the panel's
-            const int nti = (M2 + 31) >> 5;
-            const int li = lane & 31, lh = lane >> 5;
             int nq = 0;
             for (int q = q0; y + q * W < ntile; ++q) ++nq;
-            for (int t = __builtin_amdgcn_readfirstlane(w); t < nq * nti; t += NT / 64) {
-                const int qq = q0 + t / nti, ti = t % nti;
-                const int g = y + qq * W, c0 = g << 5;
-                if (c0 + 31 < c_lo) continue;                              // (the panel's own tile may have nothing right of it)
-                const int i0 = ti << 5;
-                const int col = c0 + li;
-                const bool colok = col >= c_lo && col < N;
-                const int rlim = M2 - i0 - 4 * lh;
-                T* base = A + (size_t)(c_lo + i0) * ld + c0;
-                const int voff = 4 * lh * ld + li;
-                f32x16 cur;
+            if constexpr (sizeof(T) == 4) {
+                const int nti = (M2 + 31) >> 5;
+                const int li = lane & 31, lh = lane >> 5;
+                for (int t = __builtin_amdgcn_readfirstlane(w); t < nq * nti; t += NT / 64) {
+                    const int qq = q0 + t / nti, ti = t % nti;
+                    const int g = y + qq * W, c0 = g << 5;
+                    if (c0 + 31 < c_lo) continue;                              // (the panel's own tile may have nothing right of it)
+                    const int i0 = ti << 5;
+                    const int col = c0 + li;
+                    const bool colok = col >= c_lo && col < N;
+                    const int rlim = M2 - i0 - 4 * lh;
+                    float* base = (float*)A + (size_t)(c_lo + i0) * ld + c0;
+                    const int voff = 4 * lh * ld + li;
+                    f32x16 cur;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int qrow = (q & 3) + 8 * (q >> 2);
-                    cur[q] = (colok && qrow < rlim) ? base[(size_t)qrow * ld + voff] : 0.f;
+                    for (int q = 0; q < 16; ++q) {
+                        const int qrow = (q & 3) + 8 * (q >> 2);
+                        cur[q] = (colok && qrow < rlim) ? base[(size_t)qrow * ld + voff] : 0.f;
+                    }
+                    const float* lt = (const float*)LT + i0 + li + lh * Mpad;
+                    const float* up = (const float*)UPt + (qq * PB + lh) * 32 + li;
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < PB; kk += 2) {
+                        const float a = (i0 + li < M2) ? lt[kk * Mpad] : 0.f;
+                        const float bq = colok ? up[kk * 32] : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+                    }
+                    cur -= acc;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int qrow = (q & 3) + 8 * (q >> 2);
+                        if (colok && qrow < rlim) base[(size_t)qrow * ld + voff] = cur[q];
+                    }
                 }
-                const float* lt = LT + i0 + li + lh * Mpad;
-                const float* up = UPt + (qq * PB + lh) * 32 + li;
-                f32x16 acc;
+            } else {
+                // (operand and result layout of v_mfma_f64_16x16x4_f64 as measured, tools/microbench/mfma_f64_layout.hip:
+                //  A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D register q <-> row 4 q + (l >> 4), column l & 15)
+                static_assert(sizeof(T) == 4 || PB == 4, "one matrix instruction per tile");
+                const int nti = (M2 + 15) >> 4;
+                const int li = lane & 15, lg = lane >> 4;
+                for (int t = __builtin_amdgcn_readfirstlane(w); t < nq * nti; t += NT / 64) {
+                    const int qq = q0 + t / nti, ti = t % nti;
+                    const int g = y + qq * W, c0 = g << 4;
+                    if (c0 + 15 < c_lo) continue;
+                    const int i0 = ti << 4;
+                    const int col = c0 + li;
+                    const bool colok = col >= c_lo && col < N;
+                    double* base = (double*)A + (size_t)(c_lo + i0) * ld + c0 + li;
+                    f64x4 cur;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 4 * q + lg;
+                        cur[q] = (colok && i0 + row < M2) ? base[(size_t)row * ld] : 0.0;
+                    }
+                    const double a = (i0 + li < M2) ? ((const double*)LT)[lg * Mpad + i0 + li] : 0.0;
+                    const double bq = colok ? ((const double*)UPt)[(qq * PB + lg) * 16 + li] : 0.0;
+                    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
+                    cur -= acc;
 #pragma unroll
-                for (int kk = 0; kk < PB; kk += 2) {
-                    const float a = (i0 + li < M2) ? lt[kk * Mpad] : 0.f;
-                    const float bq = colok ? up[kk * 32] : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
-                }
-                cur -= acc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int qrow = (q & 3) + 8 * (q >> 2);
-                    if (colok && qrow < rlim) base[(size_t)qrow * ld + voff] = cur[q];
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 4 * q + lg;
+                        if (colok && i0 + row < M2) base[(size_t)row * ld] = cur[q];
+                    }
                 }
             }
         }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Wide LU (csrc/lqp_lu_wide.hpp) against the one-workgroup kernel above 1024 rows: bits, pivots, time.  Usage: [B] [N ...]"""
+"""Wide LU (csrc/lqp_lu_wide.hpp) against the one-workgroup kernel above 1024 rows: bits, pivots, time.  Usage: [f32|f64] [B] [N ...]"""
 import os, sys
 os.environ.setdefault("LQP_ENV_NOCACHE", "1")
 import torch
@@ -7,8 +7,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO)
 from lqp_py_amd import _lib, lu_layer
 dev = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-sizes = [int(a) for a in sys.argv[2:]] or [1100, 1500, 2048]
+dt = torch.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else torch.float32
+args = [a for a in sys.argv[1:] if a not in ("f32", "f64")]
+B = int(args[0]) if args else 8
+sizes = [int(a) for a in args[1:]] or [1100, 1500, 2048]
 def timed(M, reps=3):
     lu_layer.lu_factor(M); torch.cuda.synchronize()
     _lib.profile(enable=True, reset=True)
@@ -19,7 +21,7 @@ def timed(M, reps=3):
     return LU, P, pr["lu_factor"][0] / pr["lu_factor"][1]
 for N in sizes:
     torch.manual_seed(N)
-    M = torch.randn(B, N, N).to(dev)
+    M = torch.randn(B, N, N, dtype=dt).to(dev)
     os.environ["LQP_LU_WIDE"] = "0"; LU0, P0, ms0 = timed(M)
     os.environ["LQP_LU_WIDE"] = "1"; LU1, P1, ms1 = timed(M)
     lib = _lib.load()

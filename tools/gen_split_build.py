@@ -49,7 +49,8 @@ EXTRA = [
     "void lqp::k_lu_inverse<double>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
     "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
     "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
-    "void lqp::k_lu_factor_wide<0>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int, unsigned long long*)",
+    "void lqp::k_lu_factor_wide<float>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int, unsigned long long*)",
+    "void lqp::k_lu_factor_wide<double>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int, unsigned long long*)",
     "void lqp::k_lu_factor_big<float>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_lu_factor_big<double>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*)",
     "void lqp::k_unroll_sweep<1>(lqp::FwdParams<float>, lqp::UnrollParams)",
@@ -73,6 +74,7 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_lu_factor_wide<0>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int, unsigned long long*)",
     "void lqp::k_lu_factor_wide<0>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int)",
     "void lqp::k_unroll_scale_fro<0>(float const*, float const*, int, float*)",
     "void lqp::k_admm_loop_lu2<float>(lqp::FwdParams<float>, int, int, int)",
