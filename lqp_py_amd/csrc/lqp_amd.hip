@@ -154,6 +154,7 @@ struct Knobs {
     int loop_split_seg;        // LQP_LOOP_SPLIT_SEG
     int lu2;                   // LQP_LU2
     int lu_wide;               // LQP_LU_WIDE
+    int lu_wide_min;           // LQP_LU_WIDE_MIN: the wide LU above this many rows (experiments; default 1024)
     int lu_mfma;               // LQP_LU_MFMA
     int lu_nt;                 // LQP_LU_NT
     int lu_pb;                 // LQP_LU_PB
@@ -197,6 +198,7 @@ Knobs read_knobs() {
     k.loop_split_seg = env_int("LQP_LOOP_SPLIT_SEG", 1);
     k.lu2 = env_int("LQP_LU2", 1);
     k.lu_wide = env_int("LQP_LU_WIDE", 1);
+    k.lu_wide_min = env_int("LQP_LU_WIDE_MIN", 1024);
     k.lu_mfma = env_int("LQP_LU_MFMA", 1);
     k.lu_nt = env_int("LQP_LU_NT", 0);
     k.lu_pb = env_int("LQP_LU_PB", 0);
@@ -287,7 +289,7 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
 template <typename T>
 int launch_lu_wide(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                    const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
-    if (!scr || 2 * scr_stride < luw_scratch_words<T>(N) || N <= 1024 || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
+    if (!scr || 2 * scr_stride < luw_scratch_words<T>(N) || N <= knobs().lu_wide_min || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
         (((uintptr_t)M) % 128) != 0)
         return -1;
     int dev = 0, cus = 0, per_cu = 0;
@@ -310,11 +312,11 @@ int launch_lu_wide(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, i
 
 int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr, unsigned long long* scr = nullptr, size_t scr_stride = 0) {
-    if (N > 1024) {
+    if (N > 512) {
         const int rw = launch_lu_wide<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
         if (rw >= 0) return rw;
-        return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     }
+    if (N > 1024) return launch_lu_big<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     { const int r2 = launch_lu2<float>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
       if (r2 >= 0) return r2; }
     int nt = lu_threads<float>(N);
@@ -336,11 +338,11 @@ int launch_lu(hipStream_t st, float* M, int B, int N, int ld, size_t mstride, in
 }
 int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
               const int* gate, const int* nvec = nullptr, unsigned long long* scr = nullptr, size_t scr_stride = 0) {
-    if (N > 1024) {
+    if (N > 512) {
         const int rw = launch_lu_wide<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
         if (rw >= 0) return rw;
-        return launch_lu_big<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     }
+    if (N > 1024) return launch_lu_big<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec);
     { const int r2 = launch_lu2<double>(st, M, B, N, ld, mstride, piv, pstride, info, gate, nvec, scr, scr_stride);
       if (r2 >= 0) return r2; }
     const int nt = lu_threads<double>(N);
@@ -1341,7 +1343,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
 // ---------------------------------------------------------------------------
 // LU / solve / KKT entry points
 // ---------------------------------------------------------------------------
-inline size_t lu_scratch_u64(int N) { return N > 1024 ? (luw_scratch_words<double>(N) + 1) / 2 : (size_t)LU2_SCR_WORDS; }
+inline size_t lu_scratch_u64(int N) { return N > 512 ? (luw_scratch_words<double>(N) + 1) / 2 : (size_t)LU2_SCR_WORDS; }
 template <typename T>
 size_t carve_lu(void* ws, int B, int N, T*& M, int*& piv, unsigned long long*& scr) {
     const int Np = round_up(N, LQP_NB);

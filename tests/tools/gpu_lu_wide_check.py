@@ -23,7 +23,7 @@ for N in sizes:
     torch.manual_seed(N)
     M = torch.randn(B, N, N, dtype=dt).to(dev)
     os.environ["LQP_LU_WIDE"] = "0"; LU0, P0, ms0 = timed(M)
-    os.environ["LQP_LU_WIDE"] = "1"; LU1, P1, ms1 = timed(M)
+    os.environ["LQP_LU_WIDE"] = "1"; LU1, P1, ms1 = timed(M)        # (LQP_LU_WIDE_MIN=512: also between 512 and 1024 rows)
     lib = _lib.load()
     dbg = torch.zeros(B * 16, dtype=torch.int64, device=dev)
     lib.lqp_debug_set_lu_counters(_lib.ptr(dbg))
