@@ -231,6 +231,14 @@ const Knobs& knobs() {
     return fresh;
 }
 
+// The LU kernels that share a matrix between workgroups (lqp_lu2.hpp, lqp_lu_wide.hpp) need all of them resident at once; the
+// launch checks that they fit, not that the chip is otherwise idle (another stream's kernels, RCCL).  When a hand-off times out
+// (info word -7: the waits are bounded, the kernels drain) the call is repeated ONCE with one workgroup per matrix.
+thread_local bool t_single_wg_lu = false;
+struct SingleWgLu {
+    SingleWgLu() { t_single_wg_lu = true; }
+    ~SingleWgLu() { t_single_wg_lu = false; }
+};
 unsigned long long* g_lu_dbg = nullptr;     // optional device buffer (4 counters per problem), debug only
 
 // ---- LU launch: pick panel width / trailing-update flavour --------------------
@@ -269,7 +277,7 @@ template <typename T>
 int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
     constexpr int PB = lu2_panel_width<T>();
-    if (!scr || scr_stride < (size_t)LU2_SCR_WORDS || N > 512 || N < 3 * PB || knobs().lu2 == 0) return -1;
+    if (!scr || scr_stride < (size_t)LU2_SCR_WORDS || N > 512 || N < 3 * PB || knobs().lu2 == 0 || t_single_wg_lu) return -1;
     int dev = 0, cus = 0, per_cu = 0;
     auto fn = k_lu_factor2<T, PB>;
     const int lds = Lu2Lds<T, PB>(round_up(N, 64)).total;
@@ -289,7 +297,7 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
 template <typename T>
 int launch_lu_wide(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                    const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
-    if (!scr || 2 * scr_stride < luw_scratch_words<T>(N) || N <= knobs().lu_wide_min || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
+    if (!scr || t_single_wg_lu || 2 * scr_stride < luw_scratch_words<T>(N) || N <= knobs().lu_wide_min || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
         (((uintptr_t)M) % 128) != 0)
         return -1;
     int dev = 0, cus = 0, per_cu = 0;
@@ -422,9 +430,12 @@ int first_failure(hipStream_t st, const int* info_dev, int B, int* fail_index, c
     }
     *fail_index = -1;
     for (int i = 0; i < B; ++i)
+        if (((const volatile int*)words)[i] == -7) { *fail_index = i; return LQP_ERR_TIMEOUT; }      // a multi-workgroup LU never met its partner
+    for (int i = 0; i < B; ++i)
         if (((const volatile int*)words)[i] != 0) { *fail_index = i; return LQP_ERR_SINGULAR; }
     return LQP_OK;
 }
+
 
 // A synchronous call waits for its report, not for its stream: the words of a host report (pinned host memory, all set to
 // -1 by the call before its first launch; every word the kernels store is >= 0) are polled until none is missing.  A
@@ -463,6 +474,7 @@ int wait_report(hipStream_t st, const int* host_report, int words) {
 // with n_launch / linsolve_used / factor_launches / loop_workgroups of the enqueue and keeps them.
 // LQP_RETRY_LU (internal): the matrix left the symmetric x-update -- repeat the solve with linsolve = 1.
 constexpr int LQP_RETRY_LU = 100;
+inline bool flags_timeout_loop(const int* rep) { return ((const volatile int*)rep)[ST_TIMEOUT] != 0; }
 int collect_report(hipStream_t st, const int* rep, const bool polled, const int B, const int max_iters, const int check,
                    lqp_boxqp_stats* stats) {
     if (polled) {
@@ -471,10 +483,13 @@ int collect_report(hipStream_t st, const int* rep, const bool polled, const int 
     }
     const volatile int* rv = (const volatile int*)rep;
     int fail_index = -1, flags_or = 0;
+    bool lu_timeout = false;
     for (int i = 0; i < B; ++i) {
         if (fail_index < 0 && rv[ST_WORDS + i] != 0) fail_index = i;
+        lu_timeout = lu_timeout || rv[ST_WORDS + i] == -7;          // (a multi-workgroup LU never met its partner)
         flags_or |= rv[ST_WORDS + B + i];
     }
+    if (lu_timeout && stats->linsolve_used != 2) return LQP_ERR_TIMEOUT;
     if (fail_index >= 0 && stats->linsolve_used == 2) return LQP_RETRY_LU;
     if (fail_index >= 0) {
         memset(stats, 0, sizeof(*stats));
@@ -1035,6 +1050,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             so->n_launch = n_launch; so->linsolve_used = spd ? 2 : 1; so->factor_launches = factor_launches;
             so->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : 1);
             rc = collect_report(st, rep, rep == P.host_report, B, max_iters, check, so);
+            if (rc == LQP_ERR_TIMEOUT && !spd && !t_single_wg_lu && !(flags_timeout_loop(rep))) {      // a shared LU timed out: one workgroup per matrix
+                SingleWgLu only;
+                return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes, retry);
+            }
             if (rc == LQP_RETRY_LU)         // Qs + rho I not positive definite in f32 (first factorisation or an
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
                                        ws, ws_bytes, retry | 1);     // adaptive-rho one): the LU path takes the solve
@@ -1140,6 +1159,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         auto after_factorisation = [&]() -> int {
             int rcf = first_failure(st, P.info, B, &fail_index, P.host_report ? P.host_report + ST_WORDS : nullptr);      // synchronises
             if (rcf == LQP_OK || rcf == LQP_ERR_SINGULAR) { const int r4 = fetch_status(); if (r4) return r4; }
+            if (rcf == LQP_ERR_TIMEOUT && !spd && !t_single_wg_lu) return -2;
             if (rcf != LQP_OK && rcf != LQP_ERR_SINGULAR) return rcf;
             bool leave_spd = rcf == LQP_ERR_SINGULAR && spd, singular = rcf == LQP_ERR_SINGULAR && !spd;
             if (ctl->check_hook) {
@@ -1163,6 +1183,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             if (rc == -1)       // Qs + rho I not positive definite in f32 (on some rank): the LU path takes it
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
                                        ws, ws_bytes, retry | 1);
+            if (rc == -2) {     // a shared LU timed out: once more, one workgroup per matrix
+                SingleWgLu only;
+                return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes, retry);
+            }
             if (rc) return rc;
         } else {
             { const int r4 = fetch_status(); if (r4) return r4; }
@@ -1171,6 +1195,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 if (rc == -1)
                     return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
                                            ws, ws_bytes, retry | 1);
+                if (rc == -2) {
+                    SingleWgLu only;
+                    return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes, retry);
+                }
                 if (rc) return rc;
             }
         }
@@ -1331,6 +1359,11 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             rc = fi >= 0 ? LQP_ERR_SINGULAR : LQP_OK;
         } else
             rc = first_failure(st, P.info, B, &fi, P.host_report);
+        if (rc == LQP_ERR_TIMEOUT && !chol && !t_single_wg_lu) {      // a shared LU timed out: once more, one workgroup per matrix
+            SingleWgLu only;
+            return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
+                                    db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report, kkt, 0);
+        }
         if (rc == LQP_ERR_SINGULAR && chol)           // Q_FF not positive definite in f32: the pivoted LU takes it
             return backward_impl<T>(st, B, n, m, g, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA,
                                     db, dlb, dub, fail_index, ws, ws_bytes, 1, host_report, kkt, 0);
