@@ -154,6 +154,7 @@ struct Knobs {
     int loop_split_seg;        // LQP_LOOP_SPLIT_SEG
     int lu2;                   // LQP_LU2
     int lu_wide;               // LQP_LU_WIDE
+    int unroll_split;          // LQP_UNROLL_SPLIT
     int lu_wide_min;           // LQP_LU_WIDE_MIN: the wide LU above this many rows (experiments; default 1024)
     int lu_mfma;               // LQP_LU_MFMA
     int lu_nt;                 // LQP_LU_NT
@@ -198,6 +199,7 @@ Knobs read_knobs() {
     k.loop_split_seg = env_int("LQP_LOOP_SPLIT_SEG", 1);
     k.lu2 = env_int("LQP_LU2", 1);
     k.lu_wide = env_int("LQP_LU_WIDE", 1);
+    k.unroll_split = env_int("LQP_UNROLL_SPLIT", 1);
     k.lu_wide_min = env_int("LQP_LU_WIDE_MIN", 1024);
     k.lu_mfma = env_int("LQP_LU_MFMA", 1);
     k.lu_nt = env_int("LQP_LU_NT", 0);
@@ -1659,12 +1661,31 @@ int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd
     U.g = (const float*)dl_dx;
     U.dps = (float*)dps; U.dlbs = (float*)dlbs; U.dubs = (float*)dubs; U.dD = (float*)dD;
     U.dAs = (float*)dAs; U.dbs = (float*)dbs; U.drho = (float*)drho;
-    const int lds = unroll_lds_bytes(m, P.Ks, U.rl);
-    auto sweep_fn = m <= 1 ? k_unroll_sweep<1> : k_unroll_sweep<SPD_MAXM>;
-    int rc = ensure_lds((const void*)sweep_fn, lds);
-    if (rc) return rc;
-    { ProfScope ps(st, PC_UNROLL);
-      hipLaunchKernelGGL(sweep_fn, dim3(B), dim3(LQP_NT), lds, st, P, U); }
+    // two workgroups per QP when half the chip would idle (the split loop's products, lqp_unroll.hpp: k_unroll_sweep_split)
+    bool split_done = false;
+    if (P.xchg && P.Ks >= 5 && P.Ks <= SPD_MAXK && knobs().unroll_split != 0) {
+        void (*fn2)(const FwdParams<float>, const UnrollParams, const unsigned int) =
+            P.Ks == 8 ? (m <= 1 ? k_unroll_sweep_split<8, 1> : k_unroll_sweep_split<8, SPD_MAXM>)
+            : P.Ks == 7 ? k_unroll_sweep_split<7, SPD_MAXM> : P.Ks == 6 ? k_unroll_sweep_split<6, SPD_MAXM> : k_unroll_sweep_split<5, SPD_MAXM>;
+        const int lds2 = P.Ks == 8 ? unroll_split_lds_bytes<8>(m) : P.Ks == 7 ? unroll_split_lds_bytes<7>(m)
+                       : P.Ks == 6 ? unroll_split_lds_bytes<6>(m) : unroll_split_lds_bytes<5>(m);
+        int dev = 0, cus = 0, per_cu = 0;
+        if (current_device_cus(&dev, &cus) && ensure_lds((const void*)fn2, lds2) == LQP_OK &&
+            blocks_per_cu(&per_cu, fn2, 512, lds2, dev) && per_cu >= 1 && 2 * B <= cus * per_cu) {
+            static std::atomic<unsigned int> run{1u};
+            ProfScope ps(st, PC_UNROLL);
+            hipLaunchKernelGGL(fn2, dim3(2 * B), dim3(512), lds2, st, P, U, run.fetch_add(1u));
+            split_done = true;
+        }
+    }
+    if (!split_done) {
+        const int lds = unroll_lds_bytes(m, P.Ks, U.rl);
+        auto sweep_fn = m <= 1 ? k_unroll_sweep<1> : k_unroll_sweep<SPD_MAXM>;
+        int rc = ensure_lds((const void*)sweep_fn, lds);
+        if (rc) return rc;
+        ProfScope ps(st, PC_UNROLL);
+        hipLaunchKernelGGL(sweep_fn, dim3(B), dim3(LQP_NT), lds, st, P, U);
+    }
     if (dQs) {
         ProfScope ps(st, PC_UNROLL);
         const int tiles = (n + 63) / 64;

@@ -171,6 +171,179 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep(const FwdParams<float> 
     if (tid == 0) U.drho[b] = rsum;
 }
 
+// The same sweep on TWO workgroups per QP (2 B <= #CUs, 3 <= Ks <= 8): the products are those of k_admm_loop_split -- each
+// workgroup holds its half of the blocks of H in registers / LDS for the whole launch (wg_sym_gemv_split), the partial vectors
+// cross as tagged 8-byte granules through the forward's exchange area (two buffers by step parity; tag = 0x10000000 | run | step:
+// apart from the loop's own) and are added in the fixed order part 0 + part 1 -- so both workgroups hold bit-identical iterates
+// and run all element-wise work redundantly; both write the (identical) scratch rows they read back, part 0 the results.  One
+// workgroup per QP streams two thirds of H per product from beyond the L2: 122 products = 1.6 ms at the headline size.
+// LDS (floats): [rl blocks] v yrow cvl part[8][Nps] | nus[m] dnu[m] red[8 + 8] | flags[8]
+template <int KS> __host__ __device__ inline int unroll_split_lds_bytes(int m) {
+    const int mm = m > 0 ? m : 1;
+    return (split_lds_blocks<512, 2>(KS) * LQP_BLK + (3 + 8) * KS * LQP_NB + 2 * mm + 16 + 8) * 4 + 64;
+}
+template <int KS, int MA>
+__global__ __launch_bounds__(512) void k_unroll_sweep_split(const FwdParams<float> P, const UnrollParams U, const unsigned int run) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    constexpr int NT = 512, NP = 2, NWV = NT / 64, Nps = KS * LQP_NB, rl = split_lds_blocks<NT, NP>(KS);
+    constexpr int XPART = SPD_MAXK * LQP_NB, XPAR = NP * XPART;
+    const int b = (int)blockIdx.x % P.B, part_id = (int)blockIdx.x / P.B;
+    const int n = P.n, m = P.m, T = U.T;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* const lds_res = (float*)smem;
+    float* const v = lds_res + (size_t)rl * LQP_BLK;
+    float* const yrow = v + Nps;
+    float* const cvl = yrow + Nps;
+    float* const part = cvl + Nps;
+    float* const nus = part + (size_t)NWV * Nps;
+    float* const dnul = nus + (m > 0 ? m : 1);
+    float* const red = dnul + (m > 0 ? m : 1);
+    int* const flags = (int*)(red + 16);
+    VecView<float> V(P.vecs + (size_t)b * P.vstride, n, m);
+    const float rho = P.scal[(size_t)b * SC_WORDS + SC_RHO];
+    const float* packed = P.packed + (size_t)b * packed_blocks(P.K) * LQP_BLK;
+    unsigned long long* xq = P.xchg + (size_t)b * XCHG_WORDS;
+    float* X = U.X + (size_t)b * T * n;
+    float* Wd = U.W + (size_t)b * T * n;
+    float* DX = U.DX + (size_t)b * T * n;
+    float* NU = U.NU + (size_t)b * T * (m > 0 ? m : 1);
+    signed char* MK = U.MK + (size_t)b * T * n;
+
+    SplitResident<NT> rr;
+#define LQP_BY_PART2(CALL) do { if (part_id == 0) { constexpr int PARTC = 0; CALL; } else { constexpr int PARTC = 1; CALL; } } while (0)
+    LQP_BY_PART2((split_resident_load<KS, PARTC, NT, NP>(rr, lds_res, packed)));
+    for (int e = tid; e < Nps; e += NT) { cvl[e] = (e < n && m > 0) ? V.cv[e] : 0.f; yrow[e] = 0.f; }
+    for (int e = tid; e < NWV * Nps; e += NT) part[e] = 0.f;
+    if (tid < 8) flags[tid] = 0;
+    const int i = tid;                                       // (Nps <= 512: element i of every vector lives in thread i)
+    const bool live = i < n;
+    const float psi = live ? V.ps[i] : 0.f, lbi = live ? V.lbs[i] : 0.f, ubi = live ? V.ubs[i] : 0.f;
+    __syncthreads();
+
+    // y = (this workgroup's partial) + (the partner's), in the order part 0 + part 1; step: the number of the product in the launch
+    auto full_product = [&](const int step) -> float {
+        LQP_BY_PART2((wg_sym_gemv_split<KS, PARTC, NT, NP>(rr, lds_res, Nps, v, yrow, part)));
+        wg_barrier_lds();
+        float y = 0.f;
+        if (tid < Nps) {
+            const float own = split_combine<NT>(tid, Nps, yrow, part);
+            const unsigned int tag = 0x10000000u | ((run & 0xFFu) << 16) | (unsigned int)(step & 0xFFFF);
+            unsigned long long* base = xq + (size_t)(step & 1) * XPAR;
+            __hip_atomic_store(base + (size_t)part_id * XPART + tid,
+                               ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, own),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long* src = base + (size_t)(1 - part_id) * XPART + tid;
+            unsigned long long g = 0;
+            if (!flags[0]) {
+                unsigned int spins = 0;
+                unsigned long long t0 = 0;
+                for (;;) {
+                    g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(g >> 32) == tag) break;
+                    if ((++spins & 1023u) == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > 50000000ULL) {                                   // 0.5 s: give up, flagged
+                            __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            flags[0] = 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            const float other = __builtin_bit_cast(float, (unsigned int)g);
+            y = part_id == 0 ? own + other : other + own;
+        }
+        return y;
+    };
+
+    // ---- replay of the forward loop (:258-282) ----
+    float zi = 0.f, ui = 0.f;
+    for (int k = 0; k < T; ++k) {
+        const float wd = zi - ui;
+        if (tid < Nps) v[tid] = live ? -psi + rho * wd : 0.f;
+        if (live) Wd[(size_t)k * n + i] = wd;
+        wg_barrier_lds();
+        const float y = full_product(k);
+        for (int r = w; r < m; r += NWV) {                   // nu_k = T^T w - s0 (one wave per row) while v still holds w
+            float acc = 0.f;
+            for (int e = lane; e < n; e += 64) acc += V.Tm[(size_t)r * n + e] * v[e];
+            acc = wave_sum(acc);
+            if (lane == 0) NU[(size_t)k * m + r] = acc - V.s0[r];
+        }
+        if (live) {
+            const float xi = cvl[i] - y;
+            X[(size_t)k * n + i] = xi;
+            const float s = xi + ui;
+            const float zn = tmin(tmax(s, lbi), ubi);
+            MK[(size_t)k * n + i] = (signed char)(tmax(s, lbi) > ubi ? 1 : (s < lbi ? -1 : 0));
+            ui = ui + (xi - zn);
+            zi = zn;
+        }
+        wg_barrier_lds();
+    }
+
+    // ---- reverse sweep ----
+    const float gi = live ? U.g[(size_t)b * n + i] : 0.f;
+    const float di = live ? V.D[i] : 0.f;
+    float ubar = 0.f, zbar = 0.f, pbar = 0.f, lbbar = 0.f, ubbar = 0.f, rho_part = 0.f, bbar = 0.f;
+    float dA[MA];
+#pragma unroll
+    for (int q = 0; q < MA; ++q) dA[q] = 0.f;
+    __syncthreads();
+    for (int k = T - 1; k >= 0; --k) {
+        float unew = 0.f;
+        {
+            const int code = live ? (int)MK[(size_t)k * n + i] : 0;
+            const float zt = zbar - ubar;
+            const float wfree = code == 0 ? zt : 0.f;
+            lbbar += code < 0 ? zt : 0.f;
+            ubbar += code > 0 ? zt : 0.f;
+            unew = wfree + ubar;
+            const float xb = unew + (k == T - 1 ? di * gi : 0.f);
+            if (tid < Nps) v[tid] = live ? xb : 0.f;
+        }
+        wg_barrier_lds();
+        const float dxx = full_product(T + (T - 1 - k));       // packed = -H:  -H xbar
+        if (m > 0) {
+            for (int r = w; r < m; r += NWV) {               // nu part of dx_k: -T^T xbar
+                float acc = 0.f;
+                for (int e = lane; e < n; e += 64) acc += V.Tm[(size_t)r * n + e] * v[e];
+                acc = wave_sum(acc);
+                if (lane == 0) { dnul[r] = -acc; nus[r] = NU[(size_t)k * m + r]; }
+            }
+            wg_barrier_lds();
+        }
+        if (live) {
+            const float xk = X[(size_t)k * n + i];
+            DX[(size_t)k * n + i] = dxx;
+            pbar += dxx;
+            rho_part += dxx * (xk - Wd[(size_t)k * n + i]);
+            zbar = -rho * dxx;
+            ubar = unew + rho * dxx;
+#pragma unroll
+            for (int q = 0; q < MA; ++q)
+                if (q < m) dA[q] += dnul[q] * xk + nus[q] * dxx;
+        }
+        if (tid < m) bbar -= dnul[tid];
+        wg_barrier_lds();
+    }
+#undef LQP_BY_PART2
+    const float rsum = wg_sum_nw<NWV>(rho_part, red);
+    if (part_id != 0) return;
+    if (live) {
+        U.dps[(size_t)b * n + i] = pbar;
+        U.dlbs[(size_t)b * n + i] = lbbar;
+        U.dubs[(size_t)b * n + i] = ubbar;
+        U.dD[(size_t)b * n + i] = gi * X[(size_t)(T - 1) * n + i];
+#pragma unroll
+        for (int q = 0; q < MA; ++q)
+            if (q < m) U.dAs[((size_t)b * m + q) * n + i] = dA[q];
+    }
+    if (tid < m) U.dbs[(size_t)b * m + tid] = bbar;
+    if (tid == 0) U.drho[b] = rsum;
+}
+
 // Qsbar[b] = sum_k DX[b][k][:]^T X[b][k][:]  (n x n, T terms): 64 x 64 tile per 256-thread workgroup, 4 x 4 per thread
 template <int LQP_ANY = 0>
 __global__ __launch_bounds__(256) void k_unroll_outer(const float* __restrict__ DXall, const float* __restrict__ Xall,

@@ -1119,6 +1119,33 @@ def test_unroll_scaling_chain_native_vs_autograd(dev, monkeypatch, case):
             assert err(a, e) <= 2e-5 * scale, (case, flag, nm, err(a, e), scale)
 
 
+@pytest.mark.parametrize("n,B,m", [(300, 4, 1), (500, 6, 1), (400, 3, 3), (512, 2, 0)])
+def test_unroll_sweep_on_two_workgroups(dev, monkeypatch, n, B, m):
+    """unroll=True: the reverse sweep shared by two workgroups per QP (k_unroll_sweep_split: the split loop's products, partial
+    vectors exchanged per product) against the one-workgroup sweep (LQP_UNROLL_SPLIT=0): the same recurrence, products summed in
+    another order -- gradients to float32 rounding of their scale."""
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=50 + n)
+    if m == 0:
+        A = b = None
+    elif m > 1:
+        A = torch.randn(B, m, n, generator=torch.Generator().manual_seed(51))
+        b = A @ (0.5 * (lb + ub))
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(52)).to(dev)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_UNROLL_SPLIT", flag)
+        leaves = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        x = L.SolveBoxQP(control=L.box_qp_control(unroll=True, **TOL))(*leaves)
+        x.backward(cot)
+        got[flag] = [None if t is None else t.grad for t in leaves]
+    for nm, a, e in zip(GRADS, got["1"], got["0"]):
+        if e is None:
+            assert a is None, nm
+            continue
+        scale = max(1e-3, float(e.abs().max()))
+        assert err(a, e) <= 5e-5 * scale, (n, m, nm, err(a, e), scale)
+
+
 def test_unroll_native_falls_back(dev):
     """What the reverse sweep does not cover takes the taped loop by itself: float64, the cached-LU x-update, a solve in
     which rho was adapted (the factor is no longer constant along the tape)."""

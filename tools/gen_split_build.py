@@ -56,6 +56,11 @@ EXTRA = [
     "void lqp::k_unroll_sweep<1>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_unroll_sweep<16>(lqp::FwdParams<float>, lqp::UnrollParams)",
     "void lqp::k_unroll_outer<0>(float const*, float const*, float*, int, int)",
+    "void lqp::k_unroll_sweep_split<8, 1>(lqp::FwdParams<float>, lqp::UnrollParams, unsigned int)",
+    "void lqp::k_unroll_sweep_split<8, 16>(lqp::FwdParams<float>, lqp::UnrollParams, unsigned int)",
+    "void lqp::k_unroll_sweep_split<7, 16>(lqp::FwdParams<float>, lqp::UnrollParams, unsigned int)",
+    "void lqp::k_unroll_sweep_split<6, 16>(lqp::FwdParams<float>, lqp::UnrollParams, unsigned int)",
+    "void lqp::k_unroll_sweep_split<5, 16>(lqp::FwdParams<float>, lqp::UnrollParams, unsigned int)",
     "void lqp::k_unroll_scale_colmax<0>(float const*, int, float*, int*, int*)",
     "void lqp::k_unroll_scale_grad<0>(float const*, float const*, float const*, float*, int, float*)",
     "void lqp::k_unroll_scale_vectors<0>(lqp::ScaleVecParams)",
