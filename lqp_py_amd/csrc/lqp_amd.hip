@@ -397,23 +397,38 @@ int launch_solve(hipStream_t st, int B, const T* packed, int N, const int* dest,
 }
 
 // X = M^-1 from the packed factor (lqp_dense.hpp): G workgroups per matrix, each takes column tiles g, g + G, ...
-template <typename T>
-int launch_lu_inverse(hipStream_t st, int B, int N, const T* packed, size_t pkstride, const int* dest, int dstride, T* X,
-                      size_t xstride, int ldx, const int* gate) {
+template <typename T, bool SMALL>
+int launch_lu_inverse_cfg(hipStream_t st, int B, int N, const T* packed, size_t pkstride, const int* dest, int dstride, T* X,
+                          size_t xstride, int ldx, const int* gate) {
+    typedef InvCfg<T, SMALL> C;
     const int Np = round_up(N, LQP_NB);
-    const int lds = lu_inverse_lds_bytes<T>(Np);
-    auto fn = k_lu_inverse<T>;
+    const int lds = lu_inverse_lds_bytes<T, SMALL>(Np);
+    if (lds > 160 * 1024) return LQP_ERR_UNSUPPORTED;
+    auto fn = k_lu_inverse<T, SMALL>;
     const int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
     int dev = 0, cus = 256;
     (void)current_device_cus(&dev, &cus);
-    const int ntiles = (N + InvCfg<T>::TWG - 1) / InvCfg<T>::TWG;
+    const int ntiles = (N + C::TWG - 1) / C::TWG;
     // (column tiles are independent: every tile its own workgroup while the grid stays within a few waves of workgroups per CU --
     //  several 256-thread workgroups per CU hide each other's barriers and operand loads)
     int G = std::max(1, std::min(ntiles, (12 * cus) / std::max(B, 1)));
     ProfScope ps(st, PC_PACK);
     hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, Np / LQP_NB, dest, dstride, X, xstride, ldx, gate);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+// float32: 64-column tiles on v_mfma_f32_32x32x2 while Y fits the LDS (N <= 576), 16-column tiles on v_mfma_f32_16x16x4 above
+template <typename T>
+int launch_lu_inverse(hipStream_t st, int B, int N, const T* packed, size_t pkstride, const int* dest, int dstride, T* X,
+                      size_t xstride, int ldx, const int* gate) {
+    if constexpr (sizeof(T) == 4) {
+        if (lu_inverse_lds_bytes<T, false>(round_up(N, LQP_NB)) > 160 * 1024)
+            return launch_lu_inverse_cfg<T, true>(st, B, N, packed, pkstride, dest, dstride, X, xstride, ldx, gate);
+    }
+    return launch_lu_inverse_cfg<T, false>(st, B, N, packed, pkstride, dest, dstride, X, xstride, ldx, gate);
+}
+template <typename T> inline bool lu_inverse_fits(int Np) {
+    return lu_inverse_lds_bytes<T, false>(Np) <= 160 * 1024 || (sizeof(T) == 4 && lu_inverse_lds_bytes<T, true>(Np) <= 160 * 1024);
 }
 
 // first failing batch index from the per-problem info array (host side, after a sync)
@@ -1522,7 +1537,7 @@ int lqp_debug_xcd(void* stream, int blocks, void* out_dev) {
 }
 
 int lqp_debug_lu_inverse(void* stream, int dtype, int B, int N, const void* packed_buf, void* X_out) {
-    if (bad_dims(dtype, B, N, 0) || !packed_buf || !X_out || N > (dtype == LQP_F32 ? 512 : 1024)) return LQP_ERR_INVALID;
+    if (bad_dims(dtype, B, N, 0) || !packed_buf || !X_out || N > (dtype == LQP_F32 ? 2048 : 1024)) return LQP_ERR_INVALID;
     const int K = round_up(N, LQP_NB) / LQP_NB;
     if (dtype == LQP_F32) {
         int* dest; float* packed;

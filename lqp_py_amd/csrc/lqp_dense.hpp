@@ -23,23 +23,25 @@ namespace lqp {
 // ---------------------------------------------------------------------------------------------------------------------
 // One workgroup of 256 threads works on a tile of TWG columns of X at a time: 4 waves = (64 / TR row tiles) x (TWG / TC column
 // tiles) of one 64-row block; Y (Np x TWG, the right-hand sides turning into the solution) lives in LDS.
-template <typename T> struct InvCfg {
-    static constexpr int TR = sizeof(T) == 4 ? 32 : 16;       // rows / columns of one matrix-instruction tile
+// SMALL (float32 only): 16 x 16 tiles of v_mfma_f32_16x16x4 instead of 32 x 32 of v_mfma_f32_32x32x2 -- a workgroup tile of 16 columns,
+// so that Y fits the LDS for N up to 2048 (64 columns: N <= 630); float64 is always 16 x 16.
+template <typename T, bool SMALL = false> struct InvCfg {
+    static constexpr int TR = (sizeof(T) == 4 && !SMALL) ? 32 : 16;       // rows / columns of one matrix-instruction tile
     static constexpr int TC = TR;
-    static constexpr int KS = sizeof(T) == 4 ? 2 : 4;         // k-depth of one instruction (= lane groups)
+    static constexpr int KS = (sizeof(T) == 4 && !SMALL) ? 2 : 4;         // k-depth of one instruction (= lane groups)
     static constexpr int RT = 64 / TR;                        // row tiles per 64-row block: 2 | 4
     static constexpr int CT = 4 / RT;                         // column tiles per workgroup: 2 | 1
     static constexpr int TWG = CT * TC;                       // columns of X per workgroup tile: 64 | 16
     static constexpr int YS = TWG + 1;                        // row stride of Y in LDS: odd, so that the lane groups' rows (16 / 32 apart)
                                                               // start 128 B apart in the banks (an even stride put all of them on the same ones)
 };
-template <typename T> __host__ __device__ inline int lu_inverse_lds_bytes(int Np) { return Np * InvCfg<T>::YS * (int)sizeof(T); }
+template <typename T, bool SMALL = false> __host__ __device__ inline int lu_inverse_lds_bytes(int Np) { return Np * InvCfg<T, SMALL>::YS * (int)sizeof(T); }
 
 // acc (one TR x TC tile, C layout) -= A[TR x 64] * Y[64 x TC]:  A = rows r0 .. r0+TR of a 64 x 64 row-major block `blk`;
 // Y rows yr0 .. yr0+64, columns yc0 .. of the LDS array (row stride YS)
-template <typename T>
+template <typename T, bool SMALL = false>
 struct InvAcc;
-template <> struct InvAcc<float> {
+template <> struct InvAcc<float, false> {
     static constexpr int NA = 32;                                  // A operands of one 64-deep block product
     f32x16 a;
     __device__ __forceinline__ void zero() {
@@ -68,7 +70,33 @@ template <> struct InvAcc<float> {
         for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f32_32x32x2f32(op[t], bq[t], a, 0, 0, 0);
     }
 };
-template <> struct InvAcc<double> {
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// (operand / result layout of v_mfma_f32_16x16x4_f32 as measured, tools/microbench/mfma_f32_16x16x4_layout.hip: A[i = l & 15][k = l >> 4],
+//  B[k = l >> 4][j = l & 15], D register q <-> row 4 (l >> 4) + q, column l & 15 -- the rows are NOT the float64 instruction's)
+template <> struct InvAcc<float, true> {
+    static constexpr int NA = 16;
+    f32x4_t a;
+    __device__ __forceinline__ void zero() { a = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    __device__ static __forceinline__ int row(int q, int lg) { return 4 * lg + q; }
+    __device__ static __forceinline__ void load(float (&op)[NA], const float* __restrict__ blk, const int r0, const int li, const int lg) {
+        const float* ap = blk + (size_t)(r0 + li) * 64 + 16 * lg;        // (k = 16 lg + t: 64 contiguous bytes of the lane's row)
+#pragma unroll
+        for (int v = 0; v < NA / 4; ++v) {
+            const V4<float> x = *(const V4<float>*)(ap + 4 * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) op[4 * v + e] = x.v[e];
+        }
+    }
+    __device__ __forceinline__ void mac(const float (&op)[NA], const float* __restrict__ Y, const int YS, const int li, const int lg) {
+        const float* bp = Y + (size_t)(16 * lg) * YS + li;
+        float bq[NA];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) bq[t] = bp[(size_t)t * YS];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) a = __builtin_amdgcn_mfma_f32_16x16x4f32(op[t], bq[t], a, 0, 0, 0);
+    }
+};
+template <bool SMALL> struct InvAcc<double, SMALL> {
     static constexpr int NA = 16;
     f64x4 a;
     __device__ __forceinline__ void zero() { a = f64x4{0.0, 0.0, 0.0, 0.0}; }
@@ -94,13 +122,14 @@ template <> struct InvAcc<double> {
 
 // X[0:N, 0:N] (row-major, leading dimension ldx) = M^-1; packed / dest: what k_pack left (dest[r]: position of original
 // right-hand-side row r after the row interchanges).  grid = (B, G): workgroup (b, g) takes column tiles g, g + G, ...
-template <typename T>
+template <typename T, bool SMALL = false>
 __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed_all, const size_t pkstride, const int Nuni,
                                                     const int Kmax, const int* __restrict__ dest_all, const int dstride,
                                                     T* __restrict__ X_all, const size_t xstride, const int ldx,
                                                     const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
-    typedef InvCfg<T> C;
+    typedef InvCfg<T, SMALL> C;
+    typedef InvAcc<T, SMALL> Acc;
     if (gate && *gate == 0) return;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int N = Nuni;
@@ -122,26 +151,26 @@ __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed
         __syncthreads();
         if (tid < C::TWG && c0 + tid < N) Y[(size_t)dest[c0 + tid] * C::YS + tid] = T(1);
         __syncthreads();
-        InvAcc<T> acc;
+        Acc acc;
         const int ycol = ct * C::TC;
         // One block row of a phase: acc = sum_j B_j Y_(col j) over the off-diagonal blocks (A operands of the NEXT block are
         // requested before the current block's matrix instructions: the loads' latency stands behind 1024 cycles of them),
         // Y_k -= acc, barrier, Y_k <- Dinv Y_k with the pre-inverted diagonal block (loaded ahead of the barrier).
         auto block_row = [&](const T* rowblk, const int noff, const int k, auto col_of) {
             T* Yk = Y + (size_t)(64 * k) * C::YS + ycol;
-            T opA[InvAcc<T>::NA], opB[InvAcc<T>::NA];
-            constexpr int NQ = sizeof(T) == 4 ? 16 : 4;
+            T opA[Acc::NA], opB[Acc::NA];
+            constexpr int NQ = (sizeof(T) == 4 && !SMALL) ? 16 : 4;
             acc.zero();
-            InvAcc<T>::load(opA, rowblk, C::TR * rt, li, lg);                 // block 0 (the diagonal one when noff == 0)
+            Acc::load(opA, rowblk, C::TR * rt, li, lg);                 // block 0 (the diagonal one when noff == 0)
             for (int j = 0; j < noff; ++j) {
-                InvAcc<T>::load(opB, rowblk + (size_t)(j + 1) * LQP_BLK, C::TR * rt, li, lg);
+                Acc::load(opB, rowblk + (size_t)(j + 1) * LQP_BLK, C::TR * rt, li, lg);
                 acc.mac(opA, Y + (size_t)(64 * col_of(j)) * C::YS + ycol, C::YS, li, lg);
 #pragma unroll
-                for (int t = 0; t < InvAcc<T>::NA; ++t) opA[t] = opB[t];
+                for (int t = 0; t < Acc::NA; ++t) opA[t] = opB[t];
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                T* p = Yk + (size_t)(C::TR * rt + InvAcc<T>::row(q, lg)) * C::YS + li;
+                T* p = Yk + (size_t)(C::TR * rt + Acc::row(q, lg)) * C::YS + li;
                 *p = *p - acc.a[q];
             }
             __syncthreads();
@@ -149,7 +178,7 @@ __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed
             acc.mac(opA, Yk, C::YS, li, lg);                             // (opA holds the diagonal block's operands by now)
             __syncthreads();                                                   // (every wave has read the old Y_k)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) Yk[(size_t)(C::TR * rt + InvAcc<T>::row(q, lg)) * C::YS + li] = acc.a[q];
+            for (int q = 0; q < NQ; ++q) Yk[(size_t)(C::TR * rt + Acc::row(q, lg)) * C::YS + li] = acc.a[q];
             __syncthreads();
         };
         // ---- L phase: Y_k <- inv(L_kk) (Y_k - sum_{j<k} L_kj Y_j), k ascending: L(k,0) .. L(k,k-1), inv(L(k,k)) ----

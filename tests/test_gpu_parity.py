@@ -131,7 +131,9 @@ def test_two_workgroup_lu(dev, monkeypatch, N, B, dtype):
 
 
 @pytest.mark.parametrize("N,B,dtype", [(70, 3, torch.float32), (266, 8, torch.float32), (317, 4, torch.float32), (512, 2, torch.float32),
-                                       (64, 2, torch.float64), (266, 8, torch.float64), (300, 3, torch.float64), (501, 2, torch.float64)])
+                                       (64, 2, torch.float64), (266, 8, torch.float64), (300, 3, torch.float64), (501, 2, torch.float64),
+                                       # float32 above 576 rows: 16-column tiles on v_mfma_f32_16x16x4 (Y would not fit the LDS otherwise)
+                                       (700, 2, torch.float32), (1100, 2, torch.float32), (1501, 1, torch.float32)])
 def test_inverse_from_the_packed_factor(dev, N, B, dtype):
     """csrc/lqp_dense.hpp, k_lu_inverse: X = M^-1 from the packed factor (blocked triangular solves with N right-hand sides on
     the matrix cores) against torch.linalg.inv of a KKT-like matrix (zero lower-right block: the pivoting matters)."""
@@ -151,10 +153,10 @@ def test_inverse_from_the_packed_factor(dev, N, B, dtype):
     _lib.check(lib.lqp_debug_lu_inverse(_lib.stream_ptr(dev), _lib.dtype_code(Ad), B, N, _lib.ptr(buf), _lib.ptr(X)), "lu_inverse")
     torch.cuda.synchronize()
     ref = torch.linalg.inv(A)
-    tol = 2e-4 if dtype == torch.float32 else 1e-10
+    tol = (2e-4 if N <= 512 else 1e-3) if dtype == torch.float32 else 1e-10
     assert rel(X, ref.to(dtype)) < tol
     eye = torch.eye(N, dtype=torch.float64)
-    assert float((A @ X.cpu().double() - eye).abs().max()) < (5e-4 if dtype == torch.float32 else 1e-10)
+    assert float((A @ X.cpu().double() - eye).abs().max()) < ((5e-4 if N <= 512 else 3e-3) if dtype == torch.float32 else 1e-10)
 
 
 @pytest.mark.parametrize("N,B,dtype", [(1100, 3, torch.float32), (1500, 8, torch.float32), (2048, 2, torch.float32), (1030, 5, torch.float32),

@@ -45,8 +45,9 @@ GROUPS = [
 EXTRA = [
     "void lqp::k_admm_loop_dense<float>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_admm_loop_dense<double>(lqp::FwdParams<double>, int, int, int)",
-    "void lqp::k_lu_inverse<float>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
-    "void lqp::k_lu_inverse<double>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
+    "void lqp::k_lu_inverse<float, false>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
+    "void lqp::k_lu_inverse<float, true>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
+    "void lqp::k_lu_inverse<double, false>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
     "void lqp::k_lu_factor2<float, 32>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
     "void lqp::k_lu_factor2<double, 16>(double*, int, int, unsigned long, int*, int, int*, int const*, int const*, unsigned long long*, unsigned long, unsigned int, unsigned long long*, int, int)",
     "void lqp::k_lu_factor_wide<float>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int, unsigned long long*)",
@@ -79,6 +80,8 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_lu_inverse<float>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
+    "void lqp::k_lu_inverse<double>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
     "void lqp::k_lu_factor_wide<0>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int, unsigned long long*)",
     "void lqp::k_lu_factor_wide<0>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int)",
     "void lqp::k_unroll_scale_fro<0>(float const*, float const*, int, float*)",
