@@ -148,6 +148,7 @@ struct Knobs {
     int linsolve;              // LQP_LINSOLVE
     int loop512;               // LQP_LOOP512
     int loop_dense;            // LQP_LOOP_DENSE
+    int loop_dense_w;          // LQP_LOOP_DENSE_W
     int loop_small;            // LQP_LOOP_SMALL
     int loop_split;            // LQP_LOOP_SPLIT
     int loop_split4;           // LQP_LOOP_SPLIT4
@@ -193,6 +194,7 @@ Knobs read_knobs() {
     k.linsolve = env_int("LQP_LINSOLVE", 0);
     k.loop512 = env_int("LQP_LOOP512", 0);
     k.loop_dense = env_int("LQP_LOOP_DENSE", 1);
+    k.loop_dense_w = env_int("LQP_LOOP_DENSE_W", 1);
     k.loop_small = env_int("LQP_LOOP_SMALL", 1);
     k.loop_split = env_int("LQP_LOOP_SPLIT", 1);
     k.loop_split4 = env_int("LQP_LOOP_SPLIT4", 1);
@@ -560,7 +562,11 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK)
                  ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + XCHG_TAIL)) : nullptr;
     // granules of the dense LU-tier loop (lqp_dense.hpp): batches that can leave half a chip idle, n <= 256
-    P.dnx = (B <= 256 && n <= DENSE_NMAX && P.N <= 1024) ? c.take<unsigned long long>((size_t)B * DNX_WORDS) : nullptr;
+    // granules of the dense LU-tier loops: two workgroups per problem to n = 256; W workgroups per problem for small batches at any
+    // n the inverse kernel takes (two parities x n elements x one or two words)
+    P.dnx_words = (B <= 256 && n <= DENSE_NMAX && P.N <= 1024) ? DNX_WORDS
+                : (B <= 64 && P.N <= 2048) ? (int)std::max((size_t)DNX_WORDS, densew_xchg_words<T>(n)) : 0;
+    P.dnx = P.dnx_words ? c.take<unsigned long long>((size_t)B * P.dnx_words) : nullptr;
     L.bytes = c.off + kAlign;
     return L;
 }
@@ -904,7 +910,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // workgroups per problem (lqp_dense.hpp) -- float64, many equality rows, non-symmetric Q, control['linsolve'] = 'lu'
     bool loop_dense = false;
     int dense_lds = 0;
-    if (!spd && mode == 2 && P.dnx && knobs().loop_dense != 0) {
+    if (!spd && mode == 2 && P.dnx && n <= DENSE_NMAX && knobs().loop_dense != 0) {
         int dev = 0, cus = 0, per_cu = 0;
         dense_lds = dense_loop_lds_bytes<T>(m);
         auto fnd = k_admm_loop_dense<T>;
@@ -912,6 +918,22 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             ensure_lds((const void*)fnd, dense_lds) == LQP_OK && blocks_per_cu(&per_cu, fnd, DENSE_NT, dense_lds, dev) &&
             per_cu >= 1 && 2 * B <= cus * per_cu)
             loop_dense = true;
+    }
+    // ... and for batches that leave most of the chip idle, any n the inverse kernel takes: W workgroups per problem, each with its
+    // rows of the inverse in registers (k_admm_loop_dense_w): a matrix-vector product spreads over CUs, triangular solves do not
+    bool loop_dense_w = false;
+    int densew_lds = 0, densew_tprv = 0, densew_W = 0;
+    if (!spd && mode == 2 && P.dnx && !loop_dense && n > DENSE_NMAX && knobs().loop_dense_w != 0 && lu_inverse_fits<T>(P.Np) &&
+        (size_t)P.dnx_words >= densew_xchg_words<T>(n)) {
+        int dev = 0, cus = 0, per_cu = 0;
+        densew_lds = densew_lds_bytes<T>(n, m);
+        densew_tprv = densew_tpr(n, densew_cpt<T>());
+        densew_W = (n + DENSEW_NT / densew_tprv - 1) / (DENSEW_NT / densew_tprv);
+        auto fnw = k_admm_loop_dense_w<T>;
+        if (densew_tprv <= 32 && densew_W >= 2 && densew_lds <= 160 * 1024 && current_device_cus(&dev, &cus) &&
+            ensure_lds((const void*)fnw, densew_lds) == LQP_OK && blocks_per_cu(&per_cu, fnw, DENSEW_NT, densew_lds, dev) &&
+            per_cu >= 1 && densew_W * B <= cus * per_cu)
+            loop_dense_w = true;
     }
     // small problems (n <= 128, e.g. BASELINE configs[1]): 256 threads per QP, the full matrix in registers (k_admm_loop_small)
     bool loop_small = false;
@@ -932,7 +954,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         P.eq_in_loop = (loop_split && spd_resident && m > 0 && !(ctl->reserved2 & 1) && knobs().eq_in_loop) ? 1 : 0;
     rc = factor_step(nullptr);
     if (rc) return rc;
-    if (loop_dense) {
+    if (loop_dense || loop_dense_w) {
         // X = M^-1 over the LAPACK copy of the factor (the pack kernel has read it; a refactorisation re-assembles M anyway)
         rc = launch_lu_inverse<T>(st, B, P.N, P.packed, packed_blocks(P.K) * LQP_BLK, P.dest, P.Np, P.M, (size_t)P.Np * P.Np, P.Np, nullptr);
         if (rc) return rc;
@@ -953,6 +975,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         }
         if (loop_dense && it == 0) {
             hipLaunchKernelGGL(k_admm_loop_dense<T>, dim3(2 * B), dim3(DENSE_NT), dense_lds, st, P, it, e, ctr_base);
+            return;
+        }
+        if (loop_dense_w && it == 0) {
+            hipLaunchKernelGGL(k_admm_loop_dense_w<T>, dim3(densew_W * B), dim3(DENSEW_NT), densew_lds, st, P, it, e, ctr_base, densew_tprv);
             return;
         }
         hipLaunchKernelGGL(loop_fn, dim3(B), dim3(loop_nt), loop_lds, st, P, it, e, ctr_base, prev_slot, flags);
@@ -1032,7 +1058,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     stats->any_lb = stats->any_ub = -1;
                     stats->linsolve_used = spd ? 2 : 1;
                     stats->factor_launches = factor_launches;
-                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : 1);
+                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : (loop_dense_w ? densew_W : 1));
                 }
                 return LQP_OK;
             }
@@ -1046,7 +1072,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     stats->any_lb = stats->any_ub = -1;
                     stats->linsolve_used = spd ? 2 : 1;
                     stats->factor_launches = factor_launches;
-                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : 1);
+                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : (loop_dense_w ? densew_W : 1));
                 }
                 return LQP_OK;
             }
@@ -1065,7 +1091,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             lqp_boxqp_stats* so = stats ? stats : &local;
             memset(so, 0, sizeof(*so));
             so->n_launch = n_launch; so->linsolve_used = spd ? 2 : 1; so->factor_launches = factor_launches;
-            so->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : 1);
+            so->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : (loop_dense_w ? densew_W : 1));
             rc = collect_report(st, rep, rep == P.host_report, B, max_iters, check, so);
             if (rc == LQP_ERR_TIMEOUT && !spd && !t_single_wg_lu && !(flags_timeout_loop(rep))) {      // a shared LU timed out: one workgroup per matrix
                 SingleWgLu only;

@@ -77,7 +77,8 @@ template <typename T> struct FwdParams {
     int* status;      // ST_WORDS
     unsigned int* counters;   // ring of CT_WORDS per check
     unsigned long long* xchg; // B * XCHG_WORDS granules: partial-product exchange of the two-workgroup loop (or null)
-    unsigned long long* dnx;  // B * DNX_WORDS granules: x-halves of the dense LU-tier loop, lqp_dense.hpp (or null)
+    unsigned long long* dnx;  // B * dnx_words granules: x-parts of the dense LU-tier loops, lqp_dense.hpp (or null)
+    int dnx_words;            // granules per problem (DNX_WORDS, or what the W-workgroup form needs: 2 parities x n elements)
     size_t vstride;
     // controls
     int scale, rho_mode, beta_mode, check_solved, adaptive_rho;
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
     unsigned long long tst = clock64();
 #define SETUP_STAMP(i) do { if (P.dbg_setup && tid == 0) { const unsigned long long t_ = clock64(); P.dbg_setup[(size_t)b * 8 + (i)] = t_ - tst; tst = t_; } } while (0)
     if (P.dnx) {                           // granules of the dense LU-tier loop (lqp_dense.hpp): tags start from zero
-        unsigned long long* dq = P.dnx + (size_t)b * DNX_WORDS;
-        for (int i = tid; i < DNX_WORDS; i += LQP_NT) dq[i] = 0ull;
+        unsigned long long* dq = P.dnx + (size_t)b * P.dnx_words;
+        for (int i = tid; i < P.dnx_words; i += LQP_NT) dq[i] = 0ull;
     }
     if (P.xchg) {                          // exchange granules of the two-workgroup loop: tags start from zero
         unsigned long long* xq = P.xchg + (size_t)b * XCHG_WORDS;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(DENSE_NT) void k_admm_loop_dense(const FwdParams<T>
     const T rho = scal[SC_RHO];
     const T pnorm = scal[SC_PNORM];
     static_assert(dense_xchg_words<T>() <= (size_t)DNX_WORDS, "granule area");
-    unsigned long long* const xq = P.dnx + (size_t)b * DNX_WORDS;
+    unsigned long long* const xq = P.dnx + (size_t)b * P.dnx_words;
 
     // ---- my rows of X[0:n, 0:n] into registers ----
     T H[CPT];
@@ -408,6 +408,243 @@ __global__ __launch_bounds__(DENSE_NT) void k_admm_loop_dense(const FwdParams<T>
             }
             ++slot;
             grid_wait(ct + CT_ARRIVE, 2u * (unsigned int)P.B, P.status);      // device-wide "all optimal?" (torch.all at :312)
+            const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (notopt == 0 || tmo) {
+                if (blockIdx.x == 0 && tid == 0) {
+                    P.status[ST_FINAL_ITER] = it;
+                    __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                break;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- state for the continuation launch / the epilogue ----
+    if (part == 0) {
+        for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }
+        for (int k = tid; k < m; k += NT) V.nu[k] = nul[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same loop on W workgroups per problem, for batches that leave most of the chip idle and any n the inverse kernel takes
+// (float32 to 2048, float64 to ~1100): the cached-LU loop is ONE workgroup per problem streaming the whole factor every
+// iteration (B = 8, n = 1500: 9.8 MB at the ~80 GB/s one CU keeps in flight = 123 us per iteration, 9.9 of the 21 ms of a step),
+// and triangular solves do not spread over CUs -- a matrix-vector product does.  Workgroup `part` of W holds rows
+// [part RPW, (part + 1) RPW) of X[0:n, 0:n] in registers, TPR threads per row with CPT columns each (RPW = 512 / TPR); per
+// iteration it forms its RPW entries of x, publishes them as tagged granules and takes everybody else's (an all-gather through
+// global memory: two buffers by iteration parity), then runs the element-wise update of ALL n variables like every other
+// workgroup of the problem (identical bits; everybody knows the verdict of a check).
+// LDS: wl[TPR chunks of CPT + pad] xs z u ps lb ub D [7 x NV] cvl[128] | bs nul [2 m] | red | flags   (NV = n rounded up to 64)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DENSEW_NT = 512;
+template <typename T> __host__ __device__ constexpr int densew_cpt() { return sizeof(T) == 4 ? 192 : 88; }      // columns of a row per thread: 192 / 176 VGPRs (96 doubles: 60 spilled registers)
+template <typename T> __host__ __device__ constexpr int densew_ws() { return densew_cpt<T>() + (sizeof(T) == 4 ? 4 : 2); }
+__host__ __device__ inline int densew_tpr(int n, int cpt) {
+    int t = 4;
+    while (t * cpt < n) t <<= 1;
+    return t;                                       // threads per row: 4, 8, 16 or 32 (adjacent lanes)
+}
+template <typename T> __host__ __device__ inline int densew_lds_bytes(int n, int m) {
+    const int NV = round_up(n, 64), tpr = densew_tpr(n, densew_cpt<T>());
+    return (tpr * densew_ws<T>() + 7 * NV + 128 + 2 * (m > 0 ? m : 1) + (DENSEW_NT / 64) * 8 + 8 + 8) * (int)sizeof(T) + 64;
+}
+// granules per problem: [parity][element], one (float32) or two (float64) 8-byte words per element
+template <typename T> __host__ __device__ inline size_t densew_xchg_words(int n) { return (size_t)2 * round_up(n, 64) * (sizeof(T) / 4); }
+
+template <typename T>
+__global__ __launch_bounds__(DENSEW_NT) void k_admm_loop_dense_w(const FwdParams<T> P, const int it0, const int it1, const int ctr_base,
+                                                                 const int TPR) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    constexpr int NT = DENSEW_NT, NWV = NT / 64, CPT = densew_cpt<T>(), WS = densew_ws<T>(), GW = sizeof(T) / 4;
+    const int b = (int)blockIdx.x % P.B, part = (int)blockIdx.x / P.B, W = (int)gridDim.x / P.B;
+    const int n = P.n, m = P.m, Np = P.Np, NV = round_up(n, 64);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (it0 >= it1) return;
+    T* wl = (T*)smem;
+    T* xs = wl + TPR * WS;
+    T* z = xs + NV;
+    T* u = z + NV;
+    T* ps = u + NV;
+    T* lb = ps + NV;
+    T* ub = lb + NV;
+    T* D = ub + NV;
+    T* cvl = D + NV;
+    T* bs = cvl + 128;
+    T* nul = bs + (m > 0 ? m : 1);
+    T* red = nul + (m > 0 ? m : 1);
+    int* flags = (int*)(red + NWV * 8 + 8);                   // [0] exchange timed out (sticky)
+    const int RPW = NT / TPR;
+    const int h0 = part * RPW, h1 = (h0 + RPW < n) ? h0 + RPW : n;
+    const int r = tid / TPR, q = tid % TPR, row = h0 + r;
+    const bool rowok = row < h1;
+    const T* X = P.M + (size_t)b * Np * Np;                   // the inverse, written over the factor's LAPACK copy by k_lu_inverse
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    T* scal = P.scal + (size_t)b * SC_WORDS;
+    const T rho = scal[SC_RHO];
+    const T pnorm = scal[SC_PNORM];
+    unsigned long long* const xq = P.dnx + (size_t)b * P.dnx_words;
+
+    // ---- my rows of X[0:n, 0:n] into registers ----
+    T H[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = q * CPT + j;
+        H[j] = (rowok && c < n) ? X[(size_t)row * Np + c] : T(0);
+    }
+    for (int i = tid; i < NV; i += NT) {
+        const bool in = i < n;
+        z[i] = in ? V.z[i] : T(0); u[i] = in ? V.u[i] : T(0); ps[i] = in ? V.ps[i] : T(0);
+        lb[i] = in ? V.lbs[i] : T(0); ub[i] = in ? V.ubs[i] : T(0); D[i] = in ? V.D[i] : T(1);
+        xs[i] = T(0);
+    }
+    for (int k = tid; k < m; k += NT) { bs[k] = V.bs[k]; nul[k] = T(0); }
+    for (int i = tid; i < TPR * WS; i += NT) wl[i] = T(0);
+    if (tid < 8) flags[tid] = 0;
+    __syncthreads();
+    if (q == 0 && r < 128) {                                     // c = X[0:n, n:N] b, my rows
+        T acc = T(0);
+        if (rowok)
+            for (int k = 0; k < m; ++k) acc += X[(size_t)row * Np + n + k] * bs[k];
+        cvl[r] = acc;
+    }
+    for (int i = tid; i < n; i += NT) wl[(i / CPT) * WS + (i % CPT)] = -ps[i] + rho * (z[i] - u[i]);
+    __syncthreads();
+
+    int slot = ctr_base;
+    for (int it = it0; it < it1; ++it) {
+        const bool check = (it % P.check_solved) == 0;
+        // ---- x (my rows) = X w + c ----
+        const T* wq = wl + q * WS;
+        T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+#pragma unroll
+        for (int j = 0; j < CPT; j += 4) {
+            a0 += H[j] * wq[j]; a1 += H[j + 1] * wq[j + 1]; a2 += H[j + 2] * wq[j + 2]; a3 += H[j + 3] * wq[j + 3];
+        }
+        T acc = (a0 + a1) + (a2 + a3);
+        acc += dpp<0xB1>(acc);                                   // the TPR threads of a row are adjacent lanes
+        acc += dpp<0x4E>(acc);
+        if (TPR >= 8) acc += (T)__shfl_xor(acc, 4);              // (butterfly: every lane of the row's group ends with the sum)
+        if (TPR >= 16) acc += (T)__shfl_xor(acc, 8);
+        if (TPR >= 32) acc += xor16(acc);
+        const unsigned int tag = (unsigned int)(it + 1);
+        unsigned long long* const xb = xq + (size_t)(it & 1) * NV * GW;
+        if (q == 0 && rowok) {
+            const T xi = acc + cvl[r];
+            xs[row] = xi;
+            if constexpr (GW == 1) {
+                __hip_atomic_store(xb + row, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, xi),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const unsigned long long bits = __builtin_bit_cast(unsigned long long, xi);
+                __hip_atomic_store(xb + 2 * row, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xb + 2 * row + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- everybody else's rows ----
+        for (int i = tid; i < n; i += NT) {
+            if (i >= h0 && i < h1) continue;
+            unsigned long long g[GW];
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < GW; ++e) {
+                unsigned int spins = 0;
+                unsigned long long t0 = 0;
+                for (;;) {
+                    g[e] = __hip_atomic_load(xb + GW * i + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(g[e] >> 32) == tag || flags[0]) break;
+                    if ((++spins & 255u) == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();         // 100 MHz
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > 50000000ULL) {                                       // 0.5 s: give up, flagged
+                            __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            flags[0] = 1;
+                            bad = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (!bad) {
+                if constexpr (GW == 1) xs[i] = __builtin_bit_cast(float, (unsigned int)g[0]);
+                else xs[i] = __builtin_bit_cast(double, (g[GW - 1] << 32) | (g[0] & 0xFFFFFFFFull));
+            }
+        }
+        __syncthreads();
+        // ---- nu = X[n:N, :] [w; b] where a check or the end of the launch needs it (w is still this iteration's) ----
+        if ((check || it + 1 == it1) && m > 0) {
+            for (int k = w; k < m; k += NWV) {
+                const T* xr = X + (size_t)(n + k) * Np;
+                T a = T(0);
+                for (int i = lane; i < n; i += 64) a += xr[i] * wl[(i / CPT) * WS + (i % CPT)];
+                for (int j = lane; j < m; j += 64) a += xr[n + j] * bs[j];
+                a = wave_sum(a);
+                if (lane == 0) nul[k] = a;
+            }
+            __syncthreads();
+        }
+        // ---- z-update, residuals, dual (:271-282), all n variables on every workgroup ----
+        T mx[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) mx[e] = T(0);
+        for (int i = tid; i < n; i += NT) {
+            const T xi = xs[i];
+            const T zp = z[i];
+            const T ui = u[i];
+            T zn = xi + ui;
+            zn = tmin(tmax(zn, lb[i]), ub[i]);
+            const T rr = xi - zn;
+            const T ss = rho * (zn - zp);
+            const T un = ui + rr;
+            z[i] = zn; u[i] = un;
+            if (check) {
+                const T di = D[i];
+                mx[0] = tmax(mx[0], tabs(di * rr));
+                mx[1] = tmax(mx[1], tabs(di * ss));
+                mx[2] = tmax(mx[2], tabs(di * xi));
+                mx[3] = tmax(mx[3], tabs(di * zn));
+                mx[4] = tmax(mx[4], tabs((rho * di) * un));
+                T qx = -ps[i] + rho * (zp - ui) - rho * xi;
+                for (int k = 0; k < m; ++k) qx -= V.As[(size_t)k * n + i] * nul[k];
+                mx[5] = tmax(mx[5], tabs(qx / di));
+            }
+            wl[(i / CPT) * WS + (i % CPT)] = -ps[i] + rho * (zn - un);
+        }
+        if (check) {
+            T mv[6] = {mx[0], mx[1], mx[2], mx[3], mx[4], mx[5]};
+            wg_max_n<T, 6, NWV>(mv, red);
+            const T tiny = T(1e-16);
+            const T pri_scale = tmax(tmax(mv[2], mv[3]), tiny);
+            const T tol_p = P.eps_abs + P.eps_rel * pri_scale;
+            const T dua_scale = tmax(tmax(tmax(mv[4], mv[5]), pnorm), tiny);
+            const T tol_d = P.eps_abs + P.eps_rel * dua_scale;
+            const bool solved = (mv[0] < tol_p) && (mv[1] < tol_d);
+            const bool wants = (mv[0] > tmax(tol_p, P.ar_thr)) || (mv[1] > tmax(tol_d, P.ar_thr));
+            const T num = tmax(mv[0] / pri_scale, tiny);
+            const T den = tmax(mv[1] / dua_scale, tiny);
+            const T ratio = tsqrt(num / den);
+            const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
+            unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
+            if (tid == 0) {
+                unsigned int r1 = 0, r2 = 0;
+                if (part == 0) {
+                    scal[SC_RATIO] = ratio;
+                    scal[SC_WANTS] = wants ? T(1) : T(0);
+                    scal[SC_PRI] = mv[0];
+                    scal[SC_DUA] = mv[1];
+                    if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
+                    if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" :: "v"(r1), "v"(r2) : "memory");
+                // every workgroup arrives (they computed the same numbers); the verdict is counted once, by part 0
+                __hip_atomic_fetch_add((unsigned long long*)(ct + CT_NOTOPT), ((part == 0 && !solved) ? 1ull : 0ull) | (1ull << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ++slot;
+            grid_wait(ct + CT_ARRIVE, (unsigned int)gridDim.x, P.status);      // device-wide "all optimal?" (torch.all at :312)
             const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (notopt == 0 || tmo) {

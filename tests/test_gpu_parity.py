@@ -380,6 +380,42 @@ def test_dense_loop_matches_cached_lu_loop(dev, monkeypatch, name):
         assert err(a[k], ref[k]) < tol * scale, (k, err(a[k], ref[k]))
 
 
+@pytest.mark.parametrize("n,B,m,dtype,extra", [(600, 4, 2, torch.float32, {"linsolve": "lu"}), (1200, 3, 1, torch.float32, {}),
+                                               (500, 6, 5, torch.float64, {}), (1000, 2, 3, torch.float64, {}),
+                                               (333, 5, 0, torch.float64, {})])
+def test_dense_loop_on_many_workgroups(dev, monkeypatch, n, B, m, dtype, extra):
+    """csrc/lqp_dense.hpp, k_admm_loop_dense_w: small batches on the LU path above n = 256 -- the explicit inverse (k_lu_inverse; float32
+    above 576 rows on 16-column tiles) spread by rows over W workgroups per problem, x all-gathered per iteration -- against the
+    cached triangular solves (LQP_LOOP_DENSE_W=0) and the CPU oracle: the same iteration count, iterates to rounding."""
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=60 + n)
+    if m == 0:
+        A = b = None
+    elif m > 1:
+        A = torch.randn(B, m, n, generator=torch.Generator().manual_seed(61))
+        b = A @ (0.5 * (lb + ub))
+    inp = tuple(None if t is None else t.to(dtype) for t in (Q, p, A, b, lb, ub))
+    ctl = dict(O.make_control(**TOL), **extra)
+    ref = O.solve_box_qp(*inp, O.make_control(**TOL))
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_LOOP_DENSE_W", flag)
+        sol, _ = solve(dev, inp, ctl)
+        st = sol["_stats"]
+        assert st["linsolve_used"] == 1, st
+        assert (st["loop_workgroups"] > 2) == (flag == "1"), (flag, st)
+        out[flag] = sol
+    a, c = out["1"], out["0"]
+    assert a["iter"] == c["iter"] == ref["iter"], (a["iter"], c["iter"], ref["iter"])
+    tol = 1e-9 if dtype == torch.float64 else 3e-5
+    tol_ref = tol if (dtype == torch.float64 or n <= 1024) else 1e-4       # (float32 rounding of ~80 iterations at n = 1200, either side)
+    for k in ("x", "z", "u", "lams", "nus"):
+        if ref[k] is None:
+            continue
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert err(a[k], c[k]) < tol * scale, (k, err(a[k], c[k]))
+        assert err(a[k], ref[k]) < tol_ref * scale, (k, err(a[k], ref[k]))
+
+
 @pytest.mark.parametrize("linsolve,mode", [("lu", 2), ("spd", 2), ("spd", 1)])
 @pytest.mark.parametrize("tag", ["noscale", "scale"])
 def test_g6_adaptive_rho_refactorises(dev, tag, linsolve, mode):

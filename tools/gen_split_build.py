@@ -31,7 +31,7 @@ GROUPS = [
     ("split_b", lambda n: "k_admm_loop_split<" in n),
     ("loop_tail", lambda n: re.search(r"k_admm_loop<\w+, \w+, true,", n)),
     ("loop_hot", lambda n: "k_admm_loop<" in n),
-    ("dense", lambda n: "k_lu_inverse<" in n or "k_admm_loop_dense<" in n),
+    ("dense", lambda n: "k_lu_inverse<" in n or "k_admm_loop_dense" in n),
     ("lu2", lambda n: "k_lu_factor2<" in n),
     ("lu_a", lambda n: re.search(r"k_lu_factor<float, (32|16), true|k_lu_factor_big|k_lu_factor_wide", n)),
     ("lu_b", lambda n: "k_lu_factor<" in n),
@@ -43,6 +43,8 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
+    "void lqp::k_admm_loop_dense_w<float>(lqp::FwdParams<float>, int, int, int, int)",
+    "void lqp::k_admm_loop_dense_w<double>(lqp::FwdParams<double>, int, int, int, int)",
     "void lqp::k_admm_loop_dense<float>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_admm_loop_dense<double>(lqp::FwdParams<double>, int, int, int)",
     "void lqp::k_lu_inverse<float, false>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
