@@ -500,17 +500,28 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
                 T cm[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) cm[q] = T(0);
-                // (sixteen unconditional loads per row -- lanes past the row end re-read its first column and are masked: a guarded load
+                // (unconditional loads, eight in flight per wave -- lanes past the row end re-read its first column and are masked: a guarded load
                 //  is a branch with a full wait behind it, one 256-B load in flight per wave: 9 MB in 0.6 ms at n = 1500)
                 for (int i = w; i < n; i += LQP_NW) {
                     const T* qr = Q + (size_t)i * n + c0;
-                    T v[16];
+                    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) { const int j = lane + 64 * q; v[q] = qr[(c0 + j < n) ? j : 0]; }
+                        for (int h = 0; h < 16; h += 8) {
+                            T v[8];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int j = lane + 64 * q;
-                        cm[q] = tmax(cm[q], (c0 + j < n) ? tabs(v[q]) : T(0));
+                            for (int q = 0; q < 8; ++q) { const int j = lane + 64 * (h + q); v[q] = qr[(c0 + j < n) ? j : 0]; }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int j = lane + 64 * (h + q);
+                                cm[h + q] = tmax(cm[h + q], (c0 + j < n) ? tabs(v[q]) : T(0));
+                            }
+                        }
+                    } else {                                      // (float64: the unconditional form spills registers in this kernel)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int j = lane + 64 * q;
+                            if (c0 + j < n) cm[q] = tmax(cm[q], tabs(qr[j]));
+                        }
                     }
                 }
                 for (int round = 0; round < LQP_NW / nred; ++round) {
@@ -556,13 +567,14 @@ __global__ __launch_bounds__(LQP_NT) void k_fwd_setup(const FwdParams<T> P) {
                 T* qo = Qw + (size_t)i * ldq;
                 T* mo = Mw + (size_t)i * Np;
                 const T di = d[i];
-                // (eight loads in flight; every lane meets its elements in the order it always did: the norm keeps its bits)
-                for (int j0 = lane; j0 < n; j0 += 64 * 8) {
-                    T qv[8];
+                // (eight / four loads in flight; every lane meets its elements in the order it always did: the norm keeps its bits)
+                constexpr int SQ = sizeof(T) == 8 ? 4 : 8;
+                for (int j0 = lane; j0 < n; j0 += 64 * SQ) {
+                    T qv[SQ];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { const int j = j0 + 64 * q; qv[q] = qr[j < n ? j : lane]; }
+                    for (int q = 0; q < SQ; ++q) { const int j = j0 + 64 * q; qv[q] = qr[j < n ? j : lane]; }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
+                    for (int q = 0; q < SQ; ++q) {
                         const int j = j0 + 64 * q;
                         if (j < n) {
                             const T v = (di * qv[q]) * d[j];
