@@ -192,7 +192,13 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(T* __restrict__ Mall,
                 __syncthreads();
                 LUW_STAMP(1);
                 if (cnt[2]) { dead = true; break; }
-                for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; st_sc1(LTg + (size_t)c * Mpad + i, LT[c * Mpad + i]); }
+                {   // (16-byte write-through stores: element by element the message was 12 fabric writes per thread)
+                    const int nv4 = (M2 + 3) >> 2;
+                    for (int e = tid; e < PB * nv4; e += NT) {
+                        const int c = e / nv4, i4 = e - c * nv4;
+                        st_vec_sc1(LTg + (size_t)c * Mpad + 4 * i4, *(const vec*)(LT + c * Mpad + 4 * i4));
+                    }
+                }
                 if (tid < PB * (PB + 1)) st_sc1((T*)(slot + LUW_L11) + tid, L11[tid]);
                 if (tid < PB) { st_sc1(slot + 4 + tid, src[tid]); st_sc1(slot + 4 + PB + tid, tid < ne ? xdst[tid] : 0); st_sc1(slot + 4 + 2 * PB + tid, tid < ne ? xsrc[tid] : 0); }
                 if (tid == 0) { st_sc1(slot + 1, ne); st_sc1(slot + 2, cnt[1]); }
@@ -210,7 +216,13 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(T* __restrict__ Mall,
             __syncthreads();
             LUW_STAMP(3);
             if (cnt[2]) { dead = true; break; }
-            for (int e = tid; e < PB * M2; e += NT) { const int c = e / M2, i = e - c * M2; LT[c * Mpad + i] = ld_sc1(LTg + (size_t)c * Mpad + i); }
+            {
+                const int nv4 = (M2 + 3) >> 2;
+                for (int e = tid; e < PB * nv4; e += NT) {
+                    const int c = e / nv4, i4 = e - c * nv4;
+                    *(vec*)(LT + c * Mpad + 4 * i4) = ld_vec_sc1(LTg + (size_t)c * Mpad + 4 * i4);
+                }
+            }
             if (tid < PB * (PB + 1)) L11[tid] = ld_sc1((const T*)(slot + LUW_L11) + tid);
             if (tid < PB) { src[tid] = ld_sc1(slot + 4 + tid); xdst[tid] = ld_sc1(slot + 4 + PB + tid); xsrc[tid] = ld_sc1(slot + 4 + 2 * PB + tid); }
             if (tid == 0) { cnt[3] = ld_sc1(slot + 1); const int z = ld_sc1(slot + 2); if (z != 0 && cnt[1] == 0) cnt[1] = z; }
