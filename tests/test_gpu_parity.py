@@ -416,6 +416,30 @@ def test_dense_loop_on_many_workgroups(dev, monkeypatch, n, B, m, dtype, extra):
         assert err(a[k], ref[k]) < tol_ref * scale, (k, err(a[k], ref[k]))
 
 
+@pytest.mark.parametrize("n,B,dtype", [(300, 4, torch.float64), (1100, 2, torch.float64)])
+def test_refactorisation_behind_the_small_batch_tiers(dev, n, B, dtype):
+    """rho = 100 forces an adaptive-rho refactorisation at iteration 100 (as in G6): the first segment runs on the dense loop of W
+    workgroups per problem (and, above 1024 rows, the factorisations on the wide LU, the second one through its device-side gate),
+    the continuation on the cached triangular solves.  Against the oracle: the same iteration count, at least two factorisations, iterates to
+    rounding.  (float64: in float32 the new rho -- a square root of a ratio of two residuals at the 1e-6 level -- is rounding noise
+    amplified, and at n = 1100 the CPU oracle itself stops at 210 or 240 iterations depending on the host's BLAS threading.)"""
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=70 + n)
+    inp = tuple(t.to(dtype) for t in (Q, p, A, b, lb, ub))
+    kw = dict(rho=100.0, **TOL)
+    ref = O.solve_box_qp(*inp, O.make_control(**kw))
+    sol, _ = solve(dev, inp, O.make_control(**kw))
+    st = sol["_stats"]
+    assert st["linsolve_used"] == 1 and st["loop_workgroups"] > 2, st
+    assert sol["iter"] == ref["iter"] and st["n_factor"] >= 2 and ref["iter"] >= 100, (sol["iter"], ref["iter"], st)
+    if dtype == torch.float64:
+        for k in ("x", "z", "u", "lams", "nus"):
+            assert err(sol[k], ref[k]) < 1e-9 * max(1.0, float(ref[k].abs().max())), k
+    else:
+        t64 = O.solve_box_qp(*[t.double() for t in inp], O.make_control(rho=100.0, eps_abs=1e-12, eps_rel=1e-12, max_iters=ref["iter"] + 1))
+        for k in ("x", "z", "lams", "nus"):
+            close_or_fp64(f"refactor_small_batch_n{n}", k, sol[k], ref[k], t64[k], X_TOL)
+
+
 @pytest.mark.parametrize("linsolve,mode", [("lu", 2), ("spd", 2), ("spd", 1)])
 @pytest.mark.parametrize("tag", ["noscale", "scale"])
 def test_g6_adaptive_rho_refactorises(dev, tag, linsolve, mode):
