@@ -416,6 +416,34 @@ def test_dense_loop_on_many_workgroups(dev, monkeypatch, n, B, m, dtype, extra):
         assert err(a[k], ref[k]) < tol_ref * scale, (k, err(a[k], ref[k]))
 
 
+@pytest.mark.parametrize("n,B,dtype", [(600, 4, torch.float32), (1100, 3, torch.float32), (500, 5, torch.float64)])
+def test_small_batch_tiers_pipelined_and_through_the_layer(dev, n, B, dtype):
+    """The small-batch tiers of the LU path (wide LU above 1024 rows, dense loop on W workgroups) in a pipelined call
+    (control['sync'] = False: the whole schedule enqueued, nothing waited for) and through the layer with its fixed-point backward:
+    the same bits as the synchronous functional call, gradients against the oracle's."""
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=80 + n)
+    inp = tuple(t.to(dtype) for t in (Q, p, A, b, lb, ub))
+    extra = {"linsolve": "lu"} if n <= 1024 and dtype == torch.float32 else {}
+    ctl = dict(O.make_control(**TOL), **extra)
+    ref_sol, args = solve(dev, inp, ctl)
+    assert ref_sol["_stats"]["loop_workgroups"] > 2
+    piped = L.torch_solve_box_qp(*args, dict(ctl, sync=False))
+    L.synchronize()
+    for k in ("x", "z", "u", "lams", "nus"):
+        assert torch.equal(piped[k], ref_sol[k]), k
+    leaves = [t.clone().requires_grad_(True) for t in args]
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(81), dtype=dtype).to(dev)
+    x = L.SolveBoxQP(control=dict(L.box_qp_control(**TOL), **extra))(*leaves)
+    assert torch.equal(x.detach(), ref_sol["x"])
+    x.backward(cot)
+    ref = O.solve_box_qp(*inp, O.make_control(**TOL))
+    g = O.solve_box_qp_grad(cot.cpu(), ref["x"], ref["u"], ref["lams"], ref["nus"], inp[0], inp[2], inp[4], inp[5], ref["rho"])
+    rt = 1e-8 if dtype == torch.float64 else 2e-3
+    for nm, t, e in zip(GRADS, leaves, g):
+        scale = max(1e-6, float(e.abs().max()))
+        assert err(t.grad, e) <= rt * scale, (nm, err(t.grad, e), scale)
+
+
 @pytest.mark.parametrize("n,B,dtype", [(300, 4, torch.float64), (1100, 2, torch.float64)])
 def test_refactorisation_behind_the_small_batch_tiers(dev, n, B, dtype):
     """rho = 100 forces an adaptive-rho refactorisation at iteration 100 (as in G6): the first segment runs on the dense loop of W
