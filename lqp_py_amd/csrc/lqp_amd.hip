@@ -24,7 +24,7 @@ using namespace lqp;
 
 namespace {
 
-constexpr int kRing = 1024;          // per-check counter slots
+constexpr int kRing = 2048;          // per-check counter slots (a continuation launch holds kRing / 2 checks: 10 000 iterations at a check every 10 in ONE launch)
 constexpr int kMaxN = 2048;          // pivoted LU: one panel row per thread to 1024, two above (k_lu_factor_big)
 constexpr size_t kAlign = 256;
 constexpr int kSplitMaxB = 8192;     // two-workgroup loop: exchange granules (32 KB per problem) are carved for batches up to this
