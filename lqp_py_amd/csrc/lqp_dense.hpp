@@ -440,7 +440,7 @@ __global__ __launch_bounds__(DENSE_NT) void k_admm_loop_dense(const FwdParams<T>
 // LDS: wl[TPR chunks of CPT + pad] xs z u ps lb ub D [7 x NV] cvl[128] | bs nul [2 m] | red | flags   (NV = n rounded up to 64)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int DENSEW_NT = 512;
-template <typename T> __host__ __device__ constexpr int densew_cpt() { return sizeof(T) == 4 ? 192 : 88; }      // columns of a row per thread: 192 / 176 VGPRs (96 doubles: 60 spilled registers)
+template <typename T> __host__ __device__ constexpr int densew_cpt() { return sizeof(T) == 4 ? 192 : 64; }      // columns of a row per thread: 192 / 128 VGPRs (72 doubles: 12 spilled registers, 88: 44, 96: 60)
 template <typename T> __host__ __device__ constexpr int densew_ws() { return densew_cpt<T>() + (sizeof(T) == 4 ? 4 : 2); }
 __host__ __device__ inline int densew_tpr(int n, int cpt) {
     int t = 4;

@@ -212,7 +212,14 @@ def test_register_budgets_of_the_hot_kernels():
                 "lqp::k_bwd_chol_solve<0>": (33, 112),
                 # round 5, the two-workgroup pivoted LU: nothing spilled in the panel's column steps (the chain); 24 registers around
                 # the hand-off loads of the f32 build
-                "lqp::k_lu_factor2<float, 32>": (24, 100), "lqp::k_lu_factor2<double, 16>": (0, 0)}
+                "lqp::k_lu_factor2<float, 32>": (24, 100), "lqp::k_lu_factor2<double, 16>": (0, 0),
+                # round 5, second half: the wide LU (nothing spilled in float64; 12 registers around the float32 panel), the dense loop on W
+                # workgroups (192 float32 columns per thread: 9 registers outside the product; 64 float64 columns: none), the two-workgroup
+                # unroll sweep and the scaling-chain kernels (none)
+                "lqp::k_lu_factor_wide<float>": (12, 48), "lqp::k_lu_factor_wide<double>": (0, 320),
+                "lqp::k_admm_loop_dense_w<float>": (9, 40), "lqp::k_admm_loop_dense_w<double>": (0, 0),
+                "lqp::k_unroll_sweep_split<8, 1>": (0, 0), "lqp::k_unroll_sweep_split<8, 16>": (0, 0), "lqp::k_unroll_sweep_split<7, 16>": (0, 0),
+                "lqp::k_unroll_scale_grad<0>": (0, 0), "lqp::k_unroll_scale_vectors<0>": (0, 0), "lqp::k_lu_inverse<float, true>": (0, 0)}
     for k, (spill, scratch) in ceilings.items():
         assert res[k][1] <= spill and res[k][2] <= scratch, (k, res[k])
     for k, (vg, _, _) in res.items():
