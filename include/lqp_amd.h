@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 10
+#define LQP_ABI_VERSION 11
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -269,12 +269,20 @@ size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m);
  * `backward`.  lqp_boxqp_backward_fp called afterwards on the SAME workspace (nothing else may have used it in between)
  * with linsolve = 2 | LQP_BWD_PREFACTORED only gathers dl_dz, solves and writes the gradients; a factorisation that
  * failed still ends in that call's pivoted-LU retry.  LQP_ERR_UNSUPPORTED: no Cholesky form for these sizes / dtype
- * (float32, linsolve 2 only) -- nothing was enqueued, call lqp_boxqp_backward_fp without the flag.                     */
+ * (float32, linsolve 2 only) -- nothing was enqueued, call lqp_boxqp_backward_fp without the flag.
+ * host_report (optional, pinned host memory, B ints; ABI 11): the factorisation is the only step of the Cholesky form that
+ * sends a caller to the LU retry, so its info words are final when this call's last kernel ends -- it stores them there
+ * (set to -1 by this call before its first launch).  lqp_boxqp_backward_fp given the SAME buffer and
+ * linsolve = 2 | LQP_BWD_PREFACTORED | LQP_BWD_REPORTED neither resets nor stores them again: with fail_index it waits for
+ * those words only, i.e. it returns as soon as the factorisation is known to have succeeded, while its own solves and the
+ * gradient epilogue still run (stream-ordered results, like every other output of this library).  Without the prefactor call
+ * lqp_boxqp_backward_fp's Cholesky form reports at the same point: right behind its factorisation.                       */
 #define LQP_BWD_PREFACTORED 0x100
+#define LQP_BWD_REPORTED 0x200
 int lqp_boxqp_backward_fp_prefactor(void* stream, int dtype, int B, int n, int m,
                                     const void* x, const void* u,
                                     const void* Q, const void* A, const void* lb, const void* ub,
-                                    void* workspace, size_t workspace_bytes, int linsolve);
+                                    void* workspace, size_t workspace_bytes, int linsolve, void* host_report);
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m,
                           const void* dl_dz, const void* x, const void* u,
                           const void* lams, const void* nus,

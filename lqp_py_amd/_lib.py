@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQ
 SOURCES = ["lqp_amd.hip", "lqp_unroll.hpp", "lqp_boxqp.hpp", "lqp_lu.hpp", "lqp_lu_big.hpp", "lqp_lu2.hpp", "lqp_lu_wide.hpp", "lqp_dense.hpp", "lqp_trsv.hpp", "lqp_spd.hpp", "lqp_common.hpp"]
 
 LQP_F32, LQP_F64 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
           5: "grid barrier timeout", 6: "unsupported size", 7: "matrix outside the symmetric x-update"}
 
@@ -76,7 +76,7 @@ SYMBOLS = {
     "lqp_unroll_scale_scatter": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "lqp_boxqp_last_residuals": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
-    "lqp_boxqp_backward_fp_prefactor": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 6 + [_P, c_size_t, c_int]),
+    "lqp_boxqp_backward_fp_prefactor": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 6 + [_P, c_size_t, c_int, _P]),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
                               [ctypes.POINTER(ctypes.c_int32), _P, c_size_t, c_int, _P]),
     "lqp_boxqp_backward_kkt": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 8 + [_P] * 6 +
@@ -216,8 +216,19 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def current_stream_handle(device):
+    """The raw handle of torch's current stream on `device` (an int).  torch.cuda.current_stream builds a Stream object around
+    it (~2.5 us, in front of the first launch of every call); the C hook underneath returns the number itself."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(current_stream_handle(device))
 
 
 # ---- deferred error reporting for calls that did not synchronise with the host -----------------
@@ -234,12 +245,27 @@ _pending_lock = threading.Lock()
 
 
 _pinned_free = {}        # number of int32 words -> pinned host buffers waiting for re-use (cudaHostAlloc costs ~50 us)
+_pinned_quarantine = []  # report buffers a kernel that is still queued may write (a prefactored backward that was dropped)
+
+
+def pinned_release(report):
+    """A report buffer goes back to the pool -- at once when nothing can write it any more (every word has arrived: a kernel
+    stores each word exactly once, the library set them to -1 before), otherwise when a later allocation finds it complete."""
+    if bool((report >= 0).all()):
+        _pinned_free.setdefault(report.numel(), []).append(report)
+    else:
+        _pinned_quarantine.append(report)
+
 
 
 def _pinned(words):
     """One pinned int32 buffer of `words` words.  An empty pool is refilled SIXTEEN buffers at a time from one pinned
     allocation (a pipelined loop keeps a dozen reports in flight before the first one comes back: sixteen host allocations of
     ~30-100 us each used to sit in the first steps on fresh tensors)."""
+    if _pinned_quarantine:
+        for rep in [r for r in _pinned_quarantine if bool((r >= 0).all())]:
+            _pinned_quarantine.remove(rep)
+            _pinned_free.setdefault(rep.numel(), []).append(rep)
     pool = _pinned_free.setdefault(words, [])
     if not pool:
         stride = (words + 15) // 16 * 16                      # (64-byte aligned slices)
@@ -350,7 +376,7 @@ def workspace(device, nbytes, tag, stream=None):
     """Reusable device scratch buffer per (device, STREAM, tag); grows monotonically.  Kernels of one stream are
     ordered, so re-using the buffer call after call is safe; two streams (pipelined layers, threads) never share
     one -- a persistent loop of one stream would otherwise read factors another stream is overwriting."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream if stream is None else stream, tag)
+    key = (device.index, current_stream_handle(device) if stream is None else stream, tag)
     with _ws_lock:
         buf = _ws_cache.get(key)
         if buf is None or buf.numel() < nbytes:

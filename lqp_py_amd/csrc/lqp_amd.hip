@@ -1308,9 +1308,13 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     BwdParams<T> P;
     memset(&P, 0, sizeof(P));
     P.kkt = kkt ? 1 : 0;
+    const bool reported = (linsolve & LQP_BWD_REPORTED) != 0;
+    linsolve &= ~LQP_BWD_REPORTED;
     if (linsolve & LQP_BWD_PREFACTORED) { linsolve &= ~LQP_BWD_PREFACTORED; if (phase == 0 && !kkt) phase = 2; }
     P.host_report = (int*)host_report;
-    if (P.host_report) report_reset(P.host_report, B);
+    // (the words are set to -1 before the first launch, below -- unless the prefactor call has reported into them and this call
+    //  solves on its factor)
+    bool reset_pending = P.host_report != nullptr;
     P.early_report = knobs().bwd_early != 0 ? 1 : 0;
     const size_t need = carve_backward<T>(ws, B, n, m, P);
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
@@ -1331,6 +1335,9 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (!chol && phase == 1) return LQP_ERR_UNSUPPORTED;      // (nothing to run ahead of the cotangent on the LU form)
         if (!chol) phase = 0;
         P.phase = phase;
+        P.reported = (reported && phase == 2 && P.host_report) ? 1 : 0;
+        if (reset_pending && !P.reported) report_reset(P.host_report, B);
+        reset_pending = false;
         if (chol) {
             P.chol = 1;
             if (phase != 2) {
@@ -1351,6 +1358,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             if (phase == 1) return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
         }
     } else if (phase == 1) return LQP_ERR_UNSUPPORTED;
+    if (reset_pending) report_reset(P.host_report, B);
     if (chol) {
     } else if (P.reduced) {
         const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
@@ -1834,13 +1842,13 @@ size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m) {
 
 int lqp_boxqp_backward_fp_prefactor(void* stream, int dtype, int B, int n, int m, const void* x, const void* u, const void* Q,
                                     const void* A, const void* lb, const void* ub, void* workspace, size_t workspace_bytes,
-                                    int linsolve) {
+                                    int linsolve, void* host_report) {
     if (bad_dims(dtype, B, n, m) || !x || !u || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
     if (m > 0 && !A) return LQP_ERR_INVALID;
     if (dtype != LQP_F32 || linsolve != 2 || n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
     return backward_impl<float>((hipStream_t)stream, B, n, m, nullptr, x, u, nullptr, nullptr, Q, A, lb, ub, 1, 1.0, nullptr,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, 2,
-                                nullptr, 0, 1);
+                                host_report, 0, 1);
 }
 
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x, const void* u,

@@ -2376,7 +2376,8 @@ template <typename T> struct BwdParams {
     unsigned long long* dbg;   // optional cycle counters (8 per problem), debug only
     int la_maxk;               // largest block count the look-ahead Cholesky may take (LDS of the launch), 0 = off
     int* host_report;          // optional pinned host memory, B ints: the epilogue leaves every problem's info word there
-    int early_report;          // 1: Cholesky form -- k_bwd_chol_solve reports (the info words are final there), not the epilogue
+    int early_report;          // 1: Cholesky form -- k_bwd_chol_solve reports right behind its factorisation, not the epilogue
+    int reported;              // 1 (phase 2 only): the phase-1 call has stored the info words into host_report already
     int phase;                 // Cholesky form in two calls: 1 = free set + Q_FF + its factorisation only (no cotangent needed:
                                // enqueued right behind the forward), 2 = the solves + epilogue on that factor; 0 = everything
     int kkt;                   // 1: the KKT-system backward (backward='kkt', reference :435-584) on the same kernels: the (3n+m)
@@ -2657,6 +2658,18 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
         else if (Kb <= SPD_MAXK) wg_chol_factor(Ls, Kb, P.info + b, smem);
         else wg_chol_factor_big(Ls, Kb, P.info + b, smem);
     }
+    // The factorisation is what can fail (Q_FF not positive definite in float32: the caller repeats on the pivoted LU): its info
+    // word goes to the caller's pinned host memory NOW -- of the prefactor call when there was one (phase 1; phase 2 then finds
+    // P.reported) --, so that a synchronous caller, which polls those words, returns while the solves and the epilogue still run
+    // (stream-ordered results) and prepares its next call under them.  What the Schur complement of the equality rows can still
+    // find below (a pivot that is not a positive number: with its -1e-8 I that is a NaN, i.e. NaN inputs) is not reported
+    // any more: the epilogue poisons that problem's gradients with NaN, which is what the reference's solve hands back for it.
+    if (P.host_report && (P.early_report || P.phase == 1) && !P.reported) {      // (a prefactor call always reports)
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(P.host_report + b, __hip_atomic_load(P.info + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (P.phase == 1) return;              // (the factor is in the workspace: lqp_boxqp_backward_fp_prefactor)
     __syncthreads();
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 0] = t - dt0; dt0 = t; P.dbg[(size_t)b * 8 + 3] = Kb; }
@@ -2730,15 +2743,6 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     }
     for (int q = tid; q < m; q += LQP_NT) rhs[nf + q] = dn[q];
     if (P.dbg && tid == 0) P.dbg[(size_t)b * 8 + 2] = clock64() - dt0;
-    // The info word of this problem is final here: it goes to the caller's pinned host memory NOW (the epilogue of the
-    // Cholesky form does not report again), so a synchronous caller -- it polls those words -- returns while the epilogue
-    // still writes the gradients (stream-ordered results) and prepares its next call under it.
-    if (P.host_report && P.early_report) {
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(P.host_report + b, __hip_atomic_load(P.info + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // One step of iterative refinement for the LU form of the reduced system: r = rhs - M d with the ORIGINAL entries

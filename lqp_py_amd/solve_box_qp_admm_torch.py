@@ -28,6 +28,7 @@ _KKT_NATIVE = os.environ.get("LQP_KKT_NATIVE", "1") != "0"      # (A/B knob: 0 =
 _PREPARE_BWD = os.environ.get("LQP_PREPARE_BWD", "1") != "0"    # (A/B knob: 0 = the backward prepares itself when it is called)
 _PREFACTOR_BWD = os.environ.get("LQP_PREFACTOR_BWD", "1") != "0"   # (A/B knob: 0 = nothing of the backward runs ahead of the cotangent)
 _BWD_PREFACTORED = 0x100                                         # include/lqp_amd.h: LQP_BWD_PREFACTORED
+_BWD_REPORTED = 0x200                                            # include/lqp_amd.h: LQP_BWD_REPORTED
 
 
 class SolveBoxQP(nn.Module):
@@ -194,7 +195,7 @@ def _kkt_backward(dl_dz, x, lams, nus, Q, A, lb, ub, flags=None, linsolve=1, wan
         only_lb, only_ub = any_lb and not any_ub, any_ub and not any_lb
         dlb = mk((want['dlb'] and any_lb) or (want['dub'] and only_ub), (B, n, 1))
         dub = mk(want['dub'] and any_lb and any_ub, (B, n, 1))
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.current_stream_handle(dev)
         ws = _lib.workspace(dev, lib.lqp_boxqp_backward_fp_workspace_bytes(dt, B, n, m), "bwd", stream)
         fail = ctypes.c_int32(-1)
         report = _lib.host_report(B)
@@ -406,11 +407,22 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     ckey, cached = None, None
     cache = _ctl_cache.__dict__.setdefault('d', {})   # (per thread: the struct is written to below)
     if check_hook is None:
+        # (the dict of the last call, unchanged -- one C-level comparison of two dicts -- skips building and hashing the key)
+        last = _ctl_cache.__dict__.get('last')
         try:
-            ckey = (tuple(kv for kv in control.items() if kv[0][0] != '_'), n, bool(any_bound), bool(sync), p.dtype)
-            cached = cache.get(ckey)
-        except Exception:                             # an unhashable value, a key that is not a string: no caching
-            ckey = None
+            same = last is not None and last[0] is control and last[2] == (n, any_bound, sync, p.dtype) and last[1] == control
+        except Exception:                             # (a value that does not compare to a truth value: a tensor)
+            same = False
+        if same:
+            ckey, cached = last[3], last[4]
+        else:
+            try:
+                ckey = (tuple(kv for kv in control.items() if kv[0][0] != '_'), n, bool(any_bound), bool(sync), p.dtype)
+                cached = cache.get(ckey)
+            except Exception:                         # an unhashable value, a key that is not a string: no caching
+                ckey = None
+            if cached is not None:
+                _ctl_cache.last = (control, dict(control), (n, any_bound, sync, p.dtype), ckey, cached)
     if cached is not None:
         r, rho, ctl = cached
         rho_mode, rho_value, rho_tensor, beta_tensor = ctl.rho_mode, ctl.rho_value, None, None
@@ -468,7 +480,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     nbytes = _ws_bytes.get((dt, B, n, m))
     if nbytes is None:
         nbytes = _ws_bytes[(dt, B, n, m)] = lib.lqp_boxqp_forward_workspace_bytes(dt, B, n, m)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.current_stream_handle(dev)
     # (private_ws / keep_factor: the unroll mode keeps the solve's workspace -- factor included -- for its backward)
     ws = private_ws if private_ws is not None else _lib.workspace(dev, nbytes, "fwd", stream)
     ctl.reserved2 = 1 if keep_factor else 0
@@ -588,7 +600,7 @@ def last_forward_status(device):
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    ws, dt, B, n, m, st, check, max_iters = _last_forward[(device.index, torch.cuda.current_stream(device).cuda_stream)]
+    ws, dt, B, n, m, st, check, max_iters = _last_forward[(device.index, _lib.current_stream_handle(device))]
     if st["mode_used"] == 3:
         lib = _lib.load()
         so, sb, io, ib = (ctypes.c_size_t() for _ in range(4))
@@ -606,14 +618,17 @@ def last_forward_status(device):
 class _Prepared(dict):
     """What _fp_backward_prepare hands to _fp_backward_run.  A forward that is never followed by its backward (validation with
     grad enabled, an exception, a retry on the other schedule) drops it: the pinned report buffer then goes back to the pool
-    instead of leaking one buffer per call.  Nothing writes that buffer before the run (the prefactor phase reports
-    nothing: include/lqp_amd.h, lqp_boxqp_backward_fp_prefactor)."""
+    instead of leaking one buffer per call.  The prefactor phase reports into that buffer (include/lqp_amd.h,
+    lqp_boxqp_backward_fp_prefactor): it is re-used only once every word of it has arrived (_lib.pinned_release)."""
 
     def __del__(self):
         try:
             rep = self.get('report')
             if rep is not None and not self.get('ran'):
-                _lib._pinned_free.setdefault(rep.numel(), []).append(rep)
+                if self.get('pref_reported'):
+                    _lib.pinned_release(rep)
+                else:
+                    _lib._pinned_free.setdefault(rep.numel(), []).append(rep)
         except Exception:
             pass
 
@@ -646,7 +661,7 @@ def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, li
     dlb = mk(want['dlb'], (B, n, 1))
     dub = mk(want['dub'], (B, n, 1))
     nbytes = lib.lqp_boxqp_backward_fp_workspace_bytes(dt, B, n, m)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.current_stream_handle(dev)
     ws = _lib.workspace(dev, nbytes, "bwd", stream)
     fail = ctypes.c_int32(-1)
     report = _lib.host_report(B)                        # (the info words go straight into pinned host memory)
@@ -657,20 +672,22 @@ def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, li
             ctypes.byref(fail) if sync else None, _lib.ptr(ws), ws.numel())
     rep = None if report is None else ctypes.c_void_p(report.data_ptr())
     keep = (xc, uc, lc, nc, Qc, Ac, lbc, ubc, rho_tensor, ws)          # (the pointers above point into these)
-    pref = None
+    pref, pref_reported = None, False
     if prefactor and int(linsolve) == 2 and dt == _lib.LQP_F32:
         # (reads x, u behind the forward's kernels in stream order; LQP_ERR_UNSUPPORTED = no Cholesky form at this size:
-        #  nothing was enqueued)
+        #  nothing was enqueued.  The factorisation's info words go into the report buffer of the backward call: that call
+        #  then waits for them only -- it returns while its solves and the gradient epilogue run)
         with _lib.on_device(dev):
             st = lib.lqp_boxqp_backward_fp_prefactor(*head, _lib.ptr(xc), _lib.ptr(uc), _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc),
-                                                     _lib.ptr(ubc), _lib.ptr(ws), ws.numel(), 2)
+                                                     _lib.ptr(ubc), _lib.ptr(ws), ws.numel(), 2, rep if sync else None)
         if st == 0:
             pref = _lib.workspace_uses(dev, "bwd", stream)      # (still ours at `backward` if nobody asked for the buffer since)
+            pref_reported = bool(sync and rep is not None)
         elif st != 6:
             _lib.check(st, "torch_solve_box_qp_grad (prefactor)")
     return _Prepared(lib=lib, head=head, tail=tail, keep=keep, grads=(dQ, dp, dA, db, dlb, dub, None), fail=fail, report=report,
                      dev=dev, dty=dty, B=B, sync=sync, linsolve=int(linsolve), rep=rep, pref=pref, stream=stream,
-                     late_dQ=(B, n) if late_dQ else None)
+                     late_dQ=(B, n) if late_dQ else None, pref_reported=pref_reported)
 
 
 def _fp_backward_run(prep, dl_dz):
@@ -680,6 +697,8 @@ def _fp_backward_run(prep, dl_dz):
     linsolve = prep['linsolve']
     if prep['pref'] is not None and prep['pref'] == _lib.workspace_uses(dev, "bwd", prep['stream']):
         linsolve |= _BWD_PREFACTORED                       # the factorisation made behind the forward is still in the workspace
+        if prep.get('pref_reported'):
+            linsolve |= _BWD_REPORTED                      # ... and its info words are in (or on their way into) the report buffer
     # Every run writes the (shared, cached) backward workspace: a full run rebuilds free set, factor and info words in it, the
     # solve phase its right-hand sides.  Whoever prefactored into the same buffer earlier (forward A, forward B, backward A,
     # backward B: B's factor is overwritten by A's full run) must see the count move and run in full too.

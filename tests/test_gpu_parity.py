@@ -896,8 +896,53 @@ def test_backward_factorisation_ahead_of_the_cotangent_falls_back(dev):
     # float64 / the LU form: nothing to run ahead
     ws = torch.empty(int(lib.lqp_boxqp_backward_fp_workspace_bytes(_lib.LQP_F64, 3, 40, 1)), dtype=torch.uint8, device=dev)
     st = lib.lqp_boxqp_backward_fp_prefactor(_lib.stream_ptr(dev), _lib.LQP_F64, 3, 40, 1, _lib.ptr(x), _lib.ptr(u), _lib.ptr(a[0]),
-                                             _lib.ptr(a[2]), _lib.ptr(a[4]), _lib.ptr(a[5]), _lib.ptr(ws), ws.numel(), 2)
+                                             _lib.ptr(a[2]), _lib.ptr(a[4]), _lib.ptr(a[5]), _lib.ptr(ws), ws.numel(), 2, None)
     assert st == 6
+
+
+def test_report_of_the_factorisation_made_ahead(dev, monkeypatch):
+    """ABI 11: the prefactor call stores the factorisation's info words into the report buffer of the backward call, which then
+    waits for those words only (LQP_BWD_REPORTED) -- it returns while its solves and the epilogue run.  The same gradients as
+    without the early report; a prepared backward that is dropped while its prefactor kernels may still be queued keeps its
+    report buffer out of the pool until every word has arrived."""
+    import gc
+    n, B = 300, 16
+    d = O.create_qp_data(n, B, seed=31)
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(7)).to(dev)
+    layer = L.SolveBoxQP(control=L.box_qp_control(**TOL))
+    seen = []
+    real = SB._fp_backward_run
+
+    def spy(prep, dl_dz):
+        seen.append(bool(prep.get('pref_reported')))
+        return real(prep, dl_dz)
+    monkeypatch.setattr(SB, "_fp_backward_run", spy)
+    out = {}
+    for early in ("1", "0"):
+        monkeypatch.setenv("LQP_BWD_EARLY", early)
+        lv = [t.clone().to(dev).requires_grad_(True) for t in d]
+        layer(*lv).backward(cot)
+        torch.cuda.synchronize()
+        out[early] = [t.grad for t in lv]
+    assert seen == [True, True]
+    for a, b_ in zip(out["1"], out["0"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b_)
+    # dropped right behind the forward: the buffer may only come back once the prefactor's words are in
+    mine = lambda: [r for r in _lib._pinned_quarantine if r.numel() == B]
+    for _ in range(4):
+        lv = [t.clone().to(dev).requires_grad_(True) for t in d]
+        x = layer(*lv)
+        del x, lv
+        gc.collect()
+    torch.cuda.synchronize()
+    rep = _lib.host_report(B)                  # (an allocation sweeps the quarantine)
+    assert not mine()
+    _lib._pinned_free[B].append(rep)
+    lv = [t.clone().to(dev).requires_grad_(True) for t in d]
+    layer(*lv).backward(cot)
+    torch.cuda.synchronize()
+    for a, t in zip(out["1"], lv):
+        assert torch.equal(a, t.grad)
 
 
 # ---------------------------------------------------------------- SURVEY 8f rank 4: NumPy twin, OptNet (equality only)
