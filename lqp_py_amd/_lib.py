@@ -251,7 +251,7 @@ _pinned_quarantine = []  # report buffers a kernel that is still queued may writ
 def pinned_release(report):
     """A report buffer goes back to the pool -- at once when nothing can write it any more (every word has arrived: a kernel
     stores each word exactly once, the library set them to -1 before), otherwise when a later allocation finds it complete."""
-    if bool((report >= 0).all()):
+    if bool((report != -1).all()):
         _pinned_free.setdefault(report.numel(), []).append(report)
     else:
         _pinned_quarantine.append(report)
@@ -263,7 +263,7 @@ def _pinned(words):
     allocation (a pipelined loop keeps a dozen reports in flight before the first one comes back: sixteen host allocations of
     ~30-100 us each used to sit in the first steps on fresh tensors)."""
     if _pinned_quarantine:
-        for rep in [r for r in _pinned_quarantine if bool((r >= 0).all())]:
+        for rep in [r for r in _pinned_quarantine if bool((r != -1).all())]:
             _pinned_quarantine.remove(rep)
             _pinned_free.setdefault(rep.numel(), []).append(rep)
     pool = _pinned_free.setdefault(words, [])

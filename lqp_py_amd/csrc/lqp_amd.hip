@@ -139,6 +139,7 @@ struct Knobs {
     int bwd_early;             // LQP_BWD_EARLY
     int bwd_full;              // LQP_BWD_FULL
     int bwd_lookahead;         // LQP_BWD_LOOKAHEAD
+    int dbg_lu2_absent;        // LQP_DBG_LU2_ABSENT: tests only -- the partner workgroups of the two-workgroup LU are not launched
     int bwd_refine;            // LQP_BWD_REFINE
     int dbg_qpass;             // LQP_DBG_QPASS
     int dbg_setup;             // LQP_DBG_SETUP
@@ -185,6 +186,7 @@ Knobs read_knobs() {
     k.bwd_early = env_int("LQP_BWD_EARLY", 1);
     k.bwd_full = env_int("LQP_BWD_FULL", 0);
     k.bwd_lookahead = env_int("LQP_BWD_LOOKAHEAD", 1);
+    k.dbg_lu2_absent = env_int("LQP_DBG_LU2_ABSENT", 0);
     k.bwd_refine = env_int("LQP_BWD_REFINE", 1);
     k.dbg_qpass = env_int("LQP_DBG_QPASS", 0);
     k.dbg_setup = env_int("LQP_DBG_SETUP", 0);
@@ -290,7 +292,8 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
         return -1;
     const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
     { ProfScope ps(st, PC_LU);
-      hipLaunchKernelGGL(fn, dim3(2 * B), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
+      // (LQP_DBG_LU2_ABSENT: the hand-offs of workgroups b time out, info = -7, the caller repeats on one workgroup per matrix)
+      hipLaunchKernelGGL(fn, dim3(knobs().dbg_lu2_absent ? B : 2 * B), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
                          scr_stride, epoch, knobs().dbg_setup ? nullptr : g_lu_dbg, B, knobs().xcd_local != 0 ? 1 : 0); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
@@ -457,7 +460,7 @@ int first_failure(hipStream_t st, const int* info_dev, int B, int* fail_index, c
 
 
 // A synchronous call waits for its report, not for its stream: the words of a host report (pinned host memory, all set to
-// -1 by the call before its first launch; every word the kernels store is >= 0) are polled until none is missing.  A
+// -1 by the call before its first launch; no word the kernels store is -1) are polled until none is missing.  A
 // hipStreamSynchronize of a ~0.5 ms schedule parks the thread after 100 us of spinning and pays the interrupt + wake-up
 // on top of the completion signal's trip; the polled word is seen ~a microsecond after the store.  The device results
 // themselves are stream-ordered like those of any torch operator -- the host only ever reads the report.  The stream is
@@ -470,7 +473,7 @@ int wait_report(hipStream_t st, const int* host_report, int words) {
     int first_missing = 0;
     auto t_query = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
-        while (first_missing < words && r[first_missing] >= 0) ++first_missing;
+        while (first_missing < words && r[first_missing] != -1) ++first_missing;      // (-7, a hand-off that timed out, HAS arrived)
         if (first_missing >= words) { std::atomic_thread_fence(std::memory_order_acquire); return LQP_OK; }
         __builtin_ia32_pause();
         if ((spins & 255u) == 255u) {
@@ -479,7 +482,7 @@ int wait_report(hipStream_t st, const int* host_report, int words) {
                 t_query = now;
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipSuccess) {              // everything enqueued has run: the report must be complete now
-                    for (int i = first_missing; i < words; ++i) if (r[i] < 0) return LQP_ERR_HIP;
+                    for (int i = first_missing; i < words; ++i) if (r[i] == -1) return LQP_ERR_HIP;
                     return LQP_OK;
                 }
                 if (q != hipErrorNotReady) return LQP_ERR_HIP;
@@ -1335,7 +1338,8 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (!chol && phase == 1) return LQP_ERR_UNSUPPORTED;      // (nothing to run ahead of the cotangent on the LU form)
         if (!chol) phase = 0;
         P.phase = phase;
-        P.reported = (reported && phase == 2 && P.host_report) ? 1 : 0;
+        // (with LQP_BWD_EARLY=0 the epilogue reports: the words are this call's to reset and to wait for)
+        P.reported = (reported && phase == 2 && P.host_report && P.early_report) ? 1 : 0;
         if (reset_pending && !P.reported) report_reset(P.host_report, B);
         reset_pending = false;
         if (chol) {
@@ -1405,9 +1409,13 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (P.host_report && knobs().sync_plan != 0) {
             rc = wait_report(st, P.host_report, B);
             if (rc) return rc;
-            for (int i = 0; i < B && fi < 0; ++i)
-                if (((const volatile int*)P.host_report)[i] != 0) fi = i;
-            rc = fi >= 0 ? LQP_ERR_SINGULAR : LQP_OK;
+            bool gave_up = false;                    // (-7: a hand-off of a shared LU timed out)
+            for (int i = 0; i < B; ++i) {
+                const int v = ((const volatile int*)P.host_report)[i];
+                if (v != 0 && fi < 0) fi = i;
+                gave_up = gave_up || v == -7;
+            }
+            rc = gave_up ? LQP_ERR_TIMEOUT : fi >= 0 ? LQP_ERR_SINGULAR : LQP_OK;
         } else
             rc = first_failure(st, P.info, B, &fi, P.host_report);
         if (rc == LQP_ERR_TIMEOUT && !chol && !t_single_wg_lu) {      // a shared LU timed out: once more, one workgroup per matrix

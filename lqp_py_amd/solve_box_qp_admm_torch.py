@@ -73,6 +73,9 @@ class SolveBoxQPLayer(torch.autograd.Function):
             # a synchronous call only waits while its schedule runs: the backward's outputs, workspace and argument list are
             # made in that window (the cotangent is all that is missing), see _fp_backward_prepare
             def while_running(parts, linsolve_used):
+                if parts is None:          # (the solve is being repeated on another schedule: what was prepared is void)
+                    ctx.prepared = None
+                    return
                 # ... and the part of the backward that does not need the cotangent (free set, Q_FF, its Cholesky
                 # factorisation) is enqueued right behind the forward: it runs while this call returns, the caller forms its
                 # loss and autograd finds its way to `backward`, which then only solves
@@ -370,7 +373,7 @@ def _beta_argument(beta, B, like):
 
 
 def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residuals=False, check_hook=None, mutate=False,
-                   holder=None, private_ws=None, keep_factor=False, while_running=None):
+                   holder=None, private_ws=None, keep_factor=False, while_running=None, one_call=False):
     """bounds: (any_lb, any_ub) when the caller KNOWS them (a shard of a larger batch with host-side flags); None: found
     on the device.  mutate: apply the reference layer's dict side effect control['rho'] = 0 (:37-38).  holder: the
     nn.Module on whose behalf the call is made (keys what is remembered between calls, see _assume_any_bound)."""
@@ -457,6 +460,10 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
             if len(cache) > 64:
                 cache.clear()
             cache[ckey] = (r, rho, ctl)
+    # 1: pipelined (nothing waits); 2: split synchronous call -- enqueue, build the output views while the GPU runs, then
+    # lqp_boxqp_forward_finish polls the report (include/lqp_amd.h); 0: the library waits itself (and repeats by itself on the
+    # schedule that needs no partner when a shared kernel timed out: one_call, below)
+    ctl.reserved = (2 if (check_hook is None and _SYNC_SPLIT and not one_call) else 0) if sync else 1
     Qc, pc, Ac, bc, lbc, ubc = (_lib.norm(t, p.dtype) for t in (Q, p, A, b, lb, ub))
     hook_c = None
     # status / info words arrive in pinned host memory, stored there by the forward's last kernel (include/lqp_amd.h:
@@ -520,6 +527,16 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         # (the views above were made while the GPU ran; now the report: polled in pinned memory, no stream wait)
         st = lib.lqp_boxqp_forward_finish(ctypes.c_void_p(stream), B, ctl.max_iters, ctl.check_solved,
                                           ctypes.c_void_p(report.data_ptr()), ctypes.byref(stats))
+        if st == 5 and not one_call:
+            # a kernel that shares its problem with a partner workgroup gave up waiting for it (bounded spins; something else
+            # held the CUs): the one-call form of the synchronous forward degrades by itself -- one workgroup per matrix, the
+            # loop that needs nobody -- instead of failing
+            _lib._pinned_free.setdefault(report.numel(), []).append(report)
+            if while_running is not None:
+                while_running(None, 0)
+            return _forward_solve(Q, p, A, b, lb, ub, control, bounds=bounds, sync=sync, residuals=residuals, check_hook=check_hook,
+                                  mutate=mutate, holder=holder, private_ws=private_ws, keep_factor=keep_factor,
+                                  while_running=while_running, one_call=True)
         if st == 7:
             # the matrix left the symmetric x-update (not symmetric, or Qs + rho I not positive definite in f32): the
             # reference's algorithm -- the pivoted LU -- takes the solve, as a one-call synchronous forward does by itself

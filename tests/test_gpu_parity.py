@@ -900,6 +900,34 @@ def test_backward_factorisation_ahead_of_the_cotangent_falls_back(dev):
     assert st == 6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_shared_lu_that_times_out_degrades(dev, monkeypatch, dtype):
+    """The two-workgroup LU with its partner workgroups missing (LQP_DBG_LU2_ABSENT: what a chip whose CUs are held by somebody
+    else looks like): the hand-offs give up after their bounded spin, the info words say -7, and the synchronous layer repeats
+    the solve -- forward and backward -- with one workgroup per matrix instead of failing: the same numbers as an
+    undisturbed run."""
+    n, B, m = 200, 3, 2
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=77, with_eq=False)
+    g = torch.Generator().manual_seed(78)
+    A = torch.randn(B, m, n, generator=g)
+    b = A @ (0.5 * (lb + ub))
+    cot = torch.randn(B, n, 1, generator=g)
+    out = {}
+    for absent in ("0", "1"):
+        monkeypatch.setenv("LQP_DBG_LU2_ABSENT", absent)
+        lv = [t.clone().to(dtype).to(dev).requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        _lib.profile(enable=True, reset=True)
+        x = L.SolveBoxQP(control=L.box_qp_control(linsolve="lu", **TOL))(*lv)
+        x.backward(cot.to(dtype).to(dev))
+        torch.cuda.synchronize()
+        used = _lib.profile(); _lib.profile(enable=False)
+        out[absent] = ([x.detach()] + [t.grad for t in lv], used["lu_factor"][1])
+    assert out["1"][1] > out["0"][1], (out["0"][1], out["1"][1])          # (the repeated factorisations)
+    for a, e in zip(out["1"][0], out["0"][0]):
+        assert torch.isfinite(a).all()
+        assert err(a, e) <= 1e-5 * max(1.0, float(e.abs().max())), err(a, e)
+
+
 def test_report_of_the_factorisation_made_ahead(dev, monkeypatch):
     """ABI 11: the prefactor call stores the factorisation's info words into the report buffer of the backward call, which then
     waits for those words only (LQP_BWD_REPORTED) -- it returns while its solves and the epilogue run.  The same gradients as
