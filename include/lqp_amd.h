@@ -80,7 +80,11 @@ typedef struct lqp_boxqp_ctrl {
                                         rank-m equality correction (f32, n <= 1024, m <= 16, rho > 0; anything
                                         else, or a matrix that is not positive definite, runs on LU)            */
     int32_t reserved2;               /* bit 0: leave the complete factor (equality correction included) in the workspace for
-                                        lqp_boxqp_unroll_backward                                                    */
+                                        lqp_boxqp_unroll_backward; bit 1 (ABI 11): share nothing between workgroups -- one
+                                        workgroup per matrix everywhere, host-launched check segments: what the library falls
+                                        back to by itself when a kernel that waits for a partner workgroup gives up (CUs held
+                                        by another stream / process), and what a caller of lqp_boxqp_forward_finish that got
+                                        LQP_ERR_TIMEOUT passes when it repeats the forward                              */
     double eps_abs;
     double eps_rel;
     double rho_value;

@@ -140,6 +140,7 @@ struct Knobs {
     int bwd_full;              // LQP_BWD_FULL
     int bwd_lookahead;         // LQP_BWD_LOOKAHEAD
     int dbg_lu2_absent;        // LQP_DBG_LU2_ABSENT: tests only -- the partner workgroups of the two-workgroup LU are not launched
+    int dbg_loop_absent;       // LQP_DBG_LOOP_ABSENT: tests only -- bit 0 ... of the two-workgroup loop, bit 1 ... of the resident sweep, bit 2 ... of the unroll sweep
     int bwd_refine;            // LQP_BWD_REFINE
     int dbg_qpass;             // LQP_DBG_QPASS
     int dbg_setup;             // LQP_DBG_SETUP
@@ -187,6 +188,7 @@ Knobs read_knobs() {
     k.bwd_full = env_int("LQP_BWD_FULL", 0);
     k.bwd_lookahead = env_int("LQP_BWD_LOOKAHEAD", 1);
     k.dbg_lu2_absent = env_int("LQP_DBG_LU2_ABSENT", 0);
+    k.dbg_loop_absent = env_int("LQP_DBG_LOOP_ABSENT", 0);
     k.bwd_refine = env_int("LQP_BWD_REFINE", 1);
     k.dbg_qpass = env_int("LQP_DBG_QPASS", 0);
     k.dbg_setup = env_int("LQP_DBG_SETUP", 0);
@@ -581,7 +583,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                  const int retry = 0) {
     // retry: bit 0 -- the symmetric x-update gave the solve up (not symmetric / not positive definite in f32): pivoted LU;
     //        bit 1 -- a pair of the turn-taking two-workgroup loop (split_seg) waited for its partner in vain: the one-workgroup loop
+    //        bit 2 -- a kernel that shares its problems between workgroups gave up waiting (bounded spins: something else holds the
+    //                 CUs -- another stream, another process, RCCL): nothing shared this time -- one workgroup per matrix in every
+    //                 factorisation, host-launched check segments instead of the persistent loop with its grid barrier
     const bool force_lu = (retry & 1) != 0;
+    const bool solo = (retry & 4) != 0;
+    struct SoloScope { bool on; explicit SoloScope(bool o) : on(o && !t_single_wg_lu) { if (on) t_single_wg_lu = true; }
+                       ~SoloScope() { if (on) t_single_wg_lu = false; } } solo_scope(solo);
     FwdLayout<T> L = carve_forward<T>(ws, B, n, m);
     if (ws_bytes < L.bytes) return LQP_ERR_WORKSPACE;
     FwdParams<T>& P = L.P;
@@ -637,12 +645,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if (current_device_cus(&dev_, &cus_)) spd_split = B * SPD_NP <= cus_;
         spd_split = (knobs().spd_split < 0 ? (spd_split ? 1 : 0) : knobs().spd_split) != 0;
         spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
+        spd_split = spd_split && !solo;
     }
     bool spd_big_split = false;
     if (spd && P.Ks > SPD_MAXK) {
         int dev_ = 0, cus_ = 0;
         if (current_device_cus(&dev_, &cus_)) spd_big_split = B * SPD_NP <= cus_;
-        spd_big_split = (knobs().spd_split < 0 ? (spd_big_split ? 1 : 0) : knobs().spd_split) != 0;
+        spd_big_split = (knobs().spd_split < 0 ? (spd_big_split ? 1 : 0) : knobs().spd_split) != 0 && !solo;
     }
     // ... and, with the exchange buffer in the M area and the step flags behind the loop's granules, in ONE launch
     // (More matrices than half the CUs: the register-resident sweep with its pairs taking turns on the chip, as the loop does it
@@ -755,7 +764,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                         const int rlds = rs_q_lds_bytes(P.Ks);
                         r3 = ensure_lds((const void*)rs_fn, rlds);
                         if (r3) return r3;
-                        hipLaunchKernelGGL(rs_fn, dim3(B * rs_np), dim3(RS_NT), rlds, st, P, gate);
+                        hipLaunchKernelGGL(rs_fn, dim3((knobs().dbg_loop_absent & 2) ? B : B * rs_np), dim3(RS_NT), rlds, st, P, gate);
                         n_launch += 1;
                     } else {
                         for (int k = 0; k < P.Ks; ++k)
@@ -837,7 +846,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     if (rc) return rc;
     int mode = ctl->launch_mode;
     if (mode == 0) mode = knobs().launch_mode;     // auto: persistent when every workgroup is resident
-    if (ctl->check_hook) mode = 1;                           // the hook sits between the check segments
+    if (ctl->check_hook || solo) mode = 1;                   // the hook sits between the check segments | no grid barrier
     if (mode == 2) {
         // the grid barrier needs EVERY workgroup resident -- of the hot kernel and of the continuation kernel
         // (own block size and LDS footprint): take the smaller of the two answers
@@ -897,7 +906,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     bool loop_split_seg = false;
     if constexpr (sizeof(T) == 4) {
         if (spd && mode == 1 && !loop_split && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 &&
-            knobs().loop_split != 0 && knobs().loop_split_seg != 0 && !(retry & 2)) {
+            knobs().loop_split != 0 && knobs().loop_split_seg != 0 && !(retry & 2) && !solo) {
             int dev = 0, cus = 0, per_cu = 0;
             split_nt = 512;
             split_lds = split_loop_lds_bytes<512>(P.Ks, m);
@@ -968,7 +977,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         ProfScope ps(st, PC_LOOP);
         if constexpr (sizeof(T) == 4) {
             if (loop_split && it == 0) {
-                hipLaunchKernelGGL(split_fn, dim3(loop_np * B), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
+                hipLaunchKernelGGL(split_fn, dim3((knobs().dbg_loop_absent & 1) ? B : loop_np * B), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
                 return;
             }
             if (loop_small && it == 0) {
@@ -1100,6 +1109,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 SingleWgLu only;
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes, retry);
             }
+            if (rc == LQP_ERR_TIMEOUT && !solo)     // a shared sweep / loop / grid barrier gave up: once more with nothing shared
+                return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes,
+                                       retry | 4);
             if (rc == LQP_RETRY_LU)         // Qs + rho I not positive definite in f32 (first factorisation or an
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats,
                                        ws, ws_bytes, retry | 1);     // adaptive-rho one): the LU path takes the solve
@@ -1257,6 +1269,9 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             if (loop_split_seg && !(retry & 2))
                 return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes,
                                        retry | 2);
+            if (!solo)                      // (the same for every other shared schedule: retry bit 2)
+                return forward_impl<T>(st, B, n, m, Q, p, A, b, lb, ub, ctl, rho_in, x, z, u, lams, nus, rho_out, stats, ws, ws_bytes,
+                                       retry | 4);
             return LQP_ERR_TIMEOUT;
         }
         done = h_status[ST_DONE] != 0;
@@ -1664,9 +1679,10 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m, const void* 
     if (ctrl->max_iters < 1) return LQP_ERR_INVALID;
     if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    const int retry0 = (ctrl->reserved2 & 2) ? 4 : 0;      // (bit 1: the caller has seen a shared schedule time out -- nothing shared)
     if (dtype == LQP_F32)
-        return forward_impl<float>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes);
-    return forward_impl<double>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes);
+        return forward_impl<float>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes, retry0);
+    return forward_impl<double>(st, B, n, m, Q, p, A, b, lb, ub, ctrl, rho_in, x, z, u, lams, nus, rho_out, stats, workspace, workspace_bytes, retry0);
 }
 
 int lqp_boxqp_forward_finish(void* stream, int B, int max_iters, int check_solved, const void* host_report,
@@ -1731,7 +1747,7 @@ int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd
             blocks_per_cu(&per_cu, fn2, 512, lds2, dev) && per_cu >= 1 && 2 * B <= cus * per_cu) {
             static std::atomic<unsigned int> run{1u};
             ProfScope ps(st, PC_UNROLL);
-            hipLaunchKernelGGL(fn2, dim3(2 * B), dim3(512), lds2, st, P, U, run.fetch_add(1u));
+            hipLaunchKernelGGL(fn2, dim3((knobs().dbg_loop_absent & 4) ? B : 2 * B), dim3(512), lds2, st, P, U, run.fetch_add(1u));
             split_done = true;
         }
     }

@@ -251,7 +251,9 @@ __global__ __launch_bounds__(512) void k_unroll_sweep_split(const FwdParams<floa
                     }
                 }
             }
-            const float other = __builtin_bit_cast(float, (unsigned int)g);
+            // (a partner that never showed up -- the wait is bounded -- must not leave plausible numbers: NaN from here on, through
+            //  every later product into every gradient of this problem, and the time-out word for whoever reads the status)
+            const float other = flags[0] ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned int)g);
             y = part_id == 0 ? own + other : other + own;
         }
         return y;

@@ -490,7 +490,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     stream = _lib.current_stream_handle(dev)
     # (private_ws / keep_factor: the unroll mode keeps the solve's workspace -- factor included -- for its backward)
     ws = private_ws if private_ws is not None else _lib.workspace(dev, nbytes, "fwd", stream)
-    ctl.reserved2 = 1 if keep_factor else 0
+    ctl.reserved2 = (1 if keep_factor else 0) | (2 if one_call else 0)      # (bit 1: nothing shared between workgroups, see one_call)
     if check_hook is not None:
         # check_hook(counters) all-reduces (SUM) the four uint32 words of a check -- {not optimal, arrivals, wants rho,
         # ratio trigger} -- in place; it gets a tensor VIEW of the workspace at the device address the library names.

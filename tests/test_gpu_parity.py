@@ -928,6 +928,65 @@ def test_shared_lu_that_times_out_degrades(dev, monkeypatch, dtype):
         assert err(a, e) <= 1e-5 * max(1.0, float(e.abs().max())), err(a, e)
 
 
+def test_shared_sweep_that_times_out_degrades(dev, monkeypatch):
+    """... and the register-resident sweep of the factorisation with its partner workgroups missing (LQP_DBG_LOOP_ABSENT bit 1):
+    the step flags time out, the synchronous solve is repeated with one workgroup per matrix."""
+    n, B = 500, 3
+    d = [t.to(dev) for t in O.create_qp_data(n, B, seed=89)]
+    want = L.torch_solve_box_qp(*d, dict(L.box_qp_control(**TOL)))
+    monkeypatch.setenv("LQP_DBG_LOOP_ABSENT", "2")
+    got = L.torch_solve_box_qp(*d, dict(L.box_qp_control(**TOL)))
+    assert got["iter"] == want["iter"] and err(got["x"], want["x"]) <= 2e-5
+    assert got["_stats"]["loop_workgroups"] == 1 and want["_stats"]["loop_workgroups"] >= 2
+
+
+def test_shared_unroll_sweep_that_times_out_leaves_nan(dev, monkeypatch):
+    """unroll=True, the reverse sweep on two workgroups per QP with the partners missing (LQP_DBG_LOOP_ABSENT bit 2): nothing
+    waits for that launch, so nothing can repeat it -- the gradients of the problems concerned are NaN, never plausible numbers."""
+    n, B = 400, 2
+    Q, p, A, b, lb, ub = O.create_qp_data(n, B, seed=90)
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(91)).to(dev)
+    grads = {}
+    for absent in ("0", "4"):
+        monkeypatch.setenv("LQP_DBG_LOOP_ABSENT", absent)
+        lv = [t.clone().to(dev).requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        x = L.SolveBoxQP(control=L.box_qp_control(unroll=True, **TOL))(*lv)
+        x.backward(cot)
+        torch.cuda.synchronize()
+        grads[absent] = [t.grad for t in lv]
+    assert all(torch.isfinite(t).all() for t in grads["0"])
+    assert not torch.isfinite(grads["4"][1]).any() and not torch.isfinite(grads["4"][0]).all()
+
+
+@pytest.mark.parametrize("sync", [True, False])
+def test_shared_loop_that_times_out_degrades(dev, monkeypatch, sync):
+    """The two-workgroup loop of the symmetric path with its partner workgroups missing (LQP_DBG_LOOP_ABSENT): the exchange waits
+    give up after their bounded spin and raise the time-out word; a synchronous call -- the split one of the layer and the one-call
+    form of torch_solve_box_qp with a strict stop hook alike -- repeats the solve with nothing shared between workgroups and
+    returns the undisturbed answer; a pipelined call cannot repeat: it reports the time-out late, its outputs are NaN."""
+    n, B = 500, 4
+    d = [t.to(dev) for t in O.create_qp_data(n, B, seed=88)]
+    ctl = L.box_qp_control(sync=sync, **TOL)
+    want = L.torch_solve_box_qp(*d, dict(L.box_qp_control(**TOL)))
+    assert want["_stats"]["loop_workgroups"] >= 2
+    monkeypatch.setenv("LQP_DBG_LOOP_ABSENT", "1")
+    if sync:
+        got = L.torch_solve_box_qp(*d, dict(ctl))
+        assert got["iter"] == want["iter"] and got["_stats"]["loop_workgroups"] == 1
+        assert err(got["x"], want["x"]) <= 2e-5
+        x = L.SolveBoxQP(control=dict(ctl))(*d)
+        assert err(x, want["x"]) <= 2e-5
+    else:
+        x = L.SolveBoxQP(control=dict(ctl))(*d)
+        with pytest.raises(RuntimeError):
+            L.synchronize()
+        monkeypatch.setenv("LQP_DBG_LOOP_ABSENT", "0")
+        assert not torch.isfinite(x).all()
+        x = L.SolveBoxQP(control=dict(ctl))(*d)
+        L.synchronize()
+        assert err(x, want["x"]) <= 2e-5
+
+
 def test_report_of_the_factorisation_made_ahead(dev, monkeypatch):
     """ABI 11: the prefactor call stores the factorisation's info words into the report buffer of the backward call, which then
     waits for those words only (LQP_BWD_REPORTED) -- it returns while its solves and the epilogue run.  The same gradients as
