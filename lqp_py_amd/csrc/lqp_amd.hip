@@ -1393,6 +1393,11 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec,
                        (unsigned long long*)P.packed, packed_blocks(P.K) * LQP_BLK * sizeof(T) / 8);
         if (rc) return rc;
+        if (P.host_report && P.early_report && fail_index) {      // (a caller that waits: the LU is the step that can fail or time out -- its info words now, see k_report_info)
+            ProfScope ps(st, PC_MISC);
+            hipLaunchKernelGGL(k_report_info<>, dim3((B + 255) / 256), dim3(256), 0, st, (const int*)P.info, P.host_report, B);
+            P.lu_reported = 1;
+        }
         rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr, nvec);
         if (rc) return rc;
         rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);

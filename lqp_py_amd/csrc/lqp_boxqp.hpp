@@ -2378,6 +2378,7 @@ template <typename T> struct BwdParams {
     int* host_report;          // optional pinned host memory, B ints: the epilogue leaves every problem's info word there
     int early_report;          // 1: Cholesky form -- k_bwd_chol_solve reports right behind its factorisation, not the epilogue
     int reported;              // 1 (phase 2 only): the phase-1 call has stored the info words into host_report already
+    int lu_reported;           // 1: LU form -- k_report_info has stored them right behind the factorisation, the epilogue does not
     int phase;                 // Cholesky form in two calls: 1 = free set + Q_FF + its factorisation only (no cotangent needed:
                                // enqueued right behind the forward), 2 = the solves + epilogue on that factor; 0 = everything
     int kkt;                   // 1: the KKT-system backward (backward='kkt', reference :435-584) on the same kernels: the (3n+m)
@@ -2863,7 +2864,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_epilogue(const BwdParams<T> P) {
     const T* x = P.x + (size_t)b * n;
     // singular system / Q_FF not positive definite: gradients come out as NaN, never as plausible garbage
     const T poison = P.info[b] != 0 ? T(__builtin_nanf("")) : T(0);
-    if (P.host_report && !(P.chol && P.early_report) && tid == 0 && blockIdx.y == 0)      // (straight into pinned host memory: no device-to-host copy behind the
+    if (P.host_report && !(P.chol && P.early_report) && !P.lu_reported && tid == 0 && blockIdx.y == 0)      // (straight into pinned host memory: no device-to-host copy behind the
                                                                        //  call; Cholesky form: k_bwd_chol_solve has reported already)
         __hip_atomic_store(P.host_report + b, P.info[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (P.reduced) {
@@ -3024,6 +3025,14 @@ __global__ void k_copy_matrix(const T* __restrict__ src, const int lds_, const s
     for (int i = w; i < N; i += nw)
         for (int j = lane; j < N; j += 64) dst[(size_t)b * dstride + (size_t)i * ldd + j] = src[(size_t)b * sstride + (size_t)i * lds_ + j];
 }
+// the info words of a factorisation into the caller's pinned host memory (LU form of the backward: they are final behind the LU, a
+// synchronous caller that polls them returns while pack, solves and epilogue still run)
+template <int LQP_ANY = 0>
+__global__ void k_report_info(const int* __restrict__ info, int* __restrict__ host_report, const int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) __hip_atomic_store(host_report + i, info[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <typename TI>
 __global__ void k_copy_ints(const TI* __restrict__ src, const int sstride, TI* __restrict__ dst, const int dstride, const int N) {
     const int b = blockIdx.x;

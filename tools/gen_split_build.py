@@ -43,6 +43,7 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
+    "void lqp::k_report_info<0>(int const*, int*, int)",
     "void lqp::k_admm_loop_dense_w<float>(lqp::FwdParams<float>, int, int, int, int)",
     "void lqp::k_admm_loop_dense_w<double>(lqp::FwdParams<double>, int, int, int, int)",
     "void lqp::k_admm_loop_dense<float>(lqp::FwdParams<float>, int, int, int)",

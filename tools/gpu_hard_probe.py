@@ -10,21 +10,22 @@ from lqp_py_amd.synthetic import create_hard_qp_data
 dev = torch.device("cuda:0")
 dt_ = torch.float64 if (len(sys.argv) < 2 or sys.argv[1] == "f64") else torch.float32
 hard = create_hard_qp_data(250, 0.85, range(128), dtype=dt_, device=dev)
-layer = L.SolveBoxQP(control=dict(L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5), sync=False))
+SYNC = bool(int(os.environ.get("SYNC", "0")))          # SYNC=1: the layer's default synchronous calls (what experiment_1_hard.py gets)
+layer = L.SolveBoxQP(control=dict(L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5), sync=SYNC))
 cot = torch.ones_like(hard[1])
 def step():
     Q = hard[0].detach().requires_grad_(True); p = hard[1].detach().requires_grad_(True)
     layer(Q, p, *hard[2:]).backward(cot)
-for _ in range(3): step()
+for _ in range(10): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(10): step()
+for _ in range(40): step()
 torch.cuda.synchronize(); L.synchronize()
-dt = (time.perf_counter() - t0) / 10
+dt = (time.perf_counter() - t0) / 40
 st = last_forward_status(dev)
 _lib.profile(enable=True, reset=True)
 for _ in range(5): step()
 torch.cuda.synchronize()
 pr = {k: round(v[0] / 5, 4) for k, v in _lib.profile().items() if v[1]}
 _lib.profile(enable=False)
-print(f"{dt_}: {dt*1e3:.3f} ms/step  iters {st['iters']} linsolve {st['linsolve_used']} mode {st['mode_used']}  {pr}")
+print(f"{dt_} sync={SYNC}: {dt*1e3:.3f} ms/step  iters {st['iters']} linsolve {st['linsolve_used']} mode {st['mode_used']}  {pr}")
