@@ -272,8 +272,10 @@ size_t lqp_boxqp_backward_fp_workspace_bytes(int dtype, int B, int n, int m);
  * forward (the reference's semantics) then has the factorisation running while its host code travels from `forward` to
  * `backward`.  lqp_boxqp_backward_fp called afterwards on the SAME workspace (nothing else may have used it in between)
  * with linsolve = 2 | LQP_BWD_PREFACTORED only gathers dl_dz, solves and writes the gradients; a factorisation that
- * failed still ends in that call's pivoted-LU retry.  LQP_ERR_UNSUPPORTED: no Cholesky form for these sizes / dtype
- * (float32, linsolve 2 only) -- nothing was enqueued, call lqp_boxqp_backward_fp without the flag.
+ * failed still ends in that call's pivoted-LU retry.  ABI 11: the LU form (float64, linsolve 0 / 1, sizes without a Cholesky
+ * form) has the same two phases -- free set, reduced system, pivoted LU and packed factor ahead; gather, solve, refinement and
+ * epilogue behind.  LQP_ERR_UNSUPPORTED: this form has no phases (LQP_BWD_FULL builds) -- nothing was enqueued, call
+ * lqp_boxqp_backward_fp without the flag.
  * host_report (optional, pinned host memory, B ints; ABI 11): the factorisation is the only step of the Cholesky form that
  * sends a caller to the LU retry, so its info words are final when this call's last kernel ends -- it stores them there
  * (set to -1 by this call before its first launch).  lqp_boxqp_backward_fp given the SAME buffer and

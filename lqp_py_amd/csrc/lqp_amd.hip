@@ -1350,13 +1350,20 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     if constexpr (sizeof(T) == 4) {
         chol = P.reduced && linsolve == 2 && knobs().bwd_chol && round_up(n, LQP_NB) / LQP_NB <= SPD_BIGK &&
                m <= SPD_MAXM && bwd_chol_lds_bytes(n, m) <= 160 * 1024;
-        if (!chol && phase == 1) return LQP_ERR_UNSUPPORTED;      // (nothing to run ahead of the cotangent on the LU form)
-        if (!chol) phase = 0;
-        P.phase = phase;
-        // (with LQP_BWD_EARLY=0 the epilogue reports: the words are this call's to reset and to wait for)
-        P.reported = (reported && phase == 2 && P.host_report && P.early_report) ? 1 : 0;
-        if (reset_pending && !P.reported) report_reset(P.host_report, B);
-        reset_pending = false;
+    }
+    // the LU form has the same two phases (ABI 11): 1 = free set, reduced system, its pivoted LU and the packed factor -- none of
+    // them needs the cotangent --, 2 = gather the cotangent over the free set, solve (+ refinement), epilogue
+    const bool lu_phases = !chol && P.reduced && !kkt;
+    if (!chol && !lu_phases) {
+        if (phase == 1) return LQP_ERR_UNSUPPORTED;               // (the full-system form, the KKT backward: one call)
+        phase = 0;
+    }
+    P.phase = phase;
+    // (with LQP_BWD_EARLY=0 the epilogue reports: the words are this call's to reset and to wait for)
+    P.reported = (reported && phase == 2 && P.host_report && P.early_report) ? 1 : 0;
+    if (reset_pending && !P.reported) report_reset(P.host_report, B);
+    reset_pending = false;
+    if constexpr (sizeof(T) == 4) {
         if (chol) {
             P.chol = 1;
             if (phase != 2) {
@@ -1376,9 +1383,11 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
             hipLaunchKernelGGL(k_bwd_chol_solve<>, dim3(B), dim3(LQP_NT), lds, st, P);
             if (phase == 1) return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
         }
-    } else if (phase == 1) return LQP_ERR_UNSUPPORTED;
-    if (reset_pending) report_reset(P.host_report, B);
+    }
     if (chol) {
+    } else if (phase == 2) {
+        ProfScope ps(st, PC_BWD_BUILD);
+        hipLaunchKernelGGL(k_bwd_gather_rhs<T>, dim3(B), dim3(256), 0, st, P);
     } else if (P.reduced) {
         const int lds = (round_up(n, 8) + LQP_NW + 8) * 4;
         ProfScope ps(st, PC_BWD_BUILD);
@@ -1390,16 +1399,21 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     }
     int rc = LQP_OK;
     if (!chol) {
-        rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec,
-                       (unsigned long long*)P.packed, packed_blocks(P.K) * LQP_BLK * sizeof(T) / 8);
-        if (rc) return rc;
-        if (P.host_report && P.early_report && fail_index) {      // (a caller that waits: the LU is the step that can fail or time out -- its info words now, see k_report_info)
-            ProfScope ps(st, PC_MISC);
-            hipLaunchKernelGGL(k_report_info<>, dim3((B + 255) / 256), dim3(256), 0, st, (const int*)P.info, P.host_report, B);
-            P.lu_reported = 1;
-        }
-        rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr, nvec);
-        if (rc) return rc;
+        if (phase != 2) {
+            rc = launch_lu(st, P.M, B, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.info, nullptr, nvec,
+                           (unsigned long long*)P.packed, packed_blocks(P.K) * LQP_BLK * sizeof(T) / 8);
+            if (rc) return rc;
+            // a caller that waits (or a prefactor call: its report buffer is the backward call's): the LU is the step that can
+            // fail or time out -- its info words now, see k_report_info
+            if (P.host_report && (phase == 1 || (P.early_report && fail_index))) {
+                ProfScope ps(st, PC_MISC);
+                hipLaunchKernelGGL(k_report_info<>, dim3((B + 255) / 256), dim3(256), 0, st, (const int*)P.info, P.host_report, B);
+                P.lu_reported = 1;
+            }
+            rc = launch_pack<T>(st, B, P.M, P.N, P.Np, (size_t)P.Np * P.Np, P.piv, P.Np, P.packed, P.dest, nullptr, nvec);
+            if (rc) return rc;
+            if (phase == 1) return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+        } else if (P.reported) P.lu_reported = 1;
         rc = launch_solve<T>(st, B, P.packed, P.N, P.dest, P.rhs, 1, (size_t)P.Np, 1, 0, nvec);
         if (rc) return rc;
         if (P.reduced && !kkt && knobs().bwd_refine) {
@@ -1874,10 +1888,14 @@ int lqp_boxqp_backward_fp_prefactor(void* stream, int dtype, int B, int n, int m
                                     int linsolve, void* host_report) {
     if (bad_dims(dtype, B, n, m) || !x || !u || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
     if (m > 0 && !A) return LQP_ERR_INVALID;
-    if (dtype != LQP_F32 || linsolve != 2 || n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
-    return backward_impl<float>((hipStream_t)stream, B, n, m, nullptr, x, u, nullptr, nullptr, Q, A, lb, ub, 1, 1.0, nullptr,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, 2,
-                                host_report, 0, 1);
+    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (dtype == LQP_F32)
+        return backward_impl<float>((hipStream_t)stream, B, n, m, nullptr, x, u, nullptr, nullptr, Q, A, lb, ub, 1, 1.0, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                                    linsolve == 2 ? 2 : 1, host_report, 0, 1);
+    return backward_impl<double>((hipStream_t)stream, B, n, m, nullptr, x, u, nullptr, nullptr, Q, A, lb, ub, 1, 1.0, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, 1,
+                                 host_report, 0, 1);
 }
 
 int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x, const void* u,
@@ -1893,7 +1911,8 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const vo
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LQP_F32)
         return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, linsolve, host_report);
-    return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, 1, host_report);
+    return backward_impl<double>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes,
+                                 1 | (linsolve & (LQP_BWD_PREFACTORED | LQP_BWD_REPORTED)), host_report);
 }
 
 int lqp_boxqp_backward_kkt(void* stream, int dtype, int B, int n, int m, const void* dl_dz, const void* x,

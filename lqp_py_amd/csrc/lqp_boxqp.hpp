@@ -2535,7 +2535,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
             M[(size_t)a0 * Np + nf + r] = A[(size_t)r * n + i0];
             if (a1 != a0) M[(size_t)a1 * Np + nf + r] = A[(size_t)r * n + i1];
         }
-        if (lane == 0) { rhs[a0] = -g[i0]; if (a1 != a0) rhs[a1] = -g[i1]; }
+        if (lane == 0 && P.g) { rhs[a0] = -g[i0]; if (a1 != a0) rhs[a1] = -g[i1]; }      // (no cotangent yet: phase 1, k_bwd_gather_rhs later)
     }
     for (int r = w * ny + wy; r < m; r += LQP_NW * ny) {
         T* mr = M + (size_t)(nf + r) * Np;
@@ -3025,6 +3025,19 @@ __global__ void k_copy_matrix(const T* __restrict__ src, const int lds_, const s
     for (int i = w; i < N; i += nw)
         for (int j = lane; j < N; j += 64) dst[(size_t)b * dstride + (size_t)i * ldd + j] = src[(size_t)b * sstride + (size_t)i * lds_ + j];
 }
+// phase 2 of the LU form: the right-hand side [-g_F; 0] over the free set phase 1 left in the workspace (what k_bwd_build_reduced
+// writes itself when it has the cotangent)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_gather_rhs(const BwdParams<T> P) {
+    const int b = blockIdx.x, n = P.n, m = P.m;
+    const int nf = P.nred[b] - m;
+    const T* g = P.g + (size_t)b * n;
+    const int* fl = P.fidx + (size_t)b * n;
+    T* rhs = P.rhs + (size_t)b * P.Np;
+    for (int a = threadIdx.x; a < nf; a += 256) rhs[a] = -g[fl[a]];
+    for (int r = threadIdx.x; r < m; r += 256) rhs[nf + r] = T(0);
+}
+
 // the info words of a factorisation into the caller's pinned host memory (LU form of the backward: they are final behind the LU, a
 // synchronous caller that polls them returns while pack, solves and epilogue still run)
 template <int LQP_ANY = 0>

@@ -690,13 +690,14 @@ def _fp_backward_prepare(x, u, lams, nus, Q, A, lb, ub, rho, want, sync=True, li
     rep = None if report is None else ctypes.c_void_p(report.data_ptr())
     keep = (xc, uc, lc, nc, Qc, Ac, lbc, ubc, rho_tensor, ws)          # (the pointers above point into these)
     pref, pref_reported = None, False
-    if prefactor and int(linsolve) == 2 and dt == _lib.LQP_F32:
-        # (reads x, u behind the forward's kernels in stream order; LQP_ERR_UNSUPPORTED = no Cholesky form at this size:
-        #  nothing was enqueued.  The factorisation's info words go into the report buffer of the backward call: that call
-        #  then waits for them only -- it returns while its solves and the gradient epilogue run)
+    if prefactor:
+        # (reads x, u behind the forward's kernels in stream order -- the Cholesky form with linsolve 2, else the reduced system's
+        #  pivoted LU and its packed factor; LQP_ERR_UNSUPPORTED = this form has no phases: nothing was enqueued.  The
+        #  factorisation's info words go into the report buffer of the backward call: that call then waits for them only -- it
+        #  returns while its solves and the gradient epilogue run)
         with _lib.on_device(dev):
             st = lib.lqp_boxqp_backward_fp_prefactor(*head, _lib.ptr(xc), _lib.ptr(uc), _lib.ptr(Qc), _lib.ptr(Ac), _lib.ptr(lbc),
-                                                     _lib.ptr(ubc), _lib.ptr(ws), ws.numel(), 2, rep if sync else None)
+                                                     _lib.ptr(ubc), _lib.ptr(ws), ws.numel(), int(linsolve), rep if sync else None)
         if st == 0:
             pref = _lib.workspace_uses(dev, "bwd", stream)      # (still ours at `backward` if nobody asked for the buffer since)
             pref_reported = bool(sync and rep is not None)

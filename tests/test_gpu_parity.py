@@ -893,11 +893,24 @@ def test_backward_factorisation_ahead_of_the_cotangent_falls_back(dev):
         g2 = SB._fp_backward_run(prep, cot)
         for t1, t2 in zip(g1[:6], g2[:6]):
             assert torch.equal(t1, t2)
-    # float64 / the LU form: nothing to run ahead
-    ws = torch.empty(int(lib.lqp_boxqp_backward_fp_workspace_bytes(_lib.LQP_F64, 3, 40, 1)), dtype=torch.uint8, device=dev)
-    st = lib.lqp_boxqp_backward_fp_prefactor(_lib.stream_ptr(dev), _lib.LQP_F64, 3, 40, 1, _lib.ptr(x), _lib.ptr(u), _lib.ptr(a[0]),
-                                             _lib.ptr(a[2]), _lib.ptr(a[4]), _lib.ptr(a[5]), _lib.ptr(ws), ws.numel(), 2, None)
-    assert st == 6
+    # float64 / linsolve 1, the LU form (ABI 11): free set, reduced system, pivoted LU and packed factor ahead of the cotangent --
+    # the same kernels on the same values as the one-call backward
+    for dtype, ls in ((torch.float64, 1), (torch.float32, 1), (torch.float64, 2)):
+        a = [t.to(dtype).to(dev) for t in (Q, p, A, b, lb, ub)]
+        x = (0.3 * torch.randn(3, 40, 1, generator=torch.Generator().manual_seed(3))).to(dtype).to(dev)
+        u = torch.zeros_like(x)
+        lams = torch.zeros(3, 80, 1, dtype=dtype, device=dev); nus = torch.zeros(3, 1, 1, dtype=dtype, device=dev)
+        cot = torch.randn(3, 40, 1, dtype=dtype, device=dev)
+        g1 = SB._fp_backward(cot, x, u, lams, nus, a[0], a[2], a[4], a[5], 1.0, want, sync=True, linsolve=ls)
+        prep = SB._fp_backward_prepare(x, u, lams, nus, a[0], a[2], a[4], a[5], 1.0, want, sync=True, linsolve=ls, prefactor=True)
+        assert prep["pref"] is not None and prep["pref_reported"]
+        _lib.profile(enable=True, reset=True)
+        g2 = SB._fp_backward_run(prep, cot)
+        torch.cuda.synchronize()
+        used = _lib.profile(); _lib.profile(enable=False)
+        assert used["lu_factor"][1] == 0 and used["pack"][1] == 0, (dtype, ls, used)      # (the solve phase only)
+        for t1, t2 in zip(g1[:6], g2[:6]):
+            assert torch.isfinite(t1).all() and torch.equal(t1, t2), (dtype, ls)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
