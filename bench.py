@@ -589,6 +589,10 @@ def main():
         hard = create_hard_qp_data(250, 0.85, range(B), dtype=torch.float64, device=dev)      # prob 0.85 (experiment_1_hard.py:15), m = round(sqrt(250)) = 16
         more["b128_n250_m16_hard_fp64"] = dict(fwd_bwd_rate(piped(), hard, 20, warm=5), dtype="f64", linsolve="lu (pivoted LU: f64)",
                                                profile=profile_twin("hard64"))
+        # ... and with the layer's default synchronous calls: what an unchanged experiments/experiment_1_hard.py gets (the LU form of
+        # the backward factorised ahead of the cotangent and reporting behind its LU, ABI 11)
+        more["b128_n250_m16_hard_fp64_sync_default"] = dict(
+            fwd_bwd_rate(L.SolveBoxQP(control=L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False)), hard, 40, warm=10), dtype="f64")
         del hard
         out["other_workloads_fwd_bwd"] = more
         # ---- the reference's training experiment (experiments/experiment_2.py:12-20,57-99): Linear(5 -> 500) -> layer -> QP
