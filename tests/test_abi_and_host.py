@@ -224,3 +224,29 @@ def test_register_budgets_of_the_hot_kernels():
         assert res[k][1] <= spill and res[k][2] <= scratch, (k, res[k])
     for k, (vg, _, _) in res.items():
         assert vg <= 256, (k, vg)
+
+
+def test_report_buffer_quarantine():
+    """A report buffer that a queued kernel may still write (a prefactored backward that was dropped) is handed out again only
+    once every word of it has arrived: -1 is the library's "missing", everything else -- 0, a pivot index, -7 -- has arrived."""
+    import torch
+    words = 5
+    saved_free, saved_q = dict(_lib._pinned_free), list(_lib._pinned_quarantine)
+    try:
+        _lib._pinned_free.clear(); del _lib._pinned_quarantine[:]
+        spare = torch.zeros(words, dtype=torch.int32)
+        _lib._pinned_free[words] = [spare]                      # (so that the pool is never refilled from pinned memory here)
+        done = torch.tensor([0, 0, 3, 0, -7], dtype=torch.int32)
+        _lib.pinned_release(done)
+        assert _lib._pinned_free[words][-1] is done and not _lib._pinned_quarantine
+        busy = torch.tensor([0, -1, 0, -1, 0], dtype=torch.int32)
+        _lib.pinned_release(busy)
+        assert _lib._pinned_quarantine == [busy] or (len(_lib._pinned_quarantine) == 1 and _lib._pinned_quarantine[0] is busy)
+        got = _lib.host_report(words)
+        assert got is done and _lib._pinned_quarantine[0] is busy          # (still being written: stays out of the pool)
+        busy[1] = 0; busy[3] = 2
+        got2 = _lib.host_report(words)
+        assert not _lib._pinned_quarantine and got2 is busy                # (swept into the pool, handed out last-in first-out)
+    finally:
+        _lib._pinned_free.clear(); _lib._pinned_free.update(saved_free)
+        del _lib._pinned_quarantine[:]; _lib._pinned_quarantine.extend(saved_q)
