@@ -139,6 +139,7 @@ struct Knobs {
     int bwd_early;             // LQP_BWD_EARLY
     int bwd_full;              // LQP_BWD_FULL
     int bwd_lookahead;         // LQP_BWD_LOOKAHEAD
+    int inv_xcd;               // LQP_INV_XCD: the inverse's column tiles of one problem on one XCD (0: grid order)
     int dbg_lu2_absent;        // LQP_DBG_LU2_ABSENT: tests only -- the partner workgroups of the two-workgroup LU are not launched
     int dbg_loop_absent;       // LQP_DBG_LOOP_ABSENT: tests only -- bit 0 ... of the two-workgroup loop, bit 1 ... of the resident sweep, bit 2 ... of the unroll sweep
     int bwd_refine;            // LQP_BWD_REFINE
@@ -187,6 +188,7 @@ Knobs read_knobs() {
     k.bwd_early = env_int("LQP_BWD_EARLY", 1);
     k.bwd_full = env_int("LQP_BWD_FULL", 0);
     k.bwd_lookahead = env_int("LQP_BWD_LOOKAHEAD", 1);
+    k.inv_xcd = env_int("LQP_INV_XCD", 1);
     k.dbg_lu2_absent = env_int("LQP_DBG_LU2_ABSENT", 0);
     k.dbg_loop_absent = env_int("LQP_DBG_LOOP_ABSENT", 0);
     k.bwd_refine = env_int("LQP_BWD_REFINE", 1);
@@ -421,7 +423,11 @@ int launch_lu_inverse_cfg(hipStream_t st, int B, int N, const T* packed, size_t 
     //  several 256-thread workgroups per CU hide each other's barriers and operand loads)
     int G = std::max(1, std::min(ntiles, (12 * cus) / std::max(B, 1)));
     ProfScope ps(st, PC_PACK);
-    hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, Np / LQP_NB, dest, dstride, X, xstride, ldx, gate);
+    // (the tiles of a problem side by side on one XCD -- they all read the same factor --, see k_lu_inverse)
+    if (G > 1 && B % 8 == 0 && knobs().inv_xcd != 0)
+        hipLaunchKernelGGL(fn, dim3(B * G), dim3(256), lds, st, packed, pkstride, N, G, dest, dstride, X, xstride, ldx, gate);
+    else
+        hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, 0, dest, dstride, X, xstride, ldx, gate);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 // float32: 64-column tiles on v_mfma_f32_32x32x2 while Y fits the LDS (N <= 576), 16-column tiles on v_mfma_f32_16x16x4 above

@@ -122,19 +122,31 @@ template <bool SMALL> struct InvAcc<double, SMALL> {
 
 // X[0:N, 0:N] (row-major, leading dimension ldx) = M^-1; packed / dest: what k_pack left (dest[r]: position of original
 // right-hand-side row r after the row interchanges).  grid = (B, G): workgroup (b, g) takes column tiles g, g + G, ...
+// Gx > 0: a ONE-dimensional grid of B * Gx workgroups (B a multiple of 8), one tile each, dealt out so that the tiles of a
+// problem run on ONE XCD at about the same time: workgroup id -> XCD id % 8 (the dispatcher's round robin), slot id / 8 on it,
+// problem 8 * (slot / Gx) + XCD, tile slot % Gx.  Every tile reads the whole factor (960 KB at N = 266, float64); with (b, g)
+// in grid order the tiles of one problem are 128 workgroups apart, six tiles of ALL problems are resident together (16 factors
+// per 4-MB L2) and every tile's pass comes from beyond the L2: 1.25 GB per launch at B = 128.  Problem-major on an XCD, five or
+// six factors are in flight per L2 and a factor is fetched about once.
 template <typename T, bool SMALL = false>
 __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed_all, const size_t pkstride, const int Nuni,
-                                                    const int Kmax, const int* __restrict__ dest_all, const int dstride,
+                                                    const int Gx, const int* __restrict__ dest_all, const int dstride,
                                                     T* __restrict__ X_all, const size_t xstride, const int ldx,
                                                     const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     typedef InvCfg<T, SMALL> C;
     typedef InvAcc<T, SMALL> Acc;
     if (gate && *gate == 0) return;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int b = blockIdx.x, tile0 = blockIdx.y, tstep = gridDim.y;
+    if (Gx > 0) {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        b = 8 * (slot / Gx) + xcd;
+        tile0 = slot % Gx;
+        tstep = Gx;
+    }
     const int N = Nuni;
     const int K = round_up(N, LQP_NB) / LQP_NB, Np = K * LQP_NB;
-    (void)Kmax;
     const int li = lane % C::TR, lg = lane / C::TR;
     const int rt = w % C::RT, ct = w / C::RT;                // this wave's row tile of a block row / column tile of the workgroup tile
     T* Y = (T*)smem;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed
     const int* dest = dest_all + (size_t)b * dstride;
     T* X = X_all + (size_t)b * xstride;
     const int ntiles = (N + C::TWG - 1) / C::TWG;
-    for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+    for (int tile = tile0; tile < ntiles; tile += tstep) {
         const int c0 = tile * C::TWG;
         // ---- right-hand sides: columns c0 .. of P I ----
         for (int i = tid; i < Np * C::YS; i += 256) Y[i] = T(0);
