@@ -297,7 +297,7 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
     const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
     { ProfScope ps(st, PC_LU);
       // (LQP_DBG_LU2_ABSENT: the hand-offs of workgroups b time out, info = -7, the caller repeats on one workgroup per matrix)
-      hipLaunchKernelGGL(fn, dim3(knobs().dbg_lu2_absent ? B : 2 * B), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
+      hipLaunchKernelGGL(fn, dim3(knobs().dbg_lu2_absent ? B : shared_grid(B, 2)), dim3(LU2_NT), lds, st, M, N, ld, mstride, piv, pstride, info, gate, nvec, scr,
                          scr_stride, epoch, knobs().dbg_setup ? nullptr : g_lu_dbg, B, knobs().xcd_local != 0 ? 1 : 0); }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
@@ -770,7 +770,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                         const int rlds = rs_q_lds_bytes(P.Ks);
                         r3 = ensure_lds((const void*)rs_fn, rlds);
                         if (r3) return r3;
-                        hipLaunchKernelGGL(rs_fn, dim3((knobs().dbg_loop_absent & 2) ? B : B * rs_np), dim3(RS_NT), rlds, st, P, gate);
+                        hipLaunchKernelGGL(rs_fn, dim3((knobs().dbg_loop_absent & 2) ? B : shared_grid(B, rs_np)), dim3(RS_NT), rlds, st, P, gate);
                         n_launch += 1;
                     } else {
                         for (int k = 0; k < P.Ks; ++k)
@@ -983,7 +983,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         ProfScope ps(st, PC_LOOP);
         if constexpr (sizeof(T) == 4) {
             if (loop_split && it == 0) {
-                hipLaunchKernelGGL(split_fn, dim3((knobs().dbg_loop_absent & 1) ? B : loop_np * B), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
+                hipLaunchKernelGGL(split_fn, dim3((knobs().dbg_loop_absent & 1) ? B : shared_grid(B, loop_np)), dim3(split_nt), split_lds, st, P, it, e, ctr_base);
                 return;
             }
             if (loop_small && it == 0) {
@@ -992,7 +992,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             }
         }
         if (loop_dense && it == 0) {
-            hipLaunchKernelGGL(k_admm_loop_dense<T>, dim3(2 * B), dim3(DENSE_NT), dense_lds, st, P, it, e, ctr_base);
+            hipLaunchKernelGGL(k_admm_loop_dense<T>, dim3(shared_grid(B, 2)), dim3(DENSE_NT), dense_lds, st, P, it, e, ctr_base);
             return;
         }
         if (loop_dense_w && it == 0) {
@@ -1772,7 +1772,7 @@ int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd
             blocks_per_cu(&per_cu, fn2, 512, lds2, dev) && per_cu >= 1 && 2 * B <= cus * per_cu) {
             static std::atomic<unsigned int> run{1u};
             ProfScope ps(st, PC_UNROLL);
-            hipLaunchKernelGGL(fn2, dim3((knobs().dbg_loop_absent & 4) ? B : 2 * B), dim3(512), lds2, st, P, U, run.fetch_add(1u));
+            hipLaunchKernelGGL(fn2, dim3((knobs().dbg_loop_absent & 4) ? B : shared_grid(B, 2)), dim3(512), lds2, st, P, U, run.fetch_add(1u));
             split_done = true;
         }
     }

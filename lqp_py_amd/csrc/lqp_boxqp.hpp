@@ -739,7 +739,8 @@ __global__ __launch_bounds__(LU2_NT) void k_lu_factor2(T* __restrict__ Mall, con
                                                        const int B, const int xlocal_ok) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
-    const int b = (int)blockIdx.x % B, me = (int)blockIdx.x / B;
+    int b, me;
+    if (!shared_map((int)blockIdx.x, B, 2, b, me)) return;
     const int Nb = Nvec ? Nvec[b] : N;
     if (threadIdx.x == 0 && me == 0) info[b] = 0;
     __syncthreads();
@@ -1185,7 +1186,8 @@ template <int KS, int NP = 2>
 __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
-    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD
+    int b, part;                                                   // (the NP workgroups of a problem on one XCD: shared_map)
+    if (!shared_map((int)blockIdx.x, P.B, NP, b, part)) return;
     unsigned int* fl = (unsigned int*)(P.xchg + (size_t)P.B * XCHG_WORDS + (size_t)XCHG_TAIL * b);
     const unsigned int epoch = 32u * (unsigned int)P.status[ST_NFACTOR];
     RsLateRho lr;
@@ -1831,8 +1833,8 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     constexpr int NWV = NT / 64, Ks = KS, Nps = KS * LQP_NB, rl = split_lds_blocks<NT, NP>(KS);
     constexpr int XPART = SPD_MAXK * LQP_NB, XPAR = NP * XPART;      // granules of one part / of one parity of the exchange
     // (split_seg: NP == 2, B a multiple of 8 -- the host's condition)
-    const int b = P.split_seg ? 8 * ((int)blockIdx.x >> 4) + ((int)blockIdx.x & 7) : (int)blockIdx.x % P.B;
-    const int part_id = P.split_seg ? ((int)blockIdx.x >> 3) & 1 : (int)blockIdx.x / P.B;
+    int b = 8 * ((int)blockIdx.x >> 4) + ((int)blockIdx.x & 7), part_id = ((int)blockIdx.x >> 3) & 1;
+    if (!P.split_seg && !shared_map((int)blockIdx.x, P.B, NP, b, part_id)) return;
     const int n = P.n, m = P.m;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;

@@ -232,7 +232,8 @@ template <typename T>
 __global__ __launch_bounds__(DENSE_NT) void k_admm_loop_dense(const FwdParams<T> P, const int it0, const int it1, const int ctr_base) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     constexpr int NT = DENSE_NT, NWV = NT / 64, CPT = DENSE_CPT, WS = dense_ws<T>(), GW = sizeof(T) / 4, NM = DENSE_NMAX;
-    const int b = (int)blockIdx.x % P.B, part = (int)blockIdx.x / P.B;
+    int b, part;
+    if (!shared_map((int)blockIdx.x, P.B, 2, b, part)) return;
     const int n = P.n, m = P.m, Np = P.Np;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(512) void k_unroll_sweep_split(const FwdParams<floa
     extern __shared__ __attribute__((aligned(32))) char smem[];
     constexpr int NT = 512, NP = 2, NWV = NT / 64, Nps = KS * LQP_NB, rl = split_lds_blocks<NT, NP>(KS);
     constexpr int XPART = SPD_MAXK * LQP_NB, XPAR = NP * XPART;
-    const int b = (int)blockIdx.x % P.B, part_id = (int)blockIdx.x / P.B;
+    int b, part_id;
+    if (!shared_map((int)blockIdx.x, P.B, NP, b, part_id)) return;
     const int n = P.n, m = P.m, T = U.T;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* const lds_res = (float*)smem;
