@@ -292,7 +292,7 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
     auto fn = k_lu_factor2<T, PB>;
     const int lds = Lu2Lds<T, PB>(round_up(N, 64)).total;
     if (!current_device_cus(&dev, &cus) || ensure_lds((const void*)fn, lds) != LQP_OK ||
-        !blocks_per_cu(&per_cu, fn, LU2_NT, lds, dev) || per_cu < 1 || 2 * B > cus * per_cu)
+        !blocks_per_cu(&per_cu, fn, LU2_NT, lds, dev) || per_cu < 1 || shared_grid(B, 2) > cus * per_cu)
         return -1;
     const unsigned int epoch = g_lu2_epoch.fetch_add(1u) + 1u;
     { ProfScope ps(st, PC_LU);
@@ -679,7 +679,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if (P.Ks >= 7 && current_device_cus(&dev_, &cus_) && 4 * B <= cus_ && knobs().spd_resident4 != 0) {
             rs_fn = P.Ks == 7 ? k_spd_resident<7, 4> : k_spd_resident<8, 4>;
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) &&
-                 per_cu >= 1 && 4 * B <= cus_ * per_cu;
+                 per_cu >= 1 && shared_grid(B, 4) <= cus_ * per_cu;
             if (ok) rs_np = 4;
         }
 #endif
@@ -687,7 +687,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             rs_fn = P.Ks == 3 ? k_spd_resident<3> : P.Ks == 4 ? k_spd_resident<4> : P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6>
                   : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
-                 blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && B * SPD_NP <= cus_ * per_cu;
+                 blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && shared_grid(B, SPD_NP) <= cus_ * per_cu;
         }
         spd_resident = ok;
     }
@@ -891,7 +891,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 split_lds = split_loop_lds_bytes<512, 4>(P.Ks, m);
                 split_fn = P.Ks == 7 ? k_admm_loop_split<7, 512, false, 4> : k_admm_loop_split<8, 512, false, 4>;
                 if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
-                    blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1 && 4 * B <= cus * per_cu)
+                    blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1 && shared_grid(B, 4) <= cus * per_cu)
                     loop_np = 4;
             }
             if (loop_np != 4) {
@@ -899,7 +899,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 split_fn = P.Ks == 3 ? k_admm_loop_split<3, 512> : P.Ks == 4 ? k_admm_loop_split<4, 512> : P.Ks == 5 ? k_admm_loop_split<5, 512> : P.Ks == 6 ? k_admm_loop_split<6, 512>
                          : P.Ks == 7 ? k_admm_loop_split<7, 512> : (g_lu_dbg ? k_admm_loop_split<8, 512, true> : k_admm_loop_split<8, 512>);
                 if (split_lds <= 160 * 1024 && ensure_lds((const void*)split_fn, split_lds) == LQP_OK &&
-                    blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1 && 2 * B <= cus * per_cu)
+                    blocks_per_cu(&per_cu, split_fn, split_nt, split_lds, dev) && per_cu >= 1 && shared_grid(B, 2) <= cus * per_cu)
                     loop_np = 2;
             }
             loop_split = loop_np > 1;
@@ -934,7 +934,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         auto fnd = k_admm_loop_dense<T>;
         if (dense_lds <= 160 * 1024 && lu_inverse_lds_bytes<T>(P.Np) <= 160 * 1024 && current_device_cus(&dev, &cus) &&
             ensure_lds((const void*)fnd, dense_lds) == LQP_OK && blocks_per_cu(&per_cu, fnd, DENSE_NT, dense_lds, dev) &&
-            per_cu >= 1 && 2 * B <= cus * per_cu)
+            per_cu >= 1 && shared_grid(B, 2) <= cus * per_cu)
             loop_dense = true;
     }
     // ... and for batches that leave most of the chip idle, any n the inverse kernel takes: W workgroups per problem, each with its
@@ -1769,7 +1769,7 @@ int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd
                        : P.Ks == 6 ? unroll_split_lds_bytes<6>(m) : unroll_split_lds_bytes<5>(m);
         int dev = 0, cus = 0, per_cu = 0;
         if (current_device_cus(&dev, &cus) && ensure_lds((const void*)fn2, lds2) == LQP_OK &&
-            blocks_per_cu(&per_cu, fn2, 512, lds2, dev) && per_cu >= 1 && 2 * B <= cus * per_cu) {
+            blocks_per_cu(&per_cu, fn2, 512, lds2, dev) && per_cu >= 1 && shared_grid(B, 2) <= cus * per_cu) {
             static std::atomic<unsigned int> run{1u};
             ProfScope ps(st, PC_UNROLL);
             hipLaunchKernelGGL(fn2, dim3((knobs().dbg_loop_absent & 4) ? B : shared_grid(B, 2)), dim3(512), lds2, st, P, U, run.fetch_add(1u));
