@@ -718,7 +718,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             const int r3 = ensure_lds((const void*)k_spd_prep<>, lds);
             if (r3) return r3;
             ProfScope ps(st, PC_SPD_INV);
-            hipLaunchKernelGGL(k_spd_prep<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P);
+            hipLaunchKernelGGL(k_spd_prep<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P);
             ++n_launch;
         }
     }
@@ -748,10 +748,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     if (!r3) r3 = ensure_lds((const void*)k_spd_big_step<>, lds);
                     if (!r3) r3 = ensure_lds((const void*)k_spd_end<>, lds);
                     if (r3) return r3;
-                    hipLaunchKernelGGL(k_spd_begin<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
+                    hipLaunchKernelGGL(k_spd_begin<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P, gate);
                     for (int k = 0; k < P.Ks; ++k) {
-                        hipLaunchKernelGGL(k_spd_big_step<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 1);
-                        hipLaunchKernelGGL(k_spd_big_step<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, 2);
+                        hipLaunchKernelGGL(k_spd_big_step<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P, gate, k, 1);
+                        hipLaunchKernelGGL(k_spd_big_step<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P, gate, k, 2);
                     }
                     hipLaunchKernelGGL(k_spd_end<>, dim3(B), dim3(LQP_NT), lds, st, P, gate);
                     n_launch += 2 * P.Ks + 2;
@@ -764,7 +764,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     if (!r3) r3 = ensure_lds((const void*)k_spd_end<>, lds);
                     if (r3) return r3;
                     if (!(gate == nullptr && P.prep_fused))      // (the first factorisation's blocks: k_spd_prep built them)
-                        hipLaunchKernelGGL(k_spd_begin<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate);
+                        hipLaunchKernelGGL(k_spd_begin<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P, gate);
                     if (spd_resident) {
                         // all pivot steps in one launch, the matrix in the registers of its two workgroups
                         const int rlds = rs_q_lds_bytes(P.Ks);
@@ -774,7 +774,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                         n_launch += 1;
                     } else {
                         for (int k = 0; k < P.Ks; ++k)
-                            hipLaunchKernelGGL(k_spd_step<>, dim3(B * SPD_NP), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
+                            hipLaunchKernelGGL(k_spd_step<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P, gate, k, spd_pivot_tasks);
                         n_launch += P.Ks;
                     }
                     if (!(gate == nullptr && P.eq_in_loop)) hipLaunchKernelGGL(k_spd_end<>, dim3(B), dim3(LQP_NT), lds, st, P, gate);

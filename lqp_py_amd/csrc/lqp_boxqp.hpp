@@ -1062,7 +1062,8 @@ template <int LQP_ANY = 0>      // (a template only so that the split build can 
 __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
-    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
+    int b, part;
+    if (!shared_map((int)blockIdx.x, P.B, SPD_NP, b, part)) return;
     const bool lazy = P.scale && P.qs_lazy;
     const float* Qs = (P.scale && !lazy) ? (P.Qs + (size_t)b * P.n * P.ldq) : (P.Q + (size_t)b * P.n * P.n);
     const float* dsc = lazy ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
@@ -1083,7 +1084,8 @@ static_assert(SPD_NP == 2, "k_fwd_setup reads the two halves k_spd_prep leaves")
 template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_spd_prep(const FwdParams<float> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
-    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
+    int b, part;
+    if (!shared_map((int)blockIdx.x, P.B, SPD_NP, b, part)) return;
     float* sc = prep_scratch(P, b);
     const float asym = wg_sym_prep<SPD_NP>(spd_half(P, b, P.Ks & 1), P.Q + (size_t)b * P.n * P.n, P.n, P.n, P.Ks, (float*)smem,
                                            part, sc + (size_t)part * P.Ks * LQP_NB);
@@ -1094,7 +1096,8 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_step(const FwdParams<float> P, c
                                                       const int pivot_tasks) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
-    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;      // b and b + B: same XCD, the panel is shared in its L2
+    int b, part;                                                   // (the two workgroups of a matrix on one XCD: the panel is shared in its L2)
+    if (!shared_map((int)blockIdx.x, P.B, SPD_NP, b, part)) return;
     // W, W^T of the next pivot block travel between the launches in the (unused on this path) KKT matrix area
     wg_spd_sweep<SPD_NP>(spd_half(P, b, (P.Ks - k) & 1), P.Ks, P.info + b, smem, nullptr, spd_half(P, b, (P.Ks - k - 1) & 1),
                          k, k + 1, part, P.M + (size_t)b * P.Np * P.Np, pivot_tasks);
@@ -1106,7 +1109,8 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_big_step(const FwdParams<float> 
                                                           const int phases) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
-    const int b = blockIdx.x % P.B, part = blockIdx.x / P.B;
+    int b, part;
+    if (!shared_map((int)blockIdx.x, P.B, SPD_NP, b, part)) return;
     wg_spd_sweep_big<SPD_NP>(spd_half(P, b, 0), P.Ks, P.info + b, smem, P.M + (size_t)b * P.Np * P.Np, k, k + 1, phases, part);
 }
 // ---- what k_fwd_setup leaves to the resident sweep under prep_fused == 3 (the same operations on the same values as
