@@ -424,8 +424,9 @@ int launch_lu_inverse_cfg(hipStream_t st, int B, int N, const T* packed, size_t 
     int G = std::max(1, std::min(ntiles, (12 * cus) / std::max(B, 1)));
     ProfScope ps(st, PC_PACK);
     // (the tiles of a problem side by side on one XCD -- they all read the same factor --, see k_lu_inverse)
-    if (G > 1 && B % 8 == 0 && knobs().inv_xcd != 0)
-        hipLaunchKernelGGL(fn, dim3(B * G), dim3(256), lds, st, packed, pkstride, N, G, dest, dstride, X, xstride, ldx, gate);
+    if (G > 1 && G < 65536 && B < 32768 && knobs().inv_xcd != 0)
+        hipLaunchKernelGGL(fn, dim3(8 * ((B + 7) / 8) * G), dim3(256), lds, st, packed, pkstride, N, G | (B << 16), dest, dstride, X, xstride,
+                           ldx, gate);
     else
         hipLaunchKernelGGL(fn, dim3(B, G), dim3(256), lds, st, packed, pkstride, N, 0, dest, dstride, X, xstride, ldx, gate);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;

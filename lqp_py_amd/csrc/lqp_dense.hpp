@@ -122,7 +122,7 @@ template <bool SMALL> struct InvAcc<double, SMALL> {
 
 // X[0:N, 0:N] (row-major, leading dimension ldx) = M^-1; packed / dest: what k_pack left (dest[r]: position of original
 // right-hand-side row r after the row interchanges).  grid = (B, G): workgroup (b, g) takes column tiles g, g + G, ...
-// Gx > 0: a ONE-dimensional grid of B * Gx workgroups (B a multiple of 8), one tile each, dealt out so that the tiles of a
+// Gx > 0: a ONE-dimensional grid of 8 ceil(B / 8) * G workgroups, one tile each, dealt out so that the tiles of a
 // problem run on ONE XCD at about the same time: workgroup id -> XCD id % 8 (the dispatcher's round robin), slot id / 8 on it,
 // problem 8 * (slot / Gx) + XCD, tile slot % Gx.  Every tile reads the whole factor (960 KB at N = 266, float64); with (b, g)
 // in grid order the tiles of one problem are 128 workgroups apart, six tiles of ALL problems are resident together (16 factors
@@ -139,11 +139,12 @@ __global__ __launch_bounds__(256) void k_lu_inverse(const T* __restrict__ packed
     if (gate && *gate == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int b = blockIdx.x, tile0 = blockIdx.y, tstep = gridDim.y;
-    if (Gx > 0) {
-        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-        b = 8 * (slot / Gx) + xcd;
-        tile0 = slot % Gx;
-        tstep = Gx;
+    if (Gx > 0) {                                            // (Gx = G | B << 16; the grid is padded to a multiple of 8 problems)
+        const int G = Gx & 0xFFFF, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        b = 8 * (slot / G) + xcd;
+        if (b >= (Gx >> 16)) return;
+        tile0 = slot % G;
+        tstep = G;
     }
     const int N = Nuni;
     const int K = round_up(N, LQP_NB) / LQP_NB, Np = K * LQP_NB;
