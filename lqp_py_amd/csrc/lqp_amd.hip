@@ -869,7 +869,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         // 0.82 -> 0.42 ms, step 1.87 -> 1.60 ms; B = 192: 1.63 -> 1.51).  Only when the caller left the mode to the library.
         if constexpr (sizeof(T) == 4) {
             if (mode == 2 && ctl->launch_mode == 0 && knobs().launch_mode == 2 && spd && P.xchg && 2 * B > cus &&
-                P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 && knobs().loop_split != 0 &&
+                P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && knobs().loop_split != 0 &&
                 knobs().loop_split_seg != 0 && !ctl->check_hook)
                 mode = 1;
         }
@@ -912,7 +912,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // per iteration (B = 1024, n = 500: loop 3.35 -> 8 turns x 4 segments)
     bool loop_split_seg = false;
     if constexpr (sizeof(T) == 4) {
-        if (spd && mode == 1 && !loop_split && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 && B % 8 == 0 &&
+        if (spd && mode == 1 && !loop_split && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && check >= 4 &&
             knobs().loop_split != 0 && knobs().loop_split_seg != 0 && !(retry & 2) && !solo) {
             int dev = 0, cus = 0, per_cu = 0;
             split_nt = 512;
@@ -1178,7 +1178,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                       Ps.split_seg = 1;
                       Ps.seg_prev_slot = prev_slot;
                       ProfScope ps(st, PC_LOOP);
-                      hipLaunchKernelGGL(split_fn, dim3(2 * B), dim3(split_nt), split_lds, st, Ps, it, e, ctr_base);
+                      hipLaunchKernelGGL(split_fn, dim3(shared_grid(B, 2)), dim3(split_nt), split_lds, st, Ps, it, e, ctr_base);
                   }
               } else {
                   ProfScope ps(st, first ? PC_LOOP : PC_LOOP_TAIL);

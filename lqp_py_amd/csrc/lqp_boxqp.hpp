@@ -1836,9 +1836,9 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     typedef float T;
     constexpr int NWV = NT / 64, Ks = KS, Nps = KS * LQP_NB, rl = split_lds_blocks<NT, NP>(KS);
     constexpr int XPART = SPD_MAXK * LQP_NB, XPAR = NP * XPART;      // granules of one part / of one parity of the exchange
-    // (split_seg: NP == 2, B a multiple of 8 -- the host's condition)
-    int b = 8 * ((int)blockIdx.x >> 4) + ((int)blockIdx.x & 7), part_id = ((int)blockIdx.x >> 3) & 1;
-    if (!P.split_seg && !shared_map((int)blockIdx.x, P.B, NP, b, part_id)) return;
+    // (split_seg: NP == 2)
+    int b = 8 * ((int)blockIdx.x >> 4) + ((int)blockIdx.x & 7), part_id = ((int)blockIdx.x >> 3) & 1;      // (split_seg: shared_map with NP = 2)
+    if (P.split_seg ? b >= P.B : !shared_map((int)blockIdx.x, P.B, NP, b, part_id)) return;
     const int n = P.n, m = P.m;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;

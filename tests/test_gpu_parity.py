@@ -941,6 +941,32 @@ def test_shared_lu_that_times_out_degrades(dev, monkeypatch, dtype):
         assert err(a, e) <= 1e-5 * max(1.0, float(e.abs().max())), err(a, e)
 
 
+@pytest.mark.parametrize("B,n", [(130, 320), (141, 450), (100, 500), (30, 500), (7, 400)])
+def test_partner_workgroups_for_any_batch_size(dev, monkeypatch, B, n):
+    """The kernels that share a problem between workgroups map workgroup ids to (problem, part) so that the partners meet on one
+    XCD for EVERY batch size (shared_map: a grid padded to a multiple of 8 problems, surplus workgroups leave at once) -- also the
+    turn-taking loop of batches above half the CUs, which used to need a multiple of 8.  Same iteration count and iterates as
+    the schedules that share nothing (LQP_LOOP_SPLIT=0, LQP_SPD_SPLIT=0), gradients to float32 rounding."""
+    d = O.create_qp_data(n, B, seed=B + n)
+    cot = torch.randn(B, n, 1, generator=torch.Generator().manual_seed(B)).to(dev)
+    out = {}
+    for shared in ("1", "0"):
+        monkeypatch.setenv("LQP_LOOP_SPLIT", shared)
+        if shared == "0":
+            monkeypatch.setenv("LQP_SPD_SPLIT", "0")
+        lv = [t.clone().to(dev).requires_grad_(True) for t in d]
+        sol = L.torch_solve_box_qp(*[t.detach() for t in lv], dict(L.box_qp_control(**TOL)))
+        x = L.SolveBoxQP(control=L.box_qp_control(**TOL))(*lv)
+        x.backward(cot)
+        torch.cuda.synchronize()
+        out[shared] = (sol["iter"], sol["_stats"]["loop_workgroups"], x.detach(), [t.grad for t in lv])
+    assert out["1"][1] >= 2 and out["0"][1] == 1, (out["1"][1], out["0"][1])
+    assert out["1"][0] == out["0"][0]
+    assert err(out["1"][2], out["0"][2]) <= 2e-5
+    for a, e in zip(out["1"][3], out["0"][3]):
+        assert err(a, e) <= 1e-4 * max(1.0, float(e.abs().max()))
+
+
 def test_shared_sweep_that_times_out_degrades(dev, monkeypatch):
     """... and the register-resident sweep of the factorisation with its partner workgroups missing (LQP_DBG_LOOP_ABSENT bit 1):
     the step flags time out, the synchronous solve is repeated with one workgroup per matrix."""
