@@ -366,7 +366,7 @@ int launch_lu(hipStream_t st, double* M, int B, int N, int ld, size_t mstride, i
       if (r2 >= 0) return r2; }
     const int nt = lu_threads<double>(N);
     const int pb = lu_panel_width<double>(N);
-#define LQP_LU_CASE(PBV, NTV) return launch_lu_impl<double, PBV, false, NTV>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
+#define LQP_LU_CASE(PBV, NTV) return launch_lu_impl<double, PBV, true, NTV>(st, B, M, N, ld, mstride, piv, pstride, info, gate, nvec)
     if (nt == 512) {
         if (pb == 16) LQP_LU_CASE(16, 512);
         LQP_LU_CASE(8, 512);

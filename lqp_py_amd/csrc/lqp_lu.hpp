@@ -133,6 +133,41 @@ __device__ __forceinline__ void lu_trailing_mfma_f32(float* __restrict__ A22, co
     }
 }
 
+// The same for float64: 16 x 16 tiles of v_mfma_f64_16x16x4_f64 (the one-workgroup kernels above 512 rows -- the sizes the
+// two-workgroup LU does not take -- ran their trailing update on the vector unit: 4.0 ms per factorisation at N = 522, B = 128).
+//   A operand (16x4 slice of L21): lane l holds L21[i = l & 15][k = l >> 4];  B operand: U12[k = l >> 4][j = l & 15];
+//   C/D: lane l holds rows 4 q + (l >> 4), q = 0..3, of column l & 15 (tools/microbench/mfma_f64_layout.hip)
+typedef double f64x4_lu __attribute__((ext_vector_type(4)));
+template <int PB, int NT>
+__device__ __forceinline__ void lu_trailing_mfma_f64(double* __restrict__ A22, const int ld, const int M2,
+                                                      const double* __restrict__ LT, const double* __restrict__ UP,
+                                                      const int Mpad) {
+    static_assert(PB % 4 == 0, "panel width in steps of the instruction's depth");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lh = lane >> 4;
+    const int nt = (M2 + 15) >> 4;
+    const int ntiles = nt * nt;
+    for (int t = __builtin_amdgcn_readfirstlane(w); t < ntiles; t += NT / 64) {
+        const int ti = t / nt, tj = t - ti * nt;
+        const int i0 = ti << 4, j0 = tj << 4;
+        double* base = A22 + (size_t)(i0 + lh) * ld + j0 + li;
+        const bool colok = j0 + li < M2;
+        const int rlim = M2 - i0 - lh;                    // register q holds row 4 q + lh
+        f64x4_lu cur;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = (colok && 4 * q < rlim) ? base[(size_t)(4 * q) * ld] : 0.0;
+        const double* lt = LT + i0 + li + lh * Mpad;
+        const double* up = UP + j0 + li + lh * Mpad;
+        f64x4_lu acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < PB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[kk * Mpad], up[kk * Mpad], acc, 0, 0, 0);
+        cur -= acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (colok && 4 * q < rlim) base[(size_t)(4 * q) * ld] = cur[q];
+    }
+}
+
 // LDS scratch of the panel factorisation
 template <typename T> struct PanelLds {
     T* rowP; T* wval; T* wrcp; int* widx; int* wtid; int* pidx; int* cnt;
@@ -379,8 +414,10 @@ __device__ __forceinline__ void wg_lu_factor(T* __restrict__ A, const int N, con
         // ---- trailing update A22 -= L21 * U12 ----
         if (M2 > 0) {
             T* A22 = A + (size_t)(k0 + pb) * ld + (k0 + pb);
-            if constexpr (USE_MFMA) {
+            if constexpr (USE_MFMA && sizeof(T) == 4) {
                 lu_trailing_mfma_f32<PB, NT>((float*)A22, ld, M2, (const float*)LT, (const float*)UP, Mpad);
+            } else if constexpr (USE_MFMA) {
+                lu_trailing_mfma_f64<PB, NT>((double*)A22, ld, M2, (const double*)LT, (const double*)UP, Mpad);
             } else {
                 const int tj_n = (M2 + 3) >> 2, ti_n = (M2 + 7) >> 3;
                 for (int t = tid; t < ti_n * tj_n; t += NT) {

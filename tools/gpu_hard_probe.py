@@ -9,7 +9,8 @@ from lqp_py_amd.solve_box_qp_admm_torch import last_forward_status
 from lqp_py_amd.synthetic import create_hard_qp_data
 dev = torch.device("cuda:0")
 dt_ = torch.float64 if (len(sys.argv) < 2 or sys.argv[1] == "f64") else torch.float32
-hard = create_hard_qp_data(250, 0.85, range(128), dtype=dt_, device=dev)
+NH = int(os.environ.get("N", "250"))
+hard = create_hard_qp_data(NH, 0.85, range(int(os.environ.get("B", "128"))), dtype=dt_, device=dev)
 SYNC = bool(int(os.environ.get("SYNC", "0")))          # SYNC=1: the layer's default synchronous calls (what experiment_1_hard.py gets)
 layer = L.SolveBoxQP(control=dict(L.box_qp_control(eps_abs=1e-5, eps_rel=1e-5), sync=SYNC))
 cot = torch.ones_like(hard[1])
