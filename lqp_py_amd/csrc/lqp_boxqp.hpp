@@ -759,7 +759,7 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_big(T* __restrict__ Mall, 
     const int b = blockIdx.x;
     if (threadIdx.x == 0) info[b] = 0;
     __syncthreads();
-    wg_lu_factor_big<T, lu_big_panel<T>(), sizeof(T) == 4, 2>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld,
+    wg_lu_factor_big<T, lu_big_panel<T>(), true, 2>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld,
                                                                piv + (size_t)b * pstride, info + b, smem);
 }
 

@@ -228,8 +228,10 @@ __device__ __forceinline__ void wg_lu_factor_big(T* __restrict__ A, const int N,
         // ---- trailing update A22 -= L21 * U12 ----
         if (M2 > 0) {
             T* A22 = A + (size_t)(k0 + pb) * ld + (k0 + pb);
-            if constexpr (USE_MFMA) {
+            if constexpr (USE_MFMA && sizeof(T) == 4) {
                 lu_trailing_mfma_f32<PB, NT>((float*)A22, ld, M2, (const float*)LT, (const float*)UP, Mpad);
+            } else if constexpr (USE_MFMA) {
+                lu_trailing_mfma_f64<PB, NT>((double*)A22, ld, M2, (const double*)LT, (const double*)UP, Mpad);
             } else {
                 const int tj_n = (M2 + 3) >> 2, ti_n = (M2 + 7) >> 3;
                 for (int t = tid; t < ti_n * tj_n; t += NT) {
