@@ -1356,7 +1356,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     bool chol = false;
     if constexpr (sizeof(T) == 4) {
         chol = P.reduced && linsolve == 2 && knobs().bwd_chol && round_up(n, LQP_NB) / LQP_NB <= SPD_BIGK &&
-               m <= SPD_MAXM && bwd_chol_lds_bytes(n, m) <= 160 * 1024;
+               m <= SPD_MAXM && bwd_chol_lds_bytes(n, m, m >= 3 ? 4 : 2) <= 160 * 1024;
     }
     // the LU form has the same two phases (ABI 11): 1 = free set, reduced system, its pivoted LU and the packed factor -- none of
     // them needs the cotangent --, 2 = gather the cotangent over the free set, solve (+ refinement), epilogue
@@ -1379,15 +1379,17 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
                 const int split = B <= 128 ? 2 : 1;
                 hipLaunchKernelGGL(k_bwd_build_chol<>, dim3(B, split), dim3(LQP_NT), lds, st, P);
             }
-            const int lds = bwd_chol_lds_bytes(n, m);
+            const bool nr4 = m >= 3;                   // (four right-hand sides per round of the block solves)
+            const int lds = bwd_chol_lds_bytes(n, m, nr4 ? 4 : 2);
             {
                 const int Kmax = round_up(n, LQP_NB) / LQP_NB;
                 P.la_maxk = !knobs().bwd_lookahead ? 0 : (Kmax < SPD_MAXK ? Kmax : SPD_MAXK - 1);
             }
-            int r2 = ensure_lds((const void*)k_bwd_chol_solve<>, lds);
+            auto chol_fn = nr4 ? k_bwd_chol_solve<4> : k_bwd_chol_solve<0>;
+            int r2 = ensure_lds((const void*)chol_fn, lds);
             if (r2) return r2;
             ProfScope ps(st, PC_BWD_CHOL);
-            hipLaunchKernelGGL(k_bwd_chol_solve<>, dim3(B), dim3(LQP_NT), lds, st, P);
+            hipLaunchKernelGGL(chol_fn, dim3(B), dim3(LQP_NT), lds, st, P);
             if (phase == 1) return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
         }
     }

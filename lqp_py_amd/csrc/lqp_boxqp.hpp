@@ -863,6 +863,34 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_inverse_dense(const float* __res
         }
 }
 
+// Si = S^-1 (S = Sm is symmetric positive definite, m <= 16: Gauss-Jordan without pivoting, Sm is destroyed): one thread per entry
+// of [Sm | Si] -- 2 m^2 <= 512 of them -- and three barriers per column.  One thread used to walk through all of it: ~4 m^3
+// dependent LDS round trips, ~0.25 ms per forward at m = 16 (inside the loop kernel's prologue).  The same operations on the same
+// values per entry: the same bits.  Every thread of the workgroup calls; returns 1 when a pivot was not positive.
+template <typename T, typename Barrier>
+__device__ __forceinline__ int wg_gj_inverse_spd(T* __restrict__ Sm, T* __restrict__ Si, const int m, Barrier barrier) {
+    const int tid = threadIdx.x, m2 = 2 * m;
+    for (int i = tid; i < m * m; i += blockDim.x) Si[i] = (i / m == i % m) ? T(1) : T(0);
+    const int rr = tid / m2, jj = tid - rr * m2;
+    const bool mine = tid < m * m2;
+    T* const ent = !mine ? Sm : (jj < m ? Sm + rr * m + jj : Si + rr * m + (jj - m));
+    int bad = 0;
+    barrier();
+    for (int c = 0; c < m; ++c) {
+        const T d = Sm[c * m + c];
+        const T f = mine ? Sm[rr * m + c] : T(0);
+        T* const pivot_row = jj < m ? Sm + c * m + jj : Si + c * m + (jj - m);
+        if (!(d > T(0))) bad = 1;
+        const T inv = d > T(0) ? T(1) / d : T(0);
+        barrier();
+        if (mine && rr == c) *ent *= inv;
+        barrier();
+        if (mine && rr != c) *ent -= f * *pivot_row;
+        barrier();
+    }
+    return bad;
+}
+
 // equality rows: G = K^-1 A^T, S = A G, T = G S^-1, c = T b, s0 = S^-1 b, Hs += T G^T  (m <= SPD_MAXM)
 // LDS: v | ylds | part[NW][Nps] | G[m][Nps] | Tl[m][Nps] | Sm[m*m] | Si[m*m]
 __host__ __device__ inline int eqc_lds_bytes(int m, int Ks) {
@@ -901,23 +929,10 @@ __device__ __forceinline__ void wg_eq_correct(const FwdParams<float>& P, const i
         if (lane == 0) Sm[t] = acc;
     }
     __syncthreads();
-    // ---- S^-1 by Gauss-Jordan (S is SPD: no pivoting), one thread: m <= 16 ----
-    if (tid == 0) {
-        for (int i = 0; i < m * m; ++i) Si[i] = 0.f;
-        for (int i = 0; i < m; ++i) Si[i * m + i] = 1.f;
-        int bad = 0;
-        for (int c = 0; c < m; ++c) {
-            const float d = Sm[c * m + c];
-            if (!(d > 0.f)) bad = 1;
-            const float inv = d > 0.f ? 1.f / d : 0.f;
-            for (int j = 0; j < m; ++j) { Sm[c * m + j] *= inv; Si[c * m + j] *= inv; }
-            for (int r = 0; r < m; ++r) {
-                if (r == c) continue;
-                const float f = Sm[r * m + c];
-                for (int j = 0; j < m; ++j) { Sm[r * m + j] -= f * Sm[c * m + j]; Si[r * m + j] -= f * Si[c * m + j]; }
-            }
-        }
-        if (bad) { if (P.info[b] == 0) P.info[b] = P.Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient: not this path
+    // ---- S^-1 by Gauss-Jordan (S is SPD: no pivoting), m <= 16 ----
+    {
+        const int bad = wg_gj_inverse_spd(Sm, Si, m, [] { __syncthreads(); });
+        if (bad && tid == 0) { if (P.info[b] == 0) P.info[b] = P.Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient: not this path
     }
     __syncthreads();
     // ---- T = G S^-1, c = T b, s0 = S^-1 b ----
@@ -2006,22 +2021,9 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             if (lane == 0) Sm[t] = acc;
         }
         wg_barrier_lds();
-        if (tid == 0) {                                       // S^-1 by Gauss-Jordan (S is SPD: no pivoting), m <= 16
-            for (int i = 0; i < m * m; ++i) Si[i] = T(0);
-            for (int i = 0; i < m; ++i) Si[i * m + i] = T(1);
-            int bad = 0;
-            for (int c = 0; c < m; ++c) {
-                const T d = Sm[c * m + c];
-                if (!(d > T(0))) bad = 1;
-                const T inv = d > T(0) ? T(1) / d : T(0);
-                for (int j = 0; j < m; ++j) { Sm[c * m + j] *= inv; Si[c * m + j] *= inv; }
-                for (int r = 0; r < m; ++r) {
-                    if (r == c) continue;
-                    const T f = Sm[r * m + c];
-                    for (int j = 0; j < m; ++j) { Sm[r * m + j] -= f * Sm[c * m + j]; Si[r * m + j] -= f * Si[c * m + j]; }
-                }
-            }
-            if (bad) { if (P.info[b] == 0) P.info[b] = Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient
+        {                                                      // S^-1 by Gauss-Jordan (S is SPD: no pivoting), m <= 16
+            const int bad = wg_gj_inverse_spd(Sm, Si, m, [] { wg_barrier_lds(); });
+            if (bad && tid == 0) { if (P.info[b] == 0) P.info[b] = Ks * 64 + 1; P.status[ST_NOTSPD] = 1; }   // A rank deficient
         }
         wg_barrier_lds();
         // T = G S^-1, c = T b, s0 = S^-1 b (both workgroups hold them; the copies in global memory are for later launches)
@@ -2641,14 +2643,18 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
 
 // factor + solves + Schur complement of the equality rows; leaves [dv_F; dnu] in rhs like the LU path
 // LDS: wg_chol_factor's layout, then v | acc | u0 | G[m][Npm] | t[64] | part[NW*64] | S[m*m] | wv[m] | dn[m]
-__host__ __device__ inline int bwd_chol_lds_bytes(int n, int m) {
+// (nr: right-hand sides solved together, 2 or 4 -- see k_bwd_chol_solve)
+__host__ __device__ inline int bwd_chol_lds_bytes(int n, int m, int nr = 2) {
     const int Kmax = round_up(n, LQP_NB) / LQP_NB, Npm = Kmax * LQP_NB;
     const int a0 = spd_lds_bytes(Kmax > SPD_MAXK ? SPD_MAXK : Kmax);      // (above: wg_chol_factor_big, panel in chunks)
     const int a = (Kmax < SPD_MAXK && chol_la_lds_bytes(Kmax) > a0) ? chol_la_lds_bytes(Kmax) : a0;
-    const int c = ((3 + m) * Npm + 2 * 64 + 2 * LQP_NW * 64 + m * m + 2 * m + 8) * 4;
+    const int c = ((1 + nr + m) * Npm + nr * 64 + nr * LQP_NW * 64 + m * m + 2 * m + 8) * 4;
     return a > c ? a : c;
 }
-template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
+// NRV = 0: the 1 + m solves two right-hand sides at a time (the headline's m = 1: one round); NRV = 4: four at a time, an instance
+// of its own for problems with three or more equality rows (m = 16: five rounds of block-column barriers instead of nine) -- its
+// registers are not the m <= 2 kernel's problem.  The same arithmetic per right-hand side either way.
+template <int NRV = 0>
 __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
@@ -2681,7 +2687,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     __syncthreads();
     if (P.dbg && tid == 0) { const unsigned long long t = clock64(); P.dbg[(size_t)b * 8 + 0] = t - dt0; dt0 = t; P.dbg[(size_t)b * 8 + 3] = Kb; }
     // right-hand sides [rhs | A_F^T] as rows of X (u0 = X[0], G = X[1 ..]), solved two at a time
-    constexpr int NR = 2;
+    constexpr int NR = NRV == 4 ? 4 : 2;
     float* acc = (float*)smem;
     float* u0 = acc + (size_t)NR * Npm;
     float* G = u0 + Npm;
@@ -2719,27 +2725,41 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
             }
         }
         __syncthreads();
-        if (tid == 0) {                                      // (S - eps I) dnu = wv: Gauss-Jordan with partial pivoting, m <= 16
+        // (S - eps I) dnu = wv: Gauss-Jordan with partial pivoting, m <= 16.  One thread per entry of [S | wv] (a single thread walked
+        // through all of it before: ~4 m^3 dependent LDS round trips, 0.2 ms of the 0.3 ms kernel at m = 16); the same operations on
+        // the same values per entry, so the same bits.  dn[0] doubles as the pivot row, dn[1] as the skip flag of a column step.
+        {
+            const int rr = tid / (m + 1), jj = tid - rr * (m + 1);          // entry (rr, jj); jj == m: the right-hand side
+            const bool mine = tid < m * (m + 1);
+            int* pivrow = (int*)dn;
             for (int c = 0; c < m; ++c) {
-                int pr = c;
-                float best = tabs(S[c * m + c]);
-                for (int rr = c + 1; rr < m; ++rr) if (tabs(S[rr * m + c]) > best) { best = tabs(S[rr * m + c]); pr = rr; }
-                if (!(best > 0.f)) { if (P.info[b] == 0) P.info[b] = nf + c + 1; continue; }
-                if (pr != c) {
-                    for (int jj = 0; jj < m; ++jj) { const float tmp = S[c * m + jj]; S[c * m + jj] = S[pr * m + jj]; S[pr * m + jj] = tmp; }
-                    const float tmp = wv[c]; wv[c] = wv[pr]; wv[pr] = tmp;
+                if (tid == 0) {
+                    int pr = c;
+                    float best = tabs(S[c * m + c]);
+                    for (int r2 = c + 1; r2 < m; ++r2) if (tabs(S[r2 * m + c]) > best) { best = tabs(S[r2 * m + c]); pr = r2; }
+                    const bool skip = !(best > 0.f);
+                    if (skip && P.info[b] == 0) P.info[b] = nf + c + 1;
+                    pivrow[0] = pr; pivrow[1] = skip ? 1 : 0;
                 }
-                const float inv = 1.f / S[c * m + c];
-                for (int jj = 0; jj < m; ++jj) S[c * m + jj] *= inv;
-                wv[c] *= inv;
-                for (int rr = 0; rr < m; ++rr) {
-                    if (rr == c) continue;
-                    const float f = S[rr * m + c];
-                    for (int jj = 0; jj < m; ++jj) S[rr * m + jj] -= f * S[c * m + jj];
-                    wv[rr] -= f * wv[c];
+                __syncthreads();
+                const int pr = pivrow[0];
+                const bool skip = pivrow[1] != 0;
+                float* const rowc = jj < m ? S + c * m + jj : wv + c;        // this thread's column of rows c / pr / rr
+                float* const rowp = jj < m ? S + pr * m + jj : wv + pr;
+                float* const rowr = jj < m ? S + rr * m + jj : wv + rr;
+                if (!skip && pr != c && tid <= m) {                          // swap rows c and pr (threads 0 .. m: rr == 0, one column each)
+                    const float tmp = *rowc; *rowc = *rowp; *rowp = tmp;
                 }
+                __syncthreads();
+                const float inv = skip ? 0.f : 1.f / S[c * m + c];
+                const float f = (mine && !skip) ? S[rr * m + c] : 0.f;       // (read before anybody writes column c)
+                __syncthreads();
+                if (!skip && tid <= m) *rowc *= inv;
+                __syncthreads();
+                if (mine && !skip && rr != c) *rowr -= f * *rowc;
+                __syncthreads();
             }
-            for (int q = 0; q < m; ++q) dn[q] = wv[q];
+            for (int q = tid; q < m; q += LQP_NT) dn[q] = wv[q];
         }
         __syncthreads();
     }

@@ -43,6 +43,7 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
+    "void lqp::k_bwd_chol_solve<4>(lqp::BwdParams<float>)",
     "void lqp::k_bwd_gather_rhs<float>(lqp::BwdParams<float>)",
     "void lqp::k_bwd_gather_rhs<double>(lqp::BwdParams<double>)",
     "void lqp::k_report_info<0>(int const*, int*, int)",
