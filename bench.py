@@ -594,6 +594,11 @@ def main():
         more["b128_n250_m16_hard_fp64_sync_default"] = dict(
             fwd_bwd_rate(L.SolveBoxQP(control=L.box_qp_control(eps_rel=TOL, eps_abs=TOL, verbose=False)), hard, 40, warm=10), dtype="f64")
         del hard
+        # the same distribution in float32: the symmetric tier with sixteen equality rows (their m x m systems -- the forward's
+        # correction, the backward's Schur complement -- on one thread per entry since round 5: 0.96 -> 0.42 ms per step)
+        hard32 = create_hard_qp_data(250, 0.85, range(B), dtype=torch.float32, device=dev)
+        more["b128_n250_m16_hard_fp32"] = dict(fwd_bwd_rate(piped(), hard32, 20, warm=5), dtype="f32", linsolve="spd (m = 16 equality rows)")
+        del hard32
         out["other_workloads_fwd_bwd"] = more
         # ---- the reference's training experiment (experiments/experiment_2.py:12-20,57-99): Linear(5 -> 500) -> layer -> QP
         #      loss -> SGD, minibatch 32, 100 epochs, tol 1e-5; published (tol 1e-3 variant): 25.3 s ----
