@@ -117,7 +117,44 @@ def main():
         for nm, t in zip(GRAD_NAMES, leaves):
             out[nm] = t.grad
         save("g17_unroll_n100", **out)
-    if only and all(o.startswith(("g16", "g17")) for o in only):
+
+    # G18: the hard distribution at SURVEY 8(c)'s G11 size -- n=250, m=round(sqrt(250))=16, prob 0.85, seeds 0..127, fp64
+    #      (experiments/utils.py:64-131, experiments/experiment_1_hard.py:13-35): the benched `b128_n250_m16_hard_fp64` row.
+    #      Inputs are regenerated on the GPU box by the restated generator (asserted bit-identical here).
+    if not only or any(o.startswith("g18") for o in only):
+        seeds = list(range(128))
+        Qh, ph, Ah, bh, lbh, ubh, _, _ = generate_hard_qp_torch(250, 0.85, seeds)
+        got = O.create_hard_qp_data(250, 0.85, seeds)
+        for r, g in zip((Qh, ph, Ah, bh, lbh, ubh), got):
+            assert torch.equal(r.detach(), g), "oracle hard-QP generator drifted"
+        Qh, ph, Ah, bh, lbh, ubh = [t.detach() for t in (Qh, ph, Ah, bh, lbh, ubh)]
+        assert Ah.shape == (128, 16, 250) and Qh.dtype == torch.float64
+        sol = torch_solve_box_qp(Qh, ph, Ah, bh, lbh, ubh, box_qp_control(**tol))
+        torch.manual_seed(18)
+        gh = torch.randn(128, 250, 1, dtype=torch.float64)
+        gr = fp_grads(sol, Qh, Ah, lbh, ubh, gh)
+        rs = np.random.RandomState(18)
+        sb, si, sj = rs.randint(0, 128, 256), rs.randint(0, 250, 256), rs.randint(0, 250, 256)
+        out = dict(cot=gh, in_sum=checksum(Qh, ph, Ah, bh, lbh, ubh), sb=sb, si=si, sj=sj,
+                   dQ_fro=torch.linalg.matrix_norm(gr[0]), dQ_samples=gr[0][sb, si, sj],
+                   **{k: sol[k] for k in ("x", "u", "nus", "rho", "iter")})
+        for nm, t in zip(GRAD_NAMES[1:], gr[1:6]):
+            out[nm] = t
+        out["dA_fro"] = torch.linalg.matrix_norm(gr[2])      # (dA in full is 4 MB: its norm for every problem, the
+        out["dA"] = gr[2][:8]                                 #  entries of the first eight)
+        save("g18_hard_f64_n250_m16", **out)
+        print("   hard n=250 iter", sol["iter"])
+        del Qh, sol, gr
+
+    # G19: the per-GPU shard of BASELINE configs[4] -- B=1024 n=500 m=1 seed 0, float32, forward (experiments/experiment_1.py:12-16
+    #      with n_batch = 1024): x and the iteration count (decided by ALL 1024 problems, :312)
+    if not only or any(o.startswith("g19") for o in only):
+        Q, p, A, b, lb, ub = ref_inputs(500, 1024, 0)
+        sol = torch_solve_box_qp(Q, p, A, b, lb, ub, box_qp_control(**tol))
+        save("g19_b1024_n500_eq", in_sum=checksum(Q, p, lb, ub), x=sol["x"], u=sol["u"], rho=sol["rho"], iter=sol["iter"])
+        print("   B=1024 n=500 iter", sol["iter"])
+        del Q, sol
+    if only and all(o.startswith(("g16", "g17", "g18", "g19")) for o in only):
         return
 
     # G14: the NumPy twin (lqp_py/solve_box_qp_admm.py:45-91, single problem, float64) -- SURVEY 8f rank 4
