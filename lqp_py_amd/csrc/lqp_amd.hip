@@ -174,6 +174,7 @@ struct Knobs {
     int spd_ptasks;            // LQP_SPD_PTASKS
     int spd_resident;          // LQP_SPD_RESIDENT
     int spd_resident4;         // LQP_SPD_RESIDENT4
+    int spd_f16;               // LQP_SPD_F16: the resident sweep's panel products on the float16 matrix pipe (two-half operands); 0: float32 matrix instructions
     int spd_split;             // LQP_SPD_SPLIT
     int spec_launches;         // LQP_SPEC_LAUNCHES
     int split2;                // LQP_SPLIT2
@@ -223,6 +224,7 @@ Knobs read_knobs() {
     k.spd_ptasks = env_int("LQP_SPD_PTASKS", 48);
     k.spd_resident = env_int("LQP_SPD_RESIDENT", 1);
     k.spd_resident4 = env_int("LQP_SPD_RESIDENT4", 1);
+    k.spd_f16 = env_int("LQP_SPD_F16", 1);
     k.spd_split = env_int("LQP_SPD_SPLIT", -1);
     k.spec_launches = env_int("LQP_SPEC_LAUNCHES", 6);
     k.split2 = env_int("LQP_SPLIT2", 1);
@@ -679,6 +681,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
 #if LQP_PIV_MFMA
         if (P.Ks >= 7 && current_device_cus(&dev_, &cus_) && 4 * B <= cus_ && knobs().spd_resident4 != 0) {
             rs_fn = P.Ks == 7 ? k_spd_resident<7, 4> : k_spd_resident<8, 4>;
+            if (knobs().spd_f16 != 0) rs_fn = P.Ks == 7 ? k_spd_resident<7, 4, true> : k_spd_resident<8, 4, true>;
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) &&
                  per_cu >= 1 && shared_grid(B, 4) <= cus_ * per_cu;
             if (ok) rs_np = 4;
@@ -687,6 +690,11 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         if (!ok) {
             rs_fn = P.Ks == 3 ? k_spd_resident<3> : P.Ks == 4 ? k_spd_resident<4> : P.Ks == 5 ? k_spd_resident<5> : P.Ks == 6 ? k_spd_resident<6>
                   : P.Ks == 7 ? k_spd_resident<7> : k_spd_resident<8>;
+#if LQP_PIV_MFMA
+            if (knobs().spd_f16 != 0)
+                rs_fn = P.Ks == 3 ? k_spd_resident<3, 2, true> : P.Ks == 4 ? k_spd_resident<4, 2, true> : P.Ks == 5 ? k_spd_resident<5, 2, true>
+                      : P.Ks == 6 ? k_spd_resident<6, 2, true> : P.Ks == 7 ? k_spd_resident<7, 2, true> : k_spd_resident<8, 2, true>;
+#endif
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
                  blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && shared_grid(B, SPD_NP) <= cus_ * per_cu;
         }

@@ -1201,7 +1201,7 @@ struct RsSetupHooks {
 // all pivot steps in ONE launch, the matrix resident in the registers of its two workgroups (lqp_spd.hpp).  Reads the
 // blocks k_spd_begin built (half Ks & 1 of the packed area), leaves -(Qs + rho I)^-1 in half 0, where the loop reads it.
 // Exchange buffer: the (unused on this path) KKT-matrix area; step flags: behind the loop's exchange granules.
-template <int KS, int NP = 2>
+template <int KS, int NP = 2, bool F16 = false>
 __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     if (gate && *gate == 0) return;
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     lr.rho_given = (fused && P.rho_mode != 0) ? P.scal[(size_t)b * SC_WORDS + SC_RHO] : 0.f;
     lr.xcd_local = P.xcd_local;
     const RsSetupHooks hooks{P, b, part, NP};
-    wg_spd_sweep_resident_v2<KS, NP>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
+    wg_spd_sweep_resident_v2<KS, NP, RsSetupHooks, F16>(spd_half(P, b, KS & 1), spd_half(P, b, 0), P.M + (size_t)b * P.Np * P.Np, fl, epoch, part,
                                  P.info + b, P.status + ST_TIMEOUT, smem, lr,
                                  (P.dbg && part == 0) ? P.dbg + (size_t)b * 8 : nullptr, hooks);
 }

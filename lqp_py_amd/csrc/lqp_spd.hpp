@@ -23,6 +23,7 @@
 #include "lqp_common.hpp"
 #include "lqp_lu.hpp"
 #include "lqp_trsv.hpp"
+#include "lqp_f16x2.hpp"
 
 namespace lqp {
 
@@ -1942,7 +1943,10 @@ __device__ __forceinline__ void rs2_tile_of(int l, const int K, const int part, 
 // NP = 4 (batches up to a quarter of the CUs, K >= 7): four workgroups share a matrix, one column pair each (9 tiles at
 // K = 8: 4 + 5 per wave pair); every one of them still eliminates the pivot block and computes Y for itself -- what is
 // divided is the tile updates.  Step flags: one 64-bit granule per workgroup, a workgroup waits for all the others.
-template <int K, int NP = 2, class DFn = RsNoScaling>
+// F16: the panel products (Y = P W^T and every tile update) on the float16 matrix pipe with two-half operands
+// (lqp_f16x2.hpp): W, W^T and the Y panel live in LDS as split images of the size of their float32 rows, each 32-row
+// block in a scale of its own.  The pivot block, the exchange and the staging are the float32 ones.
+template <int K, int NP = 2, class DFn = RsNoScaling, bool F16 = false>
 __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, float* Hdst,
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
@@ -2355,6 +2359,153 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             }
             __syncthreads();
             if (dbg) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
+            if constexpr (F16) {
+            // ================= two-half operands on the float16 matrix pipe =================
+            float* const f2w = pcol + 128;                              // [RS_NW] wave maxima of |W|
+            float* const ysc = pcol + 144;                              // [2 (K-1)] 1 / scale of the 32-row blocks of Y
+            char* const Yc = (char*)Y;
+            char* const Wc = (char*)W;
+            char* const WTc = (char*)WT;
+            const int lane_b = li_s * F2_ROW + 32 * lh_s;               // the lane's cell of slice 0 of row li of an image
+            // ---- W, W^T -> split images in place (thread = one cell of one row of each; lanes 2c, 2c+1 share the bytes of a
+            //      row's 16 columns and sit in one wave: every read below precedes every write) ----
+            const int crow = tid_s >> 3, ccs = (tid_s >> 1) & 3, cch = tid_s & 1;
+            float vw[8], vt[8];
+            f2_load_cell_f32(W + crow * SPD_LS, ccs, cch, vw);
+            f2_load_cell_f32(WT + crow * SPD_LS, ccs, cch, vt);
+            {
+                float mx = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = tmax(mx, tabs(vw[j]));
+                mx = wave_max(mx);
+                if (lane == 0) f2w[w] = mx;
+            }
+            // the float32 rows of a 32-row block of the staged panel -> this lane's four cells of its row, in the block's scale
+            auto load_p = [&](const int rb, F2Cell (&pb)[4], float& isP) {
+                const float* prow = Y + ((rb >> 1) * 64 + 32 * (rb & 1) + li_s) * SPD_LS;
+                float pv[4][8], mx = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f2_load_cell_f32(prow, c, lh_s, pv[c]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mx = tmax(mx, tabs(pv[c][j]));
+                }
+                mx = wave_max(mx);
+                float sP;
+                f2_scale_of(mx, sP, isP);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pv[c][j] *= sP;
+                    f2_split8(pv[c], pb[c].hi, pb[c].mid);
+                }
+            };
+            F2Cell pb[4];
+            float isP = 1.f;
+            const int rb0 = __builtin_amdgcn_readfirstlane(w);
+            __syncthreads();                                            // (the wave maxima of |W|; every float32 read of W, W^T is through)
+            float sW, isW;
+            {
+                float wm = f2w[0];
+#pragma unroll
+                for (int ww = 1; ww < RS_NW; ++ww) wm = tmax(wm, f2w[ww]);
+                f2_scale_of(wm, sW, isW);
+            }
+            {
+                h16x8 hi, mid;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { vw[j] *= sW; vt[j] *= sW; }
+                f2_split8(vw, hi, mid);
+                f2_write_cell(Wc + crow * F2_ROW + 64 * ccs + 32 * cch, hi, mid);
+                f2_split8(vt, hi, mid);
+                f2_write_cell(WTc + crow * F2_ROW + 64 * ccs + 32 * cch, hi, mid);
+            }
+            if (rb0 < 2 * (K - 1)) load_p(rb0, pb, isP);
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
+            // ---- Y^T = W P^T: the rows of Y across the lanes, a lane's sixteen entries of an accumulator are the two
+            //      cells it stores (register q = column 8 (q >> 2) + 4 lh + (q & 3) of the 32-column half) ----
+            // (No pass for the block's scale: both operands are below 2^15 in their scales, so the 64-term sums stay below 2^36 --
+            //  taken times 2^-21 they are below 2^15 whatever the data, and a float16 pair has 39 bits of range for float32's 24:
+            //  a scale that is a few powers of two too cautious costs nothing.  Y's scale is sP sW 2^-21.)
+            auto make_y = [&](const int rb, const F2Cell (&pbl)[4], const float isPl) {
+                const char* wa = Wc + lane_b;
+                char* dst = Yc + ((rb >> 1) * 64 + 32 * (rb & 1)) * F2_ROW + lane_b;
+                if (lane == 0) ysc[rb] = (isW * isPl) * 2097152.f;
+                auto store_half = [&](const f32x16& a, const int c0) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = a[8 * c + j] * 4.76837158203125e-7f;
+                        h16x8 hi, mid;
+                        f2_split8(v, hi, mid);
+                        f2_write_cell(dst + 64 * (c0 + c), hi, mid);
+                    }
+                };
+                {   // columns 0..31 (W is lower triangular: its rows < 32 end at column 31 -- slices 0, 1)
+                    f32x16 a0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a0[q] = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) a0 = f2_mma(f2_read_cell(wa + 64 * c), pbl[c], a0);
+                    store_half(a0, 0);
+                }
+                {
+                    f32x16 a1;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a1 = f2_mma(f2_read_cell(wa + 32 * F2_ROW + 64 * c), pbl[c], a1);
+                    store_half(a1, 2);
+                }
+            };
+            if (rb0 < 2 * (K - 1)) make_y(rb0, pb, isP);
+            {
+                const int rb1 = __builtin_amdgcn_readfirstlane(w + RS_NW);
+                if (rb1 < 2 * (K - 1)) {
+                    load_p(rb1, pb, isP);
+                    make_y(rb1, pb, isP);
+                }
+            }
+            __syncthreads();
+            if (dbg) { const unsigned long long t = clock64(); dbt[3] += t - dt0; dt0 = t; }
+            // ---- every resident quadrant by its kind ----
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                int i = ti[s], j = tj[s];
+                asm volatile("" : "+s"(i), "+s"(j));
+                if (i < 0) continue;
+                if (i != k && j != k) {
+                    const int si = i < k ? i : i - 1, sj = j < k ? j : j - 1;
+                    const f32x16 a = f2_quadrant<0, 4>(Yc + (si * 64 + 32 * qi) * F2_ROW + lane_b, Yc + (sj * 64 + 32 * qj) * F2_ROW + lane_b);
+                    const float un = -(ysc[2 * si + qi] * ysc[2 * sj + qj]);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = __builtin_fmaf(a[q], un, T[s][q]);
+                } else if (i == k && j == k) {    // -W^T W (W^T is upper triangular: rows >= 32 only see columns >= 32)
+                    const char* xa = WTc + (32 * qi) * F2_ROW + lane_b;
+                    const char* zb = WTc + (32 * qj) * F2_ROW + lane_b;
+                    const f32x16 a = (qi | qj) ? f2_quadrant<2, 4>(xa, zb) : f2_quadrant<0, 4>(xa, zb);
+                    const float un = -(isW * isW);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = a[q] * un;
+                } else if (j == k) {              // tile (i, k), i > k: Y_i W
+                    const char* xa = Yc + ((i - 1) * 64 + 32 * qi) * F2_ROW + lane_b;
+                    const char* zb = WTc + (32 * qj) * F2_ROW + lane_b;
+                    const f32x16 a = qj == 1 ? f2_quadrant<2, 4>(xa, zb) : f2_quadrant<0, 4>(xa, zb);
+                    const float un = ysc[2 * (i - 1) + qi] * isW;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = a[q] * un;
+                } else {                          // tile (k, j), j < k: W^T Y_j^T
+                    const char* xa = WTc + (32 * qi) * F2_ROW + lane_b;
+                    const char* zb = Yc + (j * 64 + 32 * qj) * F2_ROW + lane_b;
+                    const f32x16 a = qi == 1 ? f2_quadrant<2, 4>(xa, zb) : f2_quadrant<0, 4>(xa, zb);
+                    const float un = isW * ysc[2 * j + qj];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) T[s][q] = a[q] * un;
+                }
+            }
+            } else {
             // ---- Y_i = P_i W^T in place: a wave takes whole 32-row blocks (both column halves) ----
             constexpr int WOFF = (K - 1) * 64 * SPD_LS, WTOFF = WOFF + 64 * SPD_LS;      // W, W^T behind the panel
             const float* const yF = Y + li_s * SPD_LS + 32 * lh_s;     // operand row li at the lane's k range (full)
@@ -2401,6 +2552,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     const int yo = j * 64 * SPD_LS + oj;
                     T[s] = qi == 1 ? spd_quadrant_lp<1>(yH + 32 + WTOFF + 32 * SPD_LS, yH + 32 + yo) : spd_quadrant_lp<0>(yF + WTOFF, yF + yo);
                 }
+            }
             }
             if (dbg) { const unsigned long long t = clock64(); dbt[4] += t - dt0; dt0 = t; }
             if (k + 1 < K) publish(k + 1);

@@ -23,9 +23,12 @@ OUT = os.path.join(CSRC, "split")
 
 # group -> predicate on the demangled name; first match wins.  Balanced by measured compile time (seconds at -O3).
 GROUPS = [
-    ("resident_c", lambda n: re.search(r"k_spd_resident<(3|4), 2>", n)),
-    ("resident_a", lambda n: re.search(r"k_spd_resident<(5|6|7), 2>", n)),
-    ("resident_b", lambda n: re.search(r"k_spd_resident<8, 2>|k_spd_resident<\d, 4>", n)),
+    ("resident_f", lambda n: re.search(r"k_spd_resident<8, 2, true>", n)),
+    ("resident_g", lambda n: re.search(r"k_spd_resident<(5|6|7), 2, true>", n)),
+    ("resident_h", lambda n: re.search(r"k_spd_resident<\d, \d, true>", n)),
+    ("resident_c", lambda n: re.search(r"k_spd_resident<(3|4), 2(, false)?>", n)),
+    ("resident_a", lambda n: re.search(r"k_spd_resident<(5|6|7), 2(, false)?>", n)),
+    ("resident_b", lambda n: re.search(r"k_spd_resident<8, 2(, false)?>|k_spd_resident<\d, 4(, false)?>", n)),
     ("split_c", lambda n: re.search(r"k_admm_loop_split<(3|4), 512, false, 2>", n)),
     ("split_a", lambda n: re.search(r"k_admm_loop_split<(5|6|7), 512, false, 2>", n)),
     ("split_b", lambda n: "k_admm_loop_split<" in n),
@@ -73,8 +76,6 @@ EXTRA = [
     "void lqp::k_unroll_scale_vectors<0>(lqp::ScaleVecParams)",
     "void lqp::k_unroll_scale_scatter<0>(float const*, float const*, int const*, int const*, float const*, float*, int)",
     "void lqp::k_admm_loop_small<0>(lqp::FwdParams<float>, int, int, int)",
-    "void lqp::k_spd_resident<3, 2>(lqp::FwdParams<float>, int const*)",
-    "void lqp::k_spd_resident<4, 2>(lqp::FwdParams<float>, int const*)",
     "void lqp::k_admm_loop_split<3, 512, false, 2>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_admm_loop_split<4, 512, false, 2>(lqp::FwdParams<float>, int, int, int)",
     "void lqp::k_spd_inverse<1>(lqp::FwdParams<float>, int const*)",
@@ -86,6 +87,14 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_spd_resident<3, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<4, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<5, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<6, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<7, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<8, 2>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<7, 4>(lqp::FwdParams<float>, int const*)",
+    "void lqp::k_spd_resident<8, 4>(lqp::FwdParams<float>, int const*)",
     "void lqp::k_lu_inverse<float>(float const*, unsigned long, int, int, int const*, int, float*, unsigned long, int, int const*)",
     "void lqp::k_lu_inverse<double>(double const*, unsigned long, int, int, int const*, int, double*, unsigned long, int, int const*)",
     "void lqp::k_lu_factor_wide<0>(float*, int, int, unsigned long, int*, int, int*, int const*, int const*, int*, unsigned long, unsigned int, int, unsigned long long*)",
