@@ -609,7 +609,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.host_report = (int*)ctl->host_report;
     if (P.host_report) report_reset(P.host_report, ST_WORDS + 2 * B);      // (before the first launch: see wait_report)
     P.xcd_local = knobs().xcd_local != 0 ? 1 : 0;
-    P.dbg_qpass = knobs().dbg_qpass != 0 ? 1 : 0;
+    P.dbg_qpass = knobs().dbg_qpass;      // (bit 0: the second half of the debug buffer; bits 8..: the wave whose stamps the resident sweep records)
     P.zero_words = (int)(((char*)(P.counters + (size_t)kRing * CT_WORDS) - (char*)P.status) / sizeof(int));
     P.dbg = g_lu_dbg;
     P.dbg_setup = nullptr;

@@ -1218,7 +1218,8 @@ __global__ __launch_bounds__(RS_NT) void k_spd_resident(const FwdParams<float> P
     lr.dsc = (fused && !qpass) ? VecView<float>(P.vecs + (size_t)b * P.vstride, P.n, P.m).D : nullptr;
     lr.q = qpass ? P.Q + (size_t)b * P.n * P.n : nullptr;
     lr.cmx = qpass ? prep_scratch(P, b) : nullptr;
-    lr.qdbg = (qpass && P.dbg && P.dbg_qpass && part == 0) ? P.dbg + (size_t)(P.B + b) * 8 : nullptr;      // (LQP_DBG_QPASS=1: the debug buffer holds 2 B x 8 words)
+    lr.dbg_tid = 64 * (P.dbg_qpass >> 8);
+    lr.qdbg = (qpass && P.dbg && (P.dbg_qpass & 1) && part == 0) ? P.dbg + (size_t)(P.B + b) * 8 : nullptr;      // (LQP_DBG_QPASS=1: the debug buffer holds 2 B x 8 words)
     lr.fro_self = (fused && P.rho_mode == 0) ? 1 : 0;
     lr.rho_given = (fused && P.rho_mode != 0) ? P.scal[(size_t)b * SC_WORDS + SC_RHO] : 0.f;
     lr.xcd_local = P.xcd_local;

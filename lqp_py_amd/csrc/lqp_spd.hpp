@@ -43,6 +43,9 @@ __host__ __device__ constexpr int sym_idx(int i, int j, int K) { return j * K - 
 #ifndef LQP_PIV_NB
 #define LQP_PIV_NB 4
 #endif
+#ifndef LQP_F16_EVEN
+#define LQP_F16_EVEN 0          // float16-pipe resident sweep: tiles dealt evenly to the two wave groups (0: 4 / 9 to the pivot block's waves)
+#endif
 constexpr int PIV_NB = LQP_PIV_NB;                            // pivot columns per LDS exchange of the pivot-block elimination
 constexpr int PIV_LDS = 2 * PIV_NB * 64 + 64;        // floats: coefficients [2][PIV_NB][64] | scales [64]
 __host__ __device__ inline int spd_lds_bytes(int K) {
@@ -669,13 +672,14 @@ __device__ __forceinline__ V4<float> ld16_handoff(const float* __restrict__ p) {
 //                barrier and leave): the role code is not even compiled in -- a caller that has already branched on the
 //                wave number keeps the roles' registers out of its other branch this way.
 // IN_W (with GSYNC): the tile already sits in the W area (row stride SPD_LS), src_blk is not read.
-template <bool GSYNC = false, bool ROLES = true, bool IN_W = false>
+template <bool GSYNC = false, bool ROLES = true, bool IN_W = false, bool WMAX = false>
 __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ src_blk, float* __restrict__ W,
                                                     float* __restrict__ WT, float* __restrict__ pcol,
                                                     int* __restrict__ flag, const int kbase,
                                                     int* __restrict__ gwords = nullptr, const int gcall = 0,
                                                     const float diag_add = 0.f,         // (!GSYNC: added to the tile's diagonal as it is staged)
-                                                    const bool handoff = false) {       // (!GSYNC: src_blk was stored by another workgroup of this launch)
+                                                    const bool handoff = false,         // (!GSYNC: src_blk was stored by another workgroup of this launch)
+                                                    float* __restrict__ wmax_out = nullptr) {      // [4]: waves 1, 2 leave max |W| of what they store (LDS)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     float* const svals = pcol;                                        // [64]: 1 / sqrt(pivot)
     int* const words = GSYNC ? gwords : (int*)(pcol + 64);            // [0] panels published, [1] consumers done
@@ -1020,6 +1024,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
         return;
 #endif
         // W = (row scale) x (unit lower triangle), zero above the diagonal; W^T
+        [[maybe_unused]] float wmx = 0.f;
         auto store_quadrant = [&](const f32x16& v, const int I, const int J, const float* scq) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -1028,6 +1033,7 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
                 for (int e = 0; e < 4; ++e) {
                     // (above the diagonal the unit triangle is exactly zero: 0 - coef * 0 at every step, no select needed)
                     v4.v[e] = v[4 * a + e] * scq[4 * a + e];
+                    if constexpr (WMAX) wmx = tmax(wmx, tabs(v4.v[e]));
                     w_o[(32 * I + 8 * a + e) * SPD_LS + 32 * J] = v4.v[e];
                 }
                 *(V4<float>*)(wt_o + (32 * J) * SPD_LS + 32 * I + 8 * a) = v4;      // (four consecutive entries of a W^T row)
@@ -1045,6 +1051,10 @@ __device__ __forceinline__ void wg_pivot_block_mfma(const float* __restrict__ sr
                 w_o[qoff(q) * SPD_LS + 32] = 0.f;
                 wtz_o[(32 + qoff(q)) * SPD_LS] = 0.f;
             }
+        }
+        if constexpr (WMAX) {
+            wmx = wave_max(wmx);
+            if (lane == 0) wmax_out[w] = wmx;
         }
     };
     if (w == 1) consumer(std::true_type());
@@ -1908,6 +1918,7 @@ struct RsLateRho {
     const float* q;           // Q of this problem (n x n, row-major); nullptr: off
     float* cmx;               // global scratch of this problem: [NP][64 K + 2] words (column maxima | asymmetry | magnitude)
     unsigned long long* qdbg; // optional: 8 cycle stamps of the pass (tools/gpu_resident_phases.py), workgroup 0 of the matrix
+    int dbg_tid;              // the thread whose phase stamps go to dbg (LQP_DBG_QPASS bits 8..: its wave)
 };
 // (the scaling vector from the column maxima: supplied by the kernel, which knows the problem's parameters)
 //  scaling(red, d, work): every thread of the workgroup; red: n column maxima, d: n values out, work: 8 + RS_NW floats (LDS)
@@ -1951,7 +1962,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                                                          float* __restrict__ xb, unsigned int* __restrict__ fl,
                                                          const unsigned int epoch, const int part, int* __restrict__ info,
                                                          int* __restrict__ status_timeout, char* smem,
-                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0},
+                                                         const RsLateRho lr = RsLateRho{0, 0, 0.f, 0.f, nullptr, nullptr, 0, 0.f, 0, nullptr, nullptr, nullptr, 0},
                                                          unsigned long long* __restrict__ dbg = nullptr,
                                                          const DFn hooks = DFn{}) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2003,7 +2014,9 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 
     auto body = [&](auto pivot_tag) {
         constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
-        constexpr int NS = PIVOT ? rs2_na<K, NP>() : rs2_nb<K, NP>(), FIRST = PIVOT ? 0 : rs2_na<K, NP>();
+        // (F16: an even deal -- the update of a quadrant keeps an accumulator and two slices of operands next to the tiles)
+        constexpr int NA_ = (F16 && LQP_F16_EVEN) ? rs2_max<K, NP>() / 2 : rs2_na<K, NP>();
+        constexpr int NS = PIVOT ? NA_ : rs2_max<K, NP>() - NA_, FIRST = PIVOT ? 0 : NA_;
         // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
         f32x16 T[NS];
         int ti[NS], tj[NS];
@@ -2231,7 +2244,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 }
             }
         }
-        unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0;
+        unsigned long long dbt[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0, dstage = 0;
         // publish the pivot tile and the panel tiles of step kk this wave holds (as soon as ITS quadrants have step kk-1's
         // update: the store drain then overlaps with the wait for the slowest wave)
         bool xlocal_p = false;          // (set before the first publish)
@@ -2243,6 +2256,20 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 if (i >= 0 && (i == kk || j == kk)) {
                     const int slot = (i == kk && j == kk) ? K - 1 : (j == kk ? i - 1 : j);      // P_i: i > kk -> i - 1, i < kk -> i
                     unsigned int* dst = (unsigned int*)(xbp + (size_t)slot * LQP_BLK + (32 * qi) * 64 + 32 * qj + li);
+                    if constexpr (F16) {
+                        // max |.| of this quadrant next to the tiles: the staging waves of every workgroup scale the panel by it
+                        if (slot != K - 1) {
+                            float mq = 0.f;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) mq = tmax(mq, tabs(T[s][q]));
+                            mq = wave_max(mq);
+                            unsigned int* mdst = (unsigned int*)(xb + (size_t)2 * K * LQP_BLK + 64 + (kk & 1) * 4 * K + slot * 4 + 2 * qi + qj);
+                            if (lane == 0) {
+                                if (xlocal_p) __hip_atomic_store(mdst, __builtin_bit_cast(unsigned int, mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                else __hip_atomic_store(mdst, __builtin_bit_cast(unsigned int, mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
                     if (xlocal_p) {
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
@@ -2326,7 +2353,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (dbg) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
             // ---- pivot tile -> W, W^T by waves 0..3 | panel tiles -> LDS by waves 4..7 (slot s holds P_i = A_ik, i.e.
             //      block (k, i) transposed when i < k) ----
-            wg_pivot_block_mfma<false, PIVOT>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64, nullptr, 0, diag_add, true);
+            wg_pivot_block_mfma<false, PIVOT, false, F16>(xbk + (size_t)(K - 1) * LQP_BLK, W, WT, pcol, flag, k * 64, nullptr, 0, diag_add, true,
+                                                          pcol + 128);
             // (lane parts of every LDS / global address of this step, opaque: as loop invariants of the step loop they
             //  would be formed once, held in registers -- one per distinct address -- and spilled with the tiles)
             int li_s = li, lh_s = lh, tid_s = tid;
@@ -2336,6 +2364,69 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 const float* const src_l = xbk + r0 * 64 + c8;
                 float* const yrow_l = Y + r0 * SPD_LS + c8;            // row-major destination
                 float* const ycol_l = Y + c8 * SPD_LS + r0;            // transposed destination
+                if constexpr (F16) {
+                    // ---- straight into the split image of the panel, in the scale of each tile; the loads of four half-tiles in
+                    //      flight (one at a time they cost a trip to the L2 each: 22 k cycles per step, as long as the pivot block) ----
+                    constexpr int NIT = 2 * (K - 1), PF = NIT < LQP_F16_PF ? NIT : LQP_F16_PF;
+                    const unsigned long long* const mq = (const unsigned long long*)(xb + (size_t)2 * K * LQP_BLK + 64 + (k & 1) * 4 * K);
+                    unsigned long long mraw[2 * (K - 1)];
+#pragma unroll
+                    for (int s0 = 0; s0 < K - 1; ++s0) {
+                        mraw[2 * s0] = __hip_atomic_load(mq + 2 * s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mraw[2 * s0 + 1] = __hip_atomic_load(mq + 2 * s0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    V4<float> ra[PF], rb[PF];
+                    auto request = [&](const int it, V4<float>& a, V4<float>& b) {
+                        const float* src = src_l + (it >> 1) * LQP_BLK + 32 * (it & 1) * 64;
+                        a = ld16_handoff(src); b = ld16_handoff(src + 4);
+                    };
+#pragma unroll
+                    for (int it = 0; it < PF; ++it) request(it, ra[it], rb[it]);
+                    // the tiles' scales from the maxima their owners published with them (four quadrants; both 32-row blocks of a
+                    // slot share it)
+                    float sPt[K - 1];
+#pragma unroll
+                    for (int s0 = 0; s0 < K - 1; ++s0) {
+                        const unsigned long long m01 = mraw[2 * s0], m23 = mraw[2 * s0 + 1];
+                        const float mt = tmax(tmax(__uint_as_float((unsigned int)m01), __uint_as_float((unsigned int)(m01 >> 32))),
+                                              tmax(__uint_as_float((unsigned int)m23), __uint_as_float((unsigned int)(m23 >> 32))));
+                        float isPt;
+                        f2_scale_of(mt, sPt[s0], isPt);
+                        if (tt == s0) (pcol + 160)[s0] = isPt;
+                    }
+                    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                    char* const Yc_ = (char*)Y;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int s0 = it >> 1, hf = it & 1;
+                        const V4<float> a = ra[it % PF], b = rb[it % PF];
+                        float va[4], vb[4];
+                        h16x4 ha, ma, hb, mb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            va[e] = a.v[e] * sPt[s0]; vb[e] = b.v[e] * sPt[s0];
+                            ha[e] = (_Float16)va[e]; ma[e] = (_Float16)(va[e] - (float)ha[e]);
+                            hb[e] = (_Float16)vb[e]; mb[e] = (_Float16)(vb[e] - (float)hb[e]);
+                        }
+                        if (it + PF < NIT) request(it + PF, ra[it % PF], rb[it % PF]);
+                        if (s0 >= k) {
+                            // row r0 + 32 hf of the slot, columns c8 .. c8 + 7: slice c8 / 16, element half (c8 / 8) & 1 of the cells
+                            // of both lane halves (a: h = 0, b: h = 1; lqp_f16x2.hpp)
+                            char* d = Yc_ + (s0 * 64 + 32 * hf + r0) * F2_ROW + 64 * (c8 >> 4) + 8 * ((c8 >> 3) & 1);
+                            *(h16x4*)d = ha; *(h16x4*)(d + 16) = ma;
+                            *(h16x4*)(d + 32) = hb; *(h16x4*)(d + 48) = mb;
+                        } else {
+                            // transposed: the value is P[row c8 + e (+ 4)][column t = r0 + 32 hf]
+                            const int t = r0 + 32 * hf;
+                            char* d = Yc_ + (s0 * 64 + c8) * F2_ROW + 64 * (t >> 4) + 32 * ((t >> 2) & 1) + 2 * (4 * ((t >> 3) & 1) + (t & 3));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                *(_Float16*)(d + e * F2_ROW) = ha[e]; *(_Float16*)(d + e * F2_ROW + 16) = ma[e];
+                                *(_Float16*)(d + (4 + e) * F2_ROW) = hb[e]; *(_Float16*)(d + (4 + e) * F2_ROW + 16) = mb[e];
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int s0 = 0; s0 < K - 1; ++s0) {
 #pragma unroll
@@ -2354,6 +2445,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                         }
                     }
                 }
+                }
+                if (dbg) dstage += clock64() - dt0;                      // (a staging wave's own work of this phase)
                 // (these waves now wait ~20 k cycles for the pivot block: room for the vectors the setup kernel left)
                 if (k == 0 && lr.q && w == RS_NW - 1) hooks.deferred(dkeep);
             }
@@ -2370,56 +2463,32 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             // ---- W, W^T -> split images in place (thread = one cell of one row of each; lanes 2c, 2c+1 share the bytes of a
             //      row's 16 columns and sit in one wave: every read below precedes every write) ----
             const int crow = tid_s >> 3, ccs = (tid_s >> 1) & 3, cch = tid_s & 1;
-            float vw[8], vt[8];
-            f2_load_cell_f32(W + crow * SPD_LS, ccs, cch, vw);
-            f2_load_cell_f32(WT + crow * SPD_LS, ccs, cch, vt);
-            {
-                float mx = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mx = tmax(mx, tabs(vw[j]));
-                mx = wave_max(mx);
-                if (lane == 0) f2w[w] = mx;
-            }
-            // the float32 rows of a 32-row block of the staged panel -> this lane's four cells of its row, in the block's scale
-            auto load_p = [&](const int rb, F2Cell (&pb)[4], float& isP) {
-                const float* prow = Y + ((rb >> 1) * 64 + 32 * (rb & 1) + li_s) * SPD_LS;
-                float pv[4][8], mx = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f2_load_cell_f32(prow, c, lh_s, pv[c]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) mx = tmax(mx, tabs(pv[c][j]));
-                }
-                mx = wave_max(mx);
-                float sP;
-                f2_scale_of(mx, sP, isP);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pv[c][j] *= sP;
-                    f2_split8(pv[c], pb[c].hi, pb[c].mid);
-                }
-            };
-            F2Cell pb[4];
-            float isP = 1.f;
-            const int rb0 = __builtin_amdgcn_readfirstlane(w);
-            __syncthreads();                                            // (the wave maxima of |W|; every float32 read of W, W^T is through)
             float sW, isW;
+            f2_scale_of(tmax(f2w[1], f2w[2]), sW, isW);                 // (max |W| from the two waves that stored it: wg_pivot_block_mfma)
             {
-                float wm = f2w[0];
-#pragma unroll
-                for (int ww = 1; ww < RS_NW; ++ww) wm = tmax(wm, f2w[ww]);
-                f2_scale_of(wm, sW, isW);
-            }
-            {
+                float vw[8], vt[8];
+                f2_load_cell_f32(W + crow * SPD_LS, ccs, cch, vw);
+                f2_load_cell_f32(WT + crow * SPD_LS, ccs, cch, vt);
                 h16x8 hi, mid;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { vw[j] *= sW; vt[j] *= sW; }
                 f2_split8(vw, hi, mid);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's float32 reads are through before any of its lanes writes)
                 f2_write_cell(Wc + crow * F2_ROW + 64 * ccs + 32 * cch, hi, mid);
                 f2_split8(vt, hi, mid);
                 f2_write_cell(WTc + crow * F2_ROW + 64 * ccs + 32 * cch, hi, mid);
             }
+            const float* const psc = pcol + 160;                        // [K - 1] 1 / scale of the staged panel slots
+            // this lane's four cells of its row of a 32-row block of the staged panel (split by the staging waves)
+            auto load_p = [&](const int rb, F2Cell (&pb)[4], float& isP) {
+                const char* prow = Yc + ((rb >> 1) * 64 + 32 * (rb & 1)) * F2_ROW + lane_b;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pb[c] = f2_read_cell(prow + 64 * c);
+                isP = psc[rb >> 1];
+            };
+            F2Cell pb[4];
+            float isP = 1.f;
+            const int rb0 = __builtin_amdgcn_readfirstlane(w);
             if (rb0 < 2 * (K - 1)) load_p(rb0, pb, isP);
             __syncthreads();
             if (dbg) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
@@ -2447,16 +2516,42 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     f32x16 a0;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) a0[q] = 0.f;
+#if LQP_F16_DB
+                    F2Cell wc = f2_read_cell(wa);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        F2Cell wn = wc;
+                        if (c + 1 < 2) wn = f2_read_cell(wa + 64 * (c + 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        a0 = f2_mma(wc, pbl[c], a0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        wc = wn;
+                    }
+#else
 #pragma unroll
                     for (int c = 0; c < 2; ++c) a0 = f2_mma(f2_read_cell(wa + 64 * c), pbl[c], a0);
+#endif
                     store_half(a0, 0);
                 }
                 {
                     f32x16 a1;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+#if LQP_F16_DB
+                    F2Cell wc = f2_read_cell(wa + 32 * F2_ROW);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        F2Cell wn = wc;
+                        if (c + 1 < 4) wn = f2_read_cell(wa + 32 * F2_ROW + 64 * (c + 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        a1 = f2_mma(wc, pbl[c], a1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        wc = wn;
+                    }
+#else
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a1 = f2_mma(f2_read_cell(wa + 32 * F2_ROW + 64 * c), pbl[c], a1);
+#endif
                     store_half(a1, 2);
                 }
             };
@@ -2558,8 +2653,10 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
             if (k + 1 < K) publish(k + 1);
             if (dbg) { const unsigned long long t = clock64(); dbt[5] += t - dt0; }
         }
-        if (dbg && tid == 0)
+        if (dbg && tid == lr.dbg_tid) {
             for (int q = 0; q < 6; ++q) dbg[q] = dbt[q];
+            if (lr.dbg_tid != 0) dbg[6] = dstage;
+        }
         // ---- the finished tiles to their home blocks ----
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -2581,7 +2678,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 __host__ __device__ inline int rs_q_lds_bytes(int K) { return spd_lds_bytes(K) + 64 + 64 * K * 4; }
 
 
-__host__ __device__ constexpr size_t rs2_xb_floats(int K) { return (size_t)2 * K * LQP_BLK + 64; }
+// (+ 64: the sums of the late rho; + 2 x 4 K: max |.| of every quadrant of the published tiles, by step parity -- the float16-pipe sweep)
+__host__ __device__ constexpr size_t rs2_xb_floats(int K) { return (size_t)2 * K * LQP_BLK + 64 + 8 * K; }
 
 // ---------------------------------------------------------------------------
 // Blocked Cholesky of an SPD matrix held as packed lower blocks, in place (the symmetric backward system):

@@ -2,7 +2,8 @@
 """In-kernel cycle breakdown of the register-resident sweep k_spd_resident (thread 0 of workgroup 0 of every QP)."""
 import os, sys
 os.environ.setdefault("LQP_ENV_NOCACHE", "1")
-os.environ["LQP_DBG_QPASS"] = "1"      # (the stamps of the pass over Q go to a second half of the debug buffer)      # (this tool flips library knobs between solves)
+WAVE = int(os.environ.get("LQP_DBG_WAVE", "0"))      # the wave of workgroup 0 whose stamps are recorded (4 .. 7: a staging wave)
+os.environ["LQP_DBG_QPASS"] = str(1 + (WAVE << 8))      # (the stamps of the pass over Q go to a second half of the debug buffer)      # (this tool flips library knobs between solves)
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -32,10 +33,12 @@ if os.environ.get("LQP_RS_FORM", "2") == "4":
         print("%-40s %9.0f cycles (%.0f per step)" % (nm, c[:, i].mean(), c[:, i].mean() / 8))
     print("total of the 8 steps %.0f cycles" % tot)
 else:
-    names = ["publish + wait for the partner", "pivot block", "panel tiles -> LDS", "Y = P W^T", "tile updates", "closing barrier"]
+    names = ["publish + wait for the partner", "pivot block + staging", "W -> halves, panel cells", "Y = P W^T", "tile updates", "publish of the next step"]
     tot = c[:, :6].sum(1).mean()
     for i, nm in enumerate(names):
         print("%-32s %9.0f cycles  (%4.1f %%)" % (nm, c[:, i].mean(), 100 * c[:, i].mean() / tot))
     print("total of the 8 steps %.0f cycles" % tot)
+    if WAVE:
+        print("wave %d: its own staging work inside the pivot phase %.0f cycles" % (WAVE, c[:, 6].mean()))
     print("pass over Q inside the sweep: tiles + mirrors %.0f cycles, up to the scaling vector %.0f" % (c[:, 7].mean(), c[:, 6].mean()))
     print("  cumulative: tiles + mirrors %.0f | maxima stored and acknowledged %.0f | partner announced %.0f | partner's maxima read %.0f | scaling vector %.0f" % tuple(q[:5]))
