@@ -174,6 +174,7 @@ struct Knobs {
     int spd_ptasks;            // LQP_SPD_PTASKS
     int spd_resident;          // LQP_SPD_RESIDENT
     int spd_resident4;         // LQP_SPD_RESIDENT4
+    int spd_turns;             // LQP_SPD_TURNS: more matrices than half the CUs -> the resident sweep anyway, its pairs taking turns on the chip
     int spd_f16;               // LQP_SPD_F16: the resident sweep's panel products on the float16 matrix pipe (two-half operands); 0: float32 matrix instructions
     int spd_split;             // LQP_SPD_SPLIT
     int spec_launches;         // LQP_SPEC_LAUNCHES
@@ -225,6 +226,7 @@ Knobs read_knobs() {
     k.spd_resident = env_int("LQP_SPD_RESIDENT", 1);
     k.spd_resident4 = env_int("LQP_SPD_RESIDENT4", 1);
     k.spd_f16 = env_int("LQP_SPD_F16", 1);
+    k.spd_turns = env_int("LQP_SPD_TURNS", 1);
     k.spd_split = env_int("LQP_SPD_SPLIT", -1);
     k.spec_launches = env_int("LQP_SPEC_LAUNCHES", 6);
     k.split2 = env_int("LQP_SPLIT2", 1);
@@ -656,6 +658,20 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         spd_split = spd_split && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS;     // room for W, W^T in the M area
         spd_split = spd_split && !solo;
     }
+    // More matrices than half the CUs (BASELINE configs[4]: 1024 per GPU): the resident sweep all the same, its pairs taking turns
+    // on the chip as the loop's do (FwdParams::split_seg) -- partners are neighbours in dispatch order on one XCD (shared_map), so a
+    // workgroup that waits for its partner waits for a CU that a COMPLETE earlier pair is about to leave.  Round 4 measured this
+    // form slower than the one-workgroup sweep (8 turns x 0.36 ms against 2.9 ms); with the panel products on the float16 pipe a
+    // turn is 0.28 ms and needs no pass over Q in front (k_spd_prep: 0.44 ms at B = 1024).
+    bool spd_turns = false;
+#if LQP_PIV_MFMA
+    if (spd && !spd_split && !solo && P.xchg && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK && knobs().spd_turns != 0 &&
+        knobs().spd_resident != 0 && knobs().spd_f16 != 0 && knobs().spd_split != 0 &&
+        (size_t)P.Np * P.Np >= rs2_xb_floats(P.Ks) && (size_t)P.Np * P.Np >= 2 * 64 * SPD_LS) {
+        int dev_ = 0, cus_ = 0;
+        if (current_device_cus(&dev_, &cus_) && B * SPD_NP > cus_) { spd_turns = true; spd_split = true; }
+    }
+#endif
     bool spd_big_split = false;
     if (spd && P.Ks > SPD_MAXK) {
         int dev_ = 0, cus_ = 0;
@@ -696,10 +712,11 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                       : P.Ks == 6 ? k_spd_resident<6, 2, true> : P.Ks == 7 ? k_spd_resident<7, 2, true> : k_spd_resident<8, 2, true>;
 #endif
             ok = ensure_lds((const void*)rs_fn, rlds) == LQP_OK && current_device_cus(&dev_, &cus_) &&
-                 blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && shared_grid(B, SPD_NP) <= cus_ * per_cu;
+                 blocks_per_cu(&per_cu, rs_fn, RS_NT, rlds, dev_) && per_cu >= 1 && (spd_turns || shared_grid(B, SPD_NP) <= cus_ * per_cu);
         }
         spd_resident = ok;
     }
+    if (spd_turns && !spd_resident) { spd_turns = false; spd_split = false; }      // (the one-workgroup sweep after all)
     // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
     P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && knobs().rho_late) ? 1 : 0;
@@ -978,7 +995,14 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // (ctrl.reserved2 bit 0: the caller will read the corrected H from the workspace afterwards -- lqp_boxqp_unroll_backward --
     //  so the correction must reach global memory: k_spd_end runs)
     if constexpr (sizeof(T) == 4)
-        P.eq_in_loop = (loop_split && spd_resident && m > 0 && !(ctl->reserved2 & 1) && knobs().eq_in_loop) ? 1 : 0;
+    {
+        // (one launch per check segment, pairs taking turns: the FIRST segment's launch applies it and writes the corrected blocks
+        //  back -- from two turns of the chip on; below that k_spd_end on every CU at once is faster: B = 256 1.39 against 1.53 ms
+        //  per step, B = 512 2.69 against 2.59)
+        int dev_ = 0, cus_ = 0;
+        const bool seg_eq = loop_split_seg && current_device_cus(&dev_, &cus_) && B >= 2 * cus_;
+        P.eq_in_loop = ((loop_split || seg_eq) && spd_resident && m > 0 && !(ctl->reserved2 & 1) && knobs().eq_in_loop) ? 1 : 0;
+    }
     rc = factor_step(nullptr);
     if (rc) return rc;
     if (loop_dense || loop_dense_w) {
@@ -1185,6 +1209,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                       FwdParams<float> Ps = P;
                       Ps.split_seg = 1;
                       Ps.seg_prev_slot = prev_slot;
+                      if (it > 0) Ps.eq_in_loop = 0;
                       ProfScope ps(st, PC_LOOP);
                       hipLaunchKernelGGL(split_fn, dim3(shared_grid(B, 2)), dim3(split_nt), split_lds, st, Ps, it, e, ctr_base);
                   }
