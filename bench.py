@@ -33,6 +33,7 @@ TOL = 1e-5
 N_SEEDS = 10                  # experiment_1.py: n_sims = 10, seed = simulation index
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_F16_PEAK_TFLOPS = 2516.6 # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16: 32 k flop in 32 cycles per SIMD)
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X: fp64 matrix = fp64 vector peak (v_mfma_f64_16x16x4_f64, 64 cycles per SIMD)
 INFINITY_CACHE_BYTES = 256 * 2 ** 20
 TRAFFIC_FILE = "profiles/r05_b_headline_traffic.json"
@@ -420,13 +421,29 @@ def main():
                        "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": f_traffic,
                        "algorithmic_flops": B * float(n) ** 3, "ms": round(f_ms, 4),
                        "minimum_traffic_bytes": 2 * B * (n * (n + 1) // 2) * es,
-                       "per": "one factorisation of the batch (all its launches)"}
+                       "per": "one factorisation of the batch (all its launches)",
+                       "peak_is": "the float32 matrix peak (the arithmetic the path computes in: n^3 float32 flops per matrix)"}
+        if st_timed["factor_launches"] == 3 and os.environ.get("LQP_SPD_F16", "1") != "0":
+            # round 6: the sweep's panel products run on the float16 matrix pipe, every float32 operand as two halves
+            # (csrc/lqp_f16x2.hpp): three matrix instructions per product term -- priced against THAT pipe's peak too
+            roof_factor["matrix_pipe"] = ("f16, two-half float32 operands: three v_mfma_f32_32x32x16_f16 per 16-deep slice "
+                                          "(issued flops = 3 x algorithmic for the panel products)")
+            roof_factor["frac_of_f16_peak_issued"] = round(3 * tfl / MFMA_F16_PEAK_TFLOPS, 4)
     # `roofline` describes the kernel (group) that takes the largest share of the step
     dominant_is_factor = roof_factor is not None and roof_factor["ms"] > loop_ms
     roofline = dict(roof_factor if dominant_is_factor else roof_loop)
     step_bytes = (fwd_b + bwd_b) * B
     roofline["whole_step_frac_of_hbm_roofline"] = round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)
     roofline["whole_step_algorithmic_bytes"] = step_bytes
+    roofline["whole_step_algorithmic_bytes_note"] = ("SURVEY 8(d)-style accounting of the path that RAN (forward: symmetric inverse; backward: "
+                                                     + ("Cholesky form, free set taken as 0.63 n -- an estimate" if (ls == 2 and prof.get("bwd_cholesky", (0, 0))[1] > 0) else "LU form")
+                                                     + "); most of these bytes stay in registers / LDS, so this is NOT a memory bandwidth -- "
+                                                     "whole_step_traffic_bytes below is what the counters saw move")
+    twin = profile_twin("headline") if (B == B_PER_GPU and n == N_X and not args.strong and not args.config5) else None
+    roofline["whole_step_traffic_bytes"] = None if twin is None else twin["traffic_bytes_per_step"]
+    roofline["whole_step_frac_of_hbm_peak_by_traffic"] = (None if twin is None else
+                                                          round(twin["traffic_bytes_per_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    roofline["whole_step_traffic_source"] = None if twin is None else twin["source"]
 
     workload = (f"BASELINE configs[4]: batch={B_total} dz={n} m={m} sharded over {world} GPU(s), {B}/GPU" if args.config5 else
                 f"BASELINE configs[2], strong scaling: ONE batch={B_total} dz={n} m={m} split over {world} GPU(s), {B} on rank 0"
@@ -471,6 +488,8 @@ def main():
             L.synchronize()
             out[key] = {"value": round(B / (dtx / k), 1), "unit": "QPs/sec", "ms_per_step": round(dtx / k * 1e3, 4), "steps": k}
             if key == "step_sync_default":
+                out["config"]["step_sync_default_QPs_per_sec"] = out[key]["value"]      # (the reference-compatible rate travels with the headline)
+                out["config"]["step_sync_default_ms_per_step"] = out[key]["ms_per_step"]
                 out[key]["timing"] = "median of three rounds of 40 steps after 10 warm-up steps"
                 out[key]["rounds_ms_per_step"] = [round(t / k * 1e3, 4) for t in rounds_x]
             if key == "step_linsolve_lu":
@@ -486,6 +505,7 @@ def main():
                     "kernel": "lqp::k_lu_factor2 (two workgroups per matrix, csrc/lqp_lu2.hpp)",
                     "algorithmic_flops_per_step": round(B * 2.0 / 3.0 * (N_f ** 3 + N_b ** 3)), "ms_per_step": round(lu_ms, 4),
                     "algorithmic_TFLOPs": round(B * 2.0 / 3.0 * (N_f ** 3 + N_b ** 3) / (lu_ms * 1e-3) / 1e12, 2) if lu_ms > 0 else None,
+                    "algorithmic_flops_are": "an ESTIMATE: the backward's reduced system is taken as 0.63 n + m rows (the free set of the benchmark data), not read back from the run",
                     "note": "forward KKT matrix (n + m rows) + the backward's reduced system (~0.63 n + m rows); the panel chain of "
                             "partial pivoting is serial: the matrix-core share (trailing update, U12) is the profile's MFMA figure"}
                 loop_lu_ms = pr.get("admm_loop", (0.0, 0))[0] / k

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 11
+#define LQP_ABI_VERSION 12
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -84,7 +84,10 @@ typedef struct lqp_boxqp_ctrl {
                                         workgroup per matrix everywhere, host-launched check segments: what the library falls
                                         back to by itself when a kernel that waits for a partner workgroup gives up (CUs held
                                         by another stream / process), and what a caller of lqp_boxqp_forward_finish that got
-                                        LQP_ERR_TIMEOUT passes when it repeats the forward                              */
+                                        LQP_ERR_TIMEOUT passes when it repeats the forward; bit 2 (ABI 12): keep a
+                                        trace of the convergence checks -- the largest primal and dual error over the batch at
+                                        every check, what the reference prints under verbose=True (:289-294) -- for
+                                        lqp_boxqp_check_trace                                                            */
     double eps_abs;
     double eps_rel;
     double rho_value;
@@ -166,7 +169,8 @@ int lqp_debug_spin(void* stream, int blocks, int usec, int lds_bytes);
  * the question the workgroups that share a matrix ask at every launch before they choose their exchange protocol.        */
 int lqp_debug_xcd(void* stream, int blocks, void* out_dev);
 /* test access to the dense tier's first kernel (csrc/lqp_dense.hpp): X (B, N, N) = M^-1 from a packed factor
- * (`packed`: the buffer lqp_lu_pack filled).  N <= 1024 (float32: 512).  No reference counterpart. */
+ * (`packed`: the buffer lqp_lu_pack filled).  Any N whose column tile fits the LDS: float32 to 2048 (above 576 rows on 16-column
+ * tiles), float64 to about 1100; LQP_ERR_UNSUPPORTED beyond.  No reference counterpart. */
 int lqp_debug_lu_inverse(void* stream, int dtype, int B, int N, const void* packed, void* X_out);
 
 /* ---- forward ADMM solve ------------------------------------------------
@@ -254,6 +258,14 @@ int lqp_unroll_scale_scatter(void* stream, int B, int n, const void* Q, const vo
 int lqp_boxqp_last_residuals(void* stream, int dtype, int B, int n, int m,
                              const void* workspace, size_t workspace_bytes,
                              void* primal_out, void* dual_out);
+
+/* ABI 12: the trace of a forward solve that ran with ctrl.reserved2 bit 2 -- for check c = 0 .. n_checks - 1 (held at
+ * iteration c * check_solved) trace_out[2 c] = max over the batch of ||D r||_inf, trace_out[2 c + 1] = max of ||D s||_inf,
+ * float32 on the DEVICE (2 * n_checks values; at most 2048 checks are kept).  Replaces the prints of
+ * solve_box_qp_admm_torch.py:289-294 (verbose=True): the loop runs on the device without the host, so the lines are
+ * printed after the solve from this trace.  Enqueued on `stream`.                                                        */
+int lqp_boxqp_check_trace(void* stream, int dtype, int B, int n, int m,
+                          const void* workspace, size_t workspace_bytes, int n_checks, void* trace_out);
 
 /* ---- fixed-point implicit backward --------------------------------------
  * Replaces torch_solve_box_qp_grad (solve_box_qp_admm_torch.py:349-432):

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQ
 SOURCES = ["lqp_amd.hip", "lqp_unroll.hpp", "lqp_boxqp.hpp", "lqp_lu.hpp", "lqp_lu_big.hpp", "lqp_lu2.hpp", "lqp_lu_wide.hpp", "lqp_dense.hpp", "lqp_trsv.hpp", "lqp_spd.hpp", "lqp_common.hpp"]
 
 LQP_F32, LQP_F64 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
           5: "grid barrier timeout", 6: "unsupported size", 7: "matrix outside the symmetric x-update"}
 
@@ -75,6 +75,7 @@ SYMBOLS = {
     "lqp_unroll_scale_vectors": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_double] + [_P] * 13 + [c_int] + [_P] * 7),
     "lqp_unroll_scale_scatter": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "lqp_boxqp_last_residuals": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "lqp_boxqp_check_trace": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, c_int, _P]),
     "lqp_boxqp_backward_fp_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_backward_fp_prefactor": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 6 + [_P, c_size_t, c_int, _P]),
     "lqp_boxqp_backward_fp": (c_int, [_P, c_int, c_int, c_int, c_int] + [_P] * 9 + [c_int, c_double, _P] + [_P] * 6 +
@@ -248,13 +249,17 @@ _pinned_free = {}        # number of int32 words -> pinned host buffers waiting 
 _pinned_quarantine = []  # report buffers a kernel that is still queued may write (a prefactored backward that was dropped)
 
 
+_pinned_lock = threading.Lock()      # (the forward's thread and the autograd thread both allocate and release report buffers)
+
+
 def pinned_release(report):
     """A report buffer goes back to the pool -- at once when nothing can write it any more (every word has arrived: a kernel
     stores each word exactly once, the library set them to -1 before), otherwise when a later allocation finds it complete."""
-    if bool((report != -1).all()):
-        _pinned_free.setdefault(report.numel(), []).append(report)
-    else:
-        _pinned_quarantine.append(report)
+    with _pinned_lock:
+        if bool((report != -1).all()):
+            _pinned_free.setdefault(report.numel(), []).append(report)
+        else:
+            _pinned_quarantine.append(report)
 
 
 
@@ -262,16 +267,18 @@ def _pinned(words):
     """One pinned int32 buffer of `words` words.  An empty pool is refilled SIXTEEN buffers at a time from one pinned
     allocation (a pipelined loop keeps a dozen reports in flight before the first one comes back: sixteen host allocations of
     ~30-100 us each used to sit in the first steps on fresh tensors)."""
-    if _pinned_quarantine:
-        for rep in [r for r in _pinned_quarantine if bool((r != -1).all())]:
-            _pinned_quarantine.remove(rep)
-            _pinned_free.setdefault(rep.numel(), []).append(rep)
-    pool = _pinned_free.setdefault(words, [])
-    if not pool:
-        stride = (words + 15) // 16 * 16                      # (64-byte aligned slices)
-        slab = torch.empty(16 * stride, dtype=torch.int32, pin_memory=True)
-        pool.extend(slab[i * stride:i * stride + words] for i in range(16))
-    return pool.pop()
+    with _pinned_lock:
+        if _pinned_quarantine:
+            done = [r for r in _pinned_quarantine if bool((r != -1).all())]
+            _pinned_quarantine[:] = [r for r in _pinned_quarantine if not any(r is d for d in done)]
+            for rep in done:
+                _pinned_free.setdefault(rep.numel(), []).append(rep)
+        pool = _pinned_free.setdefault(words, [])
+        if not pool:
+            stride = (words + 15) // 16 * 16                      # (64-byte aligned slices)
+            slab = torch.empty(16 * stride, dtype=torch.int32, pin_memory=True)
+            pool.extend(slab[i * stride:i * stride + words] for i in range(16))
+        return pool.pop()
 
 
 ST_WORDS = 16                # status block, include/lqp_amd.h (lqp_boxqp_ctrl.host_report)
@@ -315,9 +322,16 @@ def poll_errors(block=False):
             _pending.pop(0)
         p.event.synchronize()
         rep = p.keep[0].numpy()
-        if int(rep[0]) < 0:
+        if int(rep[0]) == -1:               # (-1: the library's "nothing arrived"; every stored word is >= 0 or -7)
             raise RuntimeError(f"lqp_py_amd.{p.what}: the call's report never arrived in host memory")
         info = p.info.numpy()
+        if (info == -7).any():              # a workgroup of a shared LU (two per matrix / wide) waited for its partner in vain
+            for t in getattr(p, "keep", ()):
+                _pinned_free.setdefault(t.numel(), []).append(t)
+            raise RuntimeError(f"lqp_py_amd.{p.what} (reported late: the call did not synchronise): a factorisation shared between "
+                               f"workgroups timed out waiting for its partner (batch index {int((info == -7).nonzero()[0][0])}; the "
+                               "CUs were held by somebody else); the outputs are not valid.  Repeat with control['sync']=True, which "
+                               "falls back to one workgroup per matrix by itself, or pass reserved2 bit 1 (lqp_boxqp_ctrl) for that schedule")
         bad = info.nonzero()[0]
         flags = int(numpy.bitwise_or.reduce(p.flags.numpy())) if p.flags is not None else 0
         status7 = (int(p.status[7]) or (flags & RP_NOTSPD)) if p.status is not None else 0

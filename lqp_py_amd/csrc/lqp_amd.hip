@@ -550,6 +550,7 @@ int collect_report(hipStream_t st, const int* rep, const bool polled, const int 
 template <typename T> struct FwdLayout {
     FwdParams<T> P;
     size_t bytes;
+    unsigned int* vtrace_area;      // [kRing][2]: the check trace (FwdParams::vtrace points here when ctrl.reserved2 bit 2 asks for it)
 };
 
 template <typename T>
@@ -566,6 +567,7 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.counters = c.take<unsigned int>((size_t)kRing * CT_WORDS);
     P.info = c.take<int>(B);            // (status | counters | info: one contiguous region for the deferred error fetch)
     P.bflags = c.take<int>(B);
+    L.vtrace_area = c.take<unsigned int>((size_t)kRing * 2);      // (the check trace of verbose=True; in use: FwdParams::vtrace)
     P.scal = c.take<T>((size_t)B * SC_WORDS);
     P.vecs = c.take<T>((size_t)B * P.vstride);
     P.piv = c.take<int>((size_t)B * P.Np);
@@ -608,6 +610,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in; P.beta_in = (const T*)ctl->beta_in;
     P.x = (T*)x; P.z = (T*)z; P.u = (T*)u; P.lams = (T*)lams; P.nus = (T*)nus; P.rho_out = (T*)rho_out;
     P.scale = ctl->scale; P.bound_flags_in = (const int*)ctl->bound_flags_in;
+    if (ctl->reserved2 & 4) {           // verbose: the largest primal / dual error of the batch at every check (lqp_boxqp_check_trace)
+        P.vtrace = L.vtrace_area;
+        HIP_OK(hipMemsetAsync(P.vtrace, 0, sizeof(unsigned int) * 2 * kRing, st));
+    }
     P.host_report = (int*)ctl->host_report;
     if (P.host_report) report_reset(P.host_report, ST_WORDS + 2 * B);      // (before the first launch: see wait_report)
     P.xcd_local = knobs().xcd_local != 0 ? 1 : 0;
@@ -1916,6 +1922,26 @@ int lqp_boxqp_last_residuals(void* stream, int dtype, int B, int n, int m, const
         hipLaunchKernelGGL(k_copy_residuals<double>, dim3((B + 255) / 256), dim3(256), 0, st, L.P.scal, (double*)primal_out,
                            (double*)dual_out, B);
     }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+int lqp_boxqp_check_trace(void* stream, int dtype, int B, int n, int m, const void* workspace, size_t workspace_bytes,
+                          int n_checks, void* trace_out) {
+    if (bad_dims(dtype, B, n, m) || !workspace || !trace_out || n_checks < 0) return LQP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 || n_checks == 0) return LQP_OK;
+    const unsigned int* src;
+    if (dtype == LQP_F32) {
+        FwdLayout<float> L = carve_forward<float>(const_cast<void*>(workspace), B, n, m);
+        if (workspace_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+        src = L.vtrace_area;
+    } else {
+        FwdLayout<double> L = carve_forward<double>(const_cast<void*>(workspace), B, n, m);
+        if (workspace_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+        src = L.vtrace_area;
+    }
+    const int words = 2 * (n_checks < kRing ? n_checks : kRing);
+    hipLaunchKernelGGL(k_copy_trace<>, dim3((words + 255) / 256), dim3(256), 0, st, src, (float*)trace_out, words);
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 

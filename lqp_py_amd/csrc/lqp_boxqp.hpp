@@ -25,6 +25,17 @@ enum { RP_LB = 1, RP_UB = 2, RP_TIMEOUT = 4, RP_NOTSPD = 8 };
 // per-check counters (uint32 x 4): not-optimal, arrivals, wants-rho, ratio-trigger
 // (NOTOPT and ARRIVE share one aligned 64-bit word: the two-workgroup loop adds to and reads both with ONE atomic)
 enum { CT_NOTOPT = 0, CT_ARRIVE = 1, CT_WANTS = 2, CT_TRIG = 3, CT_WORDS = 4 };
+// verbose=True (reference :289-294: the largest primal and dual error of the batch at every check): non-negative floats order like
+// their bit patterns, so one atomicMax per problem and value does it (first lap of the ring only: the trace holds `ring` checks)
+template <typename T>
+__device__ __forceinline__ void trace_check(unsigned int* __restrict__ vtrace, const int it, const int check_solved, const int ring,
+                                            const T pri, const T dua) {
+    if (!vtrace) return;
+    const int c = it / check_solved;
+    if (c >= ring) return;
+    atomicMax(vtrace + 2 * c, __float_as_uint((float)pri));
+    atomicMax(vtrace + 2 * c + 1, __float_as_uint((float)dua));
+}
 // per-problem scalars
 enum { SC_RHO = 0, SC_PNORM = 1, SC_RATIO = 2, SC_WANTS = 3, SC_PRI = 4, SC_DUA = 5, SC_WORDS = 8 };   // PRI/DUA: errors of the last check
 
@@ -76,6 +87,7 @@ template <typename T> struct FwdParams {
     int* bflags;      // B: RP_LB | RP_UB of problem b (k_fwd_setup)
     int* status;      // ST_WORDS
     unsigned int* counters;   // ring of CT_WORDS per check
+    unsigned int* vtrace;     // nullptr, or [ring][2]: bit patterns of the largest primal / dual error over the batch per check (verbose)
     unsigned long long* xchg; // B * XCHG_WORDS granules: partial-product exchange of the two-workgroup loop (or null)
     unsigned long long* dnx;  // B * dnx_words granules: x-parts of the dense LU-tier loops, lqp_dense.hpp (or null)
     int dnx_words;            // granules per problem (DNX_WORDS, or what the W-workgroup form needs: 2 parities x n elements)
@@ -1581,6 +1593,7 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
                 scal[SC_WANTS] = wants ? T(1) : T(0);
                 scal[SC_PRI] = mv[0];                        // primal / dual error of this check (the NumPy twin returns them)
                 scal[SC_DUA] = mv[1];
+                trace_check(P.vtrace, it, P.check_solved, P.ring, mv[0], mv[1]);
                 unsigned int r1 = 0, r2 = 0;
                 if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
                 if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
@@ -1816,6 +1829,7 @@ __global__ __launch_bounds__(256) void k_admm_loop_small(const FwdParams<float> 
                 scal[SC_WANTS] = wants ? T(1) : T(0);
                 scal[SC_PRI] = mv[0];
                 scal[SC_DUA] = mv[1];
+                trace_check(P.vtrace, it, P.check_solved, P.ring, mv[0], mv[1]);
                 unsigned int r1 = 0, r2 = 0;
                 if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
                 if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
@@ -2243,6 +2257,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
                     scal[SC_WANTS] = wants ? T(1) : T(0);
                     scal[SC_PRI] = mv[0];
                     scal[SC_DUA] = mv[1];
+                    trace_check(P.vtrace, it, P.check_solved, P.ring, mv[0], mv[1]);
                     if (wants) atomicAdd(ct + CT_WANTS, 1u);
                     if (trig) atomicAdd(ct + CT_TRIG, 1u);
                     atomicAdd((unsigned long long*)ct, (1ull << 32) | (solved ? 0ull : 1ull));   // {not optimal, arrival}
@@ -2346,6 +2361,12 @@ __global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, con
 }
 
 // primal / dual error of the last convergence check, per problem (lqp_boxqp_last_residuals)
+// the check trace of a verbose solve (trace_check): bit patterns -> float32 in the caller's buffer
+template <int LQP_ANY = 0>
+__global__ void k_copy_trace(const unsigned int* __restrict__ vtrace, float* __restrict__ out, const int words) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) out[i] = __uint_as_float(vtrace[i]);
+}
 template <typename T>
 __global__ void k_copy_residuals(const T* __restrict__ scal, T* __restrict__ pri, T* __restrict__ dua, const int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

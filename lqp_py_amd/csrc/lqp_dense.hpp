@@ -412,6 +412,7 @@ __global__ __launch_bounds__(DENSE_NT) void k_admm_loop_dense(const FwdParams<T>
                     scal[SC_WANTS] = wants ? T(1) : T(0);
                     scal[SC_PRI] = mv[0];
                     scal[SC_DUA] = mv[1];
+                    trace_check(P.vtrace, it, P.check_solved, P.ring, mv[0], mv[1]);
                     if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
                     if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
                 }
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(DENSEW_NT) void k_admm_loop_dense_w(const FwdParams
                     scal[SC_WANTS] = wants ? T(1) : T(0);
                     scal[SC_PRI] = mv[0];
                     scal[SC_DUA] = mv[1];
+                    trace_check(P.vtrace, it, P.check_solved, P.ring, mv[0], mv[1]);
                     if (wants) r1 = atomicAdd(ct + CT_WANTS, 1u);
                     if (trig) r2 = atomicAdd(ct + CT_TRIG, 1u);
                 }

@@ -763,11 +763,14 @@ __device__ __forceinline__ void wg_lu_factor2(T* __restrict__ A, const int N, co
         __syncthreads();
         LU2_STAMP(6);
     }
+    // One word, two writers: a time-out (-7) must survive whatever the other workgroup stores afterwards -- atomicMin for it, a
+    // compare-exchange from 0 for the index of a zero pivot.  (Workgroup 0 cleared the word when it started; a
+    // workgroup 1 that had given up BEFORE that start leaves workgroup 0 without its panels: it times out itself.)
     if (tid == 0 && me == 0) {
-        if (cnt[2]) *info = -7;                    // the partner never arrived (should never happen)
-        else if (cnt[1] != 0) *info = cnt[1];
+        if (cnt[2]) atomicMin(info, -7);           // the partner never arrived (should never happen)
+        else if (cnt[1] != 0) atomicCAS(info, 0, cnt[1]);
     }
-    if (tid == 0 && me == 1 && cnt[2]) *info = -7;
+    if (tid == 0 && me == 1 && cnt[2]) atomicMin(info, -7);
     if (dbg_on && tid == 0 && me == 0) {
         dbt[7] = clock64() - dt_all;
         dbt[11] = xlocal ? 1 : 0;

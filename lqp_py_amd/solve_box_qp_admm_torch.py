@@ -274,8 +274,9 @@ def torch_qp_int_grads_admm(x, lams, nus, dx, dlam, dnu, any_lb, any_ub):
 # ---------------------------------------------------------------------------
 def _finite_bounds(lb, ub):
     """(any_lb, any_ub): global over the whole batch, as in the reference (:33-34, :129-130) -- two reductions and a
-    host round trip.  Only the cold paths (``unroll``, ``backward='kkt'``, the first un-synchronised call of a
-    process) use it; the layer itself learns the answer from the device (see _forward_solve)."""
+    host round trip.  Only the cold paths use it (``unroll``, ``backward='kkt'``, the FIRST un-synchronised call with a
+    given control -- a module, or a plain dict with settings not seen before); the layer itself learns the answer from the
+    device (see _forward_solve)."""
     flags = torch.stack((torch.max(lb) > -_INF, torch.min(ub) < _INF)).tolist()
     return bool(flags[0]), bool(flags[1])
 
@@ -294,13 +295,41 @@ _seen_by_module = weakref.WeakKeyDictionary()
 _seen_by_dict_id = {}
 
 
+def _same_settings(snap, control):
+    """Does `control` hold what `snap` (a shallow copy taken when the answer was remembered) held?  Tensor values count
+    only by identity."""
+    if len(snap) != len(control):
+        return False
+    for k, v in snap.items():
+        if k not in control:
+            return False
+        w = control[k]
+        if v is w:
+            continue
+        if torch.is_tensor(v) or torch.is_tensor(w):
+            return False
+        try:
+            if not (v == w):
+                return False
+        except Exception:
+            return False
+    return True
+
+
 def _assume_any_bound(holder, control, sync=True):
     if holder is not None:
         return _seen_by_module.get(holder)
     # CPython hands the address of a short-lived dict (box_qp_control(...) built per call) to the next one: an entry of the
-    # id table may belong to an unrelated dict.  A call that waits can afford that (it repeats itself on the other
-    # schedule); a pipelined one cannot (wrong schedule, invalid outputs, a late error): it looks at the bounds.
-    return _seen_by_dict_id.get(id(control)) if sync else None
+    # id table may belong to another dict.  The entry therefore carries a copy of the settings it was remembered for and
+    # only answers for a dict that holds the same (ADVICE r5: a pipelined call without a module used to look at the bounds
+    # on every call instead -- two reductions and a host read that drain the stream).  A dict with EQUAL settings at a
+    # recycled address is, for this purpose, the same control: "what the last solve with these settings saw"; a wrong
+    # assumption is caught by the device-side flags as before (repeat / late report).
+    ent = _seen_by_dict_id.get(id(control))
+    if ent is None:
+        return None
+    snap, any_bound = ent
+    return any_bound if _same_settings(snap, control) else None
 
 
 def _remember_any_bound(holder, control, any_bound):
@@ -309,7 +338,7 @@ def _remember_any_bound(holder, control, any_bound):
         return
     if len(_seen_by_dict_id) > 256:
         _seen_by_dict_id.clear()
-    _seen_by_dict_id[id(control)] = bool(any_bound)
+    _seen_by_dict_id[id(control)] = (dict(control), bool(any_bound))
 
 
 def resolve_control(control, n_x):
@@ -490,7 +519,7 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     stream = _lib.current_stream_handle(dev)
     # (private_ws / keep_factor: the unroll mode keeps the solve's workspace -- factor included -- for its backward)
     ws = private_ws if private_ws is not None else _lib.workspace(dev, nbytes, "fwd", stream)
-    ctl.reserved2 = (1 if keep_factor else 0) | (2 if one_call else 0)      # (bit 1: nothing shared between workgroups, see one_call)
+    ctl.reserved2 = (1 if keep_factor else 0) | (2 if one_call else 0) | (4 if r['verbose'] else 0)      # (bit 1: nothing shared between workgroups, see one_call; bit 2: keep the check trace)
     if check_hook is not None:
         # check_hook(counters) all-reduces (SUM) the four uint32 words of a check -- {not optimal, arrivals, wants rho,
         # ratio trigger} -- in place; it gets a tensor VIEW of the workspace at the device address the library names.
@@ -584,7 +613,24 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
     if mutate and not any_bound:
         control['rho'] = owner['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
     if r['verbose']:
-        print(f'iteration = {stats.iters}  (checks: {stats.n_check}, factorisations: {stats.n_factor})')
+        # the reference prints these three lines at every check (:289-294); here the loop runs on the device without the host, so the
+        # trace it kept -- the largest primal and dual error of the batch per check -- is printed once the solve is over
+        n_chk = int(stats.n_check) if stats.n_check >= 0 else int(r['max_iters'] - 1) // int(r['check_solved']) + 1
+        tr = torch.empty((2 * max(min(n_chk, 2048), 1),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.lqp_boxqp_check_trace(_lib.stream_ptr(dev), dt, B, n, m, _lib.ptr(ws), ws.numel(), min(n_chk, 2048), _lib.ptr(tr)),
+                       "check_trace")
+        trh = tr.cpu()
+        it_last = int(stats.iters) if stats.iters >= 0 else None
+        for c in range(min(n_chk, 2048)):
+            it_c = c * int(r['check_solved'])
+            if it_last is not None and it_c > it_last:
+                break
+            if stats.iters < 0 and float(trh[2 * c]) == 0.0 and float(trh[2 * c + 1]) == 0.0 and c > 0:
+                break                                      # (a pipelined call: the checks that never ran left no mark)
+            print(f'iteration = {it_c}')
+            print(f'|| primal_error|| = {float(trh[2 * c]):.10f}')
+            print(f'|| dual_error|| = {float(trh[2 * c + 1]):.10f}')
 
     # type of the returned rho follows the reference: a python number stays one unless
     # adaptive rho rewrote it (:248-250); None becomes a (B,1,1) tensor (:200-203)
@@ -728,11 +774,15 @@ def _fp_backward_run(prep, dl_dz):
         prep['grads'] = (dQ,) + tuple(prep['grads'][1:])
         tail = tail[:11] + (_lib.ptr(dQ),) + tail[12:]                 # (the slot of dQ in lqp_boxqp_backward_fp's argument list)
     prep['ran'] = True                                                 # (the report buffer is this run's to hand back from here on)
-    with _lib.on_device(dev):
-        st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *tail, linsolve, prep['rep'])
-    if st == 3:
-        raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {prep['fail'].value})")
-    _lib.check(st, "torch_solve_box_qp_grad")
+    try:
+        with _lib.on_device(dev):
+            st = prep['lib'].lqp_boxqp_backward_fp(*prep['head'], _lib.ptr(gc), *tail, linsolve, prep['rep'])
+        if st == 3:
+            raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp_grad: the input matrix is singular (batch index {prep['fail'].value})")
+        _lib.check(st, "torch_solve_box_qp_grad")
+    except Exception:
+        _lib.pinned_release(report)     # (a failed call: its pinned report goes back -- quarantined while a queued kernel may still write it)
+        raise
     try:
         _lib.poll_errors()              # (errors of earlier calls; this call's own report is queued behind the poll)
     finally:

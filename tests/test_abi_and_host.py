@@ -254,3 +254,34 @@ def test_report_buffer_quarantine():
     finally:
         _lib._pinned_free.clear(); _lib._pinned_free.update(saved_free)
         del _lib._pinned_quarantine[:]; _lib._pinned_quarantine.extend(saved_q)
+
+
+def test_bound_assumption_remembered_for_plain_dicts():
+    """a pipelined call made with a plain control dict (no nn.Module to key on) used to look at the bounds on EVERY call
+    (two reductions and a host read: the stream drained).  The id-keyed table now carries a copy of the settings it answered for and
+    only answers for a dict that holds the same: a recycled address with other settings is a miss, equal settings are a hit,
+    tensor values count by identity, and nothing is written into the caller's dict."""
+    import torch
+    from lqp_py_amd import solve_box_qp_admm_torch as S
+    S._seen_by_dict_id.clear()
+    c = dict(eps_abs=1e-5, eps_rel=1e-5, sync=False)
+    assert S._assume_any_bound(None, c, sync=False) is None
+    S._remember_any_bound(None, c, True)
+    assert S._assume_any_bound(None, c, sync=False) is True and S._assume_any_bound(None, c, sync=True) is True
+    assert set(c) == {"eps_abs", "eps_rel", "sync"}                      # the caller's dict stays clean
+    c["eps_abs"] = 1e-3                                                   # the same object, other settings: not the remembered control
+    assert S._assume_any_bound(None, c, sync=False) is None
+    c["eps_abs"] = 1e-5
+    assert S._assume_any_bound(None, c, sync=False) is True
+    # an entry left under a recycled address by ANOTHER dict
+    other = dict(rho=1.0)
+    S._seen_by_dict_id[id(other)] = S._seen_by_dict_id.pop(id(c))
+    assert S._assume_any_bound(None, other, sync=False) is None
+    # tensor-valued settings: by identity only
+    t = torch.ones(3, 1, 1)
+    d = dict(rho=t)
+    S._remember_any_bound(None, d, False)
+    assert S._assume_any_bound(None, d, sync=False) is False
+    d["rho"] = torch.ones(3, 1, 1)
+    assert S._assume_any_bound(None, d, sync=False) is None
+    S._seen_by_dict_id.clear()

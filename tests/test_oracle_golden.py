@@ -145,6 +145,21 @@ def test_g11_hard_distribution_fp64():
         close(t, g[nm], 1e-7, 1e-7)
 
 
+def test_g18_hard_distribution_fp64_at_the_benched_size():
+    """G18 = SURVEY 8(c)'s G11 at its own size (n = 250, m = 16, seeds 0..127, float64): the oracle against the reference's run."""
+    g = load_golden("g18_hard_f64_n250_m16")
+    Q, p, A, b, lb, ub = O.create_hard_qp_data(250, 0.85, list(range(128)))
+    sol = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+    assert sol["iter"] == g["iter"] == 60
+    for k in ("x", "u", "nus", "rho"):
+        close(sol[k], g[k], 1e-9, 1e-9)
+    grads = O.solve_box_qp_grad(g["cot"], sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
+    for nm in ("dp", "db", "dlb", "dub"):
+        close(grads[GRADS.index(nm)], g[nm], 1e-7, 1e-7)
+    close(grads[2][:8], g["dA"], 1e-7, 1e-7)
+    close(torch.linalg.matrix_norm(grads[0]), g["dQ_fro"], 1e-7, 1e-7)
+
+
 def test_kkt_conditions_known_answer():
     """Independent of the reference: returned (x, lams, nus) satisfy the KKT system."""
     Q, p, A, b, lb, ub = O.create_qp_data(40, 6, seed=21, dtype=torch.float64)
