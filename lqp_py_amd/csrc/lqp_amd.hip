@@ -174,6 +174,7 @@ struct Knobs {
     int spd_ptasks;            // LQP_SPD_PTASKS
     int spd_resident;          // LQP_SPD_RESIDENT
     int spd_resident4;         // LQP_SPD_RESIDENT4
+    int hot_past;              // LQP_HOT_PAST: the persistent two-workgroup loop runs on past rho events that change nothing
     int spd_turns;             // LQP_SPD_TURNS: more matrices than half the CUs -> the resident sweep anyway, its pairs taking turns on the chip
     int spd_f16;               // LQP_SPD_F16: the resident sweep's panel products on the float16 matrix pipe (two-half operands); 0: float32 matrix instructions
     int spd_split;             // LQP_SPD_SPLIT
@@ -227,6 +228,7 @@ Knobs read_knobs() {
     k.spd_resident4 = env_int("LQP_SPD_RESIDENT4", 1);
     k.spd_f16 = env_int("LQP_SPD_F16", 1);
     k.spd_turns = env_int("LQP_SPD_TURNS", 1);
+    k.hot_past = env_int("LQP_HOT_PAST", 1);
     k.spd_split = env_int("LQP_SPD_SPLIT", -1);
     k.spec_launches = env_int("LQP_SPEC_LAUNCHES", 6);
     k.split2 = env_int("LQP_SPLIT2", 1);
@@ -1055,6 +1057,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             int it = 0;
             const bool tail_epilogue = knobs().tail_epilogue != 0;
             bool epilogue_done = false;
+            bool resume_next = false;       // the next continuation launch starts where the hot kernel says it stopped
             while (it < max_iters) {
                 // the adaptive-rho step of iteration `it` runs as the prologue of the continuation kernel
                 bool event = ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter;
@@ -1068,7 +1071,13 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     event = false;
                 }
                 int e = max_iters;
-                if (ctl->adaptive_rho && !((spd || inkernel_refactor) && it > 0)) {      // (the continuation kernel walks through its events itself)
+                // (round 6) the two-workgroup loop does not stop at the first iteration at which rho MAY be adapted: it looks at the
+                // counters of the check before and only hands over to the continuation kernel when the event changes something
+                // (FwdParams::hot_past).  Its range is the whole solve; the continuation launch is enqueued from the first event
+                // iteration on and finds its real starting point in status[ST_RESUME].
+                const bool hot_past = it == 0 && loop_split && spd && inkernel_refactor && ctl->adaptive_rho && knobs().hot_past != 0 &&
+                                      ar_iter < ctl->adaptive_rho_max_iter && ar_iter < max_iters;
+                if (ctl->adaptive_rho && !((spd || inkernel_refactor) && it > 0) && !hot_past) {      // (the continuation kernel walks through its events itself)
                     const int a = (it / ar_iter + 1) * ar_iter;
                     if (a < ctl->adaptive_rho_max_iter) e = std::min(e, a);
                 }
@@ -1088,13 +1097,18 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 const int prev_slot = it > 0 ? ((it - 1) / check) % kRing : -1;
                 bool last_tail = false;
                 if (it == 0) {
+                    P.hot_past = hot_past ? 1 : 0;
                     launch_hot(it, e, (int)(c_first % kRing), prev_slot, 1);
+                    resume_next = hot_past;
+                    if (hot_past) e = ar_iter;          // (the continuation launch below is enqueued for [first event, ...): see above)
                 } else {
                     // the last continuation launch ends with the epilogue (one launch and its boundary less)
                     last_tail = e >= max_iters && tail_epilogue;
                     ProfScope ps(st, PC_LOOP_TAIL);
                     hipLaunchKernelGGL(tail_fn, dim3(B), dim3(LQP_NT), tail_lds, st,
-                                       P, it, e, (int)(c_first % kRing), prev_slot, ((event || spd || inkernel_refactor) ? 3 : 1) | (last_tail ? 4 : 0));
+                                       P, it, e, (int)(c_first % kRing), prev_slot,
+                                       ((event || spd || inkernel_refactor) ? 3 : 1) | (last_tail ? 4 : 0) | (resume_next ? 8 : 0));
+                    resume_next = false;
                 }
                 ++n_launch;
                 it = e;

@@ -18,6 +18,7 @@ enum { ST_DONE = 0, ST_FINAL_ITER = 1, ST_GATE = 2, ST_NFACTOR = 3, ST_RHO_UPDAT
        ST_VOTE = 8,      // 4 words: {ranks leaving the symmetric path, ranks with a singular KKT matrix, -, -} (strict global stop)
        ST_ANY_LB = 12, ST_ANY_UB = 13,      // some lower / upper bound of the batch is finite (:129-130): the per-problem
                                             // answers of k_fwd_setup (FwdParams::bflags), OR-ed by the forward's last kernel
+       ST_RESUME = 14,   // the iteration at which the hot two-workgroup loop handed over to the continuation kernel (FwdParams::hot_past)
        ST_WORDS = 16 };
 // host report (lqp_boxqp_ctrl.host_report): [ST_WORDS status words as workgroup 0 of the forward's last kernel sees them |
 // B info words | B flag words], written straight into pinned host memory by that kernel
@@ -58,6 +59,9 @@ template <typename T> struct FwdParams {
     int spd;                             // 1: symmetric-inverse path (no KKT matrix M is assembled)
     int qs_lazy;                         // 1: the scaled matrix Qs is not stored; its readers compute (D_i Q_ij) D_j
     int eq_in_loop;                      // 1: k_admm_loop_split applies the equality correction to its register blocks (no k_spd_end)
+    int hot_past;                        // 1: the persistent two-workgroup loop runs on PAST the iterations at which the reference may adapt
+                                         //    rho (:237) as long as the counters of the check before say "nothing to update", leaves at one
+                                         //    that does and names it in status[ST_RESUME]; the continuation launch starts there
     int split_seg;                       // 1: k_admm_loop_split launched once per check segment for a batch LARGER than half the CUs (the
                                          //    pairs take their turns on the chip): workgroups 16 g + x and 16 g + 8 + x share problem 8 g + x
                                          //    (same XCD, neighbours in its dispatch queue), no verdict inside the kernel
@@ -1331,6 +1335,9 @@ __device__ __forceinline__ void fwd_finish(const FwdParams<T>& P, const int b) {
 // event inside [it0, it1), segment by segment.  Only this cold variant carries the factorisation code; the first
 // (hot) launch stays lean.
 // ---------------------------------------------------------------------------
+template <typename T, bool RES, bool TAIL, int NT, bool SYM>
+__device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int it0, const int it1, int ctr_base, int prev_slot,
+                                                    const int persistent, char* smem);
 template <typename T, bool RES, bool TAIL, int NT, bool SYM = false>
 __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int it0, const int it1,
                                                const int ctr_base,       // counter slot of check it0 / check
@@ -1340,6 +1347,25 @@ __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // every problem stopped at an earlier check -> nothing to do (break at :312)
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    admm_loop_body_from<T, RES, TAIL, NT, SYM>(P, it0, it1, ctr_base, prev_slot, persistent, smem);
+}
+template <typename T, bool RES, bool TAIL, int NT, bool SYM>
+__device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int it0, const int it1, int ctr_base, int prev_slot,
+                                                    const int persistent, char* smem) {
+    const int b = blockIdx.x, n = P.n, m = P.m, N = P.N, Np = P.Np, K = P.K;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if constexpr (TAIL) {
+        // persistent & 8: the hot two-workgroup loop ran past the first possible rho event (FwdParams::hot_past) and names the
+        // iteration at which it stopped -- an event that changes something, or the end of its range
+        if (persistent & 8) {
+            const int r = __builtin_amdgcn_readfirstlane(P.status[ST_RESUME]);
+            if (r > 0) {
+                it0 = r;
+                ctr_base = ((r + P.check_solved - 1) / P.check_solved) % P.ring;
+                prev_slot = ((r - 1) / P.check_solved) % P.ring;
+            }
+        }
+    }
     if (prev_slot >= 0) {
         if (__hip_atomic_load(P.counters + (size_t)prev_slot * CT_WORDS + CT_NOTOPT, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -2275,7 +2301,33 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
     };
 
     int left = 0;
-    for (int it = it0; it < it1 && !left;) {
+    int it = it0;
+    for (; it < it1 && !left;) {
+        if (P.hot_past && P.adaptive_rho && it > it0 && it % P.ar_iter == 0 && it < P.ar_max) {
+            // An iteration at which the reference may adapt rho (:237-246).  Whether anything changes is decided by the check
+            // BEFORE it -- any(do_rho_update) and the ratio test, both over the whole batch: the counters of that check, complete
+            // once every problem has arrived.  Nothing to update: run on in this kernel (a solve that never adapts rho stays on the
+            // register-resident loop: 3 us per iteration instead of the continuation kernel's 14).  Otherwise leave; the
+            // continuation launch takes over at this iteration (status[ST_RESUME]) and begins with the event.
+            if (tid == 0) {
+                const unsigned int* ce = P.counters + (size_t)(((it - 1) / P.check_solved) % P.ring) * CT_WORDS;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned long long cw;
+                while ((unsigned int)((cw = __hip_atomic_load((const unsigned long long*)ce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < (unsigned int)P.B) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {      // 2 s: give up, results are flagged
+                        __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                const bool fire = (unsigned int)cw != 0u &&
+                                  __hip_atomic_load(ce + CT_WANTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+                                  __hip_atomic_load(ce + CT_TRIG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+                flags[3] = fire ? 1 : 0;
+            }
+            __syncthreads();
+            if (flags[3]) break;
+        }
         const bool check = (it % P.check_solved) == 0;
         if (check || it + 1 == it1) {
             left = iterate(std::true_type(), it, check);
@@ -2305,6 +2357,7 @@ __global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P
             __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (P.hot_past && blockIdx.x == 0 && tid == 0) P.status[ST_RESUME] = it;      // (where the continuation launch goes on)
     if (part_id == 0) {
         for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xs[i]; }
         for (int r = tid; r < m; r += NT) V.nu[r] = nus_l[r];

@@ -16,15 +16,18 @@ cases = [("eps 1e-5", dict(eps_abs=1e-5, eps_rel=1e-5), inp),
          ("rho = 0.01 (adapts)", dict(eps_abs=1e-5, eps_rel=1e-5, rho=0.01), inp)]
 for name, kw, data in cases:
     ctl = dict(L.box_qp_control(**kw), sync=False)
-    for _ in range(3): L.torch_solve_box_qp(*data, dict(ctl))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10): sol = L.torch_solve_box_qp(*data, dict(ctl))
+    layer = L.SolveBoxQP(control=ctl)          # (a module: what it learnt about the bounds is remembered between calls, no host look)
+    with torch.no_grad():
+        for _ in range(3): layer(*data)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10): layer(*data)
     torch.cuda.synchronize(); L.synchronize()
     dt = (time.perf_counter() - t0) / 10
     st = L.solve_box_qp_admm_torch.last_forward_status(dev)
     _lib.profile(enable=True, reset=True)
-    for _ in range(3): L.torch_solve_box_qp(*data, dict(ctl))
+    with torch.no_grad():
+        for _ in range(3): layer(*data)
     torch.cuda.synchronize()
     pr = {k: (round(v[0] / 3, 3), v[1] // 3) for k, v in _lib.profile().items() if v[1]}
     _lib.profile(enable=False)
