@@ -149,7 +149,8 @@ def profile_twin(workload):
            "dominant_kernel_traffic_bytes_per_launch": tr.get(name, {}).get("hbm_bytes_per_launch_corrected")}
     cnt = sq.get(name) or sq.get("void " + name) or {}
     g = lambda k: cnt.get(k, {}).get("mean")
-    for key, peak, unit in (("SQ_INSTS_VALU_MFMA_MOPS_F32", MFMA_F32_PEAK_TFLOPS, "f32"), ("SQ_INSTS_VALU_MFMA_MOPS_F64", MFMA_F64_PEAK_TFLOPS, "f64")):
+    for key, peak, unit in (("SQ_INSTS_VALU_MFMA_MOPS_F32", MFMA_F32_PEAK_TFLOPS, "f32"), ("SQ_INSTS_VALU_MFMA_MOPS_F64", MFMA_F64_PEAK_TFLOPS, "f64"),
+                            ("SQ_INSTS_VALU_MFMA_MOPS_F16", MFMA_F16_PEAK_TFLOPS, "f16")):
         if g(key):
             tfl = g(key) * 512 / (float(dom["AverageNs"]) * 1e-9) / 1e12          # one MOP = 512 flop (a 32x32x2 f32 instruction: 8 MOPs, 4096 flop)
             out[f"dominant_kernel_mfma_{unit}_TFLOPs_issued"] = round(tfl, 2)

@@ -175,6 +175,7 @@ struct Knobs {
     int spd_resident;          // LQP_SPD_RESIDENT
     int spd_resident4;         // LQP_SPD_RESIDENT4
     int hot_past;              // LQP_HOT_PAST: the persistent two-workgroup loop runs on past rho events that change nothing
+    int bwd_f16;               // LQP_BWD_F16: the backward's look-ahead Cholesky with its tile products on the float16 pipe (with LQP_SPD_F16)
     int spd_turns;             // LQP_SPD_TURNS: more matrices than half the CUs -> the resident sweep anyway, its pairs taking turns on the chip
     int spd_f16;               // LQP_SPD_F16: the resident sweep's panel products on the float16 matrix pipe (two-half operands); 0: float32 matrix instructions
     int spd_split;             // LQP_SPD_SPLIT
@@ -228,6 +229,7 @@ Knobs read_knobs() {
     k.spd_resident4 = env_int("LQP_SPD_RESIDENT4", 1);
     k.spd_f16 = env_int("LQP_SPD_F16", 1);
     k.spd_turns = env_int("LQP_SPD_TURNS", 1);
+    k.bwd_f16 = env_int("LQP_BWD_F16", 1);
     k.hot_past = env_int("LQP_HOT_PAST", 1);
     k.spd_split = env_int("LQP_SPD_SPLIT", -1);
     k.spec_launches = env_int("LQP_SPEC_LAUNCHES", 6);
@@ -1439,6 +1441,9 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
                 P.la_maxk = !knobs().bwd_lookahead ? 0 : (Kmax < SPD_MAXK ? Kmax : SPD_MAXK - 1);
             }
             auto chol_fn = nr4 ? k_bwd_chol_solve<4> : k_bwd_chol_solve<0>;
+#if LQP_PIV_MFMA
+            if (knobs().spd_f16 != 0 && knobs().bwd_f16 != 0) chol_fn = nr4 ? k_bwd_chol_solve<4, true> : k_bwd_chol_solve<0, true>;
+#endif
             int r2 = ensure_lds((const void*)chol_fn, lds);
             if (r2) return r2;
             ProfScope ps(st, PC_BWD_CHOL);

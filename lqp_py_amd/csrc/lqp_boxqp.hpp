@@ -2729,7 +2729,8 @@ __host__ __device__ inline int bwd_chol_lds_bytes(int n, int m, int nr = 2) {
 // NRV = 0: the 1 + m solves two right-hand sides at a time (the headline's m = 1: one round); NRV = 4: four at a time, an instance
 // of its own for problems with three or more equality rows (m = 16: five rounds of block-column barriers instead of nine) -- its
 // registers are not the m <= 2 kernel's problem.  The same arithmetic per right-hand side either way.
-template <int NRV = 0>
+// F16 (round 6): the look-ahead factorisation's tile waves on the float16 matrix pipe (wg_chol_factor_la<true>)
+template <int NRV = 0, bool F16 = false>
 __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int b = blockIdx.x, n = P.n, m = P.m, Np = P.Np;
@@ -2742,7 +2743,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     float* rhs = P.rhs + (size_t)b * Np;
     unsigned long long dt0 = P.dbg ? clock64() : 0;
     if (Kb > 0 && P.phase != 2) {
-        if (Kb <= P.la_maxk) wg_chol_factor_la(Ls, Kb, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
+        if (Kb <= P.la_maxk) wg_chol_factor_la<F16>(Ls, Kb, P.info + b, smem, P.dbg ? P.dbg + (size_t)b * 8 : nullptr);
         else if (Kb <= SPD_MAXK) wg_chol_factor(Ls, Kb, P.info + b, smem);
         else wg_chol_factor_big(Ls, Kb, P.info + b, smem);
     }

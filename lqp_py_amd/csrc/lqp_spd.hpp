@@ -2930,6 +2930,11 @@ __device__ __forceinline__ void wg_chol_factor_big(float* __restrict__ Hs, const
 constexpr int CHOL_LA_CHAIN = 4;
 __host__ __device__ inline int chol_la_lds_bytes(int K) { return spd_lds_bytes(K) + 64 + 64 * 64 * 4; }
 
+// F16: the tile waves' products (Y = P W^T, the trailing updates) on the float16 matrix pipe with two-half operands
+// (lqp_f16x2.hpp), as in the resident sweep.  W stays the chain waves' float32 copy (they overwrite it as soon as the tile
+// waves let go): every tile wave builds the six cells of W it multiplies with in its registers; L_ik = Y goes to its block
+// in global memory straight from the accumulators, its split image replaces the panel rows in LDS.
+template <bool F16 = false>
 __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const int K, int* __restrict__ info, char* smem,
                                                   unsigned long long* __restrict__ dbg = nullptr) {
     constexpr int NCH = CHOL_LA_CHAIN, NTW = LQP_NW - NCH, NTT = NTW * 64;
@@ -2956,7 +2961,7 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
             lds_wait_ge(sy + 4, k);                         // W / W^T of step k-1 are no longer read
             if (dbg && tid == 0) { const unsigned long long c1 = clock64(); dbg[4] += c1 - c0; c0 = c1; }
 #if LQP_PIV_MFMA
-            wg_pivot_block_mfma<true>(St, W, WT, pcol, flag, k * 64, sy + 5, k);
+            wg_pivot_block_mfma<true, true, false, F16>(St, W, WT, pcol, flag, k * 64, sy + 5, k, 0.f, false, pcol + 128);
 #else
             wg_pivot_block<NCH, true>(St, W, WT, pcol, flag, k * 64, sy + 0, &gt);
 #endif
@@ -2999,6 +3004,83 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
             lds_wait_ge(sy + 3, k + 1);                     // W / W^T of this step
             if (dbg && tt == 0) { const unsigned long long c1 = clock64(); dbg[6] += c1 - c0; c0 = c1; }
             // ---- Y_i = P_i W^T, in place: a wave owns 32 rows of a panel block and reads nothing else of Y ----
+            [[maybe_unused]] float* const ysc = pcol + 144;           // F16: 1 / scale of the 32-row blocks of Y
+            [[maybe_unused]] char* const Yc = (char*)Y;
+            [[maybe_unused]] const int lane_b = li * F2_ROW + 32 * lh;
+            if constexpr (F16) {
+                float sW, isW;
+                f2_scale_of(tmax((pcol + 128)[1], (pcol + 128)[2]), sW, isW);      // (max |W| from the two chain waves that stored it)
+                for (int task = tw; task < np * 2; task += NTW) {
+                    const int s = task >> 1, qi = task & 1;
+                    // this lane's row of the block: its four cells, in the block's scale
+                    const float* prow = Y + ((size_t)s * 64 + 32 * qi + li) * SPD_LS;
+                    float pv[4][8], mx = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f2_load_cell_f32(prow, c, lh, pv[c]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) mx = tmax(mx, tabs(pv[c][j]));
+                    }
+                    mx = wave_max(mx);
+                    float sP, isP;
+                    f2_scale_of(mx, sP, isP);
+                    F2Cell pb[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pv[c][j] *= sP;
+                        f2_split8(pv[c], pb[c].hi, pb[c].mid);
+                    }
+                    // Y^T = W P^T (the rows of Y across the lanes); W's cells from its float32 rows li (slices 0, 1: lower
+                    // triangular) and 32 + li
+                    f32x16 a0, a1;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float wv[8];
+                        F2Cell wc;
+                        if (c < 2) {
+                            f2_load_cell_f32(W + li * SPD_LS, c, lh, wv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) wv[j] *= sW;
+                            f2_split8(wv, wc.hi, wc.mid);
+                            a0 = f2_mma(wc, pb[c], a0);
+                        }
+                        f2_load_cell_f32(W + (32 + li) * SPD_LS, c, lh, wv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) wv[j] *= sW;
+                        f2_split8(wv, wc.hi, wc.mid);
+                        a1 = f2_mma(wc, pb[c], a1);
+                    }
+                    const float un = isW * isP;
+                    if (lane == 0) ysc[task] = un * 2097152.f;
+                    // L_ik: register q of an accumulator is column 8 (q >> 2) + 4 lh + (q & 3) of its 32-column half, row li
+                    float* dstg = Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK + (32 * qi + li) * 64 + 4 * lh;
+                    char* dstl = Yc + ((size_t)s * 64 + 32 * qi) * F2_ROW + lane_b;
+#pragma unroll
+                    for (int hsel = 0; hsel < 2; ++hsel) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float v[8];
+#pragma unroll
+                            for (int gq = 0; gq < 2; ++gq) {
+                                V4<float> o;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float a = hsel ? a1[8 * c + 4 * gq + e] : a0[8 * c + 4 * gq + e];
+                                    o.v[e] = a * un;
+                                    v[4 * gq + e] = a * 4.76837158203125e-7f;
+                                }
+                                *(V4<float>*)(dstg + 32 * hsel + 8 * (2 * c + gq)) = o;
+                            }
+                            h16x8 hi, mid;
+                            f2_split8(v, hi, mid);
+                            f2_write_cell(dstl + 64 * (2 * hsel + c), hi, mid);
+                        }
+                    }
+                }
+            } else {
             for (int task = tw; task < np * 2; task += NTW) {
                 const int s = task >> 1, qi = task & 1;
                 float* Xp = Y + ((size_t)s * 64 + 32 * qi) * SPD_LS;
@@ -3009,6 +3091,7 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
                     Xp[quad_row(q, lh) * SPD_LS + li] = a0[q];
                     Xp[quad_row(q, lh) * SPD_LS + 32 + li] = a1[q];
                 }
+            }
             }
             lds_group_sync(sy + 1, gt += NTW);              // Y complete, W / W^T free
             if (tt == 0) __hip_atomic_store(sy + 4, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -3028,9 +3111,17 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
 #pragma unroll
                         for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];
                     }
+                    if constexpr (F16) {
+                        const f32x16 acc = f2_quadrant<0, 4>(Yc + ((size_t)si * 64 + 32 * qi) * F2_ROW + lane_b,
+                                                             Yc + ((size_t)sj * 64 + 32 * qj) * F2_ROW + lane_b);
+                        const float un = -(ysc[2 * si + qi] * ysc[2 * sj + qj]);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) cur[q] = __builtin_fmaf(acc[q], un, cur[q]);
+                    } else {
                     const f32x16 acc = spd_quadrant(Y + ((size_t)si * 64 + 32 * qi) * SPD_LS,
                                                     Y + ((size_t)sj * 64 + 32 * qj) * SPD_LS);
                     cur -= acc;
+                    }
                     if (p == 0) {                                      // the next diagonal tile also goes to the chain waves
                         float* Sq = St + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
@@ -3049,10 +3140,12 @@ __device__ __forceinline__ void wg_chol_factor_la(float* __restrict__ Hs, const 
                         for (int q = 0; q < 16; ++q) T0[li * 64 + 32 + quad_row(q, lh)] = cur[q];
                     }
                 }
+                if constexpr (!F16) {              // (F16: L_ik went to its block from the accumulators)
                 for (int s = 0; s < np; ++s) {
                     float* dst = Hs + (size_t)sym_idx(k + 1 + s, k, K) * LQP_BLK;
                     for (int v = tt; v < 1024; v += NTT)
                         *(V4<float>*)(dst + v * 4) = *(const V4<float>*)(Y + ((size_t)s * 64 + (v >> 4)) * SPD_LS + (v & 15) * 4);
+                }
                 }
             }
             lds_group_sync(sy + 1, gt += NTW);              // all tiles of this step are written (the next staging reads them)

@@ -23,6 +23,7 @@ OUT = os.path.join(CSRC, "split")
 
 # group -> predicate on the demangled name; first match wins.  Balanced by measured compile time (seconds at -O3).
 GROUPS = [
+    ("bwd_f", lambda n: re.search(r"k_bwd_chol_solve<\d, true>", n)),
     ("resident_f", lambda n: re.search(r"k_spd_resident<8, 2, true>", n)),
     ("resident_g", lambda n: re.search(r"k_spd_resident<(5|6|7), 2, true>", n)),
     ("resident_h", lambda n: re.search(r"k_spd_resident<\d, \d, true>", n)),
@@ -46,7 +47,6 @@ GROUPS = [
 
 # instances that are not in the built library yet (added since the last single-source build)
 EXTRA = [
-    "void lqp::k_bwd_chol_solve<4>(lqp::BwdParams<float>)",
     "void lqp::k_bwd_gather_rhs<float>(lqp::BwdParams<float>)",
     "void lqp::k_bwd_gather_rhs<double>(lqp::BwdParams<double>)",
     "void lqp::k_report_info<0>(int const*, int*, int)",
@@ -87,6 +87,8 @@ EXTRA = [
 
 # instances a built library may still hold that no longer exist in the sources
 DROP = [
+    "void lqp::k_bwd_chol_solve<0>(lqp::BwdParams<float>)",
+    "void lqp::k_bwd_chol_solve<4>(lqp::BwdParams<float>)",
     "void lqp::k_spd_resident<3, 2>(lqp::FwdParams<float>, int const*)",
     "void lqp::k_spd_resident<4, 2>(lqp::FwdParams<float>, int const*)",
     "void lqp::k_spd_resident<5, 2>(lqp::FwdParams<float>, int const*)",

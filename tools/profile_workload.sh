@@ -12,7 +12,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/k
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $P > $out/fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- $P > $out/write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $out/sq -- $P > $out/sq.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq2 -- $P > $out/sq2.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq2 -- $P > $out/sq2.log 2>&1 || true
 cd $root
 python3 tools/make_traffic_json.py $out/fetch $out/write 3 "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv (separate passes) -- python3 tools/profile_workload.py $wl --steps $steps --warmup $warm" > $out/traffic.json
 python3 tools/pmc_summary.py $out/sq $out/sq2 > $out/pmc_sq_raw.json
