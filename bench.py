@@ -36,8 +36,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 MFMA_F16_PEAK_TFLOPS = 2516.6 # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16: 32 k flop in 32 cycles per SIMD)
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X: fp64 matrix = fp64 vector peak (v_mfma_f64_16x16x4_f64, 64 cycles per SIMD)
 INFINITY_CACHE_BYTES = 256 * 2 ** 20
-TRAFFIC_FILE = "profiles/r05_b_headline_traffic.json"
-PROFILE_TAG = "r05_b"          # profiles/<tag>_<workload>_{run.json,kernel_stats.csv,traffic.json,pmc_sq_raw.json}: tools/profile_workload.sh
+TRAFFIC_FILE = "profiles/r06_b_headline_traffic.json"
+PROFILE_TAG = "r06_b"          # profiles/<tag>_<workload>_{run.json,kernel_stats.csv,traffic.json,pmc_sq_raw.json}: tools/profile_workload.sh
 
 
 def parse():
