@@ -19,13 +19,6 @@
 #pragma once
 #include "lqp_common.hpp"
 
-#ifndef LQP_F16_DB
-#define LQP_F16_DB 0            // operand cells of slice s + 1 requested before the matrix instructions of slice s
-#endif
-#ifndef LQP_F16_PF
-#define LQP_F16_PF 1            // half-tiles of the panel a staging wave keeps in flight
-#endif
-
 namespace lqp {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -87,23 +80,10 @@ __device__ __forceinline__ f32x16 f2_quadrant(const char* __restrict__ xa, const
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    // the cells of slice s + 1 are requested before the three matrix instructions of slice s are issued (left to itself the
-    // compiler reads a slice, waits, multiplies, reads the next: the LDS latency of every slice in the open)
-    F2Cell a = f2_read_cell(xa + 64 * S0), b = f2_read_cell(zb + 64 * S0);
+    // (measured: requesting the cells of slice s + 1 before the instructions of slice s costs the ten-tile waves of the K = 8
+    //  sweep another tile in scratch memory -- 0.295 against 0.280 ms; left to the compiler)
 #pragma unroll
-    for (int s = S0; s < S1; ++s) {
-#if LQP_F16_DB
-        F2Cell an = a, bn = b;
-        if (s + 1 < S1) { an = f2_read_cell(xa + 64 * (s + 1)); bn = f2_read_cell(zb + 64 * (s + 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-        acc = f2_mma(a, b, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        a = an; b = bn;
-#else
-        if (s > S0) { a = f2_read_cell(xa + 64 * s); b = f2_read_cell(zb + 64 * s); }
-        acc = f2_mma(a, b, acc);
-#endif
-    }
+    for (int s = S0; s < S1; ++s) acc = f2_mma(f2_read_cell(xa + 64 * s), f2_read_cell(zb + 64 * s), acc);
     return acc;
 }
 

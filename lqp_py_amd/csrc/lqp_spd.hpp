@@ -43,9 +43,6 @@ __host__ __device__ constexpr int sym_idx(int i, int j, int K) { return j * K - 
 #ifndef LQP_PIV_NB
 #define LQP_PIV_NB 4
 #endif
-#ifndef LQP_F16_EVEN
-#define LQP_F16_EVEN 0          // float16-pipe resident sweep: tiles dealt evenly to the two wave groups (0: 4 / 9 to the pivot block's waves)
-#endif
 constexpr int PIV_NB = LQP_PIV_NB;                            // pivot columns per LDS exchange of the pivot-block elimination
 constexpr int PIV_LDS = 2 * PIV_NB * 64 + 64;        // floats: coefficients [2][PIV_NB][64] | scales [64]
 __host__ __device__ inline int spd_lds_bytes(int K) {
@@ -2014,9 +2011,8 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 
     auto body = [&](auto pivot_tag) {
         constexpr bool PIVOT = decltype(pivot_tag)::value;     // waves 0..3
-        // (F16: an even deal -- the update of a quadrant keeps an accumulator and two slices of operands next to the tiles)
-        constexpr int NA_ = (F16 && LQP_F16_EVEN) ? rs2_max<K, NP>() / 2 : rs2_na<K, NP>();
-        constexpr int NS = PIVOT ? NA_ : rs2_max<K, NP>() - NA_, FIRST = PIVOT ? 0 : NA_;
+        // (F16 with the tiles dealt evenly, 9 / 9 at K = 8: measured, no difference -- 0.280 ms either way)
+        constexpr int NS = PIVOT ? rs2_na<K, NP>() : rs2_nb<K, NP>(), FIRST = PIVOT ? 0 : rs2_na<K, NP>();
         // ---- tiles into registers (accumulator layout: register q of lane l = element (quad_row(q, l>>5), l & 31)) ----
         f32x16 T[NS];
         int ti[NS], tj[NS];
@@ -2365,9 +2361,9 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 float* const yrow_l = Y + r0 * SPD_LS + c8;            // row-major destination
                 float* const ycol_l = Y + c8 * SPD_LS + r0;            // transposed destination
                 if constexpr (F16) {
-                    // ---- straight into the split image of the panel, in the scale of each tile; the loads of four half-tiles in
-                    //      flight (one at a time they cost a trip to the L2 each: 22 k cycles per step, as long as the pivot block) ----
-                    constexpr int NIT = 2 * (K - 1), PF = NIT < LQP_F16_PF ? NIT : LQP_F16_PF;
+                    // ---- straight into the split image of the panel, in the scale of each tile
+                    //      (the maxima of all tiles requested up front: one trip to the L2 instead of one per tile) ----
+                    constexpr int NIT = 2 * (K - 1), PF = 1;      // (half-tiles in flight per staging wave; four: measured slower, 0.31 against 0.28 ms -- registers)
                     const unsigned long long* const mq = (const unsigned long long*)(xb + (size_t)2 * K * LQP_BLK + 64 + (k & 1) * 4 * K);
                     unsigned long long mraw[2 * (K - 1)];
 #pragma unroll
@@ -2516,42 +2512,16 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     f32x16 a0;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) a0[q] = 0.f;
-#if LQP_F16_DB
-                    F2Cell wc = f2_read_cell(wa);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        F2Cell wn = wc;
-                        if (c + 1 < 2) wn = f2_read_cell(wa + 64 * (c + 1));
-                        __builtin_amdgcn_sched_barrier(0);
-                        a0 = f2_mma(wc, pbl[c], a0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        wc = wn;
-                    }
-#else
 #pragma unroll
                     for (int c = 0; c < 2; ++c) a0 = f2_mma(f2_read_cell(wa + 64 * c), pbl[c], a0);
-#endif
                     store_half(a0, 0);
                 }
                 {
                     f32x16 a1;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) a1[q] = 0.f;
-#if LQP_F16_DB
-                    F2Cell wc = f2_read_cell(wa + 32 * F2_ROW);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        F2Cell wn = wc;
-                        if (c + 1 < 4) wn = f2_read_cell(wa + 32 * F2_ROW + 64 * (c + 1));
-                        __builtin_amdgcn_sched_barrier(0);
-                        a1 = f2_mma(wc, pbl[c], a1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        wc = wn;
-                    }
-#else
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a1 = f2_mma(f2_read_cell(wa + 32 * F2_ROW + 64 * c), pbl[c], a1);
-#endif
                     store_half(a1, 2);
                 }
             };
