@@ -175,6 +175,7 @@ struct Knobs {
     int spd_resident;          // LQP_SPD_RESIDENT
     int spd_resident4;         // LQP_SPD_RESIDENT4
     int hot_past;              // LQP_HOT_PAST: the persistent two-workgroup loop runs on past rho events that change nothing
+    int hot_rounds;            // LQP_HOT_ROUNDS: with a GIVEN rho, rounds of {rho update, gated refactorisation, hot loop again} enqueued behind the first hot launch
     int bwd_f16;               // LQP_BWD_F16: the backward's look-ahead Cholesky with its tile products on the float16 pipe (with LQP_SPD_F16)
     int spd_turns;             // LQP_SPD_TURNS: more matrices than half the CUs -> the resident sweep anyway, its pairs taking turns on the chip
     int spd_f16;               // LQP_SPD_F16: the resident sweep's panel products on the float16 matrix pipe (two-half operands); 0: float32 matrix instructions
@@ -231,6 +232,7 @@ Knobs read_knobs() {
     k.spd_turns = env_int("LQP_SPD_TURNS", 1);
     k.bwd_f16 = env_int("LQP_BWD_F16", 1);
     k.hot_past = env_int("LQP_HOT_PAST", 1);
+    k.hot_rounds = env_int("LQP_HOT_ROUNDS", 2);
     k.spd_split = env_int("LQP_SPD_SPLIT", -1);
     k.spec_launches = env_int("LQP_SPEC_LAUNCHES", 6);
     k.split2 = env_int("LQP_SPLIT2", 1);
@@ -1066,7 +1068,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                 if (event && !inkernel_refactor) {      // f64 / symmetric path: separate gated kernels
                     const int last_slot = ((it - 1) / check) % kRing;
                     { ProfScope ps(st, PC_RHO);
-                      hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
+                      hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot, 0); }
                     ++n_launch;
                     rc = factor_step(P.status + ST_GATE);
                     if (rc) return rc;
@@ -1102,7 +1104,30 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     P.hot_past = hot_past ? 1 : 0;
                     launch_hot(it, e, (int)(c_first % kRing), prev_slot, 1);
                     resume_next = hot_past;
-                    if (hot_past) e = ar_iter;          // (the continuation launch below is enqueued for [first event, ...): see above)
+                    if (hot_past) {
+                        // A GIVEN rho is the case in which the adaptation does fire (`rho = 0.01`: three factorisations, 281 iterations,
+                        // 4.5 ms with everything behind iteration 100 on the continuation kernel).  Enqueue a few rounds of {the event
+                        // on the gated kernels of the refactorisation, the hot loop again from where it stopped}: each costs a solve that
+                        // is over ~5 launches that leave at once -- which is why the automatic rho (it practically never adapts) gets none.
+                        const int rounds = ctl->rho_mode != 0 ? knobs().hot_rounds : 0;
+                        for (int rd = 0; rd < rounds; ++rd) {
+                            { ProfScope ps(st, PC_RHO);
+                              hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, -1, max_iters); }
+                            ++n_launch;
+                            rc = factor_step(P.status + ST_GATE);
+                            if (rc) return rc;
+                            if constexpr (sizeof(T) == 4) {
+                                FwdParams<float> Pr = P;
+                                Pr.hot_resume = 1;
+                                Pr.eq_in_loop = 0;          // (k_spd_end has corrected the new blocks in global memory)
+                                ProfScope ps(st, PC_LOOP);
+                                hipLaunchKernelGGL(split_fn, dim3(shared_grid(B, loop_np)), dim3(split_nt), split_lds, st, Pr, ar_iter, e,
+                                                   (int)(((ar_iter + check - 1) / check) % kRing));
+                                ++n_launch;
+                            }
+                        }
+                        e = ar_iter;          // (the continuation launch below is enqueued for [first event, ...): see above)
+                    }
                 } else {
                     // the last continuation launch ends with the epilogue (one launch and its boundary less)
                     last_tail = e >= max_iters && tail_epilogue;
@@ -1198,7 +1223,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             if (!tail_events && ctl->adaptive_rho && it > 0 && it % ar_iter == 0 && it < ctl->adaptive_rho_max_iter) {
                 const int last_slot = ((it - 1) / check) % kRing;
                 { ProfScope ps(st, PC_RHO);
-                  hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot); }
+                  hipLaunchKernelGGL(k_rho_update<T>, dim3(B), dim3(LQP_NT), 0, st, P, last_slot, 0); }
                 ++n_launch;
                 rc = factor_step(P.status + ST_GATE);
                 if (rc) return rc;

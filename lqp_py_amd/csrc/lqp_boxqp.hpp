@@ -62,6 +62,8 @@ template <typename T> struct FwdParams {
     int hot_past;                        // 1: the persistent two-workgroup loop runs on PAST the iterations at which the reference may adapt
                                          //    rho (:237) as long as the counters of the check before say "nothing to update", leaves at one
                                          //    that does and names it in status[ST_RESUME]; the continuation launch starts there
+    int hot_resume;                      // 1: this launch of the persistent two-workgroup loop starts at status[ST_RESUME] (behind a rho event
+                                         //    the library handled between two launches: k_rho_update + gated refactorisation)
     int split_seg;                       // 1: k_admm_loop_split launched once per check segment for a batch LARGER than half the CUs (the
                                          //    pairs take their turns on the chip): workgroups 16 g + x and 16 g + 8 + x share problem 8 g + x
                                          //    (same XCD, neighbours in its dispatch queue), no verdict inside the kernel
@@ -1886,10 +1888,17 @@ __global__ __launch_bounds__(256) void k_admm_loop_small(const FwdParams<float> 
 // NP = 4 (batches up to a quarter of the CUs): one column pair per workgroup, every partial product published once and
 // fetched by the three others; the sum runs over the parts in their order on every workgroup (identical iterates).
 template <int KS, int NT, bool DBG = false, int NP = 2>
-__global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P, const int it0, const int it1,
-                                                        const int ctr_base) {
+__global__ __launch_bounds__(NT) void k_admm_loop_split(const FwdParams<float> P, const int it0_in, const int it1,
+                                                        const int ctr_base_in) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
     typedef float T;
+    int it0 = it0_in, ctr_base = ctr_base_in;
+    if (P.hot_resume) {            // (a later round of the hot loop: it goes on where the round before stopped)
+        const int r = __builtin_amdgcn_readfirstlane(P.status[ST_RESUME]);
+        if (r <= 0) return;
+        it0 = r;
+        ctr_base = ((r + P.check_solved - 1) / P.check_solved) % P.ring;
+    }
     constexpr int NWV = NT / 64, Ks = KS, Nps = KS * LQP_NB, rl = split_lds_blocks<NT, NP>(KS);
     constexpr int XPART = SPD_MAXK * LQP_NB, XPAR = NP * XPART;      // granules of one part / of one parity of the exchange
     // (split_seg: NP == 2)
@@ -2386,11 +2395,20 @@ __global__ void k_check_done(int* status, const unsigned int* counters, const in
 // LU + pack launches that follow.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, const int last_slot) {
+__global__ __launch_bounds__(LQP_NT) void k_rho_update(const FwdParams<T> P, int last_slot, const int max_it = 0) {
     const int b = blockIdx.x, n = P.n, m = P.m;
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         if (b == 0 && threadIdx.x == 0) P.status[ST_GATE] = 0;
         return;
+    }
+    if (last_slot < 0) {
+        // the event iteration is where the hot loop stopped (FwdParams::hot_past): an event only if it left FOR one
+        const int r = P.status[ST_RESUME];
+        if (!(r > 0 && r % P.ar_iter == 0 && r < P.ar_max && r < max_it)) {
+            if (b == 0 && threadIdx.x == 0) P.status[ST_GATE] = 0;
+            return;
+        }
+        last_slot = ((r - 1) / P.check_solved) % P.ring;
     }
     const unsigned int* ct = P.counters + (size_t)last_slot * CT_WORDS;
     const bool all_done = ct[CT_NOTOPT] == 0;

@@ -1836,6 +1836,37 @@ def test_equality_correction_in_the_loop_kernel(dev, monkeypatch, n, B, m):
         assert float((A.to(dev) @ out["1"]["x"] - b.to(dev)).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("n,B,m,rho,qscale", [(330, 16, 1, 0.01, 1.0), (500, 8, 1, 0.01, 1.0), (200, 6, 2, 100.0, 50.0)])
+def test_hot_loop_goes_on_behind_rho_events(dev, monkeypatch, n, B, m, rho, qscale):
+    """Round 6: with a GIVEN rho (the case in which the reference's adaptation, :237-256, does fire) the library enqueues rounds of
+    {the event on the gated kernels of the refactorisation, the register-resident two-workgroup loop again from where it stopped}
+    behind the first hot launch (LQP_HOT_ROUNDS, default 2), so that the iterations behind an event no longer run on the one-workgroup
+    continuation kernel.  Against LQP_HOT_ROUNDS=0 (everything behind iteration 100 on the continuation kernel) and the oracle: the same
+    number of factorisations, the same iteration count (the stop is decided at 1e-5; two summation orders), x within the tolerance."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + m, with_eq=False)
+    Q = Q * qscale
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g)
+    b = 0.1 * torch.randn(B, m, 1, generator=g)
+    kw = dict(rho=rho, scale=(qscale == 1.0), **TOL)
+    out = {}
+    for rounds in ("2", "0"):
+        monkeypatch.setenv("LQP_HOT_ROUNDS", rounds)
+        out[rounds], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(linsolve="spd", **kw))
+        st = out[rounds]["_stats"]
+        assert st["linsolve_used"] == 2 and st["loop_workgroups"] in (2, 4), st
+    ref = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**kw))
+    ref64 = O.solve_box_qp(*[t.double() for t in (Q, p, A, b, lb, ub)], O.make_control(**kw))
+    s2, s0 = out["2"], out["0"]
+    assert s2["_stats"]["n_factor"] >= 2 and s2["_stats"]["n_factor"] == s0["_stats"]["n_factor"], (s2["_stats"], s0["_stats"])
+    assert s2["_stats"]["n_launch"] > s0["_stats"]["n_launch"]                   # (the rounds were enqueued)
+    assert s2["iter"] == s0["iter"] or min(abs(s2["iter"] - r["iter"]) for r in (ref, ref64)) <= 20, (s2["iter"], s0["iter"], ref["iter"], ref64["iter"])
+    scale_x = max(1.0, float(ref64["x"].abs().max()))
+    P.record(f"hot_rounds_n{n}_B{B}", "x", err(s2["x"], ref64["x"]), scale_x, one_workgroup_tail_vs_fp64=err(s0["x"], ref64["x"]))
+    assert err(s2["x"], s0["x"]) < 5e-4 * scale_x and err(s2["x"], ref64["x"]) < 5e-4 * scale_x
+    assert float((A.to(dev) @ s2["x"] - b.to(dev)).abs().max()) < 1e-3
+
+
 def test_continuation_launch_finds_corrected_blocks(dev):
     """The two-workgroup loop kernel applies the equality correction to its register blocks; when the loop has to go on in
     a continuation launch (here: tolerances that are never met, more iterations than one launch may hold, no adaptive rho
