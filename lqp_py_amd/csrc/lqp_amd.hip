@@ -176,6 +176,7 @@ struct Knobs {
     int spd_resident4;         // LQP_SPD_RESIDENT4
     int hot_past;              // LQP_HOT_PAST: the persistent two-workgroup loop runs on past rho events that change nothing
     int hot_rounds;            // LQP_HOT_ROUNDS: with a GIVEN rho, rounds of {rho update, gated refactorisation, hot loop again} enqueued behind the first hot launch
+    int bwd_equil;             // LQP_BWD_EQUIL: power-of-two symmetric equilibration of the Cholesky backward's free-set block
     int bwd_f16;               // LQP_BWD_F16: the backward's look-ahead Cholesky with its tile products on the float16 pipe (with LQP_SPD_F16)
     int spd_turns;             // LQP_SPD_TURNS: more matrices than half the CUs -> the resident sweep anyway, its pairs taking turns on the chip
     int spd_f16;               // LQP_SPD_F16: the resident sweep's panel products on the float16 matrix pipe (two-half operands); 0: float32 matrix instructions
@@ -231,6 +232,7 @@ Knobs read_knobs() {
     k.spd_f16 = env_int("LQP_SPD_F16", 1);
     k.spd_turns = env_int("LQP_SPD_TURNS", 1);
     k.bwd_f16 = env_int("LQP_BWD_F16", 1);
+    k.bwd_equil = env_int("LQP_BWD_EQUIL", 1);
     k.hot_past = env_int("LQP_HOT_PAST", 1);
     k.hot_rounds = env_int("LQP_HOT_ROUNDS", 2);
     k.spd_split = env_int("LQP_SPD_SPLIT", -1);
@@ -1397,6 +1399,7 @@ size_t carve_backward(void* ws, int B, int n, int m, BwdParams<T>& P) {
     P.dest = c.take<int>((size_t)B * P.Np);
     P.rhs = c.take<T>((size_t)B * P.Np);
     P.rhs2 = c.take<T>((size_t)B * P.Np);
+    P.bsc = c.take<T>((size_t)B * P.Np);
     P.fidx = c.take<int>((size_t)B * n);
     P.nred = c.take<int>(B);
     P.M = c.take<T>((size_t)B * P.Np * P.Np);
@@ -1423,6 +1426,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
     P.early_report = knobs().bwd_early != 0 ? 1 : 0;
     const size_t need = carve_backward<T>(ws, B, n, m, P);
     if (ws_bytes < need) return LQP_ERR_WORKSPACE;
+    if (!knobs().bwd_equil) P.bsc = nullptr;
     P.g = (const T*)g; P.x = (const T*)x; P.u = (const T*)u; P.lams = (const T*)lams; P.nus = (const T*)nus;
     P.Q = (const T*)Q; P.A = (const T*)A; P.lb = (const T*)lb; P.ub = (const T*)ub; P.rho_in = (const T*)rho_in;
     P.rho_value = (T)rho_value; P.rho_mode = rho_mode;
@@ -1454,7 +1458,7 @@ int backward_impl(hipStream_t st, int B, int n, int m, const void* g, const void
         if (chol) {
             P.chol = 1;
             if (phase != 2) {
-                const int lds = (2 * round_up(n, 8) + LQP_NW + 8) * 4;      // (fl | wtot | the KKT form's diagonal weights)
+                const int lds = (2 * round_up(n, 8) + LQP_NW + 8 + round_up(n, 64) + 64) * 4;      // (fl | wtot | the KKT form's diagonal weights | the equilibration)
                 ProfScope ps(st, PC_BWD_BUILD);
                 const int split = B <= 128 ? 2 : 1;
                 hipLaunchKernelGGL(k_bwd_build_chol<>, dim3(B, split), dim3(LQP_NT), lds, st, P);

@@ -2476,6 +2476,7 @@ template <typename T> struct BwdParams {
     int refine;  // 1: the epilogue adds rhs2 to rhs
     unsigned long long* dbg;   // optional cycle counters (8 per problem), debug only
     int la_maxk;               // largest block count the look-ahead Cholesky may take (LDS of the launch), 0 = off
+    T* bsc;                    // Cholesky form: [B][Np] the power-of-two equilibration of the free-set block, S (Q_FF + eps I) S (0 = off)
     int* host_report;          // optional pinned host memory, B ints: the epilogue leaves every problem's info word there
     int early_report;          // 1: Cholesky form -- k_bwd_chol_solve reports right behind its factorisation, not the epilogue
     int reported;              // 1 (phase 2 only): the phase-1 call has stored the info words into host_report already
@@ -2653,6 +2654,17 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_reduced(const BwdParams<T>
 // Build: ordered compaction of the free set, Kf as packed lower 64x64 blocks (identity padding), -g_F -> rhs,
 // A_F rows -> the (otherwise unused) M buffer.  LDS: fl[n] (int) | wtot[NW]
 // ---------------------------------------------------------------------------
+// Symmetric equilibration of the backward's free-set block by POWERS OF TWO: s_a = 2^-floor(log2(d_a) / 2), d_a the diagonal entry
+// (q_aa + 1e-8, or + the KKT form's weight), so that every diagonal entry of S (Q_FF + eps I) S lies in [1, 4).  Exact in floating
+// point -- the float32 Cholesky factorisation sees the same significands, its roundoff is invariant -- and it is what lets the
+// float16-pipe tile products scale a 32-row block by ONE factor: the reference's Q is not pre-conditioned in the backward
+// (:378-393), and rows 10^3 apart in magnitude inside a block lost up to ten bits there (measured on D Q D, d = 10^U(-1.5, 1.5):
+// dp 5e-5 of scale against 5e-7).  The system solved is S K S (S^-1 dv) = S rhs, the equality rows enter as A_F S.
+__device__ __forceinline__ float bwd_equil_scale(const float d) {
+    if (!(d > 0.f) || !(d < 3.0e38f)) return 1.f;
+    const int h = (int)((__float_as_uint(d) >> 23) & 0xFFu) - 127;       // floor(log2 d)
+    return __uint_as_float((unsigned int)(127 - (h >> 1)) << 23);
+}
 template <int LQP_ANY = 0>      // (a template only so that the split build can place its one instance: tools/gen_split_build.py)
 __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float> P) {
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -2701,6 +2713,15 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
     const int Kb = round_up(nf, LQP_NB) / LQP_NB;
     const int r = tid >> 4, c4 = (tid & 15) * 4;
     const int nblk = sym_blocks(Kb);
+    // the equilibration (bwd_equil_scale): s of free variable a, 1 on the padding; kept for the solve kernel
+    float* const sl = wl + round_up(n, 8);
+    for (int a = tid; a < Npm; a += LQP_NT) {
+        float sv = 1.f;
+        if (P.bsc && a < nf) sv = bwd_equil_scale(Q[(size_t)fl[a] * n + fl[a]] + (P.kkt ? wl[fl[a]] : 1e-8f));
+        sl[a] = sv;
+        if (P.bsc && blockIdx.y == 0) P.bsc[(size_t)b * Np + a] = sv;
+    }
+    __syncthreads();
     for (int t = blockIdx.y; t < nblk; t += gridDim.y) {
         int j = 0;
         while (sym_idx(j + 1, j + 1, Kb) <= t && j + 1 < Kb) ++j;      // block column of stream position t
@@ -2721,16 +2742,16 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_build_chol(const BwdParams<float
         for (int e = 0; e < 4; ++e) {
             const int c = j * 64 + c4 + e;
             float val = (a == c) ? 1.f : 0.f;
-            if (rok && c < nf) val = q4[e] + (a == c ? (P.kkt ? wl[fl[a]] : 1e-8f) : 0.f);
+            if (rok && c < nf) val = ((q4[e] + (a == c ? (P.kkt ? wl[fl[a]] : 1e-8f) : 0.f)) * sl[a]) * sl[c];
             v.v[e] = val;
         }
         *(V4<float>*)(Ls + (size_t)t * LQP_BLK + tid * 4) = v;
     }
     if (blockIdx.y == 0) {
         if (P.phase != 1)          // (phase 1: no cotangent yet -- k_bwd_chol_solve gathers it in phase 2)
-            for (int a = tid; a < Npm; a += LQP_NT) rhs[a] = a < nf ? -g[fl[a]] : 0.f;
+            for (int a = tid; a < Npm; a += LQP_NT) rhs[a] = a < nf ? -g[fl[a]] * sl[a] : 0.f;
         for (int q = 0; q < m; ++q)
-            for (int a = tid; a < Npm; a += LQP_NT) AF[(size_t)q * Npm + a] = a < nf ? A[(size_t)q * n + fl[a]] : 0.f;
+            for (int a = tid; a < Npm; a += LQP_NT) AF[(size_t)q * Npm + a] = a < nf ? A[(size_t)q * n + fl[a]] * sl[a] : 0.f;
     }
 }
 
@@ -2793,7 +2814,8 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     if (P.phase == 2) {                    // the cotangent arrives only now: gathered over the free set of phase 1
         const float* g = P.g + (size_t)b * n;
         const int* fidx = P.fidx + (size_t)b * n;
-        for (int e = tid; e < Nb; e += LQP_NT) u0[e] = e < nf ? -g[fidx[e]] : 0.f;
+        const float* bs_ = P.bsc ? P.bsc + (size_t)b * Np : nullptr;
+        for (int e = tid; e < Nb; e += LQP_NT) u0[e] = e < nf ? -g[fidx[e]] * (bs_ ? bs_[e] : 1.f) : 0.f;
     } else {
         for (int e = tid; e < Nb; e += LQP_NT) u0[e] = rhs[e];
     }
@@ -2860,7 +2882,7 @@ __global__ __launch_bounds__(LQP_NT) void k_bwd_chol_solve(const BwdParams<float
     for (int a = tid; a < nf; a += LQP_NT) {
         float d = u0[a];
         for (int q = 0; q < m; ++q) d -= G[(size_t)q * Npm + a] * dn[q];
-        rhs[a] = d;
+        rhs[a] = P.bsc ? d * P.bsc[(size_t)b * Np + a] : d;             // dv = S (the solution of the equilibrated system)
     }
     for (int q = tid; q < m; q += LQP_NT) rhs[nf + q] = dn[q];
     if (P.dbg && tid == 0) P.dbg[(size_t)b * 8 + 2] = clock64() - dt0;

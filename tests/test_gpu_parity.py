@@ -1867,6 +1867,38 @@ def test_hot_loop_goes_on_behind_rho_events(dev, monkeypatch, n, B, m, rho, qsca
     assert float((A.to(dev) @ s2["x"] - b.to(dev)).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("n,B,m", [(333, 64, 1), (500, 17, 1), (129, 17, 3), (320, 8, 16)])
+def test_backward_on_a_badly_scaled_q(dev, monkeypatch, n, B, m):
+    """The fixed-point backward factorises the free-set block of the UNSCALED Q (reference :378-393: no pre-conditioning there).  Round 6
+    equilibrates it symmetrically by powers of two (exact: the float32 Cholesky sees the same significands) so that the float16-pipe
+    tile products may scale a 32-row block by one factor: on Q := D Q D, d = 10^U(-1.5, 1.5) -- rows a thousand times apart in
+    magnitude -- dp is held to the float64 oracle's at 5e-6 of its scale (without the equilibration the float16-pipe build measured
+    5e-5, the float32 build 1e-6), and LQP_BWD_EQUIL=0 / LQP_BWD_F16=0 stay within rtol 1e-4."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=2000 + n, with_eq=False)
+    g = torch.Generator().manual_seed(n + m)
+    d = 10.0 ** (3 * torch.rand(B, n, generator=g) - 1.5)
+    Q = d.unsqueeze(2) * Q * d.unsqueeze(1)
+    A = torch.randn(B, m, n, generator=g)
+    b = 0.1 * torch.randn(B, m, 1, generator=g)
+    cot = torch.randn(B, n, 1, generator=g)
+    iters = 40
+    ctl = O.make_control(eps_abs=1e-12, eps_rel=1e-12, max_iters=iters + 1)
+    inp = (Q, p, A, b, lb, ub)
+    t64 = O.solve_box_qp(*[t.double() for t in inp], dict(ctl))
+    g64 = O.solve_box_qp_grad(cot.double(), t64["x"], t64["u"], t64["lams"], t64["nus"], Q.double(), A.double(), lb.double(), ub.double(), t64["rho"])
+    sp, sq = float(g64[1].abs().max()), float(g64[0].abs().max())
+    args = [t.to(dev) for t in inp]
+    for env, tol in (({}, 5e-6), ({"LQP_BWD_EQUIL": "0"}, G_RTOL), ({"LQP_BWD_F16": "0"}, 5e-6)):
+        for k_, v_ in (("LQP_BWD_EQUIL", "1"), ("LQP_BWD_F16", "1")):
+            monkeypatch.setenv(k_, env.get(k_, v_))
+        Ql, pl = args[0].clone().requires_grad_(True), args[1].clone().requires_grad_(True)
+        x = L.SolveBoxQP(control=dict(ctl))(Ql, pl, *args[2:])
+        x.backward(cot.to(dev))
+        ep, eq = err(pl.grad, g64[1]) / sp, err(Ql.grad, g64[0]) / sq
+        P.record(f"bwd_badly_scaled_n{n}_B{B}_m{m}", "dp_" + ("default" if not env else "_".join(f"{a}={c}" for a, c in env.items())), ep * sp, sp, tol=tol * sp)
+        assert ep <= tol and eq <= G_RTOL, (env, ep, eq)
+
+
 def test_continuation_launch_finds_corrected_blocks(dev):
     """The two-workgroup loop kernel applies the equality correction to its register blocks; when the loop has to go on in
     a continuation launch (here: tolerances that are never met, more iterations than one launch may hold, no adaptive rho
