@@ -2363,7 +2363,7 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                 if constexpr (F16) {
                     // ---- straight into the split image of the panel, in the scale of each tile
                     //      (the maxima of all tiles requested up front: one trip to the L2 instead of one per tile) ----
-                    constexpr int NIT = 2 * (K - 1), PF = 1;      // (half-tiles in flight per staging wave; four: measured slower, 0.31 against 0.28 ms -- registers)
+                    constexpr int NIT = 2 * (K - 1);      // (one half-tile in flight per staging wave; four: measured slower, 0.31 against 0.28 ms -- registers)
                     const unsigned long long* const mq = (const unsigned long long*)(xb + (size_t)2 * K * LQP_BLK + 64 + (k & 1) * 4 * K);
                     unsigned long long mraw[2 * (K - 1)];
 #pragma unroll
@@ -2371,13 +2371,28 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                         mraw[2 * s0] = __hip_atomic_load(mq + 2 * s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         mraw[2 * s0 + 1] = __hip_atomic_load(mq + 2 * s0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    V4<float> ra[PF], rb[PF];
-                    auto request = [&](const int it, V4<float>& a, V4<float>& b) {
-                        const float* src = src_l + (it >> 1) * LQP_BLK + 32 * (it & 1) * 64;
-                        a = ld16_handoff(src); b = ld16_handoff(src + 4);
-                    };
+                    // A thread takes eight consecutive columns t0 .. t0 + 7 of ONE row of the panel slot: of a tile that is stored as the
+                    // panel wants it (slot >= k: block (i, k)) two 16-byte loads of its row; of a tile stored transposed (slot < k:
+                    // block (k, i)) eight 4-byte loads down its column -- lane = row of the panel, so every load instruction still
+                    // reads 256 contiguous bytes.  (The transposed tiles used to be loaded by rows and scattered into the image with
+                    // 2-byte LDS stores, sixteen per thread and half-tile, 4-way bank conflicts: LDS time the pivot chain's queue
+                    // traffic waited behind.)
+                    float rv[8];
+                    auto request = [&](const int it, float (&v)[8]) {
+                        const int s0 = it >> 1, hf = it & 1;
+                        if (s0 >= k) {
+                            const float* src = src_l + s0 * LQP_BLK + 32 * hf * 64;
+                            const V4<float> a = ld16_handoff(src), b = ld16_handoff(src + 4);
 #pragma unroll
-                    for (int it = 0; it < PF; ++it) request(it, ra[it], rb[it]);
+                            for (int e = 0; e < 4; ++e) { v[e] = a.v[e]; v[4 + e] = b.v[e]; }
+                        } else {
+                            const unsigned int* src = (const unsigned int*)(xbk + s0 * LQP_BLK + (8 * (tt >> 6) + 32 * hf) * 64 + (tt & 63));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                v[e] = __uint_as_float(__hip_atomic_load(src + e * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                    };
+                    request(0, rv);
                     // the tiles' scales from the maxima their owners published with them (four quadrants; both 32-row blocks of a
                     // slot share it)
                     float sPt[K - 1];
@@ -2395,32 +2410,22 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         const int s0 = it >> 1, hf = it & 1;
-                        const V4<float> a = ra[it % PF], b = rb[it % PF];
                         float va[4], vb[4];
                         h16x4 ha, ma, hb, mb;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            va[e] = a.v[e] * sPt[s0]; vb[e] = b.v[e] * sPt[s0];
+                            va[e] = rv[e] * sPt[s0]; vb[e] = rv[4 + e] * sPt[s0];
                             ha[e] = (_Float16)va[e]; ma[e] = (_Float16)(va[e] - (float)ha[e]);
                             hb[e] = (_Float16)vb[e]; mb[e] = (_Float16)(vb[e] - (float)hb[e]);
                         }
-                        if (it + PF < NIT) request(it + PF, ra[it % PF], rb[it % PF]);
-                        if (s0 >= k) {
-                            // row r0 + 32 hf of the slot, columns c8 .. c8 + 7: slice c8 / 16, element half (c8 / 8) & 1 of the cells
-                            // of both lane halves (a: h = 0, b: h = 1; lqp_f16x2.hpp)
-                            char* d = Yc_ + (s0 * 64 + 32 * hf + r0) * F2_ROW + 64 * (c8 >> 4) + 8 * ((c8 >> 3) & 1);
-                            *(h16x4*)d = ha; *(h16x4*)(d + 16) = ma;
-                            *(h16x4*)(d + 32) = hb; *(h16x4*)(d + 48) = mb;
-                        } else {
-                            // transposed: the value is P[row c8 + e (+ 4)][column t = r0 + 32 hf]
-                            const int t = r0 + 32 * hf;
-                            char* d = Yc_ + (s0 * 64 + c8) * F2_ROW + 64 * (t >> 4) + 32 * ((t >> 2) & 1) + 2 * (4 * ((t >> 3) & 1) + (t & 3));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                *(_Float16*)(d + e * F2_ROW) = ha[e]; *(_Float16*)(d + e * F2_ROW + 16) = ma[e];
-                                *(_Float16*)(d + (4 + e) * F2_ROW) = hb[e]; *(_Float16*)(d + (4 + e) * F2_ROW + 16) = mb[e];
-                            }
-                        }
+                        if (it + 1 < NIT) request(it + 1, rv);
+                        // row `prow` of the slot, columns t0 .. t0 + 7: slice t0 / 16, element half (t0 / 8) & 1 of the cells of both
+                        // lane halves (t0 .. t0 + 3: h = 0, t0 + 4 .. t0 + 7: h = 1; lqp_f16x2.hpp)
+                        const int prow = s0 >= k ? r0 + 32 * hf : (tt & 63);
+                        const int t0 = s0 >= k ? c8 : 8 * (tt >> 6) + 32 * hf;
+                        char* d = Yc_ + (s0 * 64 + prow) * F2_ROW + 64 * (t0 >> 4) + 8 * ((t0 >> 3) & 1);
+                        *(h16x4*)d = ha; *(h16x4*)(d + 16) = ma;
+                        *(h16x4*)(d + 32) = hb; *(h16x4*)(d + 48) = mb;
                     }
                 } else {
 #pragma unroll

@@ -2,7 +2,7 @@
 against the float64 oracle at a pinned iteration count.  Prints the worst cases."""
 import os, sys, itertools, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["LQP_ENV_NOCACHE"] = "1"
 import lqp_py_amd as L
 from oracle import boxqp_oracle as O
