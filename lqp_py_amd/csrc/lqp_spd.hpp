@@ -2525,8 +2525,18 @@ __device__ __forceinline__ void wg_spd_sweep_resident_v2(const float* Hsrc, floa
                     f32x16 a1;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+                    if constexpr (PIVOT) {
+                        // (the pivot block's waves hold two tiles fewer: room for the four cells of W at once -- one LDS round trip
+                        //  in front of the twelve matrix instructions instead of four between them)
+                        F2Cell wc[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) a1 = f2_mma(f2_read_cell(wa + 32 * F2_ROW + 64 * c), pbl[c], a1);
+                        for (int c = 0; c < 4; ++c) wc[c] = f2_read_cell(wa + 32 * F2_ROW + 64 * c);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a1 = f2_mma(wc[c], pbl[c], a1);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a1 = f2_mma(f2_read_cell(wa + 32 * F2_ROW + 64 * c), pbl[c], a1);
+                    }
                     store_half(a1, 2);
                 }
             };
