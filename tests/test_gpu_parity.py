@@ -1899,6 +1899,42 @@ def test_backward_on_a_badly_scaled_q(dev, monkeypatch, n, B, m):
         assert ep <= tol and eq <= G_RTOL, (env, ep, eq)
 
 
+@pytest.mark.parametrize("n,B,m", [(330, 600, 3), (500, 520, 16), (200, 300, 2)])
+def test_large_batch_sweep_on_pairs_taking_turns(dev, monkeypatch, n, B, m):
+    """Round 6: more matrices than half the CUs run the register-resident sweep too, its PAIRS of workgroups taking turns on the chip
+    (LQP_SPD_TURNS; before: k_spd_prep + the one-workgroup sweep, every tile through L2 / HBM in every pivot step); from two turns
+    on (B >= 2 #CUs) the first check segment of the loop applies the equality correction.  Against LQP_SPD_TURNS=0: the same iteration
+    count (the stop is decided by all problems), x within the tolerance of two schedules; eight problems against the float64 oracle
+    at the same count; the constraint itself; the backward on top."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + B, with_eq=False)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=g)
+    b = 0.1 * torch.randn(B, m, 1, generator=g)
+    cot = torch.randn(B, n, 1, generator=g)
+    args = [t.to(dev) for t in (Q, p, A, b, lb, ub)]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_SPD_TURNS", flag)
+        Ql, pl = args[0].clone().requires_grad_(True), args[1].clone().requires_grad_(True)
+        x = L.SolveBoxQP(control=L.box_qp_control(**TOL))(Ql, pl, *args[2:])
+        st = SB.last_forward_status(dev)
+        x.backward(cot.to(dev))
+        out[flag] = (x.detach(), pl.grad, st)
+        assert st["linsolve_used"] == 2 and st["loop_workgroups_per_qp"] == 2, st
+        assert st["factor_launches"] == (3 if flag == "1" else 1), st          # (turns: begin / resident sweep / end; else the one-workgroup sweep)
+    (x1, dp1, st1), (x0, dp0, st0) = out["1"], out["0"]
+    assert st1["iters"] == st0["iters"]
+    idx = torch.arange(0, B, B // 8)[:8]
+    sub = [t[idx].double() for t in (Q, p, A, b, lb, ub)]
+    t64 = O.solve_box_qp(*sub, O.make_control(eps_abs=1e-12, eps_rel=1e-12, max_iters=st1["iters"] + 1))
+    g64 = O.solve_box_qp_grad(cot[idx].double(), t64["x"], t64["u"], t64["lams"], t64["nus"], sub[0], sub[2], sub[4], sub[5], t64["rho"])
+    sx = max(1.0, float(t64["x"].abs().max()))
+    P.record(f"sweep_in_turns_n{n}_B{B}_m{m}", "x", err(x1[idx.to(dev)], t64["x"]), sx, one_workgroup_sweep_vs_fp64=err(x0[idx.to(dev)], t64["x"]))
+    assert err(x1[idx.to(dev)], t64["x"]) <= X_TOL * sx and err(x1, x0) <= 2 * X_TOL * sx
+    assert rel(dp1[idx.to(dev)], g64[1]) <= G_RTOL
+    assert float((args[2] @ x1 - args[3]).abs().max()) < 2e-4
+
+
 def test_continuation_launch_finds_corrected_blocks(dev):
     """The two-workgroup loop kernel applies the equality correction to its register blocks; when the loop has to go on in
     a continuation launch (here: tolerances that are never met, more iterations than one launch may hold, no adaptive rho
