@@ -37,7 +37,7 @@ enum {
     LQP_ERR_SINGULAR = 3,     /* exactly-zero pivot; batch index in stats / info         */
     LQP_ERR_HIP = 4,          /* a HIP runtime call failed                               */
     LQP_ERR_TIMEOUT = 5,      /* in-kernel grid barrier gave up (bounded spin)           */
-    LQP_ERR_UNSUPPORTED = 6,  /* size outside what the kernels are built for             */
+    LQP_ERR_UNSUPPORTED = 6,  /* size outside what the kernels are built for: n + m > 4096 (float32) / 2048 (float64) */
     LQP_ERR_NOT_SPD = 7       /* lqp_boxqp_forward_finish only: the matrix left the symmetric x-update (not symmetric / Qs + rho I not
                                  positive definite in f32): repeat lqp_boxqp_forward with ctrl.linsolve = 1                     */
 };

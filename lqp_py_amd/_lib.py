@@ -21,7 +21,7 @@ SOURCES = ["lqp_amd.hip", "lqp_unroll.hpp", "lqp_boxqp.hpp", "lqp_lu.hpp", "lqp_
 LQP_F32, LQP_F64 = 0, 1
 ABI_VERSION = 12
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
-          5: "grid barrier timeout", 6: "unsupported size", 7: "matrix outside the symmetric x-update"}
+          5: "grid barrier timeout", 6: "unsupported size (n + m <= 4096 in float32, 2048 in float64)", 7: "matrix outside the symmetric x-update"}
 
 c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
 

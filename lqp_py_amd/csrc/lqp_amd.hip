@@ -25,7 +25,9 @@ using namespace lqp;
 namespace {
 
 constexpr int kRing = 2048;          // per-check counter slots (a continuation launch holds kRing / 2 checks: 10 000 iterations at a check every 10 in ONE launch)
-constexpr int kMaxN = 2048;          // pivoted LU: one panel row per thread to 1024, two above (k_lu_factor_big)
+// pivoted LU: one panel row per thread to 1024 rows, two to 2048, four (float32, panels of 4 columns) to 4096 (k_lu_factor_big):
+// what bounds it is the LDS that holds L21^T and U12 of a panel, 2 * PB * N elements
+inline int max_rows(int dtype) { return dtype == LQP_F32 ? 4096 : 2048; }
 constexpr size_t kAlign = 256;
 constexpr int kSplitMaxB = 8192;     // two-workgroup loop: exchange granules (32 KB per problem) are carved for batches up to this
 
@@ -282,7 +284,8 @@ int launch_lu_impl(hipStream_t st, int B, T* M, int N, int ld, size_t mstride, i
 template <typename T>
 int launch_lu_big(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                   const int* gate, const int* nvec) {
-    const int lds = LuLds<T, lu_big_panel<T>()>(round_up(N, 64)).total;
+    if (N > (sizeof(T) == 4 ? 4096 : 2048)) return LQP_ERR_UNSUPPORTED;
+    const int lds = N > 2048 ? LuLds<T, 4>(round_up(N, 64)).total : LuLds<T, lu_big_panel<T>()>(round_up(N, 64)).total;
     auto fn = k_lu_factor_big<T>;
     const int rc = ensure_lds((const void*)fn, lds);
     if (rc) return rc;
@@ -1755,7 +1758,7 @@ const char* lqp_status_string(int s) {
         case LQP_ERR_SINGULAR: return "singular matrix (exactly zero pivot)";
         case LQP_ERR_HIP: return "HIP runtime error";
         case LQP_ERR_TIMEOUT: return "in-kernel grid barrier timed out";
-        case LQP_ERR_UNSUPPORTED: return "size not supported by this build (n + m <= 2048)";
+        case LQP_ERR_UNSUPPORTED: return "size not supported by this build (n + m <= 4096 in float32, 2048 in float64)";
         case LQP_ERR_NOT_SPD: return "matrix outside the symmetric x-update: repeat with linsolve = 1";
         default: return "unknown status";
     }
@@ -1792,7 +1795,7 @@ int lqp_boxqp_forward(void* stream, int dtype, int B, int n, int m, const void* 
     if (ctrl->rho_mode == 2 && !rho_in) return LQP_ERR_INVALID;
     if (ctrl->beta_mode == 2 && !ctrl->beta_in) return LQP_ERR_INVALID;
     if (ctrl->max_iters < 1) return LQP_ERR_INVALID;
-    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (n + m > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int retry0 = (ctrl->reserved2 & 2) ? 4 : 0;      // (bit 1: the caller has seen a shared schedule time out -- nothing shared)
     if (dtype == LQP_F32)
@@ -2004,7 +2007,7 @@ int lqp_boxqp_backward_fp_prefactor(void* stream, int dtype, int B, int n, int m
                                     int linsolve, void* host_report) {
     if (bad_dims(dtype, B, n, m) || !x || !u || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
     if (m > 0 && !A) return LQP_ERR_INVALID;
-    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (n + m > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     if (dtype == LQP_F32)
         return backward_impl<float>((hipStream_t)stream, B, n, m, nullptr, x, u, nullptr, nullptr, Q, A, lb, ub, 1, 1.0, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
@@ -2023,7 +2026,7 @@ int lqp_boxqp_backward_fp(void* stream, int dtype, int B, int n, int m, const vo
     if (m > 0 && (!A || !nus)) return LQP_ERR_INVALID;
     if (rho_mode != 1 && rho_mode != 2) return LQP_ERR_INVALID;
     if (rho_mode == 2 && !rho_in) return LQP_ERR_INVALID;
-    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (n + m > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LQP_F32)
         return backward_impl<float>(st, B, n, m, dl_dz, x, u, lams, nus, Q, A, lb, ub, rho_mode, rho_value, rho_in, dQ, dp, dA, db, dlb, dub, fail_index, workspace, workspace_bytes, linsolve, host_report);
@@ -2037,7 +2040,7 @@ int lqp_boxqp_backward_kkt(void* stream, int dtype, int B, int n, int m, const v
                            size_t workspace_bytes, int linsolve, void* host_report) {
     if (bad_dims(dtype, B, n, m) || !dl_dz || !x || !lams || !Q || !lb || !ub || !workspace) return LQP_ERR_INVALID;
     if (m > 0 && (!A || !nus)) return LQP_ERR_INVALID;
-    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (n + m > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LQP_F32)
         return backward_impl<float>(st, B, n, m, dl_dz, x, nullptr, lams, nus, Q, A, lb, ub, 1, 1.0, nullptr, dQ, dp, dA, db, dlb,
@@ -2085,7 +2088,7 @@ size_t lqp_lu_factor_workspace_bytes(int dtype, int B, int N) {
 int lqp_lu_factor_batched(void* stream, int dtype, int B, int N, void* M_inout, int32_t* piv_out, int32_t* info_out,
                           void* workspace, size_t workspace_bytes) {
     if (bad_dims(dtype, B, N, 0) || !M_inout || !piv_out || !info_out || !workspace) return LQP_ERR_INVALID;
-    if (N > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (N > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     return dtype == LQP_F32 ? lu_factor_impl<float>(st, B, N, M_inout, piv_out, info_out, workspace, workspace_bytes)
                             : lu_factor_impl<double>(st, B, N, M_inout, piv_out, info_out, workspace, workspace_bytes);
@@ -2099,14 +2102,14 @@ size_t lqp_lu_solve_workspace_bytes(int dtype, int B, int N) { return lqp_lu_pac
 
 int lqp_lu_pack(void* stream, int dtype, int B, int N, const void* LU, const int32_t* piv, void* packed) {
     if (bad_dims(dtype, B, N, 0) || !LU || !piv || !packed) return LQP_ERR_INVALID;
-    if (N > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (N > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     return dtype == LQP_F32 ? lu_pack_impl<float>(st, B, N, LU, piv, packed) : lu_pack_impl<double>(st, B, N, LU, piv, packed);
 }
 
 int lqp_lu_solve_packed(void* stream, int dtype, int B, int N, int k, const void* packed, void* rhs_inout) {
     if (bad_dims(dtype, B, N, 0) || k < 1 || !packed || !rhs_inout) return LQP_ERR_INVALID;
-    if (N > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (N > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     return dtype == LQP_F32 ? lu_solve_packed_impl<float>(st, B, N, k, packed, rhs_inout)
                             : lu_solve_packed_impl<double>(st, B, N, k, packed, rhs_inout);
@@ -2131,7 +2134,7 @@ int lqp_kkt_solve(void* stream, int dtype, int B, int n, int m, const void* Q, c
                   void* x, void* nus, int32_t* fail_index, void* workspace, size_t workspace_bytes) {
     if (bad_dims(dtype, B, n, m) || !Q || !p || !x || !workspace) return LQP_ERR_INVALID;
     if (m > 0 && (!A || !b || !nus)) return LQP_ERR_INVALID;
-    if (n + m > kMaxN) return LQP_ERR_UNSUPPORTED;
+    if (n + m > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     return dtype == LQP_F32 ? kkt_solve_impl<float>(st, B, n, m, Q, p, A, b, x, nus, fail_index, workspace, workspace_bytes)
                             : kkt_solve_impl<double>(st, B, n, m, Q, p, A, b, x, nus, fail_index, workspace, workspace_bytes);

@@ -766,7 +766,7 @@ __global__ __launch_bounds__(LU2_NT) void k_lu_factor2(T* __restrict__ Mall, con
                          scr + (size_t)b * scr_stride, epoch, xlocal_ok != 0, (dbg && me == 0) ? dbg + (size_t)b * 16 : nullptr);
 }
 
-// 1024 < N <= 2048: two panel rows per thread (lqp_lu_big.hpp)
+// 1024 < N <= 2048: two panel rows per thread; to 4096 in float32: four (lqp_lu_big.hpp)
 template <typename T>
 __global__ __launch_bounds__(LQP_NT) void k_lu_factor_big(T* __restrict__ Mall, const int N, const int ld,
                                                           const size_t mstride, int* __restrict__ piv,
@@ -777,6 +777,13 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_big(T* __restrict__ Mall, 
     const int b = blockIdx.x;
     if (threadIdx.x == 0) info[b] = 0;
     __syncthreads();
+    // (N is the launch's size, the LDS layout follows it: a smaller Nvec[b] runs on the same form)
+    if constexpr (sizeof(T) == 4) {
+        if (N > 2048) {           // 2048 < N <= 4096: four rows per thread, panels of 4 columns (2 * 4 * N floats of LDS)
+            wg_lu_factor_big<T, 4, true, 4>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld, piv + (size_t)b * pstride, info + b, smem);
+            return;
+        }
+    }
     wg_lu_factor_big<T, lu_big_panel<T>(), true, 2>(Mall + (size_t)b * mstride, Nvec ? Nvec[b] : N, ld,
                                                                piv + (size_t)b * pstride, info + b, smem);
 }

@@ -154,7 +154,25 @@ def main():
         save("g19_b1024_n500_eq", in_sum=checksum(Q, p, lb, ub), x=sol["x"], u=sol["u"], rho=sol["rho"], iter=sol["iter"])
         print("   B=1024 n=500 iter", sol["iter"])
         del Q, sol
-    if only and all(o.startswith(("g16", "g17", "g18", "g19")) for o in only):
+    # G20: above 2048 rows (README.md:49 discusses large n_x; the reference's LAPACK calls at :205-215 take any size) -- B=2 n=3000
+    #      m=1 float32, forward + the FP gradients for a random cotangent; inputs regenerated on the GPU box by the restated generator
+    if not only or any(o.startswith("g20") for o in only):
+        Q, p, A, b, lb, ub = ref_inputs(3000, 2, 20)
+        sol = torch_solve_box_qp(Q, p, A, b, lb, ub, box_qp_control(**tol))
+        torch.manual_seed(20)
+        cot = torch.randn(2, 3000, 1)
+        gr = fp_grads(sol, Q, A, lb, ub, cot)
+        rs = np.random.RandomState(20)
+        sb, si, sj = rs.randint(0, 2, 64), rs.randint(0, 3000, 64), rs.randint(0, 3000, 64)
+        out = dict(cot=cot, in_sum=checksum(Q, p, lb, ub), sb=sb, si=si, sj=sj,
+                   dQ_fro=torch.linalg.matrix_norm(gr[0]), dQ_samples=gr[0][sb, si, sj],
+                   **{k: sol[k] for k in ("x", "z", "u", "lams", "nus", "rho", "iter")})
+        for nm, t in zip(GRAD_NAMES[1:], gr[1:6]):
+            out[nm] = t
+        save("g20_b2_n3000_eq", **out)
+        print("   n=3000 iter", sol["iter"])
+        del Q, sol, gr
+    if only and all(o.startswith(("g16", "g17", "g18", "g19", "g20")) for o in only):
         return
 
     # G14: the NumPy twin (lqp_py/solve_box_qp_admm.py:45-91, single problem, float64) -- SURVEY 8f rank 4

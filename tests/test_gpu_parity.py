@@ -194,9 +194,11 @@ def test_lu_wide_matches_one_workgroup(dev, monkeypatch, N, B, dtype):
 
 
 @pytest.mark.parametrize("N,B,dtype", [(1025, 2, torch.float64), (1100, 2, torch.float32), (1501, 2, torch.float64),
-                                       (2048, 1, torch.float32), (2048, 1, torch.float64)])
+                                       (2048, 1, torch.float32), (2048, 1, torch.float64), (2049, 2, torch.float32),
+                                       (3001, 2, torch.float32), (4096, 1, torch.float32)])
 def test_lu_factor_above_1024(dev, N, B, dtype):
-    """1024 < N <= 2048: two panel rows per thread (k_lu_factor_big), the matrix in global memory.  float64: the pivots
+    """1024 < N <= 2048: two panel rows per thread (k_lu_factor_big), the matrix in global memory; float32 to 4096: four rows per
+    thread, panels of four columns.  float64: the pivots
     ARE LAPACK's; float32 (a near-tie may flip under another summation order at this size): P A = L U to rounding,
     |L| <= 1 (partial pivoting), and the solves."""
     torch.manual_seed(N)
@@ -1545,10 +1547,11 @@ def test_training_loop_matches_cpu_oracle(dev):
 
 
 def test_unsupported_sizes_fail_loudly(dev):
-    n = 2049                                  # (n + m <= 2048 since round 4: the pivoted LU holds two panel rows per thread)
-    with pytest.raises(RuntimeError, match="unsupported"):
-        L.torch_solve_box_qp(torch.zeros(1, n, n, device=dev), torch.zeros(1, n, 1, device=dev), None, None,
-                             -torch.ones(1, n, 1, device=dev), torch.ones(1, n, 1, device=dev), {})
+    # (n + m <= 4096 in float32 since round 6 -- four panel rows per thread --, 2048 in float64: the LDS holds 2 * PB * N elements of a panel)
+    for n, dt in ((4097, torch.float32), (2049, torch.float64)):
+        with pytest.raises(RuntimeError, match="unsupported"):
+            L.torch_solve_box_qp(torch.zeros(1, n, n, device=dev, dtype=dt), torch.zeros(1, n, 1, device=dev, dtype=dt), None, None,
+                                 -torch.ones(1, n, 1, device=dev, dtype=dt), torch.ones(1, n, 1, device=dev, dtype=dt), {})
 
 
 def test_g16_n1500_above_the_on_chip_tiers(dev):
@@ -1581,6 +1584,37 @@ def test_g16_n1500_above_the_on_chip_tiers(dev):
     x64 = L.SolveBoxQP(control=L.box_qp_control(**TOL))(Qg, *d[1:])
     x64.backward(g["cot"].double().to(dev))
     assert err(x64, t64["x"]) < 1e-4 and torch.isfinite(Qg.grad).all()      # (its own stopping point: the tolerance level)
+
+
+def test_g20_n3000_above_2048_rows(dev):
+    """Reference-made golden at n = 3000, m = 1, B = 2, float32 (the reference's LAPACK calls at solve_box_qp_admm_torch.py:205-215
+    take any size; README.md:49 discusses large n_x): forward iterates, iteration count and the fixed-point gradients.  Above 2048
+    rows the pivoted LU holds four panel rows per thread; loop and backward are the HBM-resident tier's."""
+    g = load_golden("g20_b2_n3000_eq")
+    inp = O.create_qp_data(3000, 2, seed=20)
+    assert abs(float(inp[0].double().sum()) - float(g["in_sum"][0])) < 1e-6 * abs(float(g["in_sum"][0]))
+    sol, a = solve(dev, inp, O.make_control(**TOL))
+    assert sol["iter"] == g["iter"] and sol["_stats"]["linsolve_used"] == 1
+    t64, g64 = fp64_truth(inp, int(g["iter"]), cots=(g["cot"],))
+    case = "g20_b2_n3000_eq"
+    for k in ("x", "z", "u", "lams", "nus"):
+        close_or_fp64(case, k, sol[k], g[k], t64[k], X_TOL)
+    close_or_fp64(case, "rho", sol["rho"], g["rho"], t64["rho"], 1e-5)
+    gr = L.torch_solve_box_qp_grad(g["cot"].to(dev), sol["x"], sol["u"], sol["lams"], sol["nus"], a[0], a[2], a[4], a[5], sol["rho"])
+    for idx, nm in enumerate(GRADS):
+        if nm == "dQ":
+            continue
+        close_or_fp64(case, nm, gr[idx], g[nm], g64[0][idx], G_RTOL)
+    dQ = gr[0]
+    close_or_fp64(case, "dQ_fro", torch.linalg.matrix_norm(dQ), g["dQ_fro"], torch.linalg.matrix_norm(g64[0][0]), G_RTOL)
+    sb, si, sj = (g[k].long() for k in ("sb", "si", "sj"))
+    close_or_fp64(case, "dQ_samples", dQ[sb.to(dev), si.to(dev), sj.to(dev)], g["dQ_samples"], g64[0][0][sb, si, sj], G_RTOL)
+    # the module path (autograd) at the same size
+    leaves = [t.to(dev).clone().requires_grad_(True) for t in inp]
+    xm = L.SolveBoxQP(control=L.box_qp_control(**TOL))(*leaves)
+    xm.backward(g["cot"].to(dev))
+    assert err(xm, sol["x"]) < 1e-6 and all(torch.isfinite(t.grad).all() for t in leaves)
+    assert err(leaves[1].grad, gr[1]) < 1e-6 * max(1.0, float(gr[1].abs().max()))
 
 
 # ---------------------------------------------------------------- bench.py contract
