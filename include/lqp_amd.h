@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LQP_ABI_VERSION 12
+#define LQP_ABI_VERSION 13
 
 enum { LQP_F32 = 0, LQP_F64 = 1 };
 
@@ -221,6 +221,17 @@ size_t lqp_boxqp_unroll_backward_workspace_bytes(int B, int n, int m, int iters)
 int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
                               int iters, const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs,
                               void* dubs, void* drho, void* dD, void* scratch, size_t scratch_bytes);
+
+/* ABI 13: the same reverse recurrence for a forward that ran the PIVOTED LU of the KKT matrix (stats.linsolve_used == 1: float64,
+ * more than 16 equality rows, a non-symmetric Q, ctrl.linsolve = 1) without a refactorisation -- the tape's node is
+ * TorchLULayer as it stands (lqp_py/lu_layer.py:25-58: forward lu_solve with the cached factor, backward dxv = lu_solve(LU, P, -g)
+ * with the SAME factor, dM = dxv xv^T, drhs = -dxv; xv = [x; nu]): `iters + 1` cached solves to replay the loop, as many to walk it
+ * back, on the packed factor the forward left in `fwd_workspace`.  Same outputs as lqp_boxqp_unroll_backward, in `dtype`;
+ * n + m up to what the forward takes.  Replaces the eager tape of lqp_py/solve_box_qp_admm_torch.py:235-313 under unroll=True. */
+size_t lqp_boxqp_unroll_backward_lu_workspace_bytes(int dtype, int B, int n, int m, int iters);
+int lqp_boxqp_unroll_backward_lu(void* stream, int dtype, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                 int iters, const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs, void* dubs,
+                                 void* drho, void* dD, void* scratch, size_t scratch_bytes);
 
 /* The scaling (solve_box_qp_admm_torch.py:160-203) behind the unrolled loop (ABI 10): what of its derivative walks over the
  * (B,n,n) tensors, one pass each; the reference lets autograd tape these as torch ops (:163 column maxima of |Q| --

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("LQP_LIB", os.path.join(CSRC, "liblqp_amd.so"))   # LQ
 SOURCES = ["lqp_amd.hip", "lqp_unroll.hpp", "lqp_boxqp.hpp", "lqp_lu.hpp", "lqp_lu_big.hpp", "lqp_lu2.hpp", "lqp_lu_wide.hpp", "lqp_dense.hpp", "lqp_trsv.hpp", "lqp_spd.hpp", "lqp_common.hpp"]
 
 LQP_F32, LQP_F64 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 STATUS = {0: "ok", 1: "invalid argument", 2: "workspace too small", 3: "singular", 4: "HIP error",
           5: "grid barrier timeout", 6: "unsupported size (n + m <= 4096 in float32, 2048 in float64)", 7: "matrix outside the symmetric x-update"}
 
@@ -69,6 +69,8 @@ SYMBOLS = {
     "lqp_boxqp_forward_layout": (c_int, [c_int] * 4 + [ctypes.POINTER(c_size_t)] * 4),
     "lqp_boxqp_unroll_backward_workspace_bytes": (c_size_t, [c_int] * 4),
     "lqp_boxqp_unroll_backward": (c_int, [_P, c_int, c_int, c_int, _P, c_size_t, c_int] + [_P] * 10 + [c_size_t]),
+    "lqp_boxqp_unroll_backward_lu_workspace_bytes": (c_size_t, [c_int] * 5),
+    "lqp_boxqp_unroll_backward_lu": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, c_int] + [_P] * 10 + [c_size_t]),
     "lqp_unroll_scale_colmax": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "lqp_unroll_scale_grad_slabs": (c_int, [c_int, c_int]),
     "lqp_unroll_scale_grad": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int]),

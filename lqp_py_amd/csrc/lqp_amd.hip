@@ -1667,6 +1667,63 @@ bool bad_dims(int dtype, int B, int n, int m) {
 }  // namespace
 
 // ===========================================================================
+namespace {
+// ---- the tape whose x-update is the pivoted LU (float32 / float64, any m): lqp_unroll.hpp, k_unroll_sweep_lu ----
+template <typename T> struct UnrollLuCarve { UnrollLuParams<T> U; size_t bytes; };
+template <typename T>
+static UnrollLuCarve<T> carve_unroll_lu(void* ws, int B, int n, int m, int TT) {
+    UnrollLuCarve<T> c;
+    memset(&c.U, 0, sizeof(c.U));
+    Carver cv(ws);
+    const int mm = m > 0 ? m : 1;
+    c.U.X = cv.take<T>((size_t)B * TT * n);
+    c.U.W = cv.take<T>((size_t)B * TT * n);
+    c.U.DX = cv.take<T>((size_t)B * TT * n);
+    c.U.NU = cv.take<T>((size_t)B * TT * mm);
+    c.U.DNU = cv.take<T>((size_t)B * TT * mm);
+    c.U.MK = cv.take<signed char>((size_t)B * TT * n);
+    c.bytes = cv.off + kAlign;
+    return c;
+}
+
+template <typename T>
+static int unroll_backward_lu_impl(hipStream_t st, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes, int iters,
+                                   const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs, void* dubs, void* drho,
+                                   void* dD, void* scratch, size_t scratch_bytes) {
+    FwdLayout<T> L = carve_forward<T>((void*)fwd_workspace, B, n, m);
+    if (fwd_workspace_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+    const FwdParams<T>& P = L.P;
+    const int TT = iters + 1;
+    UnrollLuCarve<T> c = carve_unroll_lu<T>(scratch, B, n, m, TT);
+    if (scratch_bytes < c.bytes) return LQP_ERR_WORKSPACE;
+    UnrollLuParams<T>& U = c.U;
+    U.T_ = TT;
+    U.g = (const T*)dl_dx;
+    U.dps = (T*)dps; U.dlbs = (T*)dlbs; U.dubs = (T*)dubs; U.dD = (T*)dD; U.dAs = (T*)dAs; U.dbs = (T*)dbs; U.drho = (T*)drho;
+    {
+        const int lds = unroll_lu_lds_bytes<T>(P.Np);
+        auto fn = k_unroll_sweep_lu<T>;
+        const int rc = ensure_lds((const void*)fn, lds);
+        if (rc) return rc;
+        ProfScope ps(st, PC_UNROLL);
+        hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P, U);
+    }
+    if (m > 0) {
+        ProfScope ps(st, PC_UNROLL);
+        int slabs = (m * n + 255) / 256;
+        if (slabs > 64) slabs = 64;
+        hipLaunchKernelGGL(k_unroll_lu_eq<T>, dim3(B, slabs), dim3(256), 0, st, U, n, m);
+    }
+    if (dQs) {
+        ProfScope ps(st, PC_UNROLL);
+        const int tiles = (n + 63) / 64;
+        hipLaunchKernelGGL(k_unroll_outer_any<T>, dim3(tiles, tiles, B), dim3(256), 0, st, (const T*)U.DX, (const T*)U.X, (T*)dQs, n, TT);
+    }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+}  // namespace
+
 extern "C" {
 
 int lqp_abi_version(void) { return LQP_ABI_VERSION; }
@@ -1884,6 +1941,26 @@ int lqp_boxqp_unroll_backward(void* stream, int B, int n, int m, const void* fwd
                            (float*)dQs, n, T);
     }
     return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+size_t lqp_boxqp_unroll_backward_lu_workspace_bytes(int dtype, int B, int n, int m, int iters) {
+    if (bad_dims(dtype, B, n, m) || iters < 0) return 0;
+    return dtype == LQP_F32 ? carve_unroll_lu<float>(nullptr, B, n, m, iters + 1).bytes : carve_unroll_lu<double>(nullptr, B, n, m, iters + 1).bytes;
+}
+
+int lqp_boxqp_unroll_backward_lu(void* stream, int dtype, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                 int iters, const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs, void* dubs,
+                                 void* drho, void* dD, void* scratch, size_t scratch_bytes) {
+    if (bad_dims(dtype, B, n, m) || iters < 0 || !fwd_workspace || !dl_dx || !dps || !dlbs || !dubs || !drho || !dD || !scratch)
+        return LQP_ERR_INVALID;
+    if (m > 0 && (!dAs || !dbs)) return LQP_ERR_INVALID;
+    if (n + m > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LQP_F32)
+        return unroll_backward_lu_impl<float>(st, B, n, m, fwd_workspace, fwd_workspace_bytes, iters, dl_dx, dQs, dps, dAs, dbs, dlbs, dubs,
+                                              drho, dD, scratch, scratch_bytes);
+    return unroll_backward_lu_impl<double>(st, B, n, m, fwd_workspace, fwd_workspace_bytes, iters, dl_dx, dQs, dps, dAs, dbs, dlbs, dubs,
+                                           drho, dD, scratch, scratch_bytes);
 }
 
 int lqp_unroll_scale_colmax(void* stream, int B, int n, const void* Q, void* colmax, void* argmax, void* count) {

@@ -396,6 +396,229 @@ __global__ __launch_bounds__(256) void k_unroll_outer(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same reverse sweep where the x-update is the PIVOTED LU of the KKT matrix (float64, more than 16 equality rows, a
+// non-symmetric Q, linsolve = 'lu'): the tape's node is TorchLULayer itself (lqp_py/lu_layer.py:25-58 -- forward lu_solve with the
+// cached factor, backward dxv_k = M^-1 (-xvbar_k) with the SAME factor, Mbar += dxv_k xv_k^T, rhsbar_k = -dxv_k), xv = [x; nu].
+// One workgroup per QP streams the packed factor (lqp_trsv.hpp) through two triangular solves per x-update: T solves to replay
+// the loop, T to walk it back -- the launches and the host round trips of the eager tape (~30 torch ops per iteration, a
+// rocBLAS product per check) are gone.  n + m to the LU tier's limit: a thread keeps four elements of every n-vector in registers.
+//   Qsbar = sum_k dxx_k x_k^T (k_unroll_outer / k_unroll_outer_any),  Asbar = sum_k dnu_k x_k^T + nu_k dxx_k^T and bsbar = -sum_k dnu_k
+//   (k_unroll_lu_eq, from the scratch rows), the rest as above.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct UnrollLuParams {
+    int T_;                 // recorded x-updates = iters + 1
+    const T* g;             // (B, n): dL/dx of the returned (unscaled) solution
+    T *X, *W, *DX;          // (B, T, n) scratch: x_k | z_k - u_k | x part of dxv_k
+    T *NU, *DNU;            // (B, T, m) scratch: nu_k | nu part of dxv_k
+    signed char* MK;        // (B, T, n) scratch: the clamp decisions
+    T *dps, *dlbs, *dubs, *dD;     // (B, n) outputs
+    T *dAs, *dbs;           // (B, m, n), (B, m) outputs (or null when m == 0)
+    T* drho;                // (B) output
+};
+// LDS: v[Np] | tmp[64] | red[NW] | dest[Np] (int)
+template <typename T> __host__ __device__ inline int unroll_lu_lds_bytes(int Np) { return (Np + 64 + LQP_NW) * (int)sizeof(T) + Np * 4; }
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P, const UnrollLuParams<T> U) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    constexpr int NT = LQP_NT, EPT = 4;               // n + m <= 4096: element tid + q NT of every vector, q < 4
+    const int b = blockIdx.x, n = P.n, m = P.m, N = P.N, K = P.K, Np = P.Np, TT = U.T_;
+    const int tid = threadIdx.x;
+    T* v = (T*)smem;
+    T* tmp = v + Np;
+    T* red = tmp + 64;
+    int* dest = (int*)(red + LQP_NW);
+    VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
+    const T rho = P.scal[(size_t)b * SC_WORDS + SC_RHO];
+    const T* packed = P.packed + (size_t)b * packed_blocks(K) * LQP_BLK;
+    const int mm = m > 0 ? m : 1;
+    T* X = U.X + (size_t)b * TT * n;
+    T* Wd = U.W + (size_t)b * TT * n;
+    T* DX = U.DX + (size_t)b * TT * n;
+    T* NU = U.NU + (size_t)b * TT * mm;
+    T* DNU = U.DNU + (size_t)b * TT * mm;
+    signed char* MK = U.MK + (size_t)b * TT * n;
+
+    BlockStream<T, NT> st;
+    stream_prime<T, NT>(st, packed, K * (K + 1));
+    for (int i = tid; i < Np; i += NT) dest[i] = P.dest[(size_t)b * Np + i];
+    T psi[EPT], lbi[EPT], ubi[EPT], zi[EPT], ui[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid + q * NT;
+        const bool live = i < n;
+        psi[q] = live ? V.ps[i] : T(0); lbi[q] = live ? V.lbs[i] : T(0); ubi[q] = live ? V.ubs[i] : T(0);
+        zi[q] = T(0); ui[q] = T(0);
+    }
+    __syncthreads();
+
+    // ---- replay of the forward loop (:258-282): x_k, nu_k, z_k - u_k and the clamp decisions ----
+    for (int k = 0; k < TT; ++k) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * NT;
+            if (i < Np) {
+                T val = T(0);
+                if (i < n) {
+                    const T wd = zi[q] - ui[q];
+                    Wd[(size_t)k * n + i] = wd;
+                    val = -psi[q] + rho * wd;
+                } else if (i < N) val = V.bs[i - n];
+                v[dest[i]] = val;
+            }
+        }
+        wg_barrier_lds();
+        wg_packed_solve<T, NT>(st, packed, K, v, tmp, true);
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * NT;
+            if (i < n) {
+                const T xi = v[i];
+                X[(size_t)k * n + i] = xi;
+                const T s = xi + ui[q];
+                const T zn = tmin(tmax(s, lbi[q]), ubi[q]);
+                MK[(size_t)k * n + i] = (signed char)(tmax(s, lbi[q]) > ubi[q] ? 1 : (s < lbi[q] ? -1 : 0));      // (maximum first, then minimum: :273-276)
+                ui[q] = ui[q] + (xi - zn);
+                zi[q] = zn;
+            } else if (i < N) NU[(size_t)k * m + (i - n)] = v[i];
+        }
+        wg_barrier_lds();
+    }
+
+    // ---- reverse sweep ----
+    T gi[EPT], di[EPT], ubar[EPT], zbar[EPT], pbar[EPT], lbbar[EPT], ubbar[EPT];
+    T rho_part = T(0);
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid + q * NT;
+        const bool live = i < n;
+        gi[q] = live ? U.g[(size_t)b * n + i] : T(0);
+        di[q] = live ? V.D[i] : T(0);
+        ubar[q] = zbar[q] = pbar[q] = lbbar[q] = ubbar[q] = T(0);
+    }
+    __syncthreads();                                       // (the scratch rows above are read back by their writers only)
+    for (int k = TT - 1; k >= 0; --k) {
+        T unew[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * NT;
+            unew[q] = T(0);
+            if (i < Np) {
+                T val = T(0);
+                if (i < n) {
+                    const int code = (int)MK[(size_t)k * n + i];
+                    const T zt = zbar[q] - ubar[q];
+                    const T wfree = code == 0 ? zt : T(0);
+                    lbbar[q] += code < 0 ? zt : T(0);
+                    ubbar[q] += code > 0 ? zt : T(0);
+                    unew[q] = wfree + ubar[q];
+                    val = -(unew[q] + (k == TT - 1 ? di[q] * gi[q] : T(0)));      // rhs = -xvbar_k (its nu part is zero: nu is not an output)
+                }
+                v[dest[i]] = val;
+            }
+        }
+        wg_barrier_lds();
+        wg_packed_solve<T, NT>(st, packed, K, v, tmp, true);
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * NT;
+            if (i < n) {
+                const T dxx = v[i];
+                const T xk = X[(size_t)k * n + i];
+                DX[(size_t)k * n + i] = dxx;
+                pbar[q] += dxx;
+                rho_part += dxx * (xk - Wd[(size_t)k * n + i]);
+                zbar[q] = -rho * dxx;
+                ubar[q] = unew[q] + rho * dxx;
+            } else if (i < N) DNU[(size_t)k * m + (i - n)] = v[i];
+        }
+        wg_barrier_lds();
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid + q * NT;
+        if (i < n) {
+            U.dps[(size_t)b * n + i] = pbar[q];
+            U.dlbs[(size_t)b * n + i] = lbbar[q];
+            U.dubs[(size_t)b * n + i] = ubbar[q];
+            U.dD[(size_t)b * n + i] = gi[q] * X[(size_t)(TT - 1) * n + i];
+        }
+    }
+    const T rsum = wg_sum(rho_part, red);
+    if (tid == 0) U.drho[b] = rsum;
+}
+
+// Asbar[b][r][i] = sum_k DNU[k][r] X[k][i] + NU[k][r] DX[k][i],  bsbar[b][r] = -sum_k DNU[k][r]   (gridDim = (B, slabs over m n))
+template <typename T>
+__global__ __launch_bounds__(256) void k_unroll_lu_eq(const UnrollLuParams<T> U, const int n, const int m) {
+    const int b = blockIdx.x, TT = U.T_;
+    const T* X = U.X + (size_t)b * TT * n;
+    const T* DX = U.DX + (size_t)b * TT * n;
+    const T* NU = U.NU + (size_t)b * TT * m;
+    const T* DNU = U.DNU + (size_t)b * TT * m;
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < m * n; t += gridDim.y * 256) {
+        const int r = t / n, i = t - r * n;
+        T acc = T(0);
+        for (int k = 0; k < TT; ++k) acc += DNU[(size_t)k * m + r] * X[(size_t)k * n + i] + NU[(size_t)k * m + r] * DX[(size_t)k * n + i];
+        U.dAs[((size_t)b * m + r) * n + i] = acc;
+    }
+    if (blockIdx.y == 0)
+        for (int r = threadIdx.x; r < m; r += 256) {
+            T acc = T(0);
+            for (int k = 0; k < TT; ++k) acc -= DNU[(size_t)k * m + r];
+            U.dbs[(size_t)b * m + r] = acc;
+        }
+}
+
+// Qsbar[b] = sum_k DX[b][k][:]^T X[b][k][:] in any dtype (the float32 tile kernel above, typed): 64 x 64 tile per 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void k_unroll_outer_any(const T* __restrict__ DXall, const T* __restrict__ Xall,
+                                                          T* __restrict__ out, const int n, const int TT) {
+    __shared__ T sa[16][64 + 4], sb[16][64 + 4];
+    const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const T* DX = DXall + (size_t)b * TT * n;
+    const T* X = Xall + (size_t)b * TT * n;
+    T acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = T(0);
+    for (int k0 = 0; k0 < TT; k0 += 16) {
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, j = e & 63;
+            const bool ok = k0 + kk < TT;
+            sa[kk][j] = (ok && r0 + j < n) ? DX[(size_t)(k0 + kk) * n + r0 + j] : T(0);
+            sb[kk][j] = (ok && c0 + j < n) ? X[(size_t)(k0 + kk) * n + c0 + j] : T(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            T av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = sa[kk][ty * 4 + a]; bv[a] = sb[kk][tx * 4 + a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] += av[a] * bv[c];
+        }
+        __syncthreads();
+    }
+    T* o = out + (size_t)b * n * n;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int r = r0 + ty * 4 + a;
+        if (r < n) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cc = c0 + tx * 4 + c;
+                if (cc < n) o[(size_t)r * n + cc] = acc[a][c];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The scaling (:160-203) behind the unrolled loop: what of its derivative touches the B x n x n tensors.
 //
 // The reference lets autograd tape the pre-conditioning too; of its ~25 operations four walk over Q-sized tensors

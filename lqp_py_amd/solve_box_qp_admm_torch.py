@@ -571,7 +571,8 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
             # reference's algorithm -- the pivoted LU -- takes the solve, as a one-call synchronous forward does by itself
             _lib._pinned_free.setdefault(report.numel(), []).append(report)
             return _forward_solve(Q, p, A, b, lb, ub, dict(control, linsolve='lu', _owner=owner), bounds=bounds, sync=sync,
-                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder, while_running=while_running)
+                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder, private_ws=private_ws,
+                                  keep_factor=keep_factor, while_running=while_running)
     if st != 0 or (check_hook is not None and hook_error):
         # kernels of the failed call may still be in flight, and they write their report into `report`: wait before the
         # pinned buffer goes back to the pool (cold path)
@@ -588,7 +589,8 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
             if has[0] or has[1]:
                 _remember_any_bound(holder, owner, True)
                 return _forward_solve(Q, p, A, b, lb, ub, control, bounds=has, sync=sync, residuals=residuals,
-                                      check_hook=check_hook, mutate=mutate, holder=holder, while_running=while_running)
+                                      check_hook=check_hook, mutate=mutate, holder=holder, private_ws=private_ws,
+                                      keep_factor=keep_factor, while_running=while_running)
         # the reference's torch.linalg.lu_factor raises on an exactly singular KKT matrix (:215)
         raise RuntimeError(f"lqp_py_amd.torch_solve_box_qp: LU factorisation hit an exactly zero pivot "
                            f"(batch index {stats.fail_index}); the KKT matrix is singular")
@@ -609,7 +611,8 @@ def _forward_solve(Q, p, A, b, lb, ub, control, bounds=None, sync=True, residual
         _remember_any_bound(holder, owner, seen)
         if seen != any_bound:
             return _forward_solve(Q, p, A, b, lb, ub, control, bounds=(bool(stats.any_lb), bool(stats.any_ub)), sync=sync,
-                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder, while_running=while_running)
+                                  residuals=residuals, check_hook=check_hook, mutate=mutate, holder=holder, private_ws=private_ws,
+                                  keep_factor=keep_factor, while_running=while_running)
     if mutate and not any_bound:
         control['rho'] = owner['rho'] = 0          # written into the CALLER's dict, as the reference does (:37-38)
     if r['verbose']:

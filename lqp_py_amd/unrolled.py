@@ -2,14 +2,15 @@
 module here, :216-219/:255-256/:264-265 swap the plain LU solve for the ``TorchLU`` layer so that autograd tapes every
 iteration).
 
-Native path (float32, symmetric x-update, no adaptive-rho refactorisation -- the benchmark case): the forward is the
-ordinary persistent HIP solve; the backward is ONE reverse sweep over the recorded iterations in the HIP library
-(``lqp_boxqp_unroll_backward``, csrc/lqp_unroll.hpp): per iteration one product with the cached inverse instead of a taped
-``TorchLULayer`` node, no per-iteration torch op, no host sync.  The kernel differentiates the loop, i.e. it returns the
+Native path (one factor for the whole solve, i.e. no adaptive-rho refactorisation): the forward is the ordinary persistent HIP
+solve; the backward is ONE reverse sweep over the recorded iterations in the HIP library (csrc/lqp_unroll.hpp): float32 on the
+symmetric x-update (the benchmark case) ``lqp_boxqp_unroll_backward`` -- per iteration one product with the cached inverse --,
+the pivoted-LU x-update (float64, m > 16, non-symmetric Q, ``linsolve='lu'``) ``lqp_boxqp_unroll_backward_lu`` -- per iteration the
+two cached triangular solves of ``TorchLULayer`` --: no taped node, no per-iteration torch op, no host sync.  The kernel differentiates the loop, i.e. it returns the
 gradients w.r.t. the SCALED problem (Qs, ps, As, bs, lbs, ubs, rho, D); the scaling itself (:160-203: ~25 element-wise /
 reduction ops, once per call) is differentiated by autograd on a small eager graph rebuilt in ``backward``.
 
-Everything else (float64, a matrix outside the symmetric x-update, a solve in which rho was adapted, no finite bound)
+What is left (a solve in which rho was adapted -- the reference's tape then runs through the adaptation itself --, no finite bound)
 takes the eager path below: the loop as torch ops with ``TorchLU`` (HIP LU factor / cached solves) as the taped solve.
 """
 import ctypes
@@ -87,11 +88,14 @@ class _UnrolledLoop(torch.autograd.Function):
         lib = _lib.load()
         B, n = Q.shape[0], p.shape[1]
         m = get_ncon(A, dim=1)
-        ws = torch.empty(int(lib.lqp_boxqp_forward_workspace_bytes(_lib.LQP_F32, B, n, m)), dtype=torch.uint8, device=p.device)
+        ws = torch.empty(int(lib.lqp_boxqp_forward_workspace_bytes(_lib.dtype_code(p), B, n, m)), dtype=torch.uint8, device=p.device)
         sol = _forward_solve(Q, p, A, b, lb, ub, control, bounds=bounds, sync=True, private_ws=ws, keep_factor=True)
         st = sol['_stats']
-        if st['linsolve_used'] != 2 or st['n_factor'] != 1:
+        # one factor for the whole solve: the symmetric x-update (float32: the packed inverse) or the pivoted LU (any dtype: the packed
+        # factor, lqp_boxqp_unroll_backward_lu); a solve in which rho was adapted keeps the eager tape
+        if st['n_factor'] != 1 or st['linsolve_used'] not in (1, 2) or (st['linsolve_used'] == 2 and p.dtype != torch.float32):
             raise _NotNative()
+        ctx.lu = st['linsolve_used'] == 1
         ctx.ws, ctx.iters, ctx.r, ctx.has_box = ws, int(st['iters']), r, bool(bounds[0] or bounds[1])
         ctx.rho_fwd = sol['rho'] if torch.is_tensor(sol['rho']) else None      # (B,1,1): clamp(||Qs||_F / sqrt(n)) when rho was not given
         ctx.save_for_backward(Q, p, A, b, lb, ub)
@@ -110,16 +114,26 @@ class _UnrolledLoop(torch.autograd.Function):
         dps, dlbs, dubs, dD, drho = mk(B, n, 1), mk(B, n, 1), mk(B, n, 1), mk(B, n, 1), mk(B, 1, 1)
         dAs, dbs = (mk(B, m, n), mk(B, m, 1)) if m > 0 else (None, None)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        nbytes = lib.lqp_boxqp_unroll_backward_workspace_bytes(B, n, m, ctx.iters)
-        scratch = _lib.workspace(dev, nbytes, "unroll", stream)
         gc = _lib.norm(g, dt)
-        with _lib.on_device(dev):
-            _lib.check(lib.lqp_boxqp_unroll_backward(
-                ctypes.c_void_p(stream), B, n, m, _lib.ptr(ctx.ws), ctx.ws.numel(), ctx.iters, _lib.ptr(gc),
-                _lib.ptr(dQs), _lib.ptr(dps), _lib.ptr(dAs), _lib.ptr(dbs), _lib.ptr(dlbs), _lib.ptr(dubs),
-                _lib.ptr(drho), _lib.ptr(dD), _lib.ptr(scratch), scratch.numel()), "unroll_backward")
+        if ctx.lu:
+            dtc = _lib.dtype_code(p)
+            nbytes = lib.lqp_boxqp_unroll_backward_lu_workspace_bytes(dtc, B, n, m, ctx.iters)
+            scratch = _lib.workspace(dev, nbytes, "unroll", stream)
+            with _lib.on_device(dev):
+                _lib.check(lib.lqp_boxqp_unroll_backward_lu(
+                    ctypes.c_void_p(stream), dtc, B, n, m, _lib.ptr(ctx.ws), ctx.ws.numel(), ctx.iters, _lib.ptr(gc),
+                    _lib.ptr(dQs), _lib.ptr(dps), _lib.ptr(dAs), _lib.ptr(dbs), _lib.ptr(dlbs), _lib.ptr(dubs),
+                    _lib.ptr(drho), _lib.ptr(dD), _lib.ptr(scratch), scratch.numel()), "unroll_backward_lu")
+        else:
+            nbytes = lib.lqp_boxqp_unroll_backward_workspace_bytes(B, n, m, ctx.iters)
+            scratch = _lib.workspace(dev, nbytes, "unroll", stream)
+            with _lib.on_device(dev):
+                _lib.check(lib.lqp_boxqp_unroll_backward(
+                    ctypes.c_void_p(stream), B, n, m, _lib.ptr(ctx.ws), ctx.ws.numel(), ctx.iters, _lib.ptr(gc),
+                    _lib.ptr(dQs), _lib.ptr(dps), _lib.ptr(dAs), _lib.ptr(dbs), _lib.ptr(dlbs), _lib.ptr(dubs),
+                    _lib.ptr(drho), _lib.ptr(dD), _lib.ptr(scratch), scratch.numel()), "unroll_backward")
         ctx.ws = None
-        if need[0] and os.environ.get("LQP_UNROLL_SCALE_NATIVE", "1") != "0":
+        if need[0] and dt == torch.float32 and os.environ.get("LQP_UNROLL_SCALE_NATIVE", "1") != "0":
             return _scaling_backward_native(ctx, lib, stream, (Q, p, A, b, lb, ub), need,
                                             dict(dQs=dQs, dps=dps, dAs=dAs, dbs=dbs, dlbs=dlbs, dubs=dubs, dD=dD, drho=drho))
         # ---- the scaling (:160-203) by autograd: leaves -> (Qs, ps, As, bs, lbs, ubs, D, rho) ----
@@ -237,7 +251,7 @@ class _NotNative(Exception):
 def unrolled_solve_box_qp(Q, p, A, b, lb, ub, r, has_lb, has_ub, control=None):
     """``r`` is the resolved control (solve_box_qp_admm_torch.resolve_control). Returns x only,
     as the reference does in unroll mode (:328-329)."""
-    if (control is not None and p.dtype == torch.float32 and (has_lb or has_ub) and r['linsolve'] != 'lu'
+    if (control is not None and p.dtype in (torch.float32, torch.float64) and (has_lb or has_ub)
             and os.environ.get("LQP_UNROLL_NATIVE", "1") != "0"):
         try:
             ctl = {k: v for k, v in control.items() if k != 'unroll'}

@@ -1496,8 +1496,9 @@ def test_unroll_sweep_on_two_workgroups(dev, monkeypatch, n, B, m):
 
 
 def test_unroll_native_falls_back(dev):
-    """What the reverse sweep does not cover takes the taped loop by itself: float64, the cached-LU x-update, a solve in
-    which rho was adapted (the factor is no longer constant along the tape)."""
+    """Which tape runs where: float64 and the cached-LU x-update take the reverse sweep on the packed LU factor (round 6:
+    lqp_boxqp_unroll_backward_lu -- sweep, equality rows, outer product: three launches); a solve in which rho was adapted (the
+    factor is no longer constant along the tape) takes the taped loop by itself."""
     g = load_golden("g13_unroll")
     for kind in ("f64", "lu", "adapted"):
         cast = (lambda t: t.double()) if kind == "f64" else (lambda t: t)
@@ -1512,7 +1513,7 @@ def test_unroll_native_falls_back(dev):
         x = L.SolveBoxQP(control=ctl)(*leaves)
         x.backward(cast(g["cot"]).to(dev))
         used = _lib.profile(); _lib.profile(enable=False)
-        assert used["unroll_backward"][1] == 0 and used["lu_factor"][1] >= 1, (kind, used)
+        assert used["unroll_backward"][1] == (0 if kind == "adapted" else 3) and used["lu_factor"][1] >= 1, (kind, used)
         assert all(torch.isfinite(t.grad).all() for t in leaves), kind
         if kind != "adapted":
             assert err(x, cast(g["x"])) < 2e-5, kind
@@ -2536,6 +2537,60 @@ def test_unroll_native_against_the_taped_loop(dev, monkeypatch, n, B, m):
             assert g0 is None
             continue
         close_or_fp64(f"unroll_vs_tape_n{n}_m{m}", nm, g1, g0, t64.grad, G_RTOL)
+
+
+@pytest.mark.parametrize("n,B,m,dtype,kind", [(60, 3, 0, torch.float64, "auto"), (96, 4, 3, torch.float64, "auto"), (120, 2, 20, torch.float32, "auto"),
+                                              (200, 2, 1, torch.float32, "lu"), (150, 2, 2, torch.float32, "nonsym"), (250, 4, 16, torch.float64, "auto"),
+                                              (1100, 1, 2, torch.float32, "auto")])
+def test_unroll_on_the_lu_tape_against_the_taped_loop(dev, monkeypatch, n, B, m, dtype, kind):
+    """unroll=True where the x-update is the pivoted LU -- float64, more than 16 equality rows, linsolve='lu', a non-symmetric Q, more
+    than 1024 rows: the reverse sweep on the packed factor (lqp_boxqp_unroll_backward_lu; the tape's node is TorchLULayer,
+    lqp_py/lu_layer.py:25-58) against the taped loop of torch ops it replaces (lqp_py/solve_box_qp_admm_torch.py:235-313 under
+    unroll): the same solution, all gradients within rtol 1e-4 of scale in float32 (the float64 tape on the host as arbiter), 1e-8
+    in float64."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + 7 * m, with_eq=False)
+    gen = torch.Generator().manual_seed(n + m)
+    if kind == "nonsym":
+        Q = Q + 0.02 * torch.triu(torch.randn(B, n, n, generator=gen), 1)
+    A = torch.randn(B, m, n, generator=gen) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=gen) if m else None
+    cot = torch.randn(B, n, 1, generator=gen)
+    names = ("Q", "p", "A", "b", "lb", "ub")
+    data = dict(zip(names, (Q, p, A, b, lb, ub)))
+    ctl = L.box_qp_control(unroll=True, **TOL)
+    if kind == "lu":
+        ctl["linsolve"] = "lu"
+    grads = {}
+    for native in ("1", "0"):
+        monkeypatch.setenv("LQP_UNROLL_NATIVE", native)
+        leaves = [None if data[k] is None else data[k].to(dtype).to(dev).requires_grad_(True) for k in names]
+        _lib.profile(enable=True, reset=True)
+        x = L.SolveBoxQP(control=dict(ctl))(*leaves)
+        x.backward(cot.to(dtype).to(dev))
+        used = _lib.profile(); _lib.profile(enable=False)
+        assert used["unroll_backward"][1] == ((3 if m else 2) if native == "1" else 0), (native, used["unroll_backward"])
+        grads[native] = (x.detach(), [None if t is None else t.grad for t in leaves])
+    case = f"unroll_lu_tape_n{n}_m{m}_{kind}_{'f32' if dtype == torch.float32 else 'f64'}"
+    if dtype == torch.float64:
+        assert err(grads["1"][0], grads["0"][0]) < 1e-9
+        for nm, g1, g0 in zip(GRADS, grads["1"][1], grads["0"][1]):
+            if g1 is None:
+                assert g0 is None
+                continue
+            e = err(g1, g0) / max(1.0, float(g0.abs().max()))
+            P.record(case, nm, e)
+            assert e < 1e-8, (nm, e)
+        return
+    from lqp_py_amd.unrolled import _eager_unrolled
+    l64 = [None if data[k] is None else data[k].double().requires_grad_(True) for k in names]
+    x64 = _eager_unrolled(*l64, SB.resolve_control(dict(ctl), n), True, True, solver_cls=_CpuLU)
+    x64.backward(cot.double())
+    close_or_fp64(case, "x", grads["1"][0], grads["0"][0], x64.detach(), X_TOL)
+    for nm, g1, g0, t64 in zip(GRADS, grads["1"][1], grads["0"][1], l64):
+        if g1 is None:
+            assert g0 is None
+            continue
+        close_or_fp64(case, nm, g1, g0, t64.grad, G_RTOL)
 
 
 @pytest.mark.parametrize("n,B,m,dtype", [(1100, 2, 0, torch.float32), (1030, 2, 20, torch.float32), (1200, 1, 2, torch.float64)])
