@@ -323,12 +323,14 @@ int launch_lu2(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* 
 template <typename T>
 int launch_lu_wide(hipStream_t st, T* M, int B, int N, int ld, size_t mstride, int* piv, int pstride, int* info,
                    const int* gate, const int* nvec, unsigned long long* scr, size_t scr_stride) {
-    if (!scr || t_single_wg_lu || 2 * scr_stride < luw_scratch_words<T>(N) || N <= knobs().lu_wide_min || N > 2048 || knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 ||
-        (((uintptr_t)M) % 128) != 0)
+    const bool tall = N > 2048;          // float32 only: sixteen panel rows per thread, panels of 4 columns
+    if (!scr || t_single_wg_lu || 2 * scr_stride < luw_scratch_words<T>(N) || N <= knobs().lu_wide_min || N > (sizeof(T) == 4 ? 4096 : 2048) ||
+        knobs().lu_wide == 0 || (ld % 32) != 0 || (mstride % 32) != 0 || (((uintptr_t)M) % 128) != 0)
         return -1;
     int dev = 0, cus = 0, per_cu = 0;
     auto fn = k_lu_factor_wide<T>;
-    const int lds = LuLds<T, luw_pb<T>()>(round_up(N, 64)).total;
+    if constexpr (sizeof(T) == 4) { if (tall) fn = k_lu_factor_wide_tall<T>; }
+    const int lds = tall ? LuLds<T, 4>(round_up(N, 64)).total : LuLds<T, luw_pb<T>()>(round_up(N, 64)).total;
     if (!current_device_cus(&dev, &cus) || ensure_lds((const void*)fn, lds) != LQP_OK ||
         !blocks_per_cu(&per_cu, fn, LQP_NT, lds, dev) || per_cu < 1)
         return -1;

@@ -1,4 +1,4 @@
-// Pivoted LU above the one-row-per-thread tier (1024 < N <= 2048) on SEVERAL workgroups per matrix, for batches that leave the
+// Pivoted LU above the one-row-per-thread tier (1024 < N <= 2048; float32 to 4096: k_lu_factor_wide_tall) on SEVERAL workgroups per matrix, for batches that leave the
 // chip idle (B = 8, n = 1500: the one-workgroup kernel of lqp_lu_big.hpp streams the trailing matrix through ONE CU 188 times --
 // 25 ms per factorisation, 34 of the 47 ms of a forward + backward step).  Same right-looking algorithm, LAPACK layout and pivot
 // rule (replaces torch.linalg.lu_factor at lqp_py/solve_box_qp_admm_torch.py:215,254, lqp_py/lu_layer.py:10,31), float32.
@@ -43,16 +43,18 @@ __device__ __forceinline__ bool luw_wait_eq(const int* p, const unsigned int wan
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(T* __restrict__ Mall, const int Nuni, const int ld, const size_t mstride,
-                                                           int* __restrict__ piv, const int pstride, int* __restrict__ info_all,
-                                                           const int* __restrict__ gate, const int* __restrict__ Nvec,
-                                                           int* __restrict__ scr_all, const size_t scr_stride, const unsigned int epoch,
-                                                           const int B, unsigned long long* __restrict__ dbg) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
-    constexpr int PB = luw_pb<T>(), NT = LQP_NT, TW = luw_tw<T>(), NV = PB / 4;
-    constexpr int R = 8, NTP = 256;           // the panel: waves 0..3, eight rows per thread (sixteen waves with two rows each share four SIMDs:
+// PB: panel width, R: panel rows per thread of waves 0..3 (R * 256 rows: 8 -> N <= 2048; float32 above, to 4096: R = 16 with panels of 4
+// columns -- the LDS holds 2 * PB * N elements of a panel; the message slots keep the size of the 8-column form)
+template <typename T, int PB, int R>
+__device__ __forceinline__ void wg_lu_factor_wide(T* __restrict__ Mall, const int Nuni, const int ld, const size_t mstride,
+                                                  int* __restrict__ piv, const int pstride, int* __restrict__ info_all,
+                                                  const int* __restrict__ gate, const int* __restrict__ Nvec,
+                                                  int* __restrict__ scr_all, const size_t scr_stride, const unsigned int epoch,
+                                                  const int B, unsigned long long* __restrict__ dbg, char* __restrict__ smem) {
+    constexpr int NT = LQP_NT, TW = luw_tw<T>(), NV = PB / 4;
+    constexpr int NTP = 256;                  // the panel: waves 0..3, R rows per thread (sixteen waves with two rows each share four SIMDs:
                                               // 7 k cycles per column; four waves alone on theirs: see DESIGN.md)
+    static_assert(PB <= luw_pb<T>() && PB % 4 == 0, "the message slots are sized for the widest panel");
     if (gate && *gate == 0) return;
     const int b = (int)blockIdx.x % B, y = (int)blockIdx.x / B, W = (int)gridDim.x / B;
     const int N = Nvec ? Nvec[b] : Nuni;
@@ -363,6 +365,27 @@ __global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(T* __restrict__ Mall,
         return;
     }
     if (tid == 0 && y == 0 && first_zero != 0) info_all[b] = first_zero;
+}
+
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide(T* __restrict__ Mall, const int Nuni, const int ld, const size_t mstride,
+                                                           int* __restrict__ piv, const int pstride, int* __restrict__ info_all,
+                                                           const int* __restrict__ gate, const int* __restrict__ Nvec,
+                                                           int* __restrict__ scr_all, const size_t scr_stride, const unsigned int epoch,
+                                                           const int B, unsigned long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    wg_lu_factor_wide<T, luw_pb<T>(), 8>(Mall, Nuni, ld, mstride, piv, pstride, info_all, gate, Nvec, scr_all, scr_stride, epoch, B, dbg, smem);
+}
+
+// 2048 < N <= 4096, float32: sixteen panel rows per thread, panels of 4 columns
+template <typename T>
+__global__ __launch_bounds__(LQP_NT) void k_lu_factor_wide_tall(T* __restrict__ Mall, const int Nuni, const int ld, const size_t mstride,
+                                                                int* __restrict__ piv, const int pstride, int* __restrict__ info_all,
+                                                                const int* __restrict__ gate, const int* __restrict__ Nvec,
+                                                                int* __restrict__ scr_all, const size_t scr_stride, const unsigned int epoch,
+                                                                const int B, unsigned long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    wg_lu_factor_wide<T, 4, 16>(Mall, Nuni, ld, mstride, piv, pstride, info_all, gate, Nvec, scr_all, scr_stride, epoch, B, dbg, smem);
 }
 
 }  // namespace lqp

@@ -221,6 +221,7 @@ def test_register_budgets_of_the_hot_kernels():
                 # workgroups (192 float32 columns per thread: 9 registers outside the product; 64 float64 columns: none), the two-workgroup
                 # unroll sweep and the scaling-chain kernels (none)
                 "lqp::k_lu_factor_wide<float>": (12, 48), "lqp::k_lu_factor_wide<double>": (0, 320),
+                "lqp::k_lu_factor_wide_tall<float>": (17, 336),      # (round 6: 2048 < N <= 4096, sixteen panel rows per thread)
                 "lqp::k_admm_loop_dense_w<float>": (9, 40), "lqp::k_admm_loop_dense_w<double>": (0, 0),
                 "lqp::k_unroll_sweep_split<8, 1>": (0, 0), "lqp::k_unroll_sweep_split<8, 16>": (0, 0), "lqp::k_unroll_sweep_split<7, 16>": (0, 0),
                 "lqp::k_unroll_scale_grad<0>": (0, 0), "lqp::k_unroll_scale_vectors<0>": (0, 0), "lqp::k_lu_inverse<float, true>": (0, 0)}

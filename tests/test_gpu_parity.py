@@ -161,9 +161,10 @@ def test_inverse_from_the_packed_factor(dev, N, B, dtype):
 
 
 @pytest.mark.parametrize("N,B,dtype", [(1100, 3, torch.float32), (1500, 8, torch.float32), (2048, 2, torch.float32), (1030, 5, torch.float32),
-                                       (1100, 2, torch.float64), (1501, 4, torch.float64), (2048, 1, torch.float64)])
+                                       (1100, 2, torch.float64), (1501, 4, torch.float64), (2048, 1, torch.float64),
+                                       (2049, 2, torch.float32), (3001, 2, torch.float32), (4096, 1, torch.float32)])
 def test_lu_wide_matches_one_workgroup(dev, monkeypatch, N, B, dtype):
-    """csrc/lqp_lu_wide.hpp: above 1024 rows, float32, the batch leaving the chip idle: the pivoted LU on W = #CUs / B workgroups per
+    """csrc/lqp_lu_wide.hpp: above 1024 rows (float32 to 4096: k_lu_factor_wide_tall, sixteen panel rows per thread), the batch leaving the chip idle: the pivoted LU on W = #CUs / B workgroups per
     matrix (32-column tiles owned cyclically, the factored panel handed round as a message) against the one-workgroup kernel
     (LQP_LU_WIDE=0): the same pivots; float32: the arithmetic per element being the same, the same factor bit for bit; float64 (the
     trailing update on v_mfma_f64_16x16x4 where the one-workgroup kernel multiplies in registers): to rounding, pivots LAPACK's.
