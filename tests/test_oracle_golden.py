@@ -160,6 +160,20 @@ def test_g18_hard_distribution_fp64_at_the_benched_size():
     close(torch.linalg.matrix_norm(grads[0]), g["dQ_fro"], 1e-7, 1e-7)
 
 
+def test_g20_above_2048_rows():
+    """G20 (n = 3000, m = 1, B = 2, float32: above the 2048 rows that bounded the build until round 6): the oracle against the
+    reference's run -- the same torch.linalg calls in the same order, so the same iteration count and iterates to float32 rounding."""
+    g = load_golden("g20_b2_n3000_eq")
+    Q, p, A, b, lb, ub = O.create_qp_data(3000, 2, seed=20)
+    sol = O.solve_box_qp(Q, p, A, b, lb, ub, O.make_control(**TOL))
+    assert sol["iter"] == g["iter"] == 50
+    for k in ("x", "u", "nus", "rho"):
+        close(sol[k], g[k], 1e-5, 1e-5)
+    grads = O.solve_box_qp_grad(g["cot"], sol["x"], sol["u"], sol["lams"], sol["nus"], Q, A, lb, ub, sol["rho"])
+    for nm in ("dp", "db", "dlb", "dub"):
+        close(grads[GRADS.index(nm)], g[nm], 1e-4, 1e-4)
+
+
 def test_kkt_conditions_known_answer():
     """Independent of the reference: returned (x, lams, nus) satisfy the KKT system."""
     Q, p, A, b, lb, ub = O.create_qp_data(40, 6, seed=21, dtype=torch.float64)
