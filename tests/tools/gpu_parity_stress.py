@@ -15,13 +15,13 @@ for n in (129, 190, 257, 320, 333, 400, 449, 500, 512):
         for m in (0, 1, 3, 16):
             cases.append((n, B, m))
 import random
-random.seed(1)
+random.seed(int(os.environ.get("SEED", "1")))
 random.shuffle(cases)
 cases = cases[:int(os.environ.get("NCASES", "60"))]
 t_start = time.time()
 for idx, (n, B, m) in enumerate(cases):
     kind = int(os.environ.get("KIND", idx % 4))
-    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=1000 + idx, with_eq=False)
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=1000 + idx + 7919 * int(os.environ.get("SEED", "1")), with_eq=False)
     g = torch.Generator().manual_seed(idx)
     A = torch.randn(B, m, n, generator=g) if m else None
     b = 0.1 * torch.randn(B, m, 1, generator=g) if m else None
