@@ -143,7 +143,7 @@ struct Knobs {
     int bwd_lookahead;         // LQP_BWD_LOOKAHEAD
     int inv_xcd;               // LQP_INV_XCD: the inverse's column tiles of one problem on one XCD (0: grid order)
     int dbg_lu2_absent;        // LQP_DBG_LU2_ABSENT: tests only -- the partner workgroups of the two-workgroup LU are not launched
-    int dbg_loop_absent;       // LQP_DBG_LOOP_ABSENT: tests only -- bit 0 ... of the two-workgroup loop, bit 1 ... of the resident sweep, bit 2 ... of the unroll sweep
+    int dbg_loop_absent;       // LQP_DBG_LOOP_ABSENT: tests only -- bit 0 ... of the two-workgroup loop, bit 1 ... of the resident sweep, bit 2 ... of the unroll sweep, bit 3 ... of the two-workgroup streaming loop
     int bwd_refine;            // LQP_BWD_REFINE
     int dbg_qpass;             // LQP_DBG_QPASS
     int dbg_setup;             // LQP_DBG_SETUP
@@ -157,6 +157,7 @@ struct Knobs {
     int loop_small;            // LQP_LOOP_SMALL
     int loop_split;            // LQP_LOOP_SPLIT
     int loop_split4;           // LQP_LOOP_SPLIT4
+    int loop_np2;              // LQP_LOOP_NP2
     int loop_split_seg;        // LQP_LOOP_SPLIT_SEG
     int lu2;                   // LQP_LU2
     int lu_wide;               // LQP_LU_WIDE
@@ -212,6 +213,7 @@ Knobs read_knobs() {
     k.loop_small = env_int("LQP_LOOP_SMALL", 1);
     k.loop_split = env_int("LQP_LOOP_SPLIT", 1);
     k.loop_split4 = env_int("LQP_LOOP_SPLIT4", 1);
+    k.loop_np2 = env_int("LQP_LOOP_NP2", 1);
     k.loop_split_seg = env_int("LQP_LOOP_SPLIT_SEG", 1);
     k.lu2 = env_int("LQP_LU2", 1);
     k.lu_wide = env_int("LQP_LU_WIDE", 1);
@@ -590,7 +592,8 @@ FwdLayout<T> carve_forward(void* ws, int B, int n, int m) {
     P.packed = c.take<T>((size_t)B * packed_blocks(P.K) * LQP_BLK);
     // granules of the two-workgroup loop (only ever used when 2 B workgroups fit the chip)
     // (only where a two-workgroup kernel can run at all: 32 KB per problem -- a batch of 8192 small problems used to carry 256 MB of it)
-    P.xchg = (sizeof(T) == 4 && B <= kSplitMaxB && P.Ks >= SPLIT_MINK && P.Ks <= SPD_MAXK)
+    // (above 512 rows: the streaming loop on two workgroups per problem, k_admm_loop_np2 -- batches that can leave half the chip idle)
+    P.xchg = (sizeof(T) == 4 && P.Ks >= SPLIT_MINK && ((B <= kSplitMaxB && P.Ks <= SPD_MAXK) || (B <= 256 && P.Ks <= SPD_BIGK)))
                  ? c.take<unsigned long long>((size_t)B * (XCHG_WORDS + XCHG_TAIL)) : nullptr;
     // granules of the dense LU-tier loop (lqp_dense.hpp): batches that can leave half a chip idle, n <= 256
     // granules of the dense LU-tier loops: two workgroups per problem to n = 256; W workgroups per problem for small batches at any
@@ -950,6 +953,19 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             loop_split = loop_np > 1;
         }
     }
+    // above 512 rows (BASELINE configs[3]: n = 1000): the streaming loop of the symmetric path with TWO workgroups per problem, each
+    // streaming one range of whole block columns of H (admm_loop_body_from, NP == 2): twice the registers and LDS under the same
+    // matrix (16 % -> 32 % of it on chip), half the stream per CU -- one CU alone pulls 58 GB/s, 29 us per iteration at n = 1000
+    bool loop_np2 = false;
+    if constexpr (sizeof(T) == 4) {
+        if (spd && mode == 2 && P.xchg && P.Ks > SPD_MAXK && P.Ks <= SPD_BIGK && loop_nt == 1024 && knobs().loop_np2 != 0 && !solo &&
+            !(retry & 2)) {
+            int dev = 0, cus = 0, per_cu = 0;
+            if (current_device_cus(&dev, &cus) && ensure_lds((const void*)k_admm_loop_np2<>, loop_lds) == LQP_OK &&
+                blocks_per_cu(&per_cu, k_admm_loop_np2<>, 1024, loop_lds, dev) && per_cu >= 1 && shared_grid(B, 2) <= cus * per_cu)
+                loop_np2 = true;
+        }
+    }
     // ... and for batches LARGER than half the CUs (BASELINE configs[4]: 1024 per GPU), where the loop runs one launch per
     // check segment anyway: the same kernel, its pairs taking turns on the chip (FwdParams::split_seg) -- a pair holds its
     // whole matrix in registers for the 15 iterations of a segment where the one-workgroup kernel streams two thirds of it
@@ -1040,6 +1056,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             }
             if (loop_small && it == 0) {
                 hipLaunchKernelGGL(k_admm_loop_small<>, dim3(B), dim3(256), small_lds, st, P, it, e, ctr_base);
+                return;
+            }
+            if (loop_np2 && it == 0) {
+                hipLaunchKernelGGL(k_admm_loop_np2<>, dim3((knobs().dbg_loop_absent & 8) ? B : shared_grid(B, 2)), dim3(1024), loop_lds, st, P, it, e, ctr_base, prev_slot, flags);
                 return;
             }
         }
@@ -1163,7 +1183,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     stats->any_lb = stats->any_ub = -1;
                     stats->linsolve_used = spd ? 2 : 1;
                     stats->factor_launches = factor_launches;
-                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : (loop_dense_w ? densew_W : 1));
+                    stats->loop_workgroups = loop_split ? loop_np : ((loop_dense || loop_np2) ? 2 : (loop_dense_w ? densew_W : 1));
                 }
                 return LQP_OK;
             }
@@ -1177,7 +1197,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     stats->any_lb = stats->any_ub = -1;
                     stats->linsolve_used = spd ? 2 : 1;
                     stats->factor_launches = factor_launches;
-                    stats->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : (loop_dense_w ? densew_W : 1));
+                    stats->loop_workgroups = loop_split ? loop_np : ((loop_dense || loop_np2) ? 2 : (loop_dense_w ? densew_W : 1));
                 }
                 return LQP_OK;
             }
@@ -1196,7 +1216,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
             lqp_boxqp_stats* so = stats ? stats : &local;
             memset(so, 0, sizeof(*so));
             so->n_launch = n_launch; so->linsolve_used = spd ? 2 : 1; so->factor_launches = factor_launches;
-            so->loop_workgroups = loop_split ? loop_np : (loop_dense ? 2 : (loop_dense_w ? densew_W : 1));
+            so->loop_workgroups = loop_split ? loop_np : ((loop_dense || loop_np2) ? 2 : (loop_dense_w ? densew_W : 1));
             rc = collect_report(st, rep, rep == P.host_report, B, max_iters, check, so);
             if (rc == LQP_ERR_TIMEOUT && !spd && !t_single_wg_lu && !(flags_timeout_loop(rep))) {      // a shared LU timed out: one workgroup per matrix
                 SingleWgLu only;
@@ -1385,7 +1405,7 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
         stats->mode_used = mode;
         stats->linsolve_used = spd ? 2 : 1;
         stats->factor_launches = spd ? (spd_big_split ? 2 * P.Ks + 2 : spd_split ? (spd_resident ? 3 : P.Ks + 2) : 1) : 2;
-        stats->loop_workgroups = (loop_split && mode == 2) ? loop_np : loop_split_seg ? 2 : 1;
+        stats->loop_workgroups = (loop_split && mode == 2) ? loop_np : (loop_split_seg || (loop_np2 && mode == 2)) ? 2 : 1;
         stats->any_lb = h_status[ST_ANY_LB]; stats->any_ub = h_status[ST_ANY_UB];
     }
     return LQP_OK;

@@ -1344,24 +1344,32 @@ __device__ __forceinline__ void fwd_finish(const FwdParams<T>& P, const int b) {
 // event inside [it0, it1), segment by segment.  Only this cold variant carries the factorisation code; the first
 // (hot) launch stays lean.
 // ---------------------------------------------------------------------------
-template <typename T, bool RES, bool TAIL, int NT, bool SYM>
+// NP == 2 (symmetric path above 512 rows, first launch, 2 B workgroups resident: k_admm_loop_np2): workgroups `part` = 0 / 1 of a
+// problem stream one RANGE of whole block columns of H each -- [0, jc) and [jc, Ks), about half of the blocks: twice the registers
+// and LDS under the same matrix, half the stream per CU -- and exchange their partial products every iteration as tagged 8-byte
+// granules (the hand-off of k_admm_loop_split: two buffers by iteration parity, tag = iteration + 1, the area zeroed by the setup
+// kernel), added in the fixed order part 0 + part 1: both hold bit-identical iterates and run the element-wise update and the
+// checks redundantly; part 0 alone reports to the counters and writes state.
+template <typename T, bool RES, bool TAIL, int NT, bool SYM, int NP = 1>
 __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int it0, const int it1, int ctr_base, int prev_slot,
                                                     const int persistent, char* smem);
-template <typename T, bool RES, bool TAIL, int NT, bool SYM = false>
+template <typename T, bool RES, bool TAIL, int NT, bool SYM = false, int NP = 1>
 __device__ __forceinline__ void admm_loop_body(const FwdParams<T>& P, const int it0, const int it1,
                                                const int ctr_base,       // counter slot of check it0 / check
                                                const int prev_slot,      // slot of the last check before it0, -1: none / known not done
                                                const int persistent, char* smem) {
-    const int b = blockIdx.x, n = P.n, m = P.m, N = P.N, Np = P.Np, K = P.K;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // every problem stopped at an earlier check -> nothing to do (break at :312)
     if (__hip_atomic_load(P.status + ST_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    admm_loop_body_from<T, RES, TAIL, NT, SYM>(P, it0, it1, ctr_base, prev_slot, persistent, smem);
+    admm_loop_body_from<T, RES, TAIL, NT, SYM, NP>(P, it0, it1, ctr_base, prev_slot, persistent, smem);
 }
-template <typename T, bool RES, bool TAIL, int NT, bool SYM>
+template <typename T, bool RES, bool TAIL, int NT, bool SYM, int NP>
 __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int it0, const int it1, int ctr_base, int prev_slot,
                                                     const int persistent, char* smem) {
-    const int b = blockIdx.x, n = P.n, m = P.m, N = P.N, Np = P.Np, K = P.K;
+    static_assert(NP == 1 || (NP == 2 && SYM && RES && !TAIL && NT == 1024 && sizeof(T) == 4), "two workgroups per problem: the hot symmetric loop only");
+    int b = blockIdx.x, part_id = 0;
+    if constexpr (NP == 2) { if (!shared_map((int)blockIdx.x, P.B, 2, b, part_id)) return; }
+    const bool lead = part_id == 0;                          // (the workgroup that reports and writes state)
+    const int n = P.n, m = P.m, N = P.N, Np = P.Np, K = P.K;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if constexpr (TAIL) {
         // persistent & 8: the hot two-workgroup loop ran past the first possible rho event (FwdParams::hot_past) and names the
@@ -1378,7 +1386,7 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
     if (prev_slot >= 0) {
         if (__hip_atomic_load(P.counters + (size_t)prev_slot * CT_WORDS + CT_NOTOPT, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            if (b == 0 && tid == 0) {
+            if (b == 0 && tid == 0 && lead) {
                 P.status[ST_FINAL_ITER] = it0 - 1;
                 __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1478,10 +1486,20 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
 
     BlockStream<T, NT> st;
     ResidentRegs<T, NT> rr;
+    // NP == 2: this workgroup's range of the stream -- block columns [rj0, ..), rsn blocks from stream index rs0
+    int rj0 = 0, rs0 = 0, rsn = -1;
+    if constexpr (NP == 2) {
+        int jc = 0, acc = 0;
+        while (jc < P.Ks && 2 * acc < S) { acc += P.Ks - jc; ++jc; }      // columns [0, jc): the first to reach half of the blocks
+        rj0 = part_id == 0 ? 0 : jc; rs0 = part_id == 0 ? 0 : acc; rsn = part_id == 0 ? acc : S - acc;
+    }
+    const T* packed_r = packed + (size_t)rs0 * LQP_BLK;
+    unsigned long long* const xq = NP == 2 ? P.xchg + (size_t)b * XCHG_WORDS : nullptr;
     if constexpr (SYM) {
         if constexpr (RES) {
-            sym_resident_load<NT>(rr, lds_res, packed, S, rl);
-            sym_prime<NT>(st, packed, (S < resident_regs<NT>() ? S : resident_regs<NT>()) + rl, S);
+            const int Sr_ = NP == 2 ? rsn : S;
+            sym_resident_load<NT>(rr, lds_res, packed_r, Sr_, rl);
+            sym_prime<NT>(st, packed_r, (Sr_ < resident_regs<NT>() ? Sr_ : resident_regs<NT>()) + rl, Sr_);
         }
     } else if constexpr (RES) {
         resident_load<T, NT>(rr, lds_res, packed);
@@ -1496,6 +1514,10 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
     for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
     if constexpr (SYM) {
         for (int i = tid; i < Nps; i += NT) cvl[i] = (i < n && m > 0) ? V.cv[i] : T(0);
+        if constexpr (NP == 2) {       // (slots and column sums of the partner's blocks are never written: they must read as zero)
+            for (int i = tid; i < S * 64; i += NT) ylds[i] = T(0);
+            for (int i = tid; i < (NT / 64) * Nps; i += NT) part[i] = T(0);
+        }
     } else {
         const int* gdest = P.dest + (size_t)b * Np;
         for (int i = tid; i < Np; i += NT) dest[i] = gdest[i];
@@ -1522,7 +1544,8 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
                 wg_barrier_lds();
             }
             if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
-            wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
+            if constexpr (NP == 2) wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed_r, P.Ks, Nps, v, ylds, part, rj0, rs0, rsn);
+            else wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
             wg_barrier_lds();
             if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
             T* nus_l = bs + m;
@@ -1537,7 +1560,38 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
             }
             if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
             for (int i = tid; i < Nps; i += NT) {
-                const T xi = cvl[i] - sym_combine<NT>(i, P.Ks, Nps, ylds, part);
+                T ysum = sym_combine<NT>(i, P.Ks, Nps, ylds, part);
+                if constexpr (NP == 2) {
+                    // this workgroup's partial out, the partner's in (one granule per element, thread i = element i)
+                    const unsigned int tag = (unsigned int)(it + 1);
+                    unsigned long long* base = xq + (size_t)(it & 1) * (2 * SPD_BIGK * LQP_NB);
+                    __hip_atomic_store(base + (size_t)part_id * (SPD_BIGK * LQP_NB) + i,
+                                       ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned int, ysum),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long* src = base + (size_t)(1 - part_id) * (SPD_BIGK * LQP_NB) + i;
+                    unsigned long long g = 0;
+                    unsigned int spins = 0;
+                    unsigned long long t0 = 0;
+                    bool lost = false;
+                    for (;;) {
+                        g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned int)(g >> 32) == tag) break;
+                        if ((++spins & 1023u) == 0) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                            if (t0 == 0) t0 = now;
+                            else if (now - t0 > 50000000ULL ||
+                                     __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {      // 0.5 s: give up, flagged
+                                __hip_atomic_store(P.status + ST_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                lost = true;
+                                break;
+                            }
+                        }
+                    }
+                    // (a partner that never showed up must not leave plausible numbers: NaN from here on, and the time-out word)
+                    const T other = lost ? T(__builtin_nanf("")) : __builtin_bit_cast(float, (unsigned int)g);
+                    ysum = part_id == 0 ? ysum + other : other + ysum;
+                }
+                const T xi = cvl[i] - ysum;
                 xs[i] = xi;
                 T wn = T(0);
                 if (i < n) {
@@ -1623,7 +1677,7 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
             const T ratio = tsqrt(num / den);
             const bool trig = (ratio > P.ar_tol) || (ratio < P.ar_inv_tol);
             unsigned int* ct = P.counters + (size_t)slot * CT_WORDS;
-            if (tid == 0) {
+            if (tid == 0 && lead) {
                 scal[SC_RATIO] = ratio;
                 scal[SC_WANTS] = wants ? T(1) : T(0);
                 scal[SC_PRI] = mv[0];                        // primal / dual error of this check (the NumPy twin returns them)
@@ -1646,19 +1700,21 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
             ++slot;
             if (persistent & 1) {
                 // all workgroups resident: device-wide "all optimal?" (torch.all at :312)
-                grid_wait(ct + CT_ARRIVE, gridDim.x, P.status);
+                grid_wait(ct + CT_ARRIVE, NP == 2 ? (unsigned int)P.B : gridDim.x, P.status);      // (one arrival per problem)
                 const unsigned int notopt = __hip_atomic_load(ct + CT_NOTOPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int tmo = __hip_atomic_load(P.status + ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (notopt == 0 || tmo) {
-                    if (b == 0 && tid == 0) {
+                    if (b == 0 && tid == 0 && lead) {
                         P.status[ST_FINAL_ITER] = it;
                         __hip_atomic_store(P.status + ST_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     // leave the loop with the state of iteration `it`
                     __syncthreads();
-                    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
-                    loop_store_nu<T, NT, SYM>(V, v, bs + m, n, m);
-                    if (dbg_on && tid == 0) {
+                    if (lead) {
+                        for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
+                        loop_store_nu<T, NT, SYM>(V, v, bs + m, n, m);
+                    }
+                    if (dbg_on && tid == 0 && lead) {
                         dbt[3] += clock64() - dt0;
                         for (int q = 0; q < 4; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
                     }
@@ -1669,16 +1725,26 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
         wg_barrier_lds();
         if (dbg_on) { const unsigned long long t = clock64(); dbt[3] += t - dt0; }
     }
-    if (dbg_on && tid == 0)
+    if (dbg_on && tid == 0 && lead)
         for (int q = 0; q < 4; ++q) P.dbg[(size_t)b * 8 + q] += dbt[q];
     // ---- save state for the next launch / the epilogue ----
-    for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
-    loop_store_nu<T, NT, SYM>(V, v, bs + m, n, m);
+    if (lead) {
+        for (int i = tid; i < n; i += NT) { V.z[i] = z[i]; V.u[i] = u[i]; V.x[i] = xv[i]; }
+        loop_store_nu<T, NT, SYM>(V, v, bs + m, n, m);
+    }
     if (!TAIL || seg1 >= it_end) break;
     seg0 = seg1;
     __syncthreads();
   }
 }
+// the first launch of the symmetric path above 512 rows on TWO workgroups per problem (admm_loop_body_from, NP == 2)
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(1024) void k_admm_loop_np2(const FwdParams<float> P, const int it0, const int it1, const int ctr_base,
+                                                        const int prev_slot, const int persistent) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    admm_loop_body<float, true, false, 1024, true, 2>(P, it0, it1, ctr_base, prev_slot, persistent, smem);
+}
+
 // persistent & 4 (continuation launches): this is the forward's LAST launch -- it ends with the epilogue (fwd_finish)
 template <typename T, bool RES, bool TAIL, int NT, bool SYM = false>
 __global__ __launch_bounds__(NT) void k_admm_loop(const FwdParams<T> P, const int it0, const int it1, const int ctr_base,

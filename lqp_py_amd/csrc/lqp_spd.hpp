@@ -1502,11 +1502,13 @@ template <int NT> struct SymWalk {
 
 // thread t of an NT-thread workgroup owns EPT = 4096 / NT consecutive elements of a block: row t / LPR,
 // columns EPT * (t % LPR) ..  (NT = 1024: 4 elements, 16 lanes per row; NT = 512: 8 elements, 8 lanes per row)
+// (j0, s0: the walk starts at block column j0, whose first block has stream index s0 -- a workgroup that holds a RANGE of whole
+//  block columns, wg_sym_gemv below)
 template <int NT>
-__device__ __forceinline__ void sym_begin(SymWalk<NT>& wk, const float* __restrict__ v) {
+__device__ __forceinline__ void sym_begin(SymWalk<NT>& wk, const float* __restrict__ v, const int j0 = 0, const int s0 = 0) {
     constexpr int EPT = LQP_BLK / NT, LPR = LQP_NB / EPT;
-    wk.i = 0; wk.j = 0; wk.s = 0;
-    const float* p = v + (threadIdx.x % LPR) * EPT;
+    wk.i = j0; wk.j = j0; wk.s = s0;
+    const float* p = v + j0 * 64 + (threadIdx.x % LPR) * EPT;
 #pragma unroll
     for (int q = 0; q < EPT / 4; ++q) wk.wj.q[q] = *(const V4<float>*)(p + 4 * q);
 #pragma unroll
@@ -1613,16 +1615,20 @@ __device__ __forceinline__ float sym_combine(const int e, const int K, const int
 
 // RES: resident head (registers + rl LDS blocks) and a ring that already holds the first streamed blocks and is
 // refilled cyclically; !RES: everything streamed, ring primed here, not cyclic.
+// Sn >= 0: a RANGE of the stream -- the Sn blocks of the whole block columns j0 .. (stream indices s0 .. s0 + Sn - 1; `Hs`, the
+// resident head and the ring are the caller's, relative to block s0): the partial product of those blocks alone -- the row sums
+// in the blocks' own ylds slots, the column sums of columns j0 .. in part[w][.]; what belongs to other columns is left alone
+// (two workgroups per matrix above 512 rows: k_admm_loop_np2).
 template <bool RES, int NT = LQP_NT>
 __device__ __forceinline__ void wg_sym_gemv(BlockStream<float, NT>& st, const ResidentRegs<float, NT>& rr,
                                             const float* __restrict__ lds_res, const int rl,
                                             const float* __restrict__ Hs, const int K, const int Np,
                                             const float* __restrict__ v, float* __restrict__ ylds,
-                                            float* __restrict__ part) {
+                                            float* __restrict__ part, const int j0 = 0, const int s0 = 0, const int Sn = -1) {
     constexpr int NR = resident_regs<NT>();
-    const int S = sym_blocks(K);
+    const int S = Sn < 0 ? sym_blocks(K) : Sn;
     SymWalk<NT> wk;
-    sym_begin<NT>(wk, v);
+    sym_begin<NT>(wk, v, j0, s0);
     int R0 = 0;
     if constexpr (RES) {
 #pragma unroll

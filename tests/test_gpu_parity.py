@@ -1115,6 +1115,46 @@ def test_shared_loop_that_times_out_degrades(dev, monkeypatch, sync):
         assert err(x, want["x"]) <= 2e-5
 
 
+@pytest.mark.parametrize("n,B,m", [(576, 3, 2), (700, 2, 0), (1000, 4, 1), (1024, 2, 0), (900, 130, 1)])
+def test_streaming_loop_on_two_workgroups(dev, monkeypatch, n, B, m):
+    """Above 512 rows (BASELINE configs[3]) the loop of the symmetric path streams H; with 2 B workgroups resident each problem gets
+    TWO of them, one range of whole block columns each, the partial products exchanged every iteration (k_admm_loop_np2) -- against
+    the one-workgroup loop (LQP_LOOP_NP2=0): the same iteration count, the iterates within float32 summation order (part 0 + part 1
+    instead of one running sum), both against the oracle at the tolerance.  B = 130: 2 B workgroups do not fit, one workgroup each."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + B, with_eq=False)
+    gen = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=gen) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=gen) if m else None
+    inp = (Q, p, A, b, lb, ub)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_LOOP_NP2", flag)
+        out[flag], _ = solve(dev, inp, O.make_control(**TOL))
+    two = 2 * B <= torch.cuda.get_device_properties(dev).multi_processor_count
+    assert out["1"]["_stats"]["linsolve_used"] == 2 and out["1"]["_stats"]["loop_workgroups"] == (2 if two else 1)
+    assert out["0"]["_stats"]["loop_workgroups"] == 1 and out["1"]["iter"] == out["0"]["iter"]
+    ref = O.solve_box_qp(*inp, O.make_control(**TOL)) if B <= 8 else None
+    for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+        assert err(out["1"][k], out["0"][k]) < 5e-6 * max(1.0, float(out["0"][k].abs().max())), k
+        if ref is not None:
+            assert err(out["1"][k], ref[k]) < 1e-4 * max(1.0, float(ref[k].abs().max())), k
+    if ref is not None:
+        assert out["1"]["iter"] == ref["iter"]
+
+
+def test_streaming_loop_partner_missing_degrades(dev, monkeypatch):
+    """... and with its partner workgroups missing (LQP_DBG_LOOP_ABSENT bit 3): the exchange gives up after its bounded spin, raises the
+    time-out word, the synchronous call repeats the solve with nothing shared and returns the undisturbed answer."""
+    n, B = 800, 2
+    d = [t.to(dev) for t in O.create_qp_data(n, B, seed=5)]
+    want = L.torch_solve_box_qp(*d, dict(L.box_qp_control(**TOL)))
+    assert want["_stats"]["loop_workgroups"] == 2
+    monkeypatch.setenv("LQP_DBG_LOOP_ABSENT", "8")
+    got = L.torch_solve_box_qp(*d, dict(L.box_qp_control(**TOL)))
+    assert got["iter"] == want["iter"] and got["_stats"]["loop_workgroups"] == 1
+    assert err(got["x"], want["x"]) <= 2e-5
+
+
 def test_report_of_the_factorisation_made_ahead(dev, monkeypatch):
     """ABI 11: the prefactor call stores the factorisation's info words into the report buffer of the backward call, which then
     waits for those words only (LQP_BWD_REPORTED) -- it returns while its solves and the epilogue run.  The same gradients as
