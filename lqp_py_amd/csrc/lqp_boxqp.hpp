@@ -1495,11 +1495,14 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
     }
     const T* packed_r = packed + (size_t)rs0 * LQP_BLK;
     unsigned long long* const xq = NP == 2 ? P.xchg + (size_t)b * XCHG_WORDS : nullptr;
+    // (LDS-resident blocks actually used: the layout is sized for the whole stream, a range may be shorter than registers + rl)
+    int rl_use = rl;
+    if constexpr (NP == 2) { const int room = rsn - resident_regs<NT>(); rl_use = room < 0 ? 0 : (room < rl ? room : rl); }
     if constexpr (SYM) {
         if constexpr (RES) {
             const int Sr_ = NP == 2 ? rsn : S;
-            sym_resident_load<NT>(rr, lds_res, packed_r, Sr_, rl);
-            sym_prime<NT>(st, packed_r, (Sr_ < resident_regs<NT>() ? Sr_ : resident_regs<NT>()) + rl, Sr_);
+            sym_resident_load<NT>(rr, lds_res, packed_r, Sr_, rl_use);
+            sym_prime<NT>(st, packed_r, (Sr_ < resident_regs<NT>() ? Sr_ : resident_regs<NT>()) + rl_use, Sr_);
         }
     } else if constexpr (RES) {
         resident_load<T, NT>(rr, lds_res, packed);
@@ -1544,7 +1547,7 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
                 wg_barrier_lds();
             }
             if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
-            if constexpr (NP == 2) wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed_r, P.Ks, Nps, v, ylds, part, rj0, rs0, rsn);
+            if constexpr (NP == 2) wg_sym_gemv<RES, NT>(st, rr, lds_res, rl_use, packed_r, P.Ks, Nps, v, ylds, part, rj0, rs0, rsn);
             else wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
             wg_barrier_lds();
             if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
