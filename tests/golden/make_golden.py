@@ -172,7 +172,24 @@ def main():
         save("g20_b2_n3000_eq", **out)
         print("   n=3000 iter", sol["iter"])
         del Q, sol, gr
-    if only and all(o.startswith(("g16", "g17", "g18", "g19", "g20")) for o in only):
+    # G21: unroll=True in float64 with several equality rows -- the tape whose every node is TorchLULayer on the pivoted LU of the KKT
+    #      matrix (lqp_py/lu_layer.py:25-58): B=4 n=60 m=3, tol 1e-8, the hard distribution's dtype; autograd through the loop, all six
+    #      gradients.  Pins lqp_boxqp_unroll_backward_lu (round 6) against the reference itself.
+    if not only or any(o.startswith("g21") for o in only):
+        Q, p, A, b, lb, ub = ref_inputs(60, 4, 21, dtype=torch.float64)
+        gen = torch.Generator().manual_seed(21)
+        A = torch.randn(4, 3, 60, generator=gen, dtype=torch.float64)
+        b = 0.1 * torch.randn(4, 3, 1, generator=gen, dtype=torch.float64)
+        cot = torch.randn(4, 60, 1, generator=gen, dtype=torch.float64)
+        ctl = box_qp_control(unroll=True, eps_abs=1e-8, eps_rel=1e-8)
+        leaves = [t.clone().requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        xu = SolveBoxQP(control=ctl)(*leaves)
+        xu.backward(cot)
+        out = dict(Q=Q, p=p, A=A, b=b, lb=lb, ub=ub, cot=cot, x=xu.detach())
+        for nm, t in zip(GRAD_NAMES, leaves):
+            out[nm] = t.grad
+        save("g21_unroll_f64_m3", **out)
+    if only and all(o.startswith(("g16", "g17", "g18", "g19", "g20", "g21")) for o in only):
         return
 
     # G14: the NumPy twin (lqp_py/solve_box_qp_admm.py:45-91, single problem, float64) -- SURVEY 8f rank 4

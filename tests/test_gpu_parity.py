@@ -1463,6 +1463,29 @@ def test_unroll_mode_goldens(dev, monkeypatch, name, tol, native):
         close_or_fp64(name, nm, t.grad, g[nm], t64, G_RTOL, native=native)
 
 
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_g21_unroll_float64_lu_tape(dev, monkeypatch, native):
+    """unroll=True in float64 with three equality rows against the reference-made golden G21 (autograd through the reference's own
+    loop, every node TorchLULayer on the pivoted LU, lqp_py/lu_layer.py:25-58; tol 1e-8): native 1 = the reverse sweep on the packed
+    LU factor (lqp_boxqp_unroll_backward_lu), 0 = the taped loop of torch ops.  float64: solution and all six gradients at 1e-7
+    of scale (the solve stops at 1e-8)."""
+    monkeypatch.setenv("LQP_UNROLL_NATIVE", native)
+    g = load_golden("g21_unroll_f64_m3")
+    leaves = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    assert leaves[0].dtype == torch.float64
+    ctl = L.box_qp_control(unroll=True, eps_abs=1e-8, eps_rel=1e-8)
+    _lib.profile(enable=True, reset=True)
+    x = L.SolveBoxQP(control=ctl)(*leaves)
+    x.backward(g["cot"].to(dev))
+    used = _lib.profile(); _lib.profile(enable=False)
+    assert (used["unroll_backward"][1] == 3) == (native == "1"), used["unroll_backward"]
+    assert err(x, g["x"]) < 1e-7 * max(1.0, float(g["x"].abs().max()))
+    for nm, t in zip(GRADS, leaves):
+        e = err(t.grad, g[nm]) / max(1.0, float(g[nm].abs().max()))
+        P.record("g21_unroll_f64_m3", nm, e, native=native)
+        assert e < 1e-7, (nm, e)
+
+
 @pytest.mark.parametrize("case", ["default", "ties", "no_scale", "rho_given", "beta_given", "box_only", "ragged", "many_rows"])
 def test_unroll_scaling_chain_native_vs_autograd(dev, monkeypatch, case):
     """unroll=True: the scaling (:160-203) behind the reverse sweep with its Q-sized nodes on the library's one-pass kernels

@@ -174,6 +174,49 @@ def test_g20_above_2048_rows():
         close(grads[GRADS.index(nm)], g[nm], 1e-4, 1e-4)
 
 
+class _CpuLU(torch.nn.Module):
+    """The taped solve of the unrolled loop on the CPU (lqp_py/lu_layer.py:5-58 restated in the oracle): forward lu_solve with the
+    cached factor, backward dA = -lu_solve(g) x^T, db = lu_solve(g) with the SAME factor."""
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, A, b, LU, piv):
+            x = O.lu_solve(LU, piv, b)
+            ctx.save_for_backward(LU, piv, x)
+            return x
+
+        @staticmethod
+        def backward(ctx, g):
+            LU, piv, x = ctx.saved_tensors
+            dA, db = O.lu_layer_backward(LU, piv, x, g)
+            return dA, db, None, None
+
+    def __init__(self, A):
+        super().__init__()
+        with torch.no_grad():
+            self.LU, self.piv = O.lu_factor(A)
+
+    def forward(self, A, b):
+        return self._Fn.apply(A, b, self.LU, self.piv)
+
+
+def test_g21_unroll_tape_float64():
+    """G21 (unroll=True, float64, three equality rows, reference-made): the host-side restatement of the taped loop
+    (lqp_py_amd.unrolled._eager_unrolled, the form the GPU tests use as the float64 arbiter of every unroll gradient) with the oracle's
+    LU layer against the reference's autograd: solution and all six gradients."""
+    from lqp_py_amd.unrolled import _eager_unrolled
+    from lqp_py_amd import solve_box_qp_admm_torch as SB
+    import lqp_py_amd as L
+    g = load_golden("g21_unroll_f64_m3")
+    leaves = [g[k].clone().requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    ctl = L.box_qp_control(unroll=True, eps_abs=1e-8, eps_rel=1e-8)
+    x = _eager_unrolled(*leaves, SB.resolve_control(ctl, 60), True, True, solver_cls=_CpuLU)
+    x.backward(g["cot"])
+    close(x.detach(), g["x"], 1e-10, 1e-10)
+    for nm, t in zip(GRADS, leaves):
+        close(t.grad, g[nm], 1e-8, 1e-8)
+
+
 def test_kkt_conditions_known_answer():
     """Independent of the reference: returned (x, lams, nus) satisfy the KKT system."""
     Q, p, A, b, lb, ub = O.create_qp_data(40, 6, seed=21, dtype=torch.float64)
