@@ -189,7 +189,27 @@ def main():
         for nm, t in zip(GRAD_NAMES, leaves):
             out[nm] = t.grad
         save("g21_unroll_f64_m3", **out)
-    if only and all(o.startswith(("g16", "g17", "g18", "g19", "g20", "g21")) for o in only):
+    # G22: unroll=True through ONE adaptive-rho refactorisation (lqp_py/solve_box_qp_admm_torch.py:237-256 inside the tape: the
+    #      reference's autograd runs through the adaptation itself) -- B=4 n=20 m=1 float32, Q x 50 with a given rho = 100 and no
+    #      auto-scaling, tol 1e-6: the plain forward of the same problem reports the iteration count and the adapted rho.
+    if not only or any(o.startswith("g22") for o in only):
+        Q, p, A, b, lb, ub = ref_inputs(20, 4, 22)
+        Q = Q * 50
+        torch.manual_seed(22)
+        cot = torch.randn(4, 20, 1)
+        kw = dict(rho=100.0, scale=False, eps_abs=1e-6, eps_rel=1e-6)
+        plain = torch_solve_box_qp(Q, p, A, b, lb, ub, box_qp_control(**kw))
+        assert int(plain["iter"]) >= 100 and float((plain["rho"] - 100.0).abs().max()) > 1.0, (plain["iter"], plain["rho"])
+        ctl = box_qp_control(unroll=True, **kw)
+        leaves = [t.clone().requires_grad_(True) for t in (Q, p, A, b, lb, ub)]
+        xu = SolveBoxQP(control=ctl)(*leaves)
+        xu.backward(cot)
+        out = dict(Q=Q, p=p, A=A, b=b, lb=lb, ub=ub, cot=cot, x=xu.detach(), iter=plain["iter"], rho=plain["rho"])
+        for nm, t in zip(GRAD_NAMES, leaves):
+            out[nm] = t.grad
+        save("g22_unroll_rho_event", **out)
+        print("   unroll with a rho event: iter", plain["iter"], "rho", plain["rho"].flatten().tolist())
+    if only and all(o.startswith(("g16", "g17", "g18", "g19", "g20", "g21", "g22")) for o in only):
         return
 
     # G14: the NumPy twin (lqp_py/solve_box_qp_admm.py:45-91, single problem, float64) -- SURVEY 8f rank 4

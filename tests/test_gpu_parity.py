@@ -1463,6 +1463,29 @@ def test_unroll_mode_goldens(dev, monkeypatch, name, tol, native):
         close_or_fp64(name, nm, t.grad, g[nm], t64, G_RTOL, native=native)
 
 
+def test_g22_unroll_through_a_rho_event(dev):
+    """unroll=True through ONE adaptive-rho refactorisation, against the reference-made golden G22 (Q x 50, rho = 100 given, no
+    auto-scaling, tol 1e-6: the reference adapts rho at iteration 100 and stops there; its autograd runs through the adaptation
+    itself, lqp_py/solve_box_qp_admm_torch.py:237-256).  The factor is not constant along this tape: the layer takes the taped loop
+    of torch ops by itself (no reverse sweep launched); solution at 1e-5, gradients at rtol 1e-4 or the float64 criterion."""
+    g = load_golden("g22_unroll_rho_event")
+    leaves = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
+    ctl = L.box_qp_control(unroll=True, rho=100.0, scale=False, eps_abs=1e-6, eps_rel=1e-6)
+    _lib.profile(enable=True, reset=True)
+    x = L.SolveBoxQP(control=dict(ctl))(*leaves)
+    x.backward(g["cot"].to(dev))
+    used = _lib.profile(); _lib.profile(enable=False)
+    assert used["unroll_backward"][1] == 0 and used["lu_factor"][1] >= 2, used      # (the tape refactorised)
+    x64, g64 = _unroll_truth64(g, dict(ctl))
+    close_or_fp64("g22_unroll_rho_event", "x", x, g["x"], x64, X_TOL)
+    for nm, t, t64 in zip(GRADS, leaves, g64):
+        close_or_fp64("g22_unroll_rho_event", nm, t.grad, g[nm], t64, G_RTOL)
+    plain = L.torch_solve_box_qp(*[t.detach() for t in leaves], dict(ctl, unroll=False))
+    assert plain["iter"] == g["iter"] == 100
+    # (the adapted rho is 100 x sqrt of a ratio of residual norms that are ~1e-6 of scale at iteration 90: float32 noise of a percent)
+    assert float(((plain["rho"].reshape(-1).cpu() - g["rho"].reshape(-1)) / g["rho"].reshape(-1)).abs().max()) < 2e-2
+
+
 @pytest.mark.parametrize("native", ["1", "0"])
 def test_g21_unroll_float64_lu_tape(dev, monkeypatch, native):
     """unroll=True in float64 with three equality rows against the reference-made golden G21 (autograd through the reference's own
