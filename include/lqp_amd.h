@@ -233,6 +233,25 @@ int lqp_boxqp_unroll_backward_lu(void* stream, int dtype, int B, int n, int m, c
                                  int iters, const void* dl_dx, void* dQs, void* dps, void* dAs, void* dbs, void* dlbs, void* dubs,
                                  void* drho, void* dD, void* scratch, size_t scratch_bytes);
 
+/* ABI 13: a tape whose factor CHANGES along it -- a solve in which rho was adapted (solve_box_qp_admm_torch.py:237-256 inside the
+ * tape).  The caller walks it epoch by epoch: for every epoch the packed factor of ITS KKT matrix (`packed_buf`: what lqp_lu_pack
+ * filled; NULL: the forward's) and its rho (B values; NULL: the forward's), the x-updates [k0, k1) of the `iters + 1` recorded ones.
+ * mode bit 0: replay them from `state` = (z, u) (B,2,n; read when k0 > 0, written when k1 < iters + 1) into the scratch rows;
+ * mode bit 1: walk them back -- `state` = the cotangents of (z, u) at k1 (read when k1 < iters + 1, written when k0 > 0), dps /
+ * dlbs / dubs accumulate over the segments, drho is THIS segment's, dD is written by the last one (k1 == iters + 1); `inj` (B,4,n):
+ * cotangents the caller adds at x-update `inj_k` to x_c | z_{c+1} | u_{c+1} | z_c -- what the gradient of the NEXT epoch's rho sends
+ * into the iterates of the check it was computed from.  z_rows / u_rows / x_rows (may be NULL): where the scratch keeps
+ * z_{k+1}, u_{k+1}, x_k as (B, iters + 1, n) (k1 <= k0: only this query).  lqp_boxqp_unroll_tape_finish: dQs, dAs, dbs over the whole
+ * tape once every segment has been walked.  The tape's nodes are TorchLULayer's (lu_layer.py:25-58), as in
+ * lqp_boxqp_unroll_backward_lu. */
+size_t lqp_boxqp_unroll_tape_workspace_bytes(int dtype, int B, int n, int m, int iters);
+int lqp_boxqp_unroll_tape_segment(void* stream, int dtype, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                  int iters, int k0, int k1, int mode, const void* packed_buf, const void* rho, void* state, int inj_k,
+                                  const void* inj, const void* dl_dx, void* dps, void* dlbs, void* dubs, void* drho, void* dD,
+                                  void* scratch, size_t scratch_bytes, void** z_rows, void** u_rows, void** x_rows);
+int lqp_boxqp_unroll_tape_finish(void* stream, int dtype, int B, int n, int m, int iters, void* dQs, void* dAs, void* dbs, void* scratch,
+                                 size_t scratch_bytes);
+
 /* The scaling (solve_box_qp_admm_torch.py:160-203) behind the unrolled loop (ABI 10): what of its derivative walks over the
  * (B,n,n) tensors, one pass each; the reference lets autograd tape these as torch ops (:163 column maxima of |Q| --
  * torch.linalg.norm(ord=inf, dim=1) --, :176 Qs = D Q D, :201 ||Qs||_F and their backward nodes: ~25 passes over Q-sized

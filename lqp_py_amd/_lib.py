@@ -71,6 +71,10 @@ SYMBOLS = {
     "lqp_boxqp_unroll_backward": (c_int, [_P, c_int, c_int, c_int, _P, c_size_t, c_int] + [_P] * 10 + [c_size_t]),
     "lqp_boxqp_unroll_backward_lu_workspace_bytes": (c_size_t, [c_int] * 5),
     "lqp_boxqp_unroll_backward_lu": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, c_int] + [_P] * 10 + [c_size_t]),
+    "lqp_boxqp_unroll_tape_workspace_bytes": (c_size_t, [c_int] * 5),
+    "lqp_boxqp_unroll_tape_segment": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, _P, _P, _P, c_int]
+                                      + [_P] * 8 + [c_size_t] + [_P] * 3),
+    "lqp_boxqp_unroll_tape_finish": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t]),
     "lqp_unroll_scale_colmax": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "lqp_unroll_scale_grad_slabs": (c_int, [c_int, c_int]),
     "lqp_unroll_scale_grad": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int]),

@@ -1693,7 +1693,7 @@ namespace {
 // ---- the tape whose x-update is the pivoted LU (float32 / float64, any m): lqp_unroll.hpp, k_unroll_sweep_lu ----
 template <typename T> struct UnrollLuCarve { UnrollLuParams<T> U; size_t bytes; };
 template <typename T>
-static UnrollLuCarve<T> carve_unroll_lu(void* ws, int B, int n, int m, int TT) {
+static UnrollLuCarve<T> carve_unroll_lu(void* ws, int B, int n, int m, int TT, bool segments = false) {
     UnrollLuCarve<T> c;
     memset(&c.U, 0, sizeof(c.U));
     Carver cv(ws);
@@ -1704,8 +1704,74 @@ static UnrollLuCarve<T> carve_unroll_lu(void* ws, int B, int n, int m, int TT) {
     c.U.NU = cv.take<T>((size_t)B * TT * mm);
     c.U.DNU = cv.take<T>((size_t)B * TT * mm);
     c.U.MK = cv.take<signed char>((size_t)B * TT * n);
+    if (segments) {             // (a tape in segments also keeps z_{k+1}, u_{k+1}: the rho adaptation reads them)
+        c.U.Zr = cv.take<T>((size_t)B * TT * n);
+        c.U.Ur = cv.take<T>((size_t)B * TT * n);
+    }
+    c.U.inj_k = -1;
     c.bytes = cv.off + kAlign;
     return c;
+}
+
+// one segment [k0, k1) of a tape whose factor changes along it (a solve in which rho was adapted): replay and / or reverse walk
+// with the epoch's packed factor and rho (lqp_unroll.hpp, UnrollLuParams)
+template <typename T>
+static int unroll_tape_segment_impl(hipStream_t st, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes, int iters,
+                                    int k0, int k1, int mode, const void* packed_buf, const void* rho, void* state, int inj_k,
+                                    const void* inj, const void* dl_dx, void* dps, void* dlbs, void* dubs, void* drho, void* dD,
+                                    void* scratch, size_t scratch_bytes, void** zrows, void** urows, void** xrows) {
+    FwdLayout<T> L = carve_forward<T>((void*)fwd_workspace, B, n, m);
+    if (fwd_workspace_bytes < L.bytes) return LQP_ERR_WORKSPACE;
+    const FwdParams<T>& P = L.P;
+    const int TT = iters + 1;
+    UnrollLuCarve<T> c = carve_unroll_lu<T>(scratch, B, n, m, TT, true);
+    if (scratch_bytes < c.bytes) return LQP_ERR_WORKSPACE;
+    if (zrows) *zrows = c.U.Zr;
+    if (urows) *urows = c.U.Ur;
+    if (xrows) *xrows = c.U.X;
+    if (k1 <= k0) return LQP_OK;             // (a query of the row pointers)
+    UnrollLuParams<T>& U = c.U;
+    U.T_ = TT; U.k0 = k0; U.k1 = k1; U.mode = mode;
+    if (packed_buf) {
+        int* dest; T* packed;
+        carve_packed<T>((void*)packed_buf, B, P.N, dest, packed);
+        U.packed_ov = packed; U.dest_ov = dest;
+    }
+    U.rho_ov = (const T*)rho;
+    U.state = (T*)state;
+    U.inj_k = inj ? inj_k : -1; U.inj = (const T*)inj;
+    U.g = (const T*)dl_dx;
+    U.dps = (T*)dps; U.dlbs = (T*)dlbs; U.dubs = (T*)dubs; U.dD = (T*)dD; U.drho = (T*)drho;
+    const int lds = unroll_lu_lds_bytes<T>(P.Np);
+    auto fn = k_unroll_sweep_lu<T>;
+    const int rc = ensure_lds((const void*)fn, lds);
+    if (rc) return rc;
+    ProfScope ps(st, PC_UNROLL);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(LQP_NT), lds, st, P, U);
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
+}
+
+// ... and what is summed over the whole tape once every segment has been walked: Asbar / bsbar, Qsbar
+template <typename T>
+static int unroll_tape_finish_impl(hipStream_t st, int B, int n, int m, int iters, void* dQs, void* dAs, void* dbs, void* scratch,
+                                   size_t scratch_bytes) {
+    const int TT = iters + 1;
+    UnrollLuCarve<T> c = carve_unroll_lu<T>(scratch, B, n, m, TT, true);
+    if (scratch_bytes < c.bytes) return LQP_ERR_WORKSPACE;
+    UnrollLuParams<T>& U = c.U;
+    U.T_ = TT; U.dAs = (T*)dAs; U.dbs = (T*)dbs;
+    if (m > 0) {
+        ProfScope ps(st, PC_UNROLL);
+        int slabs = (m * n + 255) / 256;
+        if (slabs > 64) slabs = 64;
+        hipLaunchKernelGGL(k_unroll_lu_eq<T>, dim3(B, slabs), dim3(256), 0, st, U, n, m);
+    }
+    if (dQs) {
+        ProfScope ps(st, PC_UNROLL);
+        const int tiles = (n + 63) / 64;
+        hipLaunchKernelGGL(k_unroll_outer_any<T>, dim3(tiles, tiles, B), dim3(256), 0, st, (const T*)U.DX, (const T*)U.X, (T*)dQs, n, TT);
+    }
+    return hipGetLastError() == hipSuccess ? LQP_OK : LQP_ERR_HIP;
 }
 
 template <typename T>
@@ -1983,6 +2049,36 @@ int lqp_boxqp_unroll_backward_lu(void* stream, int dtype, int B, int n, int m, c
                                               drho, dD, scratch, scratch_bytes);
     return unroll_backward_lu_impl<double>(st, B, n, m, fwd_workspace, fwd_workspace_bytes, iters, dl_dx, dQs, dps, dAs, dbs, dlbs, dubs,
                                            drho, dD, scratch, scratch_bytes);
+}
+
+size_t lqp_boxqp_unroll_tape_workspace_bytes(int dtype, int B, int n, int m, int iters) {
+    if (bad_dims(dtype, B, n, m) || iters < 0) return 0;
+    return dtype == LQP_F32 ? carve_unroll_lu<float>(nullptr, B, n, m, iters + 1, true).bytes
+                            : carve_unroll_lu<double>(nullptr, B, n, m, iters + 1, true).bytes;
+}
+
+int lqp_boxqp_unroll_tape_segment(void* stream, int dtype, int B, int n, int m, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                  int iters, int k0, int k1, int mode, const void* packed_buf, const void* rho, void* state, int inj_k,
+                                  const void* inj, const void* dl_dx, void* dps, void* dlbs, void* dubs, void* drho, void* dD,
+                                  void* scratch, size_t scratch_bytes, void** z_rows, void** u_rows, void** x_rows) {
+    if (bad_dims(dtype, B, n, m) || iters < 0 || !fwd_workspace || !scratch || k0 < 0 || k1 > iters + 1 || (mode & ~3) != 0)
+        return LQP_ERR_INVALID;
+    if (k1 > k0 && (mode & 2) && (!dl_dx || !dps || !dlbs || !dubs || !drho || !dD)) return LQP_ERR_INVALID;
+    if (n + m > max_rows(dtype)) return LQP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LQP_F32)
+        return unroll_tape_segment_impl<float>(st, B, n, m, fwd_workspace, fwd_workspace_bytes, iters, k0, k1, mode, packed_buf, rho, state,
+                                               inj_k, inj, dl_dx, dps, dlbs, dubs, drho, dD, scratch, scratch_bytes, z_rows, u_rows, x_rows);
+    return unroll_tape_segment_impl<double>(st, B, n, m, fwd_workspace, fwd_workspace_bytes, iters, k0, k1, mode, packed_buf, rho, state,
+                                            inj_k, inj, dl_dx, dps, dlbs, dubs, drho, dD, scratch, scratch_bytes, z_rows, u_rows, x_rows);
+}
+
+int lqp_boxqp_unroll_tape_finish(void* stream, int dtype, int B, int n, int m, int iters, void* dQs, void* dAs, void* dbs, void* scratch,
+                                 size_t scratch_bytes) {
+    if (bad_dims(dtype, B, n, m) || iters < 0 || !scratch || (m > 0 && (!dAs || !dbs))) return LQP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == LQP_F32 ? unroll_tape_finish_impl<float>(st, B, n, m, iters, dQs, dAs, dbs, scratch, scratch_bytes)
+                            : unroll_tape_finish_impl<double>(st, B, n, m, iters, dQs, dAs, dbs, scratch, scratch_bytes);
 }
 
 int lqp_unroll_scale_colmax(void* stream, int B, int n, const void* Q, void* colmax, void* argmax, void* count) {

@@ -414,6 +414,16 @@ template <typename T> struct UnrollLuParams {
     T *dps, *dlbs, *dubs, *dD;     // (B, n) outputs
     T *dAs, *dbs;           // (B, m, n), (B, m) outputs (or null when m == 0)
     T* drho;                // (B) output
+    // ---- a tape in SEGMENTS (a solve in which rho was adapted: one factor per epoch, lqp_boxqp_unroll_tape_segment) ----
+    int k0, k1;             // x-updates [k0, k1) of the T_ recorded ones (k1 == 0: all of them)
+    int mode;               // bit 0: replay the segment, bit 1: walk it back (0: both, the whole tape)
+    const T* packed_ov;     // the epoch's packed factor (lqp_lu_pack layout, blocks) or null: the forward's
+    const int* dest_ov;     // ... and its row permutation
+    const T* rho_ov;        // (B) the epoch's rho, or null: the forward's
+    T* state;               // (B, 2, n): replay -- (z, u) in at k0 > 0, out at k1;  reverse -- (zbar, ubar) in at k1 < T_, out at k0
+    T *Zr, *Ur;             // (B, T, n) or null: z_{k+1}, u_{k+1} of every replayed x-update (what the rho adaptation reads)
+    int inj_k;              // reverse: the x-update whose cotangents take `inj` (-1: none)
+    const T* inj;           // (B, 4, n): added to the cotangents of x_c | z_{c+1} | u_{c+1} | z_c
 };
 // LDS: v[Np] | tmp[64] | red[NW] | dest[Np] (int)
 template <typename T> __host__ __device__ inline int unroll_lu_lds_bytes(int Np) { return (Np + 64 + LQP_NW) * (int)sizeof(T) + Np * 4; }
@@ -429,8 +439,8 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P
     T* red = tmp + 64;
     int* dest = (int*)(red + LQP_NW);
     VecView<T> V(P.vecs + (size_t)b * P.vstride, n, m);
-    const T rho = P.scal[(size_t)b * SC_WORDS + SC_RHO];
-    const T* packed = P.packed + (size_t)b * packed_blocks(K) * LQP_BLK;
+    const T rho = U.rho_ov ? U.rho_ov[b] : P.scal[(size_t)b * SC_WORDS + SC_RHO];
+    const T* packed = U.packed_ov ? U.packed_ov + (size_t)b * packed_blocks(K) * LQP_BLK : P.packed + (size_t)b * packed_blocks(K) * LQP_BLK;
     const int mm = m > 0 ? m : 1;
     T* X = U.X + (size_t)b * TT * n;
     T* Wd = U.W + (size_t)b * TT * n;
@@ -438,22 +448,29 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P
     T* NU = U.NU + (size_t)b * TT * mm;
     T* DNU = U.DNU + (size_t)b * TT * mm;
     signed char* MK = U.MK + (size_t)b * TT * n;
+    const int k0 = U.k1 > 0 ? U.k0 : 0, k1 = U.k1 > 0 ? U.k1 : TT;
+    const bool do_replay = U.mode == 0 || (U.mode & 1), do_reverse = U.mode == 0 || (U.mode & 2);
+    T* stz = U.state ? U.state + (size_t)b * 2 * n : nullptr;
 
     BlockStream<T, NT> st;
     stream_prime<T, NT>(st, packed, K * (K + 1));
-    for (int i = tid; i < Np; i += NT) dest[i] = P.dest[(size_t)b * Np + i];
+    {
+        const int* gdest = U.dest_ov ? U.dest_ov + (size_t)b * Np : P.dest + (size_t)b * Np;
+        for (int i = tid; i < Np; i += NT) dest[i] = gdest[i];
+    }
     T psi[EPT], lbi[EPT], ubi[EPT], zi[EPT], ui[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int i = tid + q * NT;
         const bool live = i < n;
         psi[q] = live ? V.ps[i] : T(0); lbi[q] = live ? V.lbs[i] : T(0); ubi[q] = live ? V.ubs[i] : T(0);
-        zi[q] = T(0); ui[q] = T(0);
+        zi[q] = (live && k0 > 0 && stz && do_replay) ? stz[i] : T(0);
+        ui[q] = (live && k0 > 0 && stz && do_replay) ? stz[n + i] : T(0);
     }
     __syncthreads();
 
     // ---- replay of the forward loop (:258-282): x_k, nu_k, z_k - u_k and the clamp decisions ----
-    for (int k = 0; k < TT; ++k) {
+    for (int k = k0; k < k1 && do_replay; ++k) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int i = tid + q * NT;
@@ -480,10 +497,19 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P
                 MK[(size_t)k * n + i] = (signed char)(tmax(s, lbi[q]) > ubi[q] ? 1 : (s < lbi[q] ? -1 : 0));      // (maximum first, then minimum: :273-276)
                 ui[q] = ui[q] + (xi - zn);
                 zi[q] = zn;
+                if (U.Zr) { U.Zr[((size_t)b * TT + k) * n + i] = zn; U.Ur[((size_t)b * TT + k) * n + i] = ui[q]; }
             } else if (i < N) NU[(size_t)k * m + (i - n)] = v[i];
         }
         wg_barrier_lds();
     }
+    if (do_replay && stz && k1 < TT) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * NT;
+            if (i < n) { stz[i] = zi[q]; stz[n + i] = ui[q]; }
+        }
+    }
+    if (!do_reverse) return;
 
     // ---- reverse sweep ----
     T gi[EPT], di[EPT], ubar[EPT], zbar[EPT], pbar[EPT], lbbar[EPT], ubbar[EPT];
@@ -495,10 +521,16 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P
         gi[q] = live ? U.g[(size_t)b * n + i] : T(0);
         di[q] = live ? V.D[i] : T(0);
         ubar[q] = zbar[q] = pbar[q] = lbbar[q] = ubbar[q] = T(0);
+        if (live && k1 < TT) {            // a later segment has been walked already: its cotangents and what it accumulated
+            if (stz) { zbar[q] = stz[i]; ubar[q] = stz[n + i]; }
+            pbar[q] = U.dps[(size_t)b * n + i]; lbbar[q] = U.dlbs[(size_t)b * n + i]; ubbar[q] = U.dubs[(size_t)b * n + i];
+        }
     }
+    const T* injb = (U.inj && U.inj_k >= 0) ? U.inj + (size_t)b * 4 * n : nullptr;
     __syncthreads();                                       // (the scratch rows above are read back by their writers only)
-    for (int k = TT - 1; k >= 0; --k) {
+    for (int k = k1 - 1; k >= k0; --k) {
         T unew[EPT];
+        const bool inj_here = injb != nullptr && k == U.inj_k;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int i = tid + q * NT;
@@ -506,13 +538,14 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P
             if (i < Np) {
                 T val = T(0);
                 if (i < n) {
+                    if (inj_here) { zbar[q] += injb[(size_t)n + i]; ubar[q] += injb[(size_t)2 * n + i]; }
                     const int code = (int)MK[(size_t)k * n + i];
                     const T zt = zbar[q] - ubar[q];
                     const T wfree = code == 0 ? zt : T(0);
                     lbbar[q] += code < 0 ? zt : T(0);
                     ubbar[q] += code > 0 ? zt : T(0);
                     unew[q] = wfree + ubar[q];
-                    val = -(unew[q] + (k == TT - 1 ? di[q] * gi[q] : T(0)));      // rhs = -xvbar_k (its nu part is zero: nu is not an output)
+                    val = -(unew[q] + (k == TT - 1 ? di[q] * gi[q] : T(0)) + (inj_here ? injb[i] : T(0)));      // rhs = -xvbar_k (its nu part is zero: nu is not an output)
                 }
                 v[dest[i]] = val;
             }
@@ -528,7 +561,7 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P
                 DX[(size_t)k * n + i] = dxx;
                 pbar[q] += dxx;
                 rho_part += dxx * (xk - Wd[(size_t)k * n + i]);
-                zbar[q] = -rho * dxx;
+                zbar[q] = -rho * dxx + (inj_here ? injb[(size_t)3 * n + i] : T(0));
                 ubar[q] = unew[q] + rho * dxx;
             } else if (i < N) DNU[(size_t)k * m + (i - n)] = v[i];
         }
@@ -541,7 +574,8 @@ __global__ __launch_bounds__(LQP_NT) void k_unroll_sweep_lu(const FwdParams<T> P
             U.dps[(size_t)b * n + i] = pbar[q];
             U.dlbs[(size_t)b * n + i] = lbbar[q];
             U.dubs[(size_t)b * n + i] = ubbar[q];
-            U.dD[(size_t)b * n + i] = gi[q] * X[(size_t)(TT - 1) * n + i];
+            if (k1 == TT) U.dD[(size_t)b * n + i] = gi[q] * X[(size_t)(TT - 1) * n + i];
+            if (stz && k0 > 0) { stz[i] = zbar[q]; stz[n + i] = ubar[q]; }
         }
     }
     const T rsum = wg_sum(rho_part, red);

@@ -10,7 +10,10 @@ two cached triangular solves of ``TorchLULayer`` --: no taped node, no per-itera
 gradients w.r.t. the SCALED problem (Qs, ps, As, bs, lbs, ubs, rho, D); the scaling itself (:160-203: ~25 element-wise /
 reduction ops, once per call) is differentiated by autograd on a small eager graph rebuilt in ``backward``.
 
-What is left (a solve in which rho was adapted -- the reference's tape then runs through the adaptation itself --, no finite bound)
+A solve in which rho was ADAPTED (the reference's tape then runs through the adaptation itself, :237-256): the tape is walked
+epoch by epoch in the library on the pivoted LU of each epoch's KKT matrix (``lqp_boxqp_unroll_tape_segment``) and the adaptation --
+a few norms of the iterates of ONE check per event -- is differentiated by autograd on its own small graph
+(``_backward_with_rho_events``): no torch op per iteration there either.  What is left (no finite bound: rho = 0, one solve)
 takes the eager path below: the loop as torch ops with ``TorchLU`` (HIP LU factor / cached solves) as the taped solve.
 """
 import ctypes
@@ -93,7 +96,12 @@ class _UnrolledLoop(torch.autograd.Function):
         st = sol['_stats']
         # one factor for the whole solve: the symmetric x-update (float32: the packed inverse) or the pivoted LU (any dtype: the packed
         # factor, lqp_boxqp_unroll_backward_lu); a solve in which rho was adapted keeps the eager tape
-        if st['n_factor'] != 1 or st['linsolve_used'] not in (1, 2) or (st['linsolve_used'] == 2 and p.dtype != torch.float32):
+        if st['linsolve_used'] not in (1, 2) or (st['linsolve_used'] == 2 and p.dtype != torch.float32):
+            raise _NotNative()
+        # rho was adapted along the solve: the tape is walked epoch by epoch on the pivoted LU of each epoch's KKT matrix
+        # (_backward_with_rho_events); LQP_UNROLL_EVENTS=0 keeps the taped loop of torch ops for it
+        ctx.events = st['n_factor'] != 1
+        if ctx.events and os.environ.get("LQP_UNROLL_EVENTS", "1") == "0":
             raise _NotNative()
         ctx.lu = st['linsolve_used'] == 1
         ctx.ws, ctx.iters, ctx.r, ctx.has_box = ws, int(st['iters']), r, bool(bounds[0] or bounds[1])
@@ -103,6 +111,8 @@ class _UnrolledLoop(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.events:
+            return _backward_with_rho_events(ctx, g)
         Q, p, A, b, lb, ub = ctx.saved_tensors
         lib = _lib.load()
         B, n = Q.shape[0], p.shape[1]
@@ -147,6 +157,173 @@ class _UnrolledLoop(torch.autograd.Function):
                      else [None] * len(wanted))
         res = [next(grads) if (t is not None and t.requires_grad) else None for t in leaves]
         return tuple(res) + (None, None, None)
+
+
+def _check_quantities(r, rho, x, z, z_old, u, D, Qs, p_inf):
+    """What a check of the loop computes (lqp_py/solve_box_qp_admm_torch.py:285-305) and the adaptive step reads (:239-251), as
+    differentiable torch ops on (B,n,1) vectors: -> (ratio, wants)."""
+    dt = x.dtype
+    tiny = torch.full((1,), _TINY, dtype=dt, device=x.device)
+    thr = torch.full((1,), float(r['adaptive_rho_threshold']), dtype=dt, device=x.device)
+    res = x - z
+    s = rho * (z - z_old)
+    r_inf, s_inf = _inf_norm(D * res), _inf_norm(D * s)
+    pri = torch.maximum(torch.maximum(_inf_norm(D * x), _inf_norm(D * z)), tiny)
+    dua = torch.maximum(torch.maximum(torch.maximum(_inf_norm(rho * D * u), _inf_norm(torch.matmul(Qs, x) / D)), p_inf), tiny)
+    tol_p = r['eps_abs'] + r['eps_rel'] * pri
+    tol_d = r['eps_abs'] + r['eps_rel'] * dua
+    wants = torch.logical_or(r_inf > torch.maximum(tol_p, thr), s_inf > torch.maximum(tol_d, thr))
+    ratio = (torch.clamp(r_inf / pri, min=_TINY) / torch.clamp(s_inf / dua, min=_TINY)) ** 0.5
+    return ratio, wants
+
+
+def _adapted_rho(r, rho, ratio, wants):
+    """:246-251"""
+    rho = rho * torch.logical_not(wants) + (rho * ratio) * wants
+    return torch.clamp(rho, min=r['rho_min'], max=r['rho_max'])
+
+
+def _backward_with_rho_events(ctx, g):
+    """The tape of a solve in which rho was ADAPTED (solve_box_qp_admm_torch.py:237-256 inside the unrolled loop): the factor
+    changes along it, so it is walked epoch by epoch in the library (lqp_boxqp_unroll_tape_segment: every x-update a pair of cached
+    triangular solves with the pivoted LU of THAT epoch's KKT matrix, TorchLULayer's node), and the adaptation itself -- a few
+    norms of the iterates of one check, once per event -- is differentiated by autograd on its own small graph: its gradient
+    w.r.t. the iterates goes back into the sweep as injected cotangents, w.r.t. the previous rho into that epoch's rho.  No torch op
+    per iteration.  The epochs are re-derived by replaying the loop in segments between the possible events (multiples of
+    adaptive_rho_iter) with the reference's own decision rule on the replayed iterates."""
+    from .lu_layer import lu_factor
+    Q, p, A, b, lb, ub = ctx.saved_tensors
+    lib = _lib.load()
+    r = ctx.r
+    B, n = Q.shape[0], p.shape[1]
+    m = get_ncon(A, dim=1)
+    N = n + m
+    dev, dt = p.device, p.dtype
+    dtc = _lib.dtype_code(p)
+    need = ctx.needs_input_grad
+    T = ctx.iters + 1
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    sp = ctypes.c_void_p(stream)
+    # ---- the scaling (:160-203) as a graph: leaves -> (Qs, ps, As, bs, lbs, ubs, D, rho0), and ||p||_inf of the unscaled p (:127) ----
+    leaves = [None if t is None else t.detach().requires_grad_(bool(nd)) for t, nd in zip((Q, p, A, b, lb, ub), need[:6])]
+    with torch.enable_grad():
+        Qs, ps, As, bs, lbs, ubs, D, _E, rho0 = _scaled_problem(*leaves, r, ctx.has_box)
+        p_inf = _inf_norm(leaves[1])
+    ones = torch.ones(B, n, 1, dtype=dt, device=dev)
+    Dd = D.detach() if torch.is_tensor(D) else ones
+    Qsd = Qs.detach()
+    Asd = As.detach() if m > 0 else None
+    rho_e = (rho0.detach().reshape(B, 1, 1).to(dt) if torch.is_tensor(rho0) else torch.full((B, 1, 1), float(rho0), dtype=dt, device=dev)).clone()
+    eye = torch.eye(n, dtype=dt, device=dev).unsqueeze(0)
+
+    def packed_factor(rho_now):
+        M = Qsd + rho_now * eye
+        if m > 0:
+            corner = torch.zeros(B, m, m, dtype=dt, device=dev)
+            M = torch.cat((torch.cat((M, Asd.transpose(1, 2)), 2), torch.cat((Asd, corner), 2)), 1)
+        LU, piv = lu_factor(M)
+        buf = torch.empty(lib.lqp_lu_packed_bytes(dtc, B, N), dtype=torch.uint8, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(lib.lqp_lu_pack(sp, dtc, B, N, _lib.ptr(LU), _lib.ptr(piv), _lib.ptr(buf)), "lu_pack")
+        return buf
+
+    nbytes = lib.lqp_boxqp_unroll_tape_workspace_bytes(dtc, B, n, m, ctx.iters)
+    scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    gc = _lib.norm(g, dt)
+    mk = lambda *shape: torch.zeros(shape, dtype=dt, device=dev)
+    dps, dlbs, dubs, dD = mk(B, n, 1), mk(B, n, 1), mk(B, n, 1), mk(B, n, 1)
+
+    def segment(k0, k1, mode, packed, rho_now, state, inj_k=-1, inj=None, drho=None, rows=None):
+        zp, up, xp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        with _lib.on_device(dev):
+            _lib.check(lib.lqp_boxqp_unroll_tape_segment(
+                sp, dtc, B, n, m, _lib.ptr(ctx.ws), ctx.ws.numel(), ctx.iters, k0, k1, mode, _lib.ptr(packed),
+                _lib.ptr(rho_now), _lib.ptr(state), inj_k, _lib.ptr(inj), _lib.ptr(gc), _lib.ptr(dps), _lib.ptr(dlbs), _lib.ptr(dubs),
+                _lib.ptr(drho), _lib.ptr(dD), _lib.ptr(scratch), scratch.numel(),
+                ctypes.byref(zp) if rows else None, ctypes.byref(up) if rows else None, ctypes.byref(xp) if rows else None),
+                "unroll_tape_segment")
+        return zp.value, up.value, xp.value
+
+    def rows_view(ptr_value):
+        off = ptr_value - scratch.data_ptr()
+        return scratch[off: off + B * T * n * p.element_size()].view(dt).view(B, T, n)
+
+    zp, up, xp = segment(0, 0, 0, None, None, None, rows=True)       # (where the scratch keeps z_{k+1}, u_{k+1}, x_k)
+    Zr, Ur, Xr = rows_view(zp), rows_view(up), rows_view(xp)
+
+    # ---- replay, segment by segment: the epochs of the tape ----
+    ar, ar_iter, ar_max, chk = bool(r['adaptive_rho']), int(r['adaptive_rho_iter']), int(r['adaptive_rho_max_iter']), int(r['check_solved'])
+    state = mk(B, 2, n)
+    segs = []                 # (k0, k1, epoch)
+    epochs = [dict(rho=rho_e.reshape(B).contiguous(), packed=packed_factor(rho_e), event=None)]
+    k, wants, last = 0, None, None
+    while k < T:
+        if ar and k % ar_iter == 0 and 0 < k < ar_max and wants is not None and bool(torch.any(wants)):
+            ratio, _ = _check_quantities(r, rho_e, *last)
+            if bool((ratio > r['adaptive_rho_tol']).any()) or bool((ratio < 1 / r['adaptive_rho_tol']).any()):
+                epochs[-1]['event'] = dict(check=last, wants=wants, c=last_c)
+                rho_e = _adapted_rho(r, rho_e, ratio, wants)
+                epochs.append(dict(rho=rho_e.reshape(B).contiguous(), packed=packed_factor(rho_e), event=None))
+        k1 = T
+        if ar:
+            nxt = (k // ar_iter + 1) * ar_iter
+            if nxt < ar_max and nxt < T:
+                k1 = nxt
+        e = epochs[-1]
+        segment(k, k1, 1, e['packed'], e['rho'], state)
+        segs.append((k, k1, len(epochs) - 1))
+        if k1 < T:
+            last_c = ((k1 - 1) // chk) * chk
+            col = lambda R, kk: R[:, kk, :].unsqueeze(2).clone()
+            z_old = col(Zr, last_c - 1) if last_c > 0 else mk(B, n, 1)
+            last = (col(Xr, last_c), col(Zr, last_c), z_old, col(Ur, last_c), Dd, Qsd, p_inf.detach())
+            _, wants = _check_quantities(r, rho_e, *last)
+        k = k1
+
+    # ---- walk back: segments in reverse, the adaptation of every event by autograd on its own graph ----
+    rho_bar = [mk(B) for _ in epochs]
+    dD_extra, dQs_extra, dpinf = mk(B, n, 1), None, mk(B, 1, 1)
+    sbar = mk(B, 2, n)
+    for (k0, k1, ei) in reversed(segs):
+        e = epochs[ei]
+        inj, inj_k = None, -1
+        ev = e['event']
+        if ev is not None and ei + 1 < len(epochs) and k1 == min(kk for (kk, _, ej) in segs if ej == ei + 1):
+            # rho_{e+1} = adapt(rho_e, the iterates of check c): its cotangent is complete now (every later segment is walked)
+            with torch.enable_grad():
+                small = [t.detach().clone().requires_grad_(True) for t in ev['check']]
+                rl = e['rho'].reshape(B, 1, 1).detach().clone().requires_grad_(True)
+                ratio, _ = _check_quantities(r, rl, *small)
+                rho_new = _adapted_rho(r, rl, ratio, ev['wants'])
+                gr = torch.autograd.grad(rho_new, small + [rl], rho_bar[ei + 1].reshape(B, 1, 1), allow_unused=True)
+            zero = lambda t, like: torch.zeros_like(like) if t is None else t
+            gx, gz1, gz0, gu1, gDl, gQl, gpl, grl = [zero(t, like) for t, like in zip(gr, small + [rl])]
+            inj = torch.stack((gx, gz1, gu1, gz0), 1).reshape(B, 4, n).contiguous()
+            inj_k = ev['c']
+            rho_bar[ei] += grl.reshape(B)
+            dD_extra += gDl
+            dQs_extra = gQl if dQs_extra is None else dQs_extra + gQl
+            dpinf += gpl
+        drho_seg = mk(B)
+        segment(k0, k1, 2, e['packed'], e['rho'], sbar, inj_k=inj_k, inj=inj, drho=drho_seg)
+        rho_bar[ei] += drho_seg
+    dQs = torch.empty(B, n, n, dtype=dt, device=dev) if need[0] else None
+    dAs, dbs = (mk(B, m, n), mk(B, m, 1)) if m > 0 else (None, None)
+    with _lib.on_device(dev):
+        _lib.check(lib.lqp_boxqp_unroll_tape_finish(sp, dtc, B, n, m, ctx.iters, _lib.ptr(dQs), _lib.ptr(dAs), _lib.ptr(dbs),
+                                                   _lib.ptr(scratch), scratch.numel()), "unroll_tape_finish")
+    if dQs is not None and dQs_extra is not None:
+        dQs = dQs + dQs_extra
+    ctx.ws = None
+    # ---- the scaling chain by autograd ----
+    pairs = [(Qs, dQs), (ps, dps), (As, dAs), (bs, dbs), (lbs, dlbs), (ubs, dubs), (D, dD + dD_extra), (rho0, rho_bar[0].reshape(B, 1, 1)),
+             (p_inf, dpinf)]
+    outs = [(o, go) for o, go in pairs if torch.is_tensor(o) and o.requires_grad and go is not None]
+    wanted = [t for t in leaves if t is not None and t.requires_grad]
+    grads = iter(torch.autograd.grad([o for o, _ in outs], wanted, [go.reshape(o.shape) for o, go in outs], allow_unused=True)
+                 if outs and wanted else [None] * len(wanted))
+    res = [next(grads) if (t is not None and t.requires_grad) else None for t in leaves]
+    return tuple(res) + (None, None, None)
 
 
 def _scaling_backward_native(ctx, lib, stream, inputs, need, up):

@@ -1463,11 +1463,14 @@ def test_unroll_mode_goldens(dev, monkeypatch, name, tol, native):
         close_or_fp64(name, nm, t.grad, g[nm], t64, G_RTOL, native=native)
 
 
-def test_g22_unroll_through_a_rho_event(dev):
+@pytest.mark.parametrize("events", ["1", "0"])
+def test_g22_unroll_through_a_rho_event(dev, monkeypatch, events):
     """unroll=True through ONE adaptive-rho refactorisation, against the reference-made golden G22 (Q x 50, rho = 100 given, no
     auto-scaling, tol 1e-6: the reference adapts rho at iteration 100 and stops there; its autograd runs through the adaptation
-    itself, lqp_py/solve_box_qp_admm_torch.py:237-256).  The factor is not constant along this tape: the layer takes the taped loop
-    of torch ops by itself (no reverse sweep launched); solution at 1e-5, gradients at rtol 1e-4 or the float64 criterion."""
+    itself, lqp_py/solve_box_qp_admm_torch.py:237-256).  The factor is not constant along this tape: events 1 = walked epoch by epoch
+    in the library (lqp_boxqp_unroll_tape_segment; the adaptation by autograd on its own small graph), 0 = the taped loop of torch
+    ops; solution at 1e-5, gradients at rtol 1e-4 or the float64 criterion."""
+    monkeypatch.setenv("LQP_UNROLL_EVENTS", events)
     g = load_golden("g22_unroll_rho_event")
     leaves = [g[k].to(dev).requires_grad_(True) for k in ("Q", "p", "A", "b", "lb", "ub")]
     ctl = L.box_qp_control(unroll=True, rho=100.0, scale=False, eps_abs=1e-6, eps_rel=1e-6)
@@ -1475,15 +1478,78 @@ def test_g22_unroll_through_a_rho_event(dev):
     x = L.SolveBoxQP(control=dict(ctl))(*leaves)
     x.backward(g["cot"].to(dev))
     used = _lib.profile(); _lib.profile(enable=False)
-    assert used["unroll_backward"][1] == 0 and used["lu_factor"][1] >= 2, used      # (the tape refactorised)
+    assert (used["unroll_backward"][1] > 0) == (events == "1") and used["lu_factor"][1] >= 2, used      # (the tape refactorised)
     x64, g64 = _unroll_truth64(g, dict(ctl))
-    close_or_fp64("g22_unroll_rho_event", "x", x, g["x"], x64, X_TOL)
+    close_or_fp64("g22_unroll_rho_event", "x", x, g["x"], x64, X_TOL, events=events)
     for nm, t, t64 in zip(GRADS, leaves, g64):
-        close_or_fp64("g22_unroll_rho_event", nm, t.grad, g[nm], t64, G_RTOL)
+        close_or_fp64("g22_unroll_rho_event", nm, t.grad, g[nm], t64, G_RTOL, events=events)
     plain = L.torch_solve_box_qp(*[t.detach() for t in leaves], dict(ctl, unroll=False))
     assert plain["iter"] == g["iter"] == 100
     # (the adapted rho is 100 x sqrt of a ratio of residual norms that are ~1e-6 of scale at iteration 90: float32 noise of a percent)
     assert float(((plain["rho"].reshape(-1).cpu() - g["rho"].reshape(-1)) / g["rho"].reshape(-1)).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("case", ["f64_given_rho", "f64_three_factors", "f64_scaled_small_rho", "f32_given_rho", "f64_box_only", "f32_wide",
+                                  "f64_five_factors_auto_rho", "f32_five_factors_auto_rho", "f64_small_rho_every_20"])
+def test_unroll_tape_with_rho_events_against_the_taped_loop(dev, monkeypatch, case):
+    """Tapes along which rho is adapted once or several times (different given rho, adaptive_rho_iter 20 / 100, auto-scaling on and
+    off, with and without equality rows, float32 and float64): the epoch-by-epoch walk in the library (lqp_boxqp_unroll_tape_segment +
+    the adaptation by autograd on its own graph) against the taped loop of torch ops it replaces (LQP_UNROLL_EVENTS=0: the
+    reference's tape as restated, lqp_py/solve_box_qp_admm_torch.py:235-313 under unroll).  float64: 1e-9 of the gradient's own
+    largest entry (measured: 1e-15 ... 1e-13, two to five factorisations, active bounds); float32: rtol 1e-4 or no further from the
+    float64 tape on the host than the torch-op tape."""
+    cfg = {"f64_given_rho": (30, 5, 2, torch.float64, dict(rho=100.0, scale=False, eps_abs=1e-8, eps_rel=1e-8), 50.0),
+           "f64_three_factors": (40, 3, 1, torch.float64, dict(rho=1e3, scale=False, eps_abs=1e-8, eps_rel=1e-8), 1.0),
+           "f64_five_factors_auto_rho": (50, 4, 5, torch.float64, dict(adaptive_rho_iter=10, eps_abs=1e-9, eps_rel=1e-9), 1.0),
+           "f32_five_factors_auto_rho": (50, 4, 5, torch.float32, dict(adaptive_rho_iter=10, eps_abs=1e-6, eps_rel=1e-6), 1.0),
+           "f64_small_rho_every_20": (40, 3, 1, torch.float64, dict(rho=1e-2, scale=False, adaptive_rho_iter=20, eps_abs=1e-9, eps_rel=1e-9), 1.0),
+           "f64_scaled_small_rho": (40, 3, 3, torch.float64, dict(rho=1e-3, eps_abs=1e-8, eps_rel=1e-8), 1.0),
+           "f32_given_rho": (20, 4, 1, torch.float32, dict(rho=100.0, scale=False, eps_abs=1e-6, eps_rel=1e-6), 50.0),
+           "f64_box_only": (35, 6, 0, torch.float64, dict(rho=200.0, scale=False, adaptive_rho_iter=50, eps_abs=1e-8, eps_rel=1e-8), 20.0),
+           "f32_wide": (150, 3, 2, torch.float32, dict(rho=100.0, scale=False, eps_abs=1e-6, eps_rel=1e-6), 50.0)}[case]
+    n, B, m, dtype, kw, qmul = cfg
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + B, with_eq=False)
+    gen = torch.Generator().manual_seed(n + m)
+    Q = Q * qmul
+    A = torch.randn(B, m, n, generator=gen) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=gen) if m else None
+    cot = torch.randn(B, n, 1, generator=gen)
+    names = ("Q", "p", "A", "b", "lb", "ub")
+    data = dict(zip(names, (Q, p, A, b, lb, ub)))
+    ctl = L.box_qp_control(unroll=True, **kw)
+    plain = L.torch_solve_box_qp(*[None if data[k] is None else data[k].to(dtype).to(dev) for k in names], dict(ctl, unroll=False))
+    assert plain["_stats"]["n_factor"] >= 2, plain["_stats"]            # (the case must adapt rho at least once)
+    grads = {}
+    for events in ("1", "0"):
+        monkeypatch.setenv("LQP_UNROLL_EVENTS", events)
+        leaves = [None if data[k] is None else data[k].to(dtype).to(dev).requires_grad_(True) for k in names]
+        _lib.profile(enable=True, reset=True)
+        x = L.SolveBoxQP(control=dict(ctl))(*leaves)
+        x.backward(cot.to(dtype).to(dev))
+        used = _lib.profile(); _lib.profile(enable=False)
+        assert (used["unroll_backward"][1] > 0) == (events == "1"), (events, used["unroll_backward"])
+        grads[events] = (x.detach(), [None if t is None else t.grad for t in leaves])
+    tag = f"unroll_rho_events_{case}"
+    if dtype == torch.float64:
+        assert err(grads["1"][0], grads["0"][0]) < 1e-8
+        for nm, g1, g0 in zip(GRADS, grads["1"][1], grads["0"][1]):
+            if g1 is None:
+                assert g0 is None
+                continue
+            e = err(g1, g0) / (float(g0.abs().max()) + 1e-300)
+            P.record(tag, nm, e, n_factor=plain["_stats"]["n_factor"], scale_of_gradient=float(g0.abs().max()))
+            assert e < 1e-9, (nm, e)
+        return
+    from lqp_py_amd.unrolled import _eager_unrolled
+    l64 = [None if data[k] is None else data[k].double().requires_grad_(True) for k in names]
+    x64 = _eager_unrolled(*l64, SB.resolve_control(dict(ctl), n), True, True, solver_cls=_CpuLU)
+    x64.backward(cot.double())
+    close_or_fp64(tag, "x", grads["1"][0], grads["0"][0], x64.detach(), X_TOL)
+    for nm, g1, g0, t64 in zip(GRADS, grads["1"][1], grads["0"][1], l64):
+        if g1 is None:
+            assert g0 is None
+            continue
+        close_or_fp64(tag, nm, g1, g0, t64.grad, G_RTOL)
 
 
 @pytest.mark.parametrize("native", ["1", "0"])
@@ -1585,7 +1651,8 @@ def test_unroll_sweep_on_two_workgroups(dev, monkeypatch, n, B, m):
 def test_unroll_native_falls_back(dev):
     """Which tape runs where: float64 and the cached-LU x-update take the reverse sweep on the packed LU factor (round 6:
     lqp_boxqp_unroll_backward_lu -- sweep, equality rows, outer product: three launches); a solve in which rho was adapted (the
-    factor is no longer constant along the tape) takes the taped loop by itself."""
+    factor is no longer constant along the tape) is walked epoch by epoch (lqp_boxqp_unroll_tape_segment: a replay and a reverse
+    launch per segment + the two of the finish).  Nothing takes the taped loop of torch ops by itself any more."""
     g = load_golden("g13_unroll")
     for kind in ("f64", "lu", "adapted"):
         cast = (lambda t: t.double()) if kind == "f64" else (lambda t: t)
@@ -1600,7 +1667,7 @@ def test_unroll_native_falls_back(dev):
         x = L.SolveBoxQP(control=ctl)(*leaves)
         x.backward(cast(g["cot"]).to(dev))
         used = _lib.profile(); _lib.profile(enable=False)
-        assert used["unroll_backward"][1] == (0 if kind == "adapted" else 3) and used["lu_factor"][1] >= 1, (kind, used)
+        assert (used["unroll_backward"][1] >= 4 if kind == "adapted" else used["unroll_backward"][1] == 3) and used["lu_factor"][1] >= 1, (kind, used)
         assert all(torch.isfinite(t.grad).all() for t in leaves), kind
         if kind != "adapted":
             assert err(x, cast(g["x"])) < 2e-5, kind
