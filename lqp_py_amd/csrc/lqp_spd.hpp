@@ -1323,6 +1323,9 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
     float* pcol = WT + 64 * SPD_LS;
     int* flag = (int*)(pcol + PIV_LDS);
     if (tid == 0) flag[0] = 0;
+    // (two pivot steps per pass over the tiles, NP == 2: phases bit 4 -- this step's Y goes to the SECOND set of panel blocks, Yg + K
+    //  blocks --, bit 2 the look-ahead on block column k + 1, bit 3 the fused update of steps k and k + 1: see below)
+    float* const Ygw = Yg + ((NP == 2 && (phases & 16)) ? (size_t)K * LQP_BLK : 0);
     for (int k = (NP == 1 ? 0 : k0); k < (NP == 1 ? K : k1); ++k) {
         if (phases & 1) {
             wg_pivot<LQP_PIV_WAVES>(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK, W, WT, pcol, flag, k * 64);
@@ -1372,7 +1375,7 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
                     __syncthreads();
                 }
                 for (int u = 0; u < cn; ++u)
-                    *(V4<float>*)(Yg + (size_t)(c0 + u) * LQP_BLK + tid * 4) = *(const V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4);
+                    *(V4<float>*)(Ygw + (size_t)(c0 + u) * LQP_BLK + tid * 4) = *(const V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4);
                 for (int t2 = __builtin_amdgcn_readfirstlane(w); t2 < cn * 4; t2 += LQP_NW) {
                     const int u = t2 >> 2, qi = (t2 >> 1) & 1, qj = t2 & 1;
                     const int sl = c0 + u, i = sl < k ? sl : sl + 1;
@@ -1398,7 +1401,7 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
                 const int qi = (w >> 1) & 1, qj = w & 1;
                 const f32x16 acc = (qi | qj) ? spd_quadrant<1, true>(WT + (32 * qi) * SPD_LS, WT + (32 * qj) * SPD_LS)
                                              : spd_quadrant(WT, WT);
-                float* C = (NP == 1 ? Hs + (size_t)sym_idx(k, k, K) * LQP_BLK : Yg + (size_t)(K - 1) * LQP_BLK) + (32 * qi) * 64 + 32 * qj + li;
+                float* C = (NP == 1 ? Hs + (size_t)sym_idx(k, k, K) * LQP_BLK : Ygw + (size_t)(K - 1) * LQP_BLK) + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = -acc[q];
             }
@@ -1479,6 +1482,154 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
                 }
             }
             __threadfence_block();
+        }
+        if constexpr (NP == 2) {
+            // ---- two pivot steps per pass over the tiles (k + 1 < K).  Step k's update touches every tile, step k + 1's again: 2 x
+            //      (K^2 / 2) tile round trips through HBM per pair of steps.  Fused: launch A = phase 1 of step k (as ever); launch
+            //      B (bit 2) = step k's update on block COLUMN k + 1 only (K - 1 tiles: what step k + 1's pivot block and panel
+            //      read); launch C = phase 1 of step k + 1 with its Y' in the second set (bit 4); launch D (bit 3) = ONE read-
+            //      modify-write of every other tile with both products, Y_i Y_j^T then Y'_i Y'_j^T -- subtracted one after the
+            //      other, so every tile sees the operations of the two separate passes in their order: the same bits.  Rows are
+            //      walked in the index that skips k + 1 (= the slot index of the second set; the first set has the same index for
+            //      every row but k, whose tiles -- Y W since launch A, the pivot tile -W^T W -- take the second product only). ----
+            const int kn = k + 1;
+            if (phases & 4) {
+                if (part == 0)
+                    *(V4<float>*)(Hs + (size_t)sym_idx(k, k, K) * LQP_BLK + tid * 4) = *(const V4<float>*)(Yg + (size_t)(K - 1) * LQP_BLK + tid * 4);
+                // Y_{k+1} (first-set slot k) in LDS slot 0; the other rows of the first set in chunks of seven behind it, dealt
+                // alternately to the two workgroups; the diagonal tile (k + 1, k + 1) with part 0's first chunk
+                *(V4<float>*)(Y + (size_t)r * SPD_LS + cq * 4) = *(const V4<float>*)(Yg + (size_t)k * LQP_BLK + tid * 4);
+                int mine[SPD_BIGK], nm = 0;
+                for (int sl = 0, t = 0; sl < K - 1; ++sl) {
+                    if (sl == k) continue;
+                    if ((t++ & 1) == part) mine[nm++] = sl;
+                }
+                bool diag_done = part != 0;
+                for (int c0 = 0; c0 < nm || !diag_done; c0 += 6) {
+                    const int cn = (nm - c0) < 6 ? (nm - c0 > 0 ? nm - c0 : 0) : 6;
+                    for (int u = 0; u < cn; ++u)
+                        *(V4<float>*)(Y + ((size_t)(1 + u) * 64 + r) * SPD_LS + cq * 4) = *(const V4<float>*)(Yg + (size_t)mine[c0 + u] * LQP_BLK + tid * 4);
+                    __syncthreads();
+                    const bool with_diag = !diag_done;
+                    const int ntask = (cn + (with_diag ? 1 : 0)) * 4;
+                    for (int task = __builtin_amdgcn_readfirstlane(w); task < ntask; task += LQP_NW) {
+                        const int u = task >> 2, qi = (task >> 1) & 1, qj = task & 1;
+                        const bool is_diag = u == cn;                    // (the extra task group: tile (k + 1, k + 1))
+                        if (is_diag && qi == 0 && qj == 1) continue;   // mirrored from its (1, 0) quadrant
+                        const int sl = is_diag ? k : mine[c0 + u];
+                        const int i = sl < k ? sl : sl + 1;              // block row of the other operand (i != k)
+                        // tile (max, min): X = the panel block of the larger row, Z = that of the smaller one (as the update phase)
+                        const float* Xb = is_diag ? Y : (i > kn ? Y + (size_t)(1 + u) * 64 * SPD_LS : Y);
+                        const float* Zb = is_diag ? Y : (i > kn ? Y : Y + (size_t)(1 + u) * 64 * SPD_LS);
+                        float* T0 = Hs + (size_t)(is_diag ? sym_idx(kn, kn, K) : (i > kn ? sym_idx(i, kn, K) : sym_idx(kn, i, K))) * LQP_BLK;
+                        float* C = T0 + (32 * qi) * 64 + 32 * qj + li;
+                        f32x16 cur;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];
+                        const f32x16 acc = spd_quadrant(Xb + (size_t)(32 * qi) * SPD_LS, Zb + (size_t)(32 * qj) * SPD_LS);
+                        cur -= acc;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                        if (is_diag && qi == 1 && qj == 0) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) T0[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                        }
+                    }
+                    diag_done = true;
+                    __syncthreads();
+                }
+                __threadfence_block();
+            }
+            if (phases & 8) {
+                const float* YgB = Yg + (size_t)K * LQP_BLK;
+                if (part == 0)
+                    *(V4<float>*)(Hs + (size_t)sym_idx(kn, kn, K) * LQP_BLK + tid * 4) = *(const V4<float>*)(YgB + (size_t)(K - 1) * LQP_BLK + tid * 4);
+                constexpr int G2 = 2;                                     // rows per group: (second | first set) x (a | b) = 8 LDS slots
+                const int nrow = K - 1, ng = (nrow + G2 - 1) / G2;
+                // (group a stays in LDS for all of this workgroup's pairs of one ga: staged afresh for every pair, the panel blocks moved
+                //  as many bytes as the tiles -- 288 block loads against 272 tile round trips per pair of steps at K = 16; 168 like this)
+                for (int ga = 0; ga < ng; ++ga) {
+                    const int a0 = G2 * ga;
+                    const int an = (nrow - a0) < G2 ? (nrow - a0) : G2;
+                    for (int u = 0; u < an; ++u) {
+                        *(V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4) = *(const V4<float>*)(YgB + (size_t)(a0 + u) * LQP_BLK + tid * 4);
+                        if (a0 + u != k)
+                            *(V4<float>*)(Y + ((size_t)(G2 + u) * 64 + r) * SPD_LS + cq * 4) = *(const V4<float>*)(Yg + (size_t)(a0 + u) * LQP_BLK + tid * 4);
+                    }
+                    for (int gb = 0; gb <= ga; ++gb) {
+                        if (((ga * (ga + 1) / 2 + gb) & 1) != part) continue;      // (the pairs dealt alternately in their running number)
+                        const int b0 = G2 * gb;
+                        const int bn = (nrow - b0) < G2 ? (nrow - b0) : G2;
+                        const int boff = gb == ga ? 0 : 2 * G2;            // LDS slots: a second set 0.., a first set G2.., b: + 2 G2
+                        if (gb != ga)
+                            for (int u = 0; u < bn; ++u) {
+                                *(V4<float>*)(Y + ((size_t)(2 * G2 + u) * 64 + r) * SPD_LS + cq * 4) = *(const V4<float>*)(YgB + (size_t)(b0 + u) * LQP_BLK + tid * 4);
+                                if (b0 + u != k)
+                                    *(V4<float>*)(Y + ((size_t)(3 * G2 + u) * 64 + r) * SPD_LS + cq * 4) = *(const V4<float>*)(Yg + (size_t)(b0 + u) * LQP_BLK + tid * 4);
+                            }
+                        __syncthreads();
+                        const int npair = gb == ga ? an * (an + 1) / 2 : an * bn;
+                        auto decode = [&](const int task, int& ua, int& ub, bool& skip, bool& mirror, bool& first) -> float* {
+                            const int qi = (task >> 1) & 1, qj = task & 1, p = task >> 2;
+                            if (gb == ga) {
+                                ua = 0;
+                                while ((ua + 1) * (ua + 2) / 2 <= p) ++ua;
+                                ub = p - ua * (ua + 1) / 2;
+                            } else {
+                                ua = p / bn;
+                                ub = p - ua * bn;
+                            }
+                            const int si = a0 + ua, sj = b0 + ub;                  // si >= sj
+                            skip = si == sj && qi == 0 && qj == 1;                  // diagonal tile: mirrored from its (1,0) quadrant
+                            mirror = si == sj && qi == 1 && qj == 0;
+                            first = si != k && sj != k;                              // the first set's product applies
+                            const int i = si < kn ? si : si + 1, j = sj < kn ? sj : sj + 1;
+                            return Hs + (size_t)sym_idx(i, j, K) * LQP_BLK;
+                        };
+                        auto load_c = [&](const float* T0, const int task, f32x16& c) {
+                            const float* C = T0 + (32 * ((task >> 1) & 1)) * 64 + 32 * (task & 1) + li;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) c[q] = C[quad_row(q, lh) * 64];
+                        };
+                        const int ntask = npair * 4;
+                        int task = __builtin_amdgcn_readfirstlane(w);
+                        int ua = 0, ub = 0; bool skip = false, mirror = false, first = false;
+                        float* T0 = nullptr;
+                        f32x16 nxt;
+                        if (task < ntask) { T0 = decode(task, ua, ub, skip, mirror, first); if (!skip) load_c(T0, task, nxt); }
+                        while (task < ntask) {
+                            const int qi = (task >> 1) & 1, qj = task & 1;
+                            f32x16 cur = nxt;
+                            float* Tc = T0;
+                            const int cua = ua, cub = ub;
+                            const bool cskip = skip, cmirror = mirror, cfirst = first;
+                            const int nt = task + LQP_NW;
+                            if (nt < ntask) { T0 = decode(nt, ua, ub, skip, mirror, first); if (!skip) load_c(T0, nt, nxt); }
+                            if (!cskip) {
+                                if (cfirst) {
+                                    const f32x16 acc1 = spd_quadrant(Y + ((size_t)(G2 + cua) * 64 + 32 * qi) * SPD_LS,
+                                                                     Y + ((size_t)(boff + G2 + cub) * 64 + 32 * qj) * SPD_LS);
+                                    cur -= acc1;
+                                }
+                                const f32x16 acc2 = spd_quadrant(Y + ((size_t)cua * 64 + 32 * qi) * SPD_LS,
+                                                                 Y + ((size_t)(boff + cub) * 64 + 32 * qj) * SPD_LS);
+                                cur -= acc2;
+                                float* C = Tc + (32 * qi) * 64 + 32 * qj + li;
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
+                                if (cmirror) {
+#pragma unroll
+                                    for (int q = 0; q < 16; ++q) Tc[li * 64 + 32 + quad_row(q, lh)] = cur[q];
+                                }
+                            }
+                            task = nt;
+                        }
+                        __syncthreads();
+                    }
+                    __syncthreads();                                        // (group a is restaged: nobody may still read it)
+                }
+                __threadfence_block();
+            }
         }
     }
     if (tid == 0 && flag[0] != 0 && *info == 0) *info = flag[0];

@@ -1142,6 +1142,25 @@ def test_streaming_loop_on_two_workgroups(dev, monkeypatch, n, B, m):
         assert out["1"]["iter"] == ref["iter"]
 
 
+@pytest.mark.parametrize("n,B,m", [(577, 3, 1), (704, 2, 0), (1000, 4, 1), (1024, 2, 2), (960, 8, 5)])
+def test_sweep_above_512_rows_two_steps_per_pass(dev, monkeypatch, n, B, m):
+    """The sweep above 512 rows on two workgroups per matrix takes TWO pivot steps per pass over the tiles (wg_spd_sweep_big: step k's
+    update on block column k + 1 alone, then both products into every other tile in one read-modify-write, subtracted one after the
+    other): the operations of the two separate passes in their order -- the same bits as LQP_SPD_BIG_FUSE=0, odd and even numbers of
+    block rows."""
+    Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + B, with_eq=False)
+    gen = torch.Generator().manual_seed(n)
+    A = torch.randn(B, m, n, generator=gen) if m else None
+    b = 0.1 * torch.randn(B, m, 1, generator=gen) if m else None
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LQP_SPD_BIG_FUSE", flag)
+        out[flag], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(**TOL))
+    assert out["1"]["_stats"]["linsolve_used"] == 2 and out["1"]["iter"] == out["0"]["iter"]
+    for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
+        assert torch.equal(out["1"][k], out["0"][k]), k
+
+
 def test_streaming_loop_partner_missing_degrades(dev, monkeypatch):
     """... and with its partner workgroups missing (LQP_DBG_LOOP_ABSENT bit 3): the exchange gives up after its bounded spin, raises the
     time-out word, the synchronous call repeats the solve with nothing shared and returns the undisturbed answer."""
