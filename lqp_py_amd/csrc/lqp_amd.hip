@@ -159,6 +159,7 @@ struct Knobs {
     int loop_split4;           // LQP_LOOP_SPLIT4
     int loop_np2;              // LQP_LOOP_NP2
     int spd_big_fuse;          // LQP_SPD_BIG_FUSE
+    int spd_big_f16;           // LQP_SPD_BIG_F16
     int loop_split_seg;        // LQP_LOOP_SPLIT_SEG
     int lu2;                   // LQP_LU2
     int lu_wide;               // LQP_LU_WIDE
@@ -216,6 +217,7 @@ Knobs read_knobs() {
     k.loop_split4 = env_int("LQP_LOOP_SPLIT4", 1);
     k.loop_np2 = env_int("LQP_LOOP_NP2", 1);
     k.spd_big_fuse = env_int("LQP_SPD_BIG_FUSE", 1);
+    k.spd_big_f16 = env_int("LQP_SPD_BIG_F16", 1);
     k.loop_split_seg = env_int("LQP_LOOP_SPLIT_SEG", 1);
     k.lu2 = env_int("LQP_LU2", 1);
     k.lu_wide = env_int("LQP_LU_WIDE", 1);
@@ -801,14 +803,16 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     hipLaunchKernelGGL(k_spd_begin<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P, gate);
                     // two pivot steps per pass over the tiles (wg_spd_sweep_big, phases bits 2 .. 4): pivot + Y of step k | its update on
                     // block column k + 1 alone | pivot + Y' of step k + 1 | ONE read-modify-write of every other tile with both products
-                    const bool fuse2 = knobs().spd_big_fuse != 0 && (size_t)P.Np * P.Np >= (size_t)2 * P.Ks * LQP_BLK;
+                    const bool fuse2 = knobs().spd_big_fuse != 0 && (size_t)P.Np * P.Np >= (size_t)(2 * P.Ks + 1) * LQP_BLK;
+                    // ... its panel blocks as two-half operands, the update products on the float16 pipe (lqp_f16x2.hpp)
+                    const int f16 = (fuse2 && knobs().spd_big_f16 != 0) ? 32 : 0;
                     for (int k = 0; k < P.Ks; ++k) {
                         const dim3 grd(shared_grid(B, SPD_NP)), blk(LQP_NT);
                         if (fuse2 && k + 1 < P.Ks) {
-                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k, 1);
-                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k, 4);
-                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k + 1, 1 | 16);
-                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k, 8);
+                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k, 1 | f16);
+                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k, 4 | f16);
+                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k + 1, 1 | 16 | f16);
+                            hipLaunchKernelGGL(k_spd_big_step<>, grd, blk, lds, st, P, gate, k, 8 | f16);
                             ++k;
                             continue;
                         }

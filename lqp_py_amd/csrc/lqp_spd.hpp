@@ -1374,6 +1374,46 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
                     }
                     __syncthreads();
                 }
+                if (NP == 2 && (phases & 32)) {
+                    // the panel blocks go out as TWO-HALF operands (lqp_f16x2.hpp: cells [8 hi | 8 mid], one power-of-two scale per
+                    // block and 32-row half -- its largest entry: a wave holds four rows of one half): what the fused update and
+                    // the look-ahead multiply on the float16 pipe.  This phase's own products stay float32.
+                    unsigned int* ymx = (unsigned int*)pcol;                    // [cn][2] (the pivot block is done with pcol)
+                    if (tid < 2 * CH) ymx[tid] = 0u;
+                    __syncthreads();
+                    V4<float> yv[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        if (u < cn) {
+                            yv[u] = *(const V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4);
+                            float mx = fmaxf(fmaxf(fabsf(yv[u].v[0]), fabsf(yv[u].v[1])), fmaxf(fabsf(yv[u].v[2]), fabsf(yv[u].v[3])));
+                            mx = wave_max(mx);
+                            if (lane == 0) atomicMax(ymx + 2 * u + (w >> 3), __float_as_uint(mx));
+                        }
+                    }
+                    __syncthreads();
+                    float* ysc = Yg + (size_t)2 * K * LQP_BLK + ((phases & 16) ? 2 * K : 0);      // scales: [set][slot][half]
+                    const int cs = cq >> 2, ch = cq & 1, piece = (cq >> 1) & 1;                     // this thread's run of cell (cs, ch)
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        if (u < cn) {
+                            float sc, inv;
+                            f2_scale_of(__uint_as_float(ymx[2 * u + (w >> 3)]), sc, inv);
+                            _Float16 hi[4], mid[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = yv[u].v[e] * sc;
+                                hi[e] = (_Float16)a;
+                                mid[e] = (_Float16)(a - (float)hi[e]);
+                            }
+                            char* cell = (char*)(Ygw + (size_t)(c0 + u) * LQP_BLK) + (size_t)r * 256 + 64 * cs + 32 * ch;
+                            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                            *(h16x4*)(cell + 8 * piece) = h16x4{hi[0], hi[1], hi[2], hi[3]};
+                            *(h16x4*)(cell + 16 + 8 * piece) = h16x4{mid[0], mid[1], mid[2], mid[3]};
+                            if ((tid & 511) == 0) ysc[2 * (c0 + u) + (w >> 3)] = sc;
+                        }
+                    }
+                } else
                 for (int u = 0; u < cn; ++u)
                     *(V4<float>*)(Ygw + (size_t)(c0 + u) * LQP_BLK + tid * 4) = *(const V4<float>*)(Y + ((size_t)u * 64 + r) * SPD_LS + cq * 4);
                 for (int t2 = __builtin_amdgcn_readfirstlane(w); t2 < cn * 4; t2 += LQP_NW) {
@@ -1526,8 +1566,19 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
                         f32x16 cur;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) cur[q] = C[quad_row(q, lh) * 64];
-                        const f32x16 acc = spd_quadrant(Xb + (size_t)(32 * qi) * SPD_LS, Zb + (size_t)(32 * qj) * SPD_LS);
-                        cur -= acc;
+                        if (phases & 32) {
+                            // (two-half operands: the blocks in LDS are cell images, a scale per block and 32-row half)
+                            const float* ysc = Yg + (size_t)2 * K * LQP_BLK;
+                            const int slx = (is_diag || i < kn) ? k : sl, slz = (is_diag || i > kn) ? k : sl;
+                            const float un = -1.f / (ysc[2 * slx + qi] * ysc[2 * slz + qj]);
+                            const f32x16 acc = f2_quadrant<0, 4>((const char*)(Xb + (size_t)(32 * qi + li) * SPD_LS) + 32 * lh,
+                                                                 (const char*)(Zb + (size_t)(32 * qj + li) * SPD_LS) + 32 * lh);
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) cur[q] = fmaf(acc[q], un, cur[q]);
+                        } else {
+                            const f32x16 acc = spd_quadrant(Xb + (size_t)(32 * qi) * SPD_LS, Zb + (size_t)(32 * qj) * SPD_LS);
+                            cur -= acc;
+                        }
 #pragma unroll
                         for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];
                         if (is_diag && qi == 1 && qj == 0) {
@@ -1605,7 +1656,22 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
                             const bool cskip = skip, cmirror = mirror, cfirst = first;
                             const int nt = task + LQP_NW;
                             if (nt < ntask) { T0 = decode(nt, ua, ub, skip, mirror, first); if (!skip) load_c(T0, nt, nxt); }
-                            if (!cskip) {
+                            if (!cskip && (phases & 32)) {
+                                const float* ysc = Yg + (size_t)2 * K * LQP_BLK;          // [set][slot][half]
+                                const int sa = a0 + cua, sb = b0 + cub;
+                                if (cfirst) {
+                                    const float un = -1.f / (ysc[2 * sa + qi] * ysc[2 * sb + qj]);
+                                    const f32x16 acc1 = f2_quadrant<0, 4>((const char*)(Y + ((size_t)(G2 + cua) * 64 + 32 * qi + li) * SPD_LS) + 32 * lh,
+                                                                          (const char*)(Y + ((size_t)(boff + G2 + cub) * 64 + 32 * qj + li) * SPD_LS) + 32 * lh);
+#pragma unroll
+                                    for (int q = 0; q < 16; ++q) cur[q] = fmaf(acc1[q], un, cur[q]);
+                                }
+                                const float un2 = -1.f / (ysc[2 * K + 2 * sa + qi] * ysc[2 * K + 2 * sb + qj]);
+                                const f32x16 acc2 = f2_quadrant<0, 4>((const char*)(Y + ((size_t)cua * 64 + 32 * qi + li) * SPD_LS) + 32 * lh,
+                                                                      (const char*)(Y + ((size_t)(boff + cub) * 64 + 32 * qj + li) * SPD_LS) + 32 * lh);
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) cur[q] = fmaf(acc2[q], un2, cur[q]);
+                            } else if (!cskip) {
                                 if (cfirst) {
                                     const f32x16 acc1 = spd_quadrant(Y + ((size_t)(G2 + cua) * 64 + 32 * qi) * SPD_LS,
                                                                      Y + ((size_t)(boff + G2 + cub) * 64 + 32 * qj) * SPD_LS);
@@ -1614,6 +1680,8 @@ __device__ __forceinline__ void wg_spd_sweep_big(float* __restrict__ Hs, const i
                                 const f32x16 acc2 = spd_quadrant(Y + ((size_t)cua * 64 + 32 * qi) * SPD_LS,
                                                                  Y + ((size_t)(boff + cub) * 64 + 32 * qj) * SPD_LS);
                                 cur -= acc2;
+                            }
+                            if (!cskip) {
                                 float* C = Tc + (32 * qi) * 64 + 32 * qj + li;
 #pragma unroll
                                 for (int q = 0; q < 16; ++q) C[quad_row(q, lh) * 64] = cur[q];

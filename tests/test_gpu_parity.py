@@ -1146,19 +1146,27 @@ def test_streaming_loop_on_two_workgroups(dev, monkeypatch, n, B, m):
 def test_sweep_above_512_rows_two_steps_per_pass(dev, monkeypatch, n, B, m):
     """The sweep above 512 rows on two workgroups per matrix takes TWO pivot steps per pass over the tiles (wg_spd_sweep_big: step k's
     update on block column k + 1 alone, then both products into every other tile in one read-modify-write, subtracted one after the
-    other): the operations of the two separate passes in their order -- the same bits as LQP_SPD_BIG_FUSE=0, odd and even numbers of
-    block rows."""
+    other): the operations of the two separate passes in their order -- with float32 products (LQP_SPD_BIG_F16=0) the same bits as
+    LQP_SPD_BIG_FUSE=0, odd and even numbers of block rows.  The default carries the panel blocks as two-half operands and multiplies
+    them on the float16 pipe (lqp_f16x2.hpp): the same iteration count, iterates within float32 rounding of the float32 build, both at
+    the tolerance from the oracle."""
     Q, p, _, _, lb, ub = O.create_qp_data(n, B, seed=n + B, with_eq=False)
     gen = torch.Generator().manual_seed(n)
     A = torch.randn(B, m, n, generator=gen) if m else None
     b = 0.1 * torch.randn(B, m, 1, generator=gen) if m else None
+    inp = (Q, p, A, b, lb, ub)
     out = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("LQP_SPD_BIG_FUSE", flag)
-        out[flag], _ = solve(dev, (Q, p, A, b, lb, ub), O.make_control(**TOL))
-    assert out["1"]["_stats"]["linsolve_used"] == 2 and out["1"]["iter"] == out["0"]["iter"]
+    for fuse, f16 in (("1", "0"), ("0", "0"), ("1", "1")):
+        monkeypatch.setenv("LQP_SPD_BIG_FUSE", fuse)
+        monkeypatch.setenv("LQP_SPD_BIG_F16", f16)
+        out[fuse + f16], _ = solve(dev, inp, O.make_control(**TOL))
+    assert out["10"]["_stats"]["linsolve_used"] == 2 and out["10"]["iter"] == out["00"]["iter"] == out["11"]["iter"]
+    ref = O.solve_box_qp(*inp, O.make_control(**TOL)) if B <= 4 else None
     for k in ("x", "z", "u", "lams") + (("nus",) if m else ()):
-        assert torch.equal(out["1"][k], out["0"][k]), k
+        assert torch.equal(out["10"][k], out["00"][k]), k
+        assert err(out["11"][k], out["00"][k]) < 3e-6 * max(1.0, float(out["00"][k].abs().max())), k
+        if ref is not None:
+            assert err(out["11"][k], ref[k]) < 1e-4 * max(1.0, float(ref[k].abs().max())), k
 
 
 def test_streaming_loop_partner_missing_degrades(dev, monkeypatch):
