@@ -1397,15 +1397,30 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
     // LDS carve.  LU path:  [resident blocks] v tmp | z u ps lb ub D bs red | dest
     //            SYM path: [resident blocks] v xs ylds cvl part[NW][Nps] | z u ps lb ub D bs red
     const int Nps = SYM ? P.Ks * LQP_NB : Np;                // padded length of the solve vector
-    const int rl = SYM ? (NT == 512 ? P.sym_rl_hot : P.sym_rl) : LQP_RLDS;
+    int rl = SYM ? (NT == 512 ? P.sym_rl_hot : P.sym_rl) : LQP_RLDS;
+    // NP == 2: this workgroup's range of the stream -- block columns [rj0, rj0 + rwc), rsn blocks from stream index rs0.  Only ITS
+    // row-sum slots and column sums are kept (the layout the host sized holds them for the whole stream): what that frees holds
+    // more blocks of H -- three / two at Ks = 16.
+    int rj0 = 0, rs0 = 0, rsn = -1, rwc = P.Ks;
+    int ylds_slots = SYM ? sym_blocks(P.Ks) : 0, part_stride = Nps;
+    if constexpr (NP == 2) {
+        const int S_ = sym_blocks(P.Ks);
+        int jc = 0, acc = 0;
+        while (jc < P.Ks && 2 * acc < S_) { acc += P.Ks - jc; ++jc; }      // columns [0, jc): the first to reach half of the blocks
+        rj0 = part_id == 0 ? 0 : jc; rs0 = part_id == 0 ? 0 : acc; rsn = part_id == 0 ? acc : S_ - acc;
+        rwc = part_id == 0 ? jc : P.Ks - jc;
+        const int freed = (S_ - rsn) * 64 + (NT / 64) * (Nps - rwc * 64);      // floats
+        ylds_slots = rsn; part_stride = rwc * 64;
+        rl += freed / LQP_BLK;
+    }
     T* lds_res = (T*)smem;                                   // resident blocks (RES only), 16-KB aligned chunks
     T* v = lds_res + (RES ? (size_t)rl * LQP_BLK : 0);
     T* tmp = v + Nps;                                        // LU: 64 scratch; SYM: xs (the new x)
     T* xs = tmp;
     T* ylds = xs + Nps;                                      // SYM: one 64-slot per block of the stream
-    T* cvl = ylds + (SYM ? sym_blocks(P.Ks) * 64 : 0);
+    T* cvl = ylds + (size_t)ylds_slots * 64;
     T* part = cvl + Nps;
-    T* z = SYM ? part + (size_t)(NT / 64) * Nps : tmp + 64;
+    T* z = SYM ? part + (size_t)(NT / 64) * part_stride : tmp + 64;
     T* u = z + n;
     T* ps = u + n;
     T* lb = ps + n;
@@ -1486,13 +1501,6 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
 
     BlockStream<T, NT> st;
     ResidentRegs<T, NT> rr;
-    // NP == 2: this workgroup's range of the stream -- block columns [rj0, ..), rsn blocks from stream index rs0
-    int rj0 = 0, rs0 = 0, rsn = -1;
-    if constexpr (NP == 2) {
-        int jc = 0, acc = 0;
-        while (jc < P.Ks && 2 * acc < S) { acc += P.Ks - jc; ++jc; }      // columns [0, jc): the first to reach half of the blocks
-        rj0 = part_id == 0 ? 0 : jc; rs0 = part_id == 0 ? 0 : acc; rsn = part_id == 0 ? acc : S - acc;
-    }
     const T* packed_r = packed + (size_t)rs0 * LQP_BLK;
     unsigned long long* const xq = NP == 2 ? P.xchg + (size_t)b * XCHG_WORDS : nullptr;
     // (LDS-resident blocks actually used: the layout is sized for the whole stream, a range may be shorter than registers + rl)
@@ -1517,9 +1525,9 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
     for (int r = tid; r < m; r += NT) bs[r] = V.bs[r];
     if constexpr (SYM) {
         for (int i = tid; i < Nps; i += NT) cvl[i] = (i < n && m > 0) ? V.cv[i] : T(0);
-        if constexpr (NP == 2) {       // (slots and column sums of the partner's blocks are never written: they must read as zero)
-            for (int i = tid; i < S * 64; i += NT) ylds[i] = T(0);
-            for (int i = tid; i < (NT / 64) * Nps; i += NT) part[i] = T(0);
+        if constexpr (NP == 2) {       // (every slot / column sum of the range is written by every product; zeroed once all the same)
+            for (int i = tid; i < ylds_slots * 64; i += NT) ylds[i] = T(0);
+            for (int i = tid; i < (NT / 64) * part_stride; i += NT) part[i] = T(0);
         }
     } else {
         const int* gdest = P.dest + (size_t)b * Np;
@@ -1547,7 +1555,9 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
                 wg_barrier_lds();
             }
             if (dbg_on) { const unsigned long long t = clock64(); dbt[0] += t - dt0; dt0 = t; }
-            if constexpr (NP == 2) wg_sym_gemv<RES, NT>(st, rr, lds_res, rl_use, packed_r, P.Ks, Nps, v, ylds, part, rj0, rs0, rsn);
+            if constexpr (NP == 2)         // (the range's slots and column sums: base pointers moved so that the walk's own indices fit)
+                wg_sym_gemv<RES, NT>(st, rr, lds_res, rl_use, packed_r, P.Ks, part_stride, v, ylds - (size_t)rs0 * 64, part - (size_t)rj0 * 64,
+                                     rj0, rs0, rsn);
             else wg_sym_gemv<RES, NT>(st, rr, lds_res, rl, packed, P.Ks, Nps, v, ylds, part);
             wg_barrier_lds();
             if (dbg_on) { const unsigned long long t = clock64(); dbt[1] += t - dt0; dt0 = t; }
@@ -1563,7 +1573,21 @@ __device__ __forceinline__ void admm_loop_body_from(const FwdParams<T>& P, int i
             }
             if (dbg_on) { const unsigned long long t = clock64(); dbt[2] += t - dt0; dt0 = t; }
             for (int i = tid; i < Nps; i += NT) {
-                T ysum = sym_combine<NT>(i, P.Ks, Nps, ylds, part);
+                T ysum;
+                if constexpr (NP == 2) {
+                    // the partial product of this workgroup's columns: row sums of the blocks (bi, j), j in its range, j <= bi; column sums
+                    // where column bi is its own (the terms of sym_combine that are not zero for this range, in sym_combine's order)
+                    const int bi = i >> 6, r_ = i & 63;
+                    ysum = T(0);
+                    const int jhi = bi < rj0 + rwc - 1 ? bi : rj0 + rwc - 1;
+                    for (int j = rj0; j <= jhi; ++j) ysum += ylds[(size_t)(sym_idx(bi, j, P.Ks) - rs0) * 64 + r_];
+                    if (bi >= rj0 && bi < rj0 + rwc) {
+#pragma unroll
+                        for (int ww = 0; ww < NT / 64; ++ww) ysum += part[(size_t)ww * part_stride + (i - rj0 * 64)];
+                    }
+                } else {
+                    ysum = sym_combine<NT>(i, P.Ks, Nps, ylds, part);
+                }
                 if constexpr (NP == 2) {
                     // this workgroup's partial out, the partner's in (one granule per element, thread i = element i)
                     const unsigned int tag = (unsigned int)(it + 1);
