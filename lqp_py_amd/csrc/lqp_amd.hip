@@ -746,6 +746,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
     // rho = ||Qs||_F / sqrt(n): the norm is summed by k_spd_begin, which reads all of Q anyway, and rho is added to the
     // diagonal by the resident sweep -- the setup kernel then makes one pass over Q instead of two
     P.rho_late = (spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && knobs().rho_late) ? 1 : 0;
+    // ... and above 512 rows on two workgroups per matrix: the sums k_spd_begin leaves are turned into rho by k_spd_rho_big
+    const bool rho_late_big = spd_big_split && !spd_resident && (!P.scale || P.qs_lazy) && ctl->rho_mode == 0 && knobs().rho_late != 0 &&
+                              (size_t)P.Np * P.Np >= (size_t)(2 * P.Ks + 1) * LQP_BLK;
+    if (rho_late_big) P.rho_late = 1;
     // auto-scaling on: ONE pass over Q for the column maxima, the symmetry verdict and the (unscaled) blocks, in front of
     // the setup kernel (k_spd_prep); the resident sweep scales its tiles as it loads them and sums ||Qs||_F itself
     P.prep_fused = 0;
@@ -801,6 +805,10 @@ int forward_impl(hipStream_t st, int B, int n, int m, const void* Q, const void*
                     if (!r3) r3 = ensure_lds((const void*)k_spd_end<>, lds);
                     if (r3) return r3;
                     hipLaunchKernelGGL(k_spd_begin<>, dim3(shared_grid(B, SPD_NP)), dim3(LQP_NT), lds, st, P, gate);
+                    if (rho_late_big && gate == nullptr) {
+                        hipLaunchKernelGGL(k_spd_rho_big<>, dim3(B), dim3(LQP_NT), 0, st, P);
+                        ++n_launch;
+                    }
                     // two pivot steps per pass over the tiles (wg_spd_sweep_big, phases bits 2 .. 4): pivot + Y of step k | its update on
                     // block column k + 1 alone | pivot + Y' of step k + 1 | ONE read-modify-write of every other tile with both products
                     const bool fuse2 = knobs().spd_big_fuse != 0 && (size_t)P.Np * P.Np >= (size_t)(2 * P.Ks + 1) * LQP_BLK;

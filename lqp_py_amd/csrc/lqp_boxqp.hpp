@@ -1117,6 +1117,21 @@ __global__ __launch_bounds__(LQP_NT) void k_spd_begin(const FwdParams<float> P, 
                                                  gate == nullptr, part, dsc, fro_out);
     if (threadIdx.x == 0 && asym > 0.f) { P.info[b] = P.Ks * 64 + 2; P.status[ST_NOTSPD] = 1; }
 }
+// Above 512 rows with rho = clamp(||Qs||_F / sqrt(n)) (FwdParams::rho_late): k_spd_begin has built the blocks WITHOUT rho and left
+// the two workgroups' shares of ||Qs||_F^2 behind the panel area -- the setup kernel then makes one pass over Q (the column maxima)
+// instead of two.  Here rho is formed (part 0 + part 1, the order fixed), stored, and added to the K diagonal tiles before the
+// sweep's first launch reads them.
+template <int LQP_ANY = 0>
+__global__ __launch_bounds__(LQP_NT) void k_spd_rho_big(const FwdParams<float> P) {
+    const int b = blockIdx.x, tid = threadIdx.x, n = P.n, Ks = P.Ks;
+    const float* fr = P.M + (size_t)b * P.Np * P.Np + (size_t)2 * Ks * LQP_BLK;
+    float rho = sqrtf(fr[0] + fr[1]) / (float)sqrt((double)n);
+    rho = tmin(tmax(rho, P.rho_min), P.rho_max);
+    if (tid == 0) P.scal[(size_t)b * SC_WORDS + SC_RHO] = rho;
+    float* Hs = spd_half(P, b, 0);
+    const int j = tid >> 6, t = tid & 63;
+    if (j < Ks && j * 64 + t < n) Hs[(size_t)sym_idx(j, j, Ks) * LQP_BLK + t * 64 + t] += rho;
+}
 // the first factorisation's k_spd_begin, moved IN FRONT of the setup kernel (FwdParams::prep_fused): the column maxima the
 // scaling starts from come out of the same pass over Q that checks its symmetry and builds the blocks -- unscaled; the
 // resident sweep scales them as it loads them.  One pass over Q per solve instead of two.
